@@ -1,0 +1,21 @@
+// Error bookkeeping and ABI version for libgen6d_hip.
+#include "g6d_common.h"
+#include <string.h>
+#include <stdio.h>
+
+static thread_local char g_err[256] = "";
+
+void g6d_set_error(const char* msg) {
+  strncpy(g_err, msg, sizeof(g_err) - 1);
+  g_err[sizeof(g_err) - 1] = 0;
+}
+
+int g6d_check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) return G6D_OK;
+  snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+  return G6D_ELAUNCH;
+}
+
+extern "C" int g6d_abi_version(void) { return 1; }
+extern "C" const char* g6d_last_error(void) { return g_err; }

@@ -1,0 +1,148 @@
+// Detector glue kernels around the MFMA correlation (network/detector.py):
+//   assemble      :225-229,243-245,207-216  nearest up-sample of the coarse levels, (x-mu)/sigma, clip, bilinear resize
+//   score_mlp_max :159-163,246-247         1x1x1 Conv3d 12->64, ReLU, 64->64 per (pixel, reference), max over references
+//   decode        :84-121                   arg-max (first maximum wins) + offset/scale gather
+#include "g6d_common.h"
+
+namespace {
+
+struct LevelStats { float mu[3], sigma[3]; };
+
+__global__ void assemble_kernel(const float* __restrict__ s0, const float* __restrict__ s1, const float* __restrict__ s2,
+                                int hc, int wc, int rfn, LevelStats st, float clip, int hs, int ws, int scale_idx,
+                                int nch, float* __restrict__ stacked) {
+  const long long total = (long long)hs * ws * rfn;
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int r = (int)(i % rfn); const int pix = (int)(i / rfn);
+  const int x = pix % ws, y = pix / ws;
+  const float ry = (float)hc / (float)hs, rx = (float)wc / (float)ws;
+  float sy = ry * (y + 0.5f) - 0.5f; if (sy < 0.f) sy = 0.f;
+  float sx = rx * (x + 0.5f) - 0.5f; if (sx < 0.f) sx = 0.f;
+  const int y0 = (int)sy, x0 = (int)sx;
+  const int y1 = y0 + (y0 < hc - 1), x1 = x0 + (x0 < wc - 1);
+  const float ly = sy - y0, lx = sx - x0, hy = 1.f - ly, hx = 1.f - lx;
+  const float* src[3] = {s0, s1, s2};
+  float* dst = stacked + ((size_t)pix * rfn + r) * nch + 3 * scale_idx;
+#pragma unroll
+  for (int l = 0; l < 3; ++l) {
+    const int wl = wc >> l;
+    const float mu = st.mu[l], sg = st.sigma[l];
+    auto tap = [&](int yy, int xx) {
+      float v = src[l][((size_t)(yy >> l) * wl + (xx >> l)) * rfn + r];
+      v = (v - mu) / sg;
+      return fminf(fmaxf(v, -clip), clip);
+    };
+    dst[l] = hy * (hx * tap(y0, x0) + lx * tap(y0, x1)) + ly * (hx * tap(y1, x0) + lx * tap(y1, x1));
+  }
+}
+
+__device__ __forceinline__ int enc_f(float f) { int b = __float_as_int(f); return b >= 0 ? b : b ^ 0x7fffffff; }
+__device__ __forceinline__ float dec_f(int b) { return __int_as_float(b >= 0 ? b : b ^ 0x7fffffff); }
+
+// thread = (pixel, ref); PPB whole pixels per block; max over refs through LDS integer atomics.
+template <int NCH>
+__global__ void __launch_bounds__(256) score_mlp_max_kernel(const float* __restrict__ stacked, int P, int rfn,
+                                                            const float* __restrict__ w0, const float* __restrict__ b0,
+                                                            const float* __restrict__ w1, const float* __restrict__ b1,
+                                                            float* __restrict__ out, int ppb) {
+  extern __shared__ int smax[];   // [ppb][64]
+  const int pl = threadIdx.x / rfn, r = threadIdx.x % rfn;
+  const int pix = blockIdx.x * ppb + pl;
+  for (int i = threadIdx.x; i < ppb * 64; i += 256) smax[i] = enc_f(-INFINITY);
+  __syncthreads();
+  if (pl < ppb && pix < P) {
+    float in[NCH];
+    const float* src = stacked + ((size_t)pix * rfn + r) * NCH;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) in[k] = src[k];
+    float h[64];
+#pragma unroll
+    for (int o = 0; o < 64; ++o) {
+      float a = b0[o];
+#pragma unroll
+      for (int k = 0; k < NCH; ++k) a += w0[o * NCH + k] * in[k];
+      h[o] = fmaxf(a, 0.f);
+    }
+    for (int o = 0; o < 64; ++o) {
+      float a = b1[o];
+#pragma unroll
+      for (int k = 0; k < 64; ++k) a += w1[o * 64 + k] * h[k];
+      atomicMax(&smax[pl * 64 + o], enc_f(a));
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < ppb * 64; i += 256) {
+    const int p2 = blockIdx.x * ppb + i / 64;
+    if (p2 < P) out[(size_t)p2 * 64 + (i & 63)] = dec_f(smax[i]);
+  }
+}
+
+__global__ void __launch_bounds__(256) decode_kernel(const float* __restrict__ scores, int ld_s,
+                                                     const float* __restrict__ offset, int ld_o,
+                                                     const float* __restrict__ scale, int ld_c, int hs, int ws,
+                                                     float pool_ratio, float* __restrict__ result) {
+  __shared__ float bv[256];
+  __shared__ int bi[256];
+  const int n = hs * ws;
+  float best = -INFINITY; int idx = 0x7fffffff;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    float v = scores[(size_t)i * ld_s];
+    if (v > best || (v == best && i < idx)) { best = v; idx = i; }
+  }
+  bv[threadIdx.x] = best; bi[threadIdx.x] = idx;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+      float v = bv[threadIdx.x + s]; int j = bi[threadIdx.x + s];
+      if (v > bv[threadIdx.x] || (v == bv[threadIdx.x] && j < bi[threadIdx.x])) { bv[threadIdx.x] = v; bi[threadIdx.x] = j; }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const int id = bi[0] == 0x7fffffff ? 0 : bi[0];
+    const int x = id % ws, y = id / ws;
+    result[0] = ((float)x + offset[(size_t)id * ld_o] + 0.5f) * pool_ratio - 0.5f;
+    result[1] = ((float)y + offset[(size_t)id * ld_o + 1] + 0.5f) * pool_ratio - 0.5f;
+    result[2] = exp2f(scale[(size_t)id * ld_c]);
+    result[3] = (float)x; result[4] = (float)y;
+  }
+}
+
+}  // namespace
+
+#define STREAM(s) reinterpret_cast<hipStream_t>(s)
+
+extern "C" int g6d_detector_assemble(const float* s0, const float* s1, const float* s2, int hc, int wc, int rfn,
+                                     const float* mu_sigma, float clip, int hs, int ws, int scale_idx, int nch,
+                                     float* stacked, g6d_stream_t stream) {
+  if (!s0 || !s1 || !s2 || !mu_sigma || !stacked || hc <= 0 || wc <= 0 || (hc & 3) || (wc & 3) || rfn <= 0 ||
+      scale_idx < 0 || 3 * scale_idx + 3 > nch) {
+    g6d_set_error("detector_assemble: bad args (level-0 map must be a multiple of 4)"); return G6D_EINVAL;
+  }
+  LevelStats st;
+  for (int l = 0; l < 3; ++l) { st.mu[l] = mu_sigma[2 * l]; st.sigma[l] = mu_sigma[2 * l + 1]; }
+  const long long total = (long long)hs * ws * rfn;
+  hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, STREAM(stream), s0, s1, s2, hc,
+                     wc, rfn, st, clip, hs, ws, scale_idx, nch, stacked);
+  return g6d_check_launch("detector_assemble");
+}
+
+extern "C" int g6d_detector_score_mlp_max(const float* stacked, int P, int rfn, int nch, const float* w0, const float* b0,
+                                          const float* w1, const float* b1, float* out, g6d_stream_t stream) {
+  if (!stacked || !w0 || !b0 || !w1 || !b1 || !out || P <= 0 || rfn <= 0 || rfn > 256 || nch != 12) {
+    g6d_set_error("detector_score_mlp_max: bad args (rfn <= 256, nch == 12)"); return G6D_EINVAL;
+  }
+  const int ppb = 256 / rfn;
+  hipLaunchKernelGGL(score_mlp_max_kernel<12>, dim3((P + ppb - 1) / ppb), dim3(256), (size_t)ppb * 64 * sizeof(int),
+                     STREAM(stream), stacked, P, rfn, w0, b0, w1, b1, out, ppb);
+  return g6d_check_launch("detector_score_mlp_max");
+}
+
+extern "C" int g6d_detector_decode(const float* scores, int ld_s, const float* offset, int ld_o, const float* scale,
+                                   int ld_c, int hs, int ws, int pool_ratio, float* result, g6d_stream_t stream) {
+  if (!scores || !offset || !scale || !result || hs <= 0 || ws <= 0) { g6d_set_error("detector_decode: bad args"); return G6D_EINVAL; }
+  hipLaunchKernelGGL(decode_kernel, dim3(1), dim3(256), 0, STREAM(stream), scores, ld_s, offset, ld_o, scale, ld_c, hs, ws,
+                     (float)pool_ratio, result);
+  return g6d_check_launch("detector_decode");
+}

@@ -1,0 +1,369 @@
+// HBM-bound glue kernels: InstanceNorm finalisation, affine/ReLU/pool, bilinear up-sampling, layout change with
+// L2 normalisation, token-wise tails of the selector.  All channels-last, 16-byte accesses along C.
+#include "g6d_common.h"
+
+namespace {
+
+__global__ void stats_finalize_kernel(const double* __restrict__ st, int n, double inv_count, double eps,
+                                      float* __restrict__ scale, float* __restrict__ shift) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double mean = st[2 * i] * inv_count;
+  double var = st[2 * i + 1] * inv_count - mean * mean;
+  if (var < 0) var = 0;
+  double rs = 1.0 / sqrt(var + eps);
+  scale[i] = (float)rs;
+  shift[i] = (float)(-mean * rs);
+}
+
+__device__ __forceinline__ f32x4 aff(f32x4 v, f32x4 sc, f32x4 sh, bool has, int relu) {
+  if (has) v = v * sc + sh;
+  if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+  return v;
+}
+
+// pool: 0 none, 1 = 2x2 max
+__global__ void affine_act_pool_kernel(const float* __restrict__ in, int ld_in, const float* __restrict__ scale,
+                                       const float* __restrict__ shift, int per_n, int relu, int pool, int N, int H,
+                                       int W, int C, float* __restrict__ out, int ld_out) {
+  const int C4 = C >> 2;
+  const int Ho = pool ? H / 2 : H, Wo = pool ? W / 2 : W;
+  const long long total = (long long)N * Ho * Wo * C4;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int c = (int)(i % C4) * 4; long long t = i / C4;
+    int x = (int)(t % Wo); t /= Wo; int y = (int)(t % Ho); int n = (int)(t / Ho);
+    const bool has = scale != nullptr;
+    f32x4 sc = {1, 1, 1, 1}, sh = {0, 0, 0, 0};
+    if (has) {
+      const size_t o = (size_t)(per_n ? n : 0) * C + c;
+      sc = *reinterpret_cast<const f32x4*>(scale + o); sh = *reinterpret_cast<const f32x4*>(shift + o);
+    }
+    f32x4 v;
+    if (pool) {
+      const float* b = in + (((size_t)n * H + 2 * y) * W + 2 * x) * ld_in + c;
+      f32x4 v00 = aff(*reinterpret_cast<const f32x4*>(b), sc, sh, has, relu);
+      f32x4 v01 = aff(*reinterpret_cast<const f32x4*>(b + ld_in), sc, sh, has, relu);
+      f32x4 v10 = aff(*reinterpret_cast<const f32x4*>(b + (size_t)W * ld_in), sc, sh, has, relu);
+      f32x4 v11 = aff(*reinterpret_cast<const f32x4*>(b + (size_t)W * ld_in + ld_in), sc, sh, has, relu);
+      for (int k = 0; k < 4; ++k) v[k] = fmaxf(fmaxf(v00[k], v01[k]), fmaxf(v10[k], v11[k]));
+    } else {
+      v = aff(*reinterpret_cast<const f32x4*>(in + (((size_t)n * H + y) * W + x) * ld_in + c), sc, sh, has, relu);
+    }
+    *reinterpret_cast<f32x4*>(out + (((size_t)n * Ho + y) * Wo + x) * ld_out + c) = v;
+  }
+}
+
+// pool == 2: mean over the whole HxW window -> [N][C]
+__global__ void affine_act_avg_kernel(const float* __restrict__ in, int ld_in, const float* __restrict__ scale,
+                                      const float* __restrict__ shift, int per_n, int relu, int N, int HW, int C,
+                                      float* __restrict__ out, int ld_out) {
+  const int C4 = C >> 2;
+  const long long total = (long long)N * C4;
+  long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int c = (int)(i % C4) * 4; int n = (int)(i / C4);
+  const bool has = scale != nullptr;
+  f32x4 sc = {1, 1, 1, 1}, sh = {0, 0, 0, 0};
+  if (has) {
+    const size_t o = (size_t)(per_n ? n : 0) * C + c;
+    sc = *reinterpret_cast<const f32x4*>(scale + o); sh = *reinterpret_cast<const f32x4*>(shift + o);
+  }
+  f32x4 s = {0, 0, 0, 0};
+  for (int p = 0; p < HW; ++p) s += aff(*reinterpret_cast<const f32x4*>(in + ((size_t)n * HW + p) * ld_in + c), sc, sh, has, relu);
+  const float inv = 1.f / (float)HW;
+  *reinterpret_cast<f32x4*>(out + (size_t)n * ld_out + c) = s * inv;
+}
+
+__global__ void upsample_bilinear_kernel(const float* __restrict__ in, int ld_in, const float* __restrict__ scale,
+                                         const float* __restrict__ shift, int per_n, int N, int H, int W, int C, int f,
+                                         float* __restrict__ out, int ld_out) {
+  const int C4 = C >> 2, Ho = H * f, Wo = W * f;
+  const long long total = (long long)N * Ho * Wo * C4;
+  const float rs = 1.f / (float)f;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int c = (int)(i % C4) * 4; long long t = i / C4;
+    int x = (int)(t % Wo); t /= Wo; int y = (int)(t % Ho); int n = (int)(t / Ho);
+    float sy = rs * (y + 0.5f) - 0.5f; if (sy < 0.f) sy = 0.f;
+    float sx = rs * (x + 0.5f) - 0.5f; if (sx < 0.f) sx = 0.f;
+    int y0 = (int)sy, x0 = (int)sx;
+    int y1 = y0 + (y0 < H - 1), x1 = x0 + (x0 < W - 1);
+    float ly = sy - y0, lx = sx - x0, hy = 1.f - ly, hx = 1.f - lx;
+    const bool has = scale != nullptr;
+    f32x4 sc = {1, 1, 1, 1}, sh = {0, 0, 0, 0};
+    if (has) {
+      const size_t o = (size_t)(per_n ? n : 0) * C + c;
+      sc = *reinterpret_cast<const f32x4*>(scale + o); sh = *reinterpret_cast<const f32x4*>(shift + o);
+    }
+    const float* b = in + (size_t)n * H * W * ld_in + c;
+    f32x4 v00 = aff(*reinterpret_cast<const f32x4*>(b + ((size_t)y0 * W + x0) * ld_in), sc, sh, has, 0);
+    f32x4 v01 = aff(*reinterpret_cast<const f32x4*>(b + ((size_t)y0 * W + x1) * ld_in), sc, sh, has, 0);
+    f32x4 v10 = aff(*reinterpret_cast<const f32x4*>(b + ((size_t)y1 * W + x0) * ld_in), sc, sh, has, 0);
+    f32x4 v11 = aff(*reinterpret_cast<const f32x4*>(b + ((size_t)y1 * W + x1) * ld_in), sc, sh, has, 0);
+    f32x4 v = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+    *reinterpret_cast<f32x4*>(out + (((size_t)n * Ho + y) * Wo + x) * ld_out + c) = v;
+  }
+}
+
+// One block per (n, 32 consecutive positions). Phase 1: per-position L2 norm over C. Phase 2: LDS-tiled transpose.
+__global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* __restrict__ in, int C, int HW, int l2norm,
+                                                           float* __restrict__ out, int ld_out) {
+  __shared__ float tile[32][33];
+  __shared__ float part[8][32];
+  __shared__ float inv[32];
+  const int n = blockIdx.y, p0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  const float* src = in + (size_t)n * C * HW;
+  const int p = p0 + tx;
+  if (l2norm) {
+    float s = 0.f;
+    if (p < HW) for (int c = ty; c < C; c += 8) { float v = src[(size_t)c * HW + p]; s += v * v; }
+    part[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0) {
+      float t = 0.f;
+      for (int k = 0; k < 8; ++k) t += part[k][tx];
+      inv[tx] = 1.f / fmaxf(sqrtf(t), 1e-12f);
+    }
+    __syncthreads();
+  }
+  for (int c0 = 0; c0 < C; c0 += 32) {
+    for (int k = ty; k < 32; k += 8) {
+      int c = c0 + k;
+      tile[k][tx] = (c < C && p < HW) ? src[(size_t)c * HW + p] : 0.f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {          // k = position, tx = channel
+      int pp = p0 + k, c = c0 + tx;
+      if (pp < HW && c < C) {
+        float v = tile[tx][k];
+        if (l2norm) v *= inv[k];
+        out[((size_t)n * HW + pp) * ld_out + c] = v;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// InstanceNorm2d(3) of vps[ch][D] over D (biased var, eps 1e-5); one block per channel.
+__global__ void __launch_bounds__(256) vps_norm_kernel(const float* __restrict__ vps, int D, float* __restrict__ feats,
+                                                       int ld, int c_off) {
+  __shared__ double red[2][4];
+  const int ch = blockIdx.x;
+  const float* v = vps + (size_t)ch * D;
+  double s1 = 0, s2 = 0;
+  for (int i = threadIdx.x; i < D; i += 256) { double x = v[i]; s1 += x; s2 += x * x; }
+  s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s1; red[1][threadIdx.x >> 6] = s2; }
+  __syncthreads();
+  s1 = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+  s2 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  double mean = s1 / D, var = s2 / D - mean * mean;
+  if (var < 0) var = 0;
+  float rs = (float)(1.0 / sqrt(var + 1e-5)), mu = (float)mean;
+  for (int i = threadIdx.x; i < D; i += 256) feats[(size_t)i * ld + c_off + ch] = (v[i] - mu) * rs;
+}
+
+__global__ void max_an_add_kernel(const float* __restrict__ in, int ld_in, int rfn, int an, int C,
+                                  const float* __restrict__ embed, float* __restrict__ out, int ld_out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rfn * C) return;
+  int c = i % C, r = i / C;
+  float m = in[(size_t)(r * an) * ld_in + c];
+  for (int a = 1; a < an; ++a) m = fmaxf(m, in[(size_t)(r * an + a) * ld_in + c]);
+  out[(size_t)r * ld_out + c] = m + embed[(size_t)r * C + c];
+}
+
+// one wave per token
+__global__ void __launch_bounds__(64) layernorm_kernel(const float* __restrict__ in, int ld_in, int C,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float eps, float* __restrict__ out, int ld_out) {
+  const int t = blockIdx.x, lane = threadIdx.x;
+  const float* x = in + (size_t)t * ld_in;
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += x[c];
+  const float mean = wave_sum(s) / C;
+  float q = 0.f;
+  for (int c = lane; c < C; c += 64) { float d = x[c] - mean; q += d * d; }
+  const float rs = 1.f / sqrtf(wave_sum(q) / C + eps);
+  for (int c = lane; c < C; c += 64) out[(size_t)t * ld_out + c] = (x[c] - mean) * rs * gamma[c] + beta[c];
+}
+
+__global__ void affine_act_add_kernel(const float* __restrict__ in, int ld_in, const float* __restrict__ scale,
+                                      const float* __restrict__ shift, int relu, const float* __restrict__ res,
+                                      int ld_res, int n, int C, float* __restrict__ out, int ld_out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * C) return;
+  int c = i % C, r = i / C;
+  float v = in[(size_t)r * ld_in + c];
+  if (scale) v = v * scale[c] + shift[c];
+  if (relu) v = fmaxf(v, 0.f);
+  if (res) v += res[(size_t)r * ld_res + c];
+  out[(size_t)r * ld_out + c] = v;
+}
+
+// 8-head attention over n tokens, one wave per (head, query token). Channel c = d*heads + head.
+__global__ void __launch_bounds__(64) attention_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                       const float* __restrict__ v, int ld, int n, int C, int heads,
+                                                       float* __restrict__ out, int ld_out) {
+  extern __shared__ float sm[];           // [dh] query + [n] probabilities
+  const int dh = C / heads;
+  float* qs = sm; float* pr = sm + dh;
+  const int h = blockIdx.x % heads, i = blockIdx.x / heads, lane = threadIdx.x;
+  for (int d = lane; d < dh; d += 64) qs[d] = q[(size_t)i * ld + d * heads + h];
+  __syncthreads();
+  const float inv = 1.f / sqrtf((float)dh);
+  float mx = -INFINITY;
+  for (int j = lane; j < n; j += 64) {
+    float s = 0.f;
+    const float* kj = k + (size_t)j * ld + h;
+    for (int d = 0; d < dh; ++d) s += qs[d] * kj[d * heads];
+    s *= inv; pr[j] = s; mx = fmaxf(mx, s);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int j = lane; j < n; j += 64) { float e = expf(pr[j] - mx); pr[j] = e; sum += e; }
+  sum = wave_sum(sum);
+  __syncthreads();
+  const float rsum = 1.f / sum;
+  for (int d = lane; d < dh; d += 64) {
+    float acc = 0.f;
+    for (int j = 0; j < n; ++j) acc += pr[j] * v[(size_t)j * ld + d * heads + h];
+    out[(size_t)i * ld_out + d * heads + h] = acc * rsum;
+  }
+}
+
+// Weight-streaming GEMV: one block per output row, 16-byte loads, B <= 8 right-hand sides.
+__global__ void __launch_bounds__(256) linear_gemv_kernel(const float* __restrict__ x, int B, int K,
+                                                          const float* __restrict__ W, const float* __restrict__ bias,
+                                                          int act, float* __restrict__ out, int O) {
+  __shared__ float red[8][4];
+  const int o = blockIdx.x;
+  const float* w = W + (size_t)o * K;
+  float acc[8];
+#pragma unroll
+  for (int b = 0; b < 8; ++b) acc[b] = 0.f;
+  for (int kk = threadIdx.x * 4; kk < K; kk += 256 * 4) {
+    f32x4 wv = *reinterpret_cast<const f32x4*>(w + kk);
+#pragma unroll
+    for (int b = 0; b < 8; ++b)
+      if (b < B) {
+        f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)b * K + kk);
+        acc[b] += wv[0] * xv[0] + wv[1] * xv[1] + wv[2] * xv[2] + wv[3] * xv[3];
+      }
+  }
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    float s = wave_sum(acc[b]);
+    if ((threadIdx.x & 63) == 0) red[b][threadIdx.x >> 6] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < B) {
+    float s = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+    if (bias) s += bias[o];
+    out[(size_t)threadIdx.x * O + o] = apply_act(s, act);
+  }
+}
+
+inline int grid_for(long long total, int block) {
+  long long g = (total + block - 1) / block;
+  return (int)(g > 65535 * 16 ? 65535 * 16 : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+#define STREAM(s) reinterpret_cast<hipStream_t>(s)
+
+extern "C" int g6d_stats_finalize(const double* stats, int n, double count, double eps, float* scale, float* shift,
+                                  g6d_stream_t stream) {
+  if (!stats || !scale || !shift || n <= 0 || count <= 0) { g6d_set_error("stats_finalize: bad args"); return G6D_EINVAL; }
+  hipLaunchKernelGGL(stats_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, STREAM(stream), stats, n, 1.0 / count,
+                     eps, scale, shift);
+  return g6d_check_launch("stats_finalize");
+}
+
+extern "C" int g6d_affine_act_pool(const float* in, int ld_in, const float* scale, const float* shift, int per_n,
+                                   int relu, int pool, int N, int H, int W, int C, float* out, int ld_out,
+                                   g6d_stream_t stream) {
+  if (!in || !out || (C & 3) || (ld_in & 3) || (ld_out & 3) || N <= 0 || H <= 0 || W <= 0 || pool < 0 || pool > 2 ||
+      (pool == 1 && ((H | W) & 1)) || !g6d_aligned16(in) || !g6d_aligned16(out) || (scale && (!shift || !g6d_aligned16(scale) || !g6d_aligned16(shift)))) {
+    g6d_set_error("affine_act_pool: bad args"); return G6D_EINVAL;
+  }
+  if (pool == 2) {
+    long long total = (long long)N * (C / 4);
+    hipLaunchKernelGGL(affine_act_avg_kernel, dim3(grid_for(total, 256)), dim3(256), 0, STREAM(stream), in, ld_in, scale,
+                       shift, per_n, relu, N, H * W, C, out, ld_out);
+  } else {
+    long long total = (long long)N * (pool ? H / 2 : H) * (pool ? W / 2 : W) * (C / 4);
+    hipLaunchKernelGGL(affine_act_pool_kernel, dim3(grid_for(total, 256)), dim3(256), 0, STREAM(stream), in, ld_in, scale,
+                       shift, per_n, relu, pool, N, H, W, C, out, ld_out);
+  }
+  return g6d_check_launch("affine_act_pool");
+}
+
+extern "C" int g6d_upsample_bilinear(const float* in, int ld_in, const float* scale, const float* shift, int per_n,
+                                     int N, int H, int W, int C, int factor, float* out, int ld_out, g6d_stream_t stream) {
+  if (!in || !out || (C & 3) || (ld_in & 3) || (ld_out & 3) || factor < 1 || N <= 0 || !g6d_aligned16(in) ||
+      !g6d_aligned16(out) || (scale && (!shift || !g6d_aligned16(scale) || !g6d_aligned16(shift)))) {
+    g6d_set_error("upsample_bilinear: bad args"); return G6D_EINVAL;
+  }
+  long long total = (long long)N * H * factor * W * factor * (C / 4);
+  hipLaunchKernelGGL(upsample_bilinear_kernel, dim3(grid_for(total, 256)), dim3(256), 0, STREAM(stream), in, ld_in, scale,
+                     shift, per_n, N, H, W, C, factor, out, ld_out);
+  return g6d_check_launch("upsample_bilinear");
+}
+
+extern "C" int g6d_nchw_to_nhwc(const float* in, int N, int C, int H, int W, int l2norm, float* out, int ld_out,
+                                g6d_stream_t stream) {
+  if (!in || !out || N <= 0 || C <= 0 || H <= 0 || W <= 0 || ld_out < C) { g6d_set_error("nchw_to_nhwc: bad args"); return G6D_EINVAL; }
+  const int HW = H * W;
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((HW + 31) / 32, N), dim3(256), 0, STREAM(stream), in, C, HW, l2norm, out, ld_out);
+  return g6d_check_launch("nchw_to_nhwc");
+}
+
+extern "C" int g6d_vps_norm(const float* vps, int D, float* feats, int ld, int c_off, g6d_stream_t stream) {
+  if (!vps || !feats || D <= 0) { g6d_set_error("vps_norm: bad args"); return G6D_EINVAL; }
+  hipLaunchKernelGGL(vps_norm_kernel, dim3(3), dim3(256), 0, STREAM(stream), vps, D, feats, ld, c_off);
+  return g6d_check_launch("vps_norm");
+}
+
+extern "C" int g6d_max_an_add(const float* in, int ld_in, int rfn, int an, int C, const float* embed, float* out,
+                              int ld_out, g6d_stream_t stream) {
+  if (!in || !embed || !out || rfn <= 0 || an <= 0 || C <= 0) { g6d_set_error("max_an_add: bad args"); return G6D_EINVAL; }
+  hipLaunchKernelGGL(max_an_add_kernel, dim3((rfn * C + 255) / 256), dim3(256), 0, STREAM(stream), in, ld_in, rfn, an, C,
+                     embed, out, ld_out);
+  return g6d_check_launch("max_an_add");
+}
+
+extern "C" int g6d_attention(const float* q, const float* k, const float* v, int ld, int n, int C, int heads, float* out,
+                             int ld_out, g6d_stream_t stream) {
+  if (!q || !k || !v || !out || n <= 0 || heads <= 0 || C % heads) { g6d_set_error("attention: bad args"); return G6D_EINVAL; }
+  size_t lds = (size_t)(C / heads + n) * sizeof(float);
+  if (lds > 60000) { g6d_set_error("attention: n too large"); return G6D_EINVAL; }
+  hipLaunchKernelGGL(attention_kernel, dim3(n * heads), dim3(64), lds, STREAM(stream), q, k, v, ld, n, C, heads, out, ld_out);
+  return g6d_check_launch("attention");
+}
+
+extern "C" int g6d_layernorm(const float* in, int ld_in, int n, int C, const float* gamma, const float* beta, float eps,
+                             float* out, int ld_out, g6d_stream_t stream) {
+  if (!in || !out || !gamma || !beta || n <= 0 || C <= 0) { g6d_set_error("layernorm: bad args"); return G6D_EINVAL; }
+  hipLaunchKernelGGL(layernorm_kernel, dim3(n), dim3(64), 0, STREAM(stream), in, ld_in, C, gamma, beta, eps, out, ld_out);
+  return g6d_check_launch("layernorm");
+}
+
+extern "C" int g6d_affine_act_add(const float* in, int ld_in, const float* scale, const float* shift, int relu,
+                                  const float* residual, int ld_res, int n, int C, float* out, int ld_out,
+                                  g6d_stream_t stream) {
+  if (!in || !out || n <= 0 || C <= 0 || (scale && !shift)) { g6d_set_error("affine_act_add: bad args"); return G6D_EINVAL; }
+  hipLaunchKernelGGL(affine_act_add_kernel, dim3((n * C + 255) / 256), dim3(256), 0, STREAM(stream), in, ld_in, scale,
+                     shift, relu, residual, ld_res, n, C, out, ld_out);
+  return g6d_check_launch("affine_act_add");
+}
+
+extern "C" int g6d_linear_gemv(const float* x, int B, int K, const float* W, const float* bias, int O, int act,
+                               float* out, g6d_stream_t stream) {
+  if (!x || !W || !out || B <= 0 || B > 8 || K <= 0 || (K & 3) || O <= 0 || !g6d_aligned16(x) || !g6d_aligned16(W)) {
+    g6d_set_error("linear_gemv: bad args"); return G6D_EINVAL;
+  }
+  hipLaunchKernelGGL(linear_gemv_kernel, dim3(O), dim3(256), 0, STREAM(stream), x, B, K, W, bias, act, out, O);
+  return g6d_check_launch("linear_gemv");
+}

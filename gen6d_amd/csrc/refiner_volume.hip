@@ -1,0 +1,93 @@
+// Refiner feature-volume construction (network/refiner.py:183-206,208-247 + network/operator.py:4-17), fused.
+//
+// The reference builds a [rfn][C][sn^3] tensor with grid_sample (100 MB at C=128, sn=32, rfn=6) and then reduces it
+// three times (mean, std, query).  Here each half-wavefront owns one voxel: 32 lanes x 4 channels = 128 channels, so
+// every bilinear tap is one 512-byte coalesced read of a channels-last feature row (the 3.7 MB of feature maps stay
+// L2 resident), the per-reference samples live in registers, and mean / unbiased std / query sample are written
+// straight into the layouts the 3-D CNN consumes (cat[mean, query] and std).  HBM traffic = the 50 MB of outputs.
+#include "g6d_common.h"
+
+#define MAX_RFN 8
+
+namespace {
+
+
+__device__ __forceinline__ f32x4 sample_view(const float* __restrict__ fmap, int fh, int fw, int C, int c,
+                                             const float* P, float vx, float vy, float vz, float h_in, float w_in) {
+  float X = vx * P[0] + vy * P[1] + vz * P[2] + P[3];
+  float Y = vx * P[4] + vy * P[5] + vz * P[6] + P[7];
+  float Z = vx * P[8] + vy * P[9] + vz * P[10] + P[11];
+  if (Z < 1e-4f) Z = 1e-4f;
+  float u = X / Z, v = Y / Z;
+  float gx = ((u + 0.5f) / w_in - 0.5f) * 2.f;
+  float gy = ((v + 0.5f) / h_in - 0.5f) * 2.f;
+  float ix = ((gx + 1.f) * fw - 1.f) * 0.5f;
+  float iy = ((gy + 1.f) * fh - 1.f) * 0.5f;
+  float fx = floorf(ix), fy = floorf(iy);
+  // keep the integer conversion in range for far-away projections
+  fx = fminf(fmaxf(fx, -4.f), (float)fw + 4.f);
+  fy = fminf(fmaxf(fy, -4.f), (float)fh + 4.f);
+  int x0 = (int)fx, y0 = (int)fy;
+  float wx1 = ix - fx, wy1 = iy - fy, wx0 = (fx + 1.f) - ix, wy0 = (fy + 1.f) - iy;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const bool xv0 = (unsigned)x0 < (unsigned)fw, xv1 = (unsigned)(x0 + 1) < (unsigned)fw;
+  const bool yv0 = (unsigned)y0 < (unsigned)fh, yv1 = (unsigned)(y0 + 1) < (unsigned)fh;
+  if (yv0 && xv0) acc += (wx0 * wy0) * *reinterpret_cast<const f32x4*>(fmap + ((size_t)y0 * fw + x0) * C + c);
+  if (yv0 && xv1) acc += (wx1 * wy0) * *reinterpret_cast<const f32x4*>(fmap + ((size_t)y0 * fw + x0 + 1) * C + c);
+  if (yv1 && xv0) acc += (wx0 * wy1) * *reinterpret_cast<const f32x4*>(fmap + ((size_t)(y0 + 1) * fw + x0) * C + c);
+  if (yv1 && xv1) acc += (wx1 * wy1) * *reinterpret_cast<const f32x4*>(fmap + ((size_t)(y0 + 1) * fw + x0 + 1) * C + c);
+  return acc;
+}
+
+__global__ void __launch_bounds__(256) refiner_volume_kernel(const float* __restrict__ feats,
+                                                             const float* __restrict__ projs,
+                                                             const float* __restrict__ rot,
+                                                             const float* __restrict__ lin, int rfn, int fh, int fw,
+                                                             int C, float h_in, float w_in, int sn,
+                                                             float* __restrict__ mean_in, float* __restrict__ stdv) {
+  const int nvox = sn * sn * sn;
+  const int half = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;   // one half-wave per voxel
+  const int l32 = threadIdx.x & 31;
+  if (half >= nvox) return;
+  const int k = half % sn, j = (half / sn) % sn, i = half / (sn * sn);
+  const float g0 = lin[i], g1 = lin[j], g2 = lin[k];
+  const float vx = g0 * rot[0] + g1 * rot[3] + g2 * rot[6];
+  const float vy = g0 * rot[1] + g1 * rot[4] + g2 * rot[7];
+  const float vz = g0 * rot[2] + g1 * rot[5] + g2 * rot[8];
+  const size_t fsz = (size_t)fh * fw * C;
+  const float inv_n = 1.f / (float)rfn, inv_n1 = 1.f / (float)(rfn > 1 ? rfn - 1 : 1);
+  for (int c = l32 * 4; c < C; c += 128) {
+    f32x4 s[MAX_RFN];
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < MAX_RFN; ++r)
+      if (r < rfn) { s[r] = sample_view(feats + r * fsz, fh, fw, C, c, projs + r * 12, vx, vy, vz, h_in, w_in); sum += s[r]; }
+    const f32x4 mean = sum * inv_n;
+    f32x4 var = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < MAX_RFN; ++r)
+      if (r < rfn) { f32x4 d = s[r] - mean; var += d * d; }
+    var = var * inv_n1;
+    f32x4 sd = {sqrtf(var[0]), sqrtf(var[1]), sqrtf(var[2]), sqrtf(var[3])};
+    const f32x4 q = sample_view(feats + rfn * fsz, fh, fw, C, c, projs + rfn * 12, vx, vy, vz, h_in, w_in);
+    *reinterpret_cast<f32x4*>(mean_in + (size_t)half * 2 * C + c) = mean;
+    *reinterpret_cast<f32x4*>(mean_in + (size_t)half * 2 * C + C + c) = q;
+    *reinterpret_cast<f32x4*>(stdv + (size_t)half * C + c) = sd;
+  }
+}
+
+}  // namespace
+
+extern "C" int g6d_refiner_volume(const float* feats, const float* projs, const float* rot_in,
+                                  const float* lin, int rfn, int fh, int fw, int C, int h_in, int w_in, int sn,
+                                  float* mean_in, float* stdv, g6d_stream_t stream) {
+  if (!feats || !projs || !rot_in || !lin || !mean_in || !stdv || rfn < 1 || rfn > MAX_RFN || (C & 3) ||
+      sn < 1 || sn > 256 || !g6d_aligned16(feats) || !g6d_aligned16(mean_in) || !g6d_aligned16(stdv)) {
+    g6d_set_error("refiner_volume: bad args (1 <= rfn <= 8, C % 4 == 0)"); return G6D_EINVAL;
+  }
+  const long long threads = (long long)sn * sn * sn * 32;
+  hipLaunchKernelGGL(refiner_volume_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), feats, projs, rot_in, lin, rfn, fh, fw, C, (float)h_in, (float)w_in, sn,
+                     mean_in, stdv);
+  return g6d_check_launch("refiner_volume");
+}

@@ -1,0 +1,113 @@
+// Selector similarity kernels: the query x (reference x rotation) feature product of network/selector.py:183-195 is
+// never materialised.  The reference cache [D][HW][C] (D = rfn*an hypotheses) is streamed once per query with
+// 16-byte coalesced loads; each wavefront owns one (hypothesis, location) row of C channels and reduces the
+// per-location cosine score with shuffles.  The statistics InstanceNorm3d(512) needs over the product
+// (selector.py:28,49,63) come from two query-independent sums prepared at load time:
+//     mean_c = (1/N) sum_hw q_c(hw) R1_c(hw),  E[x^2]_c = (1/N) sum_hw q_c(hw)^2 R2_c(hw),
+//     R1 = sum_d r, R2 = sum_d r^2,  N = D*HW.
+#include "g6d_common.h"
+
+namespace {
+
+__global__ void ref_sums_kernel(const float* __restrict__ refs, int D, int HWC, double* __restrict__ r1,
+                                double* __restrict__ r2) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= HWC) return;
+  double s1 = 0, s2 = 0;
+  for (int d = 0; d < D; ++d) { double v = refs[(size_t)d * HWC + i]; s1 += v; s2 += v * v; }
+  r1[i] = s1; r2[i] = s2;
+}
+
+__global__ void prod_affine_kernel(const float* __restrict__ que, const double* __restrict__ r1,
+                                   const double* __restrict__ r2, int HW, int C, double inv_n, double eps,
+                                   float* __restrict__ scale, float* __restrict__ shift) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double m = 0, e = 0;
+  for (int p = 0; p < HW; ++p) {
+    double q = que[(size_t)p * C + c];
+    m += q * r1[(size_t)p * C + c];
+    e += q * q * r2[(size_t)p * C + c];
+  }
+  m *= inv_n; e *= inv_n;
+  double var = e - m * m; if (var < 0) var = 0;
+  double rs = 1.0 / sqrt(var + eps);
+  scale[c] = (float)rs; shift[c] = (float)(-m * rs);
+}
+
+// rows = D*HW; one wave per row, 4 rows in flight per wave.
+__global__ void __launch_bounds__(256) scan_kernel(const float* __restrict__ que, const float* __restrict__ refs,
+                                                   int rows, int HW, int C, float* __restrict__ score_map) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (int row0 = wave * 4; row0 < rows; row0 += nwaves * 4) {
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int row = row0 + u;
+      if (row < rows) {
+        const float* r = refs + (size_t)row * C;
+        const float* q = que + (size_t)(row % HW) * C;
+        for (int c = lane * 4; c < C; c += 256) {
+          f32x4 rv = *reinterpret_cast<const f32x4*>(r + c);
+          f32x4 qv = *reinterpret_cast<const f32x4*>(q + c);
+          s[u] += rv[0] * qv[0] + rv[1] * qv[1] + rv[2] * qv[2] + rv[3] * qv[3];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float t = wave_sum(s[u]);
+      if (lane == 0 && row0 + u < rows) score_map[row0 + u] = t;
+    }
+  }
+}
+
+// vps[d] = sum_hw S * (S / max_hw S); one wave per hypothesis.
+__global__ void __launch_bounds__(64) vps_kernel(const float* __restrict__ score_map, int HW, float* __restrict__ vps) {
+  const int d = blockIdx.x, lane = threadIdx.x;
+  const float* s = score_map + (size_t)d * HW;
+  float mx = -INFINITY;
+  for (int p = lane; p < HW; p += 64) mx = fmaxf(mx, s[p]);
+  mx = wave_max(mx);
+  float acc = 0.f;
+  for (int p = lane; p < HW; p += 64) { float v = s[p]; acc += v * (v / mx); }
+  acc = wave_sum(acc);
+  if (lane == 0) vps[d] = acc;
+}
+
+}  // namespace
+
+#define STREAM(s) reinterpret_cast<hipStream_t>(s)
+
+extern "C" int g6d_selector_ref_sums(const float* refs, int D, int HW, int C, double* r1, double* r2, g6d_stream_t stream) {
+  if (!refs || !r1 || !r2 || D <= 0 || HW <= 0 || C <= 0) { g6d_set_error("selector_ref_sums: bad args"); return G6D_EINVAL; }
+  const int n = HW * C;
+  hipLaunchKernelGGL(ref_sums_kernel, dim3((n + 255) / 256), dim3(256), 0, STREAM(stream), refs, D, n, r1, r2);
+  return g6d_check_launch("selector_ref_sums");
+}
+
+extern "C" int g6d_selector_prod_affine(const float* que, const double* r1, const double* r2, int D, int HW, int C,
+                                        double eps, float* scale, float* shift, g6d_stream_t stream) {
+  if (!que || !r1 || !r2 || !scale || !shift || D <= 0 || HW <= 0 || C <= 0) { g6d_set_error("selector_prod_affine: bad args"); return G6D_EINVAL; }
+  hipLaunchKernelGGL(prod_affine_kernel, dim3((C + 63) / 64), dim3(64), 0, STREAM(stream), que, r1, r2, HW, C,
+                     1.0 / ((double)D * HW), eps, scale, shift);
+  return g6d_check_launch("selector_prod_affine");
+}
+
+extern "C" int g6d_selector_scan(const float* que, const float* refs, int D, int HW, int C, float* score_map, float* vps,
+                                 g6d_stream_t stream) {
+  if (!que || !refs || !score_map || !vps || D <= 0 || HW <= 0 || C <= 0 || (C & 3) || !g6d_aligned16(que) || !g6d_aligned16(refs)) {
+    g6d_set_error("selector_scan: bad args"); return G6D_EINVAL;
+  }
+  const long long rows = (long long)D * HW;
+  if (rows > (1ll << 30)) { g6d_set_error("selector_scan: too many rows"); return G6D_EINVAL; }
+  long long blocks = (rows + 15) / 16;            // 4 waves x 4 rows per pass
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(scan_kernel, dim3((int)blocks), dim3(256), 0, STREAM(stream), que, refs, (int)rows, HW, C, score_map);
+  int rc = g6d_check_launch("selector_scan");
+  if (rc != G6D_OK) return rc;
+  hipLaunchKernelGGL(vps_kernel, dim3(D), dim3(64), 0, STREAM(stream), score_map, HW, vps);
+  return g6d_check_launch("selector_vps");
+}

@@ -1,0 +1,76 @@
+"""ctypes binding of libgen6d_hip.so (include/gen6d_hip.h).  Fails loudly when the library is missing: there is no
+CPU or PyTorch fallback for the kernels behind this ABI."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgen6d_hip.so")
+
+G6D_ERRORS = {-1: "G6D_EINVAL", -2: "G6D_ENOSPC", -3: "G6D_ELAUNCH"}
+
+
+class G6dConv(C.Structure):
+    _fields_ = [
+        ("in_", C.c_void_p), ("mul", C.c_void_p), ("in_scale", C.c_void_p), ("in_shift", C.c_void_p),
+        ("weight", C.c_void_p), ("bias", C.c_void_p), ("out", C.c_void_p), ("stats", C.c_void_p),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("N", C.c_int32), ("Di", C.c_int32), ("Hi", C.c_int32), ("Wi", C.c_int32), ("Cin", C.c_int32), ("ld_in", C.c_int32),
+        ("Do", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32), ("Cout", C.c_int32), ("ld_out", C.c_int32),
+        ("kd", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32),
+        ("sd", C.c_int32), ("sh", C.c_int32), ("sw", C.c_int32),
+        ("pd", C.c_int32), ("ph", C.c_int32), ("pw", C.c_int32),
+        ("in_relu", C.c_int32), ("in_affine_per_n", C.c_int32), ("out_act", C.c_int32),
+        ("stat_rows_per_group", C.c_int32), ("split_k", C.c_int32),
+    ]
+
+
+_P, _I, _F, _D = C.c_void_p, C.c_int, C.c_float, C.c_double
+
+# name -> argtypes (every function returns int); mirrors include/gen6d_hip.h
+SIGNATURES = {
+    "g6d_conv_igemm": [C.POINTER(G6dConv), _P],
+    "g6d_stats_finalize": [_P, _I, _D, _D, _P, _P, _P],
+    "g6d_affine_act_pool": [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P],
+    "g6d_upsample_bilinear": [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P],
+    "g6d_nchw_to_nhwc": [_P, _I, _I, _I, _I, _I, _P, _I, _P],
+    "g6d_selector_ref_sums": [_P, _I, _I, _I, _P, _P, _P],
+    "g6d_selector_prod_affine": [_P, _P, _P, _I, _I, _I, _D, _P, _P, _P],
+    "g6d_selector_scan": [_P, _P, _I, _I, _I, _P, _P, _P],
+    "g6d_refiner_volume": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P],
+    "g6d_detector_assemble": [_P, _P, _P, _I, _I, _I, C.POINTER(C.c_float), _F, _I, _I, _I, _I, _P, _P],
+    "g6d_detector_score_mlp_max": [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P],
+    "g6d_detector_decode": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P],
+    "g6d_vps_norm": [_P, _I, _P, _I, _I, _P],
+    "g6d_max_an_add": [_P, _I, _I, _I, _I, _P, _P, _I, _P],
+    "g6d_attention": [_P, _P, _P, _I, _I, _I, _I, _P, _I, _P],
+    "g6d_layernorm": [_P, _I, _I, _I, _P, _P, _F, _P, _I, _P],
+    "g6d_affine_act_add": [_P, _I, _P, _P, _I, _P, _I, _I, _I, _P, _I, _P],
+    "g6d_linear_gemv": [_P, _I, _I, _P, _P, _I, _I, _P, _P],
+}
+
+_lib = None
+
+
+def load():
+    """Load (once) and type the shared library. Raises RuntimeError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: build it with `python __graft_entry__.py` "
+                           "(make -C gen6d_amd/csrc). There is no fallback path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    lib.g6d_abi_version.restype = C.c_int
+    lib.g6d_last_error.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().g6d_last_error().decode()
+        raise RuntimeError(f"{what} failed: {G6D_ERRORS.get(rc, rc)} ({msg})")

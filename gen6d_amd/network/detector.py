@@ -1,0 +1,162 @@
+"""Detector — drop-in for the reference's network/detector.py:Detector (same constructor, state_dict keys, methods and
+output dicts), driving hand-written HIP kernels for everything after the VGG trunk.
+
+Per detection scale (reference detect_impl, detector.py:232-266):
+    trunk (PyTorch-ROCm)            -> x0 @1/8, x1 @1/16, x2 @1/32
+    g6d_conv_igemm x3               query features correlated with the reference feature maps used as filters
+                                    (F.conv2d(que_x, ref_x, padding=7/3/1), detector.py:222-224): implicit GEMM with
+                                    M = positions, N = rfn, K = 512*k*k on fp32 MFMA, split along K to fill the chip
+    g6d_detector_assemble           nearest up-sampling, (x-mu)/sigma, clip, bilinear resize to (h/8,w/8), stack
+then g6d_detector_score_mlp_max     score_conv MLP + max over references, never materialising [64,rfn,hs,ws]
+     g6d_conv_igemm x7              the three 3x3 heads (first layers merged into one 64->192 conv)
+     g6d_detector_decode            arg-max + offset/scale gather.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .. import ops, specs
+from .backbone import img_norm, vgg_taps
+from .params import ParamBank, fold_vgg
+
+
+class Detector(ParamBank):
+    default_cfg = {
+        "vgg_score_stats": [[36.264317, 13.151907], [13910.291, 5345.965], [829.70807, 387.98788]],
+        "vgg_score_max": 10,
+        "detection_scales": [-1.0, -0.5, 0.0, 0.5],
+        "train_feats": False,
+    }
+
+    def __init__(self, cfg):
+        self.cfg = {**self.default_cfg, **cfg}
+        super().__init__(specs.detector_rows())
+        if len(self.cfg["detection_scales"]) != 4:
+            raise NotImplementedError("score_conv expects 3 levels x 4 detection scales (12 channels)")
+        self.pool_ratio = 8
+        self.ref_center_feats = None     # three [rfn, k*k, 512] correlation filters
+        self.ref_shape = None
+
+    # ------------------------------------------------------------------ weights
+    def _pack(self):
+        if self._packed is None:
+            pk = {"vgg": fold_vgg(self, "backbone.features")}
+            w0, b0 = self.conv_w("score_conv.0")
+            w1, b1 = self.conv_w("score_conv.2")
+            pk["mlp"] = (w0.reshape(64, 12).contiguous(), b0, w1.reshape(64, 64).contiguous(), b1)
+            heads = ("score_predict", "scale_predict", "offset_predict")
+            l0 = [self.conv_w(f"{h}.0") for h in heads]
+            pk["h0"] = (torch.cat([w for w, _ in l0], 0).contiguous(), torch.cat([b for _, b in l0], 0).contiguous())
+            pk["h1"] = [self.conv_w(f"{h}.2") for h in heads]
+            pk["h2"] = [self.conv_w(f"{h}.4") for h in heads]
+            self._packed = pk
+        return self._packed
+
+    # ------------------------------------------------------------------ trunk
+    def extract_feats(self, imgs):
+        """imgs [n,3,h,w] in [0,1] -> channels-last x0,x1,x2: [n,1,h/8,w/8,512], [.. /16 ..], [.. /32 ..]."""
+        t = vgg_taps(self._pack()["vgg"], img_norm(imgs), {"c5", "c7_pre", "p7"})
+        outs = []
+        for key in ("c5", "c7_pre", "p7"):
+            x = t[key].contiguous()
+            n, c, h, w = x.shape
+            o = torch.empty((n, 1, h, w, c), dtype=torch.float32, device=x.device)
+            outs.append(ops.nchw_to_nhwc(x, o, False))
+        return outs
+
+    def load_impl(self, ref_imgs):
+        """ref_imgs [rfn,3,h,w] in [0,1]; nearest resize to 120x120, trunk, keep as correlation filters
+        (reference detector.py:199-205)."""
+        ref_imgs = F.interpolate(ref_imgs, size=(120, 120))
+        feats = self.extract_feats(ref_imgs)                       # [rfn,1,k,k,512]
+        self.ref_center_feats = [f.reshape(f.shape[0], f.shape[2] * f.shape[3], 512).contiguous() for f in feats]
+        self.ref_ksize = [f.shape[2] for f in feats]               # 15, 7, 3
+        self.ref_shape = [120, 120]
+
+    # ------------------------------------------------------------------ detection
+    def _scores_one_scale(self, que_img, scale_idx, stacked, hs, ws):
+        x0, x1, x2 = self.extract_feats(que_img)
+        rfn = self.ref_center_feats[0].shape[0]
+        maps = []
+        for x, wref, k in zip((x0, x1, x2), self.ref_center_feats, self.ref_ksize):
+            _, _, h, w, _ = x.shape
+            o = torch.empty((1, 1, h, w, rfn), dtype=torch.float32, device=x.device)
+            ops.conv(x, wref, None, o, ksize=(1, k, k), pad=(0, k // 2, k // 2))
+            maps.append(o.reshape(h * w, rfn))
+        hc, wc = x0.shape[2], x0.shape[3]
+        ops.detector_assemble(maps[0], maps[1], maps[2], hc, wc, self.cfg["vgg_score_stats"],
+                              float(self.cfg["vgg_score_max"]), hs, ws, scale_idx, stacked)
+
+    def _detect_one(self, que_img):
+        pk = self._pack()
+        _, _, hq, wq = que_img.shape
+        hs, ws = hq // 8, wq // 8
+        dev = que_img.device
+        rfn = self.ref_center_feats[0].shape[0]
+        stacked = torch.empty((hs * ws, rfn, 12), dtype=torch.float32, device=dev)
+        for si, scale in enumerate(self.cfg["detection_scales"]):
+            ht, wt = int(np.round(hq * 2 ** scale)), int(np.round(wq * 2 ** scale))
+            if ht % 32 != 0: ht = (ht // 32 + 1) * 32
+            if wt % 32 != 0: wt = (wt // 32 + 1) * 32
+            cur = F.interpolate(que_img, size=(ht, wt), mode="bilinear")
+            self._scores_one_scale(cur, si, stacked, hs, ws)
+        feats = ops.detector_score_mlp_max(stacked, *pk["mlp"])               # [P,64]
+        P = hs * ws
+        k3, p3 = (1, 3, 3), (0, 1, 1)
+        a = torch.empty((1, 1, hs, ws, 192), dtype=torch.float32, device=dev)
+        ops.conv(feats.view(1, 1, hs, ws, 64), pk["h0"][0], pk["h0"][1], a, ksize=k3, pad=p3, out_act=1)
+        b = torch.empty_like(a)
+        o4 = torch.empty((1, 1, hs, ws, 4), dtype=torch.float32, device=dev)
+        col = 0
+        for i in range(3):
+            w1, b1 = pk["h1"][i]
+            ops.conv(a[..., 64 * i:64 * i + 64], w1, b1, b[..., 64 * i:64 * i + 64], ksize=k3, pad=p3, out_act=1)
+            w2, b2 = pk["h2"][i]
+            co = w2.shape[0]
+            ops.conv(b[..., 64 * i:64 * i + 64], w2, b2, o4[..., col:col + co], ksize=k3, pad=p3)
+            col += co
+        o4 = o4.view(P, 4)                                                     # score, scale, offset x, offset y
+        res = ops.detector_decode(o4[:, 0:1], o4[:, 2:4], o4[:, 1:2], hs, ws, self.pool_ratio)
+        return o4, res, (hs, ws)
+
+    def detect_impl(self, que_imgs):
+        """que_imgs [qn,3,hq,wq] in [0,1] -> the reference's output dict (detector.py:232-266) plus
+        'positions' [qn,2] and 'scales' [qn] already decoded on the device."""
+        outs, results = [], []
+        for qi in range(que_imgs.shape[0]):
+            o4, res, (hs, ws) = self._detect_one(que_imgs[qi:qi + 1])
+            outs.append(o4.view(hs, ws, 4).permute(2, 0, 1))
+            results.append(res)
+        o = torch.stack(outs, 0)                                               # qn,4,hs,ws
+        r = torch.stack(results, 0)
+        return {"scores": o[:, 0:1], "select_pr_scale": o[:, 1:2], "select_pr_offset": o[:, 2:4],
+                "que_select_id": r[:, 3:5].round().long(), "pool_ratio": self.pool_ratio,
+                "positions": r[:, 0:2], "scales": r[:, 2]}
+
+    def forward(self, data):
+        self.load_impl(data["ref_imgs_info"]["imgs"])
+        return self.detect_impl(data["que_imgs_info"]["imgs"])
+
+    @staticmethod
+    def parse_detection(scores, scales, offsets, pool_ratio):
+        """Same contract as BaseDetector.parse_detection (detector.py:97-121), torch ops on the caller's device."""
+        qn, _, hs, ws = scores.shape
+        flat = torch.argmax(scores.flatten(1), 1)
+        sy, sx = flat // ws, flat % ws
+        ar = torch.arange(qn, device=scores.device)
+        pos = (torch.stack([sx, sy], -1) + offsets[ar, :, sy, sx] + 0.5) * pool_ratio - 0.5
+        return pos, 2 ** scales[ar, 0, sy, sx]
+
+    # ------------------------------------------------------------------ numpy API used by Gen6DEstimator
+    def load_ref_imgs(self, ref_imgs):
+        """ref_imgs: uint8 [rfn,h,w,3] (reference detector.py:277-289)."""
+        x = torch.from_numpy(np.ascontiguousarray(ref_imgs)).to(self.device_()).float().div_(255).permute(0, 3, 1, 2)
+        with torch.no_grad():
+            self.load_impl(x.contiguous())
+
+    def detect_que_imgs(self, que_imgs):
+        """que_imgs: uint8 [qn,h,w,3] -> {'positions': [qn,2], 'scales': [qn]} numpy (reference detector.py:291-304)."""
+        x = torch.from_numpy(np.ascontiguousarray(que_imgs)).to(self.device_()).float().div_(255).permute(0, 3, 1, 2)
+        with torch.no_grad():
+            out = self.detect_impl(x.contiguous())
+        return {"positions": out["positions"].cpu().numpy(), "scales": out["scales"].cpu().numpy()}

@@ -1,0 +1,182 @@
+"""VolumeRefiner — drop-in for the reference's network/refiner.py (same constructor, state_dict keys, forward dict).
+
+One refinement step (reference forward, refiner.py:249-269):
+    trunk (PyTorch-ROCm) on the 6 reference crops + the query crop, g6d_nchw_to_nhwc(l2norm)
+    RefineFeatureNet 2-D convs on g6d_conv_igemm; every InstanceNorm2d is a per-image (sum, sumsq) epilogue of the
+        producing conv and an affine(+ReLU) in the loader of the consuming conv / up-sampler      refiner.py:24-51,64-78
+    g6d_refiner_volume: projection + bilinear sampling + mean/std over references, fused            refiner.py:183-247
+    RefineVolumeEncodingNet 3x3x3 convs on g6d_conv_igemm (implicit 3-D GEMM, split-K for the 8^3/4^3 layers)
+    g6d_linear_gemv: the 32768->512 FC is a 67 MB weight stream                                     refiner.py:153-166
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .. import ops, specs
+from .backbone import img_norm, vgg_taps
+from .operator import pose_apply_th
+from .params import ParamBank, fold_vgg
+
+_K3, _P3 = (3, 3, 3), (1, 1, 1)
+_K2, _P2 = (1, 3, 3), (0, 1, 1)
+
+
+class VolumeRefiner(ParamBank):
+    default_cfg = {"refiner_sample_num": 32}
+
+    def __init__(self, cfg):
+        self.cfg = {**self.default_cfg, **cfg}
+        super().__init__(specs.refiner_rows())
+        self.ref_database = None
+        self.ref_ids = None
+
+    # ------------------------------------------------------------------ weights
+    def _pack(self):
+        if self._packed is None:
+            pk = {"vgg": fold_vgg(self, "feature_net.backbone.features")}
+            for name in ("conv0", "conv1", "conv2", "conv_out"):
+                pk[name] = [self.conv_w(f"feature_net.{name}.{i}") for i in (0, 3)]
+            for name in ("mean_embed", "var_embed", "conv5"):
+                pk["v_" + name] = [self.conv_w(f"volume_net.{name}.{i}") for i in (0, 3)]
+            for name in ("conv0", "conv1", "conv2", "conv3", "conv4"):
+                pk["v_" + name] = self.conv_w(f"volume_net.{name}.0")
+            # fc.0.0 consumes x.flatten(1) of [512,4,4,4] (index c*64+v); our code is [v][c] -> permute once
+            w = self.p("regressor.fc.0.0.weight")
+            pk["fc0"] = (w.reshape(512, 512, 64).permute(0, 2, 1).reshape(512, 32768).contiguous(),
+                         self.p("regressor.fc.0.0.bias").contiguous())
+            pk["fc1"] = (self.p("regressor.fc.1.0.weight").contiguous(), self.p("regressor.fc.1.0.bias").contiguous())
+            heads = ("fcr", "fct", "fcs")
+            pk["heads"] = (torch.cat([self.p(f"regressor.{h}.weight") for h in heads], 0).contiguous(),
+                           torch.cat([self.p(f"regressor.{h}.bias") for h in heads], 0).contiguous())
+            self._packed = pk
+        return self._packed
+
+    # ------------------------------------------------------------------ 2-D feature net
+    def run_feature_net(self, imgs):
+        """imgs [n,3,h,w] in [0,1] -> channels-last features [n,h/4,w/4,128] (reference refiner.py:64-78)."""
+        pk = self._pack()
+        n, _, h, w = imgs.shape
+        dev = imgs.device
+        t = vgg_taps(pk["vgg"], img_norm(imgs), {"c3", "c5", "c7_pre"})
+
+        def nhwc(x):
+            x = x.contiguous()
+            o = torch.empty((x.shape[0], 1, x.shape[2], x.shape[3], x.shape[1]), dtype=torch.float32, device=dev)
+            return ops.nchw_to_nhwc(x, o, True)
+
+        def pair(name, x):
+            """conv, IN, ReLU, conv, (IN returned as affine) — per-image statistics."""
+            (w0, b0), (w1, b1) = pk[name]
+            _, _, hh, ww, _ = x.shape
+            y0 = torch.empty((n, 1, hh, ww, w0.shape[0]), dtype=torch.float32, device=dev)
+            s0 = ops.new_stats(n, w0.shape[0], dev)
+            ops.conv(x, w0, b0, y0, ksize=_K2, pad=_P2, stats=s0, rows_per_group=hh * ww)
+            sc0, sh0 = ops.stats_finalize(s0, hh * ww)
+            y1 = torch.empty((n, 1, hh, ww, w1.shape[0]), dtype=torch.float32, device=dev)
+            s1 = ops.new_stats(n, w1.shape[0], dev)
+            ops.conv(y0, w1, b1, y1, ksize=_K2, pad=_P2, in_scale=sc0, in_shift=sh0, in_relu=True, per_n=True,
+                     stats=s1, rows_per_group=hh * ww)
+            sc1, sh1 = ops.stats_finalize(s1, hh * ww)
+            return y1, sc1, sh1
+
+        hq, wq = h // 4, w // 4
+        cat = torch.empty((n, 1, hq, wq, 192), dtype=torch.float32, device=dev)
+        y, sc, sh = pair("conv0", nhwc(t["c3"]))
+        ops.affine_act_pool(y, cat[..., 0:64], sc, sh, per_n=True)
+        y, sc, sh = pair("conv1", nhwc(t["c5"]))
+        ops.upsample_bilinear(y, cat[..., 64:128], 2, sc, sh, per_n=True)
+        y, sc, sh = pair("conv2", nhwc(t["c7_pre"]))
+        ops.upsample_bilinear(y, cat[..., 128:192], 4, sc, sh, per_n=True)
+        y, sc, sh = pair("conv_out", cat)
+        out = torch.empty((n, 1, hq, wq, 128), dtype=torch.float32, device=dev)
+        ops.affine_act_pool(y, out, sc, sh, per_n=True)
+        return out.view(n, hq, wq, 128)
+
+    # ------------------------------------------------------------------ 3-D volume net + regressor
+    def run_volume_net(self, mean_in, std, sn):
+        """mean_in [sn^3,256], std [sn^3,128] -> code [ (sn/8)^3, 512 ] (reference refiner.py:136-143)."""
+        pk = self._pack()
+        dev = mean_in.device
+        vox = sn ** 3
+
+        def c3(x, wb, out, stride=1, aff=None, stats_c=None):
+            st = ops.new_stats(1, stats_c, dev) if stats_c else None
+            sc, sh = aff if aff is not None else (None, None)
+            ops.conv(x, wb[0], wb[1], out, ksize=_K3, stride=(stride,) * 3, pad=_P3, in_scale=sc, in_shift=sh,
+                     in_relu=aff is not None, stats=st)
+            return st
+
+        def buf(s, c):
+            return torch.empty((1, s, s, s, c), dtype=torch.float32, device=dev)
+
+        cat = buf(sn, 128)
+        for name, x, sl in (("v_mean_embed", mean_in.view(1, sn, sn, sn, 256), slice(0, 64)),
+                            ("v_var_embed", std.view(1, sn, sn, sn, 128), slice(64, 128))):
+            y = buf(sn, 64)
+            st = c3(x, pk[name][0], y, stats_c=64)
+            c3(y, pk[name][1], cat[..., sl], aff=ops.stats_finalize(st, vox))
+        x, aff, s = cat, None, sn
+        for name, co, stride in (("v_conv0", 64, 1), ("v_conv1", 128, 2), ("v_conv2", 128, 1), ("v_conv3", 256, 2),
+                                 ("v_conv4", 256, 1)):
+            s = s // stride
+            y = buf(s, co)
+            st = c3(x, pk[name], y, stride=stride, aff=aff, stats_c=co)
+            x, aff = y, ops.stats_finalize(st, s ** 3)
+        s = s // 2
+        y = buf(s, 512)
+        st = c3(x, pk["v_conv5"][0], y, stride=2, aff=aff, stats_c=512)
+        code = buf(s, 512)
+        c3(y, pk["v_conv5"][1], code, aff=ops.stats_finalize(st, s ** 3))
+        return code.view(s ** 3, 512)
+
+    def run_regressor(self, code):
+        pk = self._pack()
+        x = ops.linear_gemv(code.reshape(1, -1), pk["fc0"][0], pk["fc0"][1], act=2)
+        x = ops.linear_gemv(x, pk["fc1"][0], pk["fc1"][1], act=2)
+        o = ops.linear_gemv(x, pk["heads"][0], pk["heads"][1])
+        return F.normalize(o[:, 0:4], dim=1), o[:, 4:6], o[:, 6:7]
+
+    def _step(self, que_img, K_in, pose_in, ref_imgs, ref_Ks, ref_poses):
+        sn = self.cfg["refiner_sample_num"]
+        dev = que_img.device
+        rfn = ref_imgs.shape[0]
+        h_in, w_in = ref_imgs.shape[-2:]
+        feats = self.run_feature_net(torch.cat([ref_imgs, que_img], 0))                  # query last
+        projs = torch.cat([ref_Ks @ ref_poses, (K_in @ pose_in)[None]], 0).contiguous()
+        lin = torch.linspace(-1, 1, sn, dtype=torch.float32, device=dev)
+        C = feats.shape[-1]
+        mean_in = torch.empty((sn ** 3, 2 * C), dtype=torch.float32, device=dev)
+        std = torch.empty((sn ** 3, C), dtype=torch.float32, device=dev)
+        ops.refiner_volume(feats.contiguous(), projs, pose_in[:, :3].contiguous(), lin, h_in, w_in, mean_in, std)
+        return self.run_regressor(self.run_volume_net(mean_in, std, sn))
+
+    def forward(self, data):
+        """Same dict contract as the reference (refiner.py:249-269)."""
+        is_inference = data["inference"] if "inference" in data else False
+        que, ref = data["que_imgs_info"], data["ref_imgs_info"]
+        outs = [self._step(que["imgs"][qi:qi + 1], que["Ks_in"][qi], que["poses_in"][qi], ref["imgs"][qi], ref["Ks"][qi],
+                           ref["poses"][qi]) for qi in range(que["imgs"].shape[0])]
+        out = {"rotation": torch.cat([o[0] for o in outs], 0), "offset": torch.cat([o[1] for o in outs], 0),
+               "scale": torch.cat([o[2] for o in outs], 0)}
+        if not is_inference:
+            sn = self.cfg["refiner_sample_num"]
+            g = torch.linspace(-1, 1, sn, dtype=torch.float32, device=que["imgs"].device)
+            V = torch.stack(torch.meshgrid(g, g, g, indexing="ij"), -1).reshape(1, sn ** 3, 3) @ que["poses_in"][:, :3, :3]
+            out["grids"] = pose_apply_th(que["poses_in"], V)
+        return out
+
+    # ------------------------------------------------------------------ estimator API
+    def load_ref_imgs(self, ref_database, ref_ids):
+        self.ref_database = ref_database
+        self.ref_ids = ref_ids
+
+    def refine_step_tensors(self, que_img_u8, K_in, pose_in, ref_imgs_u8, ref_Ks, ref_poses):
+        """Numpy boundary of one step after the host-side warps: uint8 crops [h,w,3] / [rfn,h,w,3], float32 K/poses
+        -> (quat [4], scale (=2**s) [1], offset [2]) numpy, as consumed at reference refiner.py:327-331."""
+        dev = self.device_()
+        f = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+        q = torch.from_numpy(np.ascontiguousarray(que_img_u8)).to(dev).float().div_(255).permute(2, 0, 1)[None].contiguous()
+        r = torch.from_numpy(np.ascontiguousarray(ref_imgs_u8)).to(dev).float().div_(255).permute(0, 3, 1, 2).contiguous()
+        with torch.no_grad():
+            rot, off, scl = self._step(q, f(K_in), f(pose_in), r, f(ref_Ks), f(ref_poses))
+        return rot[0].cpu().numpy(), 2 ** scl[0].cpu().numpy(), off[0].cpu().numpy()

@@ -1,0 +1,244 @@
+"""ViewpointSelector — drop-in for the reference's network/selector.py (same constructor, state_dict keys, methods).
+
+Query-time data flow (reference compute_view_point_feats, selector.py:177-215), D = rfn*an hypotheses, d = r*an + a:
+    trunk (PyTorch-ROCm) + g6d_nchw_to_nhwc(l2norm)       query features, 3 levels, channels-last
+  per level l:
+    g6d_selector_scan          score maps sum_c q*r and the "vps" scalars  (one coalesced pass over the ref cache)
+    g6d_selector_prod_affine   InstanceNorm3d(512) statistics of the never-materialised product q*r from R1/R2
+    g6d_conv_igemm             first (1,3,3) conv with the product, the norm affine and the zero padding fused into
+                               its operand loader; later convs fuse the preceding InstanceNorm(+ReLU) the same way and
+                               accumulate the next InstanceNorm's statistics in their epilogue
+    g6d_affine_act_pool        only where a MaxPool sits between two convs
+  tail: 1x1 convs as GEMMs on the same MFMA kernel, g6d_vps_norm, g6d_max_an_add, g6d_attention, g6d_layernorm,
+        g6d_affine_act_add.  AvgPool(1,4,4) is commuted in front of the last 1x1x1 conv (both linear).
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .. import ops, specs
+from .backbone import img_norm, vgg_taps
+from .params import ParamBank, fold_vgg
+
+# per level: (conv index in corr_conv_list[l], InstanceNorm after?, ReLU after?, MaxPool after?)  selector.py:27-69
+_CORR = (
+    ((1, 1, 1, 0), (4, 1, 0, 1), (7, 1, 1, 0), (10, 1, 0, 1), (13, 1, 1, 0), (16, 0, 0, 0)),
+    ((1, 1, 1, 0), (4, 1, 0, 1), (7, 1, 1, 0), (10, 0, 0, 0)),
+    ((1, 1, 1, 0), (4, 0, 0, 0)),
+)
+_K133, _P011 = (1, 3, 3), (0, 1, 1)
+FEAT_LD = 516          # 512 corr channels + 3 vps channels + 1 zero pad (16-byte rows)
+
+
+class ViewpointSelector(ParamBank):
+    default_cfg = {"selector_angle_num": 5}
+
+    def __init__(self, cfg):
+        self.cfg = {**self.default_cfg, **cfg}
+        super().__init__(specs.selector_rows(self.cfg["selector_angle_num"]))
+        self.ref_feats_cache = None      # 3 x [D, HW_l, 512] channels-last, d = r*an + a
+        self.ref_sums = None             # 3 x (R1, R2) fp64 [HW_l, 512]
+        self.ref_pose_embed = None       # [rfn, 512]
+        self.rfn = self.an = None
+
+    # ------------------------------------------------------------------ weights
+    def _pack(self):
+        if self._packed is None:
+            an = self.cfg["selector_angle_num"]
+            pk = {"vgg": fold_vgg(self, "backbone.features")}
+            pk["corr"] = [[self.conv_w(f"corr_conv_list.{l}.{i}") for i, *_ in layers] for l, layers in enumerate(_CORR)]
+            pk["fuse0"] = self.conv_w("corr_feats_conv.0")
+            pk["fuse3"] = self.conv_w("corr_feats_conv.3")
+            pk["sp0"] = self.conv_w("score_process.0", cin_pad=FEAT_LD)
+            pk["sp2"] = self.conv_w("score_process.2")
+            pk["att"] = []
+            for i in range(2):
+                qkv = [self.conv_w(f"atts.{i}.{n}") for n in ("conv_query", "conv_key", "conv_feats")]
+                pk["att"].append({
+                    "qkv": (torch.cat([w for w, _ in qkv], 0).contiguous(), torch.cat([b for _, b in qkv], 0).contiguous()),
+                    "merge": self.conv_w(f"atts.{i}.conv_merge"),
+                    "ln": (self.p(f"atts.{i}.norm.norm.weight").contiguous(), self.p(f"atts.{i}.norm.norm.bias").contiguous()),
+                    "mlp0": self.conv_w(f"mlps.{i}.0"), "mlp3": self.conv_w(f"mlps.{i}.3")})
+            pk["pred0"] = self.conv_w("score_predict.0")
+            pk["pred2"] = self.conv_w("score_predict.2")
+            # angle head consumes feats.permute(0,1,3,2).reshape(qn,515*an,rfn): channel c*an+a (selector.py:212-214);
+            # our per-reference row is [an][516], i.e. index a*516+c -> permute the weight once.
+            w, b = self.p("angle_predict.0.weight"), self.p("angle_predict.0.bias")
+            w = w.reshape(512, 515, an).permute(0, 2, 1)
+            w = F.pad(w, (0, FEAT_LD - 515)).reshape(512, 1, an * FEAT_LD).contiguous()
+            pk["ang0"] = (w, b.contiguous())
+            pk["ang2"] = self.conv_w("angle_predict.2")
+            pk["ang4"] = self.conv_w("angle_predict.4")
+            self._packed = pk
+        return self._packed
+
+    # ------------------------------------------------------------------ features
+    def get_feats(self, imgs):
+        """imgs [n,3,h,w] in [0,1] -> 3 channels-last, L2-normalised maps [n,1,h_l,w_l,512] (selector.py:113-119)."""
+        t = vgg_taps(self._pack()["vgg"], img_norm(imgs), {"c5", "c7_pre", "p7"})
+        outs = []
+        for key in ("c5", "c7_pre", "p7"):
+            x = t[key].contiguous()
+            n, c, h, w = x.shape
+            outs.append(ops.nchw_to_nhwc(x, torch.empty((n, 1, h, w, c), dtype=torch.float32, device=x.device), True))
+        return outs
+
+    def extract_ref_feats(self, ref_imgs, ref_poses, object_center, object_vert, is_train=False):
+        """ref_imgs [an,rfn,3,h,w]; builds the reference cache, its R1/R2 sums and the viewpoint embedding
+        (reference selector.py:121-148, eval branch: object_forward = first reference)."""
+        if is_train:
+            raise NotImplementedError("inference-only implementation (random object_forward is a training augmentation)")
+        an, rfn, _, h, w = ref_imgs.shape
+        if an != self.cfg["selector_angle_num"]:
+            raise ValueError("number of rotations does not match selector_angle_num")
+        self.rfn, self.an = rfn, an
+        D = rfn * an
+        imgs = ref_imgs.permute(1, 0, 2, 3, 4).reshape(D, 3, h, w)          # d = r*an + a
+        dev = imgs.device
+        cache = [torch.empty((D, 1, h >> s, w >> s, 512), dtype=torch.float32, device=dev) for s in (3, 4, 5)]
+        for i0 in range(0, D, 64):
+            feats = self.get_feats(imgs[i0:i0 + 64].contiguous())
+            for l in range(3):
+                cache[l][i0:i0 + 64].copy_(feats[l])
+        self.ref_feats_cache = cache
+        self.ref_sums = [ops.selector_ref_sums(c.view(D, -1, 512)) for c in cache]
+
+        # viewpoint embedding: tiny one-time MLP on [rfn,3] (torch ops on the device)
+        cam = (-ref_poses[:, :3, :3].transpose(1, 2) @ ref_poses[:, :3, 3:])[..., 0] - object_center[None]
+        fwd = cam[0]
+        y = torch.linalg.cross(object_vert, fwd)
+        x = torch.linalg.cross(y, object_vert)
+        R = torch.stack([F.normalize(x, dim=0), F.normalize(y, dim=0), F.normalize(object_vert, dim=0)], 0)
+        v = F.normalize(cam @ R.T, dim=1)
+        for i in (0, 2, 4):
+            v = F.linear(v, self.p(f"view_point_encoder.{i}.weight"), self.p(f"view_point_encoder.{i}.bias"))
+            if i != 4: v = F.relu(v)
+        self.ref_pose_embed = v.contiguous()
+
+    # ------------------------------------------------------------------ query
+    def _level(self, l, q, cat):
+        """One pyramid level: q [1,1,h,w,512] query features; writes channels [256l,256l+256) of cat [D,1,4,4,768];
+        returns vps [D]."""
+        pk = self._pack()
+        cache, (r1, r2) = self.ref_feats_cache[l], self.ref_sums[l]
+        D, _, h, w, _ = cache.shape
+        dev = cache.device
+        q2 = q.view(h * w, 512)
+        _, vps = ops.selector_scan(q2, cache.view(D, h * w, 512))
+        scale, shift = ops.selector_prod_affine(q2, r1, r2, D)
+        x, mul, relu = cache, q.view(h, w, 512), False
+        layers = _CORR[l]
+        for li, (idx, has_in, has_relu, has_pool) in enumerate(layers):
+            wgt, bias = pk["corr"][l][li]
+            co = wgt.shape[0]
+            last = li == len(layers) - 1
+            out = cat[..., 256 * l:256 * l + 256] if last else torch.empty((D, 1, h, w, co), dtype=torch.float32, device=dev)
+            stats = ops.new_stats(1, co, dev) if has_in else None
+            ops.conv(x, wgt, bias, out, ksize=_K133, pad=_P011, mul=mul, in_scale=scale, in_shift=shift, in_relu=relu, stats=stats)
+            mul = None
+            if last:
+                break
+            scale, shift = ops.stats_finalize(stats, D * h * w)
+            if has_pool:
+                h, w = h // 2, w // 2
+                pooled = torch.empty((D, 1, h, w, co), dtype=torch.float32, device=dev)
+                ops.affine_act_pool(out, pooled, scale, shift, relu=bool(has_relu), pool=1)
+                x, scale, shift, relu = pooled, None, None, False
+            else:
+                x, relu = out, bool(has_relu)
+        return vps
+
+    def _query_one(self, que_img):
+        pk = self._pack()
+        rfn, an = self.rfn, self.an
+        D = rfn * an
+        dev = que_img.device
+        qf = self.get_feats(que_img)
+        cat = torch.empty((D, 1, 4, 4, 768), dtype=torch.float32, device=dev)
+        vps = torch.stack([self._level(l, qf[l], cat) for l in range(3)], 0)           # [3,D]
+
+        # corr_feats_conv: 1x1x1 768->512, IN3d, ReLU, (AvgPool commuted) 512->512   selector.py:71-77,197-200
+        y = torch.empty((D, 1, 4, 4, 512), dtype=torch.float32, device=dev)
+        st = ops.new_stats(1, 512, dev)
+        ops.conv(cat, pk["fuse0"][0], pk["fuse0"][1], y, stats=st)
+        sc, sh = ops.stats_finalize(st, D * 16)
+        pooled = torch.empty((D, 1, 1, 1, 512), dtype=torch.float32, device=dev)
+        ops.affine_act_pool(y, pooled, sc, sh, relu=True, pool=2)
+        feats = torch.zeros((D, FEAT_LD), dtype=torch.float32, device=dev)
+        ops.conv(pooled.view(1, 1, 1, D, 512), pk["fuse3"][0], pk["fuse3"][1], feats.view(1, 1, 1, D, FEAT_LD)[..., :512])
+        ops.vps_norm(vps, feats, 512)                                                   # selector.py:201-202
+
+        # score_process + max over rotations + viewpoint embedding                     selector.py:204-205
+        t0 = torch.empty((1, 1, 1, D, 512), dtype=torch.float32, device=dev)
+        ops.conv(feats.view(1, 1, 1, D, FEAT_LD), pk["sp0"][0], pk["sp0"][1], t0, out_act=1)
+        t1 = torch.empty_like(t0)
+        ops.conv(t0, pk["sp2"][0], pk["sp2"][1], t1)
+        xm = torch.empty((rfn, 1024), dtype=torch.float32, device=dev)                  # [x | msg]
+        ops.max_an_add(t1.view(D, 512), rfn, an, self.ref_pose_embed, xm[:, :512])
+
+        def tok(t):          # [n, C] (row-strided) -> conv view [1,1,1,n,C]
+            return t.as_strided((1, 1, 1, t.shape[0], t.shape[1]), (0, 0, 0, t.stride(0), 1), t.storage_offset())
+
+        for i in range(2):                                                              # selector.py:207-209
+            a = pk["att"][i]
+            qkv = torch.empty((rfn, 1536), dtype=torch.float32, device=dev)
+            ops.conv(tok(xm[:, :512]), a["qkv"][0], a["qkv"][1], tok(qkv))
+            att = torch.empty((rfn, 512), dtype=torch.float32, device=dev)
+            ops.attention(qkv[:, 0:512], qkv[:, 512:1024], qkv[:, 1024:1536], 8, att)
+            mrg = torch.empty((rfn, 512), dtype=torch.float32, device=dev)
+            ops.conv(tok(att), a["merge"][0], a["merge"][1], tok(mrg))
+            ops.layernorm(mrg, a["ln"][0], a["ln"][1], xm[:, 512:])
+            y0 = torch.empty((rfn, 512), dtype=torch.float32, device=dev)
+            s0 = ops.new_stats(1, 512, dev)
+            ops.conv(tok(xm), a["mlp0"][0], a["mlp0"][1], tok(y0), stats=s0)
+            sc0, sh0 = ops.stats_finalize(s0, rfn)
+            y1 = torch.empty((rfn, 512), dtype=torch.float32, device=dev)
+            s1 = ops.new_stats(1, 512, dev)
+            ops.conv(tok(y0), a["mlp3"][0], a["mlp3"][1], tok(y1), in_scale=sc0, in_shift=sh0, in_relu=True, stats=s1)
+            sc1, sh1 = ops.stats_finalize(s1, rfn)
+            xn = torch.empty((rfn, 1024), dtype=torch.float32, device=dev)
+            ops.affine_act_add(y1, xn[:, :512], sc1, sh1, relu=True, residual=xm[:, :512])
+            xm = xn
+        p0 = torch.empty((rfn, 512), dtype=torch.float32, device=dev)
+        ops.conv(tok(xm[:, :512]), pk["pred0"][0], pk["pred0"][1], tok(p0), out_act=1)
+        logits = torch.empty((rfn, 1), dtype=torch.float32, device=dev)
+        ops.conv(tok(p0), pk["pred2"][0], pk["pred2"][1], tok(logits))
+
+        # angle head on the per-reference rows [an*516]                                 selector.py:212-214
+        a0 = torch.empty((rfn, 512), dtype=torch.float32, device=dev)
+        ops.conv(tok(feats.view(rfn, an * FEAT_LD)), pk["ang0"][0], pk["ang0"][1], tok(a0), out_act=1)
+        a1 = torch.empty_like(a0)
+        ops.conv(tok(a0), pk["ang2"][0], pk["ang2"][1], tok(a1), out_act=1)
+        angles = torch.empty((rfn, 1), dtype=torch.float32, device=dev)
+        ops.conv(tok(a1), pk["ang4"][0], pk["ang4"][1], tok(angles))
+        return logits[:, 0], angles[:, 0]
+
+    def compute_view_point_feats(self, que_imgs):
+        """que_imgs [qn,3,h,w] in [0,1] -> logits [qn,rfn], angles [qn,rfn] (reference selector.py:177-215)."""
+        outs = [self._query_one(que_imgs[i:i + 1]) for i in range(que_imgs.shape[0])]
+        return torch.stack([o[0] for o in outs], 0), torch.stack([o[1] for o in outs], 0)
+
+    def forward(self, data):
+        self.extract_ref_feats(data["ref_imgs"], data["ref_imgs_info"]["poses"], data["object_center"],
+                               data["object_vert"], "eval" not in data)
+        logits, angles = self.compute_view_point_feats(data["que_imgs_info"]["imgs"])
+        return {"ref_vp_logits": logits, "angles_pr": angles}
+
+    # ------------------------------------------------------------------ numpy API used by Gen6DEstimator
+    def load_ref_imgs(self, ref_imgs, ref_poses, object_center, object_vert):
+        """uint8 [an,rfn,h,w,3], [rfn,3,4], [3], [3] (reference selector.py:150-163)."""
+        dev = self.device_()
+        x = torch.from_numpy(np.ascontiguousarray(ref_imgs)).to(dev).float().div_(255).permute(0, 1, 4, 2, 3)
+        f = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float32)).to(dev)
+        with torch.no_grad():
+            self.extract_ref_feats(x, f(ref_poses), f(object_center), f(object_vert))
+
+    def select_que_imgs(self, que_imgs):
+        """uint8 [qn,h,w,3] -> {'ref_idx','angles','scores'} numpy; the raw network angle at the arg-max reference
+        (reference selector.py:165-175)."""
+        x = torch.from_numpy(np.ascontiguousarray(que_imgs)).to(self.device_()).float().div_(255).permute(0, 3, 1, 2)
+        with torch.no_grad():
+            logits, angles = self.compute_view_point_feats(x.contiguous())
+            idx = torch.argmax(logits, 1)
+            ang = angles[torch.arange(idx.shape[0], device=idx.device), idx]
+        return {"ref_idx": idx.cpu().numpy(), "angles": ang.cpu().numpy(), "scores": logits.cpu().numpy()}

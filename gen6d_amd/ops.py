@@ -1,0 +1,279 @@
+"""Tensor-level wrappers over the C ABI (include/gen6d_hip.h).
+
+Every function takes PyTorch tensors that live on the GPU, checks layout, and enqueues the HIP kernel on torch's
+current stream through ctypes.  PyTorch is only the owner of device memory and streams here.  Channel slices of wider
+buffers are expressed as ordinary tensor views: an activation is a 5-D view [N, D, H, W, C] whose last stride is 1
+and whose other strides are those of a dense channels-last buffer with channel stride ``ld = view.stride(3)``.
+
+The host networks call these through the module (``ops.conv(...)``), which lets the CPU test-suite substitute the
+per-op PyTorch references of tests/ref_ops.py to validate host orchestration without a GPU; the product path itself
+has no fallback — `lib.load()` raises if libgen6d_hip.so is absent.
+"""
+import ctypes as C
+
+import torch
+
+from . import lib as _lib
+
+_WS = {}
+WORKSPACE_BYTES = 256 << 20
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("gen6d_amd.ops: tensors must live on the GPU (HIP kernels only, no CPU fallback)")
+
+
+def workspace(device):
+    key = str(device)
+    if key not in _WS:
+        _WS[key] = torch.empty(WORKSPACE_BYTES // 4, dtype=torch.float32, device=device)
+    return _WS[key]
+
+
+def _cl5(t, name):
+    """Validate a channels-last 5-D view; return (N, D, H, W, C, ld)."""
+    if t.dim() != 5 or t.dtype != torch.float32:
+        raise ValueError(f"{name}: expected float32 [N,D,H,W,C], got {tuple(t.shape)} {t.dtype}")
+    N, D, H, W, Cc = t.shape
+    ld = t.stride(3)
+    s = t.stride()
+    ok = s[4] == 1 and ld >= Cc
+    exp = (D * H * W * ld, H * W * ld, W * ld, ld)
+    for dim, (got, want) in enumerate(zip(s[:4], exp)):
+        if t.shape[dim] > 1 and got != want:
+            ok = False
+    if not ok:
+        raise ValueError(f"{name}: not a channels-last view (shape {tuple(t.shape)}, strides {s})")
+    return N, D, H, W, Cc, ld
+
+
+def conv(x, w, bias, out, ksize=(1, 1, 1), stride=(1, 1, 1), pad=(0, 0, 0), mul=None, in_scale=None, in_shift=None,
+         in_relu=False, per_n=False, out_act=0, stats=None, rows_per_group=0, split_k=0):
+    """Implicit-GEMM convolution (g6d_conv_igemm). x [N,Di,Hi,Wi,Cin], w [Cout,taps,Cin], out [N,Do,Ho,Wo,Cout] views."""
+    _need_gpu(x, w, out)
+    N, Di, Hi, Wi, Cin, ld_in = _cl5(x, "conv.x")
+    No, Do, Ho, Wo, Cout, ld_out = _cl5(out, "conv.out")
+    kd, kh, kw = ksize
+    if tuple(w.shape) != (Cout, kd * kh * kw, Cin) or not w.is_contiguous():
+        raise ValueError(f"conv.w: expected contiguous {(Cout, kd * kh * kw, Cin)}, got {tuple(w.shape)}")
+    for i, (di, do, k, s, p) in enumerate(zip((Di, Hi, Wi), (Do, Ho, Wo), ksize, stride, pad)):
+        if do != (di + 2 * p - k) // s + 1:
+            raise ValueError(f"conv: output extent mismatch on axis {i}: in {di} k {k} s {s} p {p} -> out {do}")
+    if No != N:
+        raise ValueError("conv: batch mismatch")
+    if mul is not None and (tuple(mul.shape) != (Hi, Wi, Cin) or not mul.is_contiguous()):
+        raise ValueError("conv.mul: expected contiguous [Hi,Wi,Cin]")
+    ws = workspace(x.device)
+    d = _lib.G6dConv(
+        in_=x.data_ptr(), mul=mul.data_ptr() if mul is not None else None,
+        in_scale=in_scale.data_ptr() if in_scale is not None else None,
+        in_shift=in_shift.data_ptr() if in_shift is not None else None,
+        weight=w.data_ptr(), bias=bias.data_ptr() if bias is not None else None, out=out.data_ptr(),
+        stats=stats.data_ptr() if stats is not None else None, workspace=ws.data_ptr(), workspace_bytes=ws.numel() * 4,
+        N=N, Di=Di, Hi=Hi, Wi=Wi, Cin=Cin, ld_in=ld_in, Do=Do, Ho=Ho, Wo=Wo, Cout=Cout, ld_out=ld_out,
+        kd=kd, kh=kh, kw=kw, sd=stride[0], sh=stride[1], sw=stride[2], pd=pad[0], ph=pad[1], pw=pad[2],
+        in_relu=int(in_relu), in_affine_per_n=int(per_n), out_act=int(out_act),
+        stat_rows_per_group=int(rows_per_group), split_k=int(split_k))
+    _lib.check(_lib.load().g6d_conv_igemm(C.byref(d), _stream()), "g6d_conv_igemm")
+    return out
+
+
+def new_stats(groups, channels, device):
+    return torch.zeros((groups, channels, 2), dtype=torch.float64, device=device)
+
+
+def stats_finalize(stats, count, eps=1e-5):
+    """[G,C,2] fp64 (sum, sumsq) -> scale, shift float32 [G,C]."""
+    _need_gpu(stats)
+    G, Cc, _ = stats.shape
+    scale = torch.empty((G, Cc), dtype=torch.float32, device=stats.device)
+    shift = torch.empty_like(scale)
+    _lib.check(_lib.load().g6d_stats_finalize(_ptr(stats), G * Cc, float(count), float(eps), _ptr(scale), _ptr(shift),
+                                             _stream()), "g6d_stats_finalize")
+    return scale, shift
+
+
+def affine_act_pool(x, out, scale=None, shift=None, per_n=False, relu=False, pool=0):
+    """x [N,1,H,W,C] view -> out: pool 0 same shape; 1 -> [N,1,H/2,W/2,C]; 2 -> [N,1,1,1,C] (mean over HxW)."""
+    _need_gpu(x, out)
+    N, D, H, W, Cc, ld_in = _cl5(x, "affine_act_pool.x")
+    _, _, _, _, Co, ld_out = _cl5(out, "affine_act_pool.out")
+    if Co != Cc:
+        raise ValueError("affine_act_pool: channel mismatch")
+    _lib.check(_lib.load().g6d_affine_act_pool(_ptr(x), ld_in, _ptr(scale), _ptr(shift), int(per_n), int(relu), int(pool),
+                                              N * D, H, W, Cc, _ptr(out), ld_out, _stream()), "g6d_affine_act_pool")
+    return out
+
+
+def upsample_bilinear(x, out, factor, scale=None, shift=None, per_n=False):
+    _need_gpu(x, out)
+    N, D, H, W, Cc, ld_in = _cl5(x, "upsample.x")
+    _, _, Ho, Wo, Co, ld_out = _cl5(out, "upsample.out")
+    if (Ho, Wo, Co) != (H * factor, W * factor, Cc):
+        raise ValueError("upsample: output shape mismatch")
+    _lib.check(_lib.load().g6d_upsample_bilinear(_ptr(x), ld_in, _ptr(scale), _ptr(shift), int(per_n), N * D, H, W, Cc,
+                                                int(factor), _ptr(out), ld_out, _stream()), "g6d_upsample_bilinear")
+    return out
+
+
+def nchw_to_nhwc(x, out, l2norm):
+    """x [N,C,H,W] contiguous -> out [N,1,H,W,C] view, optionally L2-normalised over C."""
+    _need_gpu(x, out)
+    if not x.is_contiguous() or x.dtype != torch.float32:
+        raise ValueError("nchw_to_nhwc: x must be contiguous float32 NCHW")
+    N, Cc, H, W = x.shape
+    _, _, Ho, Wo, Co, ld_out = _cl5(out, "nchw_to_nhwc.out")
+    if (Ho, Wo, Co) != (H, W, Cc):
+        raise ValueError("nchw_to_nhwc: shape mismatch")
+    _lib.check(_lib.load().g6d_nchw_to_nhwc(_ptr(x), N, Cc, H, W, int(l2norm), _ptr(out), ld_out, _stream()), "g6d_nchw_to_nhwc")
+    return out
+
+
+def selector_ref_sums(refs):
+    """refs [D,HW,C] contiguous -> r1, r2 fp64 [HW,C]."""
+    _need_gpu(refs)
+    D, HW, Cc = refs.shape
+    r1 = torch.empty((HW, Cc), dtype=torch.float64, device=refs.device)
+    r2 = torch.empty_like(r1)
+    _lib.check(_lib.load().g6d_selector_ref_sums(_ptr(refs.contiguous()), D, HW, Cc, _ptr(r1), _ptr(r2), _stream()),
+               "g6d_selector_ref_sums")
+    return r1, r2
+
+
+def selector_prod_affine(que, r1, r2, D, eps=1e-5):
+    """que [HW,C] -> InstanceNorm affine (scale, shift) [1,C] of the product que*refs over (D,HW)."""
+    _need_gpu(que, r1, r2)
+    HW, Cc = que.shape
+    scale = torch.empty((1, Cc), dtype=torch.float32, device=que.device)
+    shift = torch.empty_like(scale)
+    _lib.check(_lib.load().g6d_selector_prod_affine(_ptr(que), _ptr(r1), _ptr(r2), D, HW, Cc, float(eps), _ptr(scale),
+                                                   _ptr(shift), _stream()), "g6d_selector_prod_affine")
+    return scale, shift
+
+
+def selector_scan(que, refs):
+    """que [HW,C], refs [D,HW,C] -> score_map [D,HW], vps [D]."""
+    _need_gpu(que, refs)
+    D, HW, Cc = refs.shape
+    if not (que.is_contiguous() and refs.is_contiguous()):
+        raise ValueError("selector_scan: operands must be contiguous")
+    smap = torch.empty((D, HW), dtype=torch.float32, device=que.device)
+    vps = torch.empty((D,), dtype=torch.float32, device=que.device)
+    _lib.check(_lib.load().g6d_selector_scan(_ptr(que), _ptr(refs), D, HW, Cc, _ptr(smap), _ptr(vps), _stream()),
+               "g6d_selector_scan")
+    return smap, vps
+
+
+def refiner_volume(feats, projs, rot_in, lin, h_in, w_in, mean_in, std):
+    """feats [rfn+1,fh,fw,C], projs [rfn+1,3,4], rot_in [3,3], lin [sn] -> mean_in [sn^3,2C], std [sn^3,C] (written)."""
+    _need_gpu(feats, projs, rot_in, lin, mean_in, std)
+    V, fh, fw, Cc = feats.shape
+    sn = lin.numel()
+    for t in (feats, projs, rot_in, lin, mean_in, std):
+        if not t.is_contiguous() or t.dtype != torch.float32:
+            raise ValueError("refiner_volume: operands must be contiguous float32")
+    if tuple(mean_in.shape) != (sn ** 3, 2 * Cc) or tuple(std.shape) != (sn ** 3, Cc) or tuple(projs.shape) != (V, 3, 4):
+        raise ValueError("refiner_volume: shape mismatch")
+    _lib.check(_lib.load().g6d_refiner_volume(_ptr(feats), _ptr(projs), _ptr(rot_in), _ptr(lin), V - 1, fh, fw, Cc,
+                                             int(h_in), int(w_in), sn, _ptr(mean_in), _ptr(std), _stream()),
+               "g6d_refiner_volume")
+    return mean_in, std
+
+
+def detector_assemble(s0, s1, s2, hc, wc, mu_sigma, clip, hs, ws, scale_idx, stacked):
+    """s_l [h_l*w_l, rfn] raw correlation maps of one scale -> channels 3*scale_idx.. of stacked [hs*ws, rfn, nch]."""
+    _need_gpu(s0, s1, s2, stacked)
+    rfn = s0.shape[1]
+    P, rfn2, nch = stacked.shape
+    if P != hs * ws or rfn2 != rfn or not stacked.is_contiguous():
+        raise ValueError("detector_assemble: stacked shape mismatch")
+    if s0.shape[0] != hc * wc or s1.shape[0] != (hc // 2) * (wc // 2) or s2.shape[0] != (hc // 4) * (wc // 4):
+        raise ValueError("detector_assemble: level map sizes do not match")
+    ms = (C.c_float * 6)(*[float(v) for pair in mu_sigma for v in pair])
+    _lib.check(_lib.load().g6d_detector_assemble(_ptr(s0), _ptr(s1), _ptr(s2), hc, wc, rfn, ms, float(clip), hs, ws,
+                                                int(scale_idx), nch, _ptr(stacked), _stream()), "g6d_detector_assemble")
+    return stacked
+
+
+def detector_score_mlp_max(stacked, w0, b0, w1, b1):
+    _need_gpu(stacked, w0, b0, w1, b1)
+    P, rfn, nch = stacked.shape
+    out = torch.empty((P, 64), dtype=torch.float32, device=stacked.device)
+    _lib.check(_lib.load().g6d_detector_score_mlp_max(_ptr(stacked), P, rfn, nch, _ptr(w0), _ptr(b0), _ptr(w1), _ptr(b1),
+                                                     _ptr(out), _stream()), "g6d_detector_score_mlp_max")
+    return out
+
+
+def detector_decode(scores, offset, scale, hs, ws, pool_ratio):
+    """scores [P,1], offset [P,2], scale [P,1] (row-strided views allowed) -> result [5]."""
+    _need_gpu(scores, offset, scale)
+    res = torch.empty((5,), dtype=torch.float32, device=scores.device)
+    _lib.check(_lib.load().g6d_detector_decode(_ptr(scores), scores.stride(0), _ptr(offset), offset.stride(0), _ptr(scale),
+                                              scale.stride(0), hs, ws, int(pool_ratio), _ptr(res), _stream()),
+               "g6d_detector_decode")
+    return res
+
+
+def vps_norm(vps, feats, c_off):
+    """vps [3,D] -> InstanceNorm over D -> feats[:, c_off:c_off+3] (feats [D,ld] contiguous)."""
+    _need_gpu(vps, feats)
+    _lib.check(_lib.load().g6d_vps_norm(_ptr(vps.contiguous()), vps.shape[1], _ptr(feats), feats.stride(0), int(c_off), _stream()),
+               "g6d_vps_norm")
+    return feats
+
+
+def max_an_add(x, rfn, an, embed, out):
+    """x [rfn*an, C] (row stride allowed) -> out[r] = max_a x[r*an+a] + embed[r]."""
+    _need_gpu(x, embed, out)
+    Cc = x.shape[1]
+    _lib.check(_lib.load().g6d_max_an_add(_ptr(x), x.stride(0), rfn, an, Cc, _ptr(embed.contiguous()), _ptr(out),
+                                         out.stride(0), _stream()), "g6d_max_an_add")
+    return out
+
+
+def attention(q, k, v, heads, out):
+    _need_gpu(q, k, v, out)
+    n, Cc = q.shape
+    if not (q.stride(0) == k.stride(0) == v.stride(0)):
+        raise ValueError("attention: q/k/v must share the row stride")
+    _lib.check(_lib.load().g6d_attention(_ptr(q), _ptr(k), _ptr(v), q.stride(0), n, Cc, heads, _ptr(out), out.stride(0),
+                                        _stream()), "g6d_attention")
+    return out
+
+
+def layernorm(x, gamma, beta, out, eps=1e-5):
+    _need_gpu(x, gamma, beta, out)
+    n, Cc = x.shape
+    _lib.check(_lib.load().g6d_layernorm(_ptr(x), x.stride(0), n, Cc, _ptr(gamma), _ptr(beta), float(eps), _ptr(out),
+                                        out.stride(0), _stream()), "g6d_layernorm")
+    return out
+
+
+def affine_act_add(x, out, scale=None, shift=None, relu=False, residual=None):
+    _need_gpu(x, out)
+    n, Cc = x.shape
+    _lib.check(_lib.load().g6d_affine_act_add(_ptr(x), x.stride(0), _ptr(scale), _ptr(shift), int(relu), _ptr(residual),
+                                             residual.stride(0) if residual is not None else 0, n, Cc, _ptr(out),
+                                             out.stride(0), _stream()), "g6d_affine_act_add")
+    return out
+
+
+def linear_gemv(x, W, bias, act=0):
+    """x [B,K] contiguous, W [O,K] contiguous -> [B,O]."""
+    _need_gpu(x, W)
+    B, K = x.shape
+    O = W.shape[0]
+    out = torch.empty((B, O), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().g6d_linear_gemv(_ptr(x.contiguous()), B, K, _ptr(W), _ptr(bias), O, int(act), _ptr(out), _stream()),
+               "g6d_linear_gemv")
+    return out

@@ -1,0 +1,181 @@
+/*
+ * gen6d_hip.h — C ABI of libgen6d_hip.so: the hand-written gfx950 kernels behind the Gen6D inference hot path
+ * (detector score-map correlation, selector viewpoint similarity, refiner feature-volume pose update).
+ *
+ * Conventions:
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch tensors' data_ptr()); nothing is allocated,
+ *     freed or synchronised inside; every call enqueues on the given hipStream_t and returns immediately;
+ *   - return value: 0 on success, a negative G6D_E* code otherwise (never throws);
+ *   - activations are CHANNELS-LAST fp32: [N][D][H][W][C] with an explicit channel stride `ld` (>= C, multiple of 4),
+ *     so a layer can read from / write into a channel slice of a wider (concatenated) buffer;
+ *   - conv weights are [Cout][taps][Cin] (the reference's [Cout][Cin][kd][kh][kw] permuted once at load time).
+ *
+ * The reference has no FFI: each entry point replaces a PyTorch op sequence of the reference, cited per function
+ * as file:line relative to liuyuan-pal/Gen6D.  INTEGRATION.md shows the ctypes binding a maintainer would add.
+ */
+#ifndef GEN6D_HIP_H
+#define GEN6D_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* g6d_stream_t; /* hipStream_t */
+
+enum {
+  G6D_OK = 0,
+  G6D_EINVAL = -1,   /* bad shape / null pointer / misaligned pointer */
+  G6D_ENOSPC = -2,   /* workspace too small */
+  G6D_ELAUNCH = -3   /* hipLaunch error (hipGetLastError != success) */
+};
+
+int g6d_abi_version(void);
+/* last HIP error string of this thread ("" if none) */
+const char* g6d_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Generic implicit-GEMM convolution on fp32 MFMA (v_mfma_f32_32x32x2_f32), 1-D/2-D/3-D, stride, zero padding.
+ * Replaces every dense conv / linear contraction of the hot path:
+ *   detector  F.conv2d(que_x, ref_x) correlation            network/detector.py:222-224
+ *             score/scale/offset heads                        network/detector.py:164-184,248-255
+ *   selector  corr_conv_list (1,3,3) Conv3d stacks            network/selector.py:27-69,187
+ *             corr_feats_conv, score_process, mlps, heads     network/selector.py:71-104,197-214
+ *   refiner   RefineFeatureNet convs                          network/refiner.py:24-51
+ *             RefineVolumeEncodingNet 3x3x3 convs             network/refiner.py:88-143
+ * Fused into the operand loader: optional elementwise multiplier (selector query x reference product,
+ * selector.py:183-186, never materialised), optional per-channel affine (the preceding InstanceNorm,
+ * applied as x*scale+shift; padding stays exactly zero as in the reference where padding follows the norm) and ReLU.
+ * Fused into the epilogue: bias, activation, per-(group,channel) sum / sum-of-squares for the FOLLOWING
+ * InstanceNorm (fp64 accumulators).
+ *   out[m][co] = act( bias[co] + sum_{tap,ci} X(m,tap,ci) * weight[co][tap][ci] )
+ *   X = relu?( (in * mul?) * in_scale + in_shift ), 0 outside the input
+ * ---------------------------------------------------------------------------------------------------------------- */
+typedef struct G6dConv {
+  const float* in;        /* [N][Di][Hi][Wi][ld_in] */
+  const float* mul;       /* optional [Hi][Wi][Cin] (dense), broadcast over N and Di; NULL = none */
+  const float* in_scale;  /* optional [in_affine_groups][Cin]; NULL = none */
+  const float* in_shift;  /* same shape as in_scale */
+  const float* weight;    /* [Cout][kd*kh*kw][Cin] */
+  const float* bias;      /* [Cout] or NULL */
+  float* out;             /* [N*Do*Ho*Wo][ld_out] */
+  double* stats;          /* optional [stat_groups][Cout][2] (sum, sumsq), caller-zeroed; NULL = none */
+  float* workspace;       /* split-K partial sums; may be NULL if workspace_bytes == 0 */
+  size_t workspace_bytes;
+  int32_t N, Di, Hi, Wi, Cin, ld_in;
+  int32_t Do, Ho, Wo, Cout, ld_out;
+  int32_t kd, kh, kw;
+  int32_t sd, sh, sw;
+  int32_t pd, ph, pw;
+  int32_t in_relu;              /* apply ReLU after the input affine */
+  int32_t in_affine_per_n;      /* 0: one affine for all N; 1: affine indexed by the batch index n */
+  int32_t out_act;              /* 0 none, 1 ReLU, 2 LeakyReLU(0.1) */
+  int32_t stat_rows_per_group;  /* output rows per statistics group (0 = all rows in one group) */
+  int32_t split_k;              /* 0 = choose automatically; 1 = never split; >1 = force */
+} G6dConv;
+
+int g6d_conv_igemm(const G6dConv* desc, g6d_stream_t stream);
+
+/* InstanceNorm finalisation: stats[g][c] = (sum, sumsq) over `count` elements ->
+ * scale = 1/sqrt(var+eps), shift = -mean*scale (biased variance; torch InstanceNorm{1,2,3}d, eps 1e-5,
+ * network/selector.py:28-77, network/refiner.py:27-50,93-133). n = groups*channels. */
+int g6d_stats_finalize(const double* stats, int n, double count, double eps, float* scale, float* shift, g6d_stream_t stream);
+
+/* y = pool2x2?( relu?( x*scale[c] + shift[c] ) ) on [N][H][W][C] channels-last rows (D folded into N).
+ * pool: 0 none, 1 = 2x2 max (MaxPool3d (1,2,2), network/selector.py:34,41,56), 2 = full-window mean over HxW
+ * (AvgPool3d (1,4,4), selector.py:76).  scale/shift may be NULL (identity); affine_per_n selects [N][C] tables. */
+int g6d_affine_act_pool(const float* in, int ld_in, const float* scale, const float* shift, int affine_per_n, int relu,
+                        int pool, int N, int H, int W, int C, float* out, int ld_out, g6d_stream_t stream);
+
+/* Bilinear up-sampling by an integer factor (align_corners=False, F.interpolate in network/refiner.py:74-75) of
+ * relu?(x*scale+shift) on [N][H][W][C] -> [N][H*f][W*f][C] written with channel stride ld_out. */
+int g6d_upsample_bilinear(const float* in, int ld_in, const float* scale, const float* shift, int affine_per_n,
+                          int N, int H, int W, int C, int factor, float* out, int ld_out, g6d_stream_t stream);
+
+/* NCHW (backbone output) -> channels-last, optionally L2-normalised over C (F.normalize eps 1e-12,
+ * network/selector.py:118, network/refiner.py:69-71). out [N][H][W][ld_out]. */
+int g6d_nchw_to_nhwc(const float* in, int N, int C, int H, int W, int l2norm, float* out, int ld_out, g6d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Selector similarity (network/selector.py:183-186,192-195 and the InstanceNorm3d(512) at :28,49,63).  The
+ * query x reference product [C][D][HW] is never materialised.
+ *   que   [HW][C]            L2-normalised query features (channels-last)
+ *   refs  [D][HW][C]         reference cache, D = rfn*an with d = r*an + a
+ * g6d_selector_ref_sums   (load time)  r1[hw][c] = sum_d refs, r2[hw][c] = sum_d refs^2      (fp64)
+ * g6d_selector_prod_affine(query time) InstanceNorm affine of the product from r1/r2:
+ *                                      mean_c = sum_hw q r1 / (D*HW), E[x^2]_c = sum_hw q^2 r2 / (D*HW)
+ *                                      scale = 1/sqrt(var+eps), shift = -mean*scale           (exact algebra)
+ * g6d_selector_scan       (query time) one coalesced streaming pass over refs, wavefront shuffle reductions:
+ *                                      score_map[d][hw] = sum_c que*ref ;  vps[d] = sum_hw S^2 / max_hw S
+ * ---------------------------------------------------------------------------------------------------------------- */
+int g6d_selector_ref_sums(const float* refs, int D, int HW, int C, double* r1, double* r2, g6d_stream_t stream);
+int g6d_selector_prod_affine(const float* que, const double* r1, const double* r2, int D, int HW, int C, double eps,
+                             float* scale, float* shift, g6d_stream_t stream);
+int g6d_selector_scan(const float* que, const float* refs, int D, int HW, int C, float* score_map, float* vps,
+                      g6d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Refiner feature-volume construction (network/refiner.py:183-206,208-247; network/operator.py:4-17), fused:
+ * rotate the sn^3 grid by R_in, project every voxel into each reference view and the query view, bilinear-sample
+ * (zeros padding, align_corners=False, coordinates normalised with the INPUT IMAGE size h_in x w_in), and reduce over
+ * the references in registers (mean, unbiased std).  All pointers are device pointers.
+ *   feats     [rfn+1][fh][fw][C]  channels-last feature maps; view rfn is the query
+ *   projs     [rfn+1][12]         row-major 3x4 K*[R|t] per view (query last)
+ *   rot_in    [9]                 row-major R_in (grid row-vector v is mapped to v @ R_in)
+ *   lin       [sn]                torch.linspace(-1,1,sn)
+ *   mean_in   [sn^3][2C]          cat[mean over refs, query sample]   (input of mean_embed)
+ *   std       [sn^3][C]           1 <= rfn <= 8
+ * ---------------------------------------------------------------------------------------------------------------- */
+int g6d_refiner_volume(const float* feats, const float* projs, const float* rot_in, const float* lin, int rfn, int fh,
+                       int fw, int C, int h_in, int w_in, int sn, float* mean_in, float* std, g6d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Detector score assembly (network/detector.py:225-229,243-245,207-216): for one detection scale, take the three raw
+ * correlation maps (level l at 1/(8*2^l) resolution, channels-last [h_l*w_l][rfn]), nearest-upsample levels 1,2 to
+ * level-0 size, normalise ((x-mu_l)/sigma_l), clip to +-clip, bilinear-resize (align_corners=False) to (hs,ws) and
+ * write channels [3*scale_idx .. 3*scale_idx+2] of stacked [hs*ws][rfn][nch].
+ * ---------------------------------------------------------------------------------------------------------------- */
+int g6d_detector_assemble(const float* s0, const float* s1, const float* s2, int hc, int wc, int rfn,
+                          const float* mu_sigma /* HOST pointer: {mu0,sigma0,mu1,sigma1,mu2,sigma2} */, float clip, int hs, int ws,
+                          int scale_idx, int nch, float* stacked, g6d_stream_t stream);
+
+/* score_conv + max over references (network/detector.py:159-163,246-247): per (pixel, ref) MLP nch->64 (ReLU) ->64,
+ * then max over rfn.  w0 [64][nch], b0[64], w1[64][64], b1[64]; out [P][64]. */
+int g6d_detector_score_mlp_max(const float* stacked, int P, int rfn, int nch, const float* w0, const float* b0,
+                               const float* w1, const float* b1, float* out, g6d_stream_t stream);
+
+/* arg-max + decode (network/detector.py:84-121): scores [hs*ws], offset [hs*ws][2], scale [hs*ws] (channels-last);
+ * result[0..1] = position (x,y) px, result[2] = 2^scale, result[3..4] = (x,y) cell of the peak (as float). */
+int g6d_detector_decode(const float* scores, int ld_s, const float* offset, int ld_o, const float* scale, int ld_c,
+                        int hs, int ws, int pool_ratio, float* result, g6d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Selector tail helpers (network/selector.py:201-214, network/attention.py:4-17,50-68).
+ * ---------------------------------------------------------------------------------------------------------------- */
+/* InstanceNorm2d(3) of vps [3][D] over D, written to channels c_off..c_off+2 of feats [D][ld] (selector.py:201-202) */
+int g6d_vps_norm(const float* vps, int D, float* feats, int ld, int c_off, g6d_stream_t stream);
+/* x[r][c] = max_a in[(r*an+a)][c] + embed[r][c]   (selector.py:204-205) */
+int g6d_max_an_add(const float* in, int ld_in, int rfn, int an, int C, const float* embed, float* out, int ld_out,
+                   g6d_stream_t stream);
+/* multi-head attention over n tokens with the reference's head split c -> (d=c/heads, head=c%heads), scale
+ * 1/sqrt(C/heads): q,k,v [n][ld] -> out [n][ld_out]  (attention.py:4-17,60-64) */
+int g6d_attention(const float* q, const float* k, const float* v, int ld, int n, int C, int heads, float* out,
+                  int ld_out, g6d_stream_t stream);
+/* LayerNorm over C per token with affine (attention.py:19-26): out may alias in */
+int g6d_layernorm(const float* in, int ld_in, int n, int C, const float* gamma, const float* beta, float eps,
+                  float* out, int ld_out, g6d_stream_t stream);
+/* out = relu?(x*scale+shift) (+ residual) elementwise on [n][C] rows (selector.py:209) */
+int g6d_affine_act_add(const float* in, int ld_in, const float* scale, const float* shift, int relu,
+                       const float* residual, int ld_res, int n, int C, float* out, int ld_out, g6d_stream_t stream);
+
+/* Small-batch linear layer, weight-streaming GEMV (network/refiner.py:153-166): out[b][o] = act(W[o].x[b] + bias[o]);
+ * W [O][K] row-major, x [B][K], B <= 8; act as G6dConv.out_act. */
+int g6d_linear_gemv(const float* x, int B, int K, const float* W, const float* bias, int O, int act, float* out,
+                    g6d_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GEN6D_HIP_H */

@@ -1,0 +1,203 @@
+"""Plain-PyTorch fp32 references of every op in gen6d_amd/ops.py (same signatures, same in-place output contract).
+
+Test infrastructure only.  Two uses:
+  * `-m gpu` tests compare each HIP kernel with its reference here on the same inputs;
+  * `-m "not gpu"` tests monkeypatch gen6d_amd.ops with this module (see `patch_ops`) so the HOST orchestration of
+    gen6d_amd/network/* (layouts, weight repacking, InstanceNorm fusion, buffer slicing) is validated against the CPU
+    oracle without a GPU.  The product never imports this file.
+"""
+import torch
+import torch.nn.functional as F
+
+
+def workspace(device):
+    return None
+
+
+def _act(v, act):
+    if act == 1: return F.relu(v)
+    if act == 2: return F.leaky_relu(v, 0.1)
+    return v
+
+
+def conv(x, w, bias, out, ksize=(1, 1, 1), stride=(1, 1, 1), pad=(0, 0, 0), mul=None, in_scale=None, in_shift=None,
+         in_relu=False, per_n=False, out_act=0, stats=None, rows_per_group=0, split_k=0):
+    N, Di, Hi, Wi, Cin = x.shape
+    Cout = w.shape[0]
+    v = x
+    if mul is not None: v = v * mul[None, None]
+    if in_scale is not None:
+        if per_n: v = v * in_scale.view(N, 1, 1, 1, Cin) + in_shift.view(N, 1, 1, 1, Cin)
+        else: v = v * in_scale.view(1, 1, 1, 1, Cin) + in_shift.view(1, 1, 1, 1, Cin)
+    if in_relu: v = F.relu(v)
+    w5 = w.view(Cout, ksize[0], ksize[1], ksize[2], Cin).permute(0, 4, 1, 2, 3)
+    y = F.conv3d(v.permute(0, 4, 1, 2, 3), w5, bias, stride=stride, padding=pad).permute(0, 2, 3, 4, 1)
+    y = _act(y, out_act)
+    out.copy_(y)
+    if stats is not None:
+        M = y.numel() // Cout
+        rpg = rows_per_group if rows_per_group > 0 else M
+        g = y.reshape(M // rpg, rpg, Cout).double()
+        stats[:, :, 0] += g.sum(1)
+        stats[:, :, 1] += (g * g).sum(1)
+    return out
+
+
+def new_stats(groups, channels, device):
+    return torch.zeros((groups, channels, 2), dtype=torch.float64, device=device)
+
+
+def stats_finalize(stats, count, eps=1e-5):
+    mean = stats[..., 0] / count
+    var = (stats[..., 1] / count - mean * mean).clamp_min(0)
+    rs = 1.0 / torch.sqrt(var + eps)
+    return rs.float(), (-mean * rs).float()
+
+
+def _aff(x, scale, shift, per_n, relu):
+    N, C = x.shape[0], x.shape[-1]
+    if scale is not None:
+        shp = (N, 1, 1, 1, C) if per_n else (1, 1, 1, 1, C)
+        x = x * scale.reshape(shp) + shift.reshape(shp)
+    return F.relu(x) if relu else x
+
+
+def affine_act_pool(x, out, scale=None, shift=None, per_n=False, relu=False, pool=0):
+    N, D, H, W, C = x.shape
+    if per_n and D != 1: raise ValueError
+    v = _aff(x, scale, shift, per_n, relu)
+    if pool == 1:
+        v = F.max_pool3d(v.permute(0, 4, 1, 2, 3), (1, 2, 2), (1, 2, 2)).permute(0, 2, 3, 4, 1)
+    elif pool == 2:
+        v = v.mean((2, 3), keepdim=True)
+    out.copy_(v)
+    return out
+
+
+def upsample_bilinear(x, out, factor, scale=None, shift=None, per_n=False):
+    N, D, H, W, C = x.shape
+    v = _aff(x, scale, shift, per_n, False).reshape(N * D, H, W, C).permute(0, 3, 1, 2)
+    v = F.interpolate(v, scale_factor=factor, mode="bilinear", align_corners=False)
+    out.copy_(v.permute(0, 2, 3, 1).reshape(N, D, H * factor, W * factor, C))
+    return out
+
+
+def nchw_to_nhwc(x, out, l2norm):
+    v = F.normalize(x, dim=1) if l2norm else x
+    out.copy_(v.permute(0, 2, 3, 1).unsqueeze(1))
+    return out
+
+
+def selector_ref_sums(refs):
+    r = refs.double()
+    return r.sum(0), (r * r).sum(0)
+
+
+def selector_prod_affine(que, r1, r2, D, eps=1e-5):
+    n = D * que.shape[0]
+    q = que.double()
+    mean = (q * r1).sum(0) / n
+    var = ((q * q * r2).sum(0) / n - mean * mean).clamp_min(0)
+    rs = 1.0 / torch.sqrt(var + eps)
+    return rs.float()[None], (-mean * rs).float()[None]
+
+
+def selector_scan(que, refs):
+    smap = (refs * que[None]).sum(2)
+    vps = (smap * (smap / smap.max(1, keepdim=True)[0])).sum(1)
+    return smap, vps
+
+
+def refiner_volume(feats, projs, rot_in, lin, h_in, w_in, mean_in, std):
+    V, fh, fw, C = feats.shape
+    sn = lin.numel()
+    g = torch.stack(torch.meshgrid(lin, lin, lin, indexing="ij"), -1).reshape(1, sn ** 3, 3) @ rot_in
+    X = g @ projs[:, :, :3].permute(0, 2, 1) + projs[:, :, 3:].permute(0, 2, 1)      # V,n,3
+    z = X[..., 2:].clone(); z[z < 1e-4] = 1e-4
+    uv = X[..., :2] / z
+    gx = ((uv[..., 0] + 0.5) / w_in - 0.5) * 2
+    gy = ((uv[..., 1] + 0.5) / h_in - 0.5) * 2
+    grid = torch.stack([gx, gy], -1).reshape(V, 1, -1, 2)
+    vol = F.grid_sample(feats.permute(0, 3, 1, 2), grid, mode="bilinear", padding_mode="zeros", align_corners=False)[:, :, 0]
+    ref = vol[:-1]
+    mean_in[:, :C] = ref.mean(0).T
+    mean_in[:, C:] = vol[-1].T
+    std.copy_(ref.std(0).T if V > 2 else torch.zeros_like(std))
+    return mean_in, std
+
+
+def detector_assemble(s0, s1, s2, hc, wc, mu_sigma, clip, hs, ws, scale_idx, stacked):
+    rfn = s0.shape[1]
+    maps = []
+    for l, s in enumerate((s0, s1, s2)):
+        m = s.reshape(hc >> l, wc >> l, rfn).permute(2, 0, 1)[None]
+        if l: m = F.interpolate(m, scale_factor=2 ** l)
+        maps.append(torch.clip((m - mu_sigma[l][0]) / mu_sigma[l][1], -clip, clip))
+    m = torch.cat(maps, 0)                                           # 3,rfn,hc,wc
+    m = F.interpolate(m, size=(hs, ws), mode="bilinear", align_corners=False)
+    stacked[:, :, 3 * scale_idx:3 * scale_idx + 3] = m.permute(2, 3, 1, 0).reshape(hs * ws, rfn, 3)
+    return stacked
+
+
+def detector_score_mlp_max(stacked, w0, b0, w1, b1):
+    h = F.relu(stacked @ w0.T + b0)
+    return (h @ w1.T + b1).max(1)[0]
+
+
+def detector_decode(scores, offset, scale, hs, ws, pool_ratio):
+    idx = int(torch.argmax(scores[:, 0]))
+    x, y = idx % ws, idx // ws
+    res = torch.empty(5, dtype=torch.float32, device=scores.device)
+    res[0] = (x + offset[idx, 0] + 0.5) * pool_ratio - 0.5
+    res[1] = (y + offset[idx, 1] + 0.5) * pool_ratio - 0.5
+    res[2] = 2 ** scale[idx, 0]
+    res[3], res[4] = x, y
+    return res
+
+
+def vps_norm(vps, feats, c_off):
+    feats[:, c_off:c_off + 3] = F.instance_norm(vps[None], eps=1e-5)[0].T
+    return feats
+
+
+def max_an_add(x, rfn, an, embed, out):
+    out.copy_(x.reshape(rfn, an, -1).max(1)[0] + embed)
+    return out
+
+
+def attention(q, k, v, heads, out):
+    n, C = q.shape
+    dh = C // heads
+    qh, kh, vh = (t.reshape(n, dh, heads) for t in (q, k, v))
+    s = torch.einsum("ndh,mdh->hnm", qh, kh) / dh ** 0.5
+    o = torch.einsum("hnm,mdh->ndh", F.softmax(s, -1), vh)
+    out.copy_(o.reshape(n, C))
+    return out
+
+
+def layernorm(x, gamma, beta, out, eps=1e-5):
+    out.copy_(F.layer_norm(x, (x.shape[1],), gamma, beta, eps))
+    return out
+
+
+def affine_act_add(x, out, scale=None, shift=None, relu=False, residual=None):
+    v = x
+    if scale is not None: v = v * scale.reshape(1, -1) + shift.reshape(1, -1)
+    if relu: v = F.relu(v)
+    if residual is not None: v = v + residual
+    out.copy_(v)
+    return out
+
+
+def linear_gemv(x, W, bias, act=0):
+    return _act(F.linear(x, W, bias), act)
+
+
+def patch_ops(monkeypatch):
+    """Route gen6d_amd.ops.* to the references above (CPU host-logic tests only)."""
+    import sys
+    from gen6d_amd import ops
+    me = sys.modules[__name__]
+    for name in dir(ops):
+        if not name.startswith("_") and callable(getattr(ops, name)) and hasattr(me, name):
+            monkeypatch.setattr(ops, name, getattr(me, name))

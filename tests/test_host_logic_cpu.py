@@ -1,0 +1,69 @@
+"""Host orchestration of gen6d_amd/network/* checked on CPU: gen6d_amd.ops is monkeypatched with the per-op PyTorch
+references (tests/ref_ops.py), so layouts, weight repacking, InstanceNorm fusion, buffer slicing and the commuted
+pooling are validated against the CPU oracle and the reference-generated golden vectors without a GPU.  The HIP
+kernels themselves are compared with the same per-op references in the `-m gpu` tests."""
+import numpy as np
+import pytest
+import torch
+
+import ref_ops
+from gen6d_amd import specs, synth
+from gen6d_amd.network import name2network
+from oracle import gen6d_oracle as O
+
+
+@pytest.fixture(autouse=True)
+def _patch(monkeypatch):
+    ref_ops.patch_ops(monkeypatch)
+
+
+def test_state_dict_contract():
+    for kind, n in (("detector", 78), ("selector", 132), ("refiner", 104)):
+        net = name2network[kind]({})
+        sd = synth.synth_state_dict(kind)
+        assert len(sd) == n                                   # SURVEY.md App. C key counts
+        missing, unexpected = net.load_state_dict(sd, strict=True)
+        assert not missing and not unexpected
+        assert {k: tuple(v.shape) for k, v in net.state_dict().items()} == {k: tuple(v.shape) for k, v in sd.items()}
+
+
+def test_detector_host_path(golden):
+    g = golden("det_small")
+    net = name2network["detector"]({"name": "t"}).eval()
+    net.load_state_dict(synth.synth_state_dict("detector"))
+    case = synth.detector_case(int(g["rfn"]), int(g["hq"]), int(g["wq"]))
+    with torch.no_grad():
+        out = net({"ref_imgs_info": {"imgs": case["ref_imgs"]}, "que_imgs_info": {"imgs": case["que_imgs"]}})
+    for k in ("scores", "select_pr_offset", "select_pr_scale"):
+        np.testing.assert_allclose(out[k].numpy(), g[k], rtol=1e-3, atol=1e-3 * np.abs(g[k]).max())
+    assert np.array_equal(out["que_select_id"].numpy(), g["que_select_id"])
+    np.testing.assert_allclose(out["positions"].numpy(), g["positions"], rtol=1e-3, atol=5e-2)
+    np.testing.assert_allclose(out["scales"].numpy(), g["scales"], rtol=2e-3)
+
+
+def test_selector_host_path(golden):
+    g = golden("sel_small")
+    an = int(g["an"])
+    net = name2network["selector"]({"name": "t", "selector_angle_num": an}).eval()
+    net.load_state_dict(synth.synth_state_dict("selector", an=an))
+    case = synth.selector_case(int(g["rfn"]), an)
+    with torch.no_grad():
+        out = net({"ref_imgs": case["ref_imgs"], "ref_imgs_info": {"poses": case["ref_poses"]},
+                   "object_center": case["object_center"], "object_vert": case["object_vert"],
+                   "que_imgs_info": {"imgs": case["que_imgs"]}, "eval": True})
+    np.testing.assert_allclose(out["ref_vp_logits"].numpy(), g["logits"], atol=2e-3)
+    np.testing.assert_allclose(out["angles_pr"].numpy(), g["angles"], atol=2e-3)
+    assert np.array_equal(out["ref_vp_logits"].argmax(1).numpy(), g["logits"].argmax(1))
+
+
+def test_refiner_host_path(golden):
+    g = golden("ref_step")
+    net = name2network["refiner"]({"name": "t"}).eval()
+    net.load_state_dict(synth.synth_state_dict("refiner"))
+    c = synth.refiner_case()
+    with torch.no_grad():
+        out = net({"que_imgs_info": {"imgs": c["que_imgs"], "Ks_in": c["Ks_in"], "poses_in": c["poses_in"]},
+                   "ref_imgs_info": {"imgs": c["ref_imgs"], "Ks": c["ref_Ks"], "poses": c["ref_poses"]},
+                   "inference": True})
+    for k in ("rotation", "offset", "scale"):
+        np.testing.assert_allclose(out[k].numpy(), g[k], rtol=1e-3, atol=1e-3)
