@@ -1,0 +1,120 @@
+#!/usr/bin/env python
+"""bench.py — query images/s of the Gen6D tensor hot path (detect + select + 3x refine, 64 reference views) on
+N MI355X, one process per GPU.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = one query through the whole path: detector on a synthetic 480x640 frame against 32 reference views,
+selector on a synthetic 128x128 crop against 64 views x 5 in-plane rotations, 3 refiner steps with 6 reference
+crops (weights: seeded synthetic state_dicts; no checkpoint/dataset exists offline).  Queries are independent, so the
+path shards by query: every rank holds a replica of the reference state and runs its own K steps (weak scaling, no
+collective on the data path); value = N*K / max-over-ranks time.
+
+Extra objects on the JSON line:
+  roofline     — the dominant kernel (g6d_conv_igemm, fp32 MFMA): algorithmic FLOPs of every launch in the timed region
+                 divided by its HIP-event duration (events recorded on the launch stream), against 157.3 TFLOP/s.
+  cpu_baseline — the CPU oracle (a port of the reference's PyTorch-CPU path) timed on this host for one query.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--sel-refs", type=int, default=64)
+    ap.add_argument("--det-refs", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from gen6d_amd import lib, ops, parallel, synth
+    from gen6d_amd.pipeline import TensorPipeline
+    lib.load()                                           # no HIP library -> hard failure
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    rank, world, local = parallel.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    pipe = TensorPipeline(dev, sel_rfn=args.sel_refs, det_rfn=args.det_refs)
+    pipe.build()
+    n_q = args.steps + args.warmup
+    fulls = synth.imgs_to_tensor(synth.synth_images(4, 480, 640, seed=100 + rank)).to(dev)
+    crops = synth.imgs_to_tensor(synth.synth_images(4, 128, 128, seed=200 + rank)).to(dev)
+
+    def step(i):
+        j = i % 4
+        return pipe.query(fulls[j:j + 1], crops[j:j + 1])
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    parallel.barrier()
+    torch.cuda.synchronize()
+    ops.PROFILE = []
+    t0 = time.perf_counter()
+    rows = [step(args.warmup + i) for i in range(args.steps)]
+    torch.cuda.synchronize()
+    parallel.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof, ops.PROFILE = ops.PROFILE, None
+    dt = parallel.max_over_ranks(dt, dev)
+    rows = parallel.gather_rows(torch.cat(rows, 0), world * args.steps) if world > 1 else torch.cat(rows, 0)
+
+    if rank != 0:
+        return
+    flops = sum(p[0] for p in prof)
+    ms = sum(p[1].elapsed_time(p[2]) for p in prof)
+    n_launch = max(len(prof), 1)
+    achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    result = {
+        "metric": "query images/sec (detect+select+3x refine), 64 ref views",
+        "value": world * args.steps / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"full tensor pipeline: detector 480x640 query vs {args.det_refs} refs (4 scales) + selector "
+                               f"128x128 crop vs {args.sel_refs} refs x 5 rotations + 3 refiner steps (6 refs, 32^3 volume); "
+                               "seeded synthetic weights", "sharding": f"query-replicas x{world}"},
+        "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (fp32 v_mfma_f32_32x32x2_f32, incl. split-K reduce)",
+                     "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                     "launches_per_step": n_launch / args.steps, "gflop_per_launch": flops / n_launch / 1e9,
+                     "avg_launch_ms": ms / n_launch, "conv_ms_per_step": ms / args.steps},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import pipeline_oracle as PO
+        cores = torch.get_num_threads()
+        st = PO.build_state(pipe.state_dicts, pipe.det_refs, pipe.sel_case)
+        iter_poses = [p.cpu() for p in pipe.iter_poses]
+        t1 = time.perf_counter()
+        row, _ = PO.query(pipe.state_dicts, st, pipe.ref_case, iter_poses, fulls[0:1].cpu(), crops[0:1].cpu())
+        cpu_dt = time.perf_counter() - t1
+        result["cpu_baseline"] = {"value": 1.0 / cpu_dt, "unit": "images/s", "cores": cores, "kind": "port",
+                                  "sample": "1 query of the same workload through oracle/ (torch CPU fp32), reference state prebuilt",
+                                  "seconds": cpu_dt}
+        got = rows[0].cpu()     # step `warmup` used image (warmup % 4); only compare when it is image 0
+        if args.warmup % 4 == 0:
+            result["parity_vs_cpu"] = {"ref_idx_equal": bool(int(got[3]) == int(row[0, 3])),
+                                       "max_abs_diff_row": float((got - row[0]).abs().max())}
+    print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

@@ -17,6 +17,9 @@ from . import lib as _lib
 
 _WS = {}
 WORKSPACE_BYTES = 256 << 20
+# When set to a list, conv() brackets every g6d_conv_igemm launch with HIP events recorded on the launch stream and
+# appends (algorithmic flops, start, end); bench.py turns this into the roofline entry.
+PROFILE = None
 
 
 def _stream():
@@ -84,6 +87,13 @@ def conv(x, w, bias, out, ksize=(1, 1, 1), stride=(1, 1, 1), pad=(0, 0, 0), mul=
         kd=kd, kh=kh, kw=kw, sd=stride[0], sh=stride[1], sw=stride[2], pd=pad[0], ph=pad[1], pw=pad[2],
         in_relu=int(in_relu), in_affine_per_n=int(per_n), out_act=int(out_act),
         stat_rows_per_group=int(rows_per_group), split_k=int(split_k))
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.check(_lib.load().g6d_conv_igemm(C.byref(d), _stream()), "g6d_conv_igemm")
+        e1.record()
+        PROFILE.append((2.0 * N * Do * Ho * Wo * Cout * kd * kh * kw * Cin, e0, e1))
+        return out
     _lib.check(_lib.load().g6d_conv_igemm(C.byref(d), _stream()), "g6d_conv_igemm")
     return out
 

@@ -1,0 +1,62 @@
+"""Multi-GPU plumbing: queries are independent given the per-object reference state, so the path
+shards by QUERY — every rank holds a replica of the reference state (feature caches 220 MB + weights 0.3 GB, trivial
+next to 288 GB of HBM), takes a contiguous slice of the query stream, and no collective sits on the data path.
+The only exchanges are a barrier / MAX-reduce for timing and an all-gather of the KB-sized per-query results.
+One process per GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU tests)."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise from RANK / WORLD_SIZE / MASTER_* (torch.distributed.run). Returns (rank, world, local_rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous, balanced [begin, end) slice of n_items for this rank (first n_items % world ranks get one more)."""
+    base, extra = divmod(n_items, world)
+    begin = rank * base + min(rank, extra)
+    return begin, begin + base + (1 if rank < extra else 0)
+
+
+def barrier():
+    if dist.is_initialized():
+        dist.barrier()
+
+
+def max_over_ranks(value, device="cpu"):
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    if dist.is_initialized():
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_rows(local_rows, n_items):
+    """All-gather per-query result rows [n_local, F] into [n_items, F] in global query order (ragged shards padded)."""
+    if not dist.is_initialized():
+        return local_rows
+    world, rank = dist.get_world_size(), dist.get_rank()
+    width = local_rows.shape[1]
+    cap = (n_items + world - 1) // world
+    pad = torch.zeros((cap, width), dtype=local_rows.dtype, device=local_rows.device)
+    pad[:local_rows.shape[0]] = local_rows
+    bufs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad)
+    out = []
+    for r in range(world):
+        b, e = shard_range(n_items, r, world)
+        out.append(bufs[r][:e - b])
+    return torch.cat(out, 0)

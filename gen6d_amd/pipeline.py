@@ -1,0 +1,54 @@
+"""Tensor-level Gen6D pipeline: detect -> select -> refine x N on device tensors (the per-query hot path of
+reference estimator.py:173-216 without the host-side cv2 warps, which are SURVEY.md §8(f) "next" rows).
+Used by bench.py, __graft_entry__.smoke() and the GPU tests; mirrors `Gen6DEstimator`'s stage order and defaults
+(det 32 refs, sel 64 refs x 5 rotations, 6 refiner views, refine_iter 3)."""
+import numpy as np
+import torch
+
+from . import synth
+from .network import name2network
+
+
+class TensorPipeline:
+    def __init__(self, device, sel_rfn=64, det_rfn=32, an=5, refine_iter=3, seed=1234):
+        self.device = torch.device(device)
+        self.refine_iter = refine_iter
+        self.cfg = dict(sel_rfn=sel_rfn, det_rfn=det_rfn, an=an, refine_iter=refine_iter)
+        self.detector = name2network["detector"]({"name": "detector_synth"})
+        self.selector = name2network["selector"]({"name": "selector_synth", "selector_angle_num": an})
+        self.refiner = name2network["refiner"]({"name": "refiner_synth"})
+        self.state_dicts = {k: synth.synth_state_dict(k, seed, an) for k in ("detector", "selector", "refiner")}
+        for k, net in (("detector", self.detector), ("selector", self.selector), ("refiner", self.refiner)):
+            net.load_state_dict(self.state_dicts[k])
+            net.to(self.device).eval()
+
+    def build(self, seed=1):
+        """Reference state from synthetic views (Gen6DEstimator.build, reference estimator.py:139-171)."""
+        c = self.cfg
+        self.sel_case = synth.selector_case(c["sel_rfn"], c["an"], seed)
+        det_refs = self.sel_case["ref_imgs"][c["an"] // 2, :min(c["det_rfn"], c["sel_rfn"])]      # un-rotated copies
+        self.det_refs = det_refs.contiguous()
+        d = self.device
+        with torch.no_grad():
+            self.detector.load_impl(self.det_refs.to(d))
+            self.selector.extract_ref_feats(self.sel_case["ref_imgs"].to(d), self.sel_case["ref_poses"].to(d),
+                                            self.sel_case["object_center"].to(d), self.sel_case["object_vert"].to(d))
+        self.ref_case = synth.refiner_case()
+        self.ref_dev = {k: v.to(d) for k, v in self.ref_case.items()}
+        # a slightly different input pose per refinement iteration (no cross-iteration caching possible)
+        self.iter_poses = [torch.from_numpy(synth.perturb_pose(self.ref_case["poses_in"][0].numpy(), 2.0 * i, 0.01 * i))[None].to(d)
+                           for i in range(self.refine_iter)]
+
+    def query(self, que_full, que_crop):
+        """que_full [1,3,H,W] (detector input), que_crop [1,3,128,128] (selector/refiner input), device tensors.
+        Returns a [1,12] row: position(2), scale, ref_idx, angle, quaternion(4), offset(2), log2-scale."""
+        r = self.ref_dev
+        with torch.no_grad():
+            det = self.detector.detect_impl(que_full)
+            logits, angles = self.selector.compute_view_point_feats(que_crop)
+            idx = torch.argmax(logits, 1)
+            ang = angles[torch.arange(1, device=idx.device), idx]
+            for it in range(self.refine_iter):
+                rot, off, scl = self.refiner._step(que_crop, r["Ks_in"][0], self.iter_poses[it][0], r["ref_imgs"][0],
+                                                   r["ref_Ks"][0], r["ref_poses"][0])
+        return torch.cat([det["positions"], det["scales"][:, None], idx[:, None].float(), ang[:, None], rot, off, scl], 1)

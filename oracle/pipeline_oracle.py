@@ -1,0 +1,29 @@
+"""CPU ORACLE (test infrastructure): the per-query tensor pipeline detect -> select -> refine x N restated with
+oracle/gen6d_oracle.py, mirroring gen6d_amd.pipeline.TensorPipeline on the same synthetic state.  Used only by
+tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg."""
+import torch
+
+from . import gen6d_oracle as O
+
+
+def build_state(state_dicts, det_refs, sel_case):
+    """One-time reference state (not part of the per-query time): detector filters, selector cache + embedding."""
+    with torch.no_grad():
+        det_feats = O.detector_ref_feats(state_dicts["detector"], det_refs)
+        cache, embed = O.selector_ref_state(state_dicts["selector"], sel_case["ref_imgs"], sel_case["ref_poses"],
+                                            sel_case["object_center"], sel_case["object_vert"])
+    return {"det_feats": det_feats, "sel_cache": cache, "sel_embed": embed}
+
+
+def query(state_dicts, state, ref_case, iter_poses, que_full, que_crop):
+    """One query: returns the same [1,12] row as TensorPipeline.query plus the selector logits."""
+    with torch.no_grad():
+        out = O.detector_detect(state_dicts["detector"], que_full, state["det_feats"])
+        pos, scl = O.detector_parse(out)
+        logits, angles = O.selector_forward(state_dicts["selector"], que_crop, state["sel_cache"], state["sel_embed"])
+        idx, ang = O.selector_select(logits, angles)
+        for p in iter_poses:
+            o = O.refiner_forward(state_dicts["refiner"], que_crop, ref_case["Ks_in"], p, ref_case["ref_imgs"],
+                                  ref_case["ref_Ks"], ref_case["ref_poses"])
+    row = torch.cat([pos, scl[:, None], idx[:, None].float(), ang[:, None], o["rotation"], o["offset"], o["scale"]], 1)
+    return row, logits

@@ -67,3 +67,19 @@ def test_refiner_host_path(golden):
                    "inference": True})
     for k in ("rotation", "offset", "scale"):
         np.testing.assert_allclose(out[k].numpy(), g[k], rtol=1e-3, atol=1e-3)
+
+
+def test_tensor_pipeline_matches_oracle_pipeline():
+    """detect -> select -> refine x2 through TensorPipeline (emulated ops) vs oracle/pipeline_oracle.py."""
+    from gen6d_amd.pipeline import TensorPipeline
+    from oracle import pipeline_oracle as PO
+    pipe = TensorPipeline("cpu", sel_rfn=8, det_rfn=8, refine_iter=2)
+    pipe.build()
+    full = synth.imgs_to_tensor(synth.synth_images(1, 96, 128, seed=100))
+    crop = synth.imgs_to_tensor(synth.synth_images(1, 128, 128, seed=200))
+    row = pipe.query(full, crop)
+    st = PO.build_state(pipe.state_dicts, pipe.det_refs, pipe.sel_case)
+    ref, logits = PO.query(pipe.state_dicts, st, pipe.ref_case, [p for p in pipe.iter_poses], full, crop)
+    assert row.shape == (1, 12)
+    assert int(row[0, 3]) == int(ref[0, 3])
+    np.testing.assert_allclose(row.numpy(), ref.numpy(), rtol=2e-3, atol=2e-2)

@@ -1,0 +1,272 @@
+"""Per-kernel parity on a real MI355X: every C-ABI entry point (called through gen6d_amd.ops -> ctypes ->
+libgen6d_hip.so) against its plain-PyTorch reference in tests/ref_ops.py evaluated in float64 on the CPU.
+
+Tolerances: the kernels compute in fp32 (MFMA fp32 = k-ordered fmaf chain); the reference is fp64, so the bound is
+fp32 accumulation error: |err| <= tol * (|a| . |b|) style magnitudes, written per test."""
+import numpy as np
+import pytest
+import torch
+
+import ref_ops
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from gen6d_amd import lib, ops as _ops
+    lib.load()                      # fails loudly if the HIP library is missing
+    assert torch.cuda.is_available()
+    return _ops
+
+
+def _rand(g, *shape, scale=1.0):
+    return (torch.rand(shape, generator=g) * 2 - 1) * scale
+
+
+def _d(t):
+    return t.detach().cpu().double() if t is not None else None
+
+
+def _check(got, want, tol, what=""):
+    got, want = got.detach().cpu().double(), want.double()
+    denom = max(want.abs().max().item(), 1e-30)
+    err = (got - want).abs().max().item() / denom
+    assert err <= tol, f"{what}: rel-to-max error {err:.3e} > {tol}"
+
+
+CONV_CASES = [
+    # N, D, H, W, Cin, Cout, k, stride, pad, extras
+    dict(N=2, D=1, H=16, W=16, Cin=64, Cout=64, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1)),
+    dict(N=3, D=1, H=9, W=7, Cin=32, Cout=128, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), aff=True, relu=True, stats=True),
+    dict(N=1, D=8, H=8, W=8, Cin=128, Cout=64, k=(3, 3, 3), s=(1, 1, 1), p=(1, 1, 1), aff=True, relu=True, stats=True),
+    dict(N=1, D=8, H=8, W=8, Cin=64, Cout=256, k=(3, 3, 3), s=(2, 2, 2), p=(1, 1, 1), stats=True),
+    dict(N=1, D=4, H=4, W=4, Cin=256, Cout=512, k=(3, 3, 3), s=(1, 1, 1), p=(1, 1, 1), aff=True, relu=True),       # M=64 tile
+    dict(N=1, D=1, H=22, W=30, Cin=512, Cout=32, k=(1, 15, 15), s=(1, 1, 1), p=(0, 7, 7)),                          # detector level 0
+    dict(N=1, D=1, H=11, W=15, Cin=512, Cout=8, k=(1, 7, 7), s=(1, 1, 1), p=(0, 3, 3)),                             # rfn=8
+    dict(N=1, D=1, H=6, W=8, Cin=512, Cout=32, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1)),
+    dict(N=40, D=1, H=8, W=8, Cin=512, Cout=128, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), mul=True, aff=True, stats=True),  # selector first layer
+    dict(N=1, D=1, H=1, W=40, Cin=516, Cout=512, k=(1, 1, 1), s=(1, 1, 1), p=(0, 0, 0), act=1),                     # Cin tail chunk
+    dict(N=1, D=1, H=1, W=8, Cin=2580, Cout=512, k=(1, 1, 1), s=(1, 1, 1), p=(0, 0, 0), act=1),
+    dict(N=1, D=1, H=1, W=8, Cin=512, Cout=1, k=(1, 1, 1), s=(1, 1, 1), p=(0, 0, 0)),
+    dict(N=1, D=1, H=16, W=16, Cin=64, Cout=2, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), ld_out=4, ld_in=192),
+    dict(N=7, D=1, H=8, W=8, Cin=512, Cout=256, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), stats=True, rpg=64),         # groups straddle tiles
+    dict(N=7, D=1, H=8, W=8, Cin=256, Cout=64, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), aff=True, relu=True, per_n=True, stats=True, rpg=64),
+    dict(N=6, D=1, H=32, W=32, Cin=64, Cout=64, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), aff=True, relu=True, per_n=True, stats=True, rpg=1024),
+    dict(N=1, D=1, H=1, W=64, Cin=1024, Cout=512, k=(1, 1, 1), s=(1, 1, 1), p=(0, 0, 0), stats=True, act=0),
+    dict(N=1, D=8, H=8, W=8, Cin=256, Cout=256, k=(3, 3, 3), s=(1, 1, 1), p=(1, 1, 1), stats=True, split=1),        # forced no split
+    dict(N=1, D=8, H=8, W=8, Cin=256, Cout=256, k=(3, 3, 3), s=(1, 1, 1), p=(1, 1, 1), stats=True, split=7, act=2),
+    dict(N=2, D=1, H=5, W=5, Cin=20, Cout=40, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), act=2),                        # odd sizes
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: f"{c['Cin']}x{c['Cout']}k{c['k'][0]}{c['k'][1]}{c['k'][2]}")
+def test_conv_igemm(ops, case):
+    g = torch.Generator().manual_seed(17)
+    c = case
+    N, D, H, W, Cin, Cout = c["N"], c["D"], c["H"], c["W"], c["Cin"], c["Cout"]
+    k, s, p = c["k"], c["s"], c["p"]
+    ld_in, ld_out = c.get("ld_in", Cin), c.get("ld_out", Cout)
+    Do, Ho, Wo = [(i + 2 * pp - kk) // ss + 1 for i, kk, ss, pp in zip((D, H, W), k, s, p)]
+    xbuf = _rand(g, N, D, H, W, ld_in)
+    off = 64 if ld_in >= Cin + 64 else 0
+    x = xbuf[..., off:off + Cin]
+    T = k[0] * k[1] * k[2]
+    w = _rand(g, Cout, T, Cin, scale=(1.0 / (T * Cin)) ** 0.5)
+    bias = _rand(g, Cout, scale=0.1)
+    mul = _rand(g, H, W, Cin) if c.get("mul") else None
+    groups_in = N if c.get("per_n") else 1
+    sc = (0.5 + torch.rand((groups_in, Cin), generator=g)) if c.get("aff") else None
+    sh = _rand(g, groups_in, Cin, scale=0.3) if c.get("aff") else None
+    M = N * Do * Ho * Wo
+    rpg = c.get("rpg", 0)
+    G = M // rpg if rpg else 1
+    dev = "cuda"
+    xg = xbuf.to(dev)
+    xv = xg[..., off:off + Cin]
+    outbuf = torch.full((N, Do, Ho, Wo, ld_out), -777.0, device=dev)
+    out = outbuf[..., :Cout]
+    stats = ops.new_stats(G, Cout, dev) if c.get("stats") else None
+    ops.conv(xv, w.to(dev), bias.to(dev), out, ksize=k, stride=s, pad=p, mul=mul.to(dev) if mul is not None else None,
+             in_scale=sc.to(dev) if sc is not None else None, in_shift=sh.to(dev) if sh is not None else None,
+             in_relu=bool(c.get("relu")), per_n=bool(c.get("per_n")), out_act=c.get("act", 0), stats=stats,
+             rows_per_group=rpg, split_k=c.get("split", 0))
+    torch.cuda.synchronize()
+    ref = torch.empty((N, Do, Ho, Wo, Cout), dtype=torch.float64)
+    rstats = torch.zeros((G, Cout, 2), dtype=torch.float64) if c.get("stats") else None
+    ref_ops.conv(_d(x), _d(w), _d(bias), ref, ksize=k, stride=s, pad=p, mul=_d(mul), in_scale=_d(sc), in_shift=_d(sh),
+                 in_relu=bool(c.get("relu")), per_n=bool(c.get("per_n")), out_act=c.get("act", 0), stats=rstats,
+                 rows_per_group=rpg)
+    _check(out, ref, 2e-5, "conv out")
+    if ld_out != Cout:
+        assert (outbuf[..., Cout:] == -777.0).all(), "conv wrote outside its channel slice"
+    if stats is not None:
+        _check(stats[..., 0], rstats[..., 0], 2e-5, "stats sum")
+        _check(stats[..., 1], rstats[..., 1], 2e-5, "stats sumsq")
+
+
+def test_conv_rejects_bad_args(ops):
+    x = torch.zeros((1, 1, 4, 4, 6), device="cuda")          # Cin % 4 != 0
+    w = torch.zeros((8, 1, 6), device="cuda")
+    out = torch.zeros((1, 1, 4, 4, 8), device="cuda")
+    with pytest.raises(RuntimeError, match="G6D_EINVAL"):
+        ops.conv(x, w, None, out)
+    with pytest.raises(RuntimeError, match="GPU"):
+        ops.conv(x.cpu(), w, None, out)
+
+
+def test_stats_finalize(ops):
+    g = torch.Generator().manual_seed(3)
+    st = torch.rand((3, 40, 2), generator=g, dtype=torch.float64)
+    st[..., 0] = (st[..., 0] - 0.5) * 200
+    st[..., 1] = st[..., 0] ** 2 / 100 + st[..., 1] * 50 + 1
+    sc, sh = ops.stats_finalize(st.cuda(), 100.0)
+    rsc, rsh = ref_ops.stats_finalize(st, 100.0)
+    _check(sc, rsc, 1e-6); _check(sh, rsh, 1e-6)
+
+
+@pytest.mark.parametrize("pool,per_n,relu", [(0, False, True), (1, False, False), (1, True, True), (2, False, True), (0, True, False)])
+def test_affine_act_pool(ops, pool, per_n, relu):
+    g = torch.Generator().manual_seed(5)
+    N, H, W, C = 6, 8, 8, 64
+    x = _rand(g, N, 1, H, W, C)
+    sc = 0.5 + torch.rand((N if per_n else 1, C), generator=g)
+    sh = _rand(g, N if per_n else 1, C)
+    shape = {0: (N, 1, H, W, C), 1: (N, 1, H // 2, W // 2, C), 2: (N, 1, 1, 1, C)}[pool]
+    obuf = torch.zeros(shape[:-1] + (C + 8,), device="cuda")
+    out = obuf[..., 4:4 + C]
+    ops.affine_act_pool(x.cuda(), out, sc.cuda(), sh.cuda(), per_n=per_n, relu=relu, pool=pool)
+    ref = torch.empty(shape, dtype=torch.float64)
+    ref_ops.affine_act_pool(_d(x), ref, _d(sc), _d(sh), per_n=per_n, relu=relu, pool=pool)
+    _check(out, ref, 1e-6)
+    # identity affine
+    out2 = torch.empty((N, 1, H, W, C), device="cuda")
+    ops.affine_act_pool(x.cuda(), out2)
+    _check(out2, x, 0)
+
+
+@pytest.mark.parametrize("factor", [2, 4])
+def test_upsample_bilinear(ops, factor):
+    g = torch.Generator().manual_seed(6)
+    N, H, W, C = 7, 8, 8, 64
+    x = _rand(g, N, 1, H, W, C)
+    sc, sh = 0.5 + torch.rand((N, C), generator=g), _rand(g, N, C)
+    obuf = torch.zeros((N, 1, H * factor, W * factor, 192), device="cuda")
+    out = obuf[..., 64:128]
+    ops.upsample_bilinear(x.cuda(), out, factor, sc.cuda(), sh.cuda(), per_n=True)
+    ref = torch.empty((N, 1, H * factor, W * factor, C), dtype=torch.float64)
+    ref_ops.upsample_bilinear(_d(x), ref, factor, _d(sc), _d(sh), per_n=True)
+    _check(out, ref, 1e-6)
+    assert (obuf[..., :64] == 0).all() and (obuf[..., 128:] == 0).all()
+
+
+@pytest.mark.parametrize("l2", [0, 1])
+def test_nchw_to_nhwc(ops, l2):
+    g = torch.Generator().manual_seed(7)
+    x = _rand(g, 3, 512, 5, 7)
+    out = torch.empty((3, 1, 5, 7, 512), device="cuda")
+    ops.nchw_to_nhwc(x.cuda(), out, bool(l2))
+    ref = torch.empty((3, 1, 5, 7, 512), dtype=torch.float64)
+    ref_ops.nchw_to_nhwc(_d(x), ref, bool(l2))
+    _check(out, ref, 1e-6)
+
+
+def test_selector_similarity(ops):
+    g = torch.Generator().manual_seed(8)
+    D, HW, C = 40, 64, 512
+    refs = torch.nn.functional.normalize(_rand(g, D, HW, C), dim=2)
+    que = torch.nn.functional.normalize(_rand(g, HW, C) + 0.3, dim=1)
+    r1, r2 = ops.selector_ref_sums(refs.cuda())
+    rr1, rr2 = ref_ops.selector_ref_sums(_d(refs))
+    _check(r1, rr1, 1e-12); _check(r2, rr2, 1e-12)
+    sc, sh = ops.selector_prod_affine(que.cuda(), r1, r2, D)
+    # ground truth: statistics of the materialised product
+    prod = _d(refs) * _d(que)[None]
+    mean, var = prod.mean((0, 1)), prod.var((0, 1), unbiased=False)
+    _check(sc[0], 1 / torch.sqrt(var + 1e-5), 1e-5)
+    _check(sh[0], -mean / torch.sqrt(var + 1e-5), 1e-5)
+    smap, vps = ops.selector_scan(que.cuda(), refs.cuda())
+    rsmap, rvps = ref_ops.selector_scan(_d(que), _d(refs))
+    _check(smap, rsmap, 2e-6); _check(vps, rvps, 1e-5)
+
+
+@pytest.mark.parametrize("rfn", [6, 1, 8])
+def test_refiner_volume(ops, rfn):
+    from gen6d_amd import synth
+    g = torch.Generator().manual_seed(9)
+    case = synth.refiner_case(rfn=rfn)
+    sn, C, fh, fw = 16, 128, 32, 32
+    feats = _rand(g, rfn + 1, fh, fw, C)
+    projs = torch.cat([case["ref_Ks"][0] @ case["ref_poses"][0], case["Ks_in"] @ case["poses_in"]], 0).contiguous()
+    rot = case["poses_in"][0, :, :3].contiguous()
+    lin = torch.linspace(-1, 1, sn)
+    mean_in = torch.empty((sn ** 3, 2 * C), device="cuda"); std = torch.empty((sn ** 3, C), device="cuda")
+    ops.refiner_volume(feats.cuda(), projs.cuda(), rot.cuda(), lin.cuda(), 128, 128, mean_in, std)
+    rm = torch.empty((sn ** 3, 2 * C), dtype=torch.float64); rs = torch.empty((sn ** 3, C), dtype=torch.float64)
+    ref_ops.refiner_volume(_d(feats), _d(projs), _d(rot), _d(lin), 128, 128, rm, rs)
+    # bilinear weights are computed from fp32 coordinates; 1e-4 of the feature range covers that
+    _check(mean_in, rm, 2e-4, "mean|query")
+    _check(std, rs, 2e-4, "std")
+
+
+def test_detector_glue(ops):
+    g = torch.Generator().manual_seed(10)
+    hc, wc, rfn, hs, ws = 12, 20, 8, 16, 16
+    stats = [[36.264317, 13.151907], [13910.291, 5345.965], [829.70807, 387.98788]]
+    s = [_rand(g, (hc >> l) * (wc >> l), rfn, scale=3 * stats[l][1]) + stats[l][0] for l in range(3)]
+    stacked = torch.zeros((hs * ws, rfn, 12), device="cuda")
+    rstacked = torch.zeros((hs * ws, rfn, 12), dtype=torch.float64)
+    for si in range(4):
+        ops.detector_assemble(s[0].cuda(), s[1].cuda(), s[2].cuda(), hc, wc, stats, 10.0, hs, ws, si, stacked)
+        ref_ops.detector_assemble(_d(s[0]), _d(s[1]), _d(s[2]), hc, wc, stats, 10.0, hs, ws, si, rstacked)
+    _check(stacked, rstacked, 1e-5, "assemble")
+    assert (stacked.abs().max() <= 10.0 + 1e-6)
+    w0, b0, w1, b1 = _rand(g, 64, 12, scale=0.3), _rand(g, 64, scale=0.1), _rand(g, 64, 64, scale=0.2), _rand(g, 64, scale=0.1)
+    out = ops.detector_score_mlp_max(stacked, w0.cuda(), b0.cuda(), w1.cuda(), b1.cuda())
+    ref = ref_ops.detector_score_mlp_max(rstacked, _d(w0), _d(b0), _d(w1), _d(b1))
+    _check(out, ref, 1e-5, "mlp max")
+    # decode incl. first-maximum tie rule
+    o4 = _rand(g, hs * ws, 4)
+    o4[37, 0] = 5.0; o4[101, 0] = 5.0
+    res = ops.detector_decode(o4.cuda()[:, 0:1], o4.cuda()[:, 2:4], o4.cuda()[:, 1:2], hs, ws, 8)
+    rres = ref_ops.detector_decode(_d(o4)[:, 0:1], _d(o4)[:, 2:4], _d(o4)[:, 1:2], hs, ws, 8)
+    assert int(res[3].item()) == 37 % ws and int(res[4].item()) == 37 // ws
+    _check(res, rres, 1e-6, "decode")
+
+
+def test_selector_tail_ops(ops):
+    g = torch.Generator().manual_seed(11)
+    rfn, an, C = 16, 5, 512
+    D = rfn * an
+    vps = _rand(g, 3, D, scale=20) + 30
+    feats = torch.zeros((D, 516), device="cuda"); rfeats = torch.zeros((D, 516), dtype=torch.float64)
+    ops.vps_norm(vps.cuda(), feats, 512); ref_ops.vps_norm(_d(vps), rfeats, 512)
+    _check(feats, rfeats, 1e-5, "vps_norm")
+    x, emb = _rand(g, D, C), _rand(g, rfn, C)
+    out = torch.zeros((rfn, 1024), device="cuda"); rout = torch.zeros((rfn, C), dtype=torch.float64)
+    ops.max_an_add(x.cuda(), rfn, an, emb.cuda(), out[:, :512]); ref_ops.max_an_add(_d(x), rfn, an, _d(emb), rout)
+    _check(out[:, :512], rout, 1e-6, "max_an_add")
+    qkv = _rand(g, rfn, 1536)
+    att = torch.empty((rfn, C), device="cuda"); ratt = torch.empty((rfn, C), dtype=torch.float64)
+    qg = qkv.cuda()
+    ops.attention(qg[:, :512], qg[:, 512:1024], qg[:, 1024:], 8, att)
+    qd = _d(qkv)
+    ref_ops.attention(qd[:, :512], qd[:, 512:1024], qd[:, 1024:], 8, ratt)
+    _check(att, ratt, 1e-5, "attention")
+    gam, bet = 0.5 + torch.rand(C, generator=g), _rand(g, C)
+    ln = torch.empty((rfn, C), device="cuda"); rln = torch.empty((rfn, C), dtype=torch.float64)
+    ops.layernorm(x[:rfn].cuda(), gam.cuda(), bet.cuda(), ln); ref_ops.layernorm(_d(x[:rfn]), _d(gam), _d(bet), rln)
+    _check(ln, rln, 1e-5, "layernorm")
+    sc, sh = 0.5 + torch.rand((1, C), generator=g), _rand(g, 1, C)
+    o = torch.empty((rfn, C), device="cuda"); ro = torch.empty((rfn, C), dtype=torch.float64)
+    ops.affine_act_add(x[:rfn].cuda(), o, sc.cuda(), sh.cuda(), relu=True, residual=emb.cuda())
+    ref_ops.affine_act_add(_d(x[:rfn]), ro, _d(sc), _d(sh), relu=True, residual=_d(emb))
+    _check(o, ro, 1e-6, "affine_act_add")
+
+
+@pytest.mark.parametrize("B,K,O,act", [(1, 32768, 512, 2), (1, 512, 7, 0), (3, 1024, 40, 1)])
+def test_linear_gemv(ops, B, K, O, act):
+    g = torch.Generator().manual_seed(12)
+    x, W, b = _rand(g, B, K), _rand(g, O, K, scale=K ** -0.5), _rand(g, O, scale=0.1)
+    out = ops.linear_gemv(x.cuda(), W.cuda(), b.cuda(), act)
+    _check(out, ref_ops.linear_gemv(_d(x), _d(W), _d(b), act), 1e-5)
