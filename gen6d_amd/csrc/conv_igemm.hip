@@ -23,7 +23,9 @@
 
 namespace {
 
-template <int BM, int BN, int WGM, int WGN>
+// MODE: 0 = plain operand, 1 = affine(+ReLU) with one table, 2 = affine(+ReLU) with a table per batch index n,
+//       3 = elementwise multiplier + affine (selector product).
+template <int BM, int BN, int WGM, int WGN, int MODE>
 __global__ void __launch_bounds__(256) conv_igemm_kernel(const G6dConv p, const int M, const int T,
                                                          const int nChunks, const int itersPerSplit,
                                                          const int totalIters, const int splits) {
@@ -32,6 +34,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const G6dConv p, const 
   constexpr int MT = WM / 32, NT = WN / 32;
   constexpr int RA = BM / 32, RB = BN / 32;
   constexpr int STAGE = (BM + BN) * LDS_K;
+  constexpr bool AFF = MODE != 0, PER_N = MODE == 2, MUL = MODE == 3;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -47,11 +50,13 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const G6dConv p, const 
   const float* __restrict__ gin = p.in;
   const float* __restrict__ gmul = p.mul;
   const float* __restrict__ gw = p.weight;
-  const bool has_aff = p.in_scale != nullptr;
-  const bool per_n = p.in_affine_per_n != 0;
+  const float* __restrict__ gsc = p.in_scale;
+  const float* __restrict__ gsh = p.in_shift;
+  const int relu = p.in_relu;
 
-  // ---- per-thread rows of the activation tile: decode output position once
-  int an_[RA], az0[RA], ay0[RA], ax0[RA];
+  // ---- per-thread rows of the activation tile: decode the output position once.  abase is the (possibly virtual,
+  //      i.e. out-of-range) element offset of input voxel (n, iz0, iy0, ix0); every tap adds a uniform offset.
+  int az0[RA], ay0[RA], ax0[RA], abase[RA], mbase[RA], nbase[RA];
 #pragma unroll
   for (int j = 0; j < RA; ++j) {
     int m = m0 + lrow + 32 * j;
@@ -59,18 +64,21 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const G6dConv p, const 
       int ow = m % p.Wo; int t1 = m / p.Wo;
       int oh = t1 % p.Ho; int t2 = t1 / p.Ho;
       int od = t2 % p.Do; int n = t2 / p.Do;
-      an_[j] = n; az0[j] = od * p.sd - p.pd; ay0[j] = oh * p.sh - p.ph; ax0[j] = ow * p.sw - p.pw;
+      az0[j] = od * p.sd - p.pd; ay0[j] = oh * p.sh - p.ph; ax0[j] = ow * p.sw - p.pw;
+      abase[j] = (((n * p.Di + az0[j]) * p.Hi + ay0[j]) * p.Wi + ax0[j]) * p.ld_in;
+      mbase[j] = (ay0[j] * p.Wi + ax0[j]) * Cin;
+      nbase[j] = n * Cin;
     } else {
-      an_[j] = 0; az0[j] = -(1 << 28); ay0[j] = 0; ax0[j] = 0;   // never valid
+      az0[j] = -(1 << 28); ay0[j] = 0; ax0[j] = 0; abase[j] = 0; mbase[j] = 0; nbase[j] = 0;   // never valid
     }
   }
   // ---- per-thread rows of the weight tile
-  size_t boff[RB]; bool bval[RB];
+  int boff[RB]; bool bval[RB];
 #pragma unroll
   for (int j = 0; j < RB; ++j) {
     int co = n0 + lrow + 32 * j;
     bval[j] = co < p.Cout;
-    boff[j] = (size_t)(bval[j] ? co : 0) * T * Cin;
+    boff[j] = (bval[j] ? co : 0) * T * Cin;
   }
 
   f32x16 acc[MT][NT];
@@ -81,41 +89,42 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const G6dConv p, const 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  f32x4 ra[RA], rm[RA], rb[RB], rsc[RA], rsh[RA];
-  bool va[RA];
+  f32x4 ra[RA], rm[RA], rb[RB], rsc[PER_N ? RA : 1], rsh[PER_N ? RA : 1];
+  bool va[RA], vb[RB];
 
   int tap = it_begin / nChunks;
   int cc = it_begin - tap * nChunks;
 
+  // All loads are unconditional (clamped to element 0 when masked) so that they pipeline; masking happens in
+  // store_stage.  A branch around a load makes hipcc wait for each one separately.
   auto issue_loads = [&](int tap_, int cc_) {
     const int kz = tap_ / khw; const int r_ = tap_ - kz * khw;
     const int ky = r_ / p.kw; const int kx = r_ - ky * p.kw;
     const int c = cc_ * BK + 4 * lseg;
     const bool cv = c < Cin;
+    const int toff = ((kz * p.Hi + ky) * p.Wi + kx) * p.ld_in + c;
+    const int moff = (ky * p.Wi + kx) * Cin + c;
 #pragma unroll
     for (int j = 0; j < RA; ++j) {
-      const int iz = az0[j] + kz, iy = ay0[j] + ky, ix = ax0[j] + kx;
-      const bool v = cv && (unsigned)iz < (unsigned)p.Di && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+      const bool v = cv && (unsigned)(az0[j] + kz) < (unsigned)p.Di && (unsigned)(ay0[j] + ky) < (unsigned)p.Hi &&
+                     (unsigned)(ax0[j] + kx) < (unsigned)p.Wi;
       va[j] = v;
-      ra[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (v) {
-        const size_t pos = ((size_t)(an_[j] * p.Di + iz) * p.Hi + iy) * p.Wi + ix;
-        ra[j] = *reinterpret_cast<const f32x4*>(gin + pos * p.ld_in + c);
-        if (gmul) rm[j] = *reinterpret_cast<const f32x4*>(gmul + ((size_t)iy * p.Wi + ix) * Cin + c);
-        if (has_aff && per_n) {
-          rsc[j] = *reinterpret_cast<const f32x4*>(p.in_scale + (size_t)an_[j] * Cin + c);
-          rsh[j] = *reinterpret_cast<const f32x4*>(p.in_shift + (size_t)an_[j] * Cin + c);
-        }
+      ra[j] = *reinterpret_cast<const f32x4*>(gin + (v ? abase[j] + toff : 0));
+      if constexpr (MUL) rm[j] = *reinterpret_cast<const f32x4*>(gmul + (v ? mbase[j] + moff : 0));
+      if constexpr (PER_N) {
+        rsc[j] = *reinterpret_cast<const f32x4*>(gsc + (cv ? nbase[j] + c : 0));
+        rsh[j] = *reinterpret_cast<const f32x4*>(gsh + (cv ? nbase[j] + c : 0));
       }
     }
-    if (has_aff && !per_n && cv) {
-      rsc[0] = *reinterpret_cast<const f32x4*>(p.in_scale + c);
-      rsh[0] = *reinterpret_cast<const f32x4*>(p.in_shift + c);
+    if constexpr (AFF && !PER_N) {
+      rsc[0] = *reinterpret_cast<const f32x4*>(gsc + (cv ? c : 0));
+      rsh[0] = *reinterpret_cast<const f32x4*>(gsh + (cv ? c : 0));
     }
 #pragma unroll
     for (int j = 0; j < RB; ++j) {
-      rb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (bval[j] && cv) rb[j] = *reinterpret_cast<const f32x4*>(gw + boff[j] + (size_t)tap_ * Cin + c);
+      const bool v = bval[j] && cv;
+      vb[j] = v;
+      rb[j] = *reinterpret_cast<const f32x4*>(gw + (v ? boff[j] + tap_ * Cin + c : 0));
     }
   };
 
@@ -123,16 +132,17 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const G6dConv p, const 
 #pragma unroll
     for (int j = 0; j < RA; ++j) {
       f32x4 v = ra[j];
-      if (va[j]) {
-        if (gmul) v *= rm[j];
-        if (has_aff) { const int q = per_n ? j : 0; v = v * rsc[q] + rsh[q]; }
-        if (p.in_relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+      if constexpr (MUL) v *= rm[j];
+      if constexpr (AFF) {
+        v = v * rsc[PER_N ? j : 0] + rsh[PER_N ? j : 0];
+        if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
       }
+      v = va[j] ? v : f32x4{0.f, 0.f, 0.f, 0.f};
       *reinterpret_cast<f32x4*>(As + (lrow + 32 * j) * LDS_K + 4 * lseg) = v;
     }
 #pragma unroll
     for (int j = 0; j < RB; ++j)
-      *reinterpret_cast<f32x4*>(Bs + (lrow + 32 * j) * LDS_K + 4 * lseg) = rb[j];
+      *reinterpret_cast<f32x4*>(Bs + (lrow + 32 * j) * LDS_K + 4 * lseg) = vb[j] ? rb[j] : f32x4{0.f, 0.f, 0.f, 0.f};
   };
 
   auto compute = [&](const float* As, const float* Bs) {
@@ -170,7 +180,11 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const G6dConv p, const 
         if (++cc == nChunks) { cc = 0; ++tap; }
         issue_loads(tap, cc);
       }
+      // keep the consumers of the prefetched registers behind the MFMAs: otherwise hipcc hoists the masking/affine
+      // (and with it the s_waitcnt vmcnt) above the matrix work and the global-load latency is exposed every K step
+      __builtin_amdgcn_sched_barrier(0);
       compute(As, Bs);
+      __builtin_amdgcn_sched_barrier(0);
       if (more) store_stage(An, Bn);
       __syncthreads();
     }
@@ -247,52 +261,73 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const G6dConv p, const 
   }
 }
 
-// Sum split-K partials, then the same epilogue as above. Block = 64 columns x 4 row lanes, 32 rows per block.
+// Sum split-K partials, then the same epilogue as above.  Thread = one row x 4 columns (16-byte loads, 4 splits in
+// flight); block = 32 column-quads x 8 rows, looping over 4 row groups (32 rows x 128 columns per block).
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ ws, int splits, int M, int Cout,
                                                             const float* __restrict__ bias, int act,
                                                             float* __restrict__ out, int ld_out, double* stats, int rpg) {
-  __shared__ float sred[64 * 2];
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int col = blockIdx.y * 64 + tx;
+  __shared__ float sred[128 * 2];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int col = blockIdx.y * 128 + tx * 4;
   const int r0 = blockIdx.x * 32;
   const int rlast = min(r0 + 32, M) - 1;
   const int g0 = rpg > 0 ? r0 / rpg : 0;
   const bool one_group = rpg <= 0 || (rlast / rpg) == g0;
-  if (threadIdx.x < 128) sred[threadIdx.x] = 0.f;
+  sred[threadIdx.x] = 0.f;
   __syncthreads();
-  float s1 = 0.f, s2 = 0.f;
+  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+  const bool vec = (Cout & 3) == 0;
+  const size_t zstride = (size_t)M * Cout;
   if (col < Cout) {
-    const float bv = bias ? bias[col] : 0.f;
-    for (int i = 0; i < 8; ++i) {
-      const int row = r0 + ty + 4 * i;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < 4; ++k) if (bias && col + k < Cout) bv[k] = bias[col + k];
+    for (int i = 0; i < 4; ++i) {
+      const int row = r0 + ty + 8 * i;
       if (row >= M) break;
-      float v = 0.f;
-      for (int z = 0; z < splits; ++z) v += ws[((size_t)z * M + row) * Cout + col];
-      v = apply_act(v + bv, act);
-      out[(size_t)row * ld_out + col] = v;
-      if (stats) {
-        if (one_group) { s1 += v; s2 += v * v; }
-        else {
-          double* st = stats + ((size_t)(row / rpg) * Cout + col) * 2;
-          atomicAdd(st, (double)v); atomicAdd(st + 1, (double)v * v);
+      const float* src = ws + (size_t)row * Cout + col;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (vec) {
+        f32x4 a0 = v, a1 = v, a2 = v, a3 = v;
+        int z = 0;
+        for (; z + 4 <= splits; z += 4) {
+          a0 += *reinterpret_cast<const f32x4*>(src + (size_t)z * zstride);
+          a1 += *reinterpret_cast<const f32x4*>(src + (size_t)(z + 1) * zstride);
+          a2 += *reinterpret_cast<const f32x4*>(src + (size_t)(z + 2) * zstride);
+          a3 += *reinterpret_cast<const f32x4*>(src + (size_t)(z + 3) * zstride);
+        }
+        for (; z < splits; ++z) a0 += *reinterpret_cast<const f32x4*>(src + (size_t)z * zstride);
+        v = (a0 + a1) + (a2 + a3);
+      } else {
+        for (int k = 0; k < 4; ++k)
+          if (col + k < Cout) for (int z = 0; z < splits; ++z) v[k] += src[(size_t)z * zstride + k];
+      }
+      for (int k = 0; k < 4; ++k) {
+        if (col + k >= Cout) break;
+        const float o = apply_act(v[k] + bv[k], act);
+        out[(size_t)row * ld_out + col + k] = o;
+        if (stats) {
+          if (one_group) { s1[k] += o; s2[k] += o * o; }
+          else {
+            double* st = stats + ((size_t)(row / rpg) * Cout + col + k) * 2;
+            atomicAdd(st, (double)o); atomicAdd(st + 1, (double)o * o);
+          }
         }
       }
     }
   }
   if (stats && one_group) {
-    atomicAdd(&sred[tx * 2], s1);
-    atomicAdd(&sred[tx * 2 + 1], s2);
+    for (int k = 0; k < 4; ++k) { atomicAdd(&sred[(tx * 4 + k) * 2], s1[k]); atomicAdd(&sred[(tx * 4 + k) * 2 + 1], s2[k]); }
     __syncthreads();
-    if (ty == 0 && col < Cout) {
-      double* st = stats + ((size_t)g0 * Cout + col) * 2;
-      atomicAdd(st, (double)sred[tx * 2]);
-      atomicAdd(st + 1, (double)sred[tx * 2 + 1]);
+    if (threadIdx.x < 128 && blockIdx.y * 128 + threadIdx.x < Cout) {
+      double* st = stats + ((size_t)g0 * Cout + blockIdx.y * 128 + threadIdx.x) * 2;
+      atomicAdd(st, (double)sred[threadIdx.x * 2]);
+      atomicAdd(st + 1, (double)sred[threadIdx.x * 2 + 1]);
     }
   }
 }
 
-template <int BM, int BN, int WGM, int WGN>
-int launch_cfg(const G6dConv& d, int M, int T, int nChunks, int splits, hipStream_t stream) {
+template <int BM, int BN, int WGM, int WGN, int MODE>
+int launch_mode(const G6dConv& d, int M, int T, int nChunks, int splits, hipStream_t stream) {
   const int total = T * nChunks;
   const int ips = (total + splits - 1) / splits;
   splits = (total + ips - 1) / ips;
@@ -300,21 +335,29 @@ int launch_cfg(const G6dConv& d, int M, int T, int nChunks, int splits, hipStrea
   const size_t lds_bytes = 2 * (size_t)(BM + BN) * LDS_K * sizeof(float);
   static bool attr_done = false;   // per template instantiation
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WGM, WGN>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WGM, WGN, MODE>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN>), grid, dim3(256), lds_bytes, stream, d, M, T, nChunks, ips,
-                     total, splits);
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, MODE>), grid, dim3(256), lds_bytes, stream, d, M, T, nChunks,
+                     ips, total, splits);
   int rc = g6d_check_launch("conv_igemm");
   if (rc != G6D_OK) return rc;
   if (splits > 1) {
-    dim3 g2((M + 31) / 32, (d.Cout + 63) / 64);
+    dim3 g2((M + 31) / 32, (d.Cout + 127) / 128);
     hipLaunchKernelGGL(splitk_reduce_kernel, g2, dim3(256), 0, stream, d.workspace, splits, M, d.Cout, d.bias, d.out_act,
                        d.out, d.ld_out, d.stats, d.stat_rows_per_group);
     rc = g6d_check_launch("splitk_reduce");
   }
   return rc;
+}
+
+template <int BM, int BN, int WGM, int WGN>
+int launch_cfg(const G6dConv& d, int M, int T, int nChunks, int splits, hipStream_t stream) {
+  if (d.mul) return launch_mode<BM, BN, WGM, WGN, 3>(d, M, T, nChunks, splits, stream);
+  if (!d.in_scale) return launch_mode<BM, BN, WGM, WGN, 0>(d, M, T, nChunks, splits, stream);
+  if (d.in_affine_per_n) return launch_mode<BM, BN, WGM, WGN, 2>(d, M, T, nChunks, splits, stream);
+  return launch_mode<BM, BN, WGM, WGN, 1>(d, M, T, nChunks, splits, stream);
 }
 
 }  // namespace
@@ -331,6 +374,10 @@ extern "C" int g6d_conv_igemm(const G6dConv* desc, g6d_stream_t stream_) {
   if (!g6d_aligned16(d.in) || !g6d_aligned16(d.weight) || (d.mul && !g6d_aligned16(d.mul)) ||
       (d.in_scale && (!g6d_aligned16(d.in_scale) || !d.in_shift || !g6d_aligned16(d.in_shift)))) {
     g6d_set_error("conv: operand pointers must be 16-byte aligned"); return G6D_EINVAL;
+  }
+  if (d.mul && !d.in_scale) { g6d_set_error("conv: mul requires in_scale/in_shift"); return G6D_EINVAL; }
+  if ((long long)d.N * d.Di * d.Hi * d.Wi * d.ld_in >= (1ll << 31) || (long long)d.Cout * d.kd * d.kh * d.kw * d.Cin >= (1ll << 31)) {
+    g6d_set_error("conv: tensor exceeds 2^31 elements"); return G6D_EINVAL;
   }
   const long long Mll = (long long)d.N * d.Do * d.Ho * d.Wo;
   if (Mll > (1ll << 30)) { g6d_set_error("conv: M too large"); return G6D_EINVAL; }
