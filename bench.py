@@ -68,8 +68,10 @@ def main():
     parallel.barrier()
     torch.cuda.synchronize()
     ops.PROFILE = []
+    ops.marker(1)
     t0 = time.perf_counter()
     rows = [step(args.warmup + i) for i in range(args.steps)]
+    ops.marker(2)
     torch.cuda.synchronize()
     parallel.barrier()
     torch.cuda.synchronize()

@@ -19,3 +19,13 @@ int g6d_check_launch(const char* what) {
 
 extern "C" int g6d_abi_version(void) { return 1; }
 extern "C" const char* g6d_last_error(void) { return g_err; }
+extern "C" int g6d_sizeof_conv_desc(void) { return (int)sizeof(G6dConv); }
+
+// Profiling aid: an empty kernel that brackets a region of interest in a rocprofv3 kernel trace
+// (tools/rocpd_stats.py keeps only the dispatches between the first and the last g6d_marker_kernel).
+__global__ void g6d_marker_kernel(int id) { (void)id; }
+
+extern "C" int g6d_marker(int id, g6d_stream_t stream) {
+  hipLaunchKernelGGL(g6d_marker_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), id);
+  return g6d_check_launch("g6d_marker");
+}

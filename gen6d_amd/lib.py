@@ -28,6 +28,7 @@ _P, _I, _F, _D = C.c_void_p, C.c_int, C.c_float, C.c_double
 
 # name -> argtypes (every function returns int); mirrors include/gen6d_hip.h
 SIGNATURES = {
+    "g6d_marker": [_I, _P],
     "g6d_conv_igemm": [C.POINTER(G6dConv), _P],
     "g6d_stats_finalize": [_P, _I, _D, _D, _P, _P, _P],
     "g6d_affine_act_pool": [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P],
@@ -65,6 +66,9 @@ def load():
         fn.argtypes = args
         fn.restype = C.c_int
     lib.g6d_abi_version.restype = C.c_int
+    lib.g6d_sizeof_conv_desc.restype = C.c_int
+    if lib.g6d_sizeof_conv_desc() != C.sizeof(G6dConv):
+        raise RuntimeError("libgen6d_hip.so: G6dConv layout differs from the ctypes binding (stale build?)")
     lib.g6d_last_error.restype = C.c_char_p
     _lib = lib
     return lib

@@ -36,6 +36,11 @@ def _need_gpu(*ts):
             raise RuntimeError("gen6d_amd.ops: tensors must live on the GPU (HIP kernels only, no CPU fallback)")
 
 
+def marker(i):
+    """Empty kernel that brackets a region in a rocprofv3 kernel trace."""
+    _lib.check(_lib.load().g6d_marker(int(i), _stream()), "g6d_marker")
+
+
 def workspace(device):
     key = str(device)
     if key not in _WS:

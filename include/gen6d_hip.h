@@ -36,6 +36,9 @@ int g6d_abi_version(void);
 /* last HIP error string of this thread ("" if none) */
 const char* g6d_last_error(void);
 
+/* Profiling aid: launches the empty kernel `g6d_marker_kernel` so a kernel trace can be cut to a region of interest. */
+int g6d_marker(int id, g6d_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Generic implicit-GEMM convolution on fp32 MFMA (v_mfma_f32_32x32x2_f32), 1-D/2-D/3-D, stride, zero padding.
  * Replaces every dense conv / linear contraction of the hot path:
@@ -77,6 +80,8 @@ typedef struct G6dConv {
 } G6dConv;
 
 int g6d_conv_igemm(const G6dConv* desc, g6d_stream_t stream);
+/* sizeof(G6dConv) as compiled into the library: bindings check their struct layout against it */
+int g6d_sizeof_conv_desc(void);
 
 /* InstanceNorm finalisation: stats[g][c] = (sum, sumsq) over `count` elements ->
  * scale = 1/sqrt(var+eps), shift = -mean*scale (biased variance; torch InstanceNorm{1,2,3}d, eps 1e-5,

@@ -1,0 +1,55 @@
+"""The C-ABI library loads on a machine without a GPU and exports every symbol include/gen6d_hip.h declares
+(no compute calls here); the product path refuses to run without the HIP library or on CPU tensors."""
+import os
+import re
+
+import pytest
+import torch
+
+from gen6d_amd import lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "gen6d_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(g6d_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported():
+    l = lib.load()
+    names = _declared()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(l, n), f"{n} declared in gen6d_hip.h but not exported by libgen6d_hip.so"
+    assert l.g6d_abi_version() == 1
+    # every typed binding corresponds to a declared symbol and vice versa
+    assert set(lib.SIGNATURES) | {"g6d_abi_version", "g6d_last_error", "g6d_sizeof_conv_desc"} == set(names)
+
+
+def test_struct_layout_matches_header():
+    # 10 pointer-sized fields followed by 25 int32 (include/gen6d_hip.h: struct G6dConv), 4 bytes tail padding
+    import ctypes as C
+    assert C.sizeof(lib.G6dConv) == 10 * 8 + 26 * 4 == lib.load().g6d_sizeof_conv_desc()
+    assert lib.G6dConv.N.offset == 80 and lib.G6dConv.split_k.offset == 80 + 24 * 4
+
+
+def test_null_descriptor_is_rejected_without_gpu():
+    assert lib.load().g6d_conv_igemm(None, None) == -1     # G6D_EINVAL before any HIP call
+
+
+def test_no_cpu_fallback():
+    from gen6d_amd import ops
+    x = torch.zeros((1, 1, 4, 4, 8))
+    with pytest.raises(RuntimeError, match="GPU"):
+        ops.conv(x, torch.zeros((8, 1, 8)), None, torch.zeros((1, 1, 4, 4, 8)))
+    with pytest.raises(RuntimeError, match="GPU"):
+        ops.selector_scan(torch.zeros((4, 8)), torch.zeros((2, 4, 8)))
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(lib, "_lib", None)
+    monkeypatch.setattr(lib, "LIB_PATH", "/nonexistent/libgen6d_hip.so")
+    with pytest.raises(RuntimeError, match="no fallback"):
+        lib.load()

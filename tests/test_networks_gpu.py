@@ -3,8 +3,9 @@ the C ABI) against (a) the golden vectors produced by the reference's own module
 fp64 on the same seeded inputs.
 
 Acceptance: the reference's own fp32 path is only accurate to ~1e-3 on selector logits (13 stacked
-instance norms), so a tensor passes when  |new - ref64| <= max(tol, 1.5 * |ref32 - ref64|)  with tol = 1e-4 relative
-to the tensor's range, and arg-max indices must be identical."""
+instance norms), so a tensor passes when  |new - ref64| <= max(tol, 1.5 * |ref32 - ref64|)  with tol = 1e-4 absolute
+(north_star: "within 1e-4 fp32 on logits"; scaled by the tensor's range when that exceeds 1), and arg-max indices must
+be identical."""
 import numpy as np
 import pytest
 import torch
@@ -30,7 +31,7 @@ def _cuda(d):
 
 def _accept(new, ref32, ref64, tol=1e-4, what=""):
     new, ref32, ref64 = (np.asarray(t.detach().cpu().double() if torch.is_tensor(t) else t, dtype=np.float64) for t in (new, ref32, ref64))
-    rng = max(np.abs(ref64).max(), 1e-30)
+    rng = max(np.abs(ref64).max(), 1.0)
     e_new, e_ref = np.abs(new - ref64).max() / rng, np.abs(ref32 - ref64).max() / rng
     assert e_new <= max(tol, 1.5 * e_ref), f"{what}: err {e_new:.3e} vs reference-fp32 noise {e_ref:.3e}"
     return e_new, e_ref

@@ -18,8 +18,12 @@ def main():
     con = sqlite3.connect(db)
     cols = [r[1] for r in con.execute("pragma table_info(kernels)")]
     namecol = "name" if "name" in cols else "kernel_name"
+    marks = [r[0] for r in con.execute(f"select start from kernels where {namecol} like '%g6d_marker_kernel%' order by start")]
+    where = f"where start > {marks[0]} and start < {marks[-1]}" if len(marks) >= 2 else ""
     rows = con.execute(f"select {namecol}, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) "
-                       f"from kernels group by {namecol} order by 3 desc").fetchall()
+                       f"from kernels {where} group by {namecol} order by 3 desc").fetchall()
+    if len(marks) >= 2:
+        print(f"region between g6d markers: {(marks[-1] - marks[0]) / 1e6:.3f} ms wall")
     total = sum(r[2] for r in rows)
     lines = ["| kernel | calls | total ms | avg us | min us | max us | % |", "|---|---|---|---|---|---|---|"]
     for n, c, t, a, mn, mx in rows:
