@@ -17,16 +17,26 @@
 // InstanceNorm statistics of the output in fp64.  Small grids are split along K into a workspace and reduced by a
 // second kernel that carries the same epilogue.
 #include "g6d_common.h"
+#include <type_traits>
 
 #define LDS_K 36
 #define BK 32
+#ifndef G6D_ABLATE
+#define G6D_ABLATE 0   // profiling builds only (tools/ablate.sh): 1 = no prefetch / LDS stores, 2 = MFMA only, 3 = no barrier,
+                       // 4 = global loads but no LDS stores, 5 = LDS stores but no global loads
+#endif
 
 namespace {
+
+// 16-byte load at base + (unsigned 32-bit element offset): scalar base + 32-bit vector offset addressing
+__device__ __forceinline__ f32x4 ldg(const float* __restrict__ base, int elem_off) {
+  return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + ((unsigned)elem_off << 2));
+}
 
 // MODE: 0 = plain operand, 1 = affine(+ReLU) with one table, 2 = affine(+ReLU) with a table per batch index n,
 //       3 = elementwise multiplier + affine (selector product).
 template <int BM, int BN, int WGM, int WGN, int MODE>
-__global__ void __launch_bounds__(256) conv_igemm_kernel(const G6dConv p, const int M, const int T,
+__global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const G6dConv p, const int M, const int T,
                                                          const int nChunks, const int itersPerSplit,
                                                          const int totalIters, const int splits) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -89,104 +99,138 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const G6dConv p, const 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  f32x4 ra[RA], rm[RA], rb[RB], rsc[PER_N ? RA : 1], rsh[PER_N ? RA : 1];
-  bool va[RA], vb[RB];
+  // Two register sets: the global loads of K step t+2 are issued during step t and written to LDS during step t+1,
+  // which gives every load ~1.6 K steps (>3000 cycles) to land while needing only two LDS stages.
+  f32x4 ra[2][RA], rm[2][MUL ? RA : 1], rb[2][RB], rsc[2][PER_N ? RA : 1], rsh[2][PER_N ? RA : 1];
+  bool va[2][RA], vb[2][RB];
 
-  int tap = it_begin / nChunks;
-  int cc = it_begin - tap * nChunks;
-
-  // All loads are unconditional (clamped to element 0 when masked) so that they pipeline; masking happens in
-  // store_stage.  A branch around a load makes hipcc wait for each one separately.
-  auto issue_loads = [&](int tap_, int cc_) {
-    const int kz = tap_ / khw; const int r_ = tap_ - kz * khw;
-    const int ky = r_ / p.kw; const int kx = r_ - ky * p.kw;
-    const int c = cc_ * BK + 4 * lseg;
-    const bool cv = c < Cin;
-    const int toff = ((kz * p.Hi + ky) * p.Wi + kx) * p.ld_in + c;
-    const int moff = (ky * p.Wi + kx) * Cin + c;
-#pragma unroll
-    for (int j = 0; j < RA; ++j) {
-      const bool v = cv && (unsigned)(az0[j] + kz) < (unsigned)p.Di && (unsigned)(ay0[j] + ky) < (unsigned)p.Hi &&
-                     (unsigned)(ax0[j] + kx) < (unsigned)p.Wi;
-      va[j] = v;
-      ra[j] = *reinterpret_cast<const f32x4*>(gin + (v ? abase[j] + toff : 0));
-      if constexpr (MUL) rm[j] = *reinterpret_cast<const f32x4*>(gmul + (v ? mbase[j] + moff : 0));
-      if constexpr (PER_N) {
-        rsc[j] = *reinterpret_cast<const f32x4*>(gsc + (cv ? nbase[j] + c : 0));
-        rsh[j] = *reinterpret_cast<const f32x4*>(gsh + (cv ? nbase[j] + c : 0));
-      }
-    }
-    if constexpr (AFF && !PER_N) {
-      rsc[0] = *reinterpret_cast<const f32x4*>(gsc + (cv ? c : 0));
-      rsh[0] = *reinterpret_cast<const f32x4*>(gsh + (cv ? c : 0));
-    }
-#pragma unroll
-    for (int j = 0; j < RB; ++j) {
-      const bool v = bval[j] && cv;
-      vb[j] = v;
-      rb[j] = *reinterpret_cast<const f32x4*>(gw + (v ? boff[j] + tap_ * Cin + c : 0));
-    }
+  // K position of the tile being LOADED = (channel chunk cc, tap = (kz,ky,kx)); taps vary FASTEST so that consecutive
+  // K steps read the same channel chunk at positions shifted by one tap: the shifted window is still in L1/L2, whereas a
+  // chunk-fastest order brings it back only after nChunks tiles per resident block (~4 MB per XCD: L2 thrash -> MALL).
+  int lt = it_begin;                       // index of the tile being loaded
+  int cc = it_begin / T;
+  int tap = it_begin - cc * T;
+  int kz = tap / khw, ky = (tap - kz * khw) / p.kw, kx = tap - kz * khw - ky * p.kw;
+  auto advance = [&]() {
+    lt += 1;
+    tap += 1; kx += 1; const bool w1 = kx == p.kw; kx = w1 ? 0 : kx;
+    ky += w1; const bool w2 = ky == p.kh; ky = w2 ? 0 : ky;
+    kz += w2; const bool w3 = kz == p.kd; kz = w3 ? 0 : kz;
+    tap = w3 ? 0 : tap; cc += w3;
   };
 
-  auto store_stage = [&](float* As, float* Bs) {
-#pragma unroll
-    for (int j = 0; j < RA; ++j) {
-      f32x4 v = ra[j];
-      if constexpr (MUL) v *= rm[j];
-      if constexpr (AFF) {
-        v = v * rsc[PER_N ? j : 0] + rsh[PER_N ? j : 0];
-        if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-      }
-      v = va[j] ? v : f32x4{0.f, 0.f, 0.f, 0.f};
-      *reinterpret_cast<f32x4*>(As + (lrow + 32 * j) * LDS_K + 4 * lseg) = v;
+  // All loads are unconditional (clamped to element 0 when masked, also beyond the K range) so that they pipeline;
+  // masking happens when the row is written to LDS.  A branch around a load makes hipcc wait for each one separately.
+  int toff = 0, moff = 0, cch = 0, woff = 0; bool cv = false;
+  auto begin_step = [&](auto S) {                 // uniform per-K-step offsets
+    constexpr int s = decltype(S)::value;
+    cch = cc * BK + 4 * lseg;
+    cv = (cch < Cin) & (lt < it_end);
+    toff = ((kz * p.Hi + ky) * p.Wi + kx) * p.ld_in + cch;
+    moff = (ky * p.Wi + kx) * Cin + cch;
+    woff = tap * Cin + cch;
+    if constexpr (AFF && !PER_N) { rsc[s][0] = ldg(gsc, cv ? cch : 0); rsh[s][0] = ldg(gsh, cv ? cch : 0); }
+  };
+  auto load_a = [&](auto S, int j) {
+    constexpr int s = decltype(S)::value;
+    const bool v = cv & ((unsigned)(az0[j] + kz) < (unsigned)p.Di) & ((unsigned)(ay0[j] + ky) < (unsigned)p.Hi) &
+                   ((unsigned)(ax0[j] + kx) < (unsigned)p.Wi);
+    va[s][j] = v;
+    ra[s][j] = ldg(gin, v ? abase[j] + toff : 0);
+    if constexpr (MUL) rm[s][j] = ldg(gmul, v ? mbase[j] + moff : 0);
+    if constexpr (PER_N) { rsc[s][j] = ldg(gsc, cv ? nbase[j] + cch : 0); rsh[s][j] = ldg(gsh, cv ? nbase[j] + cch : 0); }
+  };
+  auto load_b = [&](auto S, int j) {
+    constexpr int s = decltype(S)::value;
+    const bool v = bval[j] & cv;
+    vb[s][j] = v;
+    rb[s][j] = ldg(gw, v ? boff[j] + woff : 0);
+  };
+  auto store_a = [&](auto S, float* As, int j) {
+    constexpr int s = decltype(S)::value;
+    f32x4 v = ra[s][j];
+    if constexpr (MUL) v *= rm[s][j];
+    if constexpr (AFF) {
+      v = v * rsc[s][PER_N ? j : 0] + rsh[s][PER_N ? j : 0];
+      if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
     }
-#pragma unroll
-    for (int j = 0; j < RB; ++j)
-      *reinterpret_cast<f32x4*>(Bs + (lrow + 32 * j) * LDS_K + 4 * lseg) = vb[j] ? rb[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+    v = va[s][j] ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<f32x4*>(As + (lrow + 32 * j) * LDS_K + 4 * lseg) = v;
+  };
+  auto store_b = [&](auto S, float* Bs, int j) {
+    constexpr int s = decltype(S)::value;
+    *reinterpret_cast<f32x4*>(Bs + (lrow + 32 * j) * LDS_K + 4 * lseg) = vb[s][j] ? rb[s][j] : f32x4{0.f, 0.f, 0.f, 0.f};
   };
 
-  auto compute = [&](const float* As, const float* Bs) {
+  f32x4 fa[2][MT], fb[2][NT];
+  auto read_frags = [&](const float* As, const float* Bs, int kc) {
 #pragma unroll
-    for (int kc = 0; kc < BK / 8; ++kc) {
-      f32x4 a[MT], b[NT];
+    for (int i = 0; i < MT; ++i)
+      fa[kc & 1][i] = *reinterpret_cast<const f32x4*>(As + (wm * WM + i * 32 + li) * LDS_K + kc * 8 + 4 * lh);
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
-        a[i] = *reinterpret_cast<const f32x4*>(As + (wm * WM + i * 32 + li) * LDS_K + kc * 8 + 4 * lh);
+    for (int j = 0; j < NT; ++j)
+      fb[kc & 1][j] = *reinterpret_cast<const f32x4*>(Bs + (wn * WN + j * 32 + li) * LDS_K + kc * 8 + 4 * lh);
+  };
+  // MFMA number q of a K step, in (chunk kc, sub-step s, tile i, tile j) order
+  auto mfma_q = [&](int q) {
+    const int kc = q / (4 * MT * NT), r = q % (4 * MT * NT);
+    const int sidx = r / (MT * NT), i = (r % (MT * NT)) / NT, j = r % NT;
+    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kc & 1][i][sidx], fb[kc & 1][j][sidx], acc[i][j], 0, 0, 0);
+  };
+
+  // One K step = NP "pieces" of 2 MFMAs, each followed by a slice of the non-matrix work (one global load of K step
+  // t+2 early in the step, one LDS row store of K step t+1 late in the step, the fragment reads of the next chunk),
+  // with a scheduling barrier between pieces: v_mfma_f32_32x32x2_f32 holds the pipe for 64 cycles, i.e. ~14 issue
+  // slots per MFMA are free for other instructions, so a single wave can keep the matrix pipe fed.
+  constexpr int NMFMA = MT * NT * 16, NP = NMFMA / 2, QPC = NMFMA / 4 / 2;   // QPC = pieces per 8-wide chunk
+  constexpr int NROW = RA + RB;
+  static_assert(NP >= NROW, "tile too small for the piece schedule");
+  // PAR = parity of the tile being computed: loads go to register set PAR (tile t+2), stores come from set PAR^1.
+  auto k_step = [&](auto PAR, const float* As, const float* Bs, float* An, float* Bn) {
+    constexpr int par = decltype(PAR)::value;
+    using SL = std::integral_constant<int, par>;
+    using SS = std::integral_constant<int, par ^ 1>;
+    read_frags(As, Bs, 0);
 #pragma unroll
-      for (int j = 0; j < NT; ++j)
-        b[j] = *reinterpret_cast<const f32x4*>(Bs + (wn * WN + j * 32 + li) * LDS_K + kc * 8 + 4 * lh);
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int j = 0; j < NT; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+    for (int pc = 0; pc < NP; ++pc) {
+      if (pc % QPC == 0 && pc / QPC < 3 && G6D_ABLATE < 2) read_frags(As, Bs, pc / QPC + 1);
+      mfma_q(2 * pc); mfma_q(2 * pc + 1);
+      if (G6D_ABLATE < 1) {
+        if (pc == 0) { advance(); begin_step(SL{}); }
+        if (pc < RA) load_a(SL{}, pc); else if (pc < NROW) load_b(SL{}, pc - RA);
+        const int sr = pc - (NP - NROW);
+        if (sr >= 0) { if (sr < RA) store_a(SS{}, An, sr); else store_b(SS{}, Bn, sr - RA); }
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
 
   if (it_begin < it_end) {
-    issue_loads(tap, cc);
-    store_stage(lds, lds + BM * LDS_K);
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    begin_step(S0{});                                   // tile 0 -> set 0 -> LDS stage 0
+#pragma unroll
+    for (int j = 0; j < RA; ++j) load_a(S0{}, j);
+#pragma unroll
+    for (int j = 0; j < RB; ++j) load_b(S0{}, j);
+    advance(); begin_step(S1{});                        // tile 1 -> set 1 (stored during K step 0)
+#pragma unroll
+    for (int j = 0; j < RA; ++j) load_a(S1{}, j);
+#pragma unroll
+    for (int j = 0; j < RB; ++j) load_b(S1{}, j);
+#pragma unroll
+    for (int j = 0; j < RA; ++j) store_a(S0{}, lds, j);
+#pragma unroll
+    for (int j = 0; j < RB; ++j) store_b(S0{}, lds + BM * LDS_K, j);
     __syncthreads();
-    for (int it = it_begin; it < it_end; ++it) {
-      const int cur = (it - it_begin) & 1;
-      float* As = lds + cur * STAGE;
-      float* Bs = As + BM * LDS_K;
-      float* An = lds + (cur ^ 1) * STAGE;
-      float* Bn = An + BM * LDS_K;
-      const bool more = it + 1 < it_end;
-      if (more) {
-        if (++cc == nChunks) { cc = 0; ++tap; }
-        issue_loads(tap, cc);
+    float* L0 = lds; float* L1 = lds + STAGE;
+    for (int it = it_begin; it < it_end; it += 2) {
+      k_step(S0{}, L0, L0 + BM * LDS_K, L1, L1 + BM * LDS_K);
+      if (G6D_ABLATE < 3) __syncthreads();
+      if (it + 1 < it_end) {
+        k_step(S1{}, L1, L1 + BM * LDS_K, L0, L0 + BM * LDS_K);
+        if (G6D_ABLATE < 3) __syncthreads();
       }
-      // keep the consumers of the prefetched registers behind the MFMAs: otherwise hipcc hoists the masking/affine
-      // (and with it the s_waitcnt vmcnt) above the matrix work and the global-load latency is exposed every K step
-      __builtin_amdgcn_sched_barrier(0);
-      compute(As, Bs);
-      __builtin_amdgcn_sched_barrier(0);
-      if (more) store_stage(An, Bn);
-      __syncthreads();
     }
   }
 
@@ -263,7 +307,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const G6dConv p, const 
 
 // Sum split-K partials, then the same epilogue as above.  Thread = one row x 4 columns (16-byte loads, 4 splits in
 // flight); block = 32 column-quads x 8 rows, looping over 4 row groups (32 rows x 128 columns per block).
-__global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ ws, int splits, int M, int Cout,
+__global__ void __launch_bounds__(256) splitk_reduce_rows_kernel(const float* __restrict__ ws, int splits, int M, int Cout,
                                                             const float* __restrict__ bias, int act,
                                                             float* __restrict__ out, int ld_out, double* stats, int rpg) {
   __shared__ float sred[128 * 2];
@@ -326,6 +370,70 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
   }
 }
 
+// Variant for many splits / few output rows.  Block = 32 column-quads x 8 split lanes working on
+// 8 rows x 128 columns: the sum over splits is spread over the 8 lanes (16-byte loads) and combined through LDS, so the
+// small-M layers (few output tiles, many splits) still expose thousands of independent loads.
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ ws, int splits, int M, int Cout,
+                                                            const float* __restrict__ bias, int act,
+                                                            float* __restrict__ out, int ld_out, double* stats, int rpg) {
+  __shared__ f32x4 part[8][8][32];       // [row][split lane][column quad]
+  __shared__ float sred[128 * 2];
+  const int tx = threadIdx.x & 31, tz = threadIdx.x >> 5;
+  const int col = blockIdx.y * 128 + tx * 4;
+  const int r0 = blockIdx.x * 8;
+  const int rlast = min(r0 + 8, M) - 1;
+  const int g0 = rpg > 0 ? r0 / rpg : 0;
+  const bool one_group = rpg <= 0 || (rlast / rpg) == g0;
+  sred[threadIdx.x] = 0.f;
+  const bool vec = (Cout & 3) == 0;
+  const size_t zstride = (size_t)M * Cout;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int row = r0 + r;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (row < M && col < Cout) {
+      const float* src = ws + (size_t)row * Cout + col;
+      if (vec) {
+        for (int z = tz; z < splits; z += 8) v += *reinterpret_cast<const f32x4*>(src + (size_t)z * zstride);
+      } else {
+        for (int k = 0; k < 4; ++k)
+          if (col + k < Cout) for (int z = tz; z < splits; z += 8) v[k] += src[(size_t)z * zstride + k];
+      }
+    }
+    part[r][tz][tx] = v;
+  }
+  __syncthreads();
+  // thread (tz = row, tx = column quad) finishes one output quad
+  const int row = r0 + tz;
+  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+  if (row < M && col < Cout) {
+    f32x4 v = part[tz][0][tx];
+#pragma unroll
+    for (int z = 1; z < 8; ++z) v += part[tz][z][tx];
+    for (int k = 0; k < 4; ++k) {
+      if (col + k >= Cout) break;
+      const float o = apply_act(v[k] + (bias ? bias[col + k] : 0.f), act);
+      out[(size_t)row * ld_out + col + k] = o;
+      if (stats) {
+        if (one_group) { s1[k] = o; s2[k] = o * o; }
+        else {
+          double* st = stats + ((size_t)(row / rpg) * Cout + col + k) * 2;
+          atomicAdd(st, (double)o); atomicAdd(st + 1, (double)o * o);
+        }
+      }
+    }
+  }
+  if (stats && one_group) {
+    for (int k = 0; k < 4; ++k) { atomicAdd(&sred[(tx * 4 + k) * 2], s1[k]); atomicAdd(&sred[(tx * 4 + k) * 2 + 1], s2[k]); }
+    __syncthreads();
+    if (threadIdx.x < 128 && blockIdx.y * 128 + threadIdx.x < Cout) {
+      double* st = stats + ((size_t)g0 * Cout + blockIdx.y * 128 + threadIdx.x) * 2;
+      atomicAdd(st, (double)sred[threadIdx.x * 2]);
+      atomicAdd(st + 1, (double)sred[threadIdx.x * 2 + 1]);
+    }
+  }
+}
+
 template <int BM, int BN, int WGM, int WGN, int MODE>
 int launch_mode(const G6dConv& d, int M, int T, int nChunks, int splits, hipStream_t stream) {
   const int total = T * nChunks;
@@ -344,9 +452,15 @@ int launch_mode(const G6dConv& d, int M, int T, int nChunks, int splits, hipStre
   int rc = g6d_check_launch("conv_igemm");
   if (rc != G6D_OK) return rc;
   if (splits > 1) {
-    dim3 g2((M + 31) / 32, (d.Cout + 127) / 128);
-    hipLaunchKernelGGL(splitk_reduce_kernel, g2, dim3(256), 0, stream, d.workspace, splits, M, d.Cout, d.bias, d.out_act,
-                       d.out, d.ld_out, d.stats, d.stat_rows_per_group);
+    if (splits > 16) {
+      dim3 g2((M + 7) / 8, (d.Cout + 127) / 128);
+      hipLaunchKernelGGL(splitk_reduce_kernel, g2, dim3(256), 0, stream, d.workspace, splits, M, d.Cout, d.bias,
+                         d.out_act, d.out, d.ld_out, d.stats, d.stat_rows_per_group);
+    } else {
+      dim3 g2((M + 31) / 32, (d.Cout + 127) / 128);
+      hipLaunchKernelGGL(splitk_reduce_rows_kernel, g2, dim3(256), 0, stream, d.workspace, splits, M, d.Cout, d.bias,
+                         d.out_act, d.out, d.ld_out, d.stats, d.stat_rows_per_group);
+    }
     rc = g6d_check_launch("splitk_reduce");
   }
   return rc;
@@ -376,8 +490,8 @@ extern "C" int g6d_conv_igemm(const G6dConv* desc, g6d_stream_t stream_) {
     g6d_set_error("conv: operand pointers must be 16-byte aligned"); return G6D_EINVAL;
   }
   if (d.mul && !d.in_scale) { g6d_set_error("conv: mul requires in_scale/in_shift"); return G6D_EINVAL; }
-  if ((long long)d.N * d.Di * d.Hi * d.Wi * d.ld_in >= (1ll << 31) || (long long)d.Cout * d.kd * d.kh * d.kw * d.Cin >= (1ll << 31)) {
-    g6d_set_error("conv: tensor exceeds 2^31 elements"); return G6D_EINVAL;
+  if ((long long)d.N * d.Di * d.Hi * d.Wi * d.ld_in >= (1ll << 30) || (long long)d.Cout * d.kd * d.kh * d.kw * d.Cin >= (1ll << 30)) {
+    g6d_set_error("conv: tensor exceeds 2^30 elements (32-bit byte offsets)"); return G6D_EINVAL;
   }
   const long long Mll = (long long)d.N * d.Do * d.Ho * d.Wo;
   if (Mll > (1ll << 30)) { g6d_set_error("conv: M too large"); return G6D_EINVAL; }
@@ -388,14 +502,15 @@ extern "C" int g6d_conv_igemm(const G6dConv* desc, g6d_stream_t stream_) {
 
   // tile configuration
   int bm = 128, bn = d.Cout <= 32 ? 32 : (d.Cout <= 64 ? 64 : 128);
+  if (bn == 128 && (d.mul || (d.in_scale && d.in_affine_per_n))) bn = 64;   // 128x128 with two register sets + per-row tables would spill
   if (M <= 64 && d.Cout > 32) { bm = 64; bn = 64; }
   const long long blocks = (long long)((M + bm - 1) / bm) * ((d.Cout + bn - 1) / bn);
 
   int splits = d.split_k;
   if (splits <= 0) {
     splits = 1;
-    if (blocks < 384 && total >= 8) {
-      splits = (int)((768 + blocks - 1) / blocks);
+    if (blocks < 256 && total >= 8) {
+      splits = (int)((512 + blocks - 1) / blocks);
       if (splits > total / 4) splits = total / 4;
       if (splits > 64) splits = 64;
       if (splits < 1) splits = 1;

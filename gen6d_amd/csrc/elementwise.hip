@@ -104,43 +104,42 @@ __global__ void upsample_bilinear_kernel(const float* __restrict__ in, int ld_in
   }
 }
 
-// One block per (n, 32 consecutive positions). Phase 1: per-position L2 norm over C. Phase 2: LDS-tiled transpose.
-__global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* __restrict__ in, int C, int HW, int l2norm,
-                                                           float* __restrict__ out, int ld_out) {
-  __shared__ float tile[32][33];
-  __shared__ float part[8][32];
-  __shared__ float inv[32];
-  const int n = blockIdx.y, p0 = blockIdx.x * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+// Per-position inverse L2 norm over C of an NCHW tensor: thread = position, coalesced along HW.
+__global__ void __launch_bounds__(256) nchw_inv_norm_kernel(const float* __restrict__ in, int C, int HW,
+                                                            float* __restrict__ inv) {
+  __shared__ float part[4][64];
+  const int n = blockIdx.y, p = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
   const float* src = in + (size_t)n * C * HW;
-  const int p = p0 + tx;
-  if (l2norm) {
-    float s = 0.f;
-    if (p < HW) for (int c = ty; c < C; c += 8) { float v = src[(size_t)c * HW + p]; s += v * v; }
-    part[ty][tx] = s;
-    __syncthreads();
-    if (ty == 0) {
-      float t = 0.f;
-      for (int k = 0; k < 8; ++k) t += part[k][tx];
-      inv[tx] = 1.f / fmaxf(sqrtf(t), 1e-12f);
-    }
-    __syncthreads();
+  float s = 0.f;
+  if (p < HW) for (int c = q; c < C; c += 4) { float v = src[(size_t)c * HW + p]; s += v * v; }
+  part[q][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (q == 0 && p < HW) {
+    float t = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+    inv[(size_t)n * HW + p] = 1.f / fmaxf(sqrtf(t), 1e-12f);
   }
-  for (int c0 = 0; c0 < C; c0 += 32) {
-    for (int k = ty; k < 32; k += 8) {
-      int c = c0 + k;
-      tile[k][tx] = (c < C && p < HW) ? src[(size_t)c * HW + p] : 0.f;
+}
+
+// LDS-tiled transpose: block = (64 positions x 64 channels) tile; reads coalesced along HW, writes along C.
+__global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* __restrict__ in, int C, int HW,
+                                                           const float* __restrict__ inv, float* __restrict__ out,
+                                                           int ld_out) {
+  __shared__ float tile[64][65];
+  const int n = blockIdx.z, p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const float* src = in + (size_t)n * C * HW;
+  for (int k = ty; k < 64; k += 4) {
+    const int c = c0 + k, p = p0 + tx;
+    tile[k][tx] = (c < C && p < HW) ? src[(size_t)c * HW + p] : 0.f;
+  }
+  __syncthreads();
+  for (int k = ty; k < 64; k += 4) {           // k = position, tx = channel
+    const int p = p0 + k, c = c0 + tx;
+    if (p < HW && c < C) {
+      float v = tile[tx][k];
+      if (inv) v *= inv[(size_t)n * HW + p];
+      out[((size_t)n * HW + p) * ld_out + c] = v;
     }
-    __syncthreads();
-    for (int k = ty; k < 32; k += 8) {          // k = position, tx = channel
-      int pp = p0 + k, c = c0 + tx;
-      if (pp < HW && c < C) {
-        float v = tile[tx][k];
-        if (l2norm) v *= inv[k];
-        out[((size_t)n * HW + pp) * ld_out + c] = v;
-      }
-    }
-    __syncthreads();
   }
 }
 
@@ -313,10 +312,18 @@ extern "C" int g6d_upsample_bilinear(const float* in, int ld_in, const float* sc
 }
 
 extern "C" int g6d_nchw_to_nhwc(const float* in, int N, int C, int H, int W, int l2norm, float* out, int ld_out,
-                                g6d_stream_t stream) {
-  if (!in || !out || N <= 0 || C <= 0 || H <= 0 || W <= 0 || ld_out < C) { g6d_set_error("nchw_to_nhwc: bad args"); return G6D_EINVAL; }
+                                float* scratch, g6d_stream_t stream) {
+  if (!in || !out || N <= 0 || C <= 0 || H <= 0 || W <= 0 || ld_out < C || (l2norm && !scratch)) {
+    g6d_set_error("nchw_to_nhwc: bad args (l2norm needs a scratch of N*H*W floats)"); return G6D_EINVAL;
+  }
   const int HW = H * W;
-  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((HW + 31) / 32, N), dim3(256), 0, STREAM(stream), in, C, HW, l2norm, out, ld_out);
+  if (l2norm) {
+    hipLaunchKernelGGL(nchw_inv_norm_kernel, dim3((HW + 63) / 64, N), dim3(256), 0, STREAM(stream), in, C, HW, scratch);
+    int rc = g6d_check_launch("nchw_inv_norm");
+    if (rc != G6D_OK) return rc;
+  }
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((HW + 63) / 64, (C + 63) / 64, N), dim3(256), 0, STREAM(stream), in, C, HW,
+                     l2norm ? scratch : nullptr, out, ld_out);
   return g6d_check_launch("nchw_to_nhwc");
 }
 

@@ -29,13 +29,21 @@ __device__ __forceinline__ f32x4 sample_view(const float* __restrict__ fmap, int
   fy = fminf(fmaxf(fy, -4.f), (float)fh + 4.f);
   int x0 = (int)fx, y0 = (int)fy;
   float wx1 = ix - fx, wy1 = iy - fy, wx0 = (fx + 1.f) - ix, wy0 = (fy + 1.f) - iy;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  // unconditional, clamped loads (branches around loads serialise them); out-of-range taps get weight 0
   const bool xv0 = (unsigned)x0 < (unsigned)fw, xv1 = (unsigned)(x0 + 1) < (unsigned)fw;
   const bool yv0 = (unsigned)y0 < (unsigned)fh, yv1 = (unsigned)(y0 + 1) < (unsigned)fh;
-  if (yv0 && xv0) acc += (wx0 * wy0) * *reinterpret_cast<const f32x4*>(fmap + ((size_t)y0 * fw + x0) * C + c);
-  if (yv0 && xv1) acc += (wx1 * wy0) * *reinterpret_cast<const f32x4*>(fmap + ((size_t)y0 * fw + x0 + 1) * C + c);
-  if (yv1 && xv0) acc += (wx0 * wy1) * *reinterpret_cast<const f32x4*>(fmap + ((size_t)(y0 + 1) * fw + x0) * C + c);
-  if (yv1 && xv1) acc += (wx1 * wy1) * *reinterpret_cast<const f32x4*>(fmap + ((size_t)(y0 + 1) * fw + x0 + 1) * C + c);
+  const int xc0 = min(max(x0, 0), fw - 1), xc1 = min(max(x0 + 1, 0), fw - 1);
+  const int yc0 = min(max(y0, 0), fh - 1), yc1 = min(max(y0 + 1, 0), fh - 1);
+  const f32x4 v00 = *reinterpret_cast<const f32x4*>(fmap + ((size_t)yc0 * fw + xc0) * C + c);
+  const f32x4 v01 = *reinterpret_cast<const f32x4*>(fmap + ((size_t)yc0 * fw + xc1) * C + c);
+  const f32x4 v10 = *reinterpret_cast<const f32x4*>(fmap + ((size_t)yc1 * fw + xc0) * C + c);
+  const f32x4 v11 = *reinterpret_cast<const f32x4*>(fmap + ((size_t)yc1 * fw + xc1) * C + c);
+  const float w00 = (yv0 && xv0) ? wx0 * wy0 : 0.f, w01 = (yv0 && xv1) ? wx1 * wy0 : 0.f;
+  const float w10 = (yv1 && xv0) ? wx0 * wy1 : 0.f, w11 = (yv1 && xv1) ? wx1 * wy1 : 0.f;
+  f32x4 acc = w00 * v00;
+  acc += w01 * v01;
+  acc += w10 * v10;
+  acc += w11 * v11;
   return acc;
 }
 

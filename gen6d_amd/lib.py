@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgen6d_hip.so")
+LIB_PATH = os.environ.get("G6D_LIB_PATH") or os.path.join(_HERE, "libgen6d_hip.so")   # env override: profiling builds
 
 G6D_ERRORS = {-1: "G6D_EINVAL", -2: "G6D_ENOSPC", -3: "G6D_ELAUNCH"}
 
@@ -33,7 +33,7 @@ SIGNATURES = {
     "g6d_stats_finalize": [_P, _I, _D, _D, _P, _P, _P],
     "g6d_affine_act_pool": [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P],
     "g6d_upsample_bilinear": [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P],
-    "g6d_nchw_to_nhwc": [_P, _I, _I, _I, _I, _I, _P, _I, _P],
+    "g6d_nchw_to_nhwc": [_P, _I, _I, _I, _I, _I, _P, _I, _P, _P],
     "g6d_selector_ref_sums": [_P, _I, _I, _I, _P, _P, _P],
     "g6d_selector_prod_affine": [_P, _P, _P, _I, _I, _I, _D, _P, _P, _P],
     "g6d_selector_scan": [_P, _P, _I, _I, _I, _P, _P, _P],

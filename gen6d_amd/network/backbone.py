@@ -10,10 +10,17 @@ from .. import specs
 _POOL_BEFORE = (1, 2, 4, 6)          # positions (in the list of 8 convs) preceded by a 2x2 max-pool
 
 
+_NORM = {}
+
+
 def img_norm(x):
-    """torchvision.transforms.Normalize(ImageNet) on [n,3,h,w] in [0,1]."""
-    m = torch.tensor(specs.IMAGENET_MEAN, dtype=x.dtype, device=x.device).view(1, 3, 1, 1)
-    s = torch.tensor(specs.IMAGENET_STD, dtype=x.dtype, device=x.device).view(1, 3, 1, 1)
+    """torchvision.transforms.Normalize(ImageNet) on [n,3,h,w] in [0,1]. Constants are cached per device so that the
+    call is capturable in a hipGraph (no host-to-device copy on the query path)."""
+    key = (str(x.device), x.dtype)
+    if key not in _NORM:
+        _NORM[key] = (torch.tensor(specs.IMAGENET_MEAN, dtype=x.dtype, device=x.device).view(1, 3, 1, 1),
+                      torch.tensor(specs.IMAGENET_STD, dtype=x.dtype, device=x.device).view(1, 3, 1, 1))
+    m, s = _NORM[key]
     return (x - m) / s
 
 

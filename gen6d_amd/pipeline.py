@@ -52,3 +52,28 @@ class TensorPipeline:
                 rot, off, scl = self.refiner._step(que_crop, r["Ks_in"][0], self.iter_poses[it][0], r["ref_imgs"][0],
                                                    r["ref_Ks"][0], r["ref_poses"][0])
         return torch.cat([det["positions"], det["scales"][:, None], idx[:, None].float(), ang[:, None], rot, off, scl], 1)
+
+    # ------------------------------------------------------------------ hipGraph
+    def capture(self, full_shape=(1, 3, 480, 640), crop_shape=(1, 3, 128, 128), warmup=2):
+        """Capture one query (~770 kernel launches: MIOpen trunk + HIP kernels) into a hipGraph with static input /
+        output buffers; `query_graph` then replays it.  Removes the per-launch host cost of the eager path."""
+        d = self.device
+        self._g_full = torch.zeros(full_shape, dtype=torch.float32, device=d)
+        self._g_crop = torch.zeros(crop_shape, dtype=torch.float32, device=d)
+        side = torch.cuda.Stream(device=d)
+        side.wait_stream(torch.cuda.current_stream(d))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):                      # MIOpen find, workspace and allocator warm-up off-graph
+                self.query(self._g_full, self._g_crop)
+        torch.cuda.current_stream(d).wait_stream(side)
+        torch.cuda.synchronize(d)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._g_out = self.query(self._g_full, self._g_crop)
+        return self._graph
+
+    def query_graph(self, que_full, que_crop):
+        self._g_full.copy_(que_full, non_blocking=True)
+        self._g_crop.copy_(que_crop, non_blocking=True)
+        self._graph.replay()
+        return self._g_out.clone()
