@@ -94,12 +94,16 @@ class Detector(ParamBank):
         dev = que_img.device
         rfn = self.ref_center_feats[0].shape[0]
         stacked = torch.empty((hs * ws, rfn, 12), dtype=torch.float32, device=dev)
-        for si, scale in enumerate(self.cfg["detection_scales"]):
+        def one_scale(si, scale):
             ht, wt = int(np.round(hq * 2 ** scale)), int(np.round(wq * 2 ** scale))
             if ht % 32 != 0: ht = (ht // 32 + 1) * 32
             if wt % 32 != 0: wt = (wt // 32 + 1) * 32
             cur = F.interpolate(que_img, size=(ht, wt), mode="bilinear")
             self._scores_one_scale(cur, si, stacked, hs, ws)
+
+        # the scales are independent until `stacked` is complete: largest first on the main stream
+        order = sorted(enumerate(self.cfg["detection_scales"]), key=lambda t: -t[1])
+        ops.fork_join([(lambda si=si, sc=sc: one_scale(si, sc)) for si, sc in order], dev)
         feats = ops.detector_score_mlp_max(stacked, *pk["mlp"])               # [P,64]
         P = hs * ws
         k3, p3 = (1, 3, 3), (0, 1, 1)

@@ -81,12 +81,19 @@ class VolumeRefiner(ParamBank):
 
         hq, wq = h // 4, w // 4
         cat = torch.empty((n, 1, hq, wq, 192), dtype=torch.float32, device=dev)
-        y, sc, sh = pair("conv0", nhwc(t["c3"]))
-        ops.affine_act_pool(y, cat[..., 0:64], sc, sh, per_n=True)
-        y, sc, sh = pair("conv1", nhwc(t["c5"]))
-        ops.upsample_bilinear(y, cat[..., 64:128], 2, sc, sh, per_n=True)
-        y, sc, sh = pair("conv2", nhwc(t["c7_pre"]))
-        ops.upsample_bilinear(y, cat[..., 128:192], 4, sc, sh, per_n=True)
+        def b0():
+            y, sc, sh = pair("conv0", nhwc(t["c3"]))
+            ops.affine_act_pool(y, cat[..., 0:64], sc, sh, per_n=True)
+
+        def b1():
+            y, sc, sh = pair("conv1", nhwc(t["c5"]))
+            ops.upsample_bilinear(y, cat[..., 64:128], 2, sc, sh, per_n=True)
+
+        def b2():
+            y, sc, sh = pair("conv2", nhwc(t["c7_pre"]))
+            ops.upsample_bilinear(y, cat[..., 128:192], 4, sc, sh, per_n=True)
+
+        ops.fork_join([b0, b1, b2], dev)
         y, sc, sh = pair("conv_out", cat)
         out = torch.empty((n, 1, hq, wq, 128), dtype=torch.float32, device=dev)
         ops.affine_act_pool(y, out, sc, sh, per_n=True)
@@ -110,11 +117,13 @@ class VolumeRefiner(ParamBank):
             return torch.empty((1, s, s, s, c), dtype=torch.float32, device=dev)
 
         cat = buf(sn, 128)
-        for name, x, sl in (("v_mean_embed", mean_in.view(1, sn, sn, sn, 256), slice(0, 64)),
-                            ("v_var_embed", std.view(1, sn, sn, sn, 128), slice(64, 128))):
+        def embed(name, x, sl):
             y = buf(sn, 64)
             st = c3(x, pk[name][0], y, stats_c=64)
             c3(y, pk[name][1], cat[..., sl], aff=ops.stats_finalize(st, vox))
+
+        embed("v_mean_embed", mean_in.view(1, sn, sn, sn, 256), slice(0, 64))
+        embed("v_var_embed", std.view(1, sn, sn, sn, 128), slice(64, 128))
         x, aff, s = cat, None, sn
         for name, co, stride in (("v_conv0", 64, 1), ("v_conv1", 128, 2), ("v_conv2", 128, 1), ("v_conv3", 256, 2),
                                  ("v_conv4", 256, 1)):

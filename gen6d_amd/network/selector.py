@@ -155,7 +155,7 @@ class ViewpointSelector(ParamBank):
         dev = que_img.device
         qf = self.get_feats(que_img)
         cat = torch.empty((D, 1, 4, 4, 768), dtype=torch.float32, device=dev)
-        vps = torch.stack([self._level(l, qf[l], cat) for l in range(3)], 0)           # [3,D]
+        vps = torch.stack(ops.fork_join([(lambda l=l: self._level(l, qf[l], cat)) for l in range(3)], dev), 0)   # [3,D]
 
         # corr_feats_conv: 1x1x1 768->512, IN3d, ReLU, (AvgPool commuted) 512->512   selector.py:71-77,197-200
         y = torch.empty((D, 1, 4, 4, 512), dtype=torch.float32, device=dev)

@@ -16,7 +16,7 @@ import torch
 from . import lib as _lib
 
 _WS = {}
-WORKSPACE_BYTES = 256 << 20
+WORKSPACE_BYTES = 96 << 20
 # When set to a list, conv() brackets every g6d_conv_igemm launch with HIP events recorded on the launch stream and
 # appends (algorithmic flops, start, end); bench.py turns this into the roofline entry.
 PROFILE = None
@@ -42,10 +42,35 @@ def marker(i):
 
 
 def workspace(device):
-    key = str(device)
+    """Split-K scratch, one buffer per (device, stream): launches on different streams may overlap."""
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
     if key not in _WS:
         _WS[key] = torch.empty(WORKSPACE_BYTES // 4, dtype=torch.float32, device=device)
     return _WS[key]
+
+
+_SIDE = {}
+
+
+def fork_join(fns, device):
+    """Run independent launch sequences concurrently: fns[0] on the current stream, the others on cached side streams
+    forked from it and joined back (capturable in a hipGraph as parallel branches).  Independent stages of the path
+    (detector scales, selector pyramid levels, refiner feature branches) are small grids that do not fill 256 CUs."""
+    main = torch.cuda.current_stream(device)
+    streams = _SIDE.setdefault(str(device), [])
+    while len(streams) < len(fns) - 1:
+        streams.append(torch.cuda.Stream(device=device))
+    results = [None] * len(fns)
+    for i, fn in enumerate(fns[1:]):
+        s = streams[i]
+        s.wait_stream(main)
+        with torch.cuda.stream(s):
+            workspace(device)                    # make sure the per-stream scratch exists
+            results[i + 1] = fn()
+    results[0] = fns[0]()
+    for i in range(len(fns) - 1):
+        main.wait_stream(streams[i])
+    return results
 
 
 def _cl5(t, name):

@@ -14,6 +14,10 @@ def workspace(device):
     return None
 
 
+def fork_join(fns, device):
+    return [fn() for fn in fns]
+
+
 def _act(v, act):
     if act == 1: return F.relu(v)
     if act == 2: return F.leaky_relu(v, 0.1)
