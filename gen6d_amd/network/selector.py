@@ -11,12 +11,20 @@ Query-time data flow (reference compute_view_point_feats, selector.py:177-215), 
     g6d_affine_act_pool        only where a MaxPool sits between two convs
   tail: 1x1 convs as GEMMs on the same MFMA kernel, g6d_vps_norm, g6d_max_an_add, g6d_attention, g6d_layernorm,
         g6d_affine_act_add.  AvgPool(1,4,4) is commuted in front of the last 1x1x1 conv (both linear).
+
+Reference-sharded mode (`set_shard(rank, world)`): every rank keeps the cache of a contiguous slice of
+the references (all rotations of a reference stay together).  The logits of one reference depend on all references
+through the InstanceNorms, so the exchange is: one all-reduce of R1/R2 at build time; at query time one all-reduce of
+the 2*C fp64 (sum, sumsq) per InstanceNorm layer (<= 8 KB each), one all-gather of the vps scalars, one all-gather of the per-reference feature rows [rfn/G, 512] before the
+replicated attention tail, and one all-gather of the per-reference angles (RCCL over xGMI via torch.distributed;
+messages are KB-sized, i.e. latency-bound).  Results equal the unsharded ones up to fp reassociation of the sums.
 """
 import numpy as np
 import torch
+import torch.distributed as dist
 import torch.nn.functional as F
 
-from .. import ops, specs
+from .. import ops, parallel, specs
 from .backbone import img_norm, vgg_taps
 from .params import ParamBank, fold_vgg
 
@@ -40,6 +48,39 @@ class ViewpointSelector(ParamBank):
         self.ref_sums = None             # 3 x (R1, R2) fp64 [HW_l, 512]
         self.ref_pose_embed = None       # [rfn, 512]
         self.rfn = self.an = None
+        self.rank, self.world, self.group = 0, 1, None
+        self.r_begin, self.r_end = 0, None
+
+    # ------------------------------------------------------------------ reference sharding
+    def set_shard(self, rank, world, group=None):
+        """Keep only references [begin, end) = parallel.shard_range(rfn, rank, world) on this rank (call before
+        load_ref_imgs / extract_ref_feats). world == 1 restores the unsharded behaviour."""
+        self.rank, self.world, self.group = int(rank), int(world), group
+
+    def _allreduce(self, tensors):
+        """Sum small fp64 statistics tensors over the ranks in ONE collective."""
+        if self.world == 1:
+            return
+        flat = torch.cat([t.reshape(-1) for t in tensors])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        o = 0
+        for t in tensors:
+            t.copy_(flat[o:o + t.numel()].view_as(t)); o += t.numel()
+
+    def _allgather_rows(self, rows, n_total):
+        """[n_local, F] per rank -> [n_total, F] in global reference order."""
+        if self.world == 1:
+            return rows
+        cap = (n_total + self.world - 1) // self.world
+        pad = torch.zeros((cap, rows.shape[1]), dtype=rows.dtype, device=rows.device)
+        pad[:rows.shape[0]] = rows
+        bufs = [torch.empty_like(pad) for _ in range(self.world)]
+        dist.all_gather(bufs, pad, group=self.group)
+        out = []
+        for r in range(self.world):
+            b, e = parallel.shard_range(n_total, r, self.world)
+            out.append(bufs[r][:e - b])
+        return torch.cat(out, 0)
 
     # ------------------------------------------------------------------ weights
     def _pack(self):
@@ -92,7 +133,11 @@ class ViewpointSelector(ParamBank):
         if an != self.cfg["selector_angle_num"]:
             raise ValueError("number of rotations does not match selector_angle_num")
         self.rfn, self.an = rfn, an
-        D = rfn * an
+        self.r_begin, self.r_end = parallel.shard_range(rfn, self.rank, self.world)
+        if self.r_end == self.r_begin:
+            raise ValueError("more ranks than reference views")
+        ref_imgs = ref_imgs[:, self.r_begin:self.r_end]
+        D = (self.r_end - self.r_begin) * an                                 # local hypotheses
         imgs = ref_imgs.permute(1, 0, 2, 3, 4).reshape(D, 3, h, w)          # d = r*an + a
         dev = imgs.device
         cache = [torch.empty((D, 1, h >> s, w >> s, 512), dtype=torch.float32, device=dev) for s in (3, 4, 5)]
@@ -102,6 +147,7 @@ class ViewpointSelector(ParamBank):
                 cache[l][i0:i0 + 64].copy_(feats[l])
         self.ref_feats_cache = cache
         self.ref_sums = [ops.selector_ref_sums(c.view(D, -1, 512)) for c in cache]
+        self._allreduce([t for pair in self.ref_sums for t in pair])         # R1/R2 over ALL references
 
         # viewpoint embedding: tiny one-time MLP on [rfn,3] (torch ops on the device)
         cam = (-ref_poses[:, :3, :3].transpose(1, 2) @ ref_poses[:, :3, 3:])[..., 0] - object_center[None]
@@ -123,9 +169,10 @@ class ViewpointSelector(ParamBank):
         cache, (r1, r2) = self.ref_feats_cache[l], self.ref_sums[l]
         D, _, h, w, _ = cache.shape
         dev = cache.device
+        Dg = self.rfn * self.an                                              # global hypothesis count
         q2 = q.view(h * w, 512)
         _, vps = ops.selector_scan(q2, cache.view(D, h * w, 512))
-        scale, shift = ops.selector_prod_affine(q2, r1, r2, D)
+        scale, shift = ops.selector_prod_affine(q2, r1, r2, Dg)
         x, mul, relu = cache, q.view(h, w, 512), False
         layers = _CORR[l]
         for li, (idx, has_in, has_relu, has_pool) in enumerate(layers):
@@ -138,7 +185,8 @@ class ViewpointSelector(ParamBank):
             mul = None
             if last:
                 break
-            scale, shift = ops.stats_finalize(stats, D * h * w)
+            self._allreduce([stats])
+            scale, shift = ops.stats_finalize(stats, Dg * h * w)
             if has_pool:
                 h, w = h // 2, w // 2
                 pooled = torch.empty((D, 1, h, w, co), dtype=torch.float32, device=dev)
@@ -150,31 +198,45 @@ class ViewpointSelector(ParamBank):
 
     def _query_one(self, que_img):
         pk = self._pack()
-        rfn, an = self.rfn, self.an
-        D = rfn * an
+        an = self.an
+        rfn_all, rfn = self.rfn, self.r_end - self.r_begin                  # global / local reference counts
+        D, Dg = rfn * an, rfn_all * an
         dev = que_img.device
         qf = self.get_feats(que_img)
         cat = torch.empty((D, 1, 4, 4, 768), dtype=torch.float32, device=dev)
-        vps = torch.stack(ops.fork_join([(lambda l=l: self._level(l, qf[l], cat)) for l in range(3)], dev), 0)   # [3,D]
+        levels = [(lambda l=l: self._level(l, qf[l], cat)) for l in range(3)]
+        # collectives must be issued in the same order on every rank: no stream fork in sharded mode
+        vps = torch.stack(ops.fork_join(levels, dev) if self.world == 1 else [f() for f in levels], 0)           # [3,D]
 
         # corr_feats_conv: 1x1x1 768->512, IN3d, ReLU, (AvgPool commuted) 512->512   selector.py:71-77,197-200
         y = torch.empty((D, 1, 4, 4, 512), dtype=torch.float32, device=dev)
         st = ops.new_stats(1, 512, dev)
         ops.conv(cat, pk["fuse0"][0], pk["fuse0"][1], y, stats=st)
-        sc, sh = ops.stats_finalize(st, D * 16)
+        self._allreduce([st])
+        sc, sh = ops.stats_finalize(st, Dg * 16)
         pooled = torch.empty((D, 1, 1, 1, 512), dtype=torch.float32, device=dev)
         ops.affine_act_pool(y, pooled, sc, sh, relu=True, pool=2)
         feats = torch.zeros((D, FEAT_LD), dtype=torch.float32, device=dev)
         ops.conv(pooled.view(1, 1, 1, D, 512), pk["fuse3"][0], pk["fuse3"][1], feats.view(1, 1, 1, D, FEAT_LD)[..., :512])
-        ops.vps_norm(vps, feats, 512)                                                   # selector.py:201-202
+        if self.world == 1:
+            ops.vps_norm(vps, feats, 512)                                               # selector.py:201-202
+        else:                                                                           # norm over ALL hypotheses
+            vall = self._allgather_rows(vps.T.contiguous().view(rfn, an * 3), rfn_all).view(Dg, 3).T.contiguous()
+            fall = torch.zeros((Dg, FEAT_LD), dtype=torch.float32, device=dev)
+            ops.vps_norm(vall, fall, 512)
+            feats[:, 512:515] = fall[self.r_begin * an:self.r_end * an, 512:515]
 
         # score_process + max over rotations + viewpoint embedding                     selector.py:204-205
         t0 = torch.empty((1, 1, 1, D, 512), dtype=torch.float32, device=dev)
         ops.conv(feats.view(1, 1, 1, D, FEAT_LD), pk["sp0"][0], pk["sp0"][1], t0, out_act=1)
         t1 = torch.empty_like(t0)
         ops.conv(t0, pk["sp2"][0], pk["sp2"][1], t1)
+        xl = torch.empty((rfn, 512), dtype=torch.float32, device=dev)
+        ops.max_an_add(t1.view(D, 512), rfn, an, self.ref_pose_embed[self.r_begin:self.r_end].contiguous(), xl)
+        feats_l, rfn_l = feats, rfn
+        rfn = rfn_all                                                                   # the tail runs on ALL refs
         xm = torch.empty((rfn, 1024), dtype=torch.float32, device=dev)                  # [x | msg]
-        ops.max_an_add(t1.view(D, 512), rfn, an, self.ref_pose_embed, xm[:, :512])
+        xm[:, :512] = self._allgather_rows(xl, rfn_all)
 
         def tok(t):          # [n, C] (row-strided) -> conv view [1,1,1,n,C]
             return t.as_strided((1, 1, 1, t.shape[0], t.shape[1]), (0, 0, 0, t.stride(0), 1), t.storage_offset())
@@ -205,13 +267,13 @@ class ViewpointSelector(ParamBank):
         ops.conv(tok(p0), pk["pred2"][0], pk["pred2"][1], tok(logits))
 
         # angle head on the per-reference rows [an*516]                                 selector.py:212-214
-        a0 = torch.empty((rfn, 512), dtype=torch.float32, device=dev)
-        ops.conv(tok(feats.view(rfn, an * FEAT_LD)), pk["ang0"][0], pk["ang0"][1], tok(a0), out_act=1)
+        a0 = torch.empty((rfn_l, 512), dtype=torch.float32, device=dev)
+        ops.conv(tok(feats_l.view(rfn_l, an * FEAT_LD)), pk["ang0"][0], pk["ang0"][1], tok(a0), out_act=1)
         a1 = torch.empty_like(a0)
         ops.conv(tok(a0), pk["ang2"][0], pk["ang2"][1], tok(a1), out_act=1)
-        angles = torch.empty((rfn, 1), dtype=torch.float32, device=dev)
+        angles = torch.empty((rfn_l, 1), dtype=torch.float32, device=dev)
         ops.conv(tok(a1), pk["ang4"][0], pk["ang4"][1], tok(angles))
-        return logits[:, 0], angles[:, 0]
+        return logits[:, 0], self._allgather_rows(angles, rfn_all)[:, 0]
 
     def compute_view_point_feats(self, que_imgs):
         """que_imgs [qn,3,h,w] in [0,1] -> logits [qn,rfn], angles [qn,rfn] (reference selector.py:177-215)."""

@@ -49,3 +49,45 @@ def test_two_rank_gloo_gather(tmp_path):
                          env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count("ok") == 2
+
+
+SHARD_WORKER = textwrap.dedent("""
+    import sys, numpy as np, torch
+    sys.path.insert(0, %r); sys.path.insert(0, %r)
+    import ref_ops
+    from gen6d_amd import ops, parallel, synth
+    from gen6d_amd.network import name2network
+    for name in dir(ops):                       # CPU emulation of the HIP ops (host-logic test)
+        if not name.startswith("_") and callable(getattr(ops, name)) and hasattr(ref_ops, name):
+            setattr(ops, name, getattr(ref_ops, name))
+    rank, world, local = parallel.init_from_env(backend="gloo")
+    g = dict(np.load(%r))
+    rfn, an = int(g["rfn"]), int(g["an"])
+    net = name2network["selector"]({"name": "t", "selector_angle_num": an}).eval()
+    net.load_state_dict(synth.synth_state_dict("selector", an=an))
+    net.set_shard(rank, world)
+    case = synth.selector_case(rfn, an)
+    with torch.no_grad():
+        out = net({"ref_imgs": case["ref_imgs"], "ref_imgs_info": {"poses": case["ref_poses"]},
+                   "object_center": case["object_center"], "object_vert": case["object_vert"],
+                   "que_imgs_info": {"imgs": case["que_imgs"]}, "eval": True})
+    b, e = parallel.shard_range(rfn, rank, world)
+    assert net.ref_feats_cache[0].shape[0] == (e - b) * an          # only the local slice of the cache is resident
+    np.testing.assert_allclose(out["ref_vp_logits"].numpy(), g["logits"], atol=2e-3)
+    np.testing.assert_allclose(out["angles_pr"].numpy(), g["angles"], atol=2e-3)
+    assert np.array_equal(out["ref_vp_logits"].argmax(1).numpy(), g["logits"].argmax(1))
+    print("rank", rank, "sharded selector ok")
+""")
+
+
+@pytest.mark.parametrize("world,port", [(2, 29631), (3, 29633)])
+def test_reference_sharded_selector_matches_golden(tmp_path, world, port):
+    """8 references x 5 rotations sharded over 2 / 3 (ragged) gloo ranks reproduce the reference's logits."""
+    script = tmp_path / "shard_worker.py"
+    script.write_text(SHARD_WORKER % (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden", "sel_small.npz")))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert out.stdout.count("sharded selector ok") == world
