@@ -47,6 +47,7 @@ SIGNATURES = {
     "g6d_layernorm": [_P, _I, _I, _I, _P, _P, _F, _P, _I, _P],
     "g6d_affine_act_add": [_P, _I, _P, _P, _I, _P, _I, _I, _I, _P, _I, _P],
     "g6d_linear_gemv": [_P, _I, _I, _P, _P, _I, _I, _P, _P],
+    "g6d_warp_perspective": [_P, _I, _I, _I, C.POINTER(C.c_float), _P, _I, _I, _I, _F, _P],
 }
 
 _lib = None

@@ -179,6 +179,42 @@ class VolumeRefiner(ParamBank):
         self.ref_database = ref_database
         self.ref_ids = ref_ids
 
+    def refine_que_imgs(self, que_img, que_K, in_pose, size=128, ref_num=6, ref_even=False):
+        """One refinement step with the reference's signature (refiner.py:275-341): que_img uint8 [H,W,3] (numpy or a
+        device tensor), que_K [3,3], in_pose [3,4] -> refined pose [3,4] float32.  The look-at crop of the query and the
+        6 aligned reference crops are device warps (g6d_warp_perspective) of images cached on the GPU; the pose algebra
+        stays on the host."""
+        from .. import estimator as E
+        from .. import geometry as G
+        margin, even_num = 0.05, min(128, len(self.ref_ids))
+        dev = self.device_()
+        cache = getattr(self, "image_cache", None) or E.DeviceImageCache(dev)
+        self.image_cache = cache
+        db = E.NormalizedDatabase(self.ref_database)
+        in_pose = G.normalize_pose(np.asarray(in_pose, np.float64), db.scale, db.offset)
+        center, diameter = db.object_center, db.object_diameter
+        que_K = np.asarray(que_K, np.float64)
+        _, new_f = G.let_me_look_at(in_pose, que_K, center)
+        in_dist = np.linalg.norm(G.pose_inverse(in_pose)[:, 3] - center)
+        scale = size * (1 - margin) / diameter * in_dist / new_f
+        position = G.project_points(center[None], in_pose, que_K)[0][0]
+        K_warp, pose_warp, pose_rect, H = G.look_at_crop_params(que_K, in_pose, position, 0, scale, size, size)
+        if not torch.is_tensor(que_img):
+            que_img = torch.from_numpy(np.ascontiguousarray(que_img)).to(dev)
+        que_warp = ops.warp_perspective(que_img, H, size, size)
+        ref_ids = E.select_reference_img_ids_refinement(db, center, self.ref_ids, pose_warp, ref_num, ref_even, even_num)
+        ref_imgs, ref_Ks, ref_poses, _ = E.normalize_reference_views(db, ref_ids, size, margin, cache, True, pose_warp, K_warp)
+        f = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+        with torch.no_grad():
+            rot, off, scl = self._step(que_warp.float().div_(255).permute(2, 0, 1)[None].contiguous(), f(K_warp), f(pose_warp),
+                                       ref_imgs.float().div_(255).permute(0, 3, 1, 2).contiguous(), f(ref_Ks), f(ref_poses))
+            out = torch.cat([rot[0], off[0], scl[0]]).cpu().numpy()
+        quat, offset, scale_pr = out[:4], out[4:6], 2 ** out[6]
+        pose_sim = G.compose_sim_pose(scale_pr, quat, offset, pose_warp, center)
+        pose_pr = G.pose_sim_to_pose_rigid(pose_sim, pose_warp, K_warp, K_warp, center)
+        pose_pr = G.pose_compose(pose_pr, G.pose_inverse(pose_rect))
+        return G.denormalize_pose(pose_pr, db.scale, db.offset)
+
     def refine_step_tensors(self, que_img_u8, K_in, pose_in, ref_imgs_u8, ref_Ks, ref_poses):
         """Numpy boundary of one step after the host-side warps: uint8 crops [h,w,3] / [rfn,h,w,3], float32 K/poses
         -> (quat [4], scale (=2**s) [1], offset [2]) numpy, as consumed at reference refiner.py:327-331."""

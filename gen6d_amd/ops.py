@@ -319,3 +319,21 @@ def linear_gemv(x, W, bias, act=0):
     _lib.check(_lib.load().g6d_linear_gemv(_ptr(x.contiguous()), B, K, _ptr(W), _ptr(bias), O, int(act), _ptr(out), _stream()),
                "g6d_linear_gemv")
     return out
+
+
+def warp_perspective(src_u8, H, dh, dw, out_float=False):
+    """src_u8 uint8 [sh,sw,ch] on the GPU; H = 3x3 source->destination pixel homography (numpy, as cv2.warpPerspective
+    takes it; a 2x3 affine as cv2.warpAffine takes it is accepted too) -> [dh,dw,ch] uint8 or float32 in [0,1]."""
+    import numpy as np
+    _need_gpu(src_u8)
+    if src_u8.dtype != torch.uint8 or src_u8.dim() != 3 or not src_u8.is_contiguous():
+        raise ValueError("warp_perspective: src must be a contiguous uint8 [H,W,C] tensor")
+    H = np.asarray(H, dtype=np.float64)
+    if H.shape == (2, 3):
+        H = np.concatenate([H, [[0.0, 0.0, 1.0]]], 0)
+    hinv = np.linalg.inv(H).astype(np.float32).reshape(-1)
+    sh, sw, ch = src_u8.shape
+    dst = torch.empty((dh, dw, ch), dtype=torch.float32 if out_float else torch.uint8, device=src_u8.device)
+    _lib.check(_lib.load().g6d_warp_perspective(_ptr(src_u8), sh, sw, ch, (C.c_float * 9)(*hinv.tolist()), _ptr(dst), dh, dw,
+                                               int(out_float), 1.0 / 255.0, _stream()), "g6d_warp_perspective")
+    return dst

@@ -176,6 +176,17 @@ int g6d_layernorm(const float* in, int ld_in, int n, int C, const float* gamma, 
 int g6d_affine_act_add(const float* in, int ld_in, const float* scale, const float* shift, int relu,
                        const float* residual, int ld_res, int n, int C, float* out, int ld_out, g6d_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Inter-stage image warps of Gen6DEstimator.predict: cv2.warpAffine in transformation_crop
+ * (utils/base_utils.py:646-655), cv2.warpPerspective in look_at_crop / normalize_reference_views
+ * (utils/database_utils.py:8-25,54-110) and the rotated reference copies (estimator.py:150-164).
+ * src uint8 [sh][sw][ch] (device); hinv: HOST pointer, row-major 3x3 destination->source pixel map (inverse of the
+ * cv2 `M`/`H`); dst [dh][dw][ch] uint8 (out_float=0, round-to-nearest) or float32 * out_scale (out_float=1).
+ * Bilinear, zero outside the source.  Exact float weights: cv2 quantises them to 1/32 px (<= 1-2 grey levels apart).
+ * ---------------------------------------------------------------------------------------------------------------- */
+int g6d_warp_perspective(const unsigned char* src, int sh, int sw, int ch, const float* hinv, void* dst, int dh, int dw,
+                         int out_float, float out_scale, g6d_stream_t stream);
+
 /* Small-batch linear layer, weight-streaming GEMV (network/refiner.py:153-166): out[b][o] = act(W[o].x[b] + bias[o]);
  * W [O][K] row-major, x [B][K], B <= 8; act as G6dConv.out_act. */
 int g6d_linear_gemv(const float* x, int B, int K, const float* W, const float* bias, int O, int act, float* out,

@@ -64,6 +64,37 @@ def install_stubs():
         for a in attrs:
             setattr(m, a, None)
         sys.modules[name] = m
+    # transforms3d is not installed; the few conversions the reference's pose utilities call are provided here from
+    # their textbook definitions (static-frame Euler sequences, Hamilton quaternions w-first), written independently
+    # of gen6d_amd/geometry.py so that the golden vectors are not circular.
+    def _axis_rot(axis, a):
+        c, s_ = np.cos(a), np.sin(a)
+        return {"x": np.array([[1, 0, 0], [0, c, -s_], [0, s_, c]]), "y": np.array([[c, 0, s_], [0, 1, 0], [-s_, 0, c]]),
+                "z": np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1]])}[axis]
+
+    def euler2mat(ai, aj, ak, axes="sxyz"):
+        assert axes[0] == "s"
+        R = np.eye(3)
+        for ax, ang in zip(axes[1:], (ai, aj, ak)):      # static frame: later rotations multiply on the left
+            R = _axis_rot(ax, ang) @ R
+        return R
+
+    def mat2euler(M, axes="szyx"):
+        assert axes == "szyx"                            # M = Rx(ak) Ry(aj) Rz(ai)
+        aj = np.arcsin(np.clip(M[0, 2], -1, 1))
+        return np.arctan2(-M[0, 1], M[0, 0]), aj, np.arctan2(-M[1, 2], M[2, 2])
+
+    def quat2mat(q):
+        w, x, y, z = np.asarray(q, np.float64) / np.linalg.norm(q)
+        return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                         [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                         [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+    sys.modules["transforms3d.euler"].euler2mat = euler2mat
+    sys.modules["transforms3d.euler"].mat2euler = mat2euler
+    sys.modules["transforms3d.quaternions"].quat2mat = quat2mat
+    sys.modules["cv2"].warpPerspective = lambda img, H, size, flags=0: np.zeros((size[1], size[0]) + img.shape[2:], img.dtype)
+    sys.modules["cv2"].warpAffine = sys.modules["cv2"].warpPerspective
     sys.modules["skimage"].io = sys.modules["skimage.io"]
     for sub in ("euler", "axangles", "quaternions"):
         setattr(sys.modules["transforms3d"], sub, sys.modules[f"transforms3d.{sub}"])
@@ -77,6 +108,52 @@ def load_reference():
     pm.VGGBNPretrain._initialize_weights = lambda self: None
     from network import name2network
     return name2network
+
+
+def geometry_golden():
+    """Host pose algebra of the reference (utils/pose_utils.py, utils/database_utils.py, utils/base_utils.py,
+    dataset/database.py) on seeded inputs -> tests/golden/geometry.npz."""
+    import numpy as np
+    if not hasattr(np, "bool"): np.bool = bool           # the reference predates numpy 2
+    if not hasattr(np, "str"): np.str = str
+    from gen6d_amd import synth
+    import utils.base_utils as bu
+    import utils.pose_utils as pu
+    import utils.database_utils as du
+    from dataset.database import normalize_pose, denormalize_pose
+    rng = np.random.RandomState(5)
+    poses, Ks = synth.fibonacci_cameras(40, radius=3.0, focal=250.0, size=160)
+    poses = poses.astype(np.float64); Ks = Ks.astype(np.float64)
+    center = np.array([0.1, -0.05, 0.08])
+    out = {"center": center, "poses": poses, "Ks": Ks}
+    out["est_pose"] = np.stack([pu.estimate_pose_from_similarity_transform_compose(
+        np.array([150.0 + 3 * i, 110.0 - 2 * i]), 0.8 + 0.1 * i, 0.3 * i - 0.5, poses[i], Ks[i], Ks[0] * np.array([[1.3], [1.3], [1]]), center)
+        for i in range(4)])
+    la = [pu.let_me_look_at(poses[i], Ks[i], center) for i in range(4)]
+    out["look_R"], out["look_f"] = np.stack([a[0] for a in la]), np.asarray([a[1] for a in la])
+    sd, ad = pu.scale_rotation_difference_from_cameras(poses[:6], poses[6:12], Ks[:6], Ks[6:12], center)
+    out["scale_diff"], out["angle_diff"] = sd, ad
+    quat = rng.randn(4); offset = rng.randn(2) * 0.05
+    sim = pu.compose_sim_pose(1.17, quat, offset, poses[3], center)
+    out["quat"], out["offset"], out["sim_pose"] = quat, offset, sim
+    out["rigid_pose"] = pu.pose_sim_to_pose_rigid(sim, poses[3], Ks[3], Ks[3], center)
+    pts = rng.randn(200, 3)
+    out["fps_pts"], out["fps_idx"] = pts, bu.sample_fps_points(pts, 33, True, index_model=True)
+    out["corr"] = du.compute_normalized_view_correlation(poses[:3], poses[3:], center, False)
+    out["norm_pose"] = normalize_pose(poses[2], 1.7, np.array([0.2, -0.1, 0.05]))
+    out["denorm_pose"] = denormalize_pose(out["norm_pose"], 1.7, np.array([0.2, -0.1, 0.05]))
+    img = np.zeros((120, 160, 3), np.uint8)
+    _, K_new, pose_new, pose_rect, H = du.look_at_crop(img, Ks[5], poses[5], np.array([70.0, 66.0]), 0.4, 1.3, 128, 128)
+    out.update(lac_K=K_new, lac_pose=pose_new, lac_rect=pose_rect, lac_H=H)
+    _, M = bu.transformation_crop(img, np.array([55.0, 42.0]), 0.7, 0.25, 128)
+    out["crop_M"] = M
+
+    class DB:
+        def get_pose(self, i): return poses[int(i)].astype(np.float32)
+    ids = [str(i) for i in range(40)]
+    out["refine_ids"] = du.select_reference_img_ids_refinement(DB(), center, ids, poses[7].astype(np.float32), 6, True, 16).astype(np.int64)
+    np.savez_compressed(os.path.join(HERE, "geometry.npz"), **out)
+    print("geometry golden ok", out["fps_idx"][:5], out["refine_ids"])
 
 
 def np_(d):
@@ -117,6 +194,8 @@ def main():
         np.savez_compressed(os.path.join(HERE, tag + ".npz"), rfn=rfn, an=an, logits=out["ref_vp_logits"].numpy(),
                             angles=out["angles_pr"].numpy(), pose_embed=embed.numpy()[:, :16])
         print(tag, "argmax", out["ref_vp_logits"].argmax(1).numpy(), "logits[:4]", out["ref_vp_logits"][0, :4].numpy())
+
+    geometry_golden()
 
     # ---- refiner: one step, 6 refs
     net = name2network["refiner"]({"network": "refiner", "name": "g"}).eval()

@@ -197,6 +197,24 @@ def linear_gemv(x, W, bias, act=0):
     return _act(F.linear(x, W, bias), act)
 
 
+def warp_perspective(src_u8, H, dh, dw, out_float=False):
+    """Plain bilinear inverse warp with zero border (float weights)."""
+    import numpy as np
+    H = np.asarray(H, dtype=np.float64)
+    if H.shape == (2, 3): H = np.concatenate([H, [[0.0, 0.0, 1.0]]], 0)
+    hinv = torch.from_numpy(np.linalg.inv(H).astype(np.float32))
+    sh, sw, ch = src_u8.shape
+    ys, xs = torch.meshgrid(torch.arange(dh, dtype=torch.float32), torch.arange(dw, dtype=torch.float32), indexing="ij")
+    p = torch.stack([xs, ys, torch.ones_like(xs)], -1) @ hinv.T
+    fx, fy = p[..., 0] / p[..., 2], p[..., 1] / p[..., 2]
+    gx, gy = (fx + 0.5) / sw * 2 - 1, (fy + 0.5) / sh * 2 - 1
+    img = src_u8.float().permute(2, 0, 1)[None].cpu()
+    out = F.grid_sample(img, torch.stack([gx, gy], -1)[None], mode="bilinear", padding_mode="zeros", align_corners=False)[0]
+    out = out.permute(1, 2, 0)
+    out = (out / 255.0) if out_float else out.round().clamp(0, 255).to(torch.uint8)
+    return out.to(src_u8.device)
+
+
 def patch_ops(monkeypatch):
     """Route gen6d_amd.ops.* to the references above (CPU host-logic tests only)."""
     import sys

@@ -270,3 +270,21 @@ def test_linear_gemv(ops, B, K, O, act):
     x, W, b = _rand(g, B, K), _rand(g, O, K, scale=K ** -0.5), _rand(g, O, scale=0.1)
     out = ops.linear_gemv(x.cuda(), W.cuda(), b.cuda(), act)
     _check(out, ref_ops.linear_gemv(_d(x), _d(W), _d(b), act), 1e-5)
+
+
+@pytest.mark.parametrize("out_float", [False, True])
+def test_warp_perspective(ops, out_float):
+    """g6d_warp_perspective vs a float bilinear inverse warp (identity, integer shift, affine 2x3, homography)."""
+    from gen6d_amd import synth
+    img = torch.from_numpy(synth.synth_images(1, 96, 128, 3)[0])
+    ident = ops.warp_perspective(img.cuda(), np.eye(3), 96, 128)
+    assert torch.equal(ident.cpu(), img)
+    shift = ops.warp_perspective(img.cuda(), np.array([[1.0, 0, 5], [0, 1.0, -3]]), 96, 128).cpu()
+    assert torch.equal(shift[:93, 5:], img[3:, :123]) and (shift[93:] == 0).all() and (shift[:, :5] == 0).all()
+    H = np.array([[0.9, -0.2, 12.0], [0.15, 1.1, -7.0], [2e-4, -1e-4, 1.0]])
+    got = ops.warp_perspective(img.cuda(), H, 64, 64, out_float=out_float).cpu()
+    ref = ref_ops.warp_perspective(img, H, 64, 64, out_float=out_float)
+    if out_float:
+        assert (got - ref).abs().max() < 2e-3
+    else:
+        assert (got.int() - ref.int()).abs().max() <= 1
