@@ -53,7 +53,7 @@ def synth_images(n, h, w, seed, structured=True):
         img = 0.75 * img + 0.25 * torch.rand((n, 3, h, w), generator=g)
     else:
         img = torch.rand((n, 3, h, w), generator=g)
-    return (img.permute(0, 2, 3, 1) * 255).round().clamp(0, 255).to(torch.uint8).numpy()
+    return (img.permute(0, 2, 3, 1) * 255).round().clamp(0, 255).to(torch.uint8).contiguous().numpy()
 
 
 def fibonacci_cameras(n, radius=5.0, focal=300.0, size=128):
