@@ -23,7 +23,8 @@
 #define BK 32
 #ifndef G6D_ABLATE
 #define G6D_ABLATE 0   // profiling builds only (tools/ablate.sh): 1 = no prefetch / LDS stores, 2 = MFMA only, 3 = no barrier,
-                       // 4 = global loads but no LDS stores, 5 = LDS stores but no global loads
+                       // 4 = global loads but no LDS stores (loads get optimised away), 5 = LDS stores but no global loads,
+                       // 6 = global loads consumed by a dummy add, no LDS stores, 7 = full kernel without the per-step barrier
 #endif
 
 namespace {
@@ -162,6 +163,7 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const G6dConv p, con
     *reinterpret_cast<f32x4*>(Bs + (lrow + 32 * j) * LDS_K + 4 * lseg) = vb[s][j] ? rb[s][j] : f32x4{0.f, 0.f, 0.f, 0.f};
   };
 
+  f32x4 dummy = {0.f, 0.f, 0.f, 0.f};   // G6D_ABLATE == 6 only
   f32x4 fa[2][MT], fb[2][NT];
   auto read_frags = [&](const float* As, const float* Bs, int kc) {
 #pragma unroll
@@ -193,13 +195,19 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const G6dConv p, con
     read_frags(As, Bs, 0);
 #pragma unroll
     for (int pc = 0; pc < NP; ++pc) {
-      if (pc % QPC == 0 && pc / QPC < 3 && G6D_ABLATE < 2) read_frags(As, Bs, pc / QPC + 1);
+      if (pc % QPC == 0 && pc / QPC < 3 && (G6D_ABLATE < 2 || G6D_ABLATE >= 6)) read_frags(As, Bs, pc / QPC + 1);
       mfma_q(2 * pc); mfma_q(2 * pc + 1);
-      if (G6D_ABLATE < 1) {
-        if (pc == 0) { advance(); begin_step(SL{}); }
+      if (G6D_ABLATE < 1 || G6D_ABLATE >= 6) {
         if (pc < RA) load_a(SL{}, pc); else if (pc < NROW) load_b(SL{}, pc - RA);
         const int sr = pc - (NP - NROW);
-        if (sr >= 0) { if (sr < RA) store_a(SS{}, An, sr); else store_b(SS{}, Bn, sr - RA); }
+        if (sr >= 0) {
+          if (G6D_ABLATE == 6) {          // consume the loads without touching LDS
+            if (sr < RA) dummy += ra[par ^ 1][sr]; else dummy += rb[par ^ 1][sr - RA];
+          } else if (sr < RA) store_a(SS{}, An, sr); else store_b(SS{}, Bn, sr - RA);
+        }
+        // the K position / offsets of the NEXT step's loads are advanced here, behind the last MFMAs of this step
+        // and in front of the barrier, instead of ahead of the first MFMA of the next step
+        if (pc == NP - 1) { advance(); begin_step(SS{}); }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -222,16 +230,18 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const G6dConv p, con
     for (int j = 0; j < RA; ++j) store_a(S0{}, lds, j);
 #pragma unroll
     for (int j = 0; j < RB; ++j) store_b(S0{}, lds + BM * LDS_K, j);
+    advance(); begin_step(S0{});                        // tile 2 -> set 0, loaded during K step 0
     __syncthreads();
     float* L0 = lds; float* L1 = lds + STAGE;
     for (int it = it_begin; it < it_end; it += 2) {
       k_step(S0{}, L0, L0 + BM * LDS_K, L1, L1 + BM * LDS_K);
-      if (G6D_ABLATE < 3) __syncthreads();
+      if (G6D_ABLATE < 3 || G6D_ABLATE == 6) __syncthreads();   // 7: no barrier
       if (it + 1 < it_end) {
         k_step(S1{}, L1, L1 + BM * LDS_K, L0, L0 + BM * LDS_K);
-        if (G6D_ABLATE < 3) __syncthreads();
+        if (G6D_ABLATE < 3 || G6D_ABLATE == 6) __syncthreads();   // 7: no barrier
       }
     }
+    if (G6D_ABLATE == 6) acc[0][0][0] += dummy[0] + dummy[1] + dummy[2] + dummy[3];
   }
 
   // ---------------------------------------------------------------- epilogue

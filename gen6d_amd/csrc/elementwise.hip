@@ -104,6 +104,48 @@ __global__ void upsample_bilinear_kernel(const float* __restrict__ in, int ld_in
   }
 }
 
+// Trunk glue: y = maxpool2x2?( relu?( x + bias[c] ) ) on NCHW (the MIOpen convolutions of the VGG trunk run without
+// bias; this replaces PyTorch's separate bias-add, clamp and max_pool2d passes with one).  VEC outputs per thread
+// (4 with 16-byte accesses when the output width allows it, else 1).
+template <int VEC>
+__global__ void bias_relu_pool_nchw_kernel(const float* __restrict__ in, const float* __restrict__ bias, int C, int H,
+                                           int W, int relu, int pool, float* __restrict__ out, long long total) {
+  const int Wo = pool ? W / 2 : W, Ho = pool ? H / 2 : H;
+  for (long long i = (blockIdx.x * (long long)blockDim.x + threadIdx.x) * VEC; i < total;
+       i += (long long)gridDim.x * blockDim.x * VEC) {
+    const int x = (int)(i % Wo); long long t = i / Wo;
+    const int y = (int)(t % Ho); t /= Ho;
+    const float b = bias[(int)(t % C)];
+    const float* src = in + t * (long long)H * W;
+    float v[VEC];
+    if (pool) {
+      const float* r0 = src + (size_t)(2 * y) * W + 2 * x;
+      if constexpr (VEC == 4) {
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(r0), a1 = *reinterpret_cast<const f32x4*>(r0 + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(r0 + W), b1 = *reinterpret_cast<const f32x4*>(r0 + W + 4);
+        v[0] = fmaxf(fmaxf(a0[0], a0[1]), fmaxf(b0[0], b0[1])); v[1] = fmaxf(fmaxf(a0[2], a0[3]), fmaxf(b0[2], b0[3]));
+        v[2] = fmaxf(fmaxf(a1[0], a1[1]), fmaxf(b1[0], b1[1])); v[3] = fmaxf(fmaxf(a1[2], a1[3]), fmaxf(b1[2], b1[3]));
+      } else {
+        v[0] = fmaxf(fmaxf(r0[0], r0[1]), fmaxf(r0[W], r0[W + 1]));
+      }
+    } else {
+      if constexpr (VEC == 4) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(src + (size_t)y * W + x);
+        v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+      } else {
+        v[0] = src[(size_t)y * W + x];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {                    // max(a,b)+c == max(a+c,b+c); relu(max) == max(relu)
+      v[k] += b;
+      if (relu) v[k] = fmaxf(v[k], 0.f);
+    }
+    if constexpr (VEC == 4) *reinterpret_cast<f32x4*>(out + i) = f32x4{v[0], v[1], v[2], v[3]};
+    else out[i] = v[0];
+  }
+}
+
 // Per-position inverse L2 norm over C of an NCHW tensor: thread = position, coalesced along HW.
 __global__ void __launch_bounds__(256) nchw_inv_norm_kernel(const float* __restrict__ in, int C, int HW,
                                                             float* __restrict__ inv) {
@@ -309,6 +351,24 @@ extern "C" int g6d_upsample_bilinear(const float* in, int ld_in, const float* sc
   hipLaunchKernelGGL(upsample_bilinear_kernel, dim3(grid_for(total, 256)), dim3(256), 0, STREAM(stream), in, ld_in, scale,
                      shift, per_n, N, H, W, C, factor, out, ld_out);
   return g6d_check_launch("upsample_bilinear");
+}
+
+extern "C" int g6d_bias_relu_pool_nchw(const float* in, const float* bias, int N, int C, int H, int W, int relu, int pool,
+                                       float* out, g6d_stream_t stream) {
+  if (!in || !bias || !out || N <= 0 || C <= 0 || H <= 0 || W <= 0 || (pool && (H < 2 || W < 2))) {   // odd sizes pool with floor, as F.max_pool2d
+    g6d_set_error("bias_relu_pool_nchw: bad args"); return G6D_EINVAL;
+  }
+  const int Wo = pool ? W / 2 : W;
+  const long long total = (long long)N * C * (pool ? H / 2 : H) * Wo;
+  // 16-byte path: every row start (input and output) must stay 16-byte aligned
+  const bool vec = (Wo & 3) == 0 && (W & 3) == 0 && g6d_aligned16(in) && g6d_aligned16(out);
+  if (vec)
+    hipLaunchKernelGGL(bias_relu_pool_nchw_kernel<4>, dim3(grid_for(total / 4, 256)), dim3(256), 0, STREAM(stream), in, bias,
+                       C, H, W, relu, pool, out, total);
+  else
+    hipLaunchKernelGGL(bias_relu_pool_nchw_kernel<1>, dim3(grid_for(total, 256)), dim3(256), 0, STREAM(stream), in, bias, C,
+                       H, W, relu, pool, out, total);
+  return g6d_check_launch("bias_relu_pool_nchw");
 }
 
 extern "C" int g6d_nchw_to_nhwc(const float* in, int N, int C, int H, int W, int l2norm, float* out, int ld_out,

@@ -5,7 +5,7 @@ quirk that the 1/16 output is the BatchNorm output of conv 25 WITHOUT the final 
 import torch
 import torch.nn.functional as F
 
-from .. import specs
+from .. import ops, specs
 
 _POOL_BEFORE = (1, 2, 4, 6)          # positions (in the list of 8 convs) preceded by a 2x2 max-pool
 
@@ -29,15 +29,18 @@ def vgg_taps(folded, x, taps):
        'c3' (256ch @1/4, post-ReLU), 'c5' (512 @1/8, post-ReLU), 'c7_pre' (512 @1/16, pre-ReLU), 'p7' (max-pool of c7_pre)."""
     out = {}
     for i, (w, b) in enumerate(folded):
-        if i in _POOL_BEFORE:
-            x = F.max_pool2d(x, 2, 2)
-        x = F.conv2d(x, w, b, padding=1)
+        y = F.conv2d(x, w, None, padding=1)                                  # MIOpen; bias/ReLU/pool fused below
         if i == 7:
-            out["c7_pre"] = x
+            out["c7_pre"] = ops.bias_relu_pool_nchw(y, b, False, False)       # BN output WITHOUT the last ReLU
             if "p7" in taps:
-                out["p7"] = F.max_pool2d(x, 2, 2)
+                out["p7"] = ops.bias_relu_pool_nchw(y, b, False, True)
             break
-        x = F.relu(x)
-        if i == 3: out["c3"] = x
-        if i == 5: out["c5"] = x
-    return out
+        pool_next = (i + 1) in _POOL_BEFORE
+        tap = {3: "c3", 5: "c5"}.get(i)
+        if tap in taps and pool_next:                                         # tapped feature is the un-pooled one
+            out[tap] = ops.bias_relu_pool_nchw(y, b, True, False)
+            x = ops.bias_relu_pool_nchw(y, b, True, True)
+        else:
+            x = ops.bias_relu_pool_nchw(y, b, True, pool_next)
+            if tap in taps: out[tap] = x
+    return {k: v for k, v in out.items() if k in taps or k == "c7_pre"}

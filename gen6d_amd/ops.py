@@ -166,6 +166,18 @@ def upsample_bilinear(x, out, factor, scale=None, shift=None, per_n=False):
     return out
 
 
+def bias_relu_pool_nchw(x, bias, relu, pool):
+    """x [N,C,H,W] contiguous (conv output without bias) -> maxpool2x2?(relu?(x + bias)) in one pass."""
+    _need_gpu(x, bias)
+    if not x.is_contiguous() or x.dtype != torch.float32:
+        raise ValueError("bias_relu_pool_nchw: x must be contiguous float32 NCHW")
+    N, Cc, H, W = x.shape
+    out = torch.empty((N, Cc, H // 2, W // 2) if pool else (N, Cc, H, W), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().g6d_bias_relu_pool_nchw(_ptr(x), _ptr(bias), N, Cc, H, W, int(relu), int(pool), _ptr(out), _stream()),
+               "g6d_bias_relu_pool_nchw")
+    return out
+
+
 def nchw_to_nhwc(x, out, l2norm):
     """x [N,C,H,W] contiguous -> out [N,1,H,W,C] view, optionally L2-normalised over C."""
     _need_gpu(x, out)

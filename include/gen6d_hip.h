@@ -99,6 +99,11 @@ int g6d_affine_act_pool(const float* in, int ld_in, const float* scale, const fl
 int g6d_upsample_bilinear(const float* in, int ld_in, const float* scale, const float* shift, int affine_per_n,
                           int N, int H, int W, int C, int factor, float* out, int ld_out, g6d_stream_t stream);
 
+/* VGG trunk glue on NCHW (the trunk's convolutions themselves run on MIOpen, reference pretrain_models.py:86-104 with
+ * BatchNorm folded): out = maxpool2x2?( relu?( in + bias[c] ) ) in one pass. */
+int g6d_bias_relu_pool_nchw(const float* in, const float* bias, int N, int C, int H, int W, int relu, int pool, float* out,
+                            g6d_stream_t stream);
+
 /* NCHW (backbone output) -> channels-last, optionally L2-normalised over C (F.normalize eps 1e-12,
  * network/selector.py:118, network/refiner.py:69-71). out [N][H][W][ld_out]; scratch: N*H*W floats (only if l2norm). */
 int g6d_nchw_to_nhwc(const float* in, int N, int C, int H, int W, int l2norm, float* out, int ld_out, float* scratch,

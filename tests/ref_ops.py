@@ -86,6 +86,12 @@ def upsample_bilinear(x, out, factor, scale=None, shift=None, per_n=False):
     return out
 
 
+def bias_relu_pool_nchw(x, bias, relu, pool):
+    v = x + bias.view(1, -1, 1, 1)
+    if relu: v = F.relu(v)
+    return F.max_pool2d(v, 2, 2) if pool else v
+
+
 def nchw_to_nhwc(x, out, l2norm):
     v = F.normalize(x, dim=1) if l2norm else x
     out.copy_(v.permute(0, 2, 3, 1).unsqueeze(1))

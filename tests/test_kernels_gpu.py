@@ -288,3 +288,13 @@ def test_warp_perspective(ops, out_float):
         assert (got - ref).abs().max() < 2e-3
     else:
         assert (got.int() - ref.int()).abs().max() <= 1
+
+
+@pytest.mark.parametrize("shape,relu,pool", [((2, 64, 16, 24), True, True), ((1, 512, 22, 30), False, True),
+                                             ((1, 512, 22, 30), False, False), ((3, 128, 8, 8), True, False),
+                                             ((1, 64, 6, 10), True, True), ((2, 32, 15, 15), True, True), ((2, 32, 7, 7), False, True)])
+def test_bias_relu_pool_nchw(ops, shape, relu, pool):
+    g = torch.Generator().manual_seed(13)
+    x, b = _rand(g, *shape), _rand(g, shape[1])
+    out = ops.bias_relu_pool_nchw(x.cuda(), b.cuda(), relu, pool)
+    _check(out, ref_ops.bias_relu_pool_nchw(_d(x), _d(b), relu, pool), 1e-6)
