@@ -92,12 +92,14 @@ def main():
     if use_graph:
         # per-kernel HIP events cannot be recorded inside a graph replay: the roofline pass re-runs the same K steps
         # through the eager launch path (identical kernels, shapes and order) right after the timed region
+        ops.SERIAL = True                      # branches back to back: per-kernel durations without stream overlap
         step(0, eager=True)
         torch.cuda.synchronize()
         ops.PROFILE = []
         for i in range(args.steps):
             step(args.warmup + i, eager=True)
         torch.cuda.synchronize()
+        ops.SERIAL = False
     prof, ops.PROFILE = ops.PROFILE, None
     rows = parallel.gather_rows(torch.cat(rows, 0), world * args.steps) if (world > 1 and not shard_refs) else torch.cat(rows, 0)
     n_queries = args.steps if shard_refs else world * args.steps
@@ -125,7 +127,7 @@ def main():
                      "launches_per_step": n_launch / args.steps, "gflop_per_launch": flops / n_launch / 1e9,
                      "avg_launch_ms": ms / n_launch, "conv_ms_per_step": ms / args.steps,
                      "measured": "HIP events around every g6d_conv_igemm launch, " +
-                                 ("eager re-run of the same steps after the graph-replay timed region" if use_graph
+                                 ("serialised eager re-run of the same steps after the graph-replay timed region" if use_graph
                                   else "inside the timed region")},
     }
     if world == 1 and not args.no_cpu_baseline:

@@ -27,6 +27,9 @@
                        // 6 = global loads consumed by a dummy add, no LDS stores, 7 = full kernel without the per-step barrier
 #endif
 
+int g6d_splitk_reduce_launch(const float* ws, int splits, int M, int Cout, const float* bias, int act, float* out,
+                             int ld_out, double* stats, int rows_per_group, hipStream_t stream);
+
 namespace {
 
 // 16-byte load at base + (unsigned 32-bit element offset): scalar base + 32-bit vector offset addressing
@@ -461,18 +464,9 @@ int launch_mode(const G6dConv& d, int M, int T, int nChunks, int splits, hipStre
                      ips, total, splits);
   int rc = g6d_check_launch("conv_igemm");
   if (rc != G6D_OK) return rc;
-  if (splits > 1) {
-    if (splits > 16) {
-      dim3 g2((M + 7) / 8, (d.Cout + 127) / 128);
-      hipLaunchKernelGGL(splitk_reduce_kernel, g2, dim3(256), 0, stream, d.workspace, splits, M, d.Cout, d.bias,
-                         d.out_act, d.out, d.ld_out, d.stats, d.stat_rows_per_group);
-    } else {
-      dim3 g2((M + 31) / 32, (d.Cout + 127) / 128);
-      hipLaunchKernelGGL(splitk_reduce_rows_kernel, g2, dim3(256), 0, stream, d.workspace, splits, M, d.Cout, d.bias,
-                         d.out_act, d.out, d.ld_out, d.stats, d.stat_rows_per_group);
-    }
-    rc = g6d_check_launch("splitk_reduce");
-  }
+  if (splits > 1)
+    rc = g6d_splitk_reduce_launch(d.workspace, splits, M, d.Cout, d.bias, d.out_act, d.out, d.ld_out, d.stats,
+                                  d.stat_rows_per_group, stream);
   return rc;
 }
 
@@ -485,6 +479,21 @@ int launch_cfg(const G6dConv& d, int M, int T, int nChunks, int splits, hipStrea
 }
 
 }  // namespace
+
+// Shared with corr_patch.hip: sum split-K partials [splits][M][Cout] into out with the common epilogue.
+int g6d_splitk_reduce_launch(const float* ws, int splits, int M, int Cout, const float* bias, int act, float* out,
+                             int ld_out, double* stats, int rows_per_group, hipStream_t stream) {
+  if (splits > 16) {
+    dim3 g2((M + 7) / 8, (Cout + 127) / 128);
+    hipLaunchKernelGGL(splitk_reduce_kernel, g2, dim3(256), 0, stream, ws, splits, M, Cout, bias, act, out, ld_out, stats,
+                       rows_per_group);
+  } else {
+    dim3 g2((M + 31) / 32, (Cout + 127) / 128);
+    hipLaunchKernelGGL(splitk_reduce_rows_kernel, g2, dim3(256), 0, stream, ws, splits, M, Cout, bias, act, out, ld_out,
+                       stats, rows_per_group);
+  }
+  return g6d_check_launch("splitk_reduce");
+}
 
 extern "C" int g6d_conv_igemm(const G6dConv* desc, g6d_stream_t stream_) {
   if (!desc) return G6D_EINVAL;

@@ -1,0 +1,196 @@
+// Detector correlation with input-patch reuse in LDS (network/detector.py:222-224, the 15x15 level).
+//
+// The generic implicit-GEMM kernel re-loads a [128 x 32] activation tile from L2 for every tap, which for a skinny
+// GEMM (N = rfn = 32 output channels) needs 5 global loads per 16 MFMAs per wave: measured, that load path — not the
+// matrix pipe — bounds it (66-71 of ~120 attainable TFLOP/s).  Consecutive taps along kx read the same
+// input rows shifted by one pixel, so here a block keeps an input PATCH of 8 rows x (32 + kw - 1) columns x 32
+// channels in LDS per (channel chunk, ky) and walks the kw taps over it: 1 global load per 16 MFMAs.
+//
+//   block  = 512 threads = 8 waves; output tile = 8 rows x 32 columns (256 positions) x 32 output channels;
+//            wave w owns output row w of the tile: lane i -> column i, one 32x32 accumulator tile
+//   unit   = (channel chunk of 32, ky): patch stage [8][32+kw-1][36 floats] double-buffered; per kx one weight tile
+//            [32 co][36] double-buffered; 16 MFMAs (v_mfma_f32_32x32x2_f32) per wave per kx
+//   split  = units are split across gridDim.z; partial tiles go to a workspace and the common split-K reduce adds them.
+#include "g6d_common.h"
+
+#define LDS_K 36
+#define TH 8
+#define TW 32
+
+namespace {
+
+__device__ __forceinline__ f32x4 ldg4(const float* __restrict__ base, int elem_off) {
+  return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + ((unsigned)elem_off << 2));
+}
+
+__global__ void __launch_bounds__(512) corr_patch_kernel(const float* __restrict__ in, const float* __restrict__ wgt,
+                                                         float* __restrict__ out, int H, int W, int Cin, int ld_in,
+                                                         int Cout, int kh, int kw, int ph, int pw, int ld_out,
+                                                         int units_per_split, int total_units, int splits, int tiles_x) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int PW = TW + kw - 1;                       // patch width in positions
+  const int patch_floats = TH * PW * LDS_K;
+  float* patch0 = lds;
+  float* patch1 = lds + patch_floats;
+  float* bt0 = lds + 2 * patch_floats;              // weight tiles [32][LDS_K] x 2
+  float* bt1 = bt0 + 32 * LDS_K;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
+  const int u_begin = blockIdx.z * units_per_split, u_end = min(total_units, u_begin + units_per_split);
+  const int T = kh * kw;
+
+  // patch loader: 16-byte segment `seg` of position p (p = tid/8 + 64*j), j < NPL
+  const int seg = tid & 7;
+  const int npos = TH * PW;
+  const int NPL = (npos + 63) / 64;                 // <= 8 for kw <= 31
+  f32x4 rp[8];
+  bool vp[8];
+  f32x4 rbw; bool vbw = false;                      // weight tile load (threads 0..255: row = tid/8)
+  const int brow = tid >> 3;
+
+  auto unit_ck = [&](int u, int& chunk, int& ky) { chunk = u / kh; ky = u - chunk * kh; };
+
+  auto load_patch = [&](int u) {
+    int chunk, ky; unit_ck(u, chunk, ky);
+    const bool uv = u < u_end;
+    const int c = chunk * 32 + 4 * seg;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (j < NPL) {
+        const int p = (tid >> 3) + 64 * j;
+        const int pr = p / PW, pc = p - pr * PW;
+        const int iy = ty0 + pr + ky - ph, ix = tx0 + pc - pw;
+        const bool v = uv & (p < npos) & (c < Cin) & ((unsigned)iy < (unsigned)H) & ((unsigned)ix < (unsigned)W);
+        vp[j] = v;
+        rp[j] = ldg4(in, v ? (iy * W + ix) * ld_in + c : 0);
+      }
+    }
+  };
+  auto store_patch = [&](float* dst) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (j < NPL) {
+        const int p = (tid >> 3) + 64 * j;
+        if (p < npos) *reinterpret_cast<f32x4*>(dst + p * LDS_K + 4 * seg) = vp[j] ? rp[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  };
+  auto load_b = [&](int u, int kx) {
+    int chunk, ky; unit_ck(u, chunk, ky);
+    const int c = chunk * 32 + 4 * seg;
+    vbw = (tid < 256) & (u < u_end) & (brow < Cout) & (c < Cin);
+    rbw = ldg4(wgt, vbw ? (brow * T + ky * kw + kx) * Cin + c : 0);
+  };
+  auto store_b = [&](float* dst) {
+    if (tid < 256) *reinterpret_cast<f32x4*>(dst + brow * LDS_K + 4 * seg) = vbw ? rbw : f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  if (u_begin < u_end) {
+    load_patch(u_begin); load_b(u_begin, 0);
+    store_patch(patch0); store_b(bt0);
+    __syncthreads();
+    int pcur = 0, bcur = 0;
+    for (int u = u_begin; u < u_end; ++u) {
+      const float* P = pcur ? patch1 : patch0;
+      float* Pn = pcur ? patch0 : patch1;
+      load_patch(u + 1);                            // masked beyond u_end; lands during the kw steps below
+      for (int kx = 0; kx < kw; ++kx) {
+        const float* B = bcur ? bt1 : bt0;
+        float* Bn = bcur ? bt0 : bt1;
+        const bool last = kx == kw - 1;
+        load_b(last ? u + 1 : u, last ? 0 : kx + 1);
+        const float* arow = P + (wave * PW + li + kx) * LDS_K + 4 * lh;
+        const float* brow_p = B + li * LDS_K + 4 * lh;
+        f32x4 a[4], b[4];
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+          a[kc] = *reinterpret_cast<const f32x4*>(arow + kc * 8);
+          b[kc] = *reinterpret_cast<const f32x4*>(brow_p + kc * 8);
+        }
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kc][s], b[kc][s], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (last) store_patch(Pn);
+        store_b(Bn);
+        __syncthreads();
+        bcur ^= 1;
+      }
+      pcur ^= 1;
+    }
+  }
+
+  // epilogue: acc rows = output columns tx0 + (r&3) + 8*(r>>2) + 4*lh of image row ty0 + wave; acc column = co = li
+  const int oy = ty0 + wave;
+  if (oy < H && li < Cout) {
+    float* dst = splits > 1 ? out + (size_t)blockIdx.z * H * W * Cout : out;
+    const int ld = splits > 1 ? Cout : ld_out;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ox = tx0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (ox < W) dst[((size_t)oy * W + ox) * ld + li] = acc[r];
+    }
+  }
+}
+
+}  // namespace
+
+// Declared in conv_igemm.hip: sums split-K partials [splits][M][Cout] into out (+bias, activation, statistics).
+int g6d_splitk_reduce_launch(const float* ws, int splits, int M, int Cout, const float* bias, int act, float* out,
+                             int ld_out, double* stats, int rows_per_group, hipStream_t stream);
+
+// Stride-1 2-D cross-correlation without bias for Cout <= 32 (the detector's reference-as-filter correlation).
+//   in  [H][W][ld_in] channels-last, wgt [Cout][kh*kw][Cin], out [H*W][ld_out]; zero padding (ph, pw) with
+//   H_out = H, W_out = W (i.e. 2*ph = kh-1, 2*pw = kw-1).  workspace: split-K partials.
+extern "C" int g6d_corr2d_patch(const float* in, int H, int W, int Cin, int ld_in, const float* wgt, int Cout, int kh,
+                                int kw, float* out, int ld_out, float* workspace, size_t workspace_bytes,
+                                g6d_stream_t stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (!in || !wgt || !out || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 3) || (ld_in & 3) || ld_in < Cin || Cout <= 0 ||
+      Cout > 32 || ld_out < Cout || !(kh & 1) || !(kw & 1) || kw > 31 || !g6d_aligned16(in) || !g6d_aligned16(wgt) ||
+      (long long)H * W * ld_in >= (1ll << 30) || (long long)Cout * kh * kw * Cin >= (1ll << 30)) {
+    g6d_set_error("corr2d_patch: bad args (Cout <= 32, odd kernel <= 31, Cin % 4 == 0)"); return G6D_EINVAL;
+  }
+  const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH, tiles = tiles_x * tiles_y;
+  const int total_units = ((Cin + 31) / 32) * kh;
+  // split the (chunk, ky) units so that the grid fills whole rounds of the 256 CUs (one 115 KB block per CU):
+  // pick the split count with the best last-round utilisation, preferring fewer splits on ties
+  int splits = 1;
+  {
+    const size_t per = (size_t)H * W * Cout * sizeof(float);
+    int max_s = total_units / 2;
+    if (max_s > 64) max_s = 64;
+    if (workspace && per > 0 && (size_t)max_s > workspace_bytes / per) max_s = (int)(workspace_bytes / per);
+    if (!workspace) max_s = 1;
+    double best = -1.0;
+    for (int sp = 1; sp <= max_s; ++sp) {
+      const int ups_ = (total_units + sp - 1) / sp;
+      const int real = (total_units + ups_ - 1) / ups_;
+      const long long blocks = (long long)tiles * real;
+      const double util = (double)blocks / (256.0 * ((blocks + 255) / 256));
+      if (util > best + 0.02) { best = util; splits = real; }
+    }
+  }
+  const int ups = (total_units + splits - 1) / splits;
+  splits = (total_units + ups - 1) / ups;
+  const size_t lds_bytes = (size_t)(2 * TH * (TW + kw - 1) * LDS_K + 2 * 32 * LDS_K) * sizeof(float);
+  static size_t attr_bytes = 0;
+  if (lds_bytes > attr_bytes) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_patch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds_bytes);
+    attr_bytes = lds_bytes;
+  }
+  hipLaunchKernelGGL(corr_patch_kernel, dim3(tiles, 1, splits), dim3(512), lds_bytes, stream, in, wgt,
+                     splits > 1 ? workspace : out, H, W, Cin, ld_in, Cout, kh, kw, kh / 2, kw / 2, ld_out, ups, total_units,
+                     splits, tiles_x);
+  int rc = g6d_check_launch("corr2d_patch");
+  if (rc != G6D_OK || splits == 1) return rc;
+  return g6d_splitk_reduce_launch(workspace, splits, H * W, Cout, nullptr, 0, out, ld_out, nullptr, 0, stream);
+}

@@ -30,6 +30,7 @@ _P, _I, _F, _D = C.c_void_p, C.c_int, C.c_float, C.c_double
 SIGNATURES = {
     "g6d_marker": [_I, _P],
     "g6d_conv_igemm": [C.POINTER(G6dConv), _P],
+    "g6d_corr2d_patch": [_P, _I, _I, _I, _I, _P, _I, _I, _I, _P, _I, _P, C.c_size_t, _P],
     "g6d_stats_finalize": [_P, _I, _D, _D, _P, _P, _P],
     "g6d_affine_act_pool": [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P],
     "g6d_upsample_bilinear": [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P],

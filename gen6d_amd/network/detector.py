@@ -81,7 +81,10 @@ class Detector(ParamBank):
         for x, wref, k in zip((x0, x1, x2), self.ref_center_feats, self.ref_ksize):
             _, _, h, w, _ = x.shape
             o = torch.empty((1, 1, h, w, rfn), dtype=torch.float32, device=x.device)
-            ops.conv(x, wref, None, o, ksize=(1, k, k), pad=(0, k // 2, k // 2))
+            if k >= 9 and rfn <= 32:       # 15x15 level: input patch kept in LDS and walked by the kx taps
+                ops.corr2d_patch(x, wref, o, k)
+            else:
+                ops.conv(x, wref, None, o, ksize=(1, k, k), pad=(0, k // 2, k // 2))
             maps.append(o.reshape(h * w, rfn))
         hc, wc = x0.shape[2], x0.shape[3]
         ops.detector_assemble(maps[0], maps[1], maps[2], hc, wc, self.cfg["vgg_score_stats"],

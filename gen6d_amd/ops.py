@@ -50,12 +50,15 @@ def workspace(device):
 
 
 _SIDE = {}
+SERIAL = False      # True: fork_join runs its branches back to back on the current stream (per-kernel timing runs)
 
 
 def fork_join(fns, device):
     """Run independent launch sequences concurrently: fns[0] on the current stream, the others on cached side streams
     forked from it and joined back (capturable in a hipGraph as parallel branches).  Independent stages of the path
     (detector scales, selector pyramid levels, refiner feature branches) are small grids that do not fill 256 CUs."""
+    if SERIAL:
+        return [fn() for fn in fns]
     main = torch.cuda.current_stream(device)
     streams = _SIDE.setdefault(str(device), [])
     while len(streams) < len(fns) - 1:
@@ -125,6 +128,26 @@ def conv(x, w, bias, out, ksize=(1, 1, 1), stride=(1, 1, 1), pad=(0, 0, 0), mul=
         PROFILE.append((2.0 * N * Do * Ho * Wo * Cout * kd * kh * kw * Cin, e0, e1))
         return out
     _lib.check(_lib.load().g6d_conv_igemm(C.byref(d), _stream()), "g6d_conv_igemm")
+    return out
+
+
+def corr2d_patch(x, w, out, k):
+    """Detector correlation with LDS patch reuse: x [1,1,H,W,Cin], w [Cout<=32, k*k, Cin], out [1,1,H,W,Cout]."""
+    _need_gpu(x, w, out)
+    N, D, H, W, Cin, ld_in = _cl5(x, "corr2d.x")
+    _, _, Ho, Wo, Cout, ld_out = _cl5(out, "corr2d.out")
+    if N * D != 1 or (Ho, Wo) != (H, W) or tuple(w.shape) != (Cout, k * k, Cin) or not w.is_contiguous():
+        raise ValueError("corr2d_patch: shape mismatch")
+    ws = workspace(x.device)
+    flops = 2.0 * H * W * Cout * k * k * Cin
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.check(_lib.load().g6d_corr2d_patch(_ptr(x), H, W, Cin, ld_in, _ptr(w), Cout, k, k, _ptr(out), ld_out, _ptr(ws),
+                                           ws.numel() * 4, _stream()), "g6d_corr2d_patch")
+    if PROFILE is not None:
+        e1.record()
+        PROFILE.append((flops, e0, e1))
     return out
 
 

@@ -83,6 +83,13 @@ int g6d_conv_igemm(const G6dConv* desc, g6d_stream_t stream);
 /* sizeof(G6dConv) as compiled into the library: bindings check their struct layout against it */
 int g6d_sizeof_conv_desc(void);
 
+/* Stride-1 2-D cross-correlation without bias for Cout <= 32 with input-patch reuse in LDS: the detector's
+ * F.conv2d(que_x0, ref_x0, padding=7) (network/detector.py:224), where the generic kernel is bound by re-loading the
+ * activation tile for every one of the 225 taps.  in [H][W][ld_in], wgt [Cout][kh*kw][Cin], out [H*W][ld_out],
+ * "same" zero padding (kh, kw odd, kw <= 31).  workspace: split-K partials (splits*H*W*Cout floats). */
+int g6d_corr2d_patch(const float* in, int H, int W, int Cin, int ld_in, const float* wgt, int Cout, int kh, int kw,
+                     float* out, int ld_out, float* workspace, size_t workspace_bytes, g6d_stream_t stream);
+
 /* InstanceNorm finalisation: stats[g][c] = (sum, sumsq) over `count` elements ->
  * scale = 1/sqrt(var+eps), shift = -mean*scale (biased variance; torch InstanceNorm{1,2,3}d, eps 1e-5,
  * network/selector.py:28-77, network/refiner.py:27-50,93-133). n = groups*channels. */

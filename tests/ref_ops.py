@@ -47,6 +47,10 @@ def conv(x, w, bias, out, ksize=(1, 1, 1), stride=(1, 1, 1), pad=(0, 0, 0), mul=
     return out
 
 
+def corr2d_patch(x, w, out, k):
+    return conv(x, w, None, out, ksize=(1, k, k), pad=(0, k // 2, k // 2))
+
+
 def new_stats(groups, channels, device):
     return torch.zeros((groups, channels, 2), dtype=torch.float64, device=device)
 

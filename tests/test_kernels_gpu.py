@@ -298,3 +298,18 @@ def test_bias_relu_pool_nchw(ops, shape, relu, pool):
     x, b = _rand(g, *shape), _rand(g, shape[1])
     out = ops.bias_relu_pool_nchw(x.cuda(), b.cuda(), relu, pool)
     _check(out, ref_ops.bias_relu_pool_nchw(_d(x), _d(b), relu, pool), 1e-6)
+
+
+@pytest.mark.parametrize("H,W,Cin,Cout,k", [(22, 30, 512, 32, 15), (8, 40, 64, 8, 15), (17, 33, 96, 32, 7), (5, 5, 36, 3, 3),
+                                             (44, 60, 512, 32, 15)])
+def test_corr2d_patch(ops, H, W, Cin, Cout, k):
+    g = torch.Generator().manual_seed(21)
+    x = _rand(g, 1, 1, H, W, Cin)
+    w = _rand(g, Cout, k * k, Cin, scale=(1.0 / (k * k * Cin)) ** 0.5)
+    obuf = torch.full((1, 1, H, W, Cout + 4), -5.0, device="cuda")
+    out = obuf[..., :Cout]
+    ops.corr2d_patch(x.cuda(), w.cuda(), out, k)
+    ref = torch.empty((1, 1, H, W, Cout), dtype=torch.float64)
+    ref_ops.corr2d_patch(_d(x), _d(w), ref, k)
+    _check(out, ref, 2e-5, "corr2d_patch")
+    assert (obuf[..., Cout:] == -5.0).all()

@@ -60,6 +60,15 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
+        if name.startswith("det corr 15"):
+            xs, os_ = x[0:1, 0:1], out[0:1, 0:1]
+            for _ in range(2): ops.corr2d_patch(xs, w, os_, k[1])
+            torch.cuda.synchronize(); e0.record()
+            for _ in range(reps): ops.corr2d_patch(xs, w, os_, k[1])
+            e1.record(); torch.cuda.synchronize()
+            ms2 = e0.elapsed_time(e1) / reps
+            fl2 = 2.0 * N * Do * Ho * Wo * Cout * k[0] * k[1] * k[2] * Cin
+            print(f"{'  -> corr2d_patch':28s} {'':30s} {ms2 * 1e3:8.1f} us  {fl2 / ms2 / 1e9:7.1f} TFLOP/s")
         fl = 2.0 * N * Do * Ho * Wo * Cout * k[0] * k[1] * k[2] * Cin
         tot_f += fl; tot_t += ms
         print(f"{name:28s} M={N * Do * Ho * Wo:6d} N={Cout:4d} K={k[0] * k[1] * k[2] * Cin:6d}  {ms * 1e3:8.1f} us  {fl / ms / 1e9:7.1f} TFLOP/s")
