@@ -146,26 +146,27 @@ __global__ void bias_relu_pool_nchw_kernel(const float* __restrict__ in, const f
   }
 }
 
-// Per-position inverse L2 norm over C of an NCHW tensor: thread = position, coalesced along HW.
-__global__ void __launch_bounds__(256) nchw_inv_norm_kernel(const float* __restrict__ in, int C, int HW,
-                                                            float* __restrict__ inv) {
-  __shared__ float part[4][64];
-  const int n = blockIdx.y, p = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
-  const float* src = in + (size_t)n * C * HW;
+// In-place L2 normalisation of channels-last rows (F.normalize over C, eps 1e-12): one wave per position, 16-byte
+// accesses along C.  Runs after the layout change, where the C axis is contiguous.
+__global__ void __launch_bounds__(256) l2norm_rows_kernel(float* __restrict__ x, int rows, int C, int ld) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  float* p = x + (size_t)row * ld;
   float s = 0.f;
-  if (p < HW) for (int c = q; c < C; c += 4) { float v = src[(size_t)c * HW + p]; s += v * v; }
-  part[q][threadIdx.x & 63] = s;
-  __syncthreads();
-  if (q == 0 && p < HW) {
-    float t = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
-    inv[(size_t)n * HW + p] = 1.f / fmaxf(sqrtf(t), 1e-12f);
+  for (int c = lane * 4; c < C; c += 256) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(p + c);
+    s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  const float inv = 1.f / fmaxf(sqrtf(wave_sum(s)), 1e-12f);
+  for (int c = lane * 4; c < C; c += 256) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(p + c);
+    *reinterpret_cast<f32x4*>(p + c) = v * inv;
   }
 }
 
 // LDS-tiled transpose: block = (64 positions x 64 channels) tile; reads coalesced along HW, writes along C.
 __global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* __restrict__ in, int C, int HW,
-                                                           const float* __restrict__ inv, float* __restrict__ out,
-                                                           int ld_out) {
+                                                           float* __restrict__ out, int ld_out) {
   __shared__ float tile[64][65];
   const int n = blockIdx.z, p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -178,9 +179,7 @@ __global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* __restri
   for (int k = ty; k < 64; k += 4) {           // k = position, tx = channel
     const int p = p0 + k, c = c0 + tx;
     if (p < HW && c < C) {
-      float v = tile[tx][k];
-      if (inv) v *= inv[(size_t)n * HW + p];
-      out[((size_t)n * HW + p) * ld_out + c] = v;
+      out[((size_t)n * HW + p) * ld_out + c] = tile[tx][k];
     }
   }
 }
@@ -372,19 +371,19 @@ extern "C" int g6d_bias_relu_pool_nchw(const float* in, const float* bias, int N
 }
 
 extern "C" int g6d_nchw_to_nhwc(const float* in, int N, int C, int H, int W, int l2norm, float* out, int ld_out,
-                                float* scratch, g6d_stream_t stream) {
-  if (!in || !out || N <= 0 || C <= 0 || H <= 0 || W <= 0 || ld_out < C || (l2norm && !scratch)) {
-    g6d_set_error("nchw_to_nhwc: bad args (l2norm needs a scratch of N*H*W floats)"); return G6D_EINVAL;
+                                g6d_stream_t stream) {
+  if (!in || !out || N <= 0 || C <= 0 || H <= 0 || W <= 0 || ld_out < C ||
+      (l2norm && ((C & 3) || (ld_out & 3) || !g6d_aligned16(out)))) {
+    g6d_set_error("nchw_to_nhwc: bad args (l2norm needs C and ld_out multiples of 4)"); return G6D_EINVAL;
   }
   const int HW = H * W;
-  if (l2norm) {
-    hipLaunchKernelGGL(nchw_inv_norm_kernel, dim3((HW + 63) / 64, N), dim3(256), 0, STREAM(stream), in, C, HW, scratch);
-    int rc = g6d_check_launch("nchw_inv_norm");
-    if (rc != G6D_OK) return rc;
-  }
   hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((HW + 63) / 64, (C + 63) / 64, N), dim3(256), 0, STREAM(stream), in, C, HW,
-                     l2norm ? scratch : nullptr, out, ld_out);
-  return g6d_check_launch("nchw_to_nhwc");
+                     out, ld_out);
+  int rc = g6d_check_launch("nchw_to_nhwc");
+  if (rc != G6D_OK || !l2norm) return rc;
+  const int rows = N * HW;
+  hipLaunchKernelGGL(l2norm_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, STREAM(stream), out, rows, C, ld_out);
+  return g6d_check_launch("l2norm_rows");
 }
 
 extern "C" int g6d_vps_norm(const float* vps, int D, float* feats, int ld, int c_off, g6d_stream_t stream) {

@@ -18,21 +18,30 @@ __global__ void ref_sums_kernel(const float* __restrict__ refs, int D, int HWC, 
   r1[i] = s1; r2[i] = s2;
 }
 
-__global__ void prod_affine_kernel(const float* __restrict__ que, const double* __restrict__ r1,
-                                   const double* __restrict__ r2, int HW, int C, double inv_n, double eps,
-                                   float* __restrict__ scale, float* __restrict__ shift) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// block = 64 channels x 4 position lanes; fp64 accumulation, LDS combine
+__global__ void __launch_bounds__(256) prod_affine_kernel(const float* __restrict__ que, const double* __restrict__ r1,
+                                                          const double* __restrict__ r2, int HW, int C, double inv_n,
+                                                          double eps, float* __restrict__ scale,
+                                                          float* __restrict__ shift) {
+  __shared__ double sm[4][64], se[4][64];
+  const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   double m = 0, e = 0;
-  for (int p = 0; p < HW; ++p) {
-    double q = que[(size_t)p * C + c];
-    m += q * r1[(size_t)p * C + c];
-    e += q * q * r2[(size_t)p * C + c];
+  if (c < C)
+    for (int p = pl; p < HW; p += 4) {
+      const double q = que[(size_t)p * C + c];
+      m += q * r1[(size_t)p * C + c];
+      e += q * q * r2[(size_t)p * C + c];
+    }
+  sm[pl][cl] = m; se[pl][cl] = e;
+  __syncthreads();
+  if (pl == 0 && c < C) {
+    m = (sm[0][cl] + sm[1][cl] + sm[2][cl] + sm[3][cl]) * inv_n;
+    e = (se[0][cl] + se[1][cl] + se[2][cl] + se[3][cl]) * inv_n;
+    double var = e - m * m; if (var < 0) var = 0;
+    const double rs = 1.0 / sqrt(var + eps);
+    scale[c] = (float)rs; shift[c] = (float)(-m * rs);
   }
-  m *= inv_n; e *= inv_n;
-  double var = e - m * m; if (var < 0) var = 0;
-  double rs = 1.0 / sqrt(var + eps);
-  scale[c] = (float)rs; shift[c] = (float)(-m * rs);
 }
 
 // rows = D*HW; one wave per row, 4 rows in flight per wave.
@@ -91,7 +100,7 @@ extern "C" int g6d_selector_ref_sums(const float* refs, int D, int HW, int C, do
 extern "C" int g6d_selector_prod_affine(const float* que, const double* r1, const double* r2, int D, int HW, int C,
                                         double eps, float* scale, float* shift, g6d_stream_t stream) {
   if (!que || !r1 || !r2 || !scale || !shift || D <= 0 || HW <= 0 || C <= 0) { g6d_set_error("selector_prod_affine: bad args"); return G6D_EINVAL; }
-  hipLaunchKernelGGL(prod_affine_kernel, dim3((C + 63) / 64), dim3(64), 0, STREAM(stream), que, r1, r2, HW, C,
+  hipLaunchKernelGGL(prod_affine_kernel, dim3((C + 63) / 64), dim3(256), 0, STREAM(stream), que, r1, r2, HW, C,
                      1.0 / ((double)D * HW), eps, scale, shift);
   return g6d_check_launch("selector_prod_affine");
 }

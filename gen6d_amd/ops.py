@@ -210,9 +210,7 @@ def nchw_to_nhwc(x, out, l2norm):
     _, _, Ho, Wo, Co, ld_out = _cl5(out, "nchw_to_nhwc.out")
     if (Ho, Wo, Co) != (H, W, Cc):
         raise ValueError("nchw_to_nhwc: shape mismatch")
-    scratch = torch.empty((N, H, W), dtype=torch.float32, device=x.device) if l2norm else None
-    _lib.check(_lib.load().g6d_nchw_to_nhwc(_ptr(x), N, Cc, H, W, int(l2norm), _ptr(out), ld_out, _ptr(scratch), _stream()),
-               "g6d_nchw_to_nhwc")
+    _lib.check(_lib.load().g6d_nchw_to_nhwc(_ptr(x), N, Cc, H, W, int(l2norm), _ptr(out), ld_out, _stream()), "g6d_nchw_to_nhwc")
     return out
 
 

@@ -112,9 +112,8 @@ int g6d_bias_relu_pool_nchw(const float* in, const float* bias, int N, int C, in
                             g6d_stream_t stream);
 
 /* NCHW (backbone output) -> channels-last, optionally L2-normalised over C (F.normalize eps 1e-12,
- * network/selector.py:118, network/refiner.py:69-71). out [N][H][W][ld_out]; scratch: N*H*W floats (only if l2norm). */
-int g6d_nchw_to_nhwc(const float* in, int N, int C, int H, int W, int l2norm, float* out, int ld_out, float* scratch,
-                     g6d_stream_t stream);
+ * network/selector.py:118, network/refiner.py:69-71). out [N][H][W][ld_out]. */
+int g6d_nchw_to_nhwc(const float* in, int N, int C, int H, int W, int l2norm, float* out, int ld_out, g6d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Selector similarity (network/selector.py:183-186,192-195 and the InstanceNorm3d(512) at :28,49,63).  The
