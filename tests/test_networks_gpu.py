@@ -140,3 +140,50 @@ def test_refiner_feature_volume_intermediates(golden):
     np.testing.assert_allclose(v(mean_in[:, :128]), g["vol_mean"][0], atol=3e-4)
     np.testing.assert_allclose(v(mean_in[:, 128:]), g["vol_in"][0], atol=3e-4)
     np.testing.assert_allclose(v(std), g["vol_std"][0], atol=3e-4)
+
+
+def test_selector_36_rotations():
+    """BASELINE config 2 variant: 36 in-plane rotations (reachable only with selector_angle_num=36 weights)."""
+    out, (l32, a32), (l64, a64) = _selector_case(12, 36)
+    _accept(out["ref_vp_logits"], l32, l64, what="logits an=36")
+    _accept(out["angles_pr"], a32, a64, what="angles an=36")
+    assert np.array_equal(out["ref_vp_logits"].argmax(1).cpu().numpy(), l64.argmax(1).numpy())
+
+
+@pytest.mark.parametrize("rfn,an", [(2, 5), (3, 1), (5, 3)])
+def test_selector_small_and_ragged(rfn, an):
+    """Edge shapes: two reference views (the reference's InstanceNorm1d over the reference axis raises for one), a
+    single rotation, sizes that are not multiples of any tile."""
+    out, (l32, a32), (l64, a64) = _selector_case(rfn, an)
+    assert out["ref_vp_logits"].shape == (1, rfn)
+    _accept(out["ref_vp_logits"], l32, l64, tol=2e-4, what="logits")
+    _accept(out["angles_pr"], a32, a64, tol=2e-4, what="angles")
+
+
+@pytest.mark.parametrize("rfn,hq,wq", [(1, 64, 96), (5, 72, 104), (32, 128, 128)])
+def test_detector_ragged_sizes(rfn, hq, wq):
+    """Query sizes that are multiples of 8 but not of 32 (every scale is padded up to x32 internally), odd ref counts."""
+    net = _net("detector")
+    case = synth.detector_case(rfn, hq, wq)
+    sd = synth.synth_state_dict("detector"); sd64 = O.to_double(sd)
+    with torch.no_grad():
+        out = net({"ref_imgs_info": {"imgs": case["ref_imgs"].cuda()}, "que_imgs_info": {"imgs": case["que_imgs"].cuda()}})
+        o32 = O.detector_detect(sd, case["que_imgs"], O.detector_ref_feats(sd, case["ref_imgs"]))
+        o64 = O.detector_detect(sd64, case["que_imgs"].double(), O.detector_ref_feats(sd64, case["ref_imgs"].double()))
+    for k in ("scores", "select_pr_offset", "select_pr_scale"):
+        assert out[k].shape == o64[k].shape
+        _accept(out[k], o32[k], o64[k], what=k)
+    assert np.array_equal(out["que_select_id"].cpu().numpy(), o64["que_select_id"].numpy())
+
+
+def test_multi_query_batch():
+    """qn = 3 queries in one call keep the reference's [qn, ...] contracts (selector and detector)."""
+    net = _net("selector")
+    case = synth.selector_case(8, 5)
+    ques = synth.imgs_to_tensor(synth.synth_images(3, 128, 128, 77)).cuda()
+    with torch.no_grad():
+        net.extract_ref_feats(case["ref_imgs"].cuda(), case["ref_poses"].cuda(), case["object_center"].cuda(), case["object_vert"].cuda())
+        logits, angles = net.compute_view_point_feats(ques)
+        one = net.compute_view_point_feats(ques[1:2])
+    assert logits.shape == (3, 8) and angles.shape == (3, 8)
+    np.testing.assert_allclose(logits[1].cpu().numpy(), one[0][0].cpu().numpy(), atol=1e-4)   # atomics order, MIOpen batch algo
