@@ -40,6 +40,9 @@ def main():
     ap.add_argument("--det-refs", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="time the eager launch path instead of hipGraph replay")
+    ap.add_argument("--serial", action="store_true",
+                    help="profiling aid: no stream fork/join and no graph, so that per-kernel durations in a rocprofv3 "
+                         "trace are not inflated by overlap (this is how the roofline pass itself runs)")
     ap.add_argument("--shard-refs", action="store_true",
                     help="strong-scaling variant: all ranks work on the SAME query stream, the selector's reference cache "
                          "is sharded over the ranks (RCCL statistics all-reduces + feature all-gather); default is query replicas")
@@ -64,7 +67,9 @@ def main():
     fulls = synth.imgs_to_tensor(synth.synth_images(4, 480, 640, seed=100 + qseed)).to(dev)
     crops = synth.imgs_to_tensor(synth.synth_images(4, 128, 128, seed=200 + qseed)).to(dev)
 
-    use_graph = not args.no_graph and not shard_refs     # collectives are issued eagerly
+    use_graph = not args.no_graph and not shard_refs and not args.serial     # collectives are issued eagerly
+    if args.serial:
+        ops.SERIAL = True
     if use_graph:
         pipe.capture()
 
@@ -99,7 +104,7 @@ def main():
         for i in range(args.steps):
             step(args.warmup + i, eager=True)
         torch.cuda.synchronize()
-        ops.SERIAL = False
+        ops.SERIAL = args.serial
     prof, ops.PROFILE = ops.PROFILE, None
     rows = parallel.gather_rows(torch.cat(rows, 0), world * args.steps) if (world > 1 and not shard_refs) else torch.cat(rows, 0)
     n_queries = args.steps if shard_refs else world * args.steps
