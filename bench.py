@@ -40,6 +40,8 @@ def main():
     ap.add_argument("--det-refs", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="time the eager launch path instead of hipGraph replay")
+    ap.add_argument("--lanes", type=int, default=2,
+                    help="independent hipGraph copies kept in flight on separate streams (queries are independent)")
     ap.add_argument("--serial", action="store_true",
                     help="profiling aid: no stream fork/join and no graph, so that per-kernel durations in a rocprofv3 "
                          "trace are not inflated by overlap (this is how the roofline pass itself runs)")
@@ -70,16 +72,32 @@ def main():
     use_graph = not args.no_graph and not shard_refs and not args.serial     # collectives are issued eagerly
     if args.serial:
         ops.SERIAL = True
+    lanes = max(1, args.lanes) if use_graph else 1
     if use_graph:
-        pipe.capture()
+        pipe.capture(lanes=lanes)
+    main_stream = torch.cuda.current_stream(dev)
+    lane_busy = [None] * lanes
 
     def step(i, eager=False):
         j = i % 4
-        fn = pipe.query if (eager or not use_graph) else pipe.query_graph
-        return fn(fulls[j:j + 1], crops[j:j + 1])
+        if eager or not use_graph:
+            return pipe.query(fulls[j:j + 1], crops[j:j + 1])
+        lane = i % lanes
+        if lane_busy[lane] is not None:
+            lane_busy[lane].synchronize()            # the lane's static buffers are free again
+        out, stream = pipe.query_graph(fulls[j:j + 1], crops[j:j + 1], lane)
+        ev = torch.cuda.Event(); ev.record(stream)
+        lane_busy[lane] = ev
+        return out
+
+    def drain():
+        for ev in lane_busy:
+            if ev is not None:
+                main_stream.wait_event(ev)
 
     for i in range(args.warmup):
         step(i)
+    drain()
     torch.cuda.synchronize()
     parallel.barrier()
     torch.cuda.synchronize()
@@ -88,6 +106,7 @@ def main():
     ops.marker(1)
     t0 = time.perf_counter()
     rows = [step(args.warmup + i) for i in range(args.steps)]
+    drain()
     ops.marker(2)
     torch.cuda.synchronize()
     parallel.barrier()
@@ -125,7 +144,7 @@ def main():
                                f"128x128 crop vs {args.sel_refs} refs x 5 rotations + 3 refiner steps (6 refs, 32^3 volume); "
                                "seeded synthetic weights", "sharding": (f"selector references sharded x{world}, detector/refiner replicated" if shard_refs
                                 else f"query-replicas x{world}"),
-                   "launch": "hipGraph replay (1 graph = 1 query)" if use_graph else "eager"},
+                   "launch": f"hipGraph replay (1 graph = 1 query), {lanes} queries in flight on separate streams" if use_graph else "eager"},
         "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (fp32 v_mfma_f32_32x32x2_f32, incl. split-K reduce)",
                      "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,

@@ -55,26 +55,40 @@ class TensorPipeline:
         return torch.cat([det["positions"], det["scales"][:, None], idx[:, None].float(), ang[:, None], rot, off, scl], 1)
 
     # ------------------------------------------------------------------ hipGraph
-    def capture(self, full_shape=(1, 3, 480, 640), crop_shape=(1, 3, 128, 128), warmup=2):
-        """Capture one query (~770 kernel launches: MIOpen trunk + HIP kernels) into a hipGraph with static input /
-        output buffers; `query_graph` then replays it.  Removes the per-launch host cost of the eager path."""
+    def capture(self, full_shape=(1, 3, 480, 640), crop_shape=(1, 3, 128, 128), warmup=2, lanes=1):
+        """Capture one query (~800 kernel launches: MIOpen trunk + HIP kernels, with forked side streams) into a
+        hipGraph with static input / output buffers.  `lanes` > 1 captures that many independent copies (own static
+        buffers and intermediates, shared read-only reference state) so that `query_graph(..., lane=i)` can keep
+        several queries in flight on different streams: the small grids of one query leave CUs idle that the next
+        query fills."""
         d = self.device
-        self._g_full = torch.zeros(full_shape, dtype=torch.float32, device=d)
-        self._g_crop = torch.zeros(crop_shape, dtype=torch.float32, device=d)
+        self._lanes = []
         side = torch.cuda.Stream(device=d)
-        side.wait_stream(torch.cuda.current_stream(d))
-        with torch.cuda.stream(side):
-            for _ in range(warmup):                      # MIOpen find, workspace and allocator warm-up off-graph
-                self.query(self._g_full, self._g_crop)
-        torch.cuda.current_stream(d).wait_stream(side)
+        for _ in range(lanes):
+            g_full = torch.zeros(full_shape, dtype=torch.float32, device=d)
+            g_crop = torch.zeros(crop_shape, dtype=torch.float32, device=d)
+            stream = torch.cuda.Stream(device=d)
+            stream.wait_stream(torch.cuda.current_stream(d))
+            with torch.cuda.stream(stream):
+                for _ in range(warmup):                  # MIOpen find, workspaces and allocator warm-up off-graph
+                    self.query(g_full, g_crop)
+            torch.cuda.synchronize(d)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=stream):
+                g_out = self.query(g_full, g_crop)
+            self._lanes.append((graph, stream, g_full, g_crop, g_out))
         torch.cuda.synchronize(d)
-        self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
-            self._g_out = self.query(self._g_full, self._g_crop)
-        return self._graph
+        return self._lanes
 
-    def query_graph(self, que_full, que_crop):
-        self._g_full.copy_(que_full, non_blocking=True)
-        self._g_crop.copy_(que_crop, non_blocking=True)
-        self._graph.replay()
-        return self._g_out.clone()
+    def query_graph(self, que_full, que_crop, lane=0):
+        """Enqueue one query on lane `lane` (its own stream) and return its static output row; call
+        `torch.cuda.synchronize()` (or sync the lane's stream) before reading, and before reusing the lane."""
+        graph, stream, g_full, g_crop, g_out = self._lanes[lane]
+        cur = torch.cuda.current_stream(self.device)
+        stream.wait_stream(cur)
+        with torch.cuda.stream(stream):
+            g_full.copy_(que_full, non_blocking=True)
+            g_crop.copy_(que_crop, non_blocking=True)
+            graph.replay()
+            out = g_out.clone()
+        return out, stream
