@@ -148,6 +148,7 @@ class VolumeRefiner(ParamBank):
     def _step(self, que_img, K_in, pose_in, ref_imgs, ref_Ks, ref_poses):
         sn = self.cfg["refiner_sample_num"]
         dev = que_img.device
+        ops.stats_arena_begin(dev)
         rfn = ref_imgs.shape[0]
         h_in, w_in = ref_imgs.shape[-2:]
         feats = self.run_feature_net(torch.cat([ref_imgs, que_img], 0))                  # query last

@@ -202,6 +202,7 @@ class ViewpointSelector(ParamBank):
         rfn_all, rfn = self.rfn, self.r_end - self.r_begin                  # global / local reference counts
         D, Dg = rfn * an, rfn_all * an
         dev = que_img.device
+        ops.stats_arena_begin(dev)
         qf = self.get_feats(que_img)
         cat = torch.empty((D, 1, 4, 4, 768), dtype=torch.float32, device=dev)
         levels = [(lambda l=l: self._level(l, qf[l], cat)) for l in range(3)]

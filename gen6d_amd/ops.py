@@ -10,6 +10,7 @@ per-op PyTorch references of tests/ref_ops.py to validate host orchestration wit
 has no fallback — `lib.load()` raises if libgen6d_hip.so is absent.
 """
 import ctypes as C
+import os as _os
 
 import torch
 
@@ -151,8 +152,33 @@ def corr2d_patch(x, w, out, k):
     return out
 
 
+_ARENA = {}          # (device, stream) -> [buffer, bump offset]
+_CUR_ARENA = None    # arena of the query being enqueued (host-side state; set by stats_arena_begin)
+ARENA_DOUBLES = 1 << 17
+
+
+def stats_arena_begin(device):
+    """Start a new query: zero ONE per-(device, stream) arena of fp64 (sum, sumsq) accumulators; new_stats() then hands
+    out slices of it instead of launching one zero-fill kernel per InstanceNorm layer (62 per query).  Keyed by the
+    launching stream so that queries captured / enqueued on different streams never share accumulators."""
+    global _CUR_ARENA
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    if key not in _ARENA:
+        _ARENA[key] = [torch.zeros(ARENA_DOUBLES, dtype=torch.float64, device=device), 0]
+    a = _ARENA[key]
+    a[0].zero_()
+    a[1] = 0
+    _CUR_ARENA = a
+
+
 def new_stats(groups, channels, device):
-    return torch.zeros((groups, channels, 2), dtype=torch.float64, device=device)
+    a = None if _os.environ.get("G6D_NO_ARENA") else _CUR_ARENA
+    n = groups * channels * 2
+    if a is None or a[0].device != torch.device(device) or a[1] + n > ARENA_DOUBLES:
+        return torch.zeros((groups, channels, 2), dtype=torch.float64, device=device)
+    t = a[0][a[1]:a[1] + n].view(groups, channels, 2)
+    a[1] += n
+    return t
 
 
 def stats_finalize(stats, count, eps=1e-5):

@@ -51,6 +51,10 @@ def corr2d_patch(x, w, out, k):
     return conv(x, w, None, out, ksize=(1, k, k), pad=(0, k // 2, k // 2))
 
 
+def stats_arena_begin(device):
+    pass
+
+
 def new_stats(groups, channels, device):
     return torch.zeros((groups, channels, 2), dtype=torch.float64, device=device)
 
