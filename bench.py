@@ -142,7 +142,7 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"full tensor pipeline: detector 480x640 query vs {args.det_refs} refs (4 scales) + selector "
                                f"128x128 crop vs {args.sel_refs} refs x 5 rotations + 3 refiner steps (6 refs, 32^3 volume); "
-                               "seeded synthetic weights", "sharding": (f"selector references sharded x{world}, detector/refiner replicated" if shard_refs
+                               "seeded synthetic weights", "sharding": (f"selector and detector references sharded x{world} (RCCL all-reduce/all-gather), refiner replicated" if shard_refs
                                 else f"query-replicas x{world}"),
                    "launch": f"hipGraph replay (1 graph = 1 query), {lanes} queries in flight on separate streams" if use_graph else "eager"},
         "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (fp32 v_mfma_f32_32x32x2_f32, incl. split-K reduce)",

@@ -13,9 +13,10 @@ then g6d_detector_score_mlp_max     score_conv MLP + max over references, never 
 """
 import numpy as np
 import torch
+import torch.distributed as dist
 import torch.nn.functional as F
 
-from .. import ops, specs
+from .. import ops, parallel, specs
 from .backbone import img_norm, vgg_taps
 from .params import ParamBank, fold_vgg
 
@@ -36,6 +37,14 @@ class Detector(ParamBank):
         self.pool_ratio = 8
         self.ref_center_feats = None     # three [rfn, k*k, 512] correlation filters
         self.ref_shape = None
+        self.rank, self.world, self.group = 0, 1, None
+
+    def set_shard(self, rank, world, group=None):
+        """Reference-sharded mode: this rank correlates the query against references
+        parallel.shard_range(rfn, rank, world) only; correlation, score assembly and the score MLP are per-reference, and
+        `torch.max(scores, 2)` over the references (detector.py:247) becomes one all-reduce(MAX) of the [hs*ws, 64]
+        feature map (1.2 MB at 60x80) over torch.distributed (RCCL).  The query trunk and the heads are replicated."""
+        self.rank, self.world, self.group = int(rank), int(world), group
 
     # ------------------------------------------------------------------ weights
     def _pack(self):
@@ -67,8 +76,11 @@ class Detector(ParamBank):
     def load_impl(self, ref_imgs):
         """ref_imgs [rfn,3,h,w] in [0,1]; nearest resize to 120x120, trunk, keep as correlation filters
         (reference detector.py:199-205)."""
-        ref_imgs = F.interpolate(ref_imgs, size=(120, 120))
-        feats = self.extract_feats(ref_imgs)                       # [rfn,1,k,k,512]
+        b, e = parallel.shard_range(ref_imgs.shape[0], self.rank, self.world)
+        if e == b:
+            raise ValueError("more ranks than reference views")
+        ref_imgs = F.interpolate(ref_imgs[b:e], size=(120, 120))
+        feats = self.extract_feats(ref_imgs)                       # [rfn_local,1,k,k,512]
         self.ref_center_feats = [f.reshape(f.shape[0], f.shape[2] * f.shape[3], 512).contiguous() for f in feats]
         self.ref_ksize = [f.shape[2] for f in feats]               # 15, 7, 3
         self.ref_shape = [120, 120]
@@ -107,7 +119,9 @@ class Detector(ParamBank):
         # the scales are independent until `stacked` is complete: largest first on the main stream
         order = sorted(enumerate(self.cfg["detection_scales"]), key=lambda t: -t[1])
         ops.fork_join([(lambda si=si, sc=sc: one_scale(si, sc)) for si, sc in order], dev)
-        feats = ops.detector_score_mlp_max(stacked, *pk["mlp"])               # [P,64]
+        feats = ops.detector_score_mlp_max(stacked, *pk["mlp"])               # [P,64], max over the local references
+        if self.world > 1:
+            dist.all_reduce(feats, op=dist.ReduceOp.MAX, group=self.group)
         P = hs * ws
         k3, p3 = (1, 3, 3), (0, 1, 1)
         a = torch.empty((1, 1, hs, ws, 192), dtype=torch.float32, device=dev)

@@ -21,7 +21,8 @@ class TensorPipeline:
         for k, net in (("detector", self.detector), ("selector", self.selector), ("refiner", self.refiner)):
             net.load_state_dict(self.state_dicts[k])
             net.to(self.device).eval()
-        self.selector.set_shard(*shard)          # (rank, world): references of the selector sharded over the ranks
+        self.selector.set_shard(*shard)          # (rank, world): references of selector and detector sharded over the ranks
+        self.detector.set_shard(*shard)
 
     def build(self, seed=1):
         """Reference state from synthetic views (Gen6DEstimator.build, reference estimator.py:139-171)."""

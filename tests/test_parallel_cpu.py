@@ -91,3 +91,40 @@ def test_reference_sharded_selector_matches_golden(tmp_path, world, port):
                          env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert out.stdout.count("sharded selector ok") == world
+
+
+DET_WORKER = textwrap.dedent("""
+    import sys, numpy as np, torch
+    sys.path.insert(0, %r); sys.path.insert(0, %r)
+    import ref_ops
+    from gen6d_amd import ops, parallel, synth
+    from gen6d_amd.network import name2network
+    for name in dir(ops):
+        if not name.startswith("_") and callable(getattr(ops, name)) and hasattr(ref_ops, name):
+            setattr(ops, name, getattr(ref_ops, name))
+    rank, world, local = parallel.init_from_env(backend="gloo")
+    g = dict(np.load(%r))
+    net = name2network["detector"]({"name": "t"}).eval()
+    net.load_state_dict(synth.synth_state_dict("detector"))
+    net.set_shard(rank, world)
+    case = synth.detector_case(int(g["rfn"]), int(g["hq"]), int(g["wq"]))
+    with torch.no_grad():
+        out = net({"ref_imgs_info": {"imgs": case["ref_imgs"]}, "que_imgs_info": {"imgs": case["que_imgs"]}})
+    assert net.ref_center_feats[0].shape[0] < int(g["rfn"])            # only the local references are resident
+    for k in ("scores", "select_pr_offset", "select_pr_scale"):
+        np.testing.assert_allclose(out[k].numpy(), g[k], rtol=1e-3, atol=1e-3 * np.abs(g[k]).max())
+    assert np.array_equal(out["que_select_id"].numpy(), g["que_select_id"])
+    print("rank", rank, "sharded detector ok")
+""")
+
+
+def test_reference_sharded_detector_matches_golden(tmp_path):
+    """8 references sharded over 3 gloo ranks (3+3+2): all-reduce(MAX) of the score features reproduces the reference."""
+    script = tmp_path / "det_worker.py"
+    script.write_text(DET_WORKER % (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden", "det_small.npz")))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3",
+                          "--master-addr", "127.0.0.1", "--master-port", "29641", str(script)],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert out.stdout.count("sharded detector ok") == 3
