@@ -58,6 +58,7 @@ def main():
     rank, world, local = parallel.init_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    local = local % torch.cuda.device_count()        # (a gloo smoke run may place several ranks on one GPU)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 

@@ -13,7 +13,6 @@ then g6d_detector_score_mlp_max     score_conv MLP + max over references, never 
 """
 import numpy as np
 import torch
-import torch.distributed as dist
 import torch.nn.functional as F
 
 from .. import ops, parallel, specs
@@ -121,7 +120,7 @@ class Detector(ParamBank):
         ops.fork_join([(lambda si=si, sc=sc: one_scale(si, sc)) for si, sc in order], dev)
         feats = ops.detector_score_mlp_max(stacked, *pk["mlp"])               # [P,64], max over the local references
         if self.world > 1:
-            dist.all_reduce(feats, op=dist.ReduceOp.MAX, group=self.group)
+            parallel.all_reduce_(feats, "max", self.group)
         P = hs * ws
         k3, p3 = (1, 3, 3), (0, 1, 1)
         a = torch.empty((1, 1, hs, ws, 192), dtype=torch.float32, device=dev)

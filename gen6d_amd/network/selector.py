@@ -21,7 +21,6 @@ messages are KB-sized, i.e. latency-bound).  Results equal the unsharded ones up
 """
 import numpy as np
 import torch
-import torch.distributed as dist
 import torch.nn.functional as F
 
 from .. import ops, parallel, specs
@@ -62,7 +61,7 @@ class ViewpointSelector(ParamBank):
         if self.world == 1:
             return
         flat = torch.cat([t.reshape(-1) for t in tensors])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        parallel.all_reduce_(flat, "sum", self.group)
         o = 0
         for t in tensors:
             t.copy_(flat[o:o + t.numel()].view_as(t)); o += t.numel()
@@ -71,16 +70,7 @@ class ViewpointSelector(ParamBank):
         """[n_local, F] per rank -> [n_total, F] in global reference order."""
         if self.world == 1:
             return rows
-        cap = (n_total + self.world - 1) // self.world
-        pad = torch.zeros((cap, rows.shape[1]), dtype=rows.dtype, device=rows.device)
-        pad[:rows.shape[0]] = rows
-        bufs = [torch.empty_like(pad) for _ in range(self.world)]
-        dist.all_gather(bufs, pad, group=self.group)
-        out = []
-        for r in range(self.world):
-            b, e = parallel.shard_range(n_total, r, self.world)
-            out.append(bufs[r][:e - b])
-        return torch.cat(out, 0)
+        return parallel.all_gather_ragged_rows(rows, n_total, self.world, self.group)
 
     # ------------------------------------------------------------------ weights
     def _pack(self):

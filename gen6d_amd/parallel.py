@@ -18,7 +18,7 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("G6D_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -37,8 +37,13 @@ def barrier():
         dist.barrier()
 
 
+def _coll_device(device):
+    """gloo moves data through host memory; RCCL ("nccl") works on device tensors."""
+    return "cpu" if (dist.is_initialized() and dist.get_backend() == "gloo") else device
+
+
 def max_over_ranks(value, device="cpu"):
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=_coll_device(device))
     if dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
@@ -49,6 +54,8 @@ def gather_rows(local_rows, n_items):
     if not dist.is_initialized():
         return local_rows
     world, rank = dist.get_world_size(), dist.get_rank()
+    out_device = local_rows.device
+    local_rows = local_rows.to(_coll_device(local_rows.device))
     width = local_rows.shape[1]
     cap = (n_items + world - 1) // world
     pad = torch.zeros((cap, width), dtype=local_rows.dtype, device=local_rows.device)
@@ -59,4 +66,35 @@ def gather_rows(local_rows, n_items):
     for r in range(world):
         b, e = shard_range(n_items, r, world)
         out.append(bufs[r][:e - b])
-    return torch.cat(out, 0)
+    return torch.cat(out, 0).to(out_device)
+
+
+def all_reduce_(t, op="sum", group=None):
+    """In-place all-reduce of a tensor that may live on the GPU (RCCL) or must be staged through the host (gloo)."""
+    if not dist.is_initialized():
+        return t
+    rop = dist.ReduceOp.SUM if op == "sum" else dist.ReduceOp.MAX
+    dev = _coll_device(t.device)
+    if str(dev) == "cpu" and t.is_cuda:
+        h = t.cpu()
+        dist.all_reduce(h, op=rop, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=rop, group=group)
+    return t
+
+
+def all_gather_ragged_rows(rows, n_total, world, group=None):
+    """[n_local, F] per rank (contiguous shard_range slices) -> [n_total, F] in global order."""
+    out_device = rows.device
+    rows = rows.to(_coll_device(rows.device))
+    cap = (n_total + world - 1) // world
+    pad = torch.zeros((cap, rows.shape[1]), dtype=rows.dtype, device=rows.device)
+    pad[:rows.shape[0]] = rows
+    bufs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad, group=group)
+    out = []
+    for r in range(world):
+        b, e = shard_range(n_total, r, world)
+        out.append(bufs[r][:e - b])
+    return torch.cat(out, 0).to(out_device)
