@@ -2,7 +2,6 @@
 reference estimator.py:173-216 without the host-side cv2 warps, which are SURVEY.md §8(f) "next" rows).
 Used by bench.py, __graft_entry__.smoke() and the GPU tests; mirrors `Gen6DEstimator`'s stage order and defaults
 (det 32 refs, sel 64 refs x 5 rotations, 6 refiner views, refine_iter 3)."""
-import numpy as np
 import torch
 
 from . import synth

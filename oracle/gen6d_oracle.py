@@ -11,7 +11,6 @@ of the reference's own modules, run in the build container with import stubs by 
 committed as tests/golden/*.npz (tests/test_oracle_golden.py).  It accepts float64 state_dicts/inputs to provide
 the fp64 ground truth used to grade fp32 noise.
 """
-import math
 
 import numpy as np
 import torch
