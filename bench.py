@@ -131,6 +131,14 @@ def main():
 
     if rank != 0:
         return
+    # HBM traffic of the dominant kernel family cannot be read without rocprofv3: it is taken from the committed PMC
+    # summary of the same command (profiles/r01_pmc_conv_traffic.json, produced with tools/rocpd_pmc.py), else null
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_conv_traffic.json")) as f:
+            traffic = json.load(f)["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
     flops = sum(p[0] for p in prof)
     ms = sum(p[1].elapsed_time(p[2]) for p in prof)
     n_launch = max(len(prof), 1)
@@ -148,7 +156,8 @@ def main():
                    "launch": f"hipGraph replay (1 graph = 1 query), {lanes} queries in flight on separate streams" if use_graph else "eager"},
         "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (fp32 v_mfma_f32_32x32x2_f32, incl. split-K reduce)",
                      "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                     "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                     "traffic_unit": "HBM-side bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_conv_traffic.json)",
                      "launches_per_step": n_launch / args.steps, "gflop_per_launch": flops / n_launch / 1e9,
                      "avg_launch_ms": ms / n_launch, "conv_ms_per_step": ms / args.steps,
                      "measured": "HIP events around every g6d_conv_igemm launch, " +
