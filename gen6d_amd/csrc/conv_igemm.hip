@@ -18,6 +18,7 @@
 // second kernel that carries the same epilogue.
 #include "g6d_common.h"
 #include <type_traits>
+#include <stdlib.h>
 
 #define LDS_K 36
 #define BK 32
@@ -29,6 +30,8 @@
 
 int g6d_splitk_reduce_launch(const float* ws, int splits, int M, int Cout, const float* bias, int act, float* out,
                              int ld_out, double* stats, int rows_per_group, hipStream_t stream);
+// conv_igemm_ws.hip: warp-specialised variant (producer waves load, consumer waves run the MFMAs)
+int g6d_conv_igemm_ws_launch(const G6dConv& d, int M, int T, int nChunks, int bn, int splits, hipStream_t stream);
 
 namespace {
 
@@ -545,6 +548,12 @@ extern "C" int g6d_conv_igemm(const G6dConv* desc, g6d_stream_t stream_) {
       if (splits < 2) splits = 1;
     }
   }
+  // Warp-specialised variant for the 128-row tiles (all prologue modes except the per-image affine tables), opt-in with
+  // G6D_CONV_WS=1: it measures the same 90 TFLOP/s as the single-role kernel on the large layers and is slower with the
+  // multiplier prologue, i.e. moving the load path to other waves does not lift the limit.
+  static const bool use_ws = []() { const char* e = getenv("G6D_CONV_WS"); return e && e[0] == '1'; }();
+  if (use_ws && bm == 128 && !(d.in_scale && d.in_affine_per_n))
+    return g6d_conv_igemm_ws_launch(d, M, T, nChunks, bn, splits, stream);
   if (bm == 64) return launch_cfg<64, 64, 2, 2>(d, M, T, nChunks, splits, stream);
   if (bn == 32) return launch_cfg<128, 32, 4, 1>(d, M, T, nChunks, splits, stream);
   if (bn == 64) return launch_cfg<128, 64, 2, 2>(d, M, T, nChunks, splits, stream);

@@ -313,3 +313,12 @@ def test_corr2d_patch(ops, H, W, Cin, Cout, k):
     ref_ops.corr2d_patch(_d(x), _d(w), ref, k)
     _check(out, ref, 2e-5, "corr2d_patch")
     assert (obuf[..., Cout:] == -5.0).all()
+
+
+def test_conv_warp_specialised_variant():
+    """The opt-in producer/consumer variant (G6D_CONV_WS=1, read once per process) passes the same conv cases."""
+    import os, subprocess, sys
+    env = dict(os.environ, G6D_CONV_WS="1")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k", "test_conv_igemm"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
