@@ -188,3 +188,38 @@ def test_multi_query_batch():
         one = net.compute_view_point_feats(ques[1:2])
     assert logits.shape == (3, 8) and angles.shape == (3, 8)
     np.testing.assert_allclose(logits[1].cpu().numpy(), one[0][0].cpu().numpy(), atol=1e-4)   # atomics order, MIOpen batch algo
+
+
+def test_selector_reference_permutation_equivariance_full_size():
+    """Size-independent property at the headline size (64 refs x 5 rotations): permuting the reference views permutes
+    logits and angles the same way (every cross-reference op — InstanceNorm statistics, attention — is symmetric in the
+    references, and `object_forward` is pinned by keeping view 0 first)."""
+    an, rfn = 5, 64
+    case = synth.selector_case(rfn, an)
+    net = _net("selector", selector_angle_num=an)
+    perm = torch.cat([torch.zeros(1, dtype=torch.long), 1 + torch.randperm(rfn - 1, generator=torch.Generator().manual_seed(5))])
+    with torch.no_grad():
+        args = (case["object_center"].cuda(), case["object_vert"].cuda())
+        net.extract_ref_feats(case["ref_imgs"].cuda(), case["ref_poses"].cuda(), *args)
+        l0, a0 = net.compute_view_point_feats(case["que_imgs"].cuda())
+        net.extract_ref_feats(case["ref_imgs"][:, perm].cuda(), case["ref_poses"][perm].cuda(), *args)
+        l1, a1 = net.compute_view_point_feats(case["que_imgs"].cuda())
+    np.testing.assert_allclose(l1.cpu().numpy(), l0[:, perm.cuda()].cpu().numpy(), atol=2e-4)
+    np.testing.assert_allclose(a1.cpu().numpy(), a0[:, perm.cuda()].cpu().numpy(), atol=2e-4)
+    assert int(perm[l1.argmax(1)[0]]) == int(l0.argmax(1)[0])
+
+
+def test_detector_reference_permutation_invariance_full_size():
+    """Headline detector size (480x640 query, 32 refs): the max over references makes every output invariant to the
+    order of the reference views."""
+    case = synth.detector_case(32, 480, 640)
+    net = _net("detector")
+    perm = torch.randperm(32, generator=torch.Generator().manual_seed(6))
+    with torch.no_grad():
+        o0 = net({"ref_imgs_info": {"imgs": case["ref_imgs"].cuda()}, "que_imgs_info": {"imgs": case["que_imgs"].cuda()}})
+        o1 = net({"ref_imgs_info": {"imgs": case["ref_imgs"][perm].cuda()}, "que_imgs_info": {"imgs": case["que_imgs"].cuda()}})
+    for k in ("scores", "select_pr_offset", "select_pr_scale"):
+        rng = o0[k].abs().max().item()
+        assert (o0[k] - o1[k]).abs().max().item() <= 2e-5 * max(rng, 1.0), k
+    assert torch.equal(o0["que_select_id"], o1["que_select_id"])
+    assert o0["scores"].shape == (1, 1, 60, 80)
