@@ -35,7 +35,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--sel-refs", type=int, default=64)
     ap.add_argument("--det-refs", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
