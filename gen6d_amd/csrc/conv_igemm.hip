@@ -32,6 +32,9 @@ int g6d_splitk_reduce_launch(const float* ws, int splits, int M, int Cout, const
                              int ld_out, double* stats, int rows_per_group, hipStream_t stream);
 // conv_igemm_ws.hip: warp-specialised variant (producer waves load, consumer waves run the MFMAs)
 int g6d_conv_igemm_ws_launch(const G6dConv& d, int M, int T, int nChunks, int bn, int splits, hipStream_t stream);
+// conv_patch.hip: 3x3 / 3x3x3 stride-1 layers with Cout <= 64: spatial output tile, input patch reused by all taps
+bool g6d_conv_patch_eligible(const G6dConv& d);
+int g6d_conv_patch_launch(const G6dConv& d, int M, hipStream_t stream);
 
 namespace {
 
@@ -518,6 +521,8 @@ extern "C" int g6d_conv_igemm(const G6dConv* desc, g6d_stream_t stream_) {
   const long long Mll = (long long)d.N * d.Do * d.Ho * d.Wo;
   if (Mll > (1ll << 30)) { g6d_set_error("conv: M too large"); return G6D_EINVAL; }
   const int M = (int)Mll;
+  static const bool use_patch = []() { const char* e = getenv("G6D_CONV_PATCH"); return !(e && e[0] == '0'); }();
+  if (use_patch && g6d_conv_patch_eligible(d)) return g6d_conv_patch_launch(d, M, stream);
   const int T = d.kd * d.kh * d.kw;
   const int nChunks = (d.Cin + BK - 1) / BK;
   const int total = T * nChunks;

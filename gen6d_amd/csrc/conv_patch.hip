@@ -1,0 +1,285 @@
+// 3x3 / 3x3x3 stride-1 "same" convolution with the input patch of a spatial output tile kept in LDS and reused by all
+// taps (Cout <= 64).  Generalises corr_patch.hip: measured on conv_igemm.hip, what costs matrix-pipe time is the amount of
+// data brought into the CU per MFMA; an implicit-GEMM tile re-loads its 128 activation rows for every
+// one of the 9 / 27 taps, while a spatial tile of 128 outputs only needs its halo box once per channel chunk:
+//   3-D: outputs 2x8x8, patch 4x10x10 = 400 positions (instead of 27 x 128 = 3456 row loads per chunk)
+//   2-D: outputs 1x8x16, patch 1x10x18 = 180 positions (instead of 9 x 128 = 1152)
+// The prologue (multiplier, InstanceNorm affine, ReLU, zero padding) is applied once per patch element when it is
+// written to LDS instead of once per tap.  Weight tiles [64 co][32 ci] are streamed per tap (double-buffered).
+// Same fragment scheme (K-permuted ds_read_b128 + v_mfma_f32_32x32x2_f32), accumulator layout and epilogue (bias,
+// activation, channel-slice store, fp64 InstanceNorm statistics, split-K partials) as conv_igemm.hip.
+#include "g6d_common.h"
+
+#define LDS_K 36
+#define BN 64
+
+int g6d_splitk_reduce_launch(const float* ws, int splits, int M, int Cout, const float* bias, int act, float* out,
+                             int ld_out, double* stats, int rows_per_group, hipStream_t stream);
+
+namespace {
+
+__device__ __forceinline__ f32x4 ldg(const float* __restrict__ base, int elem_off) {
+  return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + ((unsigned)elem_off << 2));
+}
+
+// DIM3: 3-D tile 2x8x8 with kd = 3, else 2-D tile 1x8x16 with kd = 1.  MODE: 0 plain, 1 affine(+ReLU), 3 mul + affine.
+template <bool DIM3, int MODE>
+__global__ void __launch_bounds__(256) conv_patch_kernel(const G6dConv p, const int M, const int tiles_d, const int tiles_h,
+                                                         const int tiles_w, const int chunks_per_split,
+                                                         const int total_chunks, const int splits) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int TD = DIM3 ? 2 : 1, TH = 8, TW = DIM3 ? 8 : 16;
+  constexpr int KD = DIM3 ? 3 : 1, T = KD * 9;
+  constexpr int PD = TD + KD - 1, PH = TH + 2, PW = TW + 2, NPOS = PD * PH * PW;
+  constexpr int NPL = (NPOS * 8 + 255) / 256;                  // 16-byte patch loads per thread per chunk
+  constexpr int PATCH = NPOS * LDS_K, BT = BN * LDS_K;
+  constexpr bool AFF = MODE != 0, MUL = MODE == 3;
+  float* patch0 = lds; float* patch1 = lds + PATCH;
+  float* bt0 = lds + 2 * PATCH; float* bt1 = bt0 + BT;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;                     // wave tile 64 (M) x 32 (N)
+  const int li = lane & 31, lh = lane >> 5;
+  const int seg = tid & 7;
+
+  // tile coordinates
+  int t = blockIdx.x;
+  const int tw = t % tiles_w; t /= tiles_w;
+  const int th = t % tiles_h; t /= tiles_h;
+  const int td = t % tiles_d; const int n = t / tiles_d;
+  const int d0 = td * TD, h0 = th * TH, w0 = tw * TW;
+  const int n0 = blockIdx.y * BN;
+  const int D = p.Di, H = p.Hi, W = p.Wi, Cin = p.Cin, Cout = p.Cout;
+  const int c_begin = blockIdx.z * chunks_per_split, c_end = min(total_chunks, c_begin + chunks_per_split);
+
+  const float* __restrict__ gin = p.in;
+  const float* __restrict__ gmul = p.mul;
+  const float* __restrict__ gw = p.weight;
+  const int relu = p.in_relu;
+
+  // ---- patch loader state: position q = tid/8 + 32*j of the patch, j < NPL
+  int poff[NPL], pmul[NPL]; bool pval[NPL];
+#pragma unroll
+  for (int j = 0; j < NPL; ++j) {
+    const int q = (tid >> 3) + 32 * j;
+    const int px = q % PW, py = (q / PW) % PH, pz = q / (PW * PH);
+    const int iz = d0 + pz - (KD / 2), iy = h0 + py - 1, ix = w0 + px - 1;
+    pval[j] = (q < NPOS) & ((unsigned)iz < (unsigned)D) & ((unsigned)iy < (unsigned)H) & ((unsigned)ix < (unsigned)W);
+    poff[j] = pval[j] ? (((n * D + iz) * H + iy) * W + ix) * p.ld_in : 0;
+    pmul[j] = pval[j] ? (iy * W + ix) * Cin : 0;
+  }
+  f32x4 rp[NPL], rmul[MUL ? NPL : 1], rsc = {1.f, 1.f, 1.f, 1.f}, rsh = {0.f, 0.f, 0.f, 0.f};
+  bool vp[NPL];
+  auto load_patch = [&](int chunk) {
+    const int c = chunk * 32 + 4 * seg;
+    const bool cv = (c < Cin) & (chunk < c_end);
+    if constexpr (AFF) { rsc = ldg(p.in_scale, cv ? c : 0); rsh = ldg(p.in_shift, cv ? c : 0); }
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+      const bool v = pval[j] & cv;
+      vp[j] = v;
+      rp[j] = ldg(gin, v ? poff[j] + c : 0);
+      if constexpr (MUL) rmul[j] = ldg(gmul, v ? pmul[j] + c : 0);
+    }
+  };
+  auto store_patch = [&](float* dst) {
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+      const int q = (tid >> 3) + 32 * j;
+      f32x4 v = rp[j];
+      if constexpr (MUL) v *= rmul[j];
+      if constexpr (AFF) {
+        v = v * rsc + rsh;
+        if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+      }
+      v = vp[j] ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      if (q < NPOS) *reinterpret_cast<f32x4*>(dst + q * LDS_K + 4 * seg) = v;
+    }
+  };
+  // ---- weight tile loader: rows brow + 32*j, j < 2
+  f32x4 rb[2]; bool vb[2];
+  const int brow = tid >> 3;
+  auto load_b = [&](int chunk, int tap) {
+    const int c = chunk * 32 + 4 * seg;
+    const bool cv = (c < Cin) & (chunk < c_end);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int co = n0 + brow + 32 * j;
+      vb[j] = cv & (co < Cout);
+      rb[j] = ldg(gw, vb[j] ? (co * T + tap) * Cin + c : 0);
+    }
+  };
+  auto store_b = [&](float* dst) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      *reinterpret_cast<f32x4*>(dst + (brow + 32 * j) * LDS_K + 4 * seg) = vb[j] ? rb[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+
+  // ---- fragment base: output o = wm*64 + mt*32 + li of the tile -> patch position at tap (0,0,0)
+  int abase[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int o = wm * 64 + mt * 32 + li;
+    const int ow = o % TW, oh = (o / TW) % TH, od = o / (TW * TH);
+    abase[mt] = ((od * PH + oh) * PW + ow) * LDS_K + 4 * lh;
+  }
+  const int bfrag = (wn * 32 + li) * LDS_K + 4 * lh;
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  if (c_begin < c_end) {
+    load_patch(c_begin); load_b(c_begin, 0);
+    store_patch(patch0); store_b(bt0);
+    __syncthreads();
+    int pcur = 0, bcur = 0;
+    for (int chunk = c_begin; chunk < c_end; ++chunk) {
+      const float* P = pcur ? patch1 : patch0;
+      float* Pn = pcur ? patch0 : patch1;
+      load_patch(chunk + 1);                          // masked beyond c_end; lands during the T taps below
+#pragma unroll 1
+      for (int tap = 0; tap < T; ++tap) {
+        const float* B = bcur ? bt1 : bt0;
+        float* Bn = bcur ? bt0 : bt1;
+        const bool last = tap == T - 1;
+        load_b(last ? chunk + 1 : chunk, last ? 0 : tap + 1);
+        const int kz = tap / 9, ky = (tap - kz * 9) / 3, kx = tap - kz * 9 - ky * 3;
+        const int toff = ((kz * PH + ky) * PW + kx) * LDS_K;
+        f32x4 a[4][2], b[4];
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+          a[kc][0] = *reinterpret_cast<const f32x4*>(P + abase[0] + toff + kc * 8);
+          a[kc][1] = *reinterpret_cast<const f32x4*>(P + abase[1] + toff + kc * 8);
+          b[kc] = *reinterpret_cast<const f32x4*>(B + bfrag + kc * 8);
+        }
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kc][0][s], b[kc][s], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kc][1][s], b[kc][s], acc[1], 0, 0, 0);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+        if (last) store_patch(Pn);
+        store_b(Bn);
+        __syncthreads();
+        bcur ^= 1;
+      }
+      pcur ^= 1;
+    }
+  }
+
+  // ---------------------------------------------------------------- epilogue
+  const int col = n0 + wn * 32 + li;
+  const bool cval = col < Cout;
+  auto out_row = [&](int mt, int r, bool& ok) {
+    const int o = wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    const int ow = o % TW, oh = (o / TW) % TH, od = o / (TW * TH);
+    const int d = d0 + od, h = h0 + oh, w = w0 + ow;
+    ok = (d < D) & (h < H) & (w < W);
+    return ((n * D + d) * H + h) * W + w;
+  };
+  if (splits > 1) {
+    float* ws = p.workspace + (size_t)blockIdx.z * M * Cout;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        bool ok; const int row = out_row(mt, r, ok);
+        if (ok && cval) ws[(size_t)row * Cout + col] = acc[mt][r];
+      }
+    return;
+  }
+  const bool do_stats = p.stats != nullptr;
+  const int g0 = p.stat_rows_per_group > 0 ? n : 0;           // groups are whole images (checked on the host)
+  float* sred = lds;
+  if (do_stats) {
+    for (int i = tid; i < BN * 2; i += 256) sred[i] = 0.f;
+    __syncthreads();
+  }
+  const float bv = (p.bias && cval) ? p.bias[col] : 0.f;
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      bool ok; const int row = out_row(mt, r, ok);
+      const float v = apply_act(acc[mt][r] + bv, p.out_act);
+      if (ok && cval) {
+        p.out[(size_t)row * p.ld_out + col] = v;
+        s1 += v; s2 += v * v;
+      }
+    }
+  if (do_stats) {
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    if (lh == 0) { atomicAdd(&sred[(wn * 32 + li) * 2], s1); atomicAdd(&sred[(wn * 32 + li) * 2 + 1], s2); }
+    __syncthreads();
+    if (tid < BN && n0 + tid < Cout) {
+      double* st = p.stats + ((size_t)g0 * Cout + n0 + tid) * 2;
+      atomicAdd(st, (double)sred[tid * 2]);
+      atomicAdd(st + 1, (double)sred[tid * 2 + 1]);
+    }
+  }
+}
+
+template <bool DIM3, int MODE>
+int launch_patch(const G6dConv& d, int M, hipStream_t stream) {
+  constexpr int TD = DIM3 ? 2 : 1, TH = 8, TW = DIM3 ? 8 : 16, KD = DIM3 ? 3 : 1;
+  constexpr int NPOS = (TD + KD - 1) * (TH + 2) * (TW + 2);
+  const int tiles_d = (d.Di + TD - 1) / TD, tiles_h = (d.Hi + TH - 1) / TH, tiles_w = (d.Wi + TW - 1) / TW;
+  const int tiles = d.N * tiles_d * tiles_h * tiles_w, ntn = (d.Cout + BN - 1) / BN;
+  const int total_chunks = (d.Cin + 31) / 32;
+  int splits = 1;
+  if (tiles * ntn < 200 && total_chunks >= 4 && d.workspace) {
+    splits = (400 + tiles * ntn - 1) / (tiles * ntn);
+    if (splits > total_chunks / 2) splits = total_chunks / 2;
+    const size_t per = (size_t)M * d.Cout * sizeof(float);
+    if ((size_t)splits * per > d.workspace_bytes) splits = (int)(d.workspace_bytes / per);
+    if (splits < 2) splits = 1;
+  }
+  const int cps = (total_chunks + splits - 1) / splits;
+  splits = (total_chunks + cps - 1) / cps;
+  const size_t lds_bytes = (size_t)(2 * NPOS * LDS_K + 2 * BN * LDS_K) * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_patch_kernel<DIM3, MODE>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((conv_patch_kernel<DIM3, MODE>), dim3(tiles, ntn, splits), dim3(256), lds_bytes, stream, d, M, tiles_d,
+                     tiles_h, tiles_w, cps, total_chunks, splits);
+  int rc = g6d_check_launch("conv_patch");
+  if (rc != G6D_OK || splits == 1) return rc;
+  return g6d_splitk_reduce_launch(d.workspace, splits, M, d.Cout, d.bias, d.out_act, d.out, d.ld_out, d.stats,
+                                  d.stat_rows_per_group, stream);
+}
+
+}  // namespace
+
+// Eligibility (checked by the caller g6d_conv_igemm): stride 1, kernel (1,3,3) or (3,3,3) with "same" padding,
+// Cout <= 64, no per-image affine table, statistics groups = whole images or one group.
+bool g6d_conv_patch_eligible(const G6dConv& d) {
+  const bool k2 = d.kd == 1 && d.kh == 3 && d.kw == 3 && d.pd == 0 && d.ph == 1 && d.pw == 1 && d.Di == 1;
+  const bool k3 = d.kd == 3 && d.kh == 3 && d.kw == 3 && d.pd == 1 && d.ph == 1 && d.pw == 1;
+  if (!(k2 || k3) || d.sd != 1 || d.sh != 1 || d.sw != 1) return false;
+  if (d.Cout > 64 || (d.in_scale && d.in_affine_per_n) || (d.mul && !k2)) return false;
+  const int per_image = d.Do * d.Ho * d.Wo;
+  if (d.stats && d.stat_rows_per_group > 0 && d.stat_rows_per_group != per_image) return false;
+  if (d.split_k > 1) return false;                                   // forced split counts go to the generic kernel
+  // enough tiles to fill the chip and little tile padding
+  const int TD = k3 ? 2 : 1, TW = k3 ? 8 : 16;
+  const long long tiles = (long long)d.N * ((d.Di + TD - 1) / TD) * ((d.Hi + 7) / 8) * ((d.Wi + TW - 1) / TW);
+  const double eff = (double)d.N * d.Di * d.Hi * d.Wi / (double)(tiles * 128);
+  return tiles >= 128 && eff >= 0.85;
+}
+
+int g6d_conv_patch_launch(const G6dConv& d, int M, hipStream_t stream) {
+  const bool k3 = d.kd == 3;
+  if (d.mul) return launch_patch<false, 3>(d, M, stream);
+  if (k3) return d.in_scale ? launch_patch<true, 1>(d, M, stream) : launch_patch<true, 0>(d, M, stream);
+  return d.in_scale ? launch_patch<false, 1>(d, M, stream) : launch_patch<false, 0>(d, M, stream);
+}

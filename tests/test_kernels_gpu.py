@@ -57,6 +57,13 @@ CONV_CASES = [
     dict(N=1, D=8, H=8, W=8, Cin=256, Cout=256, k=(3, 3, 3), s=(1, 1, 1), p=(1, 1, 1), stats=True, split=1),        # forced no split
     dict(N=1, D=8, H=8, W=8, Cin=256, Cout=256, k=(3, 3, 3), s=(1, 1, 1), p=(1, 1, 1), stats=True, split=7, act=2),
     dict(N=2, D=1, H=5, W=5, Cin=20, Cout=40, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), act=2),                        # odd sizes
+    # shapes that take the LDS-patch kernel (conv_patch.hip): stride 1, 3x3(x3), Cout <= 64, >= 128 tiles
+    dict(N=1, D=16, H=16, W=16, Cin=64, Cout=64, k=(3, 3, 3), s=(1, 1, 1), p=(1, 1, 1), aff=True, relu=True, stats=True),
+    dict(N=1, D=16, H=24, W=16, Cin=100, Cout=48, k=(3, 3, 3), s=(1, 1, 1), p=(1, 1, 1), act=1, stats=True, ld_out=64),
+    dict(N=1, D=15, H=17, W=16, Cin=32, Cout=64, k=(3, 3, 3), s=(1, 1, 1), p=(1, 1, 1)),                            # partial tiles
+    dict(N=80, D=1, H=16, W=16, Cin=64, Cout=64, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), mul=True, aff=True, stats=True),
+    dict(N=70, D=1, H=16, W=16, Cin=96, Cout=64, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), aff=True, relu=True, stats=True, rpg=256),
+    dict(N=66, D=1, H=15, W=16, Cin=32, Cout=20, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), act=2),
 ]
 
 
