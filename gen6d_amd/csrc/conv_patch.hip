@@ -1,9 +1,9 @@
 // 3x3 / 3x3x3 stride-1 "same" convolution with the input patch of a spatial output tile kept in LDS and reused by all
-// taps (Cout <= 64).  Generalises corr_patch.hip: measured on conv_igemm.hip, what costs matrix-pipe time is the amount of
+// taps (64 output channels per block).  Generalises corr_patch.hip: measured on conv_igemm.hip, what costs matrix-pipe time is the amount of
 // data brought into the CU per MFMA; an implicit-GEMM tile re-loads its 128 activation rows for every
 // one of the 9 / 27 taps, while a spatial tile of 128 outputs only needs its halo box once per channel chunk:
 //   3-D: outputs 2x8x8, patch 4x10x10 = 400 positions (instead of 27 x 128 = 3456 row loads per chunk)
-//   2-D: outputs 1x8x16, patch 1x10x18 = 180 positions (instead of 9 x 128 = 1152)
+//   2-D: outputs 1x8x16, patch 1x10x18 = 180 positions (instead of 9 x 128 = 1152); 8x8 maps: 2 images per tile
 // The prologue (multiplier, InstanceNorm affine, ReLU, zero padding) is applied once per patch element when it is
 // written to LDS instead of once per tap.  Weight tiles [64 co][32 ci] are streamed per tap (double-buffered).
 // Same fragment scheme (K-permuted ds_read_b128 + v_mfma_f32_32x32x2_f32), accumulator layout and epilogue (bias,
@@ -22,15 +22,24 @@ __device__ __forceinline__ f32x4 ldg(const float* __restrict__ base, int elem_of
   return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + ((unsigned)elem_off << 2));
 }
 
-// DIM3: 3-D tile 2x8x8 with kd = 3, else 2-D tile 1x8x16 with kd = 1.  MODE: 0 plain, 1 affine(+ReLU), 3 mul + affine.
-template <bool DIM3, int MODE>
+// Output tile geometries (128 outputs each): images per tile x depth x height x width, and the kernel depth.
+//   KIND 0: 2-D  1 x 1 x 8 x 16          KIND 1: 3-D  1 x 2 x 8 x 8 (kd = 3)
+//   KIND 2: 2-D  2 images x 8 x 8   (8x8 maps of the selector; 4x4 maps measured slower than the generic kernel:
+//           a 6x6 halo per 4x4 outputs more than doubles the loaded rows, they stay on conv_igemm.hip)
+template <int KIND> struct TileGeo;
+template <> struct TileGeo<0> { static constexpr int TN = 1, TD = 1, TH = 8, TW = 16, KD = 1; };
+template <> struct TileGeo<1> { static constexpr int TN = 1, TD = 2, TH = 8, TW = 8, KD = 3; };
+template <> struct TileGeo<2> { static constexpr int TN = 2, TD = 1, TH = 8, TW = 8, KD = 1; };
+
+// MODE: 0 plain, 1 affine(+ReLU), 3 mul + affine.
+template <int KIND, int MODE>
 __global__ void __launch_bounds__(256) conv_patch_kernel(const G6dConv p, const int M, const int tiles_d, const int tiles_h,
                                                          const int tiles_w, const int chunks_per_split,
                                                          const int total_chunks, const int splits) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int TD = DIM3 ? 2 : 1, TH = 8, TW = DIM3 ? 8 : 16;
-  constexpr int KD = DIM3 ? 3 : 1, T = KD * 9;
-  constexpr int PD = TD + KD - 1, PH = TH + 2, PW = TW + 2, NPOS = PD * PH * PW;
+  using G = TileGeo<KIND>;
+  constexpr int TN = G::TN, TD = G::TD, TH = G::TH, TW = G::TW, KD = G::KD, T = KD * 9;
+  constexpr int PD = TD + KD - 1, PH = TH + 2, PW = TW + 2, NPOS = TN * PD * PH * PW;
   constexpr int NPL = (NPOS * 8 + 255) / 256;                  // 16-byte patch loads per thread per chunk
   constexpr int PATCH = NPOS * LDS_K, BT = BN * LDS_K;
   constexpr bool AFF = MODE != 0, MUL = MODE == 3;
@@ -46,7 +55,7 @@ __global__ void __launch_bounds__(256) conv_patch_kernel(const G6dConv p, const 
   int t = blockIdx.x;
   const int tw = t % tiles_w; t /= tiles_w;
   const int th = t % tiles_h; t /= tiles_h;
-  const int td = t % tiles_d; const int n = t / tiles_d;
+  const int td = t % tiles_d; const int n = (t / tiles_d) * TN;          // first image of the tile
   const int d0 = td * TD, h0 = th * TH, w0 = tw * TW;
   const int n0 = blockIdx.y * BN;
   const int D = p.Di, H = p.Hi, W = p.Wi, Cin = p.Cin, Cout = p.Cout;
@@ -62,10 +71,11 @@ __global__ void __launch_bounds__(256) conv_patch_kernel(const G6dConv p, const 
 #pragma unroll
   for (int j = 0; j < NPL; ++j) {
     const int q = (tid >> 3) + 32 * j;
-    const int px = q % PW, py = (q / PW) % PH, pz = q / (PW * PH);
+    const int px = q % PW, py = (q / PW) % PH, pz = (q / (PW * PH)) % PD, pn = q / (PW * PH * PD);
     const int iz = d0 + pz - (KD / 2), iy = h0 + py - 1, ix = w0 + px - 1;
-    pval[j] = (q < NPOS) & ((unsigned)iz < (unsigned)D) & ((unsigned)iy < (unsigned)H) & ((unsigned)ix < (unsigned)W);
-    poff[j] = pval[j] ? (((n * D + iz) * H + iy) * W + ix) * p.ld_in : 0;
+    pval[j] = (q < NPOS) & (n + pn < p.N) & ((unsigned)iz < (unsigned)D) & ((unsigned)iy < (unsigned)H) &
+              ((unsigned)ix < (unsigned)W);
+    poff[j] = pval[j] ? ((((n + pn) * D + iz) * H + iy) * W + ix) * p.ld_in : 0;
     pmul[j] = pval[j] ? (iy * W + ix) * Cin : 0;
   }
   f32x4 rp[NPL], rmul[MUL ? NPL : 1], rsc = {1.f, 1.f, 1.f, 1.f}, rsh = {0.f, 0.f, 0.f, 0.f};
@@ -120,8 +130,8 @@ __global__ void __launch_bounds__(256) conv_patch_kernel(const G6dConv p, const 
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
     const int o = wm * 64 + mt * 32 + li;
-    const int ow = o % TW, oh = (o / TW) % TH, od = o / (TW * TH);
-    abase[mt] = ((od * PH + oh) * PW + ow) * LDS_K + 4 * lh;
+    const int ow = o % TW, oh = (o / TW) % TH, od = (o / (TW * TH)) % TD, on = o / (TW * TH * TD);
+    abase[mt] = (((on * PD + od) * PH + oh) * PW + ow) * LDS_K + 4 * lh;
   }
   const int bfrag = (wn * 32 + li) * LDS_K + 4 * lh;
 
@@ -177,10 +187,10 @@ __global__ void __launch_bounds__(256) conv_patch_kernel(const G6dConv p, const 
   const bool cval = col < Cout;
   auto out_row = [&](int mt, int r, bool& ok) {
     const int o = wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-    const int ow = o % TW, oh = (o / TW) % TH, od = o / (TW * TH);
+    const int ow = o % TW, oh = (o / TW) % TH, od = (o / (TW * TH)) % TD, on = o / (TW * TH * TD);
     const int d = d0 + od, h = h0 + oh, w = w0 + ow;
-    ok = (d < D) & (h < H) & (w < W);
-    return ((n * D + d) * H + h) * W + w;
+    ok = (n + on < p.N) & (d < D) & (h < H) & (w < W);
+    return (((n + on) * D + d) * H + h) * W + w;
   };
   if (splits > 1) {
     float* ws = p.workspace + (size_t)blockIdx.z * M * Cout;
@@ -194,7 +204,7 @@ __global__ void __launch_bounds__(256) conv_patch_kernel(const G6dConv p, const 
     return;
   }
   const bool do_stats = p.stats != nullptr;
-  const int g0 = p.stat_rows_per_group > 0 ? n : 0;           // groups are whole images (checked on the host)
+  const int g0 = p.stat_rows_per_group > 0 ? n : 0;           // per-image groups only with one image per tile (host check)
   float* sred = lds;
   if (do_stats) {
     for (int i = tid; i < BN * 2; i += 256) sred[i] = 0.f;
@@ -226,12 +236,13 @@ __global__ void __launch_bounds__(256) conv_patch_kernel(const G6dConv p, const 
   }
 }
 
-template <bool DIM3, int MODE>
+template <int KIND, int MODE>
 int launch_patch(const G6dConv& d, int M, hipStream_t stream) {
-  constexpr int TD = DIM3 ? 2 : 1, TH = 8, TW = DIM3 ? 8 : 16, KD = DIM3 ? 3 : 1;
-  constexpr int NPOS = (TD + KD - 1) * (TH + 2) * (TW + 2);
-  const int tiles_d = (d.Di + TD - 1) / TD, tiles_h = (d.Hi + TH - 1) / TH, tiles_w = (d.Wi + TW - 1) / TW;
-  const int tiles = d.N * tiles_d * tiles_h * tiles_w, ntn = (d.Cout + BN - 1) / BN;
+  using G = TileGeo<KIND>;
+  constexpr int NPOS = G::TN * (G::TD + G::KD - 1) * (G::TH + 2) * (G::TW + 2);
+  const int tiles_n = (d.N + G::TN - 1) / G::TN;
+  const int tiles_d = (d.Di + G::TD - 1) / G::TD, tiles_h = (d.Hi + G::TH - 1) / G::TH, tiles_w = (d.Wi + G::TW - 1) / G::TW;
+  const int tiles = tiles_n * tiles_d * tiles_h * tiles_w, ntn = (d.Cout + BN - 1) / BN;
   const int total_chunks = (d.Cin + 31) / 32;
   int splits = 1;
   if (tiles * ntn < 200 && total_chunks >= 4 && d.workspace) {
@@ -246,11 +257,11 @@ int launch_patch(const G6dConv& d, int M, hipStream_t stream) {
   const size_t lds_bytes = (size_t)(2 * NPOS * LDS_K + 2 * BN * LDS_K) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_patch_kernel<DIM3, MODE>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_patch_kernel<KIND, MODE>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv_patch_kernel<DIM3, MODE>), dim3(tiles, ntn, splits), dim3(256), lds_bytes, stream, d, M, tiles_d,
+  hipLaunchKernelGGL((conv_patch_kernel<KIND, MODE>), dim3(tiles, ntn, splits), dim3(256), lds_bytes, stream, d, M, tiles_d,
                      tiles_h, tiles_w, cps, total_chunks, splits);
   int rc = g6d_check_launch("conv_patch");
   if (rc != G6D_OK || splits == 1) return rc;
@@ -258,28 +269,54 @@ int launch_patch(const G6dConv& d, int M, hipStream_t stream) {
                                   d.stat_rows_per_group, stream);
 }
 
+template <int KIND>
+int launch_kind(const G6dConv& d, int M, hipStream_t stream) {
+  if constexpr (KIND != 1) { if (d.mul) return launch_patch<KIND, 3>(d, M, stream); }
+  return d.in_scale ? launch_patch<KIND, 1>(d, M, stream) : launch_patch<KIND, 0>(d, M, stream);
+}
+
+// tile kind with the best fill for this layer, or -1
+int pick_kind(const G6dConv& d, double* eff_out, long long* tiles_out) {
+  const bool k3 = d.kd == 3;
+  int best = -1; double best_eff = 0; long long best_tiles = 0;
+  for (int kind = 0; kind < 3; ++kind) {
+    if (k3 != (kind == 1)) continue;
+    const int TN = kind == 2 ? 2 : 1, TD = kind == 1 ? 2 : 1, TH = 8, TW = kind == 0 ? 16 : 8;
+    if (TN > 1 && d.stats && d.stat_rows_per_group > 0) continue;       // per-image statistics need one image per tile
+    const long long tiles = (long long)((d.N + TN - 1) / TN) * ((d.Di + TD - 1) / TD) * ((d.Hi + TH - 1) / TH) *
+                            ((d.Wi + TW - 1) / TW);
+    const double eff = (double)d.N * d.Di * d.Hi * d.Wi / (double)(tiles * 128);
+    if (eff > best_eff + 1e-9) { best = kind; best_eff = eff; best_tiles = tiles; }
+  }
+  *eff_out = best_eff; *tiles_out = best_tiles;
+  return best;
+}
+
 }  // namespace
 
-// Eligibility (checked by the caller g6d_conv_igemm): stride 1, kernel (1,3,3) or (3,3,3) with "same" padding,
-// Cout <= 64, no per-image affine table, statistics groups = whole images or one group.
+// Eligibility (checked by the caller g6d_conv_igemm): stride 1, kernel (1,3,3) or (3,3,3) with "same" padding, no
+// per-image affine table, statistics groups = whole images or one group, enough well-filled tiles for the chip.
 bool g6d_conv_patch_eligible(const G6dConv& d) {
   const bool k2 = d.kd == 1 && d.kh == 3 && d.kw == 3 && d.pd == 0 && d.ph == 1 && d.pw == 1 && d.Di == 1;
   const bool k3 = d.kd == 3 && d.kh == 3 && d.kw == 3 && d.pd == 1 && d.ph == 1 && d.pw == 1;
   if (!(k2 || k3) || d.sd != 1 || d.sh != 1 || d.sw != 1) return false;
-  if (d.Cout > 64 || (d.in_scale && d.in_affine_per_n) || (d.mul && !k2)) return false;
+  if ((d.in_scale && d.in_affine_per_n) || (d.mul && !k2)) return false;
   const int per_image = d.Do * d.Ho * d.Wo;
   if (d.stats && d.stat_rows_per_group > 0 && d.stat_rows_per_group != per_image) return false;
   if (d.split_k > 1) return false;                                   // forced split counts go to the generic kernel
-  // enough tiles to fill the chip and little tile padding
-  const int TD = k3 ? 2 : 1, TW = k3 ? 8 : 16;
-  const long long tiles = (long long)d.N * ((d.Di + TD - 1) / TD) * ((d.Hi + 7) / 8) * ((d.Wi + TW - 1) / TW);
-  const double eff = (double)d.N * d.Di * d.Hi * d.Wi / (double)(tiles * 128);
-  return tiles >= 128 && eff >= 0.85;
+  double eff; long long tiles;
+  if (pick_kind(d, &eff, &tiles) < 0) return false;
+  const long long blocks = tiles * ((d.Cout + BN - 1) / BN);
+  // wide layers re-load the patch once per 64-channel slice: only worth it while that is still fewer bytes than the
+  // implicit-GEMM tile (9 or 27 row loads per output) and the grid fills the chip
+  return blocks >= 128 && eff >= 0.85 && d.Cout <= 256;
 }
 
 int g6d_conv_patch_launch(const G6dConv& d, int M, hipStream_t stream) {
-  const bool k3 = d.kd == 3;
-  if (d.mul) return launch_patch<false, 3>(d, M, stream);
-  if (k3) return d.in_scale ? launch_patch<true, 1>(d, M, stream) : launch_patch<true, 0>(d, M, stream);
-  return d.in_scale ? launch_patch<false, 1>(d, M, stream) : launch_patch<false, 0>(d, M, stream);
+  double eff; long long tiles;
+  switch (pick_kind(d, &eff, &tiles)) {
+    case 0: return launch_kind<0>(d, M, stream);
+    case 1: return launch_kind<1>(d, M, stream);
+    default: return launch_kind<2>(d, M, stream);
+  }
 }
