@@ -16,6 +16,9 @@ Extra objects on the JSON line:
   roofline     — the dominant kernel (g6d_conv_igemm, fp32 MFMA): algorithmic FLOPs of every launch in the timed region
                  divided by its HIP-event duration (events recorded on the launch stream), against 157.3 TFLOP/s.
   cpu_baseline — the CPU oracle (a port of the reference's PyTorch-CPU path) timed on this host for one query.
+  hbm_kernels  — the HBM-bound kernels of the path (selector scan, refiner volume, FC weight stream): algorithmic
+                 bytes / HIP-event time against 8 TB/s.
+  stages_ms    — per-stage GPU time of one query (eager launches).
 """
 import argparse
 import json
@@ -29,6 +32,28 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
+
+
+def stage_times(pipe, full, crop, reps=5):
+    """Per-stage GPU time (ms, HIP events on the current stream, eager launches with the stage's own stream fork/join)."""
+    r = pipe.ref_dev
+    stages = {
+        "detector": lambda: pipe.detector.detect_impl(full),
+        "selector": lambda: pipe.selector.compute_view_point_feats(crop),
+        "refiner_step": lambda: pipe.refiner._step(crop, r["Ks_in"][0], pipe.iter_poses[0][0], r["ref_imgs"][0],
+                                                   r["ref_Ks"][0], r["ref_poses"][0]),
+    }
+    out = {}
+    with torch.no_grad():
+        for name, fn in stages.items():
+            fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize(); e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record(); torch.cuda.synchronize()
+            out[name] = e0.elapsed_time(e1) / reps
+    return out
 
 
 def main():
@@ -103,7 +128,7 @@ def main():
     parallel.barrier()
     torch.cuda.synchronize()
     if not use_graph:
-        ops.PROFILE = []
+        ops.PROFILE, ops.PROFILE_HBM = [], {}
     ops.marker(1)
     t0 = time.perf_counter()
     rows = [step(args.warmup + i) for i in range(args.steps)]
@@ -120,12 +145,14 @@ def main():
         ops.SERIAL = True                      # branches back to back: per-kernel durations without stream overlap
         step(0, eager=True)
         torch.cuda.synchronize()
-        ops.PROFILE = []
+        ops.PROFILE, ops.PROFILE_HBM = [], {}
         for i in range(args.steps):
             step(args.warmup + i, eager=True)
         torch.cuda.synchronize()
         ops.SERIAL = args.serial
     prof, ops.PROFILE = ops.PROFILE, None
+    prof_hbm, ops.PROFILE_HBM = ops.PROFILE_HBM or {}, None
+    stages = stage_times(pipe, fulls[0:1], crops[0:1]) if (rank == 0 and not shard_refs) else None   # (sharded stages hold collectives)
     rows = parallel.gather_rows(torch.cat(rows, 0), world * args.steps) if (world > 1 and not shard_refs) else torch.cat(rows, 0)
     n_queries = args.steps if shard_refs else world * args.steps
 
@@ -154,7 +181,8 @@ def main():
                                "seeded synthetic weights", "sharding": (f"selector and detector references sharded x{world} (RCCL all-reduce/all-gather), refiner replicated" if shard_refs
                                 else f"query-replicas x{world}"),
                    "launch": f"hipGraph replay (1 graph = 1 query), {lanes} queries in flight on separate streams" if use_graph else "eager"},
-        "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (fp32 v_mfma_f32_32x32x2_f32, incl. split-K reduce)",
+        "roofline": {"bound": "mfma", "kernel": "g6d_conv_igemm family: conv_igemm / conv_patch / corr_patch kernels "
+                                                 "(fp32 v_mfma_f32_32x32x2_f32) incl. their split-K reduce",
                      "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
                      "traffic_unit": "HBM-side bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_conv_traffic.json)",
@@ -164,6 +192,18 @@ def main():
                                  ("serialised eager re-run of the same steps after the graph-replay timed region" if use_graph
                                   else "inside the timed region")},
     }
+    # HBM-bound kernels of the path (K5/K6 scan, K12/K13 volume, K15 FC): algorithmic bytes / HIP-event time
+    hbm = {}
+    for name, recs in prof_hbm.items():
+        if name.endswith("_small"):
+            continue
+        t_ms = sum(r[1].elapsed_time(r[2]) for r in recs)
+        nb = sum(r[0] for r in recs)
+        hbm[name] = {"launches_per_step": len(recs) / args.steps, "mbytes_per_launch": nb / len(recs) / 1e6,
+                     "avg_launch_us": t_ms / len(recs) * 1e3, "achieved_GBps": nb / (t_ms * 1e-3) / 1e9,
+                     "frac_of_8TBps": nb / (t_ms * 1e-3) / 8e12}
+    result["hbm_kernels"] = hbm
+    result["stages_ms"] = stages
     if world == 1 and not args.no_cpu_baseline:
         from oracle import pipeline_oracle as PO
         cores = torch.get_num_threads()

@@ -272,24 +272,41 @@ __global__ void __launch_bounds__(64) attention_kernel(const float* __restrict__
   }
 }
 
-// Weight-streaming GEMV: one block per output row, 16-byte loads, B <= 8 right-hand sides.
-__global__ void __launch_bounds__(256) linear_gemv_kernel(const float* __restrict__ x, int B, int K,
-                                                          const float* __restrict__ W, const float* __restrict__ bias,
-                                                          int act, float* __restrict__ out, int O) {
-  __shared__ float red[8][4];
+// Weight-streaming GEMV: one block of 512 threads per output row, B <= 8 right-hand sides.  HBM-bound (the refiner's
+// first FC layer reads 67 MB of weights for 33 MFLOP): every thread keeps four independent 16-byte weight loads in
+// flight so that two resident blocks per CU cover the HBM latency-bandwidth product (~64 KB per CU).
+#define GEMV_THREADS 512
+#define GEMV_UNROLL 4
+__global__ void __launch_bounds__(GEMV_THREADS) linear_gemv_kernel(const float* __restrict__ x, int B, int K,
+                                                                   const float* __restrict__ W,
+                                                                   const float* __restrict__ bias, int act,
+                                                                   float* __restrict__ out, int O) {
+  __shared__ float red[8][GEMV_THREADS / 64];
   const int o = blockIdx.x;
   const float* w = W + (size_t)o * K;
   float acc[8];
 #pragma unroll
   for (int b = 0; b < 8; ++b) acc[b] = 0.f;
-  for (int kk = threadIdx.x * 4; kk < K; kk += 256 * 4) {
-    f32x4 wv = *reinterpret_cast<const f32x4*>(w + kk);
+  constexpr int STEP = GEMV_THREADS * 4;
+  for (int k0 = threadIdx.x * 4; k0 < K; k0 += STEP * GEMV_UNROLL) {
+    f32x4 wv[GEMV_UNROLL];
 #pragma unroll
-    for (int b = 0; b < 8; ++b)
-      if (b < B) {
-        f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)b * K + kk);
-        acc[b] += wv[0] * xv[0] + wv[1] * xv[1] + wv[2] * xv[2] + wv[3] * xv[3];
-      }
+    for (int u = 0; u < GEMV_UNROLL; ++u) {
+      const int kk = k0 + u * STEP;
+      wv[u] = *reinterpret_cast<const f32x4*>(w + (kk < K ? kk : 0));
+      if (kk >= K) wv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < GEMV_UNROLL; ++u) {
+      const int kk = k0 + u * STEP;
+      const int kc = kk < K ? kk : 0;
+#pragma unroll
+      for (int b = 0; b < 8; ++b)
+        if (b < B) {
+          f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)b * K + kc);
+          acc[b] += wv[u][0] * xv[0] + wv[u][1] * xv[1] + wv[u][2] * xv[2] + wv[u][3] * xv[3];
+        }
+    }
   }
 #pragma unroll
   for (int b = 0; b < 8; ++b) {
@@ -298,7 +315,9 @@ __global__ void __launch_bounds__(256) linear_gemv_kernel(const float* __restric
   }
   __syncthreads();
   if (threadIdx.x < B) {
-    float s = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < GEMV_THREADS / 64; ++i) s += red[threadIdx.x][i];
     if (bias) s += bias[o];
     out[(size_t)threadIdx.x * O + o] = apply_act(s, act);
   }
@@ -430,6 +449,6 @@ extern "C" int g6d_linear_gemv(const float* x, int B, int K, const float* W, con
   if (!x || !W || !out || B <= 0 || B > 8 || K <= 0 || (K & 3) || O <= 0 || !g6d_aligned16(x) || !g6d_aligned16(W)) {
     g6d_set_error("linear_gemv: bad args"); return G6D_EINVAL;
   }
-  hipLaunchKernelGGL(linear_gemv_kernel, dim3(O), dim3(256), 0, STREAM(stream), x, B, K, W, bias, act, out, O);
+  hipLaunchKernelGGL(linear_gemv_kernel, dim3(O), dim3(GEMV_THREADS), 0, STREAM(stream), x, B, K, W, bias, act, out, O);
   return g6d_check_launch("linear_gemv");
 }

@@ -2,10 +2,15 @@
 BatchNorm (eval) is folded into the conv weights once.  Output taps follow the reference exactly, including its
 quirk that the 1/16 output is the BatchNorm output of conv 25 WITHOUT the final ReLU
 (reference network/pretrain_models.py:17-25,66-72,109-111)."""
+import os
+
 import torch
 import torch.nn.functional as F
 
 from .. import ops, specs
+
+if os.environ.get("G6D_MIOPEN_FIND", "0") == "1":
+    torch.backends.cudnn.benchmark = True        # MIOpen Find (measured solver choice) instead of the immediate-mode heuristic
 
 _POOL_BEFORE = (1, 2, 4, 6)          # positions (in the list of 8 convs) preceded by a 2x2 max-pool
 

@@ -21,6 +21,18 @@ WORKSPACE_BYTES = 96 << 20
 # When set to a list, conv() brackets every g6d_conv_igemm launch with HIP events recorded on the launch stream and
 # appends (algorithmic flops, start, end); bench.py turns this into the roofline entry.
 PROFILE = None
+# Same for the HBM-bound kernels: a dict name -> list of (algorithmic bytes, start, end).
+PROFILE_HBM = None
+
+
+def _timed_hbm(name, nbytes, launch):
+    if PROFILE_HBM is None:
+        return launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    launch()
+    e1.record()
+    PROFILE_HBM.setdefault(name, []).append((float(nbytes), e0, e1))
 
 
 def _stream():
@@ -270,8 +282,10 @@ def selector_scan(que, refs):
         raise ValueError("selector_scan: operands must be contiguous")
     smap = torch.empty((D, HW), dtype=torch.float32, device=que.device)
     vps = torch.empty((D,), dtype=torch.float32, device=que.device)
-    _lib.check(_lib.load().g6d_selector_scan(_ptr(que), _ptr(refs), D, HW, Cc, _ptr(smap), _ptr(vps), _stream()),
-               "g6d_selector_scan")
+    # algorithmic bytes: the reference cache and the query features read once, the score map written and re-read for vps
+    _timed_hbm("selector_scan", 4.0 * (D * HW * Cc + HW * Cc + 2 * D * HW + D),
+               lambda: _lib.check(_lib.load().g6d_selector_scan(_ptr(que), _ptr(refs), D, HW, Cc, _ptr(smap), _ptr(vps),
+                                                                _stream()), "g6d_selector_scan"))
     return smap, vps
 
 
@@ -285,9 +299,11 @@ def refiner_volume(feats, projs, rot_in, lin, h_in, w_in, mean_in, std):
             raise ValueError("refiner_volume: operands must be contiguous float32")
     if tuple(mean_in.shape) != (sn ** 3, 2 * Cc) or tuple(std.shape) != (sn ** 3, Cc) or tuple(projs.shape) != (V, 3, 4):
         raise ValueError("refiner_volume: shape mismatch")
-    _lib.check(_lib.load().g6d_refiner_volume(_ptr(feats), _ptr(projs), _ptr(rot_in), _ptr(lin), V - 1, fh, fw, Cc,
-                                             int(h_in), int(w_in), sn, _ptr(mean_in), _ptr(std), _stream()),
-               "g6d_refiner_volume")
+    # algorithmic bytes: feature maps read once (L2 resident afterwards), the three volumes written
+    _timed_hbm("refiner_volume", 4.0 * (V * fh * fw * Cc + 3 * sn ** 3 * Cc),
+               lambda: _lib.check(_lib.load().g6d_refiner_volume(_ptr(feats), _ptr(projs), _ptr(rot_in), _ptr(lin), V - 1, fh,
+                                                                 fw, Cc, int(h_in), int(w_in), sn, _ptr(mean_in), _ptr(std),
+                                                                 _stream()), "g6d_refiner_volume"))
     return mean_in, std
 
 
@@ -375,8 +391,10 @@ def linear_gemv(x, W, bias, act=0):
     B, K = x.shape
     O = W.shape[0]
     out = torch.empty((B, O), dtype=torch.float32, device=x.device)
-    _lib.check(_lib.load().g6d_linear_gemv(_ptr(x.contiguous()), B, K, _ptr(W), _ptr(bias), O, int(act), _ptr(out), _stream()),
-               "g6d_linear_gemv")
+    x = x.contiguous()
+    _timed_hbm("linear_gemv" if O * K >= (1 << 22) else "linear_gemv_small", 4.0 * (O * K + B * K + B * O),
+               lambda: _lib.check(_lib.load().g6d_linear_gemv(_ptr(x), B, K, _ptr(W), _ptr(bias), O, int(act), _ptr(out),
+                                                              _stream()), "g6d_linear_gemv"))
     return out
 
 
