@@ -531,12 +531,27 @@ extern "C" int g6d_conv_igemm(const G6dConv* desc, g6d_stream_t stream_) {
   int bm = 128, bn = d.Cout <= 32 ? 32 : (d.Cout <= 64 ? 64 : 128);
   if (bn == 128 && (d.mul || (d.in_scale && d.in_affine_per_n))) bn = 64;   // 128x128 with two register sets + per-row tables would spill
   if (M <= 64 && d.Cout > 32) { bm = 64; bn = 64; }
+  // Grids that do not fill the 256 CUs with 128-row tiles (measured per layer, profiles/r01_conv_microbench.md):
+  //  * if 64x64 tiles give >= 256 blocks on their own, take them and skip split-K and its reduce launch altogether;
+  //  * mid-size M (>= 2048 rows): 64x64 tiles need 4x fewer splits, i.e. 4x less partial-sum traffic;
+  //  * small M (<= 1024 rows) with wide N: 128x64 tiles halve the split count at the same block count.
+  static const bool tile_policy = []() { const char* e = getenv("G6D_TILE_POLICY"); return !(e && e[0] == '0'); }();
+  bool no_split = false;
+  if (tile_policy && d.Cout > 32 && bm == 128 && d.split_k <= 0) {
+    const long long blocks128 = (long long)((M + 127) / 128) * ((d.Cout + bn - 1) / bn);
+    const long long blocks64 = (long long)((M + 63) / 64) * ((d.Cout + 63) / 64);
+    if (blocks128 < 256) {
+      if (blocks64 >= 256) { bm = 64; bn = 64; no_split = true; }
+      else if (M >= 2048) { bm = 64; bn = 64; }
+      else if (M <= 1024 && bn == 128) bn = 64;
+    }
+  }
   const long long blocks = (long long)((M + bm - 1) / bm) * ((d.Cout + bn - 1) / bn);
 
   int splits = d.split_k;
   if (splits <= 0) {
     splits = 1;
-    if (blocks < 256 && total >= 8) {
+    if (blocks < 256 && total >= 8 && !no_split) {
       splits = (int)((512 + blocks - 1) / blocks);
       if (splits > total / 4) splits = total / 4;
       if (splits > 64) splits = 64;

@@ -20,7 +20,9 @@ SHAPES = [
     ("vol conv0 128->64", 1, 32, 32, 32, 128, 64, (3, 3, 3), 1, (1, 1, 1), "aff"),
     ("vol conv1 s2", 1, 32, 32, 32, 64, 128, (3, 3, 3), 2, (1, 1, 1), "aff"),
     ("vol conv2 16^3", 1, 16, 16, 16, 128, 128, (3, 3, 3), 1, (1, 1, 1), "aff"),
+    ("vol conv3 s2", 1, 16, 16, 16, 128, 256, (3, 3, 3), 2, (1, 1, 1), "aff"),
     ("vol conv4 8^3", 1, 8, 8, 8, 256, 256, (3, 3, 3), 1, (1, 1, 1), "aff"),
+    ("vol conv5.0 s2", 1, 8, 8, 8, 256, 512, (3, 3, 3), 2, (1, 1, 1), "aff"),
     ("vol conv5.3 4^3", 1, 4, 4, 4, 512, 512, (3, 3, 3), 1, (1, 1, 1), "aff"),
     ("det corr 15x15 s0.5", 1, 1, 88, 116, 512, 32, (1, 15, 15), 1, (0, 7, 7), ""),
     ("det corr 15x15 s0", 1, 1, 60, 80, 512, 32, (1, 15, 15), 1, (0, 7, 7), ""),
@@ -36,7 +38,7 @@ def main():
     only = os.environ.get("ONLY")
     tot_f = tot_t = 0.0
     for name, N, D, H, W, Cin, Cout, k, s, p, mode in SHAPES:
-        if only and only not in name:
+        if only and not any(o in name for o in only.split(",")):
             continue
         Do, Ho, Wo = [(i + 2 * pp - kk) // s + 1 for i, kk, pp in zip((D, H, W), k, p)]
         x = torch.randn((N, D, H, W, Cin), device=dev)
