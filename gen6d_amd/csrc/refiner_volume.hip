@@ -5,6 +5,8 @@
 // every bilinear tap is one 512-byte coalesced read of a channels-last feature row (the 3.7 MB of feature maps stay
 // L2 resident), the per-reference samples live in registers, and mean / unbiased std / query sample are written
 // straight into the layouts the 3-D CNN consumes (cat[mean, query] and std).  HBM traffic = the 50 MB of outputs.
+// The rfn+1 projections of a voxel are spread over the lanes of its half-wave (lane v = view v) and exchanged with
+// shuffles: done redundantly by all 32 lanes they were ~600 VALU instructions per voxel, as long as the gathers.
 #include "g6d_common.h"
 
 #define MAX_RFN 8
@@ -12,8 +14,12 @@
 namespace {
 
 
-__device__ __forceinline__ f32x4 sample_view(const float* __restrict__ fmap, int fh, int fw, int C, int c,
-                                             const float* P, float vx, float vy, float vz, float h_in, float w_in) {
+// Bilinear footprint of one view at one voxel: element offsets of the 4 taps (clamped into the map) and their weights
+// (0 for taps outside the map: grid_sample padding_mode='zeros', align_corners=False).
+struct Taps { int o00, o01, o10, o11; float w00, w01, w10, w11; };
+
+__device__ __forceinline__ Taps project_view(int fh, int fw, int C, const float* __restrict__ P, float vx, float vy,
+                                             float vz, float h_in, float w_in) {
   float X = vx * P[0] + vy * P[1] + vz * P[2] + P[3];
   float Y = vx * P[4] + vy * P[5] + vz * P[6] + P[7];
   float Z = vx * P[8] + vy * P[9] + vz * P[10] + P[11];
@@ -29,34 +35,52 @@ __device__ __forceinline__ f32x4 sample_view(const float* __restrict__ fmap, int
   fy = fminf(fmaxf(fy, -4.f), (float)fh + 4.f);
   int x0 = (int)fx, y0 = (int)fy;
   float wx1 = ix - fx, wy1 = iy - fy, wx0 = (fx + 1.f) - ix, wy0 = (fy + 1.f) - iy;
-  // unconditional, clamped loads (branches around loads serialise them); out-of-range taps get weight 0
   const bool xv0 = (unsigned)x0 < (unsigned)fw, xv1 = (unsigned)(x0 + 1) < (unsigned)fw;
   const bool yv0 = (unsigned)y0 < (unsigned)fh, yv1 = (unsigned)(y0 + 1) < (unsigned)fh;
   const int xc0 = min(max(x0, 0), fw - 1), xc1 = min(max(x0 + 1, 0), fw - 1);
   const int yc0 = min(max(y0, 0), fh - 1), yc1 = min(max(y0 + 1, 0), fh - 1);
-  const f32x4 v00 = *reinterpret_cast<const f32x4*>(fmap + ((size_t)yc0 * fw + xc0) * C + c);
-  const f32x4 v01 = *reinterpret_cast<const f32x4*>(fmap + ((size_t)yc0 * fw + xc1) * C + c);
-  const f32x4 v10 = *reinterpret_cast<const f32x4*>(fmap + ((size_t)yc1 * fw + xc0) * C + c);
-  const f32x4 v11 = *reinterpret_cast<const f32x4*>(fmap + ((size_t)yc1 * fw + xc1) * C + c);
-  const float w00 = (yv0 && xv0) ? wx0 * wy0 : 0.f, w01 = (yv0 && xv1) ? wx1 * wy0 : 0.f;
-  const float w10 = (yv1 && xv0) ? wx0 * wy1 : 0.f, w11 = (yv1 && xv1) ? wx1 * wy1 : 0.f;
-  f32x4 acc = w00 * v00;
-  acc += w01 * v01;
-  acc += w10 * v10;
-  acc += w11 * v11;
+  Taps t;
+  t.o00 = (yc0 * fw + xc0) * C; t.o01 = (yc0 * fw + xc1) * C;
+  t.o10 = (yc1 * fw + xc0) * C; t.o11 = (yc1 * fw + xc1) * C;
+  t.w00 = (yv0 && xv0) ? wx0 * wy0 : 0.f; t.w01 = (yv0 && xv1) ? wx1 * wy0 : 0.f;
+  t.w10 = (yv1 && xv0) ? wx0 * wy1 : 0.f; t.w11 = (yv1 && xv1) ? wx1 * wy1 : 0.f;
+  return t;
+}
+
+// the footprint computed by lane `src` of this half-wave
+__device__ __forceinline__ Taps taps_from(const Taps& t, int src) {
+  Taps r;
+  r.o00 = __shfl(t.o00, src, 32); r.o01 = __shfl(t.o01, src, 32);
+  r.o10 = __shfl(t.o10, src, 32); r.o11 = __shfl(t.o11, src, 32);
+  r.w00 = __shfl(t.w00, src, 32); r.w01 = __shfl(t.w01, src, 32);
+  r.w10 = __shfl(t.w10, src, 32); r.w11 = __shfl(t.w11, src, 32);
+  return r;
+}
+
+// unconditional, clamped loads (branches around loads serialise them); out-of-range taps carry weight 0
+__device__ __forceinline__ f32x4 gather_view(const float* __restrict__ fmap, const Taps& t, int c) {
+  const f32x4 v00 = *reinterpret_cast<const f32x4*>(fmap + t.o00 + c);
+  const f32x4 v01 = *reinterpret_cast<const f32x4*>(fmap + t.o01 + c);
+  const f32x4 v10 = *reinterpret_cast<const f32x4*>(fmap + t.o10 + c);
+  const f32x4 v11 = *reinterpret_cast<const f32x4*>(fmap + t.o11 + c);
+  f32x4 acc = t.w00 * v00;
+  acc += t.w01 * v01;
+  acc += t.w10 * v10;
+  acc += t.w11 * v11;
   return acc;
 }
 
-__global__ void __launch_bounds__(256) refiner_volume_kernel(const float* __restrict__ feats,
+__global__ void __launch_bounds__(256, 4) refiner_volume_kernel(const float* __restrict__ feats,
                                                              const float* __restrict__ projs,
                                                              const float* __restrict__ rot,
                                                              const float* __restrict__ lin, int rfn, int fh, int fw,
                                                              int C, float h_in, float w_in, int sn,
                                                              float* __restrict__ mean_in, float* __restrict__ stdv) {
   const int nvox = sn * sn * sn;
-  const int half = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;   // one half-wave per voxel
+  int half = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;         // one half-wave per voxel
   const int l32 = threadIdx.x & 31;
-  if (half >= nvox) return;
+  const bool live = half < nvox;                                   // (whole half-waves; keep them for the shuffles)
+  if (!live) half = nvox - 1;
   const int k = half % sn, j = (half / sn) % sn, i = half / (sn * sn);
   const float g0 = lin[i], g1 = lin[j], g2 = lin[k];
   const float vx = g0 * rot[0] + g1 * rot[3] + g2 * rot[6];
@@ -64,12 +88,16 @@ __global__ void __launch_bounds__(256) refiner_volume_kernel(const float* __rest
   const float vz = g0 * rot[2] + g1 * rot[5] + g2 * rot[8];
   const size_t fsz = (size_t)fh * fw * C;
   const float inv_n = 1.f / (float)rfn, inv_n1 = 1.f / (float)(rfn > 1 ? rfn - 1 : 1);
-  for (int c = l32 * 4; c < C; c += 128) {
+  // lane v of the half-wave projects the voxel into view v (views 0..rfn-1 = references, view rfn = query); every
+  // lane then fetches the 8 footprint values of each view with shuffles instead of redoing the 9 projections
+  const int myview = l32 <= rfn ? l32 : rfn;
+  const Taps mine = project_view(fh, fw, C, projs + myview * 12, vx, vy, vz, h_in, w_in);
+  for (int c = l32 * 4; c < C; c += 128) {           // (uniform trip count per half-wave pair: C is a kernel argument)
     f32x4 s[MAX_RFN];
     f32x4 sum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int r = 0; r < MAX_RFN; ++r)
-      if (r < rfn) { s[r] = sample_view(feats + r * fsz, fh, fw, C, c, projs + r * 12, vx, vy, vz, h_in, w_in); sum += s[r]; }
+      if (r < rfn) { s[r] = gather_view(feats + r * fsz, taps_from(mine, r), c); sum += s[r]; }
     const f32x4 mean = sum * inv_n;
     f32x4 var = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -77,7 +105,8 @@ __global__ void __launch_bounds__(256) refiner_volume_kernel(const float* __rest
       if (r < rfn) { f32x4 d = s[r] - mean; var += d * d; }
     var = var * inv_n1;
     f32x4 sd = {sqrtf(var[0]), sqrtf(var[1]), sqrtf(var[2]), sqrtf(var[3])};
-    const f32x4 q = sample_view(feats + rfn * fsz, fh, fw, C, c, projs + rfn * 12, vx, vy, vz, h_in, w_in);
+    const f32x4 q = gather_view(feats + rfn * fsz, taps_from(mine, rfn), c);
+    if (!live) continue;
     *reinterpret_cast<f32x4*>(mean_in + (size_t)half * 2 * C + c) = mean;
     *reinterpret_cast<f32x4*>(mean_in + (size_t)half * 2 * C + C + c) = q;
     *reinterpret_cast<f32x4*>(stdv + (size_t)half * C + c) = sd;
