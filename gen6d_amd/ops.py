@@ -138,7 +138,9 @@ def conv(x, w, bias, out, ksize=(1, 1, 1), stride=(1, 1, 1), pad=(0, 0, 0), mul=
         e0.record()
         _lib.check(_lib.load().g6d_conv_igemm(C.byref(d), _stream()), "g6d_conv_igemm")
         e1.record()
-        PROFILE.append((2.0 * N * Do * Ho * Wo * Cout * kd * kh * kw * Cin, e0, e1))
+        PROFILE.append((2.0 * N * Do * Ho * Wo * Cout * kd * kh * kw * Cin, e0, e1,
+                        f"conv N={N} in={Di}x{Hi}x{Wi}x{Cin} out={Do}x{Ho}x{Wo}x{Cout} k={kd}x{kh}x{kw} s={stride[0]}{stride[1]}{stride[2]}"
+                        f"{' mul' if mul is not None else ''}{' aff' if in_scale is not None else ''}{' stats' if stats is not None else ''}"))
         return out
     _lib.check(_lib.load().g6d_conv_igemm(C.byref(d), _stream()), "g6d_conv_igemm")
     return out
@@ -160,7 +162,7 @@ def corr2d_patch(x, w, out, k):
                                            ws.numel() * 4, _stream()), "g6d_corr2d_patch")
     if PROFILE is not None:
         e1.record()
-        PROFILE.append((flops, e0, e1))
+        PROFILE.append((flops, e0, e1, f"corr2d_patch in={H}x{W}x{Cin} out={Cout} k={k}x{k}"))
     return out
 
 
