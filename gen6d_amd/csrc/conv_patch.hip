@@ -78,12 +78,13 @@ __global__ void __launch_bounds__(256) conv_patch_kernel(const G6dConv p, const 
     poff[j] = pval[j] ? ((((n + pn) * D + iz) * H + iy) * W + ix) * p.ld_in : 0;
     pmul[j] = pval[j] ? (iy * W + ix) * Cin : 0;
   }
+  const int aff_off = p.in_affine_per_n ? n * Cin : 0;        // one (scale, shift) table per image: tiles of one image only
   f32x4 rp[NPL], rmul[MUL ? NPL : 1], rsc = {1.f, 1.f, 1.f, 1.f}, rsh = {0.f, 0.f, 0.f, 0.f};
   bool vp[NPL];
   auto load_patch = [&](int chunk) {
     const int c = chunk * 32 + 4 * seg;
     const bool cv = (c < Cin) & (chunk < c_end);
-    if constexpr (AFF) { rsc = ldg(p.in_scale, cv ? c : 0); rsh = ldg(p.in_shift, cv ? c : 0); }
+    if constexpr (AFF) { rsc = ldg(p.in_scale, cv ? aff_off + c : 0); rsh = ldg(p.in_shift, cv ? aff_off + c : 0); }
 #pragma unroll
     for (int j = 0; j < NPL; ++j) {
       const bool v = pval[j] & cv;
@@ -283,6 +284,7 @@ int pick_kind(const G6dConv& d, double* eff_out, long long* tiles_out) {
     if (k3 != (kind == 1)) continue;
     const int TN = kind == 2 ? 2 : 1, TD = kind == 1 ? 2 : 1, TH = 8, TW = kind == 0 ? 16 : 8;
     if (TN > 1 && d.stats && d.stat_rows_per_group > 0) continue;       // per-image statistics need one image per tile
+    if (TN > 1 && d.in_scale && d.in_affine_per_n) continue;            // ... and so do per-image affine tables
     const long long tiles = (long long)((d.N + TN - 1) / TN) * ((d.Di + TD - 1) / TD) * ((d.Hi + TH - 1) / TH) *
                             ((d.Wi + TW - 1) / TW);
     const double eff = (double)d.N * d.Di * d.Hi * d.Wi / (double)(tiles * 128);
@@ -294,22 +296,27 @@ int pick_kind(const G6dConv& d, double* eff_out, long long* tiles_out) {
 
 }  // namespace
 
-// Eligibility (checked by the caller g6d_conv_igemm): stride 1, kernel (1,3,3) or (3,3,3) with "same" padding, no
-// per-image affine table, statistics groups = whole images or one group, enough well-filled tiles for the chip.
+// Eligibility (checked by the caller g6d_conv_igemm): stride 1, kernel (1,3,3) or (3,3,3) with "same" padding,
+// statistics groups = whole images or one group, enough well-filled tiles (times channel-chunk splits) for the chip.
 bool g6d_conv_patch_eligible(const G6dConv& d) {
   const bool k2 = d.kd == 1 && d.kh == 3 && d.kw == 3 && d.pd == 0 && d.ph == 1 && d.pw == 1 && d.Di == 1;
   const bool k3 = d.kd == 3 && d.kh == 3 && d.kw == 3 && d.pd == 1 && d.ph == 1 && d.pw == 1;
   if (!(k2 || k3) || d.sd != 1 || d.sh != 1 || d.sw != 1) return false;
-  if ((d.in_scale && d.in_affine_per_n) || (d.mul && !k2)) return false;
+  if (d.mul && !k2) return false;
   const int per_image = d.Do * d.Ho * d.Wo;
   if (d.stats && d.stat_rows_per_group > 0 && d.stat_rows_per_group != per_image) return false;
-  if (d.split_k > 1) return false;                                   // forced split counts go to the generic kernel
+  if (d.split_k > 0) return false;                                   // forced split counts go to the generic kernel
   double eff; long long tiles;
   if (pick_kind(d, &eff, &tiles) < 0) return false;
-  const long long blocks = tiles * ((d.Cout + BN - 1) / BN);
-  // wide layers re-load the patch once per 64-channel slice: only worth it while that is still fewer bytes than the
-  // implicit-GEMM tile (9 or 27 row loads per output) and the grid fills the chip
-  return blocks >= 128 && eff >= 0.85 && d.Cout <= 256;
+  const int chunks = (d.Cin + 31) / 32;
+  const long long unsplit = tiles * ((d.Cout + BN - 1) / BN);
+  const bool can_split = unsplit < 200 && chunks >= 4 && d.workspace;            // over channel chunks (launch_patch)
+  // A grid of >= 128 well-filled tiles runs unsplit.  Smaller grids need the chunk split to reach >= 200 blocks: with
+  // fewer, the serial (chunks x taps) loop of a block is longer than the generic kernel's split-K path (16^3 layers:
+  // 94 vs 70 us), while the 7-image 2-D layers of the refiner feature net gain 5-20 %.
+  // Wide layers re-load the patch once per 64-channel slice, still fewer rows than 9 / 27 tile loads per output.
+  const bool enough = unsplit >= 128 || (can_split && unsplit * (chunks / 2) >= 200);
+  return enough && eff >= 0.85 && d.Cout <= 256;
 }
 
 int g6d_conv_patch_launch(const G6dConv& d, int M, hipStream_t stream) {

@@ -92,7 +92,7 @@ class Detector(ParamBank):
         for x, wref, k in zip((x0, x1, x2), self.ref_center_feats, self.ref_ksize):
             _, _, h, w, _ = x.shape
             o = torch.empty((1, 1, h, w, rfn), dtype=torch.float32, device=x.device)
-            if k >= 9 and rfn <= 32:       # 15x15 level: input patch kept in LDS and walked by the kx taps
+            if k >= 7 and rfn <= 32:       # 15x15 and 7x7 levels: input patch kept in LDS and walked by the kx taps
                 ops.corr2d_patch(x, wref, o, k)
             else:
                 ops.conv(x, wref, None, o, ksize=(1, k, k), pad=(0, k // 2, k // 2))

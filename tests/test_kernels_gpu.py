@@ -64,6 +64,8 @@ CONV_CASES = [
     dict(N=80, D=1, H=16, W=16, Cin=64, Cout=64, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), mul=True, aff=True, stats=True),
     dict(N=70, D=1, H=16, W=16, Cin=96, Cout=64, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), aff=True, relu=True, stats=True, rpg=256),
     dict(N=66, D=1, H=15, W=16, Cin=32, Cout=20, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), act=2),
+    dict(N=7, D=1, H=32, W=32, Cin=128, Cout=128, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), aff=True, relu=True, per_n=True, stats=True, rpg=1024),  # per-image tables, chunk split
+    dict(N=7, D=1, H=32, W=32, Cin=256, Cout=64, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), stats=True, rpg=1024),
     dict(N=321, D=1, H=8, W=8, Cin=64, Cout=128, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), aff=True, relu=True, stats=True),   # 2 images / tile, odd N
     dict(N=320, D=1, H=8, W=8, Cin=512, Cout=128, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), mul=True, aff=True, stats=True),
     dict(N=323, D=1, H=4, W=4, Cin=128, Cout=256, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), aff=True, relu=True),             # 4x4 maps stay on the generic kernel

@@ -27,8 +27,14 @@ SHAPES = [
     ("det corr 15x15 s0.5", 1, 1, 88, 116, 512, 32, (1, 15, 15), 1, (0, 7, 7), ""),
     ("det corr 15x15 s0", 1, 1, 60, 80, 512, 32, (1, 15, 15), 1, (0, 7, 7), ""),
     ("det corr 7x7 s0.5", 1, 1, 44, 58, 512, 32, (1, 7, 7), 1, (0, 3, 3), ""),
-    ("feat conv1.0 16x16", 7, 1, 16, 16, 512, 256, (1, 3, 3), 1, (0, 1, 1), ""),
-    ("feat conv_out.0", 7, 1, 32, 32, 192, 128, (1, 3, 3), 1, (0, 1, 1), ""),
+    ("feat conv1.0 16x16", 7, 1, 16, 16, 512, 256, (1, 3, 3), 1, (0, 1, 1), "pn"),
+    ("feat conv_out.0", 7, 1, 32, 32, 192, 128, (1, 3, 3), 1, (0, 1, 1), "pn"),
+    ("feat conv0.0 32x32", 7, 1, 32, 32, 256, 64, (1, 3, 3), 1, (0, 1, 1), "pn"),
+    ("feat conv0.1 32x32", 7, 1, 32, 32, 64, 64, (1, 3, 3), 1, (0, 1, 1), "affpn"),
+    ("feat conv1.1 16x16", 7, 1, 16, 16, 256, 64, (1, 3, 3), 1, (0, 1, 1), "affpn"),
+    ("feat conv2.0 8x8", 7, 1, 8, 8, 512, 256, (1, 3, 3), 1, (0, 1, 1), "pn"),
+    ("feat conv2.1 8x8", 7, 1, 8, 8, 256, 64, (1, 3, 3), 1, (0, 1, 1), "affpn"),
+    ("feat conv_out.1", 7, 1, 32, 32, 128, 128, (1, 3, 3), 1, (0, 1, 1), "affpn"),
 ]
 
 
@@ -46,11 +52,16 @@ def main():
         b = torch.randn((Cout,), device=dev)
         out = torch.empty((N, Do, Ho, Wo, Cout), device=dev)
         kw = {}
+        pn = mode.endswith("pn")                       # per-image statistics (InstanceNorm2d) / per-image affine tables
+        if mode == "affpn":
+            kw.update(in_scale=torch.rand((N, Cin), device=dev) + 0.5, in_shift=torch.randn((N, Cin), device=dev), in_relu=True, per_n=True)
         if mode in ("aff", "mul"):
             kw.update(in_scale=torch.rand((1, Cin), device=dev) + 0.5, in_shift=torch.randn((1, Cin), device=dev), in_relu=mode == "aff")
         if mode == "mul":
             kw.update(mul=torch.randn((H, W, Cin), device=dev))
-        stats = ops.new_stats(1, Cout, dev)
+        stats = ops.new_stats(N if pn else 1, Cout, dev)
+        if pn:
+            kw["rows_per_group"] = Do * Ho * Wo
         kw["split_k"] = int(os.environ.get("SPLITK", "0"))
         for _ in range(2):
             ops.conv(x, w, b, out, ksize=k, stride=(s,) * 3, pad=p, stats=stats, **kw)
@@ -62,7 +73,7 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
-        if name.startswith("det corr 15"):
+        if name.startswith("det corr"):
             xs, os_ = x[0:1, 0:1], out[0:1, 0:1]
             for _ in range(2): ops.corr2d_patch(xs, w, os_, k[1])
             torch.cuda.synchronize(); e0.record()
