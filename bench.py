@@ -65,11 +65,15 @@ def main():
     ap.add_argument("--det-refs", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="time the eager launch path instead of hipGraph replay")
-    ap.add_argument("--lanes", type=int, default=2,
+    ap.add_argument("--lanes", type=int, default=3,
                     help="independent hipGraph copies kept in flight on separate streams (queries are independent)")
     ap.add_argument("--serial", action="store_true",
                     help="profiling aid: no stream fork/join and no graph, so that per-kernel durations in a rocprofv3 "
                          "trace are not inflated by overlap (this is how the roofline pass itself runs)")
+    ap.add_argument("--fork", action="store_true",
+                    help="graph mode: also fork the independent branches of ONE query (4 detector scales, 3 selector levels, "
+                         "3 refiner feature branches) onto side streams inside each graph.  Off by default: measured, the "
+                         "chip is filled better by whole queries in flight on separate streams (89 vs 69 images/s)")
     ap.add_argument("--shard-refs", action="store_true",
                     help="strong-scaling variant: all ranks work on the SAME query stream, the selector's reference cache "
                          "is sharded over the ranks (RCCL statistics all-reduces + feature all-gather); default is query replicas")
@@ -96,7 +100,8 @@ def main():
     crops = synth.imgs_to_tensor(synth.synth_images(4, 128, 128, seed=200 + qseed)).to(dev)
 
     use_graph = not args.no_graph and not shard_refs and not args.serial     # collectives are issued eagerly
-    if args.serial:
+    no_fork = args.serial or (use_graph and not args.fork)
+    if no_fork:
         ops.SERIAL = True
     lanes = max(1, args.lanes) if use_graph else 1
     if use_graph:
@@ -149,7 +154,7 @@ def main():
         for i in range(args.steps):
             step(args.warmup + i, eager=True)
         torch.cuda.synchronize()
-        ops.SERIAL = args.serial
+        ops.SERIAL = no_fork
     prof, ops.PROFILE = ops.PROFILE, None
     prof_hbm, ops.PROFILE_HBM = ops.PROFILE_HBM or {}, None
     stages = stage_times(pipe, fulls[0:1], crops[0:1]) if (rank == 0 and not shard_refs) else None   # (sharded stages hold collectives)
@@ -180,7 +185,8 @@ def main():
                                f"128x128 crop vs {args.sel_refs} refs x 5 rotations + 3 refiner steps (6 refs, 32^3 volume); "
                                "seeded synthetic weights", "sharding": (f"selector and detector references sharded x{world} (RCCL all-reduce/all-gather), refiner replicated" if shard_refs
                                 else f"query-replicas x{world}"),
-                   "launch": f"hipGraph replay (1 graph = 1 query), {lanes} queries in flight on separate streams" if use_graph else "eager"},
+                   "launch": (f"hipGraph replay (1 graph = 1 query{', branches forked' if args.fork else ''}), {lanes} queries in flight "
+                              "on separate streams") if use_graph else "eager"},
         "roofline": {"bound": "mfma", "kernel": "g6d_conv_igemm family: conv_igemm / conv_patch / corr_patch kernels "
                                                  "(fp32 v_mfma_f32_32x32x2_f32) incl. their split-K reduce",
                      "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
