@@ -551,8 +551,9 @@ extern "C" int g6d_conv_igemm(const G6dConv* desc, g6d_stream_t stream_) {
   int splits = d.split_k;
   if (splits <= 0) {
     splits = 1;
-    if (blocks < 256 && total >= 8 && !no_split) {
-      splits = (int)((512 + blocks - 1) / blocks);
+    static const int split_target = []() { const char* e = getenv("G6D_SPLIT_TARGET"); return e ? atoi(e) : 512; }();
+    if (blocks < (split_target < 256 ? split_target : 256) && total >= 8 && !no_split) {
+      splits = (int)((split_target + blocks - 1) / blocks);
       if (splits > total / 4) splits = total / 4;
       if (splits > 64) splits = 64;
       if (splits < 1) splits = 1;
