@@ -43,8 +43,11 @@ __global__ void __launch_bounds__(256) conv_patch_kernel(const G6dConv p, const 
   constexpr int NPL = (NPOS * 8 + 255) / 256;                  // 16-byte patch loads per thread per chunk
   constexpr int PATCH = NPOS * LDS_K, BT = BN * LDS_K;
   constexpr bool AFF = MODE != 0, MUL = MODE == 3;
-  float* patch0 = lds; float* patch1 = lds + PATCH;
-  float* bt0 = lds + 2 * PATCH; float* bt1 = bt0 + BT;
+  // ONE patch buffer (the next chunk's patch waits in registers during the taps and is written between two barriers
+  // after the last tap): 76 KB per block for the 3-D tile instead of 134 KB, so that two blocks — or a block of another
+  // stream's kernel — share a CU.  Weight tiles stay double-buffered.
+  float* patch = lds;
+  float* bt0 = lds + PATCH; float* bt1 = bt0 + BT;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;                     // wave tile 64 (M) x 32 (N)
@@ -144,12 +147,11 @@ __global__ void __launch_bounds__(256) conv_patch_kernel(const G6dConv p, const 
 
   if (c_begin < c_end) {
     load_patch(c_begin); load_b(c_begin, 0);
-    store_patch(patch0); store_b(bt0);
+    store_patch(patch); store_b(bt0);
     __syncthreads();
-    int pcur = 0, bcur = 0;
+    int bcur = 0;
     for (int chunk = c_begin; chunk < c_end; ++chunk) {
-      const float* P = pcur ? patch1 : patch0;
-      float* Pn = pcur ? patch0 : patch1;
+      const float* P = patch;
       load_patch(chunk + 1);                          // masked beyond c_end; lands during the T taps below
 #pragma unroll 1
       for (int tap = 0; tap < T; ++tap) {
@@ -174,12 +176,14 @@ __global__ void __launch_bounds__(256) conv_patch_kernel(const G6dConv p, const 
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kc][1][s], b[kc][s], acc[1], 0, 0, 0);
           }
         __builtin_amdgcn_sched_barrier(0);
-        if (last) store_patch(Pn);
+        if (last && chunk + 1 < c_end) {
+          __syncthreads();                              // every wave is done with this chunk's patch
+          store_patch(patch);
+        }
         store_b(Bn);
         __syncthreads();
         bcur ^= 1;
       }
-      pcur ^= 1;
     }
   }
 
@@ -255,7 +259,7 @@ int launch_patch(const G6dConv& d, int M, hipStream_t stream) {
   }
   const int cps = (total_chunks + splits - 1) / splits;
   splits = (total_chunks + cps - 1) / cps;
-  const size_t lds_bytes = (size_t)(2 * NPOS * LDS_K + 2 * BN * LDS_K) * sizeof(float);
+  const size_t lds_bytes = (size_t)(NPOS * LDS_K + 2 * BN * LDS_K) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_patch_kernel<KIND, MODE>),
