@@ -8,7 +8,7 @@
 //
 //   block  = 512 threads = 8 waves; output tile = 8 rows x 32 columns (256 positions) x 32 output channels;
 //            wave w owns output row w of the tile: lane i -> column i, one 32x32 accumulator tile
-//   unit   = (channel chunk of 32, ky): patch stage [8][32+kw-1][36 floats] double-buffered; per kx one weight tile
+//   unit   = (channel chunk of 32, ky): patch stage [8][32+kw-1][36 floats] (single buffer); per kx one weight tile
 //            [32 co][36] double-buffered; 16 MFMAs (v_mfma_f32_32x32x2_f32) per wave per kx
 //   split  = units are split across gridDim.z; partial tiles go to a workspace and the common split-K reduce adds them.
 #include "g6d_common.h"
@@ -30,9 +30,11 @@ __global__ void __launch_bounds__(512) corr_patch_kernel(const float* __restrict
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int PW = TW + kw - 1;                       // patch width in positions
   const int patch_floats = TH * PW * LDS_K;
-  float* patch0 = lds;
-  float* patch1 = lds + patch_floats;
-  float* bt0 = lds + 2 * patch_floats;              // weight tiles [32][LDS_K] x 2
+  // one patch buffer: the next unit's patch waits in registers during the kw taps and is written between two barriers
+  // after the last tap (58 KB per block at kw = 15 instead of 111 KB, so that a second block — possibly of another
+  // stream's kernel — fits on the CU)
+  float* patch = lds;
+  float* bt0 = lds + patch_floats;                  // weight tiles [32][LDS_K] x 2
   float* bt1 = bt0 + 32 * LDS_K;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -93,12 +95,11 @@ __global__ void __launch_bounds__(512) corr_patch_kernel(const float* __restrict
 
   if (u_begin < u_end) {
     load_patch(u_begin); load_b(u_begin, 0);
-    store_patch(patch0); store_b(bt0);
+    store_patch(patch); store_b(bt0);
     __syncthreads();
-    int pcur = 0, bcur = 0;
+    int bcur = 0;
     for (int u = u_begin; u < u_end; ++u) {
-      const float* P = pcur ? patch1 : patch0;
-      float* Pn = pcur ? patch0 : patch1;
+      const float* P = patch;
       load_patch(u + 1);                            // masked beyond u_end; lands during the kw steps below
       for (int kx = 0; kx < kw; ++kx) {
         const float* B = bcur ? bt1 : bt0;
@@ -118,12 +119,14 @@ __global__ void __launch_bounds__(512) corr_patch_kernel(const float* __restrict
 #pragma unroll
           for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kc][s], b[kc][s], acc, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        if (last) store_patch(Pn);
+        if (last && u + 1 < u_end) {
+          __syncthreads();                          // every wave is done with this unit's patch
+          store_patch(patch);
+        }
         store_b(Bn);
         __syncthreads();
         bcur ^= 1;
       }
-      pcur ^= 1;
     }
   }
 
@@ -160,7 +163,7 @@ extern "C" int g6d_corr2d_patch(const float* in, int H, int W, int Cin, int ld_i
   }
   const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH, tiles = tiles_x * tiles_y;
   const int total_units = ((Cin + 31) / 32) * kh;
-  // split the (chunk, ky) units so that the grid fills whole rounds of the 256 CUs (one 115 KB block per CU):
+  // split the (chunk, ky) units so that the grid fills whole rounds of the 256 CUs:
   // pick the split count with the best last-round utilisation, preferring fewer splits on ties
   int splits = 1;
   {
@@ -180,7 +183,7 @@ extern "C" int g6d_corr2d_patch(const float* in, int H, int W, int Cin, int ld_i
   }
   const int ups = (total_units + splits - 1) / splits;
   splits = (total_units + ups - 1) / ups;
-  const size_t lds_bytes = (size_t)(2 * TH * (TW + kw - 1) * LDS_K + 2 * 32 * LDS_K) * sizeof(float);
+  const size_t lds_bytes = (size_t)(TH * (TW + kw - 1) * LDS_K + 2 * 32 * LDS_K) * sizeof(float);
   static size_t attr_bytes = 0;
   if (lds_bytes > attr_bytes) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_patch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
