@@ -163,7 +163,7 @@ extern "C" int g6d_corr2d_patch(const float* in, int H, int W, int Cin, int ld_i
   }
   const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH, tiles = tiles_x * tiles_y;
   const int total_units = ((Cin + 31) / 32) * kh;
-  // split the (chunk, ky) units so that the grid fills whole rounds of the 256 CUs:
+  // split the (chunk, ky) units so that the grid fills whole rounds of the chip (256 CUs x 2 resident blocks):
   // pick the split count with the best last-round utilisation, preferring fewer splits on ties
   int splits = 1;
   {
@@ -172,12 +172,13 @@ extern "C" int g6d_corr2d_patch(const float* in, int H, int W, int Cin, int ld_i
     if (max_s > 64) max_s = 64;
     if (workspace && per > 0 && (size_t)max_s > workspace_bytes / per) max_s = (int)(workspace_bytes / per);
     if (!workspace) max_s = 1;
+    static const int slots = []() { const char* e = getenv("G6D_CORR_SLOTS"); return e ? atoi(e) : 512; }();   // two 58 KB blocks per CU
     double best = -1.0;
     for (int sp = 1; sp <= max_s; ++sp) {
       const int ups_ = (total_units + sp - 1) / sp;
       const int real = (total_units + ups_ - 1) / ups_;
       const long long blocks = (long long)tiles * real;
-      const double util = (double)blocks / (256.0 * ((blocks + 255) / 256));
+      const double util = (double)blocks / ((double)slots * ((blocks + slots - 1) / slots));
       if (util > best + 0.02) { best = util; splits = real; }
     }
   }
