@@ -1,11 +1,13 @@
 // 3x3 / 3x3x3 stride-1 "same" convolution with the input patch of a spatial output tile kept in LDS and reused by all
-// taps (64 output channels per block).  Generalises corr_patch.hip: measured on conv_igemm.hip, what costs matrix-pipe time is the amount of
-// data brought into the CU per MFMA; an implicit-GEMM tile re-loads its 128 activation rows for every
-// one of the 9 / 27 taps, while a spatial tile of 128 outputs only needs its halo box once per channel chunk:
+// taps (64 output channels per block).  Generalises corr_patch.hip: measured on conv_igemm.hip, what costs matrix-pipe
+// time is the amount of data brought into the CU per MFMA; an implicit-GEMM tile re-loads its 128
+// activation rows for every one of the 9 / 27 taps, while a spatial tile of 128 outputs only needs its halo box once
+// per channel chunk:
 //   3-D: outputs 2x8x8, patch 4x10x10 = 400 positions (instead of 27 x 128 = 3456 row loads per chunk)
 //   2-D: outputs 1x8x16, patch 1x10x18 = 180 positions (instead of 9 x 128 = 1152); 8x8 maps: 2 images per tile
-// The prologue (multiplier, InstanceNorm affine, ReLU, zero padding) is applied once per patch element when it is
-// written to LDS instead of once per tap.  Weight tiles [64 co][32 ci] are streamed per tap (double-buffered).
+// The prologue (multiplier, InstanceNorm affine with one table or one per image, ReLU, zero padding) is applied once
+// per patch element when it is written to LDS instead of once per tap.  Weight tiles [64 co][32 ci] are streamed per
+// tap (double-buffered); the patch has ONE buffer (next chunk prefetched into registers), see the kernel body.
 // Same fragment scheme (K-permuted ds_read_b128 + v_mfma_f32_32x32x2_f32), accumulator layout and epilogue (bias,
 // activation, channel-slice store, fp64 InstanceNorm statistics, split-K partials) as conv_igemm.hip.
 #include "g6d_common.h"
