@@ -53,3 +53,17 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(lib, "LIB_PATH", "/nonexistent/libgen6d_hip.so")
     with pytest.raises(RuntimeError, match="no fallback"):
         lib.load()
+
+
+def test_bench_refuses_to_run_without_gpu():
+    """bench.py measures the HIP path only: on a box without a GPU it exits with an error instead of timing a fallback."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "no CPU fallback" in (r.stderr + r.stdout)
+    assert '"metric"' not in r.stdout
