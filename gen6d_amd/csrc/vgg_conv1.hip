@@ -1,0 +1,147 @@
+// First trunk layer fused: conv 3x3 (3 -> 64 channels, pad 1) + folded-BatchNorm bias + ReLU + 2x2 max-pool, NCHW in
+// and out (reference network/pretrain_models.py:17-25,66-72: features[0..3] of vgg11_bn).
+//
+// With 3 input channels the layer is 27 MACs per output: the library path (convolution, layout transposes, then the
+// separate bias/ReLU/pool pass over the 167 MB full-resolution result) takes 113 us on the 704x928 detector scale.  Here
+// a thread owns one POOLED output pixel and 16 output channels: its 4x4x3 input window sits in registers, the 27x64
+// weights in LDS (read as wave-uniform 16-byte broadcasts), 4 conv positions x 16 channels accumulate in registers, and
+// only the pooled map (1/4 of the conv output) is ever written.  fp32 FMA on the vector pipe; algorithmic bytes: 12 B read per
+// input pixel, 64 B written per input pixel.
+//
+// The two phases of the kernel are plain inline functions of (thread id, block origin) so that the index arithmetic can
+// be run thread by thread on the host: tests/test_conv1_emulation_cpu.py builds this file with -DG6D_CONV1_HOST_EMU
+// and checks the emulation against torch (test infrastructure only; the library itself has no host compute path).
+#ifndef G6D_CONV1_HOST_EMU
+#include "g6d_common.h"
+#define G6D_HD __host__ __device__ __forceinline__
+#else
+#include <cmath>
+#include <cstddef>
+#define G6D_HD inline
+#endif
+
+#define C1_PTX 32                      // pooled tile: 32 x 2 outputs; 256 threads = 64 pixels x 4 channel groups of 16
+#define C1_PTY 2
+#define C1_IW (2 * C1_PTX + 2)         // input tile incl. halo: 66 x 6
+#define C1_IH (2 * C1_PTY + 2)
+#define C1_IWP (C1_IW + 1)
+#define C1_CIN 3
+#define C1_COUT 64
+#define C1_TAPS 27
+#define C1_THREADS (C1_PTX * C1_PTY * (C1_COUT / 16))
+
+struct Conv1Smem {
+  float in[C1_CIN][C1_IH][C1_IWP];
+  float w[C1_TAPS][C1_COUT];           // tap-major: the 16 channels of one pass are contiguous
+  float b[C1_COUT];
+};
+
+// Phase 1: stage the zero-padded input tile of image n whose pooled origin is (px0, py0), and the weights.
+G6D_HD void conv1_stage(Conv1Smem& s, int tid, const float* in, const float* w_oihw, const float* bias, int n, int H, int W,
+                        int px0, int py0) {
+  const int gx0 = 2 * px0 - 1, gy0 = 2 * py0 - 1;
+  for (int i = tid; i < C1_CIN * C1_IH * C1_IW; i += C1_THREADS) {
+    const int col = i % C1_IW, r = (i / C1_IW) % C1_IH, c = i / (C1_IW * C1_IH);
+    const int gy = gy0 + r, gx = gx0 + col;
+    const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
+    s.in[c][r][col] = ok ? in[((size_t)(n * C1_CIN + c) * H + gy) * W + gx] : 0.f;
+  }
+  for (int i = tid; i < C1_TAPS * C1_COUT; i += C1_THREADS) {
+    const int co = i % C1_COUT, t = i / C1_COUT;
+    s.w[t][co] = w_oihw[co * C1_TAPS + t];          // OIHW: [co][ci][ky][kx] -> tap t = (ci*3 + ky)*3 + kx
+  }
+  if (tid < C1_COUT) s.b[tid] = bias[tid];
+}
+
+// Phase 2: thread (tx, ty, cg) computes pooled pixel (px0 + tx, py0 + ty) for the 16 channels of group cg.  A wavefront
+// holds one cg (64 pixels), so its weight reads are wave-uniform; splitting the channels over threads instead of looping
+// keeps the serial FMA chain of a thread at 1728 instead of 6912, which is what bounds the small 128x128 crops.
+G6D_HD void conv1_compute(const Conv1Smem& s, int tid, float* out, int n, int Ho, int Wo, int px0, int py0) {
+  const int pix = tid % (C1_PTX * C1_PTY), cg = tid / (C1_PTX * C1_PTY);
+  const int tx = pix % C1_PTX, ty = pix / C1_PTX;
+  const int px = px0 + tx, py = py0 + ty;
+  const bool live = px < Wo && py < Ho;
+  float v[C1_CIN][4][4];
+#pragma unroll
+  for (int c = 0; c < C1_CIN; ++c)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[c][r][j] = s.in[c][2 * ty + r][2 * tx + j];
+  {
+    float acc[4][16];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int k = 0; k < 16; ++k) acc[p][k] = 0.f;
+#pragma unroll
+    for (int t = 0; t < C1_TAPS; ++t) {
+      const int c = t / 9, ky = (t % 9) / 3, kx = t % 3;
+      float wv[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) wv[k] = s.w[t][cg * 16 + k];
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const float x = v[c][(p >> 1) + ky][(p & 1) + kx];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[p][k] = fmaf(x, wv[k], acc[p][k]);
+      }
+    }
+    if (live) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int co = cg * 16 + k;
+        float m = fmaxf(fmaxf(acc[0][k], acc[1][k]), fmaxf(acc[2][k], acc[3][k])) + s.b[co];   // max(a)+b == max(a+b)
+        m = fmaxf(m, 0.f);                                                                     // relu(max) == max(relu)
+        out[((size_t)(n * C1_COUT + co) * Ho + py) * Wo + px] = m;
+      }
+    }
+  }
+}
+
+#ifndef G6D_CONV1_HOST_EMU
+
+namespace {
+
+__global__ void __launch_bounds__(C1_THREADS) vgg_conv1_pool_kernel(const float* __restrict__ in,
+                                                                    const float* __restrict__ w_oihw,
+                                                                    const float* __restrict__ bias, int H, int W, int Ho,
+                                                                    int Wo, float* __restrict__ out) {
+  __shared__ Conv1Smem s;
+  const int px0 = blockIdx.x * C1_PTX, py0 = blockIdx.y * C1_PTY, n = blockIdx.z;
+  conv1_stage(s, threadIdx.x, in, w_oihw, bias, n, H, W, px0, py0);
+  __syncthreads();
+  conv1_compute(s, threadIdx.x, out, n, Ho, Wo, px0, py0);
+}
+
+}  // namespace
+
+// in [N][3][H][W], w_oihw [64][3][3][3] (BatchNorm folded), bias [64] -> out [N][64][H/2][W/2] (floor, as F.max_pool2d).
+extern "C" int g6d_vgg_conv1_pool(const float* in, int N, int H, int W, const float* w_oihw, const float* bias, int Cin,
+                                  int Cout, float* out, g6d_stream_t stream) {
+  if (!in || !w_oihw || !bias || !out || N <= 0 || N > 65535 || H < 2 || W < 2 || Cin != C1_CIN || Cout != C1_COUT ||
+      (long long)N * Cout * (H / 2) * (W / 2) >= (1ll << 31)) {
+    g6d_set_error("vgg_conv1_pool: bad args (3 -> 64 channels, H, W >= 2)"); return G6D_EINVAL;
+  }
+  const int Ho = H / 2, Wo = W / 2;
+  hipLaunchKernelGGL(vgg_conv1_pool_kernel, dim3((Wo + C1_PTX - 1) / C1_PTX, (Ho + C1_PTY - 1) / C1_PTY, N), dim3(C1_THREADS),
+                     0, reinterpret_cast<hipStream_t>(stream), in, w_oihw, bias, H, W, Ho, Wo, out);
+  return g6d_check_launch("vgg_conv1_pool");
+}
+
+#else   // ---- host emulation of the two phases, thread by thread (tests only) -------------------------------------
+
+extern "C" int g6d_conv1_emulate(const float* in, int N, int H, int W, const float* w_oihw, const float* bias, float* out) {
+  const int Ho = H / 2, Wo = W / 2;
+  Conv1Smem* s = new Conv1Smem;
+  for (int n = 0; n < N; ++n)
+    for (int by = 0; by < (Ho + C1_PTY - 1) / C1_PTY; ++by)
+      for (int bx = 0; bx < (Wo + C1_PTX - 1) / C1_PTX; ++bx) {
+        for (int tid = 0; tid < C1_THREADS; ++tid) conv1_stage(*s, tid, in, w_oihw, bias, n, H, W, bx * C1_PTX, by * C1_PTY);
+        for (int tid = 0; tid < C1_THREADS; ++tid) conv1_compute(*s, tid, out, n, Ho, Wo, bx * C1_PTX, by * C1_PTY);
+      }
+  delete s;
+  return 0;
+}
+
+#endif

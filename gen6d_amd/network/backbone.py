@@ -9,6 +9,9 @@ import torch.nn.functional as F
 
 from .. import ops, specs
 
+# The 3 -> 64 layer in front of the first pool runs on the fused HIP kernel g6d_vgg_conv1_pool (G6D_OWN_CONV1=0: MIOpen).
+_OWN_CONV1 = os.environ.get("G6D_OWN_CONV1", "1") != "0"
+
 if os.environ.get("G6D_MIOPEN_FIND", "0") == "1":
     torch.backends.cudnn.benchmark = True        # MIOpen Find (measured solver choice) instead of the immediate-mode heuristic
 
@@ -34,6 +37,9 @@ def vgg_taps(folded, x, taps):
        'c3' (256ch @1/4, post-ReLU), 'c5' (512 @1/8, post-ReLU), 'c7_pre' (512 @1/16, pre-ReLU), 'p7' (max-pool of c7_pre)."""
     out = {}
     for i, (w, b) in enumerate(folded):
+        if i == 0 and _OWN_CONV1 and x.shape[1] == 3 and w.shape[0] == 64 and x.shape[2] >= 2 and x.shape[3] >= 2:
+            x = ops.vgg_conv1_pool(x.contiguous(), w, b)                      # conv + bias + ReLU + pool in one kernel
+            continue
         y = F.conv2d(x, w, None, padding=1)                                  # MIOpen; bias/ReLU/pool fused below
         if i == 7:
             out["c7_pre"] = ops.bias_relu_pool_nchw(y, b, False, False)       # BN output WITHOUT the last ReLU

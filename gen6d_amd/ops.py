@@ -241,6 +241,22 @@ def bias_relu_pool_nchw(x, bias, relu, pool):
     return out
 
 
+def vgg_conv1_pool(x, w_oihw, bias):
+    """First trunk layer fused: x [N,3,H,W] contiguous, w [64,3,3,3] (BatchNorm folded), bias [64] ->
+    maxpool2x2(relu(conv3x3(x) + bias)) [N,64,H//2,W//2]."""
+    _need_gpu(x, w_oihw, bias)
+    if x.dtype != torch.float32 or x.dim() != 4 or not x.is_contiguous() or not w_oihw.is_contiguous():
+        raise ValueError("vgg_conv1_pool: x and w must be contiguous float32 NCHW / OIHW")
+    N, Cin, H, W = x.shape
+    Cout = w_oihw.shape[0]
+    if tuple(w_oihw.shape) != (Cout, Cin, 3, 3) or bias.numel() != Cout:
+        raise ValueError("vgg_conv1_pool: weight / bias shape mismatch")
+    out = torch.empty((N, Cout, H // 2, W // 2), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().g6d_vgg_conv1_pool(_ptr(x), N, H, W, _ptr(w_oihw), _ptr(bias), Cin, Cout, _ptr(out), _stream()),
+               "g6d_vgg_conv1_pool")
+    return out
+
+
 def nchw_to_nhwc(x, out, l2norm):
     """x [N,C,H,W] contiguous -> out [N,1,H,W,C] view, optionally L2-normalised over C."""
     _need_gpu(x, out)

@@ -111,6 +111,13 @@ int g6d_upsample_bilinear(const float* in, int ld_in, const float* scale, const 
 int g6d_bias_relu_pool_nchw(const float* in, const float* bias, int N, int C, int H, int W, int relu, int pool, float* out,
                             g6d_stream_t stream);
 
+/* First trunk layer fused (reference network/pretrain_models.py:17-25,66-72: vgg11_bn features[0..3] with BatchNorm
+ * folded): out = maxpool2x2( relu( conv3x3_pad1(in, w) + bias ) ).  in [N][3][H][W], w_oihw [64][3][3][3], bias [64],
+ * out [N][64][H/2][W/2] (floor); Cin must be 3 and Cout 64.  Replaces the library convolution of that layer, its two
+ * layout transposes and the g6d_bias_relu_pool_nchw pass over the full-resolution result. */
+int g6d_vgg_conv1_pool(const float* in, int N, int H, int W, const float* w_oihw, const float* bias, int Cin, int Cout,
+                       float* out, g6d_stream_t stream);
+
 /* NCHW (backbone output) -> channels-last, optionally L2-normalised over C (F.normalize eps 1e-12,
  * network/selector.py:118, network/refiner.py:69-71). out [N][H][W][ld_out]. */
 int g6d_nchw_to_nhwc(const float* in, int N, int C, int H, int W, int l2norm, float* out, int ld_out, g6d_stream_t stream);

@@ -100,6 +100,10 @@ def bias_relu_pool_nchw(x, bias, relu, pool):
     return F.max_pool2d(v, 2, 2) if pool else v
 
 
+def vgg_conv1_pool(x, w_oihw, bias):
+    return F.max_pool2d(F.relu(F.conv2d(x, w_oihw, bias, padding=1)), 2, 2)
+
+
 def nchw_to_nhwc(x, out, l2norm):
     v = F.normalize(x, dim=1) if l2norm else x
     out.copy_(v.permute(0, 2, 3, 1).unsqueeze(1))

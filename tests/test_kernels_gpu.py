@@ -118,6 +118,20 @@ def test_conv_igemm(ops, case):
         _check(stats[..., 1], rstats[..., 1], 2e-5, "stats sumsq")
 
 
+@pytest.mark.parametrize("N,H,W", [(1, 128, 128), (2, 50, 70), (1, 33, 67), (3, 2, 2), (1, 96, 160)])
+def test_vgg_conv1_pool(ops, N, H, W):
+    """Fused first trunk layer against conv2d + bias + ReLU + max_pool2d in fp64 (odd sizes pool with floor)."""
+    g = torch.Generator().manual_seed(5)
+    x = _rand(g, N, 3, H, W)
+    w = _rand(g, 64, 3, 3, 3, scale=0.3)
+    b = _rand(g, 64, scale=0.2)
+    out = ops.vgg_conv1_pool(x.cuda(), w.cuda(), b.cuda())
+    assert tuple(out.shape) == (N, 64, H // 2, W // 2)
+    _check(out, ref_ops.vgg_conv1_pool(_d(x), _d(w), _d(b)), 1e-5, "vgg_conv1_pool")
+    with pytest.raises(RuntimeError, match="G6D_EINVAL"):
+        ops.vgg_conv1_pool(torch.zeros((1, 4, 8, 8), device="cuda"), torch.zeros((64, 4, 3, 3), device="cuda"), b.cuda())
+
+
 def test_conv_rejects_bad_args(ops):
     x = torch.zeros((1, 1, 4, 4, 6), device="cuda")          # Cin % 4 != 0
     w = torch.zeros((8, 1, 6), device="cuda")
