@@ -67,3 +67,10 @@ def test_bench_refuses_to_run_without_gpu():
     assert r.returncode != 0
     assert "no CPU fallback" in (r.stderr + r.stdout)
     assert '"metric"' not in r.stdout
+
+
+def test_integration_doc_covers_every_entry_point():
+    """INTEGRATION.md's table names the reference code each exported entry point replaces: no symbol may be missing."""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    missing = [n for n in _declared() if f"`{n}`" not in doc]
+    assert not missing, f"INTEGRATION.md does not mention: {missing}"
