@@ -16,31 +16,91 @@ from . import ops
 
 
 # ------------------------------------------------------------------------------------------------ database helpers
+def _reference_database_module(db):
+    """The reference's own `dataset.database` module when this process runs under the reference repo (eval.py /
+    predict.py import it) and `db` is one of its classes: its get_object_center / get_diameter / get_object_vert /
+    get_database_split then resolve every reference database type exactly as the reference does
+    (dataset/database.py:311-397).  Never imported from here — only picked up when already loaded."""
+    import sys
+    mod = sys.modules.get("dataset.database")
+    base = getattr(mod, "BaseDatabase", None)
+    return mod if (base is not None and isinstance(db, base)) else None
+
+
+def _kind(db):
+    return type(db).__name__
+
+
 def get_object_center(db):
+    """reference dataset/database.py:365-381, by attribute instead of isinstance so that any database with the
+    BaseDatabase protocol works: LINEMOD / GSO / ShapeNet expose `object_center`, Custom `center`, GenMOP
+    `meta_info.center`, NormalizedDatabase sits at the origin."""
+    mod = _reference_database_module(db)
+    if mod is not None:
+        return np.asarray(mod.get_object_center(db), np.float32)
+    if _kind(db) == "NormalizedDatabase" and not hasattr(db, "object_center"):
+        return np.zeros(3, np.float32)
     for name in ("object_center", "center"):
         if hasattr(db, name):
             return np.asarray(getattr(db, name), np.float32)
-    raise AttributeError("database must expose object_center")
+    meta = getattr(db, "meta_info", None)
+    if meta is not None and hasattr(meta, "center"):
+        return np.asarray(meta.center, np.float32)
+    raise AttributeError(f"{_kind(db)}: no object centre (object_center / center / meta_info.center)")
 
 
 def get_diameter(db):
+    """reference dataset/database.py:346-363: GenMOP / Custom / Normalized objects are already scaled to diameter 2,
+    LINEMOD reads data/LINEMOD/<model>/distance.txt (cm), the rendered sets carry `object_diameter`."""
+    mod = _reference_database_module(db)
+    if mod is not None:
+        return float(mod.get_diameter(db))
     for name in ("object_diameter", "diameter"):
         if hasattr(db, name):
             return float(getattr(db, name))
-    raise AttributeError("database must expose object_diameter")
+    kind = _kind(db)
+    if kind in ("GenMOPDatabase", "CustomDatabase", "NormalizedDatabase") or hasattr(db, "meta_info"):
+        return 2.0
+    if kind == "LINEMODDatabase" or str(getattr(db, "database_name", "")).startswith("linemod/"):
+        model = db.database_name.split("/")[-1]
+        return float(np.loadtxt(f"data/LINEMOD/{model}/distance.txt")) / 100
+    raise AttributeError(f"{kind}: no object diameter (object_diameter / diameter)")
 
 
 def get_object_vert(db):
-    return np.asarray(getattr(db, "object_vert", (0.0, 0.0, 1.0)), np.float32)
+    """reference dataset/database.py:383-397: +z unless the database says otherwise."""
+    mod = _reference_database_module(db)
+    if mod is not None:
+        try:
+            return np.asarray(mod.get_object_vert(db), np.float32)
+        except NotImplementedError:          # the reference has no entry for NormalizedDatabase: use the wrapped one
+            pass
+    if hasattr(db, "object_vert"):
+        return np.asarray(db.object_vert, np.float32)
+    inner = getattr(db, "database", None)
+    if inner is not None:
+        return get_object_vert(inner)
+    return np.asarray((0.0, 0.0, 1.0), np.float32)
 
 
 def get_database_split(db, split_type):
-    """(ref_ids, que_ids). Databases may implement `get_split(split_type)`; otherwise every image is a reference
-    (reference dataset/database.py:311-325 hard-codes this per dataset)."""
+    """(ref_ids, que_ids) as reference dataset/database.py:311-325: 'all' -> every image on both sides,
+    'linemod_test' / 'linemod_val' -> train.txt as references, test.txt (every 10th for _val) as queries.
+    A database may override with its own `get_split(split_type)`."""
+    mod = _reference_database_module(db)
+    if mod is not None:
+        return mod.get_database_split(db, split_type)
     if hasattr(db, "get_split"):
         return db.get_split(split_type)
-    ids = list(db.get_img_ids())
-    return ids, ids
+    if split_type == "all":
+        ids = list(db.get_img_ids())
+        return ids, ids
+    if split_type.startswith("linemod"):
+        model = db.database_name.split("/")[1]
+        ids = lambda fn: [str(int(l.split("/")[-1].split(".")[0])) for l in np.loadtxt(fn, dtype=str).tolist()]
+        que = ids(f"data/LINEMOD/{model}/test.txt")
+        return ids(f"data/LINEMOD/{model}/train.txt"), (que[::10] if split_type == "linemod_val" else que)
+    raise NotImplementedError(split_type)
 
 
 class NormalizedDatabase:
@@ -63,19 +123,53 @@ class NormalizedDatabase:
     def get_mask(self, i): return self.database.get_mask(i)
 
 
+def _root(db):
+    while hasattr(db, "database") and _kind(db) == "NormalizedDatabase":
+        db = db.database
+    return db
+
+
 class DeviceImageCache:
-    """uint8 HWC images of a database uploaded once and kept on the GPU (keyed by image id)."""
+    """Per-estimator cache of what the reference re-reads from disk on every call: the uint8 HWC images (and masks)
+    of a database, uploaded once and kept on the GPU, and the pose-independent FPS subset of
+    select_reference_img_ids_refinement.  Entries are keyed by the database OBJECT (kept alive by the cache, so a
+    CPython id can never be reused by another database) and, for the subset, by the exact id list; `clear()` is
+    called by Gen6DEstimator.build."""
 
     def __init__(self, device):
         self.device = device
-        self._imgs = {}
+        self.clear()
+
+    def clear(self):
+        self._dbs, self._imgs, self._masks, self._subsets = {}, {}, {}, {}
+
+    def _key(self, db):
+        root = _root(db)
+        self._dbs[id(root)] = root                     # strong reference: the id stays unique while cached
+        return id(root)
+
+    def holds(self, db):
+        return id(_root(db)) in self._dbs
 
     def get(self, db, img_id):
-        key = (id(getattr(db, "database", db)), img_id)
+        key = (self._key(db), img_id)
         if key not in self._imgs:
-            img = np.ascontiguousarray(db.get_image(img_id))
-            self._imgs[key] = torch.from_numpy(img).to(self.device)
+            self._imgs[key] = torch.from_numpy(np.ascontiguousarray(db.get_image(img_id))).to(self.device)
         return self._imgs[key]
+
+    def get_mask(self, db, img_id):
+        """uint8 [h,w,1] (0 / 255) on the device."""
+        key = (self._key(db), img_id)
+        if key not in self._masks:
+            m = (np.asarray(db.get_mask(img_id)) > 0).astype(np.uint8) * 255
+            self._masks[key] = torch.from_numpy(np.ascontiguousarray(m[..., None])).to(self.device)
+        return self._masks[key]
+
+    def subset(self, db, ref_ids, even, even_num, compute):
+        key = (self._key(db), _kind(db), tuple(str(i) for i in ref_ids), bool(even), int(even_num))
+        if key not in self._subsets:
+            self._subsets[key] = compute()
+        return self._subsets[key]
 
 
 def select_reference_img_ids_fps(db, ref_ids_all, ref_num):
@@ -85,26 +179,31 @@ def select_reference_img_ids_fps(db, ref_ids_all, ref_num):
     return np.asarray(ref_ids_all)[G.sample_fps_points(cams, ref_num + 1, True)]
 
 
-def select_reference_img_ids_refinement(db, center, ref_ids, sel_pose, ref_num=6, even=False, even_num=128, _cache={}):
-    """reference utils/database_utils.py:125-139; the pose-independent FPS subset is computed once per id list."""
+def select_reference_img_ids_refinement(db, center, ref_ids, sel_pose, ref_num=6, even=False, even_num=128, cache=None):
+    """reference utils/database_utils.py:125-139.  The reference recomputes the pose list and its FPS subset on every
+    call; with a DeviceImageCache the (pose-independent) subset is computed once per (database, id list)."""
     ref_ids = np.asarray(ref_ids)
-    key = (id(getattr(db, "database", db)), len(ref_ids), even, even_num)
-    if key not in _cache:
-        poses = np.asarray([db.get_pose(i) for i in ref_ids])
+
+    def compute():
+        ids = ref_ids
+        poses = np.asarray([db.get_pose(i) for i in ids])
         if even:
             cams = np.asarray([G.pose_inverse(p)[:, 3] for p in poses])
             idx = G.sample_fps_points(cams, even_num + 1, True)
-            ref_ids, poses = ref_ids[idx], poses[idx]
-        _cache[key] = (ref_ids, poses)
-    ref_ids, poses = _cache[key]
+            ids, poses = ids[idx], poses[idx]
+        return ids, poses
+
+    ids, poses = cache.subset(db, ref_ids, even, even_num, compute) if cache is not None else compute()
     corr = G.view_correlation(sel_pose[None], poses, center)
-    return ref_ids[np.argsort(-corr[0])[:ref_num]]
+    return ids[np.argsort(-corr[0])[:ref_num]]
 
 
-def normalize_reference_views(db, ref_ids, size, margin, cache, rectify_rot=True, input_pose=None, input_K=None):
+def normalize_reference_views(db, ref_ids, size, margin, cache, rectify_rot=True, input_pose=None, input_K=None,
+                              with_masks=True):
     """Crop every reference view so that the object is centred, fills `size*(1-margin)` pixels and is upright (or aligned
-    with `input_pose`).  Returns device images uint8 [rfn,size,size,3], Ks, poses, Hs (reference
-    utils/database_utils.py:54-110; masks are not needed on the inference path)."""
+    with `input_pose`).  Returns, in the reference's order (utils/database_utils.py:54-110): device images uint8
+    [rfn,size,size,3], masks float32 [rfn,size,size] in [0,1] (None when with_masks=False — the per-query refiner path
+    does not use them), Ks, poses, Hs."""
     center, diameter = get_object_center(db), get_diameter(db)
     poses = np.asarray([db.get_pose(i) for i in ref_ids])
     Ks = np.asarray([db.get_K(i) for i in ref_ids])
@@ -124,12 +223,15 @@ def normalize_reference_views(db, ref_ids, size, margin, cache, rectify_rot=True
         small = np.linalg.norm(v2, 2, 1) < 1e-5
         v2[small] += 1e-5 * np.sign(v2[small])
         angles = -np.arctan2(v2[:, 1], v2[:, 0]) - np.pi / 2
-    imgs, Ks_new, poses_new, Hs = [], [], [], []
+    imgs, masks, Ks_new, poses_new, Hs = [], [], [], [], []
     for k, i in enumerate(ref_ids):
         K_new, pose_new, _, H = G.look_at_crop_params(Ks[k], poses[k], cens[k], angles[k], scales[k], size, size)
         imgs.append(ops.warp_perspective(cache.get(db, i), H, size, size))
+        if with_masks:
+            masks.append(ops.warp_perspective(cache.get_mask(db, i), H, size, size, out_float=True)[..., 0])
         Ks_new.append(K_new); poses_new.append(pose_new); Hs.append(H)
-    return torch.stack(imgs, 0), np.stack(Ks_new, 0).astype(np.float32), np.stack(poses_new, 0).astype(np.float32), np.stack(Hs, 0)
+    return (torch.stack(imgs, 0), torch.stack(masks, 0) if with_masks else None, np.stack(Ks_new, 0).astype(np.float32),
+            np.stack(poses_new, 0).astype(np.float32), np.stack(Hs, 0))
 
 
 class Gen6DEstimator:
@@ -167,11 +269,12 @@ class Gen6DEstimator:
     def build(self, database, split_type):
         """Select, normalise and rotate the reference views and load them into the networks
         (reference estimator.py:139-171)."""
+        self.cache.clear()                                     # a new object: nothing of the previous one may survive
         center, vert = get_object_center(database), get_object_vert(database)
         ref_ids_all, _ = get_database_split(database, split_type)
         ref_ids = select_reference_img_ids_fps(database, ref_ids_all, self.cfg["ref_view_num"])
         size = self.cfg["ref_resolution"]
-        ref_imgs, ref_Ks, ref_poses, ref_Hs = normalize_reference_views(database, ref_ids, size, 0.05, self.cache)
+        ref_imgs, ref_masks, ref_Ks, ref_poses, ref_Hs = normalize_reference_views(database, ref_ids, size, 0.05, self.cache)
         angles = [-np.pi / 2, -np.pi / 4, 0, np.pi / 4, np.pi / 2]
         an = self.selector.cfg["selector_angle_num"]
         if an != 5:
@@ -190,11 +293,11 @@ class Gen6DEstimator:
             f = lambda a: torch.from_numpy(np.asarray(a, np.float32)).to(self.device)
             self.selector.extract_ref_feats(ref_imgs_rots.float().div_(255).permute(0, 1, 4, 2, 3).contiguous(),
                                             f(ref_poses), f(center), f(vert))
-        self.ref_info = {"imgs": ref_imgs.cpu().numpy(), "ref_imgs": ref_imgs_rots.cpu().numpy(), "masks": None,
+        self.ref_info = {"imgs": ref_imgs.cpu().numpy(), "ref_imgs": ref_imgs_rots.cpu().numpy(), "masks": ref_masks.cpu().numpy(),
                          "Ks": ref_Ks, "poses": ref_poses, "center": center}
         if self.refiner is not None:
-            self.refiner.load_ref_imgs(database, ref_ids_all)
             self.refiner.image_cache = self.cache
+            self.refiner.load_ref_imgs(database, ref_ids_all)
 
     def predict(self, que_img, que_K, pose_init=None):
         """que_img uint8 [H,W,3], que_K [3,3] -> pose [3,4], intermediate results (reference estimator.py:173-216)."""

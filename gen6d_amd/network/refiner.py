@@ -177,6 +177,11 @@ class VolumeRefiner(ParamBank):
 
     # ------------------------------------------------------------------ estimator API
     def load_ref_imgs(self, ref_database, ref_ids):
+        """reference refiner.py:270-272.  A new database drops whatever an own image cache held for the previous one
+        (Gen6DEstimator.build shares and clears its cache itself)."""
+        cache = getattr(self, "image_cache", None)
+        if ref_database is not self.ref_database and cache is not None and not cache.holds(ref_database):
+            cache.clear()
         self.ref_database = ref_database
         self.ref_ids = ref_ids
 
@@ -189,8 +194,9 @@ class VolumeRefiner(ParamBank):
         from .. import geometry as G
         margin, even_num = 0.05, min(128, len(self.ref_ids))
         dev = self.device_()
-        cache = getattr(self, "image_cache", None) or E.DeviceImageCache(dev)
-        self.image_cache = cache
+        cache = getattr(self, "image_cache", None)
+        if cache is None:
+            cache = self.image_cache = E.DeviceImageCache(dev)
         db = E.NormalizedDatabase(self.ref_database)
         in_pose = G.normalize_pose(np.asarray(in_pose, np.float64), db.scale, db.offset)
         center, diameter = db.object_center, db.object_diameter
@@ -203,8 +209,9 @@ class VolumeRefiner(ParamBank):
         if not torch.is_tensor(que_img):
             que_img = torch.from_numpy(np.ascontiguousarray(que_img)).to(dev)
         que_warp = ops.warp_perspective(que_img, H, size, size)
-        ref_ids = E.select_reference_img_ids_refinement(db, center, self.ref_ids, pose_warp, ref_num, ref_even, even_num)
-        ref_imgs, ref_Ks, ref_poses, _ = E.normalize_reference_views(db, ref_ids, size, margin, cache, True, pose_warp, K_warp)
+        ref_ids = E.select_reference_img_ids_refinement(db, center, self.ref_ids, pose_warp, ref_num, ref_even, even_num, cache)
+        ref_imgs, _, ref_Ks, ref_poses, _ = E.normalize_reference_views(db, ref_ids, size, margin, cache, True, pose_warp, K_warp,
+                                                                     with_masks=False)
         f = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
         with torch.no_grad():
             rot, off, scl = self._step(que_warp.float().div_(255).permute(2, 0, 1)[None].contiguous(), f(K_warp), f(pose_warp),

@@ -67,13 +67,15 @@ SERIAL = False      # True: fork_join runs its branches back to back on the curr
 
 
 def fork_join(fns, device):
-    """Run independent launch sequences concurrently: fns[0] on the current stream, the others on cached side streams
-    forked from it and joined back (capturable in a hipGraph as parallel branches).  Independent stages of the path
+    """Run independent launch sequences concurrently: fns[0] on the current stream, the others on side streams cached per
+    (device, current stream), forked from it and joined back (capturable in a hipGraph as parallel branches).  Independent stages of the path
     (detector scales, selector pyramid levels, refiner feature branches) are small grids that do not fill 256 CUs."""
     if SERIAL:
         return [fn() for fn in fns]
     main = torch.cuda.current_stream(device)
-    streams = _SIDE.setdefault(str(device), [])
+    # side streams (and with them the per-stream split-K workspaces and statistics arenas) belong to ONE launching stream:
+    # queries captured / enqueued on different lanes must never share them, or concurrent replays race on the scratch
+    streams = _SIDE.setdefault((str(device), main.cuda_stream), [])
     while len(streams) < len(fns) - 1:
         streams.append(torch.cuda.Stream(device=device))
     results = [None] * len(fns)

@@ -49,6 +49,18 @@ def max_over_ranks(value, device="cpu"):
     return float(t.item())
 
 
+def sum_over_ranks(value, device="cpu"):
+    """All-reduce(SUM) of a scalar; bench.py uses it with 1 to report how many ranks really took part."""
+    t = torch.tensor([float(value)], dtype=torch.float64, device=_coll_device(device))
+    if dist.is_initialized():
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def backend_name():
+    return dist.get_backend() if dist.is_initialized() else "none"
+
+
 def gather_rows(local_rows, n_items):
     """All-gather per-query result rows [n_local, F] into [n_items, F] in global query order (ragged shards padded)."""
     if not dist.is_initialized():

@@ -12,9 +12,13 @@ committed as tests/golden/*.npz (tests/test_oracle_golden.py).  It accepts float
 the fp64 ground truth used to grade fp32 noise.
 """
 
+import time as _time
+
 import numpy as np
 import torch
 import torch.nn.functional as F
+
+TIMERS = None      # set to a dict by bench.py's cpu_baseline leg to split out the torch.std share (seconds, accumulated)
 
 MEAN = (0.485, 0.456, 0.406)
 STD = (0.229, 0.224, 0.225)
@@ -275,7 +279,11 @@ def refiner_volume(ref_feats, que_feats, poses_in, Ks_in, ref_poses, ref_Ks, h_i
     rfn, f = ref_feats.shape[:2]
     proj = ref_Ks[0] @ ref_poses[0]                                    # rfn,3,4
     vol = interpolate_volume_feats(ref_feats, V.repeat(rfn, 1, 1), proj, h_in, w_in)
-    mean, std = vol.mean(0), vol.std(0)                                # unbiased over the refs
+    mean = vol.mean(0)
+    t0 = _time.perf_counter()
+    std = vol.std(0)                                                   # unbiased over the refs
+    if TIMERS is not None:      # torch.std over the ref axis is a pathological share of the CPU step
+        TIMERS["refiner_std"] = TIMERS.get("refiner_std", 0.0) + _time.perf_counter() - t0
     qproj = Ks_in @ poses_in
     vin = interpolate_volume_feats(que_feats, V, qproj, h_in, w_in)
     shape = (1, f, sn, sn, sn)

@@ -15,15 +15,23 @@ def build_state(state_dicts, det_refs, sel_case):
     return {"det_feats": det_feats, "sel_cache": cache, "sel_embed": embed}
 
 
-def query(state_dicts, state, ref_case, iter_poses, que_full, que_crop):
-    """One query: returns the same [1,12] row as TensorPipeline.query plus the selector logits."""
+def query(state_dicts, state, ref_case, iter_poses, que_full, que_crop, stage_s=None):
+    """One query: returns the same [1,12] row as TensorPipeline.query plus the selector logits.
+    `stage_s`: optional dict that receives the wall seconds of the detector / selector / refiner stages."""
+    import time
     with torch.no_grad():
+        t0 = time.perf_counter()
         out = O.detector_detect(state_dicts["detector"], que_full, state["det_feats"])
         pos, scl = O.detector_parse(out)
+        t1 = time.perf_counter()
         logits, angles = O.selector_forward(state_dicts["selector"], que_crop, state["sel_cache"], state["sel_embed"])
         idx, ang = O.selector_select(logits, angles)
+        t2 = time.perf_counter()
         for p in iter_poses:
             o = O.refiner_forward(state_dicts["refiner"], que_crop, ref_case["Ks_in"], p, ref_case["ref_imgs"],
                                   ref_case["ref_Ks"], ref_case["ref_poses"])
+        t3 = time.perf_counter()
+    if stage_s is not None:
+        stage_s.update(detector=t1 - t0, selector=t2 - t1, refiner=t3 - t2)
     row = torch.cat([pos, scl[:, None], idx[:, None].float(), ang[:, None], o["rotation"], o["offset"], o["scale"]], 1)
     return row, logits

@@ -41,8 +41,15 @@ def test_against_reference_functions(golden):
         object_center = c
         def get_pose(self, i): return poses[int(i)].astype(np.float32)
     ids = [str(i) for i in range(40)]
-    got = E.select_reference_img_ids_refinement(DB(), c, ids, poses[7].astype(np.float32), 6, True, 16, _cache={})
+    got = E.select_reference_img_ids_refinement(DB(), c, ids, poses[7].astype(np.float32), 6, True, 16)
     assert np.array_equal(got.astype(np.int64), g["refine_ids"])
+    cache = E.DeviceImageCache("cpu")                       # memoised FPS subset: same answer, keyed by the id list
+    db = DB()
+    for _ in range(2):
+        got = E.select_reference_img_ids_refinement(db, c, ids, poses[7].astype(np.float32), 6, True, 16, cache)
+        assert np.array_equal(got.astype(np.int64), g["refine_ids"])
+    got2 = E.select_reference_img_ids_refinement(db, c, ids[::-1], poses[7].astype(np.float32), 6, True, 16, cache)
+    assert len(cache._subsets) == 2 and set(got2) <= set(ids)   # another id list of the same length is another entry
 
 
 def test_closed_forms():
