@@ -405,6 +405,14 @@ extern "C" int g6d_nchw_to_nhwc(const float* in, int N, int C, int H, int W, int
   return g6d_check_launch("l2norm_rows");
 }
 
+extern "C" int g6d_l2norm_rows(float* x, int rows, int C, int ld, g6d_stream_t stream) {
+  if (!x || rows <= 0 || C <= 0 || (C & 3) || (ld & 3) || ld < C || !g6d_aligned16(x)) {
+    g6d_set_error("l2norm_rows: bad args (C and ld multiples of 4, 16-byte aligned)"); return G6D_EINVAL;
+  }
+  hipLaunchKernelGGL(l2norm_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, STREAM(stream), x, rows, C, ld);
+  return g6d_check_launch("l2norm_rows");
+}
+
 extern "C" int g6d_vps_norm(const float* vps, int D, float* feats, int ld, int c_off, g6d_stream_t stream) {
   if (!vps || !feats || D <= 0) { g6d_set_error("vps_norm: bad args"); return G6D_EINVAL; }
   hipLaunchKernelGGL(vps_norm_kernel, dim3(3), dim3(256), 0, STREAM(stream), vps, D, feats, ld, c_off);

@@ -56,7 +56,7 @@ G6D_HD void conv1_stage(Conv1Smem& s, int tid, const float* in, const float* w_o
 // Phase 2: thread (tx, ty, cg) computes pooled pixel (px0 + tx, py0 + ty) for the 16 channels of group cg.  A wavefront
 // holds one cg (64 pixels), so its weight reads are wave-uniform; splitting the channels over threads instead of looping
 // keeps the serial FMA chain of a thread at 1728 instead of 6912, which is what bounds the small 128x128 crops.
-G6D_HD void conv1_compute(const Conv1Smem& s, int tid, float* out, int n, int Ho, int Wo, int px0, int py0) {
+G6D_HD void conv1_compute(const Conv1Smem& s, int tid, float* out, int n, int Ho, int Wo, int px0, int py0, bool nhwc) {
   const int pix = tid % (C1_PTX * C1_PTY), cg = tid / (C1_PTX * C1_PTY);
   const int tx = pix % C1_PTX, ty = pix / C1_PTX;
   const int px = px0 + tx, py = py0 + ty;
@@ -93,7 +93,8 @@ G6D_HD void conv1_compute(const Conv1Smem& s, int tid, float* out, int n, int Ho
         const int co = cg * 16 + k;
         float m = fmaxf(fmaxf(acc[0][k], acc[1][k]), fmaxf(acc[2][k], acc[3][k])) + s.b[co];   // max(a)+b == max(a+b)
         m = fmaxf(m, 0.f);                                                                     // relu(max) == max(relu)
-        out[((size_t)(n * C1_COUT + co) * Ho + py) * Wo + px] = m;
+        if (nhwc) out[((size_t)(n * Ho + py) * Wo + px) * C1_COUT + co] = m;      // 16 consecutive channels = 64 B per thread
+        else out[((size_t)(n * C1_COUT + co) * Ho + py) * Wo + px] = m;
       }
     }
   }
@@ -106,12 +107,24 @@ namespace {
 __global__ void __launch_bounds__(C1_THREADS) vgg_conv1_pool_kernel(const float* __restrict__ in,
                                                                     const float* __restrict__ w_oihw,
                                                                     const float* __restrict__ bias, int H, int W, int Ho,
-                                                                    int Wo, float* __restrict__ out) {
+                                                                    int Wo, float* __restrict__ out, int nhwc) {
   __shared__ Conv1Smem s;
   const int px0 = blockIdx.x * C1_PTX, py0 = blockIdx.y * C1_PTY, n = blockIdx.z;
   conv1_stage(s, threadIdx.x, in, w_oihw, bias, n, H, W, px0, py0);
   __syncthreads();
-  conv1_compute(s, threadIdx.x, out, n, Ho, Wo, px0, py0);
+  conv1_compute(s, threadIdx.x, out, n, Ho, Wo, px0, py0, nhwc != 0);
+}
+
+int conv1_launch(const float* in, int N, int H, int W, const float* w_oihw, const float* bias, int Cin, int Cout, float* out,
+                 int nhwc, g6d_stream_t stream) {
+  if (!in || !w_oihw || !bias || !out || N <= 0 || N > 65535 || H < 2 || W < 2 || Cin != C1_CIN || Cout != C1_COUT ||
+      (long long)N * Cout * (H / 2) * (W / 2) >= (1ll << 31)) {
+    g6d_set_error("vgg_conv1_pool: bad args (3 -> 64 channels, H, W >= 2)"); return G6D_EINVAL;
+  }
+  const int Ho = H / 2, Wo = W / 2;
+  hipLaunchKernelGGL(vgg_conv1_pool_kernel, dim3((Wo + C1_PTX - 1) / C1_PTX, (Ho + C1_PTY - 1) / C1_PTY, N), dim3(C1_THREADS),
+                     0, reinterpret_cast<hipStream_t>(stream), in, w_oihw, bias, H, W, Ho, Wo, out, nhwc);
+  return g6d_check_launch("vgg_conv1_pool");
 }
 
 }  // namespace
@@ -119,26 +132,26 @@ __global__ void __launch_bounds__(C1_THREADS) vgg_conv1_pool_kernel(const float*
 // in [N][3][H][W], w_oihw [64][3][3][3] (BatchNorm folded), bias [64] -> out [N][64][H/2][W/2] (floor, as F.max_pool2d).
 extern "C" int g6d_vgg_conv1_pool(const float* in, int N, int H, int W, const float* w_oihw, const float* bias, int Cin,
                                   int Cout, float* out, g6d_stream_t stream) {
-  if (!in || !w_oihw || !bias || !out || N <= 0 || N > 65535 || H < 2 || W < 2 || Cin != C1_CIN || Cout != C1_COUT ||
-      (long long)N * Cout * (H / 2) * (W / 2) >= (1ll << 31)) {
-    g6d_set_error("vgg_conv1_pool: bad args (3 -> 64 channels, H, W >= 2)"); return G6D_EINVAL;
-  }
-  const int Ho = H / 2, Wo = W / 2;
-  hipLaunchKernelGGL(vgg_conv1_pool_kernel, dim3((Wo + C1_PTX - 1) / C1_PTX, (Ho + C1_PTY - 1) / C1_PTY, N), dim3(C1_THREADS),
-                     0, reinterpret_cast<hipStream_t>(stream), in, w_oihw, bias, H, W, Ho, Wo, out);
-  return g6d_check_launch("vgg_conv1_pool");
+  return conv1_launch(in, N, H, W, w_oihw, bias, Cin, Cout, out, 0, stream);
+}
+
+// Same layer with a channels-last result [N][H/2][W/2][64]: the input of g6d_wino_conv3x3 (the own trunk).
+extern "C" int g6d_vgg_conv1_pool_nhwc(const float* in, int N, int H, int W, const float* w_oihw, const float* bias, int Cin,
+                                       int Cout, float* out, g6d_stream_t stream) {
+  return conv1_launch(in, N, H, W, w_oihw, bias, Cin, Cout, out, 1, stream);
 }
 
 #else   // ---- host emulation of the two phases, thread by thread (tests only) -------------------------------------
 
-extern "C" int g6d_conv1_emulate(const float* in, int N, int H, int W, const float* w_oihw, const float* bias, float* out) {
+extern "C" int g6d_conv1_emulate(const float* in, int N, int H, int W, const float* w_oihw, const float* bias, float* out,
+                                 int nhwc) {
   const int Ho = H / 2, Wo = W / 2;
   Conv1Smem* s = new Conv1Smem;
   for (int n = 0; n < N; ++n)
     for (int by = 0; by < (Ho + C1_PTY - 1) / C1_PTY; ++by)
       for (int bx = 0; bx < (Wo + C1_PTX - 1) / C1_PTX; ++bx) {
         for (int tid = 0; tid < C1_THREADS; ++tid) conv1_stage(*s, tid, in, w_oihw, bias, n, H, W, bx * C1_PTX, by * C1_PTY);
-        for (int tid = 0; tid < C1_THREADS; ++tid) conv1_compute(*s, tid, out, n, Ho, Wo, bx * C1_PTX, by * C1_PTY);
+        for (int tid = 0; tid < C1_THREADS; ++tid) conv1_compute(*s, tid, out, n, Ho, Wo, bx * C1_PTX, by * C1_PTY, nhwc != 0);
       }
   delete s;
   return 0;

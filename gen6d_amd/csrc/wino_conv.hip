@@ -1,0 +1,274 @@
+// 3x3 stride-1 pad-1 convolution as Winograd F(2x2,3x3) on the fp32 matrix cores of gfx950 — the seven 64->128 ...
+// 512->512 layers of the VGG-11-BN trunks (reference network/pretrain_models.py:9-31,61-72, BatchNorm folded), with the
+// bias, ReLU and 2x2 max-pool of the trunk fused into the epilogue, channels-last in and out.
+//
+//   Y(2x2) = A^T [ sum_ci U_ci (.) V_ci ] A,   U = G g G^T (host, once per checkpoint),  V = B^T d B (4x4 input tile)
+//
+// i.e. 16 independent GEMMs  D_ab[tile][co] = sum_ci V_ab[tile][ci] * U_ab[ci][co]  with 2.25x fewer multiplications
+// than the direct form.  Mapping to v_mfma_f32_32x32x2_f32 (M = tiles, N = co, K = ci):
+//
+//   block  = 256 threads = 4 waves = 64 Winograd tiles (four "quarters" of 4x4 tiles = 8x8 output pixels each: a 2x2
+//            arrangement inside one image, or — for maps of <= 8x8 pixels — one quarter from each of four images) x 64
+//            output channels; wave (wm, wn) owns 32 tiles x 32 channels for ALL 16 (a,b) positions: 16 accumulator
+//            tiles = 256 accumulator registers per lane, one wave per SIMD.  Because a lane holds all 16 D_ab of its
+//            (tile, co) elements, the output transform, bias, ReLU and the 2x2 max-pool (= max over the 4 outputs of a
+//            tile) are pure per-lane register arithmetic: no LDS exchange in the epilogue.
+//   K loop = chunks of 8 input channels: the RAW 10x10 input patch of every quarter (not its 3.2x larger transform) is
+//            staged in LDS through registers (zero padding + image borders masked there); the input transform runs in
+//            registers on the fragment each lane reads (16 ds_read_b128 -> 32 vector add/sub -> 16 A fragments).  The
+//            pre-transformed filters are stored [chunk][ab][co][8], so a block's 32 KB per chunk is 16 contiguous 2 KB
+//            runs that go global -> LDS directly (global_load_lds_dwordx4, no VGPR round trip: the registers are spent on
+//            accumulators).  Two LDS stages, one barrier per chunk; per wave and chunk 64 MFMAs against 32 ds_read_b128.
+//   K trick = as in conv_igemm.hip: lane-half h reads channels 4h..4h+3 of the chunk with one ds_read_b128 per operand;
+//            MFMA s consumes channel s (lanes 0-31) and 4+s (lanes 32-63) for both operands.
+//
+// Numerics: fp32 throughout; F(2x2,3x3) has transform constants {0, +-1, +-1/2} only (same error class as the MIOpen
+// Winograd solver the trunk ran on before).
+#include "g6d_common.h"
+
+namespace {
+
+#define WQ_PIX 100                         // raw patch positions per quarter (10 x 10)
+#define WRAW_LD 12                         // floats per raw patch position in LDS (8 channels + pad: conflict-free b128 reads)
+#define WRAW_FLOATS (4 * WQ_PIX * WRAW_LD) // 4800
+#define WU_FLOATS (16 * 64 * 8)            // 8192: [ab][co][8], lane-linear image of the global layout
+#define WSTAGE (WRAW_FLOATS + WU_FLOATS)   // 12992 floats = 51968 B per stage
+
+struct WinoArgs {
+  const float* in; const float* U; const float* bias; float* out_full; float* out_pool;
+  int N, H, W, Cin, ld_in, Cout, ld_full, ld_pool, relu;
+  int QH, QW, BH, BW, four_images;
+};
+
+__device__ __forceinline__ f32x4 ldg4(const float* __restrict__ base, int elem_off) {
+  return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + ((unsigned)elem_off << 2));
+}
+
+// quarter q of this block -> image, first output row / column, validity
+__device__ __forceinline__ void quarter_of(const WinoArgs& p, int q, int& n, int& oy0, int& ox0, bool& valid) {
+  if (p.four_images) {
+    n = blockIdx.x * 4 + q; oy0 = 0; ox0 = 0; valid = n < p.N;
+  } else {
+    int b = blockIdx.x;
+    const int bx = b % p.BW; b /= p.BW;
+    const int by = b % p.BH; n = b / p.BH;
+    const int qy = 2 * by + (q >> 1), qx = 2 * bx + (q & 1);
+    oy0 = 8 * qy; ox0 = 8 * qx; valid = (qy < p.QH) & (qx < p.QW);
+  }
+}
+
+__global__ void __launch_bounds__(256, 1) wino_conv3x3_kernel(const WinoArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  const int n0 = blockIdx.y * 64;
+  const int nchunks = p.Cin >> 3;
+
+  // ---- raw patch loader: pieces idx = tid + 256*j < 800 = 4 quarters x 100 positions x 2 halves of the 8-channel chunk
+  int poff[4], lsto[4]; bool pval[4], live[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int idx = tid + 256 * j;
+    const int q = idx / 200, r = idx - q * 200, pp = r >> 1, half = r & 1;
+    const int py = pp / 10, px = pp - py * 10;
+    int n, oy0, ox0; bool qv;
+    quarter_of(p, q < 4 ? q : 0, n, oy0, ox0, qv);
+    const int iy = oy0 + py - 1, ix = ox0 + px - 1;
+    pval[j] = (idx < 800) & qv & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+    poff[j] = pval[j] ? ((n * p.H + iy) * p.W + ix) * p.ld_in + 4 * half : 0;
+    lsto[j] = (q * WQ_PIX + pp) * WRAW_LD + 4 * half;
+    live[j] = idx < 800;
+  }
+  f32x4 rp[4];
+  auto load_raw = [&](int chunk) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rp[j] = ldg4(p.in, pval[j] ? poff[j] + chunk * 8 : 0);
+  };
+  auto store_raw = [&](int st) {   // unconditional stores (a branch would serialise them behind one vmcnt(0) each); the 224
+#pragma unroll                   // idle pieces (tid >= 32 of the 4th round) go to a scratch row behind the two stages
+    for (int j = 0; j < 4; ++j)
+      *reinterpret_cast<f32x4*>(lds + (live[j] ? st * WSTAGE + lsto[j] : 2 * WSTAGE + 4 * tid)) =
+          pval[j] ? rp[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  // ---- filter tiles: wave w moves (ab, half) pairs idx = 8w .. 8w+7, 1 KB (32 co x 32 B) per instruction
+  // Direct-to-LDS copy in inline asm: with the builtin, hipcc books the copy on the LDS counter as well and then waits
+  // lgkmcnt(0) in front of every fragment use (it cannot count mixed event types), which exposes the LDS latency of the
+  // fragment requests just issued.  M0 = LDS byte address of the wave's 1 KB destination, each lane lands at +16*lane.
+  const float* ubase = p.U + (size_t)n0 * 8 + lane * 4;
+  const unsigned lds_addr0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)lds;
+  auto glds = [&](int chunk, int st, int idx) {
+    const int ab = idx >> 1, h = idx & 1;
+    const float* g = ubase + ((size_t)(chunk * 16 + ab) * p.Cout + h * 32) * 8;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr0 + 4u * (unsigned)(st * WSTAGE + WRAW_FLOATS + (ab * 64 + h * 32) * 8));
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+  };
+  auto load_u = [&](int chunk, int st) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) glds(chunk, st, wave * 8 + k);
+  };
+
+  // ---- fragment bases
+  const int tl = li & 15, ty = tl >> 2, tx = tl & 3;
+  const int abase = ((2 * wm + (li >> 4)) * WQ_PIX + (2 * ty) * 10 + 2 * tx) * WRAW_LD + 4 * lh;
+  const int bbase = WRAW_FLOATS + (wn * 32 + li) * 8 + 4 * lh;
+
+  f32x16 acc[16];
+#pragma unroll
+  for (int a = 0; a < 16; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+
+  load_u(0, 0);
+  load_raw(0);
+  store_raw(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // Software pipeline (one wave per SIMD: nothing but the wave's own instruction order hides latency).  The 16 MFMAs of
+  // the LAST (a,b) group of chunk c-1 are deferred across the barrier with their operands held in registers (vD, uD):
+  // chunk c opens with them, and every request of the chunk — the direct-to-LDS filter copies and the raw loads of
+  // chunk c+1, the 16 raw-tile reads and the first 8 filter fragments of chunk c — is issued in the shadow of those MFMAs,
+  // two to three memory instructions behind each.  Groups 0-2 then run back to back (the fragments of group g+2 are
+  // requested at the start of group g), and the chunk ends by preparing vD / uD of its own last group.
+  f32x4 vD[4], uD[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { vD[j] = f32x4{0.f, 0.f, 0.f, 0.f}; uD[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  for (int c = 0; c < nchunks; ++c) {
+    const float* S = lds + (c & 1) * WSTAGE;
+    const int cn = min(c + 1, nchunks - 1);       // the last chunk re-requests itself into the idle stage: no branches
+    f32x4 d[4][4], ub[3][4];
+    auto rd_d = [&](int i, int j) { d[i][j] = *reinterpret_cast<const f32x4*>(S + abase + (i * 10 + j) * WRAW_LD); };
+    auto rd_u = [&](int g, int j) { ub[g % 3][j] = *reinterpret_cast<const f32x4*>(S + bbase + (g * 4 + j) * 512); };
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      acc[12 + (k >> 2)] = __builtin_amdgcn_mfma_f32_32x32x2f32(vD[k >> 2][k & 3], uD[k >> 2][k & 3], acc[12 + (k >> 2)], 0, 0, 0);
+      if (k < 2) { rd_d(0, 2 * k); rd_d(0, 2 * k + 1); }
+      else if (k < 4) { rd_d(2, 2 * (k - 2)); rd_d(2, 2 * (k - 2) + 1); }
+      else if (k < 6) { rd_u(0, 2 * (k - 4)); rd_u(0, 2 * (k - 4) + 1); }
+      else if (k < 8) { rd_d(1, 2 * (k - 6)); rd_d(1, 2 * (k - 6) + 1); }
+      else if (k < 10) { rd_d(3, 2 * (k - 8)); rd_d(3, 2 * (k - 8) + 1); }
+      else if (k < 12) { rd_u(1, 2 * (k - 10)); rd_u(1, 2 * (k - 10) + 1); }
+      else {
+        const int kk = k - 12;
+        rp[kk] = ldg4(p.in, pval[kk] ? poff[kk] + cn * 8 : 0);
+        glds(cn, (c & 1) ^ 1, wave * 8 + 2 * kk);
+        glds(cn, (c & 1) ^ 1, wave * 8 + 2 * kk + 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      if (i < 2) { rd_u(i + 2, 0); rd_u(i + 2, 1); rd_u(i + 2, 2); rd_u(i + 2, 3); }
+      __builtin_amdgcn_sched_barrier(0);          // the requests stay in front of this group's MFMAs
+      f32x4 rw[4], v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) rw[j] = i == 0 ? d[0][j] - d[2][j] : i == 1 ? d[1][j] + d[2][j] : d[2][j] - d[1][j];
+      v[0] = rw[0] - rw[2];
+      v[1] = rw[1] + rw[2];
+      v[2] = rw[2] - rw[1];
+      v[3] = rw[1] - rw[3];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          acc[i * 4 + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j][s], ub[i % 3][j][s], acc[i * 4 + j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    {   // operands of the deferred group 3 of this chunk
+      f32x4 rw[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { rw[j] = d[1][j] - d[3][j]; uD[j] = ub[0][j]; }     // ub[3 % 3] holds the group-3 fragments
+      vD[0] = rw[0] - rw[2];
+      vD[1] = rw[1] + rw[2];
+      vD[2] = rw[2] - rw[1];
+      vD[3] = rw[1] - rw[3];
+    }
+    store_raw((c & 1) ^ 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the direct-to-LDS filter tiles of the next chunk have landed
+    __syncthreads();
+  }
+#pragma unroll
+  for (int k = 0; k < 16; ++k)
+    acc[12 + (k >> 2)] = __builtin_amdgcn_mfma_f32_32x32x2f32(vD[k >> 2][k & 3], uD[k >> 2][k & 3], acc[12 + (k >> 2)], 0, 0, 0);
+
+  // ---------------------------------------------------------------- epilogue: A^T D A, bias, ReLU, stores, 2x2 max-pool
+  const int co = n0 + wn * 32 + li;
+  const float bv = p.bias ? p.bias[co] : 0.f;
+  const int Hp = p.H >> 1, Wp = p.W >> 1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    // accumulator row r of the 32x32 tile = tile (r&3) + 8*(r>>2) + 4*lh of the wave's 32
+    const int q = 2 * wm + (r >> 3);
+    const int tyy = lh + 2 * ((r >> 2) & 1), txx = r & 3;
+    int n, oy0, ox0; bool qv;
+    quarter_of(p, q, n, oy0, ox0, qv);
+    float sr[2][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      sr[0][j] = acc[0 + j][r] + acc[4 + j][r] + acc[8 + j][r];
+      sr[1][j] = acc[4 + j][r] - acc[8 + j][r] - acc[12 + j][r];
+    }
+    float y[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      y[a][0] = sr[a][0] + sr[a][1] + sr[a][2] + bv;
+      y[a][1] = sr[a][1] - sr[a][2] - sr[a][3] + bv;
+      if (p.relu) { y[a][0] = fmaxf(y[a][0], 0.f); y[a][1] = fmaxf(y[a][1], 0.f); }
+    }
+    const int oy = oy0 + 2 * tyy, ox = ox0 + 2 * txx;
+    if (p.out_full && qv) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          if (oy + a < p.H && ox + b < p.W)
+            p.out_full[((size_t)(n * p.H + oy + a) * p.W + ox + b) * p.ld_full + co] = y[a][b];
+    }
+    if (p.out_pool && qv) {
+      const int py = oy >> 1, px = ox >> 1;
+      if (py < Hp && px < Wp)
+        p.out_pool[((size_t)(n * Hp + py) * Wp + px) * p.ld_pool + co] = fmaxf(fmaxf(y[0][0], y[0][1]), fmaxf(y[1][0], y[1][1]));
+    }
+  }
+}
+
+}  // namespace
+
+// in [N][H][W][ld_in] channels-last (Cin % 8 == 0), U = pre-transformed filters [Cin/8][16][Cout][8] (see
+// gen6d_amd/network/backbone.py: winograd_filters), bias [Cout] or NULL, Cout % 64 == 0.
+//   y = conv3x3(in, pad 1) + bias; if relu: y = max(y, 0)
+//   out_full (optional) [N][H][W][ld_full]   <- y
+//   out_pool (optional) [N][H/2][W/2][ld_pool] <- 2x2 max-pool of y (floor, as F.max_pool2d)
+// Replaces features[4..27] of vgg11_bn (conv + folded BatchNorm + ReLU + MaxPool), network/pretrain_models.py:17-25,66-72.
+extern "C" int g6d_wino_conv3x3(const float* in, int N, int H, int W, int Cin, int ld_in, const float* U, const float* bias,
+                                int Cout, int relu, float* out_full, int ld_full, float* out_pool, int ld_pool,
+                                g6d_stream_t stream) {
+  if (!in || !U || (!out_full && !out_pool) || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 7) || (ld_in & 3) || ld_in < Cin ||
+      Cout <= 0 || (Cout & 63) || (out_full && ld_full < Cout) || (out_pool && (ld_pool < Cout || H < 2 || W < 2)) ||
+      !g6d_aligned16(in) || !g6d_aligned16(U) || (long long)N * H * W * ld_in >= (1ll << 30)) {
+    g6d_set_error("wino_conv3x3: bad args (Cin % 8 == 0, Cout % 64 == 0, 16-byte aligned operands)"); return G6D_EINVAL;
+  }
+  WinoArgs a;
+  a.in = in; a.U = U; a.bias = bias; a.out_full = out_full; a.out_pool = out_pool;
+  a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.ld_in = ld_in; a.Cout = Cout; a.ld_full = ld_full; a.ld_pool = ld_pool; a.relu = relu;
+  a.QH = (H + 7) / 8; a.QW = (W + 7) / 8;
+  a.four_images = (a.QH == 1 && a.QW == 1) ? 1 : 0;
+  a.BH = (a.QH + 1) / 2; a.BW = (a.QW + 1) / 2;
+  const long long blocks = a.four_images ? (N + 3) / 4 : (long long)N * a.BH * a.BW;
+  if (blocks > 0x7fffffffll) { g6d_set_error("wino_conv3x3: grid too large"); return G6D_EINVAL; }
+  const size_t lds_bytes = (2 * (size_t)WSTAGE + 4 * 256) * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_conv3x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds_bytes);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(wino_conv3x3_kernel, dim3((unsigned)blocks, Cout / 64), dim3(256), lds_bytes,
+                     reinterpret_cast<hipStream_t>(stream), a);
+  return g6d_check_launch("wino_conv3x3");
+}

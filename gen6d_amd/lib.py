@@ -36,6 +36,9 @@ SIGNATURES = {
     "g6d_upsample_bilinear": [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P],
     "g6d_bias_relu_pool_nchw": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
     "g6d_vgg_conv1_pool": [_P, _I, _I, _I, _P, _P, _I, _I, _P, _P],
+    "g6d_vgg_conv1_pool_nhwc": [_P, _I, _I, _I, _P, _P, _I, _I, _P, _P],
+    "g6d_wino_conv3x3": [_P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _P, _I, _P],
+    "g6d_l2norm_rows": [_P, _I, _I, _I, _P],
     "g6d_nchw_to_nhwc": [_P, _I, _I, _I, _I, _I, _P, _I, _P],
     "g6d_selector_ref_sums": [_P, _I, _I, _I, _P, _P, _P],
     "g6d_selector_prod_affine": [_P, _P, _P, _I, _I, _I, _D, _P, _P, _P],

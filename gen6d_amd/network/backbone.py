@@ -1,7 +1,13 @@
-"""VGG-11-BN trunk on PyTorch-ROCm (MIOpen convolutions), as BASELINE.json's north_star prescribes for the backbones.
-BatchNorm (eval) is folded into the conv weights once.  Output taps follow the reference exactly, including its
-quirk that the 1/16 output is the BatchNorm output of conv 25 WITHOUT the final ReLU
-(reference network/pretrain_models.py:17-25,66-72,109-111)."""
+"""VGG-11-BN trunk.  BatchNorm (eval) is folded into the conv weights once.  Output taps follow the reference exactly,
+including its quirk that the 1/16 output is the BatchNorm output of conv 25 WITHOUT the final ReLU
+(reference network/pretrain_models.py:17-25,66-72,109-111).
+
+Two implementations of the same function:
+  * `vgg_taps_cl` (default): the own trunk — g6d_vgg_conv1_pool_nhwc for the 3->64 layer and g6d_wino_conv3x3 (Winograd
+    F(2x2,3x3) on fp32 MFMA, bias + ReLU + 2x2 max-pool fused) for the other seven, channels-last end to end, so the
+    features reach the correlation / similarity / volume kernels without any layout pass;
+  * `vgg_taps` (G6D_OWN_TRUNK=0): PyTorch-ROCm / MIOpen convolutions on NCHW, which BASELINE.json's north_star allows
+    for the backbones; kept for A/B measurements."""
 import os
 
 import torch
@@ -15,7 +21,65 @@ _OWN_CONV1 = os.environ.get("G6D_OWN_CONV1", "1") != "0"
 if os.environ.get("G6D_MIOPEN_FIND", "0") == "1":
     torch.backends.cudnn.benchmark = True        # MIOpen Find (measured solver choice) instead of the immediate-mode heuristic
 
+_OWN_TRUNK = os.environ.get("G6D_OWN_TRUNK", "1") != "0"
+
 _POOL_BEFORE = (1, 2, 4, 6)          # positions (in the list of 8 convs) preceded by a 2x2 max-pool
+
+
+def winograd_filters(w):
+    """[Cout,Cin,3,3] -> U [Cin/8,16,Cout,8] with U[c][4a+b][co][k] = (G g G^T)[a][b] of filter (co, 8c+k): the operand
+    layout of g6d_wino_conv3x3 (a block's slice of one 8-channel chunk is 16 contiguous runs)."""
+    co, ci = w.shape[:2]
+    if ci % 8 or co % 64:
+        raise ValueError("winograd_filters: Cin % 8 == 0 and Cout % 64 == 0 expected")
+    G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64, device=w.device)
+    U = torch.einsum("ai,ocij,bj->ocab", G, w.double(), G).to(w.dtype)               # [co,ci,4,4]
+    return U.reshape(co, ci // 8, 8, 16).permute(1, 3, 0, 2).contiguous()
+
+
+def pack_trunk(folded):
+    """fold_vgg(...) output -> what the active trunk implementation consumes."""
+    if not _OWN_TRUNK:
+        return folded
+    return [folded[0]] + [(winograd_filters(w), b) for w, b in folded[1:]]
+
+
+def vgg_taps_cl(packed, x, taps):
+    """Own trunk, channels-last: x [n,3,h,w] normalised image -> {'c3': [n,h/4,w/4,256] post-ReLU, 'c5': [n,h/8,w/8,512]
+    post-ReLU, 'c7_pre': [n,h/16,w/16,512] pre-ReLU, 'p7': max-pool of c7_pre} (only the requested taps + c7_pre)."""
+    w0, b0 = packed[0]
+    x = ops.vgg_conv1_pool_nhwc(x.contiguous(), w0, b0)                         # conv0 + ReLU + pool
+    _, x = ops.wino_conv3x3(x, *packed[1], relu=True, full=False, pool=True)    # conv1 + ReLU + pool
+    x, _ = ops.wino_conv3x3(x, *packed[2], relu=True)                           # conv2
+    c3, x = ops.wino_conv3x3(x, *packed[3], relu=True, full="c3" in taps, pool=True)
+    x, _ = ops.wino_conv3x3(x, *packed[4], relu=True)
+    c5, x = ops.wino_conv3x3(x, *packed[5], relu=True, full="c5" in taps, pool=True)
+    x, _ = ops.wino_conv3x3(x, *packed[6], relu=True)
+    c7, p7 = ops.wino_conv3x3(x, *packed[7], relu=False, full=True, pool="p7" in taps)   # BN output WITHOUT the last ReLU
+    out = {"c3": c3, "c5": c5, "c7_pre": c7, "p7": p7}
+    return {k: v for k, v in out.items() if v is not None and (k in taps or k == "c7_pre")}
+
+
+def trunk_features(packed, imgs, keys, l2norm):
+    """Normalised images [n,3,h,w] in [0,1] -> channels-last 5-D feature maps [n,1,h_l,w_l,C] for `keys`, optionally
+    L2-normalised over C (F.normalize, reference selector.py:118 / refiner.py:69-71)."""
+    x = img_norm(imgs)
+    if _OWN_TRUNK:
+        t = vgg_taps_cl(packed, x, set(keys))
+        outs = []
+        for k in keys:
+            f = t[k]
+            if l2norm:
+                ops.l2norm_rows(f)                  # in place: a tap is never the input of a later layer
+            outs.append(f.unsqueeze(1))
+        return outs
+    t = vgg_taps(packed, x, set(keys))
+    outs = []
+    for k in keys:
+        f = t[k].contiguous()
+        n, c, h, w = f.shape
+        outs.append(ops.nchw_to_nhwc(f, torch.empty((n, 1, h, w, c), dtype=torch.float32, device=f.device), l2norm))
+    return outs
 
 
 _NORM = {}

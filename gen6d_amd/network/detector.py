@@ -16,7 +16,7 @@ import torch
 import torch.nn.functional as F
 
 from .. import ops, parallel, specs
-from .backbone import img_norm, vgg_taps
+from .backbone import pack_trunk, trunk_features
 from .params import ParamBank, fold_vgg
 
 
@@ -48,7 +48,7 @@ class Detector(ParamBank):
     # ------------------------------------------------------------------ weights
     def _pack(self):
         if self._packed is None:
-            pk = {"vgg": fold_vgg(self, "backbone.features")}
+            pk = {"vgg": pack_trunk(fold_vgg(self, "backbone.features"))}
             w0, b0 = self.conv_w("score_conv.0")
             w1, b1 = self.conv_w("score_conv.2")
             pk["mlp"] = (w0.reshape(64, 12).contiguous(), b0, w1.reshape(64, 64).contiguous(), b1)
@@ -63,14 +63,7 @@ class Detector(ParamBank):
     # ------------------------------------------------------------------ trunk
     def extract_feats(self, imgs):
         """imgs [n,3,h,w] in [0,1] -> channels-last x0,x1,x2: [n,1,h/8,w/8,512], [.. /16 ..], [.. /32 ..]."""
-        t = vgg_taps(self._pack()["vgg"], img_norm(imgs), {"c5", "c7_pre", "p7"})
-        outs = []
-        for key in ("c5", "c7_pre", "p7"):
-            x = t[key].contiguous()
-            n, c, h, w = x.shape
-            o = torch.empty((n, 1, h, w, c), dtype=torch.float32, device=x.device)
-            outs.append(ops.nchw_to_nhwc(x, o, False))
-        return outs
+        return trunk_features(self._pack()["vgg"], imgs, ("c5", "c7_pre", "p7"), False)
 
     def load_impl(self, ref_imgs):
         """ref_imgs [rfn,3,h,w] in [0,1]; nearest resize to 120x120, trunk, keep as correlation filters

@@ -13,7 +13,7 @@ import torch
 import torch.nn.functional as F
 
 from .. import ops, specs
-from .backbone import img_norm, vgg_taps
+from .backbone import pack_trunk, trunk_features
 from .operator import pose_apply_th
 from .params import ParamBank, fold_vgg
 
@@ -33,7 +33,7 @@ class VolumeRefiner(ParamBank):
     # ------------------------------------------------------------------ weights
     def _pack(self):
         if self._packed is None:
-            pk = {"vgg": fold_vgg(self, "feature_net.backbone.features")}
+            pk = {"vgg": pack_trunk(fold_vgg(self, "feature_net.backbone.features"))}
             for name in ("conv0", "conv1", "conv2", "conv_out"):
                 pk[name] = [self.conv_w(f"feature_net.{name}.{i}") for i in (0, 3)]
             for name in ("mean_embed", "var_embed", "conv5"):
@@ -57,12 +57,7 @@ class VolumeRefiner(ParamBank):
         pk = self._pack()
         n, _, h, w = imgs.shape
         dev = imgs.device
-        t = vgg_taps(pk["vgg"], img_norm(imgs), {"c3", "c5", "c7_pre"})
-
-        def nhwc(x):
-            x = x.contiguous()
-            o = torch.empty((x.shape[0], 1, x.shape[2], x.shape[3], x.shape[1]), dtype=torch.float32, device=dev)
-            return ops.nchw_to_nhwc(x, o, True)
+        f3, f5, f7 = trunk_features(pk["vgg"], imgs, ("c3", "c5", "c7_pre"), True)      # channels-last, L2-normalised
 
         def pair(name, x):
             """conv, IN, ReLU, conv, (IN returned as affine) — per-image statistics."""
@@ -82,15 +77,15 @@ class VolumeRefiner(ParamBank):
         hq, wq = h // 4, w // 4
         cat = torch.empty((n, 1, hq, wq, 192), dtype=torch.float32, device=dev)
         def b0():
-            y, sc, sh = pair("conv0", nhwc(t["c3"]))
+            y, sc, sh = pair("conv0", f3)
             ops.affine_act_pool(y, cat[..., 0:64], sc, sh, per_n=True)
 
         def b1():
-            y, sc, sh = pair("conv1", nhwc(t["c5"]))
+            y, sc, sh = pair("conv1", f5)
             ops.upsample_bilinear(y, cat[..., 64:128], 2, sc, sh, per_n=True)
 
         def b2():
-            y, sc, sh = pair("conv2", nhwc(t["c7_pre"]))
+            y, sc, sh = pair("conv2", f7)
             ops.upsample_bilinear(y, cat[..., 128:192], 4, sc, sh, per_n=True)
 
         ops.fork_join([b0, b1, b2], dev)

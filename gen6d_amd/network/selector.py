@@ -24,7 +24,7 @@ import torch
 import torch.nn.functional as F
 
 from .. import ops, parallel, specs
-from .backbone import img_norm, vgg_taps
+from .backbone import pack_trunk, trunk_features
 from .params import ParamBank, fold_vgg
 
 # per level: (conv index in corr_conv_list[l], InstanceNorm after?, ReLU after?, MaxPool after?)  selector.py:27-69
@@ -76,7 +76,7 @@ class ViewpointSelector(ParamBank):
     def _pack(self):
         if self._packed is None:
             an = self.cfg["selector_angle_num"]
-            pk = {"vgg": fold_vgg(self, "backbone.features")}
+            pk = {"vgg": pack_trunk(fold_vgg(self, "backbone.features"))}
             pk["corr"] = [[self.conv_w(f"corr_conv_list.{l}.{i}") for i, *_ in layers] for l, layers in enumerate(_CORR)]
             pk["fuse0"] = self.conv_w("corr_feats_conv.0")
             pk["fuse3"] = self.conv_w("corr_feats_conv.3")
@@ -106,13 +106,7 @@ class ViewpointSelector(ParamBank):
     # ------------------------------------------------------------------ features
     def get_feats(self, imgs):
         """imgs [n,3,h,w] in [0,1] -> 3 channels-last, L2-normalised maps [n,1,h_l,w_l,512] (selector.py:113-119)."""
-        t = vgg_taps(self._pack()["vgg"], img_norm(imgs), {"c5", "c7_pre", "p7"})
-        outs = []
-        for key in ("c5", "c7_pre", "p7"):
-            x = t[key].contiguous()
-            n, c, h, w = x.shape
-            outs.append(ops.nchw_to_nhwc(x, torch.empty((n, 1, h, w, c), dtype=torch.float32, device=x.device), True))
-        return outs
+        return trunk_features(self._pack()["vgg"], imgs, ("c5", "c7_pre", "p7"), True)
 
     def extract_ref_feats(self, ref_imgs, ref_poses, object_center, object_vert, is_train=False):
         """ref_imgs [an,rfn,3,h,w]; builds the reference cache, its R1/R2 sums and the viewpoint embedding

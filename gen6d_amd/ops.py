@@ -259,6 +259,59 @@ def vgg_conv1_pool(x, w_oihw, bias):
     return out
 
 
+def vgg_conv1_pool_nhwc(x, w_oihw, bias):
+    """As vgg_conv1_pool with a channels-last result [N,H//2,W//2,64] (the input layout of wino_conv3x3)."""
+    _need_gpu(x, w_oihw, bias)
+    if x.dtype != torch.float32 or x.dim() != 4 or not x.is_contiguous() or not w_oihw.is_contiguous():
+        raise ValueError("vgg_conv1_pool_nhwc: x and w must be contiguous float32 NCHW / OIHW")
+    N, Cin, H, W = x.shape
+    Cout = w_oihw.shape[0]
+    if tuple(w_oihw.shape) != (Cout, Cin, 3, 3) or bias.numel() != Cout:
+        raise ValueError("vgg_conv1_pool_nhwc: weight / bias shape mismatch")
+    out = torch.empty((N, H // 2, W // 2, Cout), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().g6d_vgg_conv1_pool_nhwc(_ptr(x), N, H, W, _ptr(w_oihw), _ptr(bias), Cin, Cout, _ptr(out), _stream()),
+               "g6d_vgg_conv1_pool_nhwc")
+    return out
+
+
+def wino_conv3x3(x, U, bias, relu=True, full=True, pool=False):
+    """Trunk layer on the Winograd/MFMA kernel.  x [N,H,W,Cin] channels-last (last stride 1, dense rows of ld = x.stride(2)),
+    U [Cin/8,16,Cout,8] (backbone.winograd_filters), bias [Cout] -> (y [N,H,W,Cout] or None, maxpool2x2(y) or None)."""
+    _need_gpu(x, U, bias)
+    if x.dim() != 4 or x.dtype != torch.float32 or x.stride(3) != 1:
+        raise ValueError("wino_conv3x3: x must be a float32 channels-last [N,H,W,C] view")
+    N, H, W, Cin = x.shape
+    ld_in = x.stride(2)
+    if (N > 1 and x.stride(0) != H * W * ld_in) or (H > 1 and x.stride(1) != W * ld_in):
+        raise ValueError("wino_conv3x3: x rows must be dense")
+    Cout = U.shape[2]
+    if tuple(U.shape) != (Cin // 8, 16, Cout, 8) or not U.is_contiguous() or bias.numel() != Cout:
+        raise ValueError(f"wino_conv3x3: U must be contiguous {(Cin // 8, 16, Cout, 8)}")
+    y = torch.empty((N, H, W, Cout), dtype=torch.float32, device=x.device) if full else None
+    yp = torch.empty((N, H // 2, W // 2, Cout), dtype=torch.float32, device=x.device) if pool else None
+    flops = 2.0 * N * H * W * Cout * 9 * Cin
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.check(_lib.load().g6d_wino_conv3x3(_ptr(x), N, H, W, Cin, ld_in, _ptr(U), _ptr(bias), Cout, int(relu), _ptr(y), Cout,
+                                           _ptr(yp), Cout, _stream()), "g6d_wino_conv3x3")
+    if PROFILE is not None:
+        e1.record()
+        # direct-form FLOPs / 2.25 = multiplications actually executed in the Winograd domain (what the matrix cores do)
+        PROFILE.append((flops / 2.25, e0, e1, f"wino3x3 N={N} in={H}x{W}x{Cin} out={Cout}{' full' if full else ''}{' pool' if pool else ''}"))
+    return y, yp
+
+
+def l2norm_rows(x):
+    """In-place F.normalize over the last axis of a channels-last tensor whose rows are dense (ld = C)."""
+    _need_gpu(x)
+    if x.dtype != torch.float32 or not x.is_contiguous():
+        raise ValueError("l2norm_rows: contiguous float32 expected")
+    Cc = x.shape[-1]
+    _lib.check(_lib.load().g6d_l2norm_rows(_ptr(x), x.numel() // Cc, Cc, Cc, _stream()), "g6d_l2norm_rows")
+    return x
+
+
 def nchw_to_nhwc(x, out, l2norm):
     """x [N,C,H,W] contiguous -> out [N,1,H,W,C] view, optionally L2-normalised over C."""
     _need_gpu(x, out)

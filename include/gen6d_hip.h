@@ -118,6 +118,25 @@ int g6d_bias_relu_pool_nchw(const float* in, const float* bias, int N, int C, in
 int g6d_vgg_conv1_pool(const float* in, int N, int H, int W, const float* w_oihw, const float* bias, int Cin, int Cout,
                        float* out, g6d_stream_t stream);
 
+/* The same layer with a channels-last result [N][H/2][W/2][64] (input of g6d_wino_conv3x3). */
+int g6d_vgg_conv1_pool_nhwc(const float* in, int N, int H, int W, const float* w_oihw, const float* bias, int Cin, int Cout,
+                            float* out, g6d_stream_t stream);
+
+/* The 3x3 layers 64->128 ... 512->512 of the VGG-11-BN trunks (reference network/pretrain_models.py:9-31,61-72:
+ * vgg11_bn features[4..28], BatchNorm folded) as Winograd F(2x2,3x3) on fp32 MFMA with the trunk's bias, ReLU and 2x2
+ * max-pool fused into the epilogue; channels-last in and out.
+ *   in   [N][H][W][ld_in], Cin % 8 == 0;  U = filters transformed on the host, [Cin/8][16][Cout][8] with
+ *        U[c][4a+b][co][k] = (G g G^T)[a][b] of filter (co, 8c+k), G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+ *   y = conv3x3_pad1(in) + bias[co];  relu != 0: y = max(y, 0)
+ *   out_full (optional) [N][H][W][ld_full] = y;  out_pool (optional) [N][H/2][W/2][ld_pool] = maxpool2x2(y) (floor)
+ * Replaces the MIOpen convolutions of the trunk and the bias/ReLU/pool and layout passes around them. */
+int g6d_wino_conv3x3(const float* in, int N, int H, int W, int Cin, int ld_in, const float* U, const float* bias, int Cout,
+                     int relu, float* out_full, int ld_full, float* out_pool, int ld_pool, g6d_stream_t stream);
+
+/* In-place L2 normalisation over C of channels-last rows x[rows][ld] (F.normalize eps 1e-12, network/selector.py:118,
+ * network/refiner.py:69-71). */
+int g6d_l2norm_rows(float* x, int rows, int C, int ld, g6d_stream_t stream);
+
 /* NCHW (backbone output) -> channels-last, optionally L2-normalised over C (F.normalize eps 1e-12,
  * network/selector.py:118, network/refiner.py:69-71). out [N][H][W][ld_out]. */
 int g6d_nchw_to_nhwc(const float* in, int N, int C, int H, int W, int l2norm, float* out, int ld_out, g6d_stream_t stream);

@@ -104,6 +104,37 @@ def vgg_conv1_pool(x, w_oihw, bias):
     return F.max_pool2d(F.relu(F.conv2d(x, w_oihw, bias, padding=1)), 2, 2)
 
 
+def vgg_conv1_pool_nhwc(x, w_oihw, bias):
+    return vgg_conv1_pool(x, w_oihw, bias).permute(0, 2, 3, 1).contiguous()
+
+
+def wino_conv3x3(x, U, bias, relu=True, full=True, pool=False):
+    """The Winograd F(2x2,3x3) algorithm itself (not F.conv2d), from the TRANSFORMED filters the kernel receives: checks
+    the host-side filter transform / layout (backbone.winograd_filters) together with the algebra the kernel implements."""
+    N, H, W, Cin = x.shape
+    Cout = U.shape[2]
+    dt = x.dtype
+    BT = torch.tensor([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=dt)
+    AT = torch.tensor([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=dt)
+    Ht, Wt = (H + 1) // 2, (W + 1) // 2
+    xp = F.pad(x, (0, 0, 1, 2 * Wt + 1 - W, 1, 2 * Ht + 1 - H))                       # [N, 2Ht+2, 2Wt+2, C]
+    d = xp.unfold(1, 4, 2).unfold(2, 4, 2)                                             # [N,Ht,Wt,C,4,4]
+    V = torch.einsum("ai,ntucij,bj->ntuabc", BT, d, BT)
+    U4 = U.permute(1, 2, 0, 3).reshape(4, 4, Cout, Cin).to(dt)
+    M = torch.einsum("ntuabc,aboc->ntuabo", V, U4)
+    Y = torch.einsum("pa,ntuabo,qb->ntupqo", AT, M, AT)                               # [N,Ht,Wt,2,2,Cout]
+    y = Y.permute(0, 1, 3, 2, 4, 5).reshape(N, 2 * Ht, 2 * Wt, Cout)[:, :H, :W] + bias.to(dt)
+    if relu:
+        y = F.relu(y)
+    yp = F.max_pool2d(y.permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1).contiguous() if pool else None
+    return (y.contiguous() if full else None), yp
+
+
+def l2norm_rows(x):
+    x.copy_(F.normalize(x, dim=-1))
+    return x
+
+
 def nchw_to_nhwc(x, out, l2norm):
     v = F.normalize(x, dim=1) if l2norm else x
     out.copy_(v.permute(0, 2, 3, 1).unsqueeze(1))

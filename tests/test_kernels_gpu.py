@@ -349,3 +349,97 @@ def test_conv_warp_specialised_variant():
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k", "test_conv_igemm"],
                          env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+# ---------------------------------------------------------------------------------------------------- own VGG trunk
+WINO_CASES = [
+    # N, H, W, Cin, Cout, relu, full, pool
+    (1, 16, 16, 64, 128, True, True, True),        # one block, all four quarters full
+    (1, 15, 15, 512, 512, True, True, False),      # odd map (detector reference features), quarters partly masked
+    (5, 7, 7, 512, 512, False, True, True),        # <= 8x8 maps: four images per block, N % 4 != 0, c7_pre / p7 (no ReLU)
+    (7, 8, 8, 512, 512, True, True, False),        # refiner 1/16 level
+    (2, 44, 58, 256, 256, True, True, True),       # tap + pooled output, blocks with masked quarters (58 = 7.25 quarters)
+    (1, 30, 40, 128, 256, True, False, True),      # pooled output only
+    (1, 64, 64, 64, 128, True, False, True),       # first Winograd layer of a 128x128 crop
+    (3, 10, 18, 8, 64, True, True, True),          # smallest channel counts the kernel accepts
+]
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,relu,full,pool", WINO_CASES)
+def test_wino_conv3x3(ops, N, H, W, Cin, Cout, relu, full, pool):
+    """g6d_wino_conv3x3 against F.conv2d (+bias, ReLU, max-pool) in float64: fp32 Winograd F(2x2,3x3) error class."""
+    import torch.nn.functional as F
+    from gen6d_amd.network.backbone import winograd_filters
+    g = torch.Generator().manual_seed(1000 + H * W + Cin)
+    x = _rand(g, N, H, W, Cin)
+    w = _rand(g, Cout, Cin, 3, 3, scale=(2.0 / (9 * Cin)) ** 0.5 * 1.7)
+    b = _rand(g, Cout, scale=0.3)
+    y, yp = ops.wino_conv3x3(x.cuda(), winograd_filters(w).cuda(), b.cuda(), relu=relu, full=full, pool=pool)
+    ref = F.conv2d(x.double().permute(0, 3, 1, 2), w.double(), b.double(), padding=1)
+    if relu:
+        ref = F.relu(ref)
+    assert (y is not None) == full and (yp is not None) == pool
+    if full:
+        _check(y.permute(0, 3, 1, 2), ref, 3e-5, "wino full")
+    if pool:
+        assert yp.shape == (N, H // 2, W // 2, Cout)
+        _check(yp.permute(0, 3, 1, 2), F.max_pool2d(ref, 2, 2), 3e-5, "wino pool")
+
+
+def test_wino_conv3x3_channel_slice_input(ops):
+    """Input given as a channel slice of a wider channels-last buffer (ld_in > Cin)."""
+    import torch.nn.functional as F
+    from gen6d_amd.network.backbone import winograd_filters
+    g = torch.Generator().manual_seed(77)
+    wide = _rand(g, 2, 12, 12, 96)
+    w = _rand(g, 64, 64, 3, 3, scale=0.06)
+    b = _rand(g, 64, scale=0.3)
+    xs = wide.cuda()[..., 16:80]
+    y, _ = ops.wino_conv3x3(xs, winograd_filters(w).cuda(), b.cuda(), relu=False)
+    ref = F.conv2d(wide[..., 16:80].double().permute(0, 3, 1, 2), w.double(), b.double(), padding=1)
+    _check(y.permute(0, 3, 1, 2), ref, 3e-5, "wino slice")
+
+
+def test_wino_rejects_bad_args(ops):
+    x = torch.zeros((1, 8, 8, 12), device="cuda")
+    with pytest.raises((RuntimeError, ValueError)):
+        ops.wino_conv3x3(x, torch.zeros((1, 16, 64, 8), device="cuda"), torch.zeros(64, device="cuda"))
+
+
+@pytest.mark.parametrize("N,H,W", [(1, 128, 128), (2, 50, 70), (1, 33, 67)])
+def test_vgg_conv1_pool_nhwc(ops, N, H, W):
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(5)
+    x, w, b = _rand(g, N, 3, H, W), _rand(g, 64, 3, 3, 3, scale=0.3), _rand(g, 64, scale=0.2)
+    out = ops.vgg_conv1_pool_nhwc(x.cuda(), w.cuda(), b.cuda())
+    ref = F.max_pool2d(F.relu(F.conv2d(x.double(), w.double(), b.double(), padding=1)), 2, 2)
+    assert out.shape == (N, H // 2, W // 2, 64)
+    _check(out.permute(0, 3, 1, 2), ref, 1e-5, "conv1 nhwc")
+
+
+def test_l2norm_rows(ops):
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(6)
+    x = _rand(g, 3, 5, 7, 512)
+    x[0, 0, 0] = 0.0                                   # zero row: eps branch of F.normalize
+    got = ops.l2norm_rows(x.cuda().clone())
+    _check(got, F.normalize(x.double(), dim=-1), 1e-6, "l2norm_rows")
+
+
+def test_own_trunk_matches_library_trunk(ops):
+    """The two trunk implementations (own channels-last Winograd vs MIOpen NCHW) produce the same taps."""
+    from gen6d_amd import synth
+    from gen6d_amd.network import backbone as B
+    from gen6d_amd.network.params import fold_vgg
+    from gen6d_amd.network import name2network
+    net = name2network["detector"]({"name": "t"}).eval()
+    net.load_state_dict(synth.synth_state_dict("detector"))
+    net = net.cuda()
+    folded = fold_vgg(net, "backbone.features")
+    img = synth.imgs_to_tensor(synth.synth_images(2, 96, 160, 9)).cuda()
+    with torch.no_grad():
+        x = B.img_norm(img)
+        lib_t = B.vgg_taps(folded, x, {"c3", "c5", "c7_pre", "p7"})
+        own_t = B.vgg_taps_cl([folded[0]] + [(B.winograd_filters(w), b) for w, b in folded[1:]], x, {"c3", "c5", "c7_pre", "p7"})
+    for k in ("c3", "c5", "c7_pre", "p7"):
+        _check(own_t[k].permute(0, 3, 1, 2), lib_t[k].double().cpu(), 5e-5, k)
