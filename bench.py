@@ -84,6 +84,9 @@ def main():
     ap.add_argument("--sel-refs", type=int, default=64)
     ap.add_argument("--det-refs", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lowp", default="bf16,fp16",
+                    help="comma list of reduced-precision matrix-core modes measured AFTER the fp32 headline (same launch mode, "
+                         "same steps) and reported in the `lowp` object: operands bf16 / fp16, fp32 accumulate; '' = skip")
     ap.add_argument("--cpu-reps", type=int, default=3, help="timed CPU-oracle runs after one warm-up (min is reported)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="cap on torch CPU threads for the baseline (0 = physical cores)")
     ap.add_argument("--no-graph", action="store_true", help="time the eager launch path instead of hipGraph replay")
@@ -244,6 +247,38 @@ def main():
     result["stages_ms"] = stages
     result["ranks_seen"], result["backend"] = ranks_seen, parallel.backend_name()
     got_rows = rows.cpu()
+    gpath = os.path.join(ROOT, "tests", "golden", "pipeline_rows.npz")
+
+    # ---- reduced-precision speed modes (BASELINE configs[2] "bf16", configs[4] "fp16 MFMA convs"): separately graded, never
+    #      the headline.  Same pipeline, same launch mode, matrix-core operands rounded to bf16 / fp16 in the conv / correlation
+    #      kernels (fp32 accumulation, fp32 InstanceNorm statistics, fp32 trunk).
+    lowp = {}
+    for mode in [m for m in args.lowp.split(",") if m] if (use_graph and world == 1) else []:
+        with ops.math_mode(mode):
+            pipe.capture(lanes=lanes)
+        lane_busy[:] = [None] * lanes
+        for i in range(args.warmup):
+            step(i)
+        drain(); torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        lrows = [step(args.warmup + i) for i in range(args.steps)]
+        drain(); torch.cuda.synchronize()
+        ldt = time.perf_counter() - t1
+        lrows = torch.cat(lrows, 0).cpu()
+        entry = {"dtype": mode, "value": args.steps / ldt, "unit": "images/s", "ms_per_step": ldt / args.steps * 1e3}
+        if (args.sel_refs, args.det_refs) == (64, 32) and os.path.exists(gpath):
+            import numpy as np
+            gold = torch.from_numpy(np.load(gpath)["rows"]).float()
+            ref = torch.stack([gold[(args.warmup + i) % 4] for i in range(args.steps)])
+            d = (lrows - ref).abs()
+            entry["parity_vs_reference"] = {
+                "ref_idx_equal": bool((lrows[:, 3].long() == ref[:, 3].long()).all()),
+                "detection_cell_px": float(d[:, 0:2].max()), "max_abs_diff_row": float(d.max()),
+                "max_rel_diff_row": float((d / ref.abs().clamp(min=1.0)).max()),
+                "vs_fp32_path_max_rel": float(((lrows - got_rows[:args.steps]).abs() / got_rows[:args.steps].abs().clamp(min=1.0)).max())}
+        lowp[mode] = entry
+    if lowp:
+        result["lowp"] = lowp
 
     def row_diff(got, ref):
         """Row layout: position(2, px), scale, ref_idx, angle, quaternion(4), offset(2), log2-scale."""
@@ -254,7 +289,6 @@ def main():
     # parity of EVERY timed row (graph replay, `lanes` queries in flight) against the reference's own modules: the rows of
     # the four synthetic queries were produced from /root/reference by tests/golden/make_golden_r02.py (pipeline_rows.npz)
     default_cfg = (args.sel_refs, args.det_refs) == (64, 32) and not shard_refs
-    gpath = os.path.join(ROOT, "tests", "golden", "pipeline_rows.npz")
     if default_cfg and os.path.exists(gpath):
         import numpy as np
         gold = torch.from_numpy(np.load(gpath)["rows"]).float()

@@ -45,7 +45,8 @@ __device__ __forceinline__ f32x4 ldg(const float* __restrict__ base, int elem_of
 
 // MODE: 0 = plain operand, 1 = affine(+ReLU) with one table, 2 = affine(+ReLU) with a table per batch index n,
 //       3 = elementwise multiplier + affine (selector product).
-template <int BM, int BN, int WGM, int WGN, int MODE>
+// MM: 0 = fp32 MFMA (default); 1 / 2 = bf16 / fp16 operands, fp32 accumulation (G6dConv.math_mode, g6d_common.h).
+template <int BM, int BN, int WGM, int WGN, int MODE, int MM>
 __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const G6dConv p, const int M, const int T,
                                                          const int nChunks, const int itersPerSplit,
                                                          const int totalIters, const int splits) {
@@ -201,6 +202,38 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const G6dConv p, con
     constexpr int par = decltype(PAR)::value;
     using SL = std::integral_constant<int, par>;
     using SS = std::integral_constant<int, par ^ 1>;
+    if constexpr (MM != 0) {
+      // reduced precision: a K step is 2 * MT * NT MFMAs of K = 16 (two 8-channel fragment slices each); the step is bound by
+      // the loads, so they are simply issued first, the stores last
+#pragma unroll
+      for (int j = 0; j < RA; ++j) load_a(SL{}, j);
+#pragma unroll
+      for (int j = 0; j < RB; ++j) load_b(SL{}, j);
+#pragma unroll
+      for (int kp = 0; kp < 2; ++kp) {
+        f32x4 a0[MT], a1[MT], b0[NT], b1[NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          a0[i] = *reinterpret_cast<const f32x4*>(As + (wm * WM + i * 32 + li) * LDS_K + (2 * kp) * 8 + 4 * lh);
+          a1[i] = *reinterpret_cast<const f32x4*>(As + (wm * WM + i * 32 + li) * LDS_K + (2 * kp + 1) * 8 + 4 * lh);
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          b0[j] = *reinterpret_cast<const f32x4*>(Bs + (wn * WN + j * 32 + li) * LDS_K + (2 * kp) * 8 + 4 * lh);
+          b1[j] = *reinterpret_cast<const f32x4*>(Bs + (wn * WN + j * 32 + li) * LDS_K + (2 * kp + 1) * 8 + 4 * lh);
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = g6d_mfma_lowp<MM>(a0[i], a1[i], b0[j], b1[j], acc[i][j]);
+      }
+#pragma unroll
+      for (int j = 0; j < RA; ++j) store_a(SS{}, An, j);
+#pragma unroll
+      for (int j = 0; j < RB; ++j) store_b(SS{}, Bn, j);
+      advance(); begin_step(SS{});
+      return;
+    }
     read_frags(As, Bs, 0);
 #pragma unroll
     for (int pc = 0; pc < NP; ++pc) {
@@ -453,8 +486,8 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
   }
 }
 
-template <int BM, int BN, int WGM, int WGN, int MODE>
-int launch_mode(const G6dConv& d, int M, int T, int nChunks, int splits, hipStream_t stream) {
+template <int BM, int BN, int WGM, int WGN, int MODE, int MM>
+int launch_mm(const G6dConv& d, int M, int T, int nChunks, int splits, hipStream_t stream) {
   const int total = T * nChunks;
   const int ips = (total + splits - 1) / splits;
   splits = (total + ips - 1) / ips;
@@ -462,11 +495,11 @@ int launch_mode(const G6dConv& d, int M, int T, int nChunks, int splits, hipStre
   const size_t lds_bytes = 2 * (size_t)(BM + BN) * LDS_K * sizeof(float);
   static bool attr_done = false;   // per template instantiation
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WGM, WGN, MODE>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WGM, WGN, MODE, MM>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, MODE>), grid, dim3(256), lds_bytes, stream, d, M, T, nChunks,
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, MODE, MM>), grid, dim3(256), lds_bytes, stream, d, M, T, nChunks,
                      ips, total, splits);
   int rc = g6d_check_launch("conv_igemm");
   if (rc != G6D_OK) return rc;
@@ -474,6 +507,13 @@ int launch_mode(const G6dConv& d, int M, int T, int nChunks, int splits, hipStre
     rc = g6d_splitk_reduce_launch(d.workspace, splits, M, d.Cout, d.bias, d.out_act, d.out, d.ld_out, d.stats,
                                   d.stat_rows_per_group, stream);
   return rc;
+}
+
+template <int BM, int BN, int WGM, int WGN, int MODE>
+int launch_mode(const G6dConv& d, int M, int T, int nChunks, int splits, hipStream_t stream) {
+  if (d.math_mode == 1) return launch_mm<BM, BN, WGM, WGN, MODE, 1>(d, M, T, nChunks, splits, stream);
+  if (d.math_mode == 2) return launch_mm<BM, BN, WGM, WGN, MODE, 2>(d, M, T, nChunks, splits, stream);
+  return launch_mm<BM, BN, WGM, WGN, MODE, 0>(d, M, T, nChunks, splits, stream);
 }
 
 template <int BM, int BN, int WGM, int WGN>
@@ -506,6 +546,7 @@ extern "C" int g6d_conv_igemm(const G6dConv* desc, g6d_stream_t stream_) {
   const G6dConv& d = *desc;
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (!d.in || !d.weight || !d.out) { g6d_set_error("conv: null pointer"); return G6D_EINVAL; }
+  if (d.math_mode < 0 || d.math_mode > 2) { g6d_set_error("conv: math_mode must be 0 (fp32), 1 (bf16) or 2 (fp16)"); return G6D_EINVAL; }
   if (d.N <= 0 || d.Cin <= 0 || d.Cout <= 0 || d.Do <= 0 || d.Ho <= 0 || d.Wo <= 0 || d.kd <= 0 || d.kh <= 0 || d.kw <= 0) {
     g6d_set_error("conv: bad shape"); return G6D_EINVAL;
   }

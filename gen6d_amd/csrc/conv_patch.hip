@@ -11,6 +11,8 @@
 // Same fragment scheme (K-permuted ds_read_b128 + v_mfma_f32_32x32x2_f32), accumulator layout and epilogue (bias,
 // activation, channel-slice store, fp64 InstanceNorm statistics, split-K partials) as conv_igemm.hip.
 #include "g6d_common.h"
+#include <stdlib.h>
+#include <type_traits>
 
 #define LDS_K 36
 #define BN 64
@@ -34,7 +36,9 @@ template <> struct TileGeo<1> { static constexpr int TN = 1, TD = 2, TH = 8, TW 
 template <> struct TileGeo<2> { static constexpr int TN = 2, TD = 1, TH = 8, TW = 8, KD = 1; };
 
 // MODE: 0 plain, 1 affine(+ReLU), 3 mul + affine.
-template <int KIND, int MODE>
+// VAR: 0 = fp32 MFMA, software-pipelined tap loop (default); 1 = fp32, plain tap loop (G6D_PATCH_PIPE=0, A/B measurements);
+//      2 / 3 = bf16 / fp16 operands (G6dConv.math_mode 1 / 2), plain tap loop with 4 MFMAs of K = 16 per tap.
+template <int KIND, int MODE, int VAR>
 __global__ void __launch_bounds__(256) conv_patch_kernel(const G6dConv p, const int M, const int tiles_d, const int tiles_h,
                                                          const int tiles_w, const int chunks_per_split,
                                                          const int total_chunks, const int splits) {
@@ -152,40 +156,110 @@ __global__ void __launch_bounds__(256) conv_patch_kernel(const G6dConv p, const 
     store_patch(patch); store_b(bt0);
     __syncthreads();
     int bcur = 0;
-    for (int chunk = c_begin; chunk < c_end; ++chunk) {
-      const float* P = patch;
-      load_patch(chunk + 1);                          // masked beyond c_end; lands during the T taps below
+    constexpr bool PIPE = VAR == 0;
+    if constexpr (!PIPE) {
+      for (int chunk = c_begin; chunk < c_end; ++chunk) {
+        const float* P = patch;
+        load_patch(chunk + 1);                          // masked beyond c_end; lands during the T taps below
 #pragma unroll 1
-      for (int tap = 0; tap < T; ++tap) {
-        const float* B = bcur ? bt1 : bt0;
-        float* Bn = bcur ? bt0 : bt1;
-        const bool last = tap == T - 1;
-        load_b(last ? chunk + 1 : chunk, last ? 0 : tap + 1);
-        const int kz = tap / 9, ky = (tap - kz * 9) / 3, kx = tap - kz * 9 - ky * 3;
-        const int toff = ((kz * PH + ky) * PW + kx) * LDS_K;
-        f32x4 a[4][2], b[4];
+        for (int tap = 0; tap < T; ++tap) {
+          const float* B = bcur ? bt1 : bt0;
+          float* Bn = bcur ? bt0 : bt1;
+          const bool last = tap == T - 1;
+          load_b(last ? chunk + 1 : chunk, last ? 0 : tap + 1);
+          const int kz = tap / 9, ky = (tap - kz * 9) / 3, kx = tap - kz * 9 - ky * 3;
+          const int toff = ((kz * PH + ky) * PW + kx) * LDS_K;
+          f32x4 a[4][2], b[4];
 #pragma unroll
-        for (int kc = 0; kc < 4; ++kc) {
-          a[kc][0] = *reinterpret_cast<const f32x4*>(P + abase[0] + toff + kc * 8);
-          a[kc][1] = *reinterpret_cast<const f32x4*>(P + abase[1] + toff + kc * 8);
-          b[kc] = *reinterpret_cast<const f32x4*>(B + bfrag + kc * 8);
-        }
-#pragma unroll
-        for (int kc = 0; kc < 4; ++kc)
-#pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kc][0][s], b[kc][s], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kc][1][s], b[kc][s], acc[1], 0, 0, 0);
+          for (int kc = 0; kc < 4; ++kc) {
+            a[kc][0] = *reinterpret_cast<const f32x4*>(P + abase[0] + toff + kc * 8);
+            a[kc][1] = *reinterpret_cast<const f32x4*>(P + abase[1] + toff + kc * 8);
+            b[kc] = *reinterpret_cast<const f32x4*>(B + bfrag + kc * 8);
           }
-        __builtin_amdgcn_sched_barrier(0);
-        if (last && chunk + 1 < c_end) {
-          __syncthreads();                              // every wave is done with this chunk's patch
-          store_patch(patch);
+          if constexpr (VAR >= 2) {
+#pragma unroll
+            for (int kp = 0; kp < 2; ++kp) {
+              acc[0] = g6d_mfma_lowp<VAR - 1>(a[2 * kp][0], a[2 * kp + 1][0], b[2 * kp], b[2 * kp + 1], acc[0]);
+              acc[1] = g6d_mfma_lowp<VAR - 1>(a[2 * kp][1], a[2 * kp + 1][1], b[2 * kp], b[2 * kp + 1], acc[1]);
+            }
+          } else {
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc)
+#pragma unroll
+              for (int s = 0; s < 4; ++s) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kc][0][s], b[kc][s], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kc][1][s], b[kc][s], acc[1], 0, 0, 0);
+              }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (last && chunk + 1 < c_end) {
+            __syncthreads();                              // every wave is done with this chunk's patch
+            store_patch(patch);
+          }
+          store_b(Bn);
+          __syncthreads();
+          bcur ^= 1;
         }
-        store_b(Bn);
-        __syncthreads();
-        bcur ^= 1;
       }
+    } else {
+      // Software-pipelined tap loop.  A tap = 4 groups (8-channel slices kc) of 8 MFMAs.  The fragments of group kc+1 are
+      // requested in front of the MFMAs of group kc (two register sets, static parity because a tap has 4 groups), and the
+      // LAST group of every tap is deferred across the tap's barrier with its operands already in registers (set 1): the
+      // next tap opens with those 8 MFMAs, in whose shadow the first fragments of the new weight tile — which could not be
+      // requested before the barrier — arrive.  With one block per CU (the 32^3 layers: 256 tiles) nothing else hides that
+      // latency: the plain loop above leaves the matrix pipe idle for ~400 of every 2048 + 400 cycles.
+      f32x4 fa[2][2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) { fa[i][0] = fa[i][1] = fb[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      auto rd = [&](int set, const float* P, const float* B, int toff, int kc) {
+        fa[set][0] = *reinterpret_cast<const f32x4*>(P + abase[0] + toff + kc * 8);
+        fa[set][1] = *reinterpret_cast<const f32x4*>(P + abase[1] + toff + kc * 8);
+        fb[set] = *reinterpret_cast<const f32x4*>(B + bfrag + kc * 8);
+      };
+      auto mm = [&](int set) {
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][0][s2], fb[set][s2], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][1][s2], fb[set][s2], acc[1], 0, 0, 0);
+        }
+      };
+      for (int chunk = c_begin; chunk < c_end; ++chunk) {
+        const float* P = patch;
+        load_patch(chunk + 1);                          // masked beyond c_end; lands during the T taps below
+#pragma unroll 1
+        for (int tap = 0; tap < T; ++tap) {
+          const float* B = bcur ? bt1 : bt0;
+          float* Bn = bcur ? bt0 : bt1;
+          const bool last = tap == T - 1;
+          const int kz = tap / 9, ky = (tap - kz * 9) / 3, kx = tap - kz * 9 - ky * 3;
+          const int toff = ((kz * PH + ky) * PW + kx) * LDS_K;
+          rd(0, P, B, toff, 0);                                    // group 0 of this tap
+          __builtin_amdgcn_sched_barrier(0);
+          mm(1);                                                   // deferred group 3 of the previous tap (zeros at the start)
+          load_b(last ? chunk + 1 : chunk, last ? 0 : tap + 1);
+          __builtin_amdgcn_sched_barrier(0);
+          rd(1, P, B, toff, 1);
+          __builtin_amdgcn_sched_barrier(0);
+          mm(0);
+          __builtin_amdgcn_sched_barrier(0);
+          rd(0, P, B, toff, 2);
+          __builtin_amdgcn_sched_barrier(0);
+          mm(1);
+          __builtin_amdgcn_sched_barrier(0);
+          rd(1, P, B, toff, 3);                                    // operands of the deferred group stay in set 1
+          __builtin_amdgcn_sched_barrier(0);
+          mm(0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (last && chunk + 1 < c_end) {
+            __syncthreads();                              // every wave has its last fragments of this chunk's patch in registers
+            store_patch(patch);
+          }
+          store_b(Bn);
+          __syncthreads();
+          bcur ^= 1;
+        }
+      }
+      mm(1);                                              // the deferred group of the very last tap
     }
   }
 
@@ -262,14 +336,25 @@ int launch_patch(const G6dConv& d, int M, hipStream_t stream) {
   const int cps = (total_chunks + splits - 1) / splits;
   splits = (total_chunks + cps - 1) / cps;
   const size_t lds_bytes = (size_t)(NPOS * LDS_K + 2 * BN * LDS_K) * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_patch_kernel<KIND, MODE>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    attr_done = true;
+  static const bool pipe = []() { const char* e = getenv("G6D_PATCH_PIPE"); return !(e && e[0] == '0'); }();
+  const int var = d.math_mode == 1 ? 2 : d.math_mode == 2 ? 3 : (pipe ? 0 : 1);
+  auto go = [&](auto V) {
+    constexpr int VAR = decltype(V)::value;
+    static bool attr_done = false;      // per instantiation
+    if (!attr_done) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_patch_kernel<KIND, MODE, VAR>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+      attr_done = true;
+    }
+    hipLaunchKernelGGL((conv_patch_kernel<KIND, MODE, VAR>), dim3(tiles, ntn, splits), dim3(256), lds_bytes, stream, d, M,
+                       tiles_d, tiles_h, tiles_w, cps, total_chunks, splits);
+  };
+  switch (var) {
+    case 0: go(std::integral_constant<int, 0>{}); break;
+    case 1: go(std::integral_constant<int, 1>{}); break;
+    case 2: go(std::integral_constant<int, 2>{}); break;
+    default: go(std::integral_constant<int, 3>{}); break;
   }
-  hipLaunchKernelGGL((conv_patch_kernel<KIND, MODE>), dim3(tiles, ntn, splits), dim3(256), lds_bytes, stream, d, M, tiles_d,
-                     tiles_h, tiles_w, cps, total_chunks, splits);
   int rc = g6d_check_launch("conv_patch");
   if (rc != G6D_OK || splits == 1) return rc;
   return g6d_splitk_reduce_launch(d.workspace, splits, M, d.Cout, d.bias, d.out_act, d.out, d.ld_out, d.stats,

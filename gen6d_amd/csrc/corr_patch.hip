@@ -12,6 +12,8 @@
 //            [32 co][36] double-buffered; 16 MFMAs (v_mfma_f32_32x32x2_f32) per wave per kx
 //   split  = units are split across gridDim.z; partial tiles go to a workspace and the common split-K reduce adds them.
 #include "g6d_common.h"
+#include <stdlib.h>
+#include <type_traits>
 
 #define LDS_K 36
 #define TH 8
@@ -23,6 +25,7 @@ __device__ __forceinline__ f32x4 ldg4(const float* __restrict__ base, int elem_o
   return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + ((unsigned)elem_off << 2));
 }
 
+template <int MM>     // 0 = fp32 MFMA; 1 / 2 = bf16 / fp16 operands (two 8-channel groups per v_mfma_f32_32x32x16_*)
 __global__ void __launch_bounds__(512) corr_patch_kernel(const float* __restrict__ in, const float* __restrict__ wgt,
                                                          float* __restrict__ out, int H, int W, int Cin, int ld_in,
                                                          int Cout, int kh, int kw, int ph, int pw, int ld_out,
@@ -98,6 +101,24 @@ __global__ void __launch_bounds__(512) corr_patch_kernel(const float* __restrict
     store_patch(patch); store_b(bt0);
     __syncthreads();
     int bcur = 0;
+    // Software-pipelined tap loop (same scheme as conv_patch.hip): a tap = 4 groups (8-channel slices) of 4 MFMAs; the
+    // fragments of group kc+1 are requested in front of the MFMAs of group kc, and the last group of every tap is
+    // deferred across the tap's barrier with its operands in registers (set 1), so that the first fragments of the next
+    // weight tile arrive in the shadow of those MFMAs instead of in front of an idle matrix pipe.
+    f32x4 fa[2], fb[2];
+    fa[0] = fa[1] = fb[0] = fb[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto mm = [&](int set) {
+      if constexpr (MM == 0) {
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][s2], fb[set][s2], acc, 0, 0, 0);
+      } else if (set == 1) {
+        // reduced precision: one K = 16 MFMA per two 8-channel groups.  It runs whenever set 1 is due and consumes whatever
+        // the two sets hold at that point — (group 0 of this tap, deferred group 3 of the previous tap) at the top of a tap,
+        // (group 2, group 1) in its middle: every slot multiplies matching A and B entries and every group is consumed exactly
+        // once, so the sum is the same.
+        acc = g6d_mfma_lowp<MM>(fa[0], fa[1], fb[0], fb[1], acc);
+      }
+    };
     for (int u = u_begin; u < u_end; ++u) {
       const float* P = patch;
       load_patch(u + 1);                            // masked beyond u_end; lands during the kw steps below
@@ -105,22 +126,31 @@ __global__ void __launch_bounds__(512) corr_patch_kernel(const float* __restrict
         const float* B = bcur ? bt1 : bt0;
         float* Bn = bcur ? bt0 : bt1;
         const bool last = kx == kw - 1;
-        load_b(last ? u + 1 : u, last ? 0 : kx + 1);
         const float* arow = P + (wave * PW + li + kx) * LDS_K + 4 * lh;
         const float* brow_p = B + li * LDS_K + 4 * lh;
-        f32x4 a[4], b[4];
-#pragma unroll
-        for (int kc = 0; kc < 4; ++kc) {
-          a[kc] = *reinterpret_cast<const f32x4*>(arow + kc * 8);
-          b[kc] = *reinterpret_cast<const f32x4*>(brow_p + kc * 8);
-        }
-#pragma unroll
-        for (int kc = 0; kc < 4; ++kc)
-#pragma unroll
-          for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kc][s], b[kc][s], acc, 0, 0, 0);
+        auto rd = [&](int set, int kc) {
+          fa[set] = *reinterpret_cast<const f32x4*>(arow + kc * 8);
+          fb[set] = *reinterpret_cast<const f32x4*>(brow_p + kc * 8);
+        };
+        rd(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(1);                                      // deferred group 3 of the previous tap (zeros at the very start)
+        load_b(last ? u + 1 : u, last ? 0 : kx + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        rd(1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(0);
+        __builtin_amdgcn_sched_barrier(0);
+        rd(0, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(1);
+        __builtin_amdgcn_sched_barrier(0);
+        rd(1, 3);                                   // stays in set 1 across the barrier
+        __builtin_amdgcn_sched_barrier(0);
+        mm(0);
         __builtin_amdgcn_sched_barrier(0);
         if (last && u + 1 < u_end) {
-          __syncthreads();                          // every wave is done with this unit's patch
+          __syncthreads();                          // every wave holds its last fragments of this unit's patch in registers
           store_patch(patch);
         }
         store_b(Bn);
@@ -128,6 +158,8 @@ __global__ void __launch_bounds__(512) corr_patch_kernel(const float* __restrict
         bcur ^= 1;
       }
     }
+    if constexpr (MM != 0) fa[0] = fb[0] = f32x4{0.f, 0.f, 0.f, 0.f};      // group 2 of the last tap is already in the sum
+    mm(1);
   }
 
   // epilogue: acc rows = output columns tx0 + (r&3) + 8*(r>>2) + 4*lh of image row ty0 + wave; acc column = co = li
@@ -153,7 +185,7 @@ int g6d_splitk_reduce_launch(const float* ws, int splits, int M, int Cout, const
 //   in  [H][W][ld_in] channels-last, wgt [Cout][kh*kw][Cin], out [H*W][ld_out]; zero padding (ph, pw) with
 //   H_out = H, W_out = W (i.e. 2*ph = kh-1, 2*pw = kw-1).  workspace: split-K partials.
 extern "C" int g6d_corr2d_patch(const float* in, int H, int W, int Cin, int ld_in, const float* wgt, int Cout, int kh,
-                                int kw, float* out, int ld_out, float* workspace, size_t workspace_bytes,
+                                int kw, float* out, int ld_out, float* workspace, size_t workspace_bytes, int math_mode,
                                 g6d_stream_t stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (!in || !wgt || !out || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 3) || (ld_in & 3) || ld_in < Cin || Cout <= 0 ||
@@ -185,15 +217,21 @@ extern "C" int g6d_corr2d_patch(const float* in, int H, int W, int Cin, int ld_i
   const int ups = (total_units + splits - 1) / splits;
   splits = (total_units + ups - 1) / ups;
   const size_t lds_bytes = (size_t)(TH * (TW + kw - 1) * LDS_K + 2 * 32 * LDS_K) * sizeof(float);
-  static size_t attr_bytes = 0;
-  if (lds_bytes > attr_bytes) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_patch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds_bytes);
-    attr_bytes = lds_bytes;
-  }
-  hipLaunchKernelGGL(corr_patch_kernel, dim3(tiles, 1, splits), dim3(512), lds_bytes, stream, in, wgt,
-                     splits > 1 ? workspace : out, H, W, Cin, ld_in, Cout, kh, kw, kh / 2, kw / 2, ld_out, ups, total_units,
-                     splits, tiles_x);
+  auto go = [&](auto V) {
+    constexpr int MM = decltype(V)::value;
+    static size_t attr_bytes = 0;       // per instantiation
+    if (lds_bytes > attr_bytes) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_patch_kernel<MM>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds_bytes);
+      attr_bytes = lds_bytes;
+    }
+    hipLaunchKernelGGL(corr_patch_kernel<MM>, dim3(tiles, 1, splits), dim3(512), lds_bytes, stream, in, wgt,
+                       splits > 1 ? workspace : out, H, W, Cin, ld_in, Cout, kh, kw, kh / 2, kw / 2, ld_out, ups, total_units,
+                       splits, tiles_x);
+  };
+  if (math_mode == 1) go(std::integral_constant<int, 1>{});
+  else if (math_mode == 2) go(std::integral_constant<int, 2>{});
+  else go(std::integral_constant<int, 0>{});
   int rc = g6d_check_launch("corr2d_patch");
   if (rc != G6D_OK || splits == 1) return rc;
   return g6d_splitk_reduce_launch(workspace, splits, H * W, Cout, nullptr, 0, out, ld_out, nullptr, 0, stream);

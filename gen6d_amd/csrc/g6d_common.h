@@ -8,7 +8,29 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
 #define G6D_WAVE 64
+
+// Reduced-precision matrix-core mode (G6dConv.math_mode / g6d_corr2d_patch's math_mode; opt-in speed mode, fp32 stays the
+// default and the parity path): operands rounded to bf16 (1) or fp16 (2) when the fragments leave LDS, fp32 accumulation.
+// Two consecutive 8-channel fragment slices (lane-half h holds channels 4h..4h+3 of each) form the 8 operand slots of one
+// v_mfma_f32_32x32x16_{bf16,f16}: the K permutation is the same for A and B, so the sum is over the same 16 channels.
+template <int MM>
+__device__ __forceinline__ f32x16 g6d_mfma_lowp(f32x4 alo, f32x4 ahi, f32x4 blo, f32x4 bhi, f32x16 acc) {
+  if constexpr (MM == 1) {
+    bf16x8 a, b;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a[i] = (__bf16)alo[i]; a[4 + i] = (__bf16)ahi[i]; b[i] = (__bf16)blo[i]; b[4 + i] = (__bf16)bhi[i]; }
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+  } else {
+    f16x8 a, b;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a[i] = (_Float16)alo[i]; a[4 + i] = (_Float16)ahi[i]; b[i] = (_Float16)blo[i]; b[4 + i] = (_Float16)bhi[i]; }
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+  }
+}
 
 int g6d_check_launch(const char* what);   // returns G6D_OK or G6D_ELAUNCH, records the error string
 void g6d_set_error(const char* msg);

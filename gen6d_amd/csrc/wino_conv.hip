@@ -19,18 +19,27 @@
 //            pre-transformed filters are stored [chunk][ab][co][8], so a block's 32 KB per chunk is 16 contiguous 2 KB
 //            runs that go global -> LDS directly (global_load_lds_dwordx4, no VGPR round trip: the registers are spent on
 //            accumulators).  Two LDS stages, one barrier per chunk; per wave and chunk 64 MFMAs against 32 ds_read_b128.
+//   split  = small maps do not fill 256 CUs with 64-tile blocks and a block's K loop is serial (2-3 us per chunk): the
+//            channel chunks are then split over gridDim.z; partial OUTPUT tiles (the output transform is linear) go to a
+//            workspace and a small second kernel adds them and applies bias / ReLU / max-pool.
 //   K trick = as in conv_igemm.hip: lane-half h reads channels 4h..4h+3 of the chunk with one ds_read_b128 per operand;
 //            MFMA s consumes channel s (lanes 0-31) and 4+s (lanes 32-63) for both operands.
 //
 // Numerics: fp32 throughout; F(2x2,3x3) has transform constants {0, +-1, +-1/2} only (same error class as the MIOpen
 // Winograd solver the trunk ran on before).
 #include "g6d_common.h"
+#include <stdlib.h>
 
 namespace {
 
-#define WQ_PIX 100                         // raw patch positions per quarter (10 x 10)
-#define WRAW_LD 12                         // floats per raw patch position in LDS (8 channels + pad: conflict-free b128 reads)
-#define WRAW_FLOATS (4 * WQ_PIX * WRAW_LD) // 4800
+// Raw patch image in LDS: position (q, py, px) of quarter q at ((q*101 + py*10 + px) * 8) floats, its two 4-channel halves
+// swapped when (py >> 1) is odd; filter image [ab][co][8] with the halves swapped when (co & 8) (done once on the host, the
+// direct-to-LDS copy is lane-linear).  Both layouts make every ds_read_b128 of the fragment loops bank-conflict free
+// (checked exhaustively over the four 16-lane service groups of the instruction; plain 12-float rows were 3-way, plain
+// [co][8] rows 2-way conflicted).
+#define WQ_PIX 101                         // position stride between quarters (10 x 10 used)
+#define WRAW_LD 8                          // floats per raw patch position
+#define WRAW_FLOATS (4 * WQ_PIX * WRAW_LD) // 3232
 #define WU_FLOATS (16 * 64 * 8)            // 8192: [ab][co][8], lane-linear image of the global layout
 #define WSTAGE (WRAW_FLOATS + WU_FLOATS)   // 12992 floats = 51968 B per stage
 
@@ -38,6 +47,7 @@ struct WinoArgs {
   const float* in; const float* U; const float* bias; float* out_full; float* out_pool;
   int N, H, W, Cin, ld_in, Cout, ld_full, ld_pool, relu;
   int QH, QW, BH, BW, four_images;
+  int splits, chunks_per_split; float* ws;       // splits > 1: partial outputs [split][N][H][W][Cout] (no bias / ReLU / pool)
 };
 
 __device__ __forceinline__ f32x4 ldg4(const float* __restrict__ base, int elem_off) {
@@ -64,7 +74,8 @@ __global__ void __launch_bounds__(256, 1) wino_conv3x3_kernel(const WinoArgs p) 
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, lh = lane >> 5;
   const int n0 = blockIdx.y * 64;
-  const int nchunks = p.Cin >> 3;
+  const int c_first = blockIdx.z * p.chunks_per_split;                    // this block's slice of the channel chunks
+  const int c_last = min(p.Cin >> 3, c_first + p.chunks_per_split) - 1;
 
   // ---- raw patch loader: pieces idx = tid + 256*j < 800 = 4 quarters x 100 positions x 2 halves of the 8-channel chunk
   int poff[4], lsto[4]; bool pval[4], live[4];
@@ -78,7 +89,7 @@ __global__ void __launch_bounds__(256, 1) wino_conv3x3_kernel(const WinoArgs p) 
     const int iy = oy0 + py - 1, ix = ox0 + px - 1;
     pval[j] = (idx < 800) & qv & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
     poff[j] = pval[j] ? ((n * p.H + iy) * p.W + ix) * p.ld_in + 4 * half : 0;
-    lsto[j] = (q * WQ_PIX + pp) * WRAW_LD + 4 * half;
+    lsto[j] = (q * WQ_PIX + pp) * WRAW_LD + 4 * (half ^ ((py >> 1) & 1));
     live[j] = idx < 800;
   }
   f32x4 rp[4];
@@ -113,8 +124,10 @@ __global__ void __launch_bounds__(256, 1) wino_conv3x3_kernel(const WinoArgs p) 
 
   // ---- fragment bases
   const int tl = li & 15, ty = tl >> 2, tx = tl & 3;
-  const int abase = ((2 * wm + (li >> 4)) * WQ_PIX + (2 * ty) * 10 + 2 * tx) * WRAW_LD + 4 * lh;
-  const int bbase = WRAW_FLOATS + (wn * 32 + li) * 8 + 4 * lh;
+  const int apos = ((2 * wm + (li >> 4)) * WQ_PIX + (2 * ty) * 10 + 2 * tx) * WRAW_LD;
+  const int abase01 = apos + 4 * (lh ^ (ty & 1));            // patch rows 2ty, 2ty+1   ((py >> 1) & 1 == ty & 1)
+  const int abase23 = apos + 4 * (lh ^ (ty & 1) ^ 1);        // patch rows 2ty+2, 2ty+3
+  const int bbase = WRAW_FLOATS + (wn * 32 + li) * 8 + 4 * (lh ^ ((li >> 3) & 1));
 
   f32x16 acc[16];
 #pragma unroll
@@ -122,8 +135,8 @@ __global__ void __launch_bounds__(256, 1) wino_conv3x3_kernel(const WinoArgs p) 
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
 
-  load_u(0, 0);
-  load_raw(0);
+  load_u(c_first, 0);
+  load_raw(c_first);
   store_raw(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -138,27 +151,27 @@ __global__ void __launch_bounds__(256, 1) wino_conv3x3_kernel(const WinoArgs p) 
 #pragma unroll
   for (int j = 0; j < 4; ++j) { vD[j] = f32x4{0.f, 0.f, 0.f, 0.f}; uD[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-  for (int c = 0; c < nchunks; ++c) {
+  for (int cc = c_first; cc <= c_last; ++cc) {
+    const int c = cc - c_first;                   // stage parity counts from the block's first chunk
     const float* S = lds + (c & 1) * WSTAGE;
-    const int cn = min(c + 1, nchunks - 1);       // the last chunk re-requests itself into the idle stage: no branches
+    const int cn = min(cc + 1, c_last);           // the last chunk re-requests itself into the idle stage: no branches
     f32x4 d[4][4], ub[3][4];
-    auto rd_d = [&](int i, int j) { d[i][j] = *reinterpret_cast<const f32x4*>(S + abase + (i * 10 + j) * WRAW_LD); };
+    auto rd_d = [&](int i, int j) { d[i][j] = *reinterpret_cast<const f32x4*>(S + (i < 2 ? abase01 : abase23) + (i * 10 + j) * WRAW_LD); };
     auto rd_u = [&](int g, int j) { ub[g % 3][j] = *reinterpret_cast<const f32x4*>(S + bbase + (g * 4 + j) * 512); };
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       acc[12 + (k >> 2)] = __builtin_amdgcn_mfma_f32_32x32x2f32(vD[k >> 2][k & 3], uD[k >> 2][k & 3], acc[12 + (k >> 2)], 0, 0, 0);
-      if (k < 2) { rd_d(0, 2 * k); rd_d(0, 2 * k + 1); }
-      else if (k < 4) { rd_d(2, 2 * (k - 2)); rd_d(2, 2 * (k - 2) + 1); }
-      else if (k < 6) { rd_u(0, 2 * (k - 4)); rd_u(0, 2 * (k - 4) + 1); }
-      else if (k < 8) { rd_d(1, 2 * (k - 6)); rd_d(1, 2 * (k - 6) + 1); }
-      else if (k < 10) { rd_d(3, 2 * (k - 8)); rd_d(3, 2 * (k - 8) + 1); }
-      else if (k < 12) { rd_u(1, 2 * (k - 10)); rd_u(1, 2 * (k - 10) + 1); }
-      else {
-        const int kk = k - 12;
-        rp[kk] = ldg4(p.in, pval[kk] ? poff[kk] + cn * 8 : 0);
-        glds(cn, (c & 1) ^ 1, wave * 8 + 2 * kk);
-        glds(cn, (c & 1) ^ 1, wave * 8 + 2 * kk + 1);
+      if (k < 4) {                                   // global requests first: they have the longest way to go
+        rp[k] = ldg4(p.in, pval[k] ? poff[k] + cn * 8 : 0);
+        glds(cn, (c & 1) ^ 1, wave * 8 + 2 * k);
+        glds(cn, (c & 1) ^ 1, wave * 8 + 2 * k + 1);
       }
+      else if (k < 6) { rd_d(0, 2 * (k - 4)); rd_d(0, 2 * (k - 4) + 1); }
+      else if (k < 8) { rd_d(2, 2 * (k - 6)); rd_d(2, 2 * (k - 6) + 1); }
+      else if (k < 10) { rd_u(0, 2 * (k - 8)); rd_u(0, 2 * (k - 8) + 1); }
+      else if (k < 12) { rd_d(1, 2 * (k - 10)); rd_d(1, 2 * (k - 10) + 1); }
+      else if (k < 14) { rd_d(3, 2 * (k - 12)); rd_d(3, 2 * (k - 12) + 1); }
+      else { rd_u(1, 2 * (k - 14)); rd_u(1, 2 * (k - 14) + 1); }
       __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
@@ -198,7 +211,8 @@ __global__ void __launch_bounds__(256, 1) wino_conv3x3_kernel(const WinoArgs p) 
 
   // ---------------------------------------------------------------- epilogue: A^T D A, bias, ReLU, stores, 2x2 max-pool
   const int co = n0 + wn * 32 + li;
-  const float bv = p.bias ? p.bias[co] : 0.f;
+  const float bv = (p.bias && p.splits == 1) ? p.bias[co] : 0.f;
+  const bool do_relu = p.relu && p.splits == 1;
   const int Hp = p.H >> 1, Wp = p.W >> 1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -218,9 +232,20 @@ __global__ void __launch_bounds__(256, 1) wino_conv3x3_kernel(const WinoArgs p) 
     for (int a = 0; a < 2; ++a) {
       y[a][0] = sr[a][0] + sr[a][1] + sr[a][2] + bv;
       y[a][1] = sr[a][1] - sr[a][2] - sr[a][3] + bv;
-      if (p.relu) { y[a][0] = fmaxf(y[a][0], 0.f); y[a][1] = fmaxf(y[a][1], 0.f); }
+      if (do_relu) { y[a][0] = fmaxf(y[a][0], 0.f); y[a][1] = fmaxf(y[a][1], 0.f); }
     }
     const int oy = oy0 + 2 * tyy, ox = ox0 + 2 * txx;
+    if (p.splits > 1) {
+      if (qv) {
+        float* w = p.ws + (size_t)blockIdx.z * p.N * p.H * p.W * p.Cout;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+            if (oy + a < p.H && ox + b < p.W) w[((size_t)(n * p.H + oy + a) * p.W + ox + b) * p.Cout + co] = y[a][b];
+      }
+      continue;
+    }
     if (p.out_full && qv) {
 #pragma unroll
       for (int a = 0; a < 2; ++a)
@@ -237,6 +262,38 @@ __global__ void __launch_bounds__(256, 1) wino_conv3x3_kernel(const WinoArgs p) 
   }
 }
 
+// Second half of a split launch: thread = one 2x2 output cell x 4 channels; sums the partial outputs of all splits, adds the
+// bias, applies ReLU, writes the full-resolution result and / or the max-pooled one.
+__global__ void __launch_bounds__(256) wino_reduce_kernel(const float* __restrict__ ws, int splits, int N, int H, int W, int Cout,
+                                                          const float* __restrict__ bias, int relu, float* __restrict__ out_full,
+                                                          int ld_full, float* __restrict__ out_pool, int ld_pool) {
+  const int c4 = Cout >> 2, Hc = (H + 1) >> 1, Wc = (W + 1) >> 1;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)N * Hc * Wc * c4) return;
+  const int c = (int)(i % c4) * 4; long long t = i / c4;
+  const int cx = (int)(t % Wc); t /= Wc;
+  const int cy = (int)(t % Hc); const int n = (int)(t / Hc);
+  const size_t zstride = (size_t)N * H * W * Cout;
+  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+  if (bias) bv = *reinterpret_cast<const f32x4*>(bias + c);
+  f32x4 m = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int oy = 2 * cy + a, ox = 2 * cx + b;
+      if (oy >= H || ox >= W) continue;
+      const float* src = ws + ((size_t)(n * H + oy) * W + ox) * Cout + c;
+      f32x4 v = bv;
+      for (int z = 0; z < splits; ++z) v += *reinterpret_cast<const f32x4*>(src + (size_t)z * zstride);
+      if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+      if (out_full) *reinterpret_cast<f32x4*>(out_full + ((size_t)(n * H + oy) * W + ox) * ld_full + c) = v;
+      m[0] = fmaxf(m[0], v[0]); m[1] = fmaxf(m[1], v[1]); m[2] = fmaxf(m[2], v[2]); m[3] = fmaxf(m[3], v[3]);
+    }
+  if (out_pool && cy < (H >> 1) && cx < (W >> 1))
+    *reinterpret_cast<f32x4*>(out_pool + ((size_t)(n * (H >> 1) + cy) * (W >> 1) + cx) * ld_pool + c) = m;
+}
+
 }  // namespace
 
 // in [N][H][W][ld_in] channels-last (Cin % 8 == 0), U = pre-transformed filters [Cin/8][16][Cout][8] (see
@@ -244,10 +301,11 @@ __global__ void __launch_bounds__(256, 1) wino_conv3x3_kernel(const WinoArgs p) 
 //   y = conv3x3(in, pad 1) + bias; if relu: y = max(y, 0)
 //   out_full (optional) [N][H][W][ld_full]   <- y
 //   out_pool (optional) [N][H/2][W/2][ld_pool] <- 2x2 max-pool of y (floor, as F.max_pool2d)
+//   workspace (optional): split partial outputs for grids that would not fill the chip (splits*N*H*W*Cout floats)
 // Replaces features[4..27] of vgg11_bn (conv + folded BatchNorm + ReLU + MaxPool), network/pretrain_models.py:17-25,66-72.
 extern "C" int g6d_wino_conv3x3(const float* in, int N, int H, int W, int Cin, int ld_in, const float* U, const float* bias,
                                 int Cout, int relu, float* out_full, int ld_full, float* out_pool, int ld_pool,
-                                g6d_stream_t stream) {
+                                float* workspace, size_t workspace_bytes, g6d_stream_t stream) {
   if (!in || !U || (!out_full && !out_pool) || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 7) || (ld_in & 3) || ld_in < Cin ||
       Cout <= 0 || (Cout & 63) || (out_full && ld_full < Cout) || (out_pool && (ld_pool < Cout || H < 2 || W < 2)) ||
       !g6d_aligned16(in) || !g6d_aligned16(U) || (long long)N * H * W * ld_in >= (1ll << 30)) {
@@ -261,6 +319,24 @@ extern "C" int g6d_wino_conv3x3(const float* in, int N, int H, int W, int Cin, i
   a.BH = (a.QH + 1) / 2; a.BW = (a.QW + 1) / 2;
   const long long blocks = a.four_images ? (N + 3) / 4 : (long long)N * a.BH * a.BW;
   if (blocks > 0x7fffffffll) { g6d_set_error("wino_conv3x3: grid too large"); return G6D_EINVAL; }
+  // split the channel chunks when the grid leaves most of the chip idle (each block is a serial loop over the chunks)
+  const int nchunks = Cin / 8;
+  int splits = 1;
+  const long long grid2 = blocks * (Cout / 64);
+  static const int split_target = []() { const char* e = getenv("G6D_WINO_SPLIT_TARGET"); return e ? atoi(e) : 384; }();
+  if (grid2 < 192 && workspace && split_target > 0) {
+    splits = (int)((split_target + grid2 - 1) / grid2);
+    if (splits > nchunks / 2) splits = nchunks / 2;
+    if (splits > 32) splits = 32;
+    const size_t per = (size_t)N * H * W * Cout * sizeof(float);
+    if ((size_t)splits * per > workspace_bytes) splits = (int)(workspace_bytes / per);
+    if (splits < 2) splits = 1;
+    if ((ld_full & 3) || (ld_pool & 3) || (out_full && !g6d_aligned16(out_full)) || (out_pool && !g6d_aligned16(out_pool)) ||
+        (bias && !g6d_aligned16(bias)) || !g6d_aligned16(workspace)) splits = 1;
+  }
+  const int cps = (nchunks + splits - 1) / splits;
+  splits = (nchunks + cps - 1) / cps;
+  a.splits = splits; a.chunks_per_split = cps; a.ws = workspace;
   const size_t lds_bytes = (2 * (size_t)WSTAGE + 4 * 256) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
@@ -268,7 +344,12 @@ extern "C" int g6d_wino_conv3x3(const float* in, int N, int H, int W, int Cin, i
                               (int)lds_bytes);
     attr_done = true;
   }
-  hipLaunchKernelGGL(wino_conv3x3_kernel, dim3((unsigned)blocks, Cout / 64), dim3(256), lds_bytes,
+  hipLaunchKernelGGL(wino_conv3x3_kernel, dim3((unsigned)blocks, Cout / 64, splits), dim3(256), lds_bytes,
                      reinterpret_cast<hipStream_t>(stream), a);
-  return g6d_check_launch("wino_conv3x3");
+  int rc = g6d_check_launch("wino_conv3x3");
+  if (rc != G6D_OK || splits == 1) return rc;
+  const long long cells = (long long)N * ((H + 1) / 2) * ((W + 1) / 2) * (Cout / 4);
+  hipLaunchKernelGGL(wino_reduce_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     workspace, splits, N, H, W, Cout, bias, relu, out_full, ld_full, out_pool, ld_pool);
+  return g6d_check_launch("wino_reduce");
 }

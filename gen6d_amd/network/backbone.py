@@ -27,14 +27,19 @@ _POOL_BEFORE = (1, 2, 4, 6)          # positions (in the list of 8 convs) preced
 
 
 def winograd_filters(w):
-    """[Cout,Cin,3,3] -> U [Cin/8,16,Cout,8] with U[c][4a+b][co][k] = (G g G^T)[a][b] of filter (co, 8c+k): the operand
-    layout of g6d_wino_conv3x3 (a block's slice of one 8-channel chunk is 16 contiguous runs)."""
+    """[Cout,Cin,3,3] -> U [Cin/8,16,Cout,8] with U[c][4a+b][co][k ^ (4 if co & 8 else 0)] = (G g G^T)[a][b] of filter
+    (co, 8c+k): the operand layout of g6d_wino_conv3x3 (a block's slice of one 8-channel chunk is 16 contiguous runs)."""
     co, ci = w.shape[:2]
     if ci % 8 or co % 64:
         raise ValueError("winograd_filters: Cin % 8 == 0 and Cout % 64 == 0 expected")
     G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64, device=w.device)
     U = torch.einsum("ai,ocij,bj->ocab", G, w.double(), G).to(w.dtype)               # [co,ci,4,4]
-    return U.reshape(co, ci // 8, 8, 16).permute(1, 3, 0, 2).contiguous()
+    U = U.reshape(co, ci // 8, 8, 16).permute(1, 3, 0, 2).contiguous()               # [chunk][ab][co][8]
+    # the kernel copies a block's rows straight into LDS (lane-linear): rows with co & 8 carry their two 4-channel halves
+    # swapped so that the fragment reads (one 16-byte half per lane) spread over all banks
+    swap = (torch.arange(co, device=w.device) & 8) != 0
+    U[:, :, swap] = torch.cat([U[:, :, swap, 4:], U[:, :, swap, :4]], -1)
+    return U
 
 
 def pack_trunk(folded):

@@ -132,7 +132,13 @@ class Detector(ParamBank):
         res = ops.detector_decode(o4[:, 0:1], o4[:, 2:4], o4[:, 1:2], hs, ws, self.pool_ratio)
         return o4, res, (hs, ws)
 
-    def detect_impl(self, que_imgs):
+    def detect_impl(self, *a, **k):
+        """cfg key 'math_mode' ('bf16' / 'fp16'; default fp32) selects the matrix-core operand precision of this network's conv /
+        correlation launches; absent, an enclosing `ops.math_mode(...)` context applies."""
+        with ops.math_mode(self.cfg.get("math_mode"), inherit_if_none=True):
+            return self._detect_impl_fp(*a, **k)
+
+    def _detect_impl_fp(self, que_imgs):
         """que_imgs [qn,3,hq,wq] in [0,1] -> the reference's output dict (detector.py:232-266) plus
         'positions' [qn,2] and 'scales' [qn] already decoded on the device."""
         outs, results = [], []

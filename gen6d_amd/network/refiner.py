@@ -140,7 +140,13 @@ class VolumeRefiner(ParamBank):
         o = ops.linear_gemv(x, pk["heads"][0], pk["heads"][1])
         return F.normalize(o[:, 0:4], dim=1), o[:, 4:6], o[:, 6:7]
 
-    def _step(self, que_img, K_in, pose_in, ref_imgs, ref_Ks, ref_poses):
+    def _step(self, *a, **k):
+        """cfg key 'math_mode' ('bf16' / 'fp16'; default fp32) selects the matrix-core operand precision of this network's conv /
+        correlation launches; absent, an enclosing `ops.math_mode(...)` context applies."""
+        with ops.math_mode(self.cfg.get("math_mode"), inherit_if_none=True):
+            return self._step_fp(*a, **k)
+
+    def _step_fp(self, que_img, K_in, pose_in, ref_imgs, ref_Ks, ref_poses):
         sn = self.cfg["refiner_sample_num"]
         dev = que_img.device
         ops.stats_arena_begin(dev)

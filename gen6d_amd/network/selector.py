@@ -260,7 +260,13 @@ class ViewpointSelector(ParamBank):
         ops.conv(tok(a1), pk["ang4"][0], pk["ang4"][1], tok(angles))
         return logits[:, 0], self._allgather_rows(angles, rfn_all)[:, 0]
 
-    def compute_view_point_feats(self, que_imgs):
+    def compute_view_point_feats(self, *a, **k):
+        """cfg key 'math_mode' ('bf16' / 'fp16'; default fp32) selects the matrix-core operand precision of this network's conv /
+        correlation launches; absent, an enclosing `ops.math_mode(...)` context applies."""
+        with ops.math_mode(self.cfg.get("math_mode"), inherit_if_none=True):
+            return self._compute_view_point_feats_fp(*a, **k)
+
+    def _compute_view_point_feats_fp(self, que_imgs):
         """que_imgs [qn,3,h,w] in [0,1] -> logits [qn,rfn], angles [qn,rfn] (reference selector.py:177-215)."""
         outs = [self._query_one(que_imgs[i:i + 1]) for i in range(que_imgs.shape[0])]
         return torch.stack([o[0] for o in outs], 0), torch.stack([o[1] for o in outs], 0)

@@ -18,6 +18,30 @@ from . import lib as _lib
 
 _WS = {}
 WORKSPACE_BYTES = 96 << 20
+# Matrix-core operand precision of the conv / correlation kernels: 0 = fp32 (default, the parity path), 1 = bf16, 2 = fp16
+# (fp32 accumulation, fp32 InstanceNorm statistics).  Opt-in speed mode: set through `math_mode(...)` / the networks'
+# cfg key "math_mode"; graded separately from the fp32 path (arg-max equality + reported logit error).
+MATH_MODE = 0
+_MATH_NAMES = {"fp32": 0, "f32": 0, "bf16": 1, "fp16": 2, "f16": 2, 0: 0, 1: 1, 2: 2, None: 0}
+
+
+class math_mode:
+    """Context manager: `with ops.math_mode("bf16"): ...` runs the enclosed launches (and graph captures) in that mode."""
+
+    def __init__(self, mode, inherit_if_none=False):
+        self.mode = None if (mode is None and inherit_if_none) else _MATH_NAMES[mode]
+
+    def __enter__(self):
+        global MATH_MODE
+        self.prev = MATH_MODE
+        if self.mode is not None:
+            MATH_MODE = self.mode
+        return self
+
+    def __exit__(self, *exc):
+        global MATH_MODE
+        MATH_MODE = self.prev
+        return False
 # When set to a list, conv() brackets every g6d_conv_igemm launch with HIP events recorded on the launch stream and
 # appends (algorithmic flops, start, end); bench.py turns this into the roofline entry.
 PROFILE = None
@@ -134,7 +158,7 @@ def conv(x, w, bias, out, ksize=(1, 1, 1), stride=(1, 1, 1), pad=(0, 0, 0), mul=
         N=N, Di=Di, Hi=Hi, Wi=Wi, Cin=Cin, ld_in=ld_in, Do=Do, Ho=Ho, Wo=Wo, Cout=Cout, ld_out=ld_out,
         kd=kd, kh=kh, kw=kw, sd=stride[0], sh=stride[1], sw=stride[2], pd=pad[0], ph=pad[1], pw=pad[2],
         in_relu=int(in_relu), in_affine_per_n=int(per_n), out_act=int(out_act),
-        stat_rows_per_group=int(rows_per_group), split_k=int(split_k))
+        stat_rows_per_group=int(rows_per_group), split_k=int(split_k), math_mode=int(MATH_MODE))
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -161,7 +185,7 @@ def corr2d_patch(x, w, out, k):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     _lib.check(_lib.load().g6d_corr2d_patch(_ptr(x), H, W, Cin, ld_in, _ptr(w), Cout, k, k, _ptr(out), ld_out, _ptr(ws),
-                                           ws.numel() * 4, _stream()), "g6d_corr2d_patch")
+                                           ws.numel() * 4, int(MATH_MODE), _stream()), "g6d_corr2d_patch")
     if PROFILE is not None:
         e1.record()
         PROFILE.append((flops, e0, e1, f"corr2d_patch in={H}x{W}x{Cin} out={Cout} k={k}x{k}"))
@@ -293,8 +317,9 @@ def wino_conv3x3(x, U, bias, relu=True, full=True, pool=False):
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
+    ws = workspace(x.device)
     _lib.check(_lib.load().g6d_wino_conv3x3(_ptr(x), N, H, W, Cin, ld_in, _ptr(U), _ptr(bias), Cout, int(relu), _ptr(y), Cout,
-                                           _ptr(yp), Cout, _stream()), "g6d_wino_conv3x3")
+                                           _ptr(yp), Cout, _ptr(ws), ws.numel() * 4, _stream()), "g6d_wino_conv3x3")
     if PROFILE is not None:
         e1.record()
         # direct-form FLOPs / 2.25 = multiplications actually executed in the Winograd domain (what the matrix cores do)

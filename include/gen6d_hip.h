@@ -77,6 +77,8 @@ typedef struct G6dConv {
   int32_t out_act;              /* 0 none, 1 ReLU, 2 LeakyReLU(0.1) */
   int32_t stat_rows_per_group;  /* output rows per statistics group (0 = all rows in one group) */
   int32_t split_k;              /* 0 = choose automatically; 1 = never split; >1 = force */
+  int32_t math_mode;            /* 0 = fp32 MFMA (default, the parity path); 1 = bf16, 2 = fp16 operands with fp32 accumulation:
+                                   v_mfma_f32_32x32x16_{bf16,f16}, opt-in speed mode graded separately (BASELINE configs[2], [4]) */
 } G6dConv;
 
 int g6d_conv_igemm(const G6dConv* desc, g6d_stream_t stream);
@@ -88,7 +90,8 @@ int g6d_sizeof_conv_desc(void);
  * activation tile for every one of the 225 taps.  in [H][W][ld_in], wgt [Cout][kh*kw][Cin], out [H*W][ld_out],
  * "same" zero padding (kh, kw odd, kw <= 31).  workspace: split-K partials (splits*H*W*Cout floats). */
 int g6d_corr2d_patch(const float* in, int H, int W, int Cin, int ld_in, const float* wgt, int Cout, int kh, int kw,
-                     float* out, int ld_out, float* workspace, size_t workspace_bytes, g6d_stream_t stream);
+                     float* out, int ld_out, float* workspace, size_t workspace_bytes, int math_mode /* as G6dConv.math_mode */,
+                     g6d_stream_t stream);
 
 /* InstanceNorm finalisation: stats[g][c] = (sum, sumsq) over `count` elements ->
  * scale = 1/sqrt(var+eps), shift = -mean*scale (biased variance; torch InstanceNorm{1,2,3}d, eps 1e-5,
@@ -126,12 +129,15 @@ int g6d_vgg_conv1_pool_nhwc(const float* in, int N, int H, int W, const float* w
  * vgg11_bn features[4..28], BatchNorm folded) as Winograd F(2x2,3x3) on fp32 MFMA with the trunk's bias, ReLU and 2x2
  * max-pool fused into the epilogue; channels-last in and out.
  *   in   [N][H][W][ld_in], Cin % 8 == 0;  U = filters transformed on the host, [Cin/8][16][Cout][8] with
- *        U[c][4a+b][co][k] = (G g G^T)[a][b] of filter (co, 8c+k), G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+ *        U[c][4a+b][co][k ^ (co & 8 ? 4 : 0)] = (G g G^T)[a][b] of filter (co, 8c+k), G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+ *        (the two 4-channel halves of a row are swapped for co & 8: bank-conflict-free LDS image, the copy is lane-linear)
  *   y = conv3x3_pad1(in) + bias[co];  relu != 0: y = max(y, 0)
  *   out_full (optional) [N][H][W][ld_full] = y;  out_pool (optional) [N][H/2][W/2][ld_pool] = maxpool2x2(y) (floor)
+ *   workspace (optional): small maps split the channel chunks over more blocks; partial outputs (<= 32*N*H*W*Cout floats)
  * Replaces the MIOpen convolutions of the trunk and the bias/ReLU/pool and layout passes around them. */
 int g6d_wino_conv3x3(const float* in, int N, int H, int W, int Cin, int ld_in, const float* U, const float* bias, int Cout,
-                     int relu, float* out_full, int ld_full, float* out_pool, int ld_pool, g6d_stream_t stream);
+                     int relu, float* out_full, int ld_full, float* out_pool, int ld_pool, float* workspace,
+                     size_t workspace_bytes, g6d_stream_t stream);
 
 /* In-place L2 normalisation over C of channels-last rows x[rows][ld] (F.normalize eps 1e-12, network/selector.py:118,
  * network/refiner.py:69-71). */

@@ -120,6 +120,9 @@ def wino_conv3x3(x, U, bias, relu=True, full=True, pool=False):
     xp = F.pad(x, (0, 0, 1, 2 * Wt + 1 - W, 1, 2 * Ht + 1 - H))                       # [N, 2Ht+2, 2Wt+2, C]
     d = xp.unfold(1, 4, 2).unfold(2, 4, 2)                                             # [N,Ht,Wt,C,4,4]
     V = torch.einsum("ai,ntucij,bj->ntuabc", BT, d, BT)
+    U = U.clone()
+    swap = (torch.arange(Cout) & 8) != 0                                               # undo the LDS-bank swizzle of the halves
+    U[:, :, swap] = torch.cat([U[:, :, swap, 4:], U[:, :, swap, :4]], -1)
     U4 = U.permute(1, 2, 0, 3).reshape(4, 4, Cout, Cin).to(dt)
     M = torch.einsum("ntuabc,aboc->ntuabo", V, U4)
     Y = torch.einsum("pa,ntuabo,qb->ntupqo", AT, M, AT)                               # [N,Ht,Wt,2,2,Cout]

@@ -362,6 +362,8 @@ WINO_CASES = [
     (1, 30, 40, 128, 256, True, False, True),      # pooled output only
     (1, 64, 64, 64, 128, True, False, True),       # first Winograd layer of a 128x128 crop
     (3, 10, 18, 8, 64, True, True, True),          # smallest channel counts the kernel accepts
+    (8, 64, 64, 64, 128, True, True, True),        # 256 blocks: the un-split path (smaller grids above split the channel chunks)
+    (12, 16, 16, 256, 512, True, False, True),     # 96 blocks x 2 splits
 ]
 
 

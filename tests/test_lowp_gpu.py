@@ -1,0 +1,113 @@
+"""Reduced-precision matrix-core mode (G6dConv.math_mode / ops.math_mode: bf16 or fp16 operands, fp32 accumulation) — the
+opt-in speed mode of BASELINE configs[2] ("bf16") and [4] ("fp16 MFMA convs").  It is graded separately from the fp32 path:
+per kernel against the float64 reference with the operand-rounding bound of the type, per stage by arg-max equality with the
+reference's own outputs plus the achieved logit error (recorded in the parity log, profiles/r02_parity.md)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gen6d_amd import synth
+from parity_log import record
+from test_networks_gpu import _net
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"bf16": 2e-2, "fp16": 3e-3}        # relative to the output range: ~ 2^-8 / 2^-11 operand rounding, random signs
+
+
+def _rand(g, *shape, scale=1.0):
+    return (torch.rand(shape, generator=g) * 2 - 1) * scale
+
+
+CASES = [
+    dict(N=1, D=8, H=8, W=8, Cin=128, Cout=64, k=(3, 3, 3), s=1, p=(1, 1, 1)),                 # conv_igemm split-K or patch
+    dict(N=1, D=16, H=16, W=16, Cin=64, Cout=64, k=(3, 3, 3), s=1, p=(1, 1, 1), aff=True),     # conv_patch 3-D
+    dict(N=40, D=1, H=16, W=16, Cin=512, Cout=64, k=(1, 3, 3), s=1, p=(0, 1, 1), mul=True),    # conv_patch 2-D with product prologue
+    dict(N=1, D=8, H=8, W=8, Cin=64, Cout=256, k=(3, 3, 3), s=2, p=(1, 1, 1)),                 # strided, generic kernel
+    dict(N=1, D=1, H=1, W=320, Cin=516, Cout=512, k=(1, 1, 1), s=1, p=(0, 0, 0)),              # 1x1 tail GEMM, ragged Cin
+]
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+@pytest.mark.parametrize("case", CASES)
+def test_conv_lowp(mode, case):
+    from gen6d_amd import ops
+    c = case
+    g = torch.Generator().manual_seed(7 + c["Cin"])
+    kd, kh, kw = c["k"]
+    x = _rand(g, c["N"], c["D"], c["H"], c["W"], c["Cin"])
+    w = _rand(g, c["Cout"], kd * kh * kw, c["Cin"], scale=(1.0 / (kd * kh * kw * c["Cin"])) ** 0.5 * 3)
+    b = _rand(g, c["Cout"], scale=0.2)
+    mul = _rand(g, c["H"], c["W"], c["Cin"]) if c.get("mul") else None
+    sc = (_rand(g, 1, c["Cin"]) * 0.5 + 1.0) if (c.get("aff") or c.get("mul")) else None
+    sh = _rand(g, 1, c["Cin"], scale=0.3) if sc is not None else None
+    st = (c["s"],) * 3
+    Do, Ho, Wo = [(i + 2 * pp - kk) // c["s"] + 1 for i, kk, pp in zip((c["D"], c["H"], c["W"]), c["k"], c["p"])]
+    out = torch.empty((c["N"], Do, Ho, Wo, c["Cout"]), device="cuda")
+    cu = lambda t: t.cuda() if t is not None else None
+    with ops.math_mode(mode):
+        ops.conv(cu(x), cu(w), cu(b), out, ksize=c["k"], stride=st, pad=c["p"], mul=cu(mul), in_scale=cu(sc), in_shift=cu(sh),
+                 in_relu=bool(c.get("aff")))
+    xin = x.double()
+    if mul is not None:
+        xin = xin * mul.double()
+    if sc is not None:
+        xin = xin * sc.double().view(1, 1, 1, 1, -1) + sh.double().view(1, 1, 1, 1, -1)
+        if c.get("aff"):
+            xin = F.relu(xin)
+    w5 = w.double().reshape(c["Cout"], kd, kh, kw, c["Cin"]).permute(0, 4, 1, 2, 3)
+    ref = F.conv3d(xin.permute(0, 4, 1, 2, 3), w5, b.double(), stride=st, padding=c["p"]).permute(0, 2, 3, 4, 1)
+    err = (out.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+    record("test_conv_lowp", f"{mode} N={c['N']} {c['D']}x{c['H']}x{c['W']}x{c['Cin']}->{c['Cout']} k={c['k']}", err, TOL[mode], note="relative to range")
+    assert err <= TOL[mode], err
+    assert ops.MATH_MODE == 0                          # the context manager restores the default
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+def test_corr2d_patch_lowp(mode):
+    from gen6d_amd import ops
+    g = torch.Generator().manual_seed(3)
+    H, W, Cin, Cout, k = 30, 40, 512, 32, 15
+    x = F.relu(_rand(g, 1, 1, H, W, Cin))
+    w = F.relu(_rand(g, Cout, k * k, Cin))
+    out = torch.empty((1, 1, H, W, Cout), device="cuda")
+    with ops.math_mode(mode):
+        ops.corr2d_patch(x.cuda(), w.cuda(), out, k)
+    w4 = w.double().reshape(Cout, k, k, Cin).permute(0, 3, 1, 2)
+    ref = F.conv2d(x.double()[0].permute(0, 3, 1, 2), w4, padding=k // 2)[0].permute(1, 2, 0)
+    err = (out.cpu().double()[0, 0] - ref).abs().max().item() / ref.abs().max().item()
+    record("test_corr2d_patch_lowp", f"{mode} 30x40x512 -> 32, 15x15", err, TOL[mode], note="relative to range")
+    assert err <= TOL[mode], err
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+def test_selector_headline_lowp(golden, mode):
+    """64 references x 5 rotations with the cfg key: same arg-max viewpoint as the reference, logit error recorded."""
+    g = golden("sel_head")
+    case = synth.selector_case(64, 5)
+    net = _net("selector", math_mode=mode)
+    with torch.no_grad():
+        out = net({"ref_imgs": case["ref_imgs"].cuda(), "ref_imgs_info": {"poses": case["ref_poses"].cuda()},
+                   "object_center": case["object_center"].cuda(), "object_vert": case["object_vert"].cuda(),
+                   "que_imgs_info": {"imgs": case["que_imgs"].cuda()}, "eval": True})
+    got = out["ref_vp_logits"].cpu().numpy()
+    err = np.abs(got - g["logits"]).max()
+    spread = float(np.sort(g["logits"][0])[-1] - np.sort(g["logits"][0])[-2])
+    record("test_selector_headline_lowp", f"{mode} 64x5 logits vs reference golden (top-2 margin {spread:.3f})", err,
+           {"bf16": 0.5, "fp16": 0.1}[mode])
+    assert np.array_equal(got.argmax(1), g["logits"].argmax(1)), (err, spread)
+    assert err <= {"bf16": 0.5, "fp16": 0.1}[mode]
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+def test_detector_headline_lowp(golden, mode):
+    g = golden("det_head")
+    net = _net("detector", math_mode=mode)
+    case = synth.detector_case(32, 480, 640)
+    with torch.no_grad():
+        out = net({"ref_imgs_info": {"imgs": case["ref_imgs"].cuda()}, "que_imgs_info": {"imgs": case["que_imgs"].cuda()}})
+    err = np.abs(out["scores"].cpu().numpy() - g["scores"]).max() / max(np.abs(g["scores"]).max(), 1.0)
+    record("test_detector_headline_lowp", f"{mode} 480x640x32 scores vs reference golden", err, 5e-2, note="relative to range")
+    assert np.array_equal(out["que_select_id"].cpu().numpy(), g["que_select_id"])
+    assert err <= 5e-2
