@@ -7,8 +7,8 @@
 // i.e. 16 independent GEMMs  D_ab[tile][co] = sum_ci V_ab[tile][ci] * U_ab[ci][co]  with 2.25x fewer multiplications
 // than the direct form.  Mapping to v_mfma_f32_32x32x2_f32 (M = tiles, N = co, K = ci):
 //
-//   block  = 256 threads = 4 waves = 64 Winograd tiles (four "quarters" of 4x4 tiles = 8x8 output pixels each: a 2x2
-//            arrangement inside one image, or — for maps of <= 8x8 pixels — one quarter from each of four images) x 64
+//   block  = 256 threads = 4 waves = 64 Winograd tiles (four "quarters" of 4x4 tiles = 8x8 output pixels each, consecutive
+//            entries of the flat list of all quarters of all images) x 64
 //            output channels; wave (wm, wn) owns 32 tiles x 32 channels for ALL 16 (a,b) positions: 16 accumulator
 //            tiles = 256 accumulator registers per lane, one wave per SIMD.  Because a lane holds all 16 D_ab of its
 //            (tile, co) elements, the output transform, bias, ReLU and the 2x2 max-pool (= max over the 4 outputs of a
@@ -46,7 +46,7 @@ namespace {
 struct WinoArgs {
   const float* in; const float* U; const float* bias; float* out_full; float* out_pool;
   int N, H, W, Cin, ld_in, Cout, ld_full, ld_pool, relu;
-  int QH, QW, BH, BW, four_images;
+  int QH, QW;
   int splits, chunks_per_split; float* ws;       // splits > 1: partial outputs [split][N][H][W][Cout] (no bias / ReLU / pool)
 };
 
@@ -54,17 +54,17 @@ __device__ __forceinline__ f32x4 ldg4(const float* __restrict__ base, int elem_o
   return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + ((unsigned)elem_off << 2));
 }
 
-// quarter q of this block -> image, first output row / column, validity
+// quarter q of this block -> image, first output row / column, validity.  The quarters (8x8 output pixels) of all images
+// form one flat list, four consecutive ones per block: no block-level padding on odd quarter counts, and small maps
+// (<= 8x8 pixels = one quarter per image) simply put four images into a block.
 __device__ __forceinline__ void quarter_of(const WinoArgs& p, int q, int& n, int& oy0, int& ox0, bool& valid) {
-  if (p.four_images) {
-    n = blockIdx.x * 4 + q; oy0 = 0; ox0 = 0; valid = n < p.N;
-  } else {
-    int b = blockIdx.x;
-    const int bx = b % p.BW; b /= p.BW;
-    const int by = b % p.BH; n = b / p.BH;
-    const int qy = 2 * by + (q >> 1), qx = 2 * bx + (q & 1);
-    oy0 = 8 * qy; ox0 = 8 * qx; valid = (qy < p.QH) & (qx < p.QW);
-  }
+  const int Q = blockIdx.x * 4 + q;
+  const int per = p.QH * p.QW;
+  valid = Q < p.N * per;
+  n = valid ? Q / per : 0;
+  const int r = valid ? Q - n * per : 0;
+  const int qy = r / p.QW, qx = r - qy * p.QW;
+  oy0 = 8 * qy; ox0 = 8 * qx;
 }
 
 __global__ void __launch_bounds__(256, 1) wino_conv3x3_kernel(const WinoArgs p) {
@@ -315,9 +315,7 @@ extern "C" int g6d_wino_conv3x3(const float* in, int N, int H, int W, int Cin, i
   a.in = in; a.U = U; a.bias = bias; a.out_full = out_full; a.out_pool = out_pool;
   a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.ld_in = ld_in; a.Cout = Cout; a.ld_full = ld_full; a.ld_pool = ld_pool; a.relu = relu;
   a.QH = (H + 7) / 8; a.QW = (W + 7) / 8;
-  a.four_images = (a.QH == 1 && a.QW == 1) ? 1 : 0;
-  a.BH = (a.QH + 1) / 2; a.BW = (a.QW + 1) / 2;
-  const long long blocks = a.four_images ? (N + 3) / 4 : (long long)N * a.BH * a.BW;
+  const long long blocks = ((long long)N * a.QH * a.QW + 3) / 4;
   if (blocks > 0x7fffffffll) { g6d_set_error("wino_conv3x3: grid too large"); return G6D_EINVAL; }
   // split the channel chunks when the grid leaves most of the chip idle (each block is a serial loop over the chunks)
   const int nchunks = Cin / 8;
