@@ -26,6 +26,7 @@ import os
 import sys
 import time
 
+import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -87,6 +88,10 @@ def main():
     ap.add_argument("--lowp", default="bf16,fp16",
                     help="comma list of reduced-precision matrix-core modes measured AFTER the fp32 headline (same launch mode, "
                          "same steps) and reported in the `lowp` object: operands bf16 / fp16, fp32 accumulate; '' = skip")
+    ap.add_argument("--chained", action="store_true",
+                    help="additionally time the device-resident predict chain (gen6d_amd/chain.py: detection -> crop -> selection "
+                         "-> pose -> 3 x refine with every inter-stage warp and the pose algebra on the GPU, one captured graph "
+                         "per lane) on a procedural 480x640 database with REAL data flow between the stages; reported as `chained`")
     ap.add_argument("--cpu-reps", type=int, default=3, help="timed CPU-oracle runs after one warm-up (min is reported)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="cap on torch CPU threads for the baseline (0 = physical cores)")
     ap.add_argument("--no-graph", action="store_true", help="time the eager launch path instead of hipGraph replay")
@@ -301,6 +306,36 @@ def main():
         lowp[mode] = entry
     if lowp:
         result["lowp"] = lowp
+
+    if args.chained and world == 1:
+        # the estimator-level path: the crop fed to the selector comes from the detection, the refiner inputs from the pose of
+        # the previous stage (bench headline: canned crops / poses)
+        from gen6d_amd.estimator import Gen6DEstimator
+        from gen6d_amd.synth_db import SyntheticDatabase
+        tb = time.perf_counter()
+        db = SyntheticDatabase(n_views=88, size=(480, 640), focal=560.0)
+        est = Gen6DEstimator({"ref_view_num": args.sel_refs, "det_ref_view_num": args.det_refs, "refine_iter": 3},
+                             modules={"detector": pipe.detector, "selector": pipe.selector, "refiner": pipe.refiner})
+        est.build(db, "all")
+        torch.cuda.synchronize()
+        cbuild = time.perf_counter() - tb
+        _, qids = db.get_split("all")
+        imgs = [torch.from_numpy(db.get_image(i)).to(dev) for i in qids[:8]]
+        Ks = [db.get_K(i) for i in qids[:8]]
+        n_c = max(args.steps, 8)
+        qi = [imgs[i % 8] for i in range(n_c + lanes)]
+        qk = [Ks[i % 8] for i in range(n_c + lanes)]
+        chain = est.device_chain()
+        chain.predict_many(qi[:lanes], qk[:lanes], lanes)                 # capture + warm-up
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        res = chain.predict_many(qi[:n_c], qk[:n_c], lanes)
+        cdt = time.perf_counter() - t1
+        host_p, _ = est.predict(imgs[0], Ks[0])
+        result["chained"] = {"value": n_c / cdt, "unit": "images/s", "ms_per_query": cdt / n_c * 1e3, "queries": n_c, "lanes": lanes,
+                             "database": "procedural sphere, 66 reference views 480x640, 64/32 selected; build incl. rendering "
+                                         f"{cbuild:.1f} s", "finite": bool(all(np.isfinite(p).all() for p, _ in res)),
+                             "first_pose_vs_host_driven_predict_maxabs": float(np.abs(res[0][0] - host_p).max())}
 
     def row_diff(got, ref):
         """Row layout: position(2, px), scale, ref_idx, angle, quaternion(4), offset(2), log2-scale."""

@@ -1,0 +1,141 @@
+"""Device-resident `Gen6DEstimator.predict` (BASELINE configs[4]): detect -> crop -> select -> pose ->
+refine_iter x (look-at crop, reference selection + alignment, refiner, pose update) as ONE chain of kernel launches with no
+host synchronisation between the stages — the pose algebra and warp parameters the reference computes on the host
+(estimator.py:173-216, network/refiner.py:275-341) run in the single-thread float64 kernels of csrc/pose_chain.hip.  The chain
+is therefore capturable in a hipGraph, and `predict_many` keeps several queries in flight on separate streams, which is
+how bench.py fills the chip.
+
+Reference state resident on the GPU (built once per object by `DeviceChain(estimator)` after `estimator.build`):
+  * detector / selector reference state inside the networks (as before) + the 64 selected views' poses and intrinsics;
+  * for the refiner: the farthest-point subset (<= 128 views) of the reference images as one uint8 stack [n,H,W,3] plus
+    their normalised poses and intrinsics — the reference re-reads these from disk on every refinement step.
+"""
+import numpy as np
+import torch
+
+from . import estimator as E
+from . import geometry as G
+from . import ops
+
+
+class DeviceChain:
+    REF_NUM = 6
+    MARGIN = 0.05
+
+    def __init__(self, est, even_num=128):
+        self.est = est
+        self.dev = est.device
+        self.size = int(est.cfg["ref_resolution"])
+        self.refine_iter = int(est.cfg["refine_iter"]) if est.refiner is not None else 0
+        info = est.ref_info
+        f = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.dev)
+        self.ref_poses = f(info["poses"]).reshape(-1, 12)
+        self.ref_Ks = f(info["Ks"]).reshape(-1, 9)
+        self.center = f(info["center"])
+        if self.refine_iter:
+            db = est.refiner.ref_database
+            ndb = E.NormalizedDatabase(db)
+            ids_all = np.asarray(est.refiner.ref_ids)
+            even = min(even_num, len(ids_all))
+            poses = np.asarray([ndb.get_pose(i) for i in ids_all])
+            cams = np.asarray([G.pose_inverse(p)[:, 3] for p in poses])
+            sub = G.sample_fps_points(cams, even + 1, True)          # the `ref_even=True` subset of refine_que_imgs
+            self.sub_ids = ids_all[sub]
+            self.sub_poses = f(poses[sub]).reshape(-1, 12)
+            self.sub_Ks = f(np.asarray([ndb.get_K(i) for i in self.sub_ids])).reshape(-1, 9)
+            self.norm = f(np.concatenate([[ndb.scale], ndb.offset]))
+            imgs = [np.ascontiguousarray(db.get_image(i)) for i in self.sub_ids]
+            if len({im.shape for im in imgs}) != 1:
+                raise ValueError("DeviceChain: the reference images of one object must share one size")
+            self.stack = torch.from_numpy(np.stack(imgs, 0)).to(self.dev)
+        self._lanes = None
+
+    # ------------------------------------------------------------------ one query, no host synchronisation
+    def query(self, que_img, que_K):
+        """que_img uint8 [H,W,3] and que_K float32 [3,3], both on the device -> dict of device tensors:
+        'pose' [3,4], 'det' [5] (x, y, 2^scale, cell), 'sel' [2] (reference index, in-plane angle), 'logits' [rfn]."""
+        est, size = self.est, self.size
+        with torch.no_grad():
+            x = que_img.permute(2, 0, 1)[None].float().div_(255)
+            det = est.detector.detect_impl(x.contiguous())
+            det5 = torch.cat([det["positions"][0], det["scales"][0:1], det["que_select_id"][0].float()]).contiguous()
+            crop = ops.warp_batch(None, que_img, None, ops.chain_crop_from_detection(det5, size), size, size)
+            logits, angles = est.selector.compute_view_point_feats(crop)
+            que_K9 = que_K.reshape(9).contiguous()
+            pose, sel = ops.chain_pose_from_selection(det5, logits[0].contiguous(), angles[0].contiguous(), self.ref_poses, self.ref_Ks,
+                                                      que_K9, self.center)
+            poses = [pose]
+            R = self.REF_NUM
+            for _ in range(self.refine_iter):
+                geo, idx = ops.chain_refine_prepare(pose.reshape(12), que_K9, self.norm, size, self.MARGIN, self.sub_poses, self.sub_Ks, R)
+                hinv = geo[33 + 21 * R:].view(1 + R, 9)
+                imgs = torch.empty((1 + R, 3, size, size), dtype=torch.float32, device=self.dev)
+                ops.warp_batch(None, que_img, None, hinv[0:1], size, size, out=imgs[0:1])
+                ops.warp_batch(self.stack, None, idx, hinv[1:], size, size, out=imgs[1:])
+                rot, off, scl = est.refiner._step(imgs[0:1], geo[0:9].view(3, 3), geo[9:21].view(3, 4), imgs[1:],
+                                                  geo[33:33 + 9 * R].view(R, 3, 3), geo[33 + 9 * R:33 + 21 * R].view(R, 3, 4))
+                pose = ops.chain_refine_update(rot[0].contiguous(), off[0].contiguous(), scl[0].contiguous(), geo, self.norm)
+                poses.append(pose)
+        return {"pose": pose, "det": det5, "sel": sel, "logits": logits[0], "refine_poses": poses, "crop": crop}
+
+    # ------------------------------------------------------------------ hipGraph lanes
+    def capture(self, img_shape, lanes=3, warmup=2):
+        """One captured copy of the whole chain per lane (own static input / output buffers, shared read-only reference state)."""
+        d = self.dev
+        old_serial, ops.SERIAL = ops.SERIAL, True          # whole queries in flight; no intra-query stream forks
+        try:
+            self._lanes = []
+            for _ in range(lanes):
+                g_img = torch.zeros(img_shape, dtype=torch.uint8, device=d)
+                g_K = torch.eye(3, dtype=torch.float32, device=d)
+                g_K[0, 0] = g_K[1, 1] = 500.0; g_K[0, 2] = img_shape[1] / 2; g_K[1, 2] = img_shape[0] / 2
+                stream = torch.cuda.Stream(device=d)
+                stream.wait_stream(torch.cuda.current_stream(d))
+                with torch.cuda.stream(stream):
+                    for _ in range(warmup):
+                        self.query(g_img, g_K)
+                torch.cuda.synchronize(d)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=stream):
+                    out = self.query(g_img, g_K)
+                keep = torch.cat([out["pose"].reshape(12), out["det"], out["sel"]])
+                self._lanes.append((graph, stream, g_img, g_K, out, keep))
+            torch.cuda.synchronize(d)
+        finally:
+            ops.SERIAL = old_serial
+        return self
+
+    def enqueue(self, lane, que_img, que_K):
+        """Replay lane `lane` on its stream for this query; returns (row [19] = pose(12) | det(5) | sel(2), stream).  The caller
+        synchronises (event on the stream) before reusing the lane."""
+        graph, stream, g_img, g_K, out, _ = self._lanes[lane]
+        stream.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(stream):
+            g_img.copy_(que_img, non_blocking=True)
+            g_K.copy_(que_K, non_blocking=True)
+            graph.replay()
+            row = torch.cat([out["pose"].reshape(12), out["det"], out["sel"]])
+        return row, stream
+
+    def predict_many(self, que_imgs, que_Ks, lanes=3):
+        """Queries [(H,W,3) uint8 numpy or device tensors], intrinsics [3,3] -> list of (pose [3,4] float32 numpy, inter dict).
+        Several queries are kept in flight (one captured graph per lane); ONE host synchronisation at the end."""
+        imgs = [q if torch.is_tensor(q) else torch.from_numpy(np.ascontiguousarray(q)) for q in que_imgs]
+        if self._lanes is None or len(self._lanes) != lanes or tuple(self._lanes[0][2].shape) != tuple(imgs[0].shape):
+            self.capture(tuple(imgs[0].shape), lanes)
+        busy, rows = [None] * lanes, []
+        for i, (img, K) in enumerate(zip(imgs, que_Ks)):
+            lane = i % lanes
+            if busy[lane] is not None:
+                busy[lane].synchronize()
+            K_t = K if torch.is_tensor(K) else torch.from_numpy(np.ascontiguousarray(K, dtype=np.float32))
+            row, stream = self.enqueue(lane, img.to(self.dev, non_blocking=True), K_t.to(self.dev, non_blocking=True))
+            ev = torch.cuda.Event(); ev.record(stream)
+            busy[lane] = ev
+            rows.append(row)
+        torch.cuda.synchronize(self.dev)
+        out = []
+        for r in torch.stack(rows, 0).cpu().numpy():
+            out.append((r[:12].reshape(3, 4).astype(np.float32),
+                        {"det_position": r[12:14], "det_scale_r2q": float(r[14]), "sel_ref_idx": int(r[17]), "sel_angle_r2q": float(r[18])}))
+        return out

@@ -331,4 +331,31 @@ class Gen6DEstimator:
         return np.asarray(pose_pr, np.float32), inter
 
 
+    # ------------------------------------------------------------------ device-resident variants (gen6d_amd/chain.py)
+    def device_chain(self):
+        """The whole of `predict` as one chain of launches on reference state resident in HBM (built lazily after `build`)."""
+        from .chain import DeviceChain
+        if getattr(self, "_chain", None) is None or self._chain_info is not self.ref_info:
+            self._chain, self._chain_info = DeviceChain(self), self.ref_info
+        return self._chain
+
+    def predict_device(self, que_img, que_K):
+        """`predict` without host round trips between the stages: que_img uint8 [H,W,3] (numpy or device tensor), que_K [3,3]
+        -> (pose [3,4] float32 numpy, inter) with one synchronisation at the end."""
+        chain = self.device_chain()
+        img = que_img if torch.is_tensor(que_img) else torch.from_numpy(np.ascontiguousarray(que_img))
+        K = torch.from_numpy(np.ascontiguousarray(que_K, dtype=np.float32)).to(self.device)
+        out = chain.query(img.to(self.device), K)
+        det, sel = out["det"].cpu().numpy(), out["sel"].cpu().numpy()
+        inter = {"det_position": det[:2], "det_scale_r2q": float(det[2]), "det_que_img": None, "sel_angle_r2q": float(sel[1]),
+                 "sel_scores": out["logits"].cpu().numpy(), "sel_ref_idx": int(sel[0]),
+                 "refine_poses": [p.cpu().numpy() for p in out["refine_poses"]]}
+        return out["pose"].cpu().numpy().astype(np.float32), inter
+
+    def predict_many(self, que_imgs, que_Ks, lanes=3):
+        """Several queries in flight at once (one captured hipGraph of the whole chain per lane), one synchronisation at the
+        end: [(pose, inter)] in query order (BASELINE configs[4]: batched multi-query stream)."""
+        return self.device_chain().predict_many(que_imgs, que_Ks, lanes)
+
+
 name2estimator = {"gen6d": Gen6DEstimator}

@@ -512,3 +512,70 @@ def warp_perspective(src_u8, H, dh, dw, out_float=False):
     _lib.check(_lib.load().g6d_warp_perspective(_ptr(src_u8), sh, sw, ch, (C.c_float * 9)(*hinv.tolist()), _ptr(dst), dh, dw,
                                                int(out_float), 1.0 / 255.0, _stream()), "g6d_warp_perspective")
     return dst
+
+
+# ------------------------------------------------------------------------------------------------ device-resident chain
+def _f32c(*ts):
+    for t in ts:
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise ValueError("chain ops: contiguous float32 device tensors expected")
+
+
+def chain_crop_from_detection(det, size):
+    """det [5] (g6d_detector_decode result) -> hinv [1,9] of the selector crop."""
+    _need_gpu(det); _f32c(det)
+    hinv = torch.empty((1, 9), dtype=torch.float32, device=det.device)
+    _lib.check(_lib.load().g6d_chain_crop_from_detection(_ptr(det), float(size), _ptr(hinv), _stream()), "g6d_chain_crop_from_detection")
+    return hinv
+
+
+def chain_pose_from_selection(det, logits, angles, ref_poses, ref_Ks, que_K, center):
+    """-> pose [3,4], sel [2] = (reference index, in-plane angle), all on the device."""
+    _need_gpu(det, logits, angles, ref_poses, ref_Ks, que_K, center); _f32c(det, logits, angles, ref_poses, ref_Ks, que_K, center)
+    pose = torch.empty((3, 4), dtype=torch.float32, device=det.device)
+    sel = torch.empty((2,), dtype=torch.float32, device=det.device)
+    _lib.check(_lib.load().g6d_chain_pose_from_selection(_ptr(det), _ptr(logits), _ptr(angles), logits.numel(), _ptr(ref_poses),
+                                                        _ptr(ref_Ks), _ptr(que_K), _ptr(center), _ptr(pose), _ptr(sel), _stream()),
+               "g6d_chain_pose_from_selection")
+    return pose, sel
+
+
+def chain_refine_prepare(pose_in, que_K, norm, size, margin, sub_poses, sub_Ks, ref_num):
+    """-> geo [42 + 30*ref_num] float32 (see include/gen6d_hip.h), ref_idx [ref_num] int32."""
+    _need_gpu(pose_in, que_K, norm, sub_poses, sub_Ks); _f32c(pose_in, que_K, norm, sub_poses, sub_Ks)
+    geo = torch.empty((42 + 30 * ref_num,), dtype=torch.float32, device=pose_in.device)
+    idx = torch.empty((ref_num,), dtype=torch.int32, device=pose_in.device)
+    _lib.check(_lib.load().g6d_chain_refine_prepare(_ptr(pose_in), _ptr(que_K), _ptr(norm), float(size), float(margin), _ptr(sub_poses),
+                                                   _ptr(sub_Ks), sub_poses.shape[0], int(ref_num), _ptr(geo), _ptr(idx), _stream()),
+               "g6d_chain_refine_prepare")
+    return geo, idx
+
+
+def chain_refine_update(rot, off, scl, geo, norm):
+    _need_gpu(rot, off, scl, geo, norm); _f32c(rot, off, scl, geo, norm)
+    pose = torch.empty((3, 4), dtype=torch.float32, device=geo.device)
+    _lib.check(_lib.load().g6d_chain_refine_update(_ptr(rot), _ptr(off), _ptr(scl), _ptr(geo), _ptr(norm), _ptr(pose), _stream()),
+               "g6d_chain_refine_update")
+    return pose
+
+
+def warp_batch(stack, single, idx, hinv, dh, dw, out=None):
+    """stack uint8 [n,sh,sw,ch] or None, single uint8 [sh,sw,ch] or None, idx int32 [B] or None, hinv float32 [B,9]
+    -> float32 [B,ch,dh,dw] in [0,1] (uint8-rounded); `out`: optional contiguous destination (e.g. rows of a larger batch)."""
+    src = stack if stack is not None else single
+    _need_gpu(src, hinv)
+    if src.dtype != torch.uint8 or not src.is_contiguous() or (single is not None and (single.dtype != torch.uint8 or not single.is_contiguous())):
+        raise ValueError("warp_batch: contiguous uint8 sources expected")
+    if stack is not None and single is not None and tuple(stack.shape[1:]) != tuple(single.shape):
+        raise ValueError("warp_batch: stack and single image sizes differ")
+    sh, sw, ch = src.shape[-3:]
+    B = hinv.shape[0]
+    _f32c(hinv)
+    if idx is not None and (idx.dtype != torch.int32 or idx.numel() != B):
+        raise ValueError("warp_batch: idx must be int32 [B]")
+    dst = out if out is not None else torch.empty((B, ch, dh, dw), dtype=torch.float32, device=src.device)
+    if tuple(dst.shape) != (B, ch, dh, dw) or dst.dtype != torch.float32 or not dst.is_contiguous():
+        raise ValueError("warp_batch: out must be a contiguous float32 [B,ch,dh,dw] tensor")
+    _lib.check(_lib.load().g6d_warp_batch(_ptr(stack), _ptr(single), _ptr(idx), B, sh, sw, ch, _ptr(hinv), _ptr(dst), dh, dw, _stream()),
+               "g6d_warp_batch")
+    return dst

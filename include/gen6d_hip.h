@@ -230,6 +230,40 @@ int g6d_affine_act_add(const float* in, int ld_in, const float* scale, const flo
 int g6d_warp_perspective(const unsigned char* src, int sh, int sw, int ch, const float* hinv, void* dst, int dh, int dw,
                          int out_float, float out_scale, g6d_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Device-resident inter-stage glue: what Gen6DEstimator.predict computes on the HOST between the
+ * network calls, as single-launch kernels on device buffers (float32 in memory, float64 arithmetic), so that
+ * detect -> crop -> select -> pose -> 3 x refine is one chain of launches without host synchronisation (hipGraph-capturable).
+ * All pointers are DEVICE pointers.  3x3 matrices are row-major [9], poses row-major [3][4] = [12].
+ * ---------------------------------------------------------------------------------------------------------------- */
+/* det = result of g6d_detector_decode (x, y, 2^scale, ...) -> hinv[9]: destination->source map of
+ * transformation_crop(que_img, position, 1/scale_r2q, 0, size) (estimator.py:184, utils/base_utils.py:646-655) */
+int g6d_chain_crop_from_detection(const float* det, float size, float* hinv, g6d_stream_t stream);
+/* arg-max viewpoint (first maximum) + estimate_pose_from_similarity_transform_compose (estimator.py:193-206,
+ * utils/pose_utils.py:12-49,104-111): logits/angles [rfn], ref_poses [rfn][12], ref_Ks [rfn][9] -> pose_out[12],
+ * sel_out[2] = (selected reference index, its in-plane angle) */
+int g6d_chain_pose_from_selection(const float* det, const float* logits, const float* angles, int rfn, const float* ref_poses,
+                                  const float* ref_Ks, const float* que_K, const float* center, float* pose_out, float* sel_out,
+                                  g6d_stream_t stream);
+/* Geometry of one refinement step before the network (network/refiner.py:275-313, utils/database_utils.py:54-139 on the
+ * NormalizedDatabase): pose_in[12] in the database frame, que_K[9], norm[4] = (NormalizedDatabase.scale, offset xyz),
+ * sub_poses [n_sub][12] / sub_Ks [n_sub][9] = normalised poses and intrinsics of the (FPS) reference subset, n_sub <= 128.
+ * Writes ref_idx[ref_num] (the views most aligned with the warped input pose) and the record
+ *   geo = K_warp[9] | pose_warp[12] | pose_rect[12] | ref_Ks[ref_num][9] | ref_poses[ref_num][12] | hinv[1+ref_num][9]
+ * (42 + 30*ref_num floats; hinv[0] warps the query, hinv[1+k] reference k: inputs of g6d_warp_batch). */
+int g6d_chain_refine_prepare(const float* pose_in, const float* que_K, const float* norm, float size, float margin,
+                             const float* sub_poses, const float* sub_Ks, int n_sub, int ref_num, float* geo, int* ref_idx,
+                             g6d_stream_t stream);
+/* Refiner outputs (rotation[4] w-first, offset[2], log2 scale[1]) + the step's geo record -> refined pose in the database frame
+ * (refiner.py:327-341: compose_sim_pose, pose_sim_to_pose_rigid with the polar factor of the SVD, un-rectify, denormalise). */
+int g6d_chain_refine_update(const float* rot, const float* off, const float* scl, const float* geo, const float* norm,
+                            float* pose_out, g6d_stream_t stream);
+/* Batched g6d_warp_perspective with homographies and source selection in device memory, output in the layout the networks
+ * take: dst [B][ch][dh][dw] float = rint(bilinear)/255 (the uint8 image cv2.warpPerspective would return, scaled to [0,1]);
+ * image b reads `single` when idx == NULL or idx[b] < 0, else stack[idx[b]] (uint8 [.][sh][sw][ch]); hinv [B][9]. */
+int g6d_warp_batch(const unsigned char* stack, const unsigned char* single, const int* idx, int B, int sh, int sw, int ch,
+                   const float* hinv, float* dst, int dh, int dw, g6d_stream_t stream);
+
 /* Small-batch linear layer, weight-streaming GEMV (network/refiner.py:153-166): out[b][o] = act(W[o].x[b] + bias[o]);
  * W [O][K] row-major, x [B][K], B <= 8; act as G6dConv.out_act. */
 int g6d_linear_gemv(const float* x, int B, int K, const float* W, const float* bias, int O, int act, float* out,

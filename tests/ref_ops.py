@@ -267,6 +267,80 @@ def warp_perspective(src_u8, H, dh, dw, out_float=False):
     return out.to(src_u8.device)
 
 
+# ---- device-resident chain ops emulated with the HOST pose algebra (gen6d_amd/geometry.py)
+def _np(t):
+    import numpy as np
+    return t.detach().cpu().numpy().astype(np.float64)
+
+
+def chain_crop_from_detection(det, size):
+    import numpy as np
+    from gen6d_amd import geometry as G
+    d = _np(det)
+    M = np.concatenate([G.crop_transform(d[:2], 1 / d[2], 0, size), [[0, 0, 1]]], 0)
+    return torch.from_numpy(np.linalg.inv(M).reshape(1, 9).astype(np.float32))
+
+
+def chain_pose_from_selection(det, logits, angles, ref_poses, ref_Ks, que_K, center):
+    import numpy as np
+    from gen6d_amd import geometry as G
+    d, lg, an = _np(det), _np(logits), _np(angles)
+    i = int(np.argmax(lg))
+    pose = G.estimate_pose_from_similarity_transform_compose(d[:2], d[2], an[i], _np(ref_poses)[i].reshape(3, 4), _np(ref_Ks)[i].reshape(3, 3),
+                                                             _np(que_K).reshape(3, 3), _np(center))
+    return torch.from_numpy(pose.astype(np.float32)), torch.tensor([float(i), float(an[i])])
+
+
+def chain_refine_prepare(pose_in, que_K, norm, size, margin, sub_poses, sub_Ks, ref_num):
+    import numpy as np
+    from gen6d_amd import geometry as G
+    nm = _np(norm); c0 = np.zeros(3)
+    in_pose = G.normalize_pose(_np(pose_in).reshape(3, 4), nm[0], nm[1:]).astype(np.float64)
+    K = _np(que_K).reshape(3, 3)
+    _, new_f = G.let_me_look_at(in_pose, K, c0)
+    scale = size * (1 - margin) / 2.0 * np.linalg.norm(G.pose_inverse(in_pose)[:, 3]) / new_f
+    K_warp, pose_warp, pose_rect, H = G.look_at_crop_params(K, in_pose, G.project_points(c0[None], in_pose, K)[0][0], 0, scale, size, size)
+    sp, sk = _np(sub_poses).reshape(-1, 3, 4), _np(sub_Ks).reshape(-1, 3, 3)
+    idx = np.argsort(-G.view_correlation(pose_warp[None].astype(np.float64), sp, c0)[0], kind="stable")[:ref_num]
+    Ks, poses, hinvs = [], [], [np.linalg.inv(H)]
+    for i in idx:
+        cen = G.project_points(c0[None], sp[i], sk[i])[0][0]
+        f_look = G.let_me_look_at(sp[i], sk[i], c0)[1]
+        _, ang = G.scale_rotation_difference_from_cameras(sp[i][None], pose_warp[None].astype(np.float64), sk[i][None],
+                                                          K_warp[None].astype(np.float64), c0)
+        Kn, pn, _, Hr = G.look_at_crop_params(sk[i], sp[i], cen, ang[0], size * (1 - margin) / 2.0 * np.linalg.norm(G.pose_inverse(sp[i])[:, 3]) / f_look,
+                                              size, size)
+        Ks.append(Kn); poses.append(pn); hinvs.append(np.linalg.inv(Hr))
+    geo = np.concatenate([np.ravel(K_warp), np.ravel(pose_warp), np.ravel(pose_rect), np.ravel(Ks), np.ravel(poses), np.ravel(hinvs)])
+    return torch.from_numpy(geo.astype(np.float32)), torch.from_numpy(idx.astype(np.int32))
+
+
+def chain_refine_update(rot, off, scl, geo, norm):
+    import numpy as np
+    from gen6d_amd import geometry as G
+    g, nm, c0 = _np(geo), _np(norm), np.zeros(3)
+    K_warp, pose_warp, pose_rect = g[:9].reshape(3, 3), g[9:21].reshape(3, 4), g[21:33].reshape(3, 4)
+    sim = G.compose_sim_pose(2 ** float(_np(scl)[0]), _np(rot), _np(off), pose_warp, c0)
+    pr = G.pose_compose(G.pose_sim_to_pose_rigid(sim, pose_warp, K_warp, K_warp, c0), G.pose_inverse(pose_rect))
+    return torch.from_numpy(G.denormalize_pose(pr, nm[0], nm[1:]).astype(np.float32))
+
+
+def warp_batch(stack, single, idx, hinv, dh, dw, out=None):
+    import numpy as np
+    B = hinv.shape[0]
+    res = []
+    for b in range(B):
+        sel = -1 if idx is None else int(idx[b])
+        src = single if sel < 0 else stack[sel]
+        H = np.linalg.inv(_np(hinv[b]).reshape(3, 3))
+        res.append(warp_perspective(src, H, dh, dw).float().div(255).permute(2, 0, 1))
+    r = torch.stack(res, 0)
+    if out is not None:
+        out.copy_(r)
+        return out
+    return r
+
+
 def patch_ops(monkeypatch):
     """Route gen6d_amd.ops.* to the references above (CPU host-logic tests only)."""
     import sys

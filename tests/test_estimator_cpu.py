@@ -47,3 +47,23 @@ def test_build_and_predict_contract(monkeypatch):
     # pose_init skips detection/selection (predict.py:56-59)
     pose3, inter3 = est.predict(img, K, pose_init=db.get_pose(que_ids[0]))
     assert "det_position" not in inter3 and pose3.shape == (3, 4) and np.isfinite(pose3).all()
+
+
+def test_device_chain_matches_host_predict(monkeypatch):
+    """DeviceChain.query (the launch sequence of the device-resident predict) with every op emulated on the CPU — the chain
+    ops by the host pose algebra — reproduces Gen6DEstimator.predict: same detection, same viewpoint, same refined pose."""
+    ref_ops.patch_ops(monkeypatch)
+    db = SyntheticDatabase(n_views=24, size=(96, 128), focal=140.0)
+    est = make_estimator(refine_iter=1)
+    est.build(db, "all")
+    _, que_ids = db.get_split("all")
+    img, K = db.get_image(que_ids[2]), db.get_K(que_ids[2])
+    pose_h, inter_h = est.predict(img, K)
+    pose_d, inter_d = est.predict_device(img, K)
+    assert inter_d["sel_ref_idx"] == inter_h["sel_ref_idx"]
+    np.testing.assert_allclose(inter_d["det_position"], inter_h["det_position"], atol=1e-3)
+    assert len(inter_d["refine_poses"]) == 2
+    np.testing.assert_allclose(inter_d["refine_poses"][0], inter_h["refine_poses"][0], atol=1e-5)     # pose from detection + selection
+    # one refinement step from the same pose: the crops differ by single grey levels (float32 vs float64 homographies), which
+    # the randomly initialised refiner amplifies; iterating it is chaotic (see test_estimator_gpu.py), so one step is compared
+    np.testing.assert_allclose(pose_d, pose_h, atol=2e-2)
