@@ -317,20 +317,28 @@ extern "C" int g6d_wino_conv3x3(const float* in, int N, int H, int W, int Cin, i
   a.QH = (H + 7) / 8; a.QW = (W + 7) / 8;
   const long long blocks = ((long long)N * a.QH * a.QW + 3) / 4;
   if (blocks > 0x7fffffffll) { g6d_set_error("wino_conv3x3: grid too large"); return G6D_EINVAL; }
-  // split the channel chunks when the grid leaves most of the chip idle (each block is a serial loop over the chunks)
+  // Split of the channel chunks over gridDim.z.  One block per CU is resident (512 registers per lane, 108 KB of LDS) and
+  // runs a serial loop of ~2.7 us per chunk, so a launch takes ceil(grid / 256) rounds of (chunks per block) steps: small
+  // grids leave CUs idle and grids just above a multiple of 256 pay a nearly empty last round.  Pick the split count with
+  // the smallest modelled time (rounds x block time + the reduce pass over the partial outputs).
   const int nchunks = Cin / 8;
   int splits = 1;
   const long long grid2 = blocks * (Cout / 64);
-  static const int split_target = []() { const char* e = getenv("G6D_WINO_SPLIT_TARGET"); return e ? atoi(e) : 384; }();
-  if (grid2 < 192 && workspace && split_target > 0) {
-    splits = (int)((split_target + grid2 - 1) / grid2);
-    if (splits > nchunks / 2) splits = nchunks / 2;
-    if (splits > 32) splits = 32;
-    const size_t per = (size_t)N * H * W * Cout * sizeof(float);
-    if ((size_t)splits * per > workspace_bytes) splits = (int)(workspace_bytes / per);
-    if (splits < 2) splits = 1;
-    if ((ld_full & 3) || (ld_pool & 3) || (out_full && !g6d_aligned16(out_full)) || (out_pool && !g6d_aligned16(out_pool)) ||
-        (bias && !g6d_aligned16(bias)) || !g6d_aligned16(workspace)) splits = 1;
+  static const int split_max = []() { const char* e = getenv("G6D_WINO_SPLIT_MAX"); return e ? atoi(e) : 32; }();
+  const bool can_reduce = workspace && !(ld_full & 3) && !(ld_pool & 3) && (!out_full || g6d_aligned16(out_full)) &&
+                          (!out_pool || g6d_aligned16(out_pool)) && (!bias || g6d_aligned16(bias)) && g6d_aligned16(workspace);
+  if (can_reduce && split_max > 1 && nchunks >= 4) {
+    const double out_bytes = (double)N * H * W * Cout * sizeof(float);
+    double best = 1e30;
+    for (int sp = 1; sp <= split_max && sp <= nchunks / 2; ++sp) {
+      if ((double)sp * out_bytes > (double)workspace_bytes) break;
+      const int cps_ = (nchunks + sp - 1) / sp, real = (nchunks + cps_ - 1) / cps_;
+      if (real != sp) continue;
+      const double rounds = (double)((grid2 * sp + 255) / 256);
+      double t = rounds * (cps_ * 2.7 + 4.0);                                   // us: chunks + prologue / epilogue of a block
+      if (sp > 1) t += 6.0 + (sp + 1) * out_bytes / 3.0e6;                      // reduce launch + its traffic at ~3 TB/s
+      if (t < best * 0.97) { best = t; splits = sp; }                           // prefer fewer splits on near-ties
+    }
   }
   const int cps = (nchunks + splits - 1) / splits;
   splits = (nchunks + cps - 1) / cps;

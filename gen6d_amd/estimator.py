@@ -302,7 +302,7 @@ class Gen6DEstimator:
     def predict(self, que_img, que_K, pose_init=None):
         """que_img uint8 [H,W,3], que_K [3,3] -> pose [3,4], intermediate results (reference estimator.py:173-216)."""
         inter = {}
-        que_dev = torch.from_numpy(np.ascontiguousarray(que_img)).to(self.device)
+        que_dev = (que_img if torch.is_tensor(que_img) else torch.from_numpy(np.ascontiguousarray(que_img))).to(self.device)
         if pose_init is None:
             with torch.no_grad():
                 x = que_dev.float().div_(255).permute(2, 0, 1)[None].contiguous()

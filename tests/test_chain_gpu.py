@@ -104,4 +104,6 @@ def test_predict_many_three_lanes(built):
     for (pe, ie), (pm, im_) in zip(eager, many):
         assert im_["sel_ref_idx"] == ie["sel_ref_idx"]
         np.testing.assert_allclose(im_["det_position"], ie["det_position"], atol=1e-3)
-        np.testing.assert_allclose(pm, pe, atol=5e-3)
+        # replay vs eager: statistics atomics reorder (1e-5), a detection that moves by 1e-4 px flips the rounding of a few crop
+        # pixels, and the randomly initialised refiner amplifies single grey levels to ~1e-2 (same effect as in the CPU test)
+        np.testing.assert_allclose(pm, pe, atol=3e-2)
