@@ -250,8 +250,9 @@ def main():
     if wino_p:
         wf = sum(p[0] for p in wino_p)                  # executed (Winograd-domain) FLOPs = direct-form / 2.25
         wms = sum(p[1].elapsed_time(p[2]) for p in wino_p)
-        result["roofline_trunk"] = {
-            "bound": "mfma", "kernel": "g6d_wino_conv3x3 (own VGG trunk, Winograd F(2x2,3x3) on fp32 MFMA) incl. its split reduce",
+        result["roofline_winograd"] = {
+            "bound": "mfma", "kernel": "wino_conv3x3_kernel (Winograd F(2x2,3x3) on fp32 MFMA): the own VGG trunk (g6d_wino_conv3x3) and the "
+                                       "stride-1 3x3 / 3x3x3 layers g6d_conv_igemm routes to it (G6dConv.weight_wino), incl. the split reduce",
             "achieved": wf / (wms * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s executed in the Winograd domain",
             "frac": wf / (wms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
             "achieved_direct_form_equivalent": 2.25 * wf / (wms * 1e-3) / 1e12,

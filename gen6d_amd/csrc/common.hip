@@ -17,7 +17,7 @@ int g6d_check_launch(const char* what) {
   return G6D_ELAUNCH;
 }
 
-extern "C" int g6d_abi_version(void) { return 2; }
+extern "C" int g6d_abi_version(void) { return 3; }
 extern "C" const char* g6d_last_error(void) { return g_err; }
 extern "C" int g6d_sizeof_conv_desc(void) { return (int)sizeof(G6dConv); }
 

@@ -32,6 +32,9 @@ int g6d_splitk_reduce_launch(const float* ws, int splits, int M, int Cout, const
                              int ld_out, double* stats, int rows_per_group, hipStream_t stream);
 // conv_igemm_ws.hip: warp-specialised variant (producer waves load, consumer waves run the MFMAs)
 int g6d_conv_igemm_ws_launch(const G6dConv& d, int M, int T, int nChunks, int bn, int splits, hipStream_t stream);
+// wino_conv.hip: eligible 3x3 / 3x3x3 stride-1 layers with pre-transformed filters (G6dConv.weight_wino) on the Winograd kernel
+bool g6d_wino_eligible(const G6dConv& d);
+int g6d_wino_launch(const G6dConv& d, hipStream_t stream);
 // conv_patch.hip: 3x3 / 3x3x3 stride-1 layers with Cout <= 64: spatial output tile, input patch reused by all taps
 bool g6d_conv_patch_eligible(const G6dConv& d);
 int g6d_conv_patch_launch(const G6dConv& d, int M, hipStream_t stream);
@@ -541,6 +544,15 @@ int g6d_splitk_reduce_launch(const float* ws, int splits, int M, int Cout, const
   return g6d_check_launch("splitk_reduce");
 }
 
+// Which kernel family g6d_conv_igemm will run this descriptor on: 0 generic implicit GEMM, 1 LDS-patch kernel, 2 Winograd kernel
+// (no launch; bench.py uses it to book the executed FLOPs of a launch in the right roofline family).
+extern "C" int g6d_conv_plan(const G6dConv* desc) {
+  if (!desc) return G6D_EINVAL;
+  if (g6d_wino_eligible(*desc)) return 2;
+  static const bool use_patch = []() { const char* e = getenv("G6D_CONV_PATCH"); return !(e && e[0] == '0'); }();
+  return (use_patch && g6d_conv_patch_eligible(*desc)) ? 1 : 0;
+}
+
 extern "C" int g6d_conv_igemm(const G6dConv* desc, g6d_stream_t stream_) {
   if (!desc) return G6D_EINVAL;
   const G6dConv& d = *desc;
@@ -562,6 +574,7 @@ extern "C" int g6d_conv_igemm(const G6dConv* desc, g6d_stream_t stream_) {
   const long long Mll = (long long)d.N * d.Do * d.Ho * d.Wo;
   if (Mll > (1ll << 30)) { g6d_set_error("conv: M too large"); return G6D_EINVAL; }
   const int M = (int)Mll;
+  if (g6d_wino_eligible(d)) return g6d_wino_launch(d, stream);
   static const bool use_patch = []() { const char* e = getenv("G6D_CONV_PATCH"); return !(e && e[0] == '0'); }();
   if (use_patch && g6d_conv_patch_eligible(d)) return g6d_conv_patch_launch(d, M, stream);
   const int T = d.kd * d.kh * d.kw;

@@ -40,14 +40,29 @@ namespace {
 #define WQ_PIX 101                         // position stride between quarters (10 x 10 used)
 #define WRAW_LD 8                          // floats per raw patch position
 #define WRAW_FLOATS (4 * WQ_PIX * WRAW_LD) // 3232
-#define WU_FLOATS (16 * 64 * 8)            // 8192: [ab][co][8], lane-linear image of the global layout
-#define WSTAGE (WRAW_FLOATS + WU_FLOATS)   // 12992 floats = 51968 B per stage
+
+// The same kernel also runs the stride-1 3x3 / 3x3x3 layers of the selector, the refiner feature net and the refiner volume
+// net when g6d_conv_igemm finds pre-transformed filters in G6dConv.weight_wino (template parameters):
+//   MODE  operand prologue applied when the raw patch is written to LDS, as in conv_igemm.hip: 0 none, 1 InstanceNorm
+//         affine(+ReLU) with one table, 2 one table per image, 3 elementwise multiplier (selector query x reference
+//         product) + affine; zero padding stays exactly zero.  The affine tables sit in LDS (loaded once per block).
+//   KD    3: 3x3x3 layers as a 2-D Winograd over (h, w) with the three depth taps folded into the reduction: chunk c =
+//         (kd, 8 input channels) reads depth slice d + kd - 1 — the transform-domain accumulators are shared, so the
+//         multiplication count drops from 27 to 12 per output.
+//   NWN   output-channel width of a block in 32s: 2 = 64 channels / 4 waves; 1 = 32 channels / 2 waves (two such blocks share a
+//         CU), used when 64-wide blocks would leave CUs idle (e.g. the 32^3 x 64 volume layers: 128 -> 256 blocks).
+// Epilogue additions for those layers: per-(group, channel) sum / sum of squares of the outputs for the following
+// InstanceNorm (float partials per block, one fp64 atomic per channel and run of equal groups).
 
 struct WinoArgs {
   const float* in; const float* U; const float* bias; float* out_full; float* out_pool;
-  int N, H, W, Cin, ld_in, Cout, ld_full, ld_pool, relu;
+  int N, H, W, Cin, ld_in, Cout, ld_full, ld_pool, relu;      // N = images x depth slices (every slice is a 2-D map)
   int QH, QW;
   int splits, chunks_per_split; float* ws;       // splits > 1: partial outputs [split][N][H][W][Cout] (no bias / ReLU / pool)
+  // conv-family extras (zero / null for the trunk)
+  int D;                                         // depth slices per image (1 for 2-D layers); KD = 3 pads in depth
+  const float* mul; const float* in_scale; const float* in_shift; int in_relu;
+  double* stats; int stats_per_image;            // [groups][Cout][2]; groups = images (N / D) or 1
 };
 
 __device__ __forceinline__ f32x4 ldg4(const float* __restrict__ base, int elem_off) {
@@ -67,21 +82,30 @@ __device__ __forceinline__ void quarter_of(const WinoArgs& p, int q, int& n, int
   oy0 = 8 * qy; ox0 = 8 * qx;
 }
 
-__global__ void __launch_bounds__(256, 1) wino_conv3x3_kernel(const WinoArgs p) {
+template <int MODE, int KD, int NWN>
+__global__ void __launch_bounds__(128 * NWN, 1) wino_conv3x3_kernel(const WinoArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int THREADS = 128 * NWN;
+  constexpr int NPR = (800 + THREADS - 1) / THREADS;          // raw-patch pieces per thread and chunk (4 or 7)
+  constexpr int WU_FLOATS = 16 * 32 * NWN * 8;                // [ab][co][8], lane-linear image of the global layout
+  constexpr int WSTAGE = WRAW_FLOATS + WU_FLOATS;
+  constexpr int AFF0 = 2 * WSTAGE + 4 * THREADS;              // affine tables behind the stages and the scratch row
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / NWN, wn = wave % NWN;
   const int li = lane & 31, lh = lane >> 5;
-  const int n0 = blockIdx.y * 64;
-  const int c_first = blockIdx.z * p.chunks_per_split;                    // this block's slice of the channel chunks
-  const int c_last = min(p.Cin >> 3, c_first + p.chunks_per_split) - 1;
+  const int n0 = blockIdx.y * (32 * NWN);
+  const int nc8 = p.Cin >> 3;                                             // 8-channel chunks per depth tap
+  const int c_first = blockIdx.z * p.chunks_per_split;                    // this block's slice of the (kd, chunk) list
+  const int c_last = min(KD * nc8, c_first + p.chunks_per_split) - 1;
 
-  // ---- raw patch loader: pieces idx = tid + 256*j < 800 = 4 quarters x 100 positions x 2 halves of the 8-channel chunk
-  int poff[4], lsto[4]; bool pval[4], live[4];
+  // ---- raw patch loader: pieces idx = tid + THREADS*j < 800 = 4 quarters x 100 positions x 2 halves of the 8-channel chunk
+  int poff[NPR], lsto[NPR], moff[MODE == 3 ? NPR : 1], aoff[MODE != 0 ? NPR : 1];
+  bool pval[NPR], live[NPR];
+  unsigned dbits = 0;                                          // KD = 3: bit 2j / 2j+1 = piece j has a slice below / above
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int idx = tid + 256 * j;
+  for (int j = 0; j < NPR; ++j) {
+    const int idx = tid + THREADS * j;
     const int q = idx / 200, r = idx - q * 200, pp = r >> 1, half = r & 1;
     const int py = pp / 10, px = pp - py * 10;
     int n, oy0, ox0; bool qv;
@@ -91,18 +115,52 @@ __global__ void __launch_bounds__(256, 1) wino_conv3x3_kernel(const WinoArgs p) 
     poff[j] = pval[j] ? ((n * p.H + iy) * p.W + ix) * p.ld_in + 4 * half : 0;
     lsto[j] = (q * WQ_PIX + pp) * WRAW_LD + 4 * (half ^ ((py >> 1) & 1));
     live[j] = idx < 800;
+    if constexpr (MODE == 3) moff[j] = pval[j] ? (iy * p.W + ix) * p.Cin + 4 * half : 0;
+    if constexpr (MODE != 0) aoff[j] = (MODE == 2 ? (q < 4 ? q : 0) * p.Cin : 0) + 4 * half;
+    if constexpr (KD == 3) { const int dd = n % p.D; dbits |= (unsigned)(dd > 0) << (2 * j) | (unsigned)(dd < p.D - 1) << (2 * j + 1); }
   }
-  f32x4 rp[4];
+  const int slice = p.H * p.W * p.ld_in;                     // KD = 3: one depth step
+  f32x4 rp[NPR], rm[MODE == 3 ? NPR : 1];
+  bool rv[NPR];                                               // validity of the piece for the chunk it was loaded for
+  auto load_piece = [&](int j, int chunk) {
+    const int kd = KD == 3 ? chunk / nc8 : 0, cc = KD == 3 ? chunk - kd * nc8 : chunk;
+    bool v = pval[j];
+    int off = poff[j] + cc * 8;
+    if constexpr (KD == 3) { v &= kd == 1 || ((dbits >> (2 * j + (kd >> 1))) & 1u) != 0; off += (kd - 1) * slice; }
+    rv[j] = v;
+    rp[j] = ldg4(p.in, v ? off : 0);
+    if constexpr (MODE == 3) rm[j] = ldg4(p.mul, v ? moff[j] + cc * 8 : 0);
+  };
   auto load_raw = [&](int chunk) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) rp[j] = ldg4(p.in, pval[j] ? poff[j] + chunk * 8 : 0);
+    for (int j = 0; j < NPR; ++j) load_piece(j, chunk);
   };
-  auto store_raw = [&](int st) {   // unconditional stores (a branch would serialise them behind one vmcnt(0) each); the 224
-#pragma unroll                   // idle pieces (tid >= 32 of the 4th round) go to a scratch row behind the two stages
-    for (int j = 0; j < 4; ++j)
-      *reinterpret_cast<f32x4*>(lds + (live[j] ? st * WSTAGE + lsto[j] : 2 * WSTAGE + 4 * tid)) =
-          pval[j] ? rp[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+  auto store_raw = [&](int st, int chunk) {   // unconditional stores (a branch would serialise them behind one vmcnt(0) each); the
+    const int cc = KD == 3 ? chunk % nc8 : chunk;          // idle pieces of the last round go to a scratch row behind the stages
+#pragma unroll
+    for (int j = 0; j < NPR; ++j) {
+      f32x4 v = rp[j];
+      if constexpr (MODE == 3) v *= rm[j];
+      if constexpr (MODE != 0) {
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(lds + AFF0 + aoff[j] + cc * 8);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(lds + AFF0 + (MODE == 2 ? 4 : 1) * p.Cin + aoff[j] + cc * 8);
+        v = v * sc + sh;
+        if (p.in_relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+      }
+      *reinterpret_cast<f32x4*>(lds + (live[j] ? st * WSTAGE + lsto[j] : 2 * WSTAGE + 4 * tid)) = rv[j] ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
   };
+  if constexpr (MODE != 0) {                  // InstanceNorm affine tables -> LDS: [G][Cin] scales, then [G][Cin] shifts
+    constexpr int G = MODE == 2 ? 4 : 1;
+    for (int i = tid; i < G * p.Cin; i += THREADS) {
+      int g = 0;
+      if constexpr (MODE == 2) { int n, oy0, ox0; bool qv; quarter_of(p, i / p.Cin, n, oy0, ox0, qv); g = n / p.D; }
+      const int c = MODE == 2 ? i % p.Cin : i;
+      lds[AFF0 + i] = p.in_scale[g * p.Cin + c];
+      lds[AFF0 + G * p.Cin + i] = p.in_shift[g * p.Cin + c];
+    }
+    __syncthreads();
+  }
   // ---- filter tiles: wave w moves (ab, half) pairs idx = 8w .. 8w+7, 1 KB (32 co x 32 B) per instruction
   // Direct-to-LDS copy in inline asm: with the builtin, hipcc books the copy on the LDS counter as well and then waits
   // lgkmcnt(0) in front of every fragment use (it cannot count mixed event types), which exposes the LDS latency of the
@@ -110,9 +168,9 @@ __global__ void __launch_bounds__(256, 1) wino_conv3x3_kernel(const WinoArgs p) 
   const float* ubase = p.U + (size_t)n0 * 8 + lane * 4;
   const unsigned lds_addr0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)lds;
   auto glds = [&](int chunk, int st, int idx) {
-    const int ab = idx >> 1, h = idx & 1;
+    const int ab = idx / NWN, h = idx % NWN;
     const float* g = ubase + ((size_t)(chunk * 16 + ab) * p.Cout + h * 32) * 8;
-    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr0 + 4u * (unsigned)(st * WSTAGE + WRAW_FLOATS + (ab * 64 + h * 32) * 8));
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr0 + 4u * (unsigned)(st * WSTAGE + WRAW_FLOATS + (ab * 32 * NWN + h * 32) * 8));
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
@@ -128,6 +186,7 @@ __global__ void __launch_bounds__(256, 1) wino_conv3x3_kernel(const WinoArgs p) 
   const int abase01 = apos + 4 * (lh ^ (ty & 1));            // patch rows 2ty, 2ty+1   ((py >> 1) & 1 == ty & 1)
   const int abase23 = apos + 4 * (lh ^ (ty & 1) ^ 1);        // patch rows 2ty+2, 2ty+3
   const int bbase = WRAW_FLOATS + (wn * 32 + li) * 8 + 4 * (lh ^ ((li >> 3) & 1));
+  constexpr int USTRIDE = 32 * NWN * 8;                      // floats between (a,b) positions of the filter image
 
   f32x16 acc[16];
 #pragma unroll
@@ -137,7 +196,7 @@ __global__ void __launch_bounds__(256, 1) wino_conv3x3_kernel(const WinoArgs p) 
 
   load_u(c_first, 0);
   load_raw(c_first);
-  store_raw(0);
+  store_raw(0, c_first);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -157,15 +216,13 @@ __global__ void __launch_bounds__(256, 1) wino_conv3x3_kernel(const WinoArgs p) 
     const int cn = min(cc + 1, c_last);           // the last chunk re-requests itself into the idle stage: no branches
     f32x4 d[4][4], ub[3][4];
     auto rd_d = [&](int i, int j) { d[i][j] = *reinterpret_cast<const f32x4*>(S + (i < 2 ? abase01 : abase23) + (i * 10 + j) * WRAW_LD); };
-    auto rd_u = [&](int g, int j) { ub[g % 3][j] = *reinterpret_cast<const f32x4*>(S + bbase + (g * 4 + j) * 512); };
+    auto rd_u = [&](int g, int j) { ub[g % 3][j] = *reinterpret_cast<const f32x4*>(S + bbase + (g * 4 + j) * USTRIDE); };
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       acc[12 + (k >> 2)] = __builtin_amdgcn_mfma_f32_32x32x2f32(vD[k >> 2][k & 3], uD[k >> 2][k & 3], acc[12 + (k >> 2)], 0, 0, 0);
-      if (k < 4) {                                   // global requests first: they have the longest way to go
-        rp[k] = ldg4(p.in, pval[k] ? poff[k] + cn * 8 : 0);
-        glds(cn, (c & 1) ^ 1, wave * 8 + 2 * k);
-        glds(cn, (c & 1) ^ 1, wave * 8 + 2 * k + 1);
-      }
+      if (k < 8) glds(cn, (c & 1) ^ 1, wave * 8 + k);           // global requests first: they have the longest way to go
+      if (k < NPR) load_piece(k, cn);
+      if (k < 4) {}
       else if (k < 6) { rd_d(0, 2 * (k - 4)); rd_d(0, 2 * (k - 4) + 1); }
       else if (k < 8) { rd_d(2, 2 * (k - 6)); rd_d(2, 2 * (k - 6) + 1); }
       else if (k < 10) { rd_u(0, 2 * (k - 8)); rd_u(0, 2 * (k - 8) + 1); }
@@ -201,7 +258,7 @@ __global__ void __launch_bounds__(256, 1) wino_conv3x3_kernel(const WinoArgs p) 
       vD[2] = rw[2] - rw[1];
       vD[3] = rw[1] - rw[3];
     }
-    store_raw((c & 1) ^ 1);
+    store_raw((c & 1) ^ 1, cn);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the direct-to-LDS filter tiles of the next chunk have landed
     __syncthreads();
   }
@@ -213,7 +270,9 @@ __global__ void __launch_bounds__(256, 1) wino_conv3x3_kernel(const WinoArgs p) 
   const int co = n0 + wn * 32 + li;
   const float bv = (p.bias && p.splits == 1) ? p.bias[co] : 0.f;
   const bool do_relu = p.relu && p.splits == 1;
+  const bool do_stats = p.stats != nullptr;
   const int Hp = p.H >> 1, Wp = p.W >> 1;
+  float st1[2] = {0.f, 0.f}, st2[2] = {0.f, 0.f};       // statistics of this lane's column, per quarter of the wave
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     // accumulator row r of the 32x32 tile = tile (r&3) + 8*(r>>2) + 4*lh of the wave's 32
@@ -251,13 +310,52 @@ __global__ void __launch_bounds__(256, 1) wino_conv3x3_kernel(const WinoArgs p) 
       for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
-          if (oy + a < p.H && ox + b < p.W)
+          if (oy + a < p.H && ox + b < p.W) {
             p.out_full[((size_t)(n * p.H + oy + a) * p.W + ox + b) * p.ld_full + co] = y[a][b];
+            if (do_stats) { st1[r >> 3] += y[a][b]; st2[r >> 3] += y[a][b] * y[a][b]; }
+          }
     }
     if (p.out_pool && qv) {
       const int py = oy >> 1, px = ox >> 1;
       if (py < Hp && px < Wp)
         p.out_pool[((size_t)(n * Hp + py) * Wp + px) * p.ld_pool + co] = fmaxf(fmaxf(y[0][0], y[0][1]), fmaxf(y[1][0], y[1][1]));
+    }
+  }
+  if (do_stats) {
+    // lanes l and l+32 hold the same column; [quarter][column][2] float partials in LDS (the stages are free: every wave has
+    // passed the last barrier of the K loop), then one fp64 atomic per column and run of quarters with the same group
+    float* sred = lds;
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      st1[h] += __shfl_xor(st1[h], 32, 64);
+      st2[h] += __shfl_xor(st2[h], 32, 64);
+      if (lh == 0) {
+        sred[((2 * wm + h) * 32 * NWN + wn * 32 + li) * 2] = st1[h];
+        sred[((2 * wm + h) * 32 * NWN + wn * 32 + li) * 2 + 1] = st2[h];
+      }
+    }
+    __syncthreads();
+    if (tid < 32 * NWN) {
+      double a1 = 0.0, a2 = 0.0;
+      int cur = -1;
+      for (int q = 0; q < 4; ++q) {
+        int n, oy0, ox0; bool qv;
+        quarter_of(p, q, n, oy0, ox0, qv);
+        if (!qv) break;
+        const int g = p.stats_per_image ? n / p.D : 0;
+        if (g != cur && cur >= 0) {
+          double* st = p.stats + ((size_t)cur * p.Cout + n0 + tid) * 2;
+          atomicAdd(st, a1); atomicAdd(st + 1, a2); a1 = a2 = 0.0;
+        }
+        cur = g;
+        a1 += (double)sred[(q * 32 * NWN + tid) * 2];
+        a2 += (double)sred[(q * 32 * NWN + tid) * 2 + 1];
+      }
+      if (cur >= 0) {
+        double* st = p.stats + ((size_t)cur * p.Cout + n0 + tid) * 2;
+        atomicAdd(st, a1); atomicAdd(st + 1, a2);
+      }
     }
   }
 }
@@ -294,6 +392,74 @@ __global__ void __launch_bounds__(256) wino_reduce_kernel(const float* __restric
     *reinterpret_cast<f32x4*>(out_pool + ((size_t)(n * (H >> 1) + cy) * (W >> 1) + cx) * ld_pool + c) = m;
 }
 
+// ---- launch: tile width, split over the chunks, instantiation
+template <int MODE, int KD, int NWN>
+int wino_launch_t(WinoArgs& a, long long blocks, hipStream_t stream) {
+  constexpr int THREADS = 128 * NWN;
+  const size_t lds_bytes = (2 * (size_t)(WRAW_FLOATS + 16 * 32 * NWN * 8) + 4 * THREADS + (MODE == 0 ? 0 : (MODE == 2 ? 8 : 2) * a.Cin)) * sizeof(float);
+  static bool attr_done = false;      // per instantiation
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_conv3x3_kernel<MODE, KD, NWN>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((wino_conv3x3_kernel<MODE, KD, NWN>), dim3((unsigned)blocks, a.Cout / (32 * NWN), a.splits), dim3(THREADS), lds_bytes,
+                     stream, a);
+  return g6d_check_launch("wino_conv3x3");
+}
+
+template <int MODE, int KD>
+int wino_launch_w(WinoArgs& a, long long blocks, int nwn, hipStream_t stream) {
+  return nwn == 1 ? wino_launch_t<MODE, KD, 1>(a, blocks, stream) : wino_launch_t<MODE, KD, 2>(a, blocks, stream);
+}
+
+// Fills the geometry / split fields of `a` and launches.  kd = 1 or 3; mode as the kernel's MODE.
+int wino_run(WinoArgs& a, int mode, int kd, float* workspace, size_t workspace_bytes, hipStream_t stream) {
+  a.QH = (a.H + 7) / 8; a.QW = (a.W + 7) / 8;
+  const long long blocks = ((long long)a.N * a.QH * a.QW + 3) / 4;
+  if (blocks > 0x7fffffffll) { g6d_set_error("wino_conv3x3: grid too large"); return G6D_EINVAL; }
+  // 32-channel blocks (two per CU) when 64-channel ones would not even fill one round of the chip
+  const int nwn = ((a.Cout & 63) || (blocks * (a.Cout / 64) < 256 && a.out_pool == nullptr && (a.Cout / 32) * blocks >= 64)) ? 1 : 2;
+  // Split of the (kd, chunk) list over gridDim.z.  One 64-channel block per CU is resident (512 registers per lane, ~100 KB
+  // of LDS) and runs a serial loop of ~2.7 us per chunk, so a launch takes ceil(grid / 256) rounds of (chunks per block)
+  // steps: small grids leave CUs idle and grids just above a multiple of 256 pay a nearly empty last round.  Pick the split
+  // count with the smallest modelled time (rounds x block time + the reduce pass over the partial outputs).
+  const int nchunks = kd * (a.Cin / 8);
+  int splits = 1;
+  const long long grid2 = blocks * (a.Cout / (32 * nwn));
+  const int slots = 256 * (nwn == 1 ? 2 : 1);
+  static const int split_max = []() { const char* e = getenv("G6D_WINO_SPLIT_MAX"); return e ? atoi(e) : 32; }();
+  const bool can_reduce = workspace && !a.stats && !(a.ld_full & 3) && !(a.ld_pool & 3) && (!a.out_full || g6d_aligned16(a.out_full)) &&
+                          (!a.out_pool || g6d_aligned16(a.out_pool)) && (!a.bias || g6d_aligned16(a.bias)) && g6d_aligned16(workspace);
+  if (can_reduce && split_max > 1 && nchunks >= 4) {
+    const double out_bytes = (double)a.N * a.H * a.W * a.Cout * sizeof(float);
+    double best = 1e30;
+    for (int sp = 1; sp <= split_max && sp <= nchunks / 2; ++sp) {
+      if ((double)sp * out_bytes > (double)workspace_bytes) break;
+      const int cps_ = (nchunks + sp - 1) / sp, real = (nchunks + cps_ - 1) / cps_;
+      if (real != sp) continue;
+      const double rounds = (double)((grid2 * sp + slots - 1) / slots);
+      double t = rounds * (cps_ * 2.7 + 4.0);                                   // us: chunks + prologue / epilogue of a block
+      if (sp > 1) t += 6.0 + (sp + 1) * out_bytes / 3.0e6;                      // reduce launch + its traffic at ~3 TB/s
+      if (t < best * 0.97) { best = t; splits = sp; }                           // prefer fewer splits on near-ties
+    }
+  }
+  const int cps = (nchunks + splits - 1) / splits;
+  splits = (nchunks + cps - 1) / cps;
+  a.splits = splits; a.chunks_per_split = cps; a.ws = workspace;
+  int rc;
+  if (kd == 3) rc = mode == 1 ? wino_launch_w<1, 3>(a, blocks, nwn, stream) : wino_launch_w<0, 3>(a, blocks, nwn, stream);
+  else if (mode == 3) rc = wino_launch_w<3, 1>(a, blocks, nwn, stream);
+  else if (mode == 2) rc = wino_launch_w<2, 1>(a, blocks, nwn, stream);
+  else if (mode == 1) rc = wino_launch_w<1, 1>(a, blocks, nwn, stream);
+  else rc = wino_launch_w<0, 1>(a, blocks, nwn, stream);
+  if (rc != G6D_OK || splits == 1) return rc;
+  const long long cells = (long long)a.N * ((a.H + 1) / 2) * ((a.W + 1) / 2) * (a.Cout / 4);
+  hipLaunchKernelGGL(wino_reduce_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, stream, workspace, splits, a.N, a.H,
+                     a.W, a.Cout, a.bias, a.relu, a.out_full, a.ld_full, a.out_pool, a.ld_pool);
+  return g6d_check_launch("wino_reduce");
+}
+
 }  // namespace
 
 // in [N][H][W][ld_in] channels-last (Cin % 8 == 0), U = pre-transformed filters [Cin/8][16][Cout][8] (see
@@ -311,51 +477,37 @@ extern "C" int g6d_wino_conv3x3(const float* in, int N, int H, int W, int Cin, i
       !g6d_aligned16(in) || !g6d_aligned16(U) || (long long)N * H * W * ld_in >= (1ll << 30)) {
     g6d_set_error("wino_conv3x3: bad args (Cin % 8 == 0, Cout % 64 == 0, 16-byte aligned operands)"); return G6D_EINVAL;
   }
-  WinoArgs a;
+  WinoArgs a = {};
   a.in = in; a.U = U; a.bias = bias; a.out_full = out_full; a.out_pool = out_pool;
   a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.ld_in = ld_in; a.Cout = Cout; a.ld_full = ld_full; a.ld_pool = ld_pool; a.relu = relu;
-  a.QH = (H + 7) / 8; a.QW = (W + 7) / 8;
-  const long long blocks = ((long long)N * a.QH * a.QW + 3) / 4;
-  if (blocks > 0x7fffffffll) { g6d_set_error("wino_conv3x3: grid too large"); return G6D_EINVAL; }
-  // Split of the channel chunks over gridDim.z.  One block per CU is resident (512 registers per lane, 108 KB of LDS) and
-  // runs a serial loop of ~2.7 us per chunk, so a launch takes ceil(grid / 256) rounds of (chunks per block) steps: small
-  // grids leave CUs idle and grids just above a multiple of 256 pay a nearly empty last round.  Pick the split count with
-  // the smallest modelled time (rounds x block time + the reduce pass over the partial outputs).
-  const int nchunks = Cin / 8;
-  int splits = 1;
-  const long long grid2 = blocks * (Cout / 64);
-  static const int split_max = []() { const char* e = getenv("G6D_WINO_SPLIT_MAX"); return e ? atoi(e) : 32; }();
-  const bool can_reduce = workspace && !(ld_full & 3) && !(ld_pool & 3) && (!out_full || g6d_aligned16(out_full)) &&
-                          (!out_pool || g6d_aligned16(out_pool)) && (!bias || g6d_aligned16(bias)) && g6d_aligned16(workspace);
-  if (can_reduce && split_max > 1 && nchunks >= 4) {
-    const double out_bytes = (double)N * H * W * Cout * sizeof(float);
-    double best = 1e30;
-    for (int sp = 1; sp <= split_max && sp <= nchunks / 2; ++sp) {
-      if ((double)sp * out_bytes > (double)workspace_bytes) break;
-      const int cps_ = (nchunks + sp - 1) / sp, real = (nchunks + cps_ - 1) / cps_;
-      if (real != sp) continue;
-      const double rounds = (double)((grid2 * sp + 255) / 256);
-      double t = rounds * (cps_ * 2.7 + 4.0);                                   // us: chunks + prologue / epilogue of a block
-      if (sp > 1) t += 6.0 + (sp + 1) * out_bytes / 3.0e6;                      // reduce launch + its traffic at ~3 TB/s
-      if (t < best * 0.97) { best = t; splits = sp; }                           // prefer fewer splits on near-ties
-    }
-  }
-  const int cps = (nchunks + splits - 1) / splits;
-  splits = (nchunks + cps - 1) / cps;
-  a.splits = splits; a.chunks_per_split = cps; a.ws = workspace;
-  const size_t lds_bytes = (2 * (size_t)WSTAGE + 4 * 256) * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_conv3x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds_bytes);
-    attr_done = true;
-  }
-  hipLaunchKernelGGL(wino_conv3x3_kernel, dim3((unsigned)blocks, Cout / 64, splits), dim3(256), lds_bytes,
-                     reinterpret_cast<hipStream_t>(stream), a);
-  int rc = g6d_check_launch("wino_conv3x3");
-  if (rc != G6D_OK || splits == 1) return rc;
-  const long long cells = (long long)N * ((H + 1) / 2) * ((W + 1) / 2) * (Cout / 4);
-  hipLaunchKernelGGL(wino_reduce_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     workspace, splits, N, H, W, Cout, bias, relu, out_full, ld_full, out_pool, ld_pool);
-  return g6d_check_launch("wino_reduce");
+  a.D = 1;
+  return wino_run(a, 0, 1, workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream));
+}
+
+// ---- the conv family on the Winograd kernel (called by g6d_conv_igemm when G6dConv.weight_wino is set)
+// Eligible: kernel (1,3,3) on 2-D maps or (3,3,3), stride 1, "same" padding, Cin % 8 == 0, Cout % 32 == 0, maps of at least
+// 6x6 (4x4 maps would fill a quarter of an 8x8 output quarter: the direct kernels are better there), fp32 math, no LeakyReLU,
+// statistics groups = whole images or one group, no forced split.
+bool g6d_wino_eligible(const G6dConv& d) {
+  static const bool on = []() { const char* e = getenv("G6D_CONV_WINO"); return !(e && e[0] == '0'); }();
+  if (!on || !d.weight_wino || d.math_mode != 0) return false;
+  const bool k2 = d.kd == 1 && d.Di == 1 && d.pd == 0, k3 = d.kd == 3 && d.pd == 1;
+  if (!(k2 || k3) || d.kh != 3 || d.kw != 3 || d.ph != 1 || d.pw != 1 || d.sd != 1 || d.sh != 1 || d.sw != 1) return false;
+  if ((d.Cin & 7) || (d.Cout & 31) || d.Hi < 6 || d.Wi < 6 || d.out_act > 1 || d.split_k > 1) return false;
+  if (d.mul && (!k2 || !d.in_scale || d.in_affine_per_n)) return false;
+  if (k3 && d.in_scale && d.in_affine_per_n) return false;
+  if (d.stats && d.stat_rows_per_group > 0 && d.stat_rows_per_group != d.Do * d.Ho * d.Wo) return false;
+  if (!g6d_aligned16(d.weight_wino) || (d.in_scale && ((d.Cin & 3) != 0))) return false;
+  return (long long)d.N * d.Di * d.Hi * d.Wi * d.ld_in < (1ll << 30);
+}
+
+int g6d_wino_launch(const G6dConv& d, hipStream_t stream) {
+  WinoArgs a = {};
+  a.in = d.in; a.U = d.weight_wino; a.bias = d.bias; a.out_full = d.out; a.out_pool = nullptr;
+  a.D = d.Di; a.N = d.N * d.Di; a.H = d.Hi; a.W = d.Wi; a.Cin = d.Cin; a.ld_in = d.ld_in; a.Cout = d.Cout; a.ld_full = d.ld_out;
+  a.ld_pool = 0; a.relu = d.out_act == 1;
+  a.mul = d.mul; a.in_scale = d.in_scale; a.in_shift = d.in_shift; a.in_relu = d.in_relu;
+  a.stats = d.stats; a.stats_per_image = d.stat_rows_per_group > 0;
+  const int mode = d.mul ? 3 : (!d.in_scale ? 0 : (d.in_affine_per_n ? 2 : 1));
+  return wino_run(a, mode, d.kd, d.workspace, d.workspace_bytes, stream);
 }

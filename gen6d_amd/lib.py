@@ -21,6 +21,7 @@ class G6dConv(C.Structure):
         ("pd", C.c_int32), ("ph", C.c_int32), ("pw", C.c_int32),
         ("in_relu", C.c_int32), ("in_affine_per_n", C.c_int32), ("out_act", C.c_int32),
         ("stat_rows_per_group", C.c_int32), ("split_k", C.c_int32), ("math_mode", C.c_int32),
+        ("weight_wino", C.c_void_p),
     ]
 
 
@@ -30,6 +31,7 @@ _P, _I, _F, _D = C.c_void_p, C.c_int, C.c_float, C.c_double
 SIGNATURES = {
     "g6d_marker": [_I, _P],
     "g6d_conv_igemm": [C.POINTER(G6dConv), _P],
+    "g6d_conv_plan": [C.POINTER(G6dConv)],
     "g6d_corr2d_patch": [_P, _I, _I, _I, _I, _P, _I, _I, _I, _P, _I, _P, C.c_size_t, _I, _P],
     "g6d_stats_finalize": [_P, _I, _D, _D, _P, _P, _P],
     "g6d_affine_act_pool": [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P],

@@ -30,8 +30,8 @@ def winograd_filters(w):
     """[Cout,Cin,3,3] -> U [Cin/8,16,Cout,8] with U[c][4a+b][co][k ^ (4 if co & 8 else 0)] = (G g G^T)[a][b] of filter
     (co, 8c+k): the operand layout of g6d_wino_conv3x3 (a block's slice of one 8-channel chunk is 16 contiguous runs)."""
     co, ci = w.shape[:2]
-    if ci % 8 or co % 64:
-        raise ValueError("winograd_filters: Cin % 8 == 0 and Cout % 64 == 0 expected")
+    if ci % 8 or co % 32:
+        raise ValueError("winograd_filters: Cin % 8 == 0 and Cout % 32 == 0 expected")
     G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64, device=w.device)
     U = torch.einsum("ai,ocij,bj->ocab", G, w.double(), G).to(w.dtype)               # [co,ci,4,4]
     U = U.reshape(co, ci // 8, 8, 16).permute(1, 3, 0, 2).contiguous()               # [chunk][ab][co][8]
@@ -40,6 +40,15 @@ def winograd_filters(w):
     swap = (torch.arange(co, device=w.device) & 8) != 0
     U[:, :, swap] = torch.cat([U[:, :, swap, 4:], U[:, :, swap, :4]], -1)
     return U
+
+
+def winograd_filters_taps(w_taps, kd=1):
+    """[Cout, kd*9, Cin] (the tap-major layout of ParamBank.conv_w) -> [kd*Cin/8, 16, Cout, 8]: one winograd_filters block per
+    depth tap, stacked along the chunk axis (the K loop of the kernel walks depth taps outermost)."""
+    co, taps, ci = w_taps.shape
+    assert taps == kd * 9
+    w = w_taps.reshape(co, kd, 3, 3, ci).permute(1, 0, 4, 2, 3)              # [kd, co, ci, 3, 3]
+    return torch.cat([winograd_filters(w[k].contiguous()) for k in range(kd)], 0).contiguous()
 
 
 def pack_trunk(folded):

@@ -7,6 +7,16 @@ import torch.nn as nn
 from .. import specs
 
 
+class ConvW(tuple):
+    """(weight [Cout,taps,Cin], bias) as the conv kernels take them, plus `.u`: the same filters transformed for the Winograd
+    kernel (None when the layer never qualifies).  Unpacks like the plain pair."""
+
+    def __new__(cls, w, b, u=None):
+        t = super().__new__(cls, (w, b))
+        t.u = u
+        return t
+
+
 class ParamBank(nn.Module):
     def __init__(self, rows):
         super().__init__()
@@ -48,14 +58,24 @@ class ParamBank(nn.Module):
     def device_(self):
         return next(self.parameters()).device
 
-    def conv_w(self, prefix, cin_pad=None):
-        """[Cout,Cin,*k] -> [Cout,taps,Cin] contiguous (Cin zero-padded to cin_pad), bias."""
+    def conv_w(self, prefix, cin_pad=None, wino_kd=0):
+        """[Cout,Cin,*k] -> ConvW([Cout,taps,Cin] contiguous (Cin zero-padded to cin_pad), bias).  wino_kd = 1 / 3: the layer is
+        a stride-1 (1,3,3) / (3,3,3) convolution — also keep its Winograd-domain filters (`.u`, see G6dConv.weight_wino)."""
         w = self.p(prefix + ".weight")
         co, ci = w.shape[:2]
         w = w.reshape(co, ci, -1).permute(0, 2, 1)
         if cin_pad is not None and cin_pad != ci:
             w = torch.nn.functional.pad(w, (0, cin_pad - ci))
-        return w.contiguous(), self.p(prefix + ".bias").contiguous()
+        w = w.contiguous()
+        u = None
+        if wino_kd and ci % 8 == 0 and co % 32 == 0 and w.shape[1] == 9 * wino_kd:
+            from .backbone import winograd_filters_taps
+            u = _wino_pad(winograd_filters_taps(w, wino_kd), co)
+        return ConvW(w, self.p(prefix + ".bias").contiguous(), u)
+
+
+def _wino_pad(u, co):
+    return u
 
 
 def fold_vgg(bank, prefix):

@@ -35,11 +35,11 @@ class VolumeRefiner(ParamBank):
         if self._packed is None:
             pk = {"vgg": pack_trunk(fold_vgg(self, "feature_net.backbone.features"))}
             for name in ("conv0", "conv1", "conv2", "conv_out"):
-                pk[name] = [self.conv_w(f"feature_net.{name}.{i}") for i in (0, 3)]
-            for name in ("mean_embed", "var_embed", "conv5"):
-                pk["v_" + name] = [self.conv_w(f"volume_net.{name}.{i}") for i in (0, 3)]
+                pk[name] = [self.conv_w(f"feature_net.{name}.{i}", wino_kd=1) for i in (0, 3)]
+            for name in ("mean_embed", "var_embed", "conv5"):         # conv5 works on 8^3 -> 4^3 maps: never on the Winograd kernel
+                pk["v_" + name] = [self.conv_w(f"volume_net.{name}.{i}", wino_kd=0 if name == "conv5" else 3) for i in (0, 3)]
             for name in ("conv0", "conv1", "conv2", "conv3", "conv4"):
-                pk["v_" + name] = self.conv_w(f"volume_net.{name}.0")
+                pk["v_" + name] = self.conv_w(f"volume_net.{name}.0", wino_kd=3 if name in ("conv0", "conv2", "conv4") else 0)
             # fc.0.0 consumes x.flatten(1) of [512,4,4,4] (index c*64+v); our code is [v][c] -> permute once
             w = self.p("regressor.fc.0.0.weight")
             pk["fc0"] = (w.reshape(512, 512, 64).permute(0, 2, 1).reshape(512, 32768).contiguous(),
@@ -62,15 +62,16 @@ class VolumeRefiner(ParamBank):
         def pair(name, x):
             """conv, IN, ReLU, conv, (IN returned as affine) — per-image statistics."""
             (w0, b0), (w1, b1) = pk[name]
+            u0, u1 = pk[name][0].u, pk[name][1].u
             _, _, hh, ww, _ = x.shape
             y0 = torch.empty((n, 1, hh, ww, w0.shape[0]), dtype=torch.float32, device=dev)
             s0 = ops.new_stats(n, w0.shape[0], dev)
-            ops.conv(x, w0, b0, y0, ksize=_K2, pad=_P2, stats=s0, rows_per_group=hh * ww)
+            ops.conv(x, w0, b0, y0, ksize=_K2, pad=_P2, stats=s0, rows_per_group=hh * ww, w_wino=u0)
             sc0, sh0 = ops.stats_finalize(s0, hh * ww)
             y1 = torch.empty((n, 1, hh, ww, w1.shape[0]), dtype=torch.float32, device=dev)
             s1 = ops.new_stats(n, w1.shape[0], dev)
             ops.conv(y0, w1, b1, y1, ksize=_K2, pad=_P2, in_scale=sc0, in_shift=sh0, in_relu=True, per_n=True,
-                     stats=s1, rows_per_group=hh * ww)
+                     stats=s1, rows_per_group=hh * ww, w_wino=u1)
             sc1, sh1 = ops.stats_finalize(s1, hh * ww)
             return y1, sc1, sh1
 
@@ -105,7 +106,7 @@ class VolumeRefiner(ParamBank):
             st = ops.new_stats(1, stats_c, dev) if stats_c else None
             sc, sh = aff if aff is not None else (None, None)
             ops.conv(x, wb[0], wb[1], out, ksize=_K3, stride=(stride,) * 3, pad=_P3, in_scale=sc, in_shift=sh,
-                     in_relu=aff is not None, stats=st)
+                     in_relu=aff is not None, stats=st, w_wino=getattr(wb, "u", None) if stride == 1 else None)
             return st
 
         def buf(s, c):

@@ -77,7 +77,7 @@ class ViewpointSelector(ParamBank):
         if self._packed is None:
             an = self.cfg["selector_angle_num"]
             pk = {"vgg": pack_trunk(fold_vgg(self, "backbone.features"))}
-            pk["corr"] = [[self.conv_w(f"corr_conv_list.{l}.{i}") for i, *_ in layers] for l, layers in enumerate(_CORR)]
+            pk["corr"] = [[self.conv_w(f"corr_conv_list.{l}.{i}", wino_kd=1) for i, *_ in layers] for l, layers in enumerate(_CORR)]
             pk["fuse0"] = self.conv_w("corr_feats_conv.0")
             pk["fuse3"] = self.conv_w("corr_feats_conv.3")
             pk["sp0"] = self.conv_w("score_process.0", cin_pad=FEAT_LD)
@@ -161,11 +161,13 @@ class ViewpointSelector(ParamBank):
         layers = _CORR[l]
         for li, (idx, has_in, has_relu, has_pool) in enumerate(layers):
             wgt, bias = pk["corr"][l][li]
+            wu = pk["corr"][l][li].u
             co = wgt.shape[0]
             last = li == len(layers) - 1
             out = cat[..., 256 * l:256 * l + 256] if last else torch.empty((D, 1, h, w, co), dtype=torch.float32, device=dev)
             stats = ops.new_stats(1, co, dev) if has_in else None
-            ops.conv(x, wgt, bias, out, ksize=_K133, pad=_P011, mul=mul, in_scale=scale, in_shift=shift, in_relu=relu, stats=stats)
+            ops.conv(x, wgt, bias, out, ksize=_K133, pad=_P011, mul=mul, in_scale=scale, in_shift=shift, in_relu=relu, stats=stats,
+                     w_wino=wu)
             mul = None
             if last:
                 break

@@ -133,7 +133,7 @@ def _cl5(t, name):
 
 
 def conv(x, w, bias, out, ksize=(1, 1, 1), stride=(1, 1, 1), pad=(0, 0, 0), mul=None, in_scale=None, in_shift=None,
-         in_relu=False, per_n=False, out_act=0, stats=None, rows_per_group=0, split_k=0):
+         in_relu=False, per_n=False, out_act=0, stats=None, rows_per_group=0, split_k=0, w_wino=None):
     """Implicit-GEMM convolution (g6d_conv_igemm). x [N,Di,Hi,Wi,Cin], w [Cout,taps,Cin], out [N,Do,Ho,Wo,Cout] views."""
     _need_gpu(x, w, out)
     N, Di, Hi, Wi, Cin, ld_in = _cl5(x, "conv.x")
@@ -148,6 +148,8 @@ def conv(x, w, bias, out, ksize=(1, 1, 1), stride=(1, 1, 1), pad=(0, 0, 0), mul=
         raise ValueError("conv: batch mismatch")
     if mul is not None and (tuple(mul.shape) != (Hi, Wi, Cin) or not mul.is_contiguous()):
         raise ValueError("conv.mul: expected contiguous [Hi,Wi,Cin]")
+    if w_wino is not None and (tuple(w_wino.shape) != (kd * (Cin // 8), 16, Cout, 8) or not w_wino.is_contiguous()):
+        raise ValueError(f"conv.w_wino: expected contiguous {(kd * (Cin // 8), 16, Cout, 8)}, got {tuple(w_wino.shape)}")
     ws = workspace(x.device)
     d = _lib.G6dConv(
         in_=x.data_ptr(), mul=mul.data_ptr() if mul is not None else None,
@@ -158,14 +160,17 @@ def conv(x, w, bias, out, ksize=(1, 1, 1), stride=(1, 1, 1), pad=(0, 0, 0), mul=
         N=N, Di=Di, Hi=Hi, Wi=Wi, Cin=Cin, ld_in=ld_in, Do=Do, Ho=Ho, Wo=Wo, Cout=Cout, ld_out=ld_out,
         kd=kd, kh=kh, kw=kw, sd=stride[0], sh=stride[1], sw=stride[2], pd=pad[0], ph=pad[1], pw=pad[2],
         in_relu=int(in_relu), in_affine_per_n=int(per_n), out_act=int(out_act),
-        stat_rows_per_group=int(rows_per_group), split_k=int(split_k), math_mode=int(MATH_MODE))
+        stat_rows_per_group=int(rows_per_group), split_k=int(split_k), math_mode=int(MATH_MODE),
+        weight_wino=w_wino.data_ptr() if w_wino is not None else None)
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         _lib.check(_lib.load().g6d_conv_igemm(C.byref(d), _stream()), "g6d_conv_igemm")
         e1.record()
-        PROFILE.append((2.0 * N * Do * Ho * Wo * Cout * kd * kh * kw * Cin, e0, e1,
-                        f"conv N={N} in={Di}x{Hi}x{Wi}x{Cin} out={Do}x{Ho}x{Wo}x{Cout} k={kd}x{kh}x{kw} s={stride[0]}{stride[1]}{stride[2]}"
+        fam = _lib.load().g6d_conv_plan(C.byref(d))
+        fl = 2.0 * N * Do * Ho * Wo * Cout * kd * kh * kw * Cin
+        PROFILE.append((fl / 2.25 if fam == 2 else fl, e0, e1,            # Winograd kernel: FLOPs executed in the transform domain
+                        ("wino3x3 " if fam == 2 else "") + f"conv N={N} in={Di}x{Hi}x{Wi}x{Cin} out={Do}x{Ho}x{Wo}x{Cout} k={kd}x{kh}x{kw} s={stride[0]}{stride[1]}{stride[2]}"
                         f"{' mul' if mul is not None else ''}{' aff' if in_scale is not None else ''}{' stats' if stats is not None else ''}"))
         return out
     _lib.check(_lib.load().g6d_conv_igemm(C.byref(d), _stream()), "g6d_conv_igemm")

@@ -79,9 +79,16 @@ typedef struct G6dConv {
   int32_t split_k;              /* 0 = choose automatically; 1 = never split; >1 = force */
   int32_t math_mode;            /* 0 = fp32 MFMA (default, the parity path); 1 = bf16, 2 = fp16 operands with fp32 accumulation:
                                    v_mfma_f32_32x32x16_{bf16,f16}, opt-in speed mode graded separately (BASELINE configs[2], [4]) */
+  const float* weight_wino;     /* optional: the same filters transformed for Winograd F(2x2,3x3), [kd][Cin/8][16][Cout][8] in the
+                                   layout of g6d_wino_conv3x3 (per depth tap for 3x3x3).  When set and the layer is eligible
+                                   (stride 1, "same" padding, maps >= 6x6, Cin % 8 == 0, Cout % 32 == 0, fp32), the launch runs on
+                                   the Winograd kernel (2.25x fewer multiplications) with the same prologue / epilogue semantics;
+                                   otherwise `weight` is used.  NULL = never. */
 } G6dConv;
 
 int g6d_conv_igemm(const G6dConv* desc, g6d_stream_t stream);
+/* Kernel family g6d_conv_igemm will run `desc` on (no launch): 0 generic implicit GEMM, 1 LDS-patch kernel, 2 Winograd kernel */
+int g6d_conv_plan(const G6dConv* desc);
 /* sizeof(G6dConv) as compiled into the library: bindings check their struct layout against it */
 int g6d_sizeof_conv_desc(void);
 

@@ -107,3 +107,21 @@ def test_predict_many_three_lanes(built):
         # replay vs eager: statistics atomics reorder (1e-5), a detection that moves by 1e-4 px flips the rounding of a few crop
         # pixels, and the randomly initialised refiner amplifies single grey levels to ~1e-2 (same effect as in the CPU test)
         np.testing.assert_allclose(pm, pe, atol=3e-2)
+
+
+def test_streaming_eval_driver(built):
+    """gen6d_amd/eval.run_queries: prefetching decode threads + three lanes; poses equal predict_many's, metrics finite."""
+    from gen6d_amd import eval as EV
+    db, est = built
+    _, que_ids = db.get_split("all")
+    seen = []
+    poses, secs, inters = EV.run_queries(est, db, list(que_ids), lanes=3, prefetch=4, decode_threads=2,
+                                         on_result=lambda qi, p, it: seen.append(qi))
+    assert poses.shape == (len(que_ids), 3, 4) and sorted(seen) == list(range(len(que_ids))) and secs > 0
+    many = est.predict_many([db.get_image(i) for i in que_ids], [db.get_K(i) for i in que_ids], lanes=3)
+    for i, (pm, im_) in enumerate(many):
+        assert inters[i]["sel_ref_idx"] == im_["sel_ref_idx"]
+        np.testing.assert_allclose(poses[i], pm, atol=3e-2)
+    res = EV.compute_metrics(EV.get_ref_point_cloud(db), db.object_diameter, [db.get_pose(i) for i in que_ids], poses,
+                             [db.get_K(i) for i in que_ids])
+    assert set(res) == {"add-0.1d", "prj-5"} and all(0.0 <= v <= 1.0 for v in res.values())

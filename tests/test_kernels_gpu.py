@@ -75,6 +75,35 @@ CONV_CASES = [
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: f"{c['Cin']}x{c['Cout']}k{c['k'][0]}{c['k'][1]}{c['k'][2]}")
 def test_conv_igemm(ops, case):
+    _run_conv_case(ops, case, False)
+
+
+# Layers that g6d_conv_igemm routes to the Winograd kernel when G6dConv.weight_wino is given (every prologue / epilogue variant the
+# selector, the refiner feature net and the volume net use), plus shapes that must fall back to the direct kernels.
+WINO_CONV_CASES = [
+    dict(N=20, D=1, H=16, W=16, Cin=512, Cout=64, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), mul=True, aff=True, stats=True),      # selector product layer
+    dict(N=21, D=1, H=16, W=16, Cin=64, Cout=64, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), aff=True, relu=True, stats=True),
+    dict(N=13, D=1, H=8, W=8, Cin=64, Cout=128, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), stats=True),                           # one quarter per image
+    dict(N=320, D=1, H=8, W=8, Cin=128, Cout=128, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), aff=True, relu=True, stats=True),
+    dict(N=7, D=1, H=32, W=32, Cin=256, Cout=64, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), stats=True, rpg=1024),                # per-image statistics
+    dict(N=7, D=1, H=16, W=16, Cin=256, Cout=64, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), aff=True, relu=True, per_n=True, stats=True, rpg=256),
+    dict(N=7, D=1, H=8, W=8, Cin=512, Cout=256, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), stats=True, rpg=64),                    # groups inside a block
+    dict(N=7, D=1, H=32, W=32, Cin=192, Cout=128, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), stats=True, rpg=1024, ld_in=256),
+    dict(N=1, D=16, H=16, W=16, Cin=128, Cout=64, k=(3, 3, 3), s=(1, 1, 1), p=(1, 1, 1), stats=True),                          # 3-D: depth taps folded into K
+    dict(N=1, D=8, H=8, W=8, Cin=256, Cout=256, k=(3, 3, 3), s=(1, 1, 1), p=(1, 1, 1), aff=True, relu=True, stats=True),
+    dict(N=1, D=32, H=32, W=32, Cin=64, Cout=64, k=(3, 3, 3), s=(1, 1, 1), p=(1, 1, 1), aff=True, relu=True, ld_out=128),     # channel slice of the concat buffer
+    dict(N=2, D=5, H=9, W=11, Cin=16, Cout=32, k=(3, 3, 3), s=(1, 1, 1), p=(1, 1, 1), act=1, stats=True, rpg=495),             # odd sizes, 32 output channels
+    dict(N=3, D=1, H=4, W=4, Cin=128, Cout=256, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), aff=True, relu=True),                   # not eligible: 4x4 map
+    dict(N=1, D=8, H=8, W=8, Cin=64, Cout=128, k=(3, 3, 3), s=(2, 2, 2), p=(1, 1, 1), stats=True),                             # not eligible: stride 2
+]
+
+
+@pytest.mark.parametrize("case", WINO_CONV_CASES, ids=lambda c: f"{c['N']}x{c['D']}x{c['H']}_{c['Cin']}x{c['Cout']}k{c['k'][0]}")
+def test_conv_on_winograd_kernel(ops, case):
+    _run_conv_case(ops, case, True)
+
+
+def _run_conv_case(ops, case, wino):
     g = torch.Generator().manual_seed(17)
     c = case
     N, D, H, W, Cin, Cout = c["N"], c["D"], c["H"], c["W"], c["Cin"], c["Cout"]
@@ -103,19 +132,24 @@ def test_conv_igemm(ops, case):
     ops.conv(xv, w.to(dev), bias.to(dev), out, ksize=k, stride=s, pad=p, mul=mul.to(dev) if mul is not None else None,
              in_scale=sc.to(dev) if sc is not None else None, in_shift=sh.to(dev) if sh is not None else None,
              in_relu=bool(c.get("relu")), per_n=bool(c.get("per_n")), out_act=c.get("act", 0), stats=stats,
-             rows_per_group=rpg, split_k=c.get("split", 0))
+             rows_per_group=rpg, split_k=c.get("split", 0), w_wino=_wino_u(w, k).to(dev) if wino else None)
     torch.cuda.synchronize()
     ref = torch.empty((N, Do, Ho, Wo, Cout), dtype=torch.float64)
     rstats = torch.zeros((G, Cout, 2), dtype=torch.float64) if c.get("stats") else None
     ref_ops.conv(_d(x), _d(w), _d(bias), ref, ksize=k, stride=s, pad=p, mul=_d(mul), in_scale=_d(sc), in_shift=_d(sh),
                  in_relu=bool(c.get("relu")), per_n=bool(c.get("per_n")), out_act=c.get("act", 0), stats=rstats,
                  rows_per_group=rpg)
-    _check(out, ref, 2e-5, "conv out")
+    _check(out, ref, 4e-5 if wino else 2e-5, "conv out")
     if ld_out != Cout:
         assert (outbuf[..., Cout:] == -777.0).all(), "conv wrote outside its channel slice"
     if stats is not None:
-        _check(stats[..., 0], rstats[..., 0], 2e-5, "stats sum")
-        _check(stats[..., 1], rstats[..., 1], 2e-5, "stats sumsq")
+        _check(stats[..., 0], rstats[..., 0], 4e-5 if wino else 2e-5, "stats sum")
+        _check(stats[..., 1], rstats[..., 1], 4e-5 if wino else 2e-5, "stats sumsq")
+
+
+def _wino_u(w_taps, k):
+    from gen6d_amd.network.backbone import winograd_filters_taps
+    return winograd_filters_taps(w_taps, k[0])
 
 
 @pytest.mark.parametrize("N,H,W", [(1, 128, 128), (2, 50, 70), (1, 33, 67), (3, 2, 2), (1, 96, 160)])
