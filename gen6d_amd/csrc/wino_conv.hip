@@ -270,7 +270,7 @@ __global__ void __launch_bounds__(128 * NWN, 1) wino_conv3x3_kernel(const WinoAr
   const int co = n0 + wn * 32 + li;
   const float bv = (p.bias && p.splits == 1) ? p.bias[co] : 0.f;
   const bool do_relu = p.relu && p.splits == 1;
-  const bool do_stats = p.stats != nullptr;
+  const bool do_stats = p.stats != nullptr && p.splits == 1;     // split launches: the reduce kernel owns the statistics
   const int Hp = p.H >> 1, Wp = p.W >> 1;
   float st1[2] = {0.f, 0.f}, st2[2] = {0.f, 0.f};       // statistics of this lane's column, per quarter of the wave
 #pragma unroll
@@ -361,35 +361,67 @@ __global__ void __launch_bounds__(128 * NWN, 1) wino_conv3x3_kernel(const WinoAr
 }
 
 // Second half of a split launch: thread = one 2x2 output cell x 4 channels; sums the partial outputs of all splits, adds the
-// bias, applies ReLU, writes the full-resolution result and / or the max-pooled one.
+// bias, applies ReLU, writes the full-resolution result and / or the max-pooled one, and accumulates the InstanceNorm statistics of
+// the result (float partials per block in LDS, one fp64 atomic per channel and block; a block that straddles two statistics
+// groups falls back to per-thread atomics).  Images here are N x D slices; a statistics group is an image (D slices) or everything.
 __global__ void __launch_bounds__(256) wino_reduce_kernel(const float* __restrict__ ws, int splits, int N, int H, int W, int Cout,
                                                           const float* __restrict__ bias, int relu, float* __restrict__ out_full,
-                                                          int ld_full, float* __restrict__ out_pool, int ld_pool) {
+                                                          int ld_full, float* __restrict__ out_pool, int ld_pool,
+                                                          double* __restrict__ stats, int D, int stats_per_image) {
+  extern __shared__ float sred[];                        // [Cout][2] when stats
   const int c4 = Cout >> 2, Hc = (H + 1) >> 1, Wc = (W + 1) >> 1;
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (long long)N * Hc * Wc * c4) return;
-  const int c = (int)(i % c4) * 4; long long t = i / c4;
-  const int cx = (int)(t % Wc); t /= Wc;
-  const int cy = (int)(t % Hc); const int n = (int)(t / Hc);
-  const size_t zstride = (size_t)N * H * W * Cout;
-  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-  if (bias) bv = *reinterpret_cast<const f32x4*>(bias + c);
-  f32x4 m = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int oy = 2 * cy + a, ox = 2 * cx + b;
-      if (oy >= H || ox >= W) continue;
-      const float* src = ws + ((size_t)(n * H + oy) * W + ox) * Cout + c;
-      f32x4 v = bv;
-      for (int z = 0; z < splits; ++z) v += *reinterpret_cast<const f32x4*>(src + (size_t)z * zstride);
-      if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-      if (out_full) *reinterpret_cast<f32x4*>(out_full + ((size_t)(n * H + oy) * W + ox) * ld_full + c) = v;
-      m[0] = fmaxf(m[0], v[0]); m[1] = fmaxf(m[1], v[1]); m[2] = fmaxf(m[2], v[2]); m[3] = fmaxf(m[3], v[3]);
+  const long long total = (long long)N * Hc * Wc * c4;
+  const long long i0 = (long long)blockIdx.x * 256, i = i0 + threadIdx.x;
+  const long long per_img = (long long)Hc * Wc * c4;
+  int g_first = 0, g_last = 0;
+  if (stats) {
+    for (int k = threadIdx.x; k < 2 * Cout; k += 256) sred[k] = 0.f;
+    if (stats_per_image) {
+      g_first = (int)(i0 / per_img) / D;
+      g_last = (int)(min(i0 + 255, total - 1) / per_img) / D;
     }
-  if (out_pool && cy < (H >> 1) && cx < (W >> 1))
-    *reinterpret_cast<f32x4*>(out_pool + ((size_t)(n * (H >> 1) + cy) * (W >> 1) + cx) * ld_pool + c) = m;
+    __syncthreads();
+  }
+  const bool one_group = g_first == g_last;
+  if (i < total) {
+    const int c = (int)(i % c4) * 4; long long t = i / c4;
+    const int cx = (int)(t % Wc); t /= Wc;
+    const int cy = (int)(t % Hc); const int n = (int)(t / Hc);
+    const size_t zstride = (size_t)N * H * W * Cout;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (bias) bv = *reinterpret_cast<const f32x4*>(bias + c);
+    f32x4 m = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f}, s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int oy = 2 * cy + a, ox = 2 * cx + b;
+        if (oy >= H || ox >= W) continue;
+        const float* src = ws + ((size_t)(n * H + oy) * W + ox) * Cout + c;
+        f32x4 v = bv;
+        for (int z = 0; z < splits; ++z) v += *reinterpret_cast<const f32x4*>(src + (size_t)z * zstride);
+        if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        if (out_full) *reinterpret_cast<f32x4*>(out_full + ((size_t)(n * H + oy) * W + ox) * ld_full + c) = v;
+        m[0] = fmaxf(m[0], v[0]); m[1] = fmaxf(m[1], v[1]); m[2] = fmaxf(m[2], v[2]); m[3] = fmaxf(m[3], v[3]);
+        s1 += v; s2 += v * v;
+      }
+    if (out_pool && cy < (H >> 1) && cx < (W >> 1))
+      *reinterpret_cast<f32x4*>(out_pool + ((size_t)(n * (H >> 1) + cy) * (W >> 1) + cx) * ld_pool + c) = m;
+    if (stats) {
+      if (one_group) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { atomicAdd(&sred[(c + k) * 2], s1[k]); atomicAdd(&sred[(c + k) * 2 + 1], s2[k]); }
+      } else {
+        double* st = stats + ((size_t)(stats_per_image ? n / D : 0) * Cout + c) * 2;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { atomicAdd(st + 2 * k, (double)s1[k]); atomicAdd(st + 2 * k + 1, (double)s2[k]); }
+      }
+    }
+  }
+  if (stats && one_group) {
+    __syncthreads();
+    for (int k = threadIdx.x; k < 2 * Cout; k += 256) atomicAdd(stats + (size_t)g_first * Cout * 2 + k, (double)sred[k]);
+  }
 }
 
 // ---- launch: tile width, split over the chunks, instantiation
@@ -418,8 +450,9 @@ int wino_run(WinoArgs& a, int mode, int kd, float* workspace, size_t workspace_b
   a.QH = (a.H + 7) / 8; a.QW = (a.W + 7) / 8;
   const long long blocks = ((long long)a.N * a.QH * a.QW + 3) / 4;
   if (blocks > 0x7fffffffll) { g6d_set_error("wino_conv3x3: grid too large"); return G6D_EINVAL; }
-  // 32-channel blocks (two per CU) when 64-channel ones would not even fill one round of the chip
-  const int nwn = ((a.Cout & 63) || (blocks * (a.Cout / 64) < 256 && a.out_pool == nullptr && (a.Cout / 32) * blocks >= 64)) ? 1 : 2;
+  // 32-channel (two-wave) blocks only for channel counts that are not multiples of 64: two of them share a CU, so they do not
+  // spread a small grid over more CUs — the split over the chunks below does
+  const int nwn = (a.Cout & 63) ? 1 : 2;
   // Split of the (kd, chunk) list over gridDim.z.  One 64-channel block per CU is resident (512 registers per lane, ~100 KB
   // of LDS) and runs a serial loop of ~2.7 us per chunk, so a launch takes ceil(grid / 256) rounds of (chunks per block)
   // steps: small grids leave CUs idle and grids just above a multiple of 256 pay a nearly empty last round.  Pick the split
@@ -429,7 +462,7 @@ int wino_run(WinoArgs& a, int mode, int kd, float* workspace, size_t workspace_b
   const long long grid2 = blocks * (a.Cout / (32 * nwn));
   const int slots = 256 * (nwn == 1 ? 2 : 1);
   static const int split_max = []() { const char* e = getenv("G6D_WINO_SPLIT_MAX"); return e ? atoi(e) : 32; }();
-  const bool can_reduce = workspace && !a.stats && !(a.ld_full & 3) && !(a.ld_pool & 3) && (!a.out_full || g6d_aligned16(a.out_full)) &&
+  const bool can_reduce = workspace && !(a.Cout & 3) && !(a.ld_full & 3) && !(a.ld_pool & 3) && (!a.out_full || g6d_aligned16(a.out_full)) &&
                           (!a.out_pool || g6d_aligned16(a.out_pool)) && (!a.bias || g6d_aligned16(a.bias)) && g6d_aligned16(workspace);
   if (can_reduce && split_max > 1 && nchunks >= 4) {
     const double out_bytes = (double)a.N * a.H * a.W * a.Cout * sizeof(float);
@@ -455,8 +488,9 @@ int wino_run(WinoArgs& a, int mode, int kd, float* workspace, size_t workspace_b
   else rc = wino_launch_w<0, 1>(a, blocks, nwn, stream);
   if (rc != G6D_OK || splits == 1) return rc;
   const long long cells = (long long)a.N * ((a.H + 1) / 2) * ((a.W + 1) / 2) * (a.Cout / 4);
-  hipLaunchKernelGGL(wino_reduce_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, stream, workspace, splits, a.N, a.H,
-                     a.W, a.Cout, a.bias, a.relu, a.out_full, a.ld_full, a.out_pool, a.ld_pool);
+  hipLaunchKernelGGL(wino_reduce_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), a.stats ? 2 * a.Cout * sizeof(float) : 0, stream,
+                     workspace, splits, a.N, a.H, a.W, a.Cout, a.bias, a.relu, a.out_full, a.ld_full, a.out_pool, a.ld_pool, a.stats,
+                     a.D, a.stats_per_image);
   return g6d_check_launch("wino_reduce");
 }
 

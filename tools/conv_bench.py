@@ -63,6 +63,10 @@ def main():
         if pn:
             kw["rows_per_group"] = Do * Ho * Wo
         kw["split_k"] = int(os.environ.get("SPLITK", "0"))
+        if os.environ.get("WINO", "0") == "1" and k[1] == 3 and s == 1 and Cin % 8 == 0 and Cout % 32 == 0:
+            # direct-form TFLOP/s are printed: a layer g6d_conv_igemm runs on the Winograd kernel executes 1/2.25 of those FLOPs
+            from gen6d_amd.network.backbone import winograd_filters_taps
+            kw["w_wino"] = winograd_filters_taps(w, k[0])
         for _ in range(2):
             ops.conv(x, w, b, out, ksize=k, stride=(s,) * 3, pad=p, stats=stats, **kw)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
