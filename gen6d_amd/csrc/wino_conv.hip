@@ -532,6 +532,14 @@ bool g6d_wino_eligible(const G6dConv& d) {
   if (k3 && d.in_scale && d.in_affine_per_n) return false;
   if (d.stats && d.stat_rows_per_group > 0 && d.stat_rows_per_group != d.Do * d.Ho * d.Wo) return false;
   if (!g6d_aligned16(d.weight_wino) || (d.in_scale && ((d.Cin & 3) != 0))) return false;
+  // Profitability (measured per layer, profiles/r02_layer_table.md): a block pays ~4 us of prologue / output transform and the
+  // kernel holds a whole SIMD per wave, so layers with a short reduction (K = kd*Cin < 128: 64-channel inputs) or little total work
+  // (M * K * Cout < 1.5e8: the 7-image 8x8 / 16x16 feature-net layers, the 8^3 volume layer) stay on the direct kernels.
+  // (G6D_WINO_MIN_WORK is read per call so that tests can send small shapes down this path; 0 disables the rule.)
+  const char* mw = getenv("G6D_WINO_MIN_WORK");
+  const double min_work = mw ? atof(mw) : 1.5e8;
+  const double M = (double)d.N * d.Di * d.Hi * d.Wi, K = (double)d.kd * d.Cin;
+  if (min_work > 0 && (K < 128 || M * K * d.Cout < min_work)) return false;
   return (long long)d.N * d.Di * d.Hi * d.Wi * d.ld_in < (1ll << 30);
 }
 

@@ -45,6 +45,7 @@ def pytest_sessionstart(session):
     os.environ.setdefault("G6D_PARITY_LOG", os.path.join(ROOT, "gpurun_out", "parity_r02.jsonl"))
 
 
+
 @pytest.fixture(scope="session")
 def golden():
     import numpy as np

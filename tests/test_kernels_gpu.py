@@ -99,8 +99,17 @@ WINO_CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", WINO_CONV_CASES, ids=lambda c: f"{c['N']}x{c['D']}x{c['H']}_{c['Cin']}x{c['Cout']}k{c['k'][0]}")
-def test_conv_on_winograd_kernel(ops, case):
-    _run_conv_case(ops, case, True)
+def test_conv_on_winograd_kernel(ops, case, monkeypatch):
+    """G6D_WINO_MIN_WORK=0 lifts the library's profitability rule (read per call) so that the small test shapes take the Winograd
+    path; the stage-level parity tests run with the production rule."""
+    monkeypatch.setenv("G6D_WINO_MIN_WORK", "0")
+    ops.PROFILE = []
+    try:
+        _run_conv_case(ops, case, True)
+        routed = ops.PROFILE[0][3].startswith("wino3x3")
+    finally:
+        ops.PROFILE = None
+    assert routed == (case["H"] >= 6 and case["s"] == (1, 1, 1)), "unexpected kernel family for this descriptor"
 
 
 def _run_conv_case(ops, case, wino):
