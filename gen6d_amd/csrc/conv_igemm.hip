@@ -186,10 +186,21 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const G6dConv p, con
     for (int j = 0; j < NT; ++j)
       fb[kc & 1][j] = *reinterpret_cast<const f32x4*>(Bs + (wn * WN + j * 32 + li) * LDS_K + kc * 8 + 4 * lh);
   };
-  // MFMA number q of a K step, in (chunk kc, sub-step s, tile i, tile j) order
+  // MFMA number q of a K step, in (chunk kc, sub-step s, tile i, tile j) order.  A wave tile of ONE 32x32 accumulator (the
+  // 64x64 and 128x32 block tiles of the small layers) alternates between two accumulators that are added in front of the
+  // epilogue: instructions issued between two MFMAs on the same accumulator stretch the dependent pair.
+  constexpr bool ONE_ACC = MT * NT == 1;
+  f32x16 acc_odd;
+  if constexpr (ONE_ACC) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc_odd[r] = 0.f;
+  }
   auto mfma_q = [&](int q) {
     const int kc = q / (4 * MT * NT), r = q % (4 * MT * NT);
     const int sidx = r / (MT * NT), i = (r % (MT * NT)) / NT, j = r % NT;
+    if constexpr (ONE_ACC) {
+      if (sidx & 1) { acc_odd = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kc & 1][0][sidx], fb[kc & 1][0][sidx], acc_odd, 0, 0, 0); return; }
+    }
     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kc & 1][i][sidx], fb[kc & 1][j][sidx], acc[i][j], 0, 0, 0);
   };
 
@@ -290,6 +301,10 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const G6dConv p, con
   }
 
   // ---------------------------------------------------------------- epilogue
+  if constexpr (ONE_ACC) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][0][r] += acc_odd[r];
+  }
   const int Cout = p.Cout;
   if (splits > 1) {
     float* ws = p.workspace + (size_t)blockIdx.z * M * Cout;

@@ -92,9 +92,11 @@ __global__ void __launch_bounds__(512) corr_patch_kernel(const float* __restrict
     if (tid < 256) *reinterpret_cast<f32x4*>(dst + brow * LDS_K + 4 * seg) = vbw ? rbw : f32x4{0.f, 0.f, 0.f, 0.f};
   };
 
-  f32x16 acc;
+  // two accumulators, alternating per MFMA and added at the end: a wave owns ONE 32x32 output tile, and instructions issued
+  // between two MFMAs on the same accumulator (fragment requests, barriers) stretch the dependent pair
+  f32x16 acc, acc2;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
 
   if (u_begin < u_end) {
     load_patch(u_begin); load_b(u_begin, 0);
@@ -110,7 +112,10 @@ __global__ void __launch_bounds__(512) corr_patch_kernel(const float* __restrict
     auto mm = [&](int set) {
       if constexpr (MM == 0) {
 #pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][s2], fb[set][s2], acc, 0, 0, 0);
+        for (int s2 = 0; s2 < 4; s2 += 2) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][s2], fb[set][s2], acc, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][s2 + 1], fb[set][s2 + 1], acc2, 0, 0, 0);
+        }
       } else if (set == 1) {
         // reduced precision: one K = 16 MFMA per two 8-channel groups.  It runs whenever set 1 is due and consumes whatever
         // the two sets hold at that point — (group 0 of this tap, deferred group 3 of the previous tap) at the top of a tap,
@@ -161,6 +166,8 @@ __global__ void __launch_bounds__(512) corr_patch_kernel(const float* __restrict
     if constexpr (MM != 0) fa[0] = fb[0] = f32x4{0.f, 0.f, 0.f, 0.f};      // group 2 of the last tap is already in the sum
     mm(1);
   }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
 
   // epilogue: acc rows = output columns tx0 + (r&3) + 8*(r>>2) + 4*lh of image row ty0 + wave; acc column = co = li
   const int oy = ty0 + wave;

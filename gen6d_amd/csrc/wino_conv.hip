@@ -219,7 +219,9 @@ __global__ void __launch_bounds__(128 * NWN, 1) wino_conv3x3_kernel(const WinoAr
     auto rd_u = [&](int g, int j) { ub[g % 3][j] = *reinterpret_cast<const f32x4*>(S + bbase + (g * 4 + j) * USTRIDE); };
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-      acc[12 + (k >> 2)] = __builtin_amdgcn_mfma_f32_32x32x2f32(vD[k >> 2][k & 3], uD[k >> 2][k & 3], acc[12 + (k >> 2)], 0, 0, 0);
+      // consecutive MFMAs go to DIFFERENT accumulators (k & 3): instructions issued between two MFMAs on the same accumulator
+      // stretch the dependent pair (MI355X_MICROARCH.md, per-instruction constants)
+      acc[12 + (k & 3)] = __builtin_amdgcn_mfma_f32_32x32x2f32(vD[k & 3][k >> 2], uD[k & 3][k >> 2], acc[12 + (k & 3)], 0, 0, 0);
       if (k < 8) glds(cn, (c & 1) ^ 1, wave * 8 + k);           // global requests first: they have the longest way to go
       if (k < NPR) load_piece(k, cn);
       if (k < 4) {}
@@ -243,9 +245,9 @@ __global__ void __launch_bounds__(128 * NWN, 1) wino_conv3x3_kernel(const WinoAr
       v[2] = rw[2] - rw[1];
       v[3] = rw[1] - rw[3];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+        for (int j = 0; j < 4; ++j)           // accumulator changes fastest
           acc[i * 4 + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j][s], ub[i % 3][j][s], acc[i * 4 + j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -264,7 +266,7 @@ __global__ void __launch_bounds__(128 * NWN, 1) wino_conv3x3_kernel(const WinoAr
   }
 #pragma unroll
   for (int k = 0; k < 16; ++k)
-    acc[12 + (k >> 2)] = __builtin_amdgcn_mfma_f32_32x32x2f32(vD[k >> 2][k & 3], uD[k >> 2][k & 3], acc[12 + (k >> 2)], 0, 0, 0);
+    acc[12 + (k & 3)] = __builtin_amdgcn_mfma_f32_32x32x2f32(vD[k & 3][k >> 2], uD[k & 3][k >> 2], acc[12 + (k & 3)], 0, 0, 0);
 
   // ---------------------------------------------------------------- epilogue: A^T D A, bias, ReLU, stores, 2x2 max-pool
   const int co = n0 + wn * 32 + li;

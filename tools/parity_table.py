@@ -1,0 +1,34 @@
+#!/usr/bin/env python
+"""gpurun_out/parity_r02.jsonl (written by the GPU tests through tests/parity_log.py) -> profiles/r02_parity.md: the achieved
+error of every parity assertion next to its tolerance and, where the oracle was also run in fp32, next to the fp32 noise of the
+reference's own arithmetic."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "parity_r02.jsonl")
+    dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "r02_parity.md")
+    last = {}
+    for line in open(src):
+        r = json.loads(line)
+        last[(r["test"], r["tensor"])] = r                      # the latest run of each assertion
+    lines = ["# Achieved parity errors on MI355X (round 2)", "",
+             "One row per parity assertion of the `-m gpu` tests (latest run), written by `tests/parity_log.py`.",
+             "`err` = max |HIP path - reference| (vs the float64 oracle unless the row says otherwise); `fp32 noise` = max |oracle fp32 - oracle fp64|,",
+             "i.e. the error of the reference's own arithmetic; acceptance is `err <= max(tol, 1.5 x fp32 noise)` with tol = 1e-4 ABSOLUTE for",
+             "selector / refiner outputs and 1e-4 of the tensor's range for the detector's un-normalised maps (`note`).",
+             "Rows `bf16` / `fp16` belong to the opt-in reduced-precision mode and are graded separately.", "",
+             "| test | tensor | err | tolerance used | fp32 noise of the reference | note |", "|---|---|---|---|---|---|"]
+    for (t, w), r in sorted(last.items()):
+        noise = "" if r["ref_fp32_noise"] is None else f"{r['ref_fp32_noise']:.2e}"
+        lines.append(f"| {t} | {w} | {r['err']:.2e} | {r['tol']:.2e} | {noise} | {r.get('note', '')} |")
+    open(dst, "w").write("\n".join(lines) + "\n")
+    print(f"{len(last)} rows -> {dst}")
+
+
+if __name__ == "__main__":
+    main()

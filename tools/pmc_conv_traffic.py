@@ -11,9 +11,11 @@ import sys
 
 MAIN = ("conv_igemm_kernel", "conv_patch_kernel", "corr_patch_kernel", "conv_igemm_ws_kernel")
 FAMILY = MAIN + ("splitk_reduce",)
+WMAIN = ("wino_conv3x3_kernel",)
+WFAMILY = WMAIN + ("wino_reduce_kernel",)
 
 
-def family_sum(db, counter):
+def family_sum(db, counter, FAMILY=FAMILY, MAIN=MAIN):
     con = sqlite3.connect(db)
     marks = [r[0] for r in con.execute("select start from counters_collection where kernel_name like '%g6d_marker_kernel%' "
                                        "group by dispatch_id order by start")]
@@ -40,6 +42,11 @@ def main():
         "fetch_kb_total": fetch_kb, "write_kb_total": write_kb, "steps": steps, "launches": launches,
         "hbm_bytes_per_launch": (2 * fetch_kb + write_kb) * 1024 / max(launches, 1),
     }
+    wf, wl = family_sum(fetch_db, "FETCH_SIZE", WFAMILY, WMAIN)
+    ww, _ = family_sum(write_db, "WRITE_SIZE", WFAMILY, WMAIN)
+    res["winograd_family"] = {"kernels": "wino_conv3x3_kernel + wino_reduce_kernel (own trunk and the conv layers routed to it)",
+                              "fetch_kb_total": wf, "write_kb_total": ww, "launches": wl,
+                              "hbm_bytes_per_launch": (2 * wf + ww) * 1024 / max(wl, 1)}
     with open(out, "w") as f:
         json.dump(res, f, indent=1)
     print(json.dumps(res))
