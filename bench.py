@@ -13,9 +13,15 @@ path shards by query: every rank holds a replica of the reference state and runs
 collective on the data path); value = N*K / max-over-ranks time.
 
 Extra objects on the JSON line:
-  roofline     — the dominant kernel (g6d_conv_igemm, fp32 MFMA): algorithmic FLOPs of every launch in the timed region
-                 divided by its HIP-event duration (events recorded on the launch stream), against 157.3 TFLOP/s.
-  cpu_baseline — the CPU oracle (a port of the reference's PyTorch-CPU path) timed on this host for one query.
+  roofline     — the dominant MFMA-bound kernel family by serialised time (since round 2 the Winograd kernel: own VGG trunk +
+                 the conv layers routed to it): FLOPs EXECUTED by every launch divided by its HIP-event duration (events
+                 recorded on the launch stream), against 157.3 TFLOP/s; for the Winograd family the direct-form equivalent
+                 (x2.25) is given beside it.  roofline_conv / roofline_winograd — the other family, same fields.
+  cpu_baseline — the CPU oracle (a port of the reference's PyTorch-CPU path) timed on this host for one query: physical
+                 cores, 1 warm-up + min of 3, per-stage seconds, torch.std share.
+  parity_vs_reference — every timed row against the rows the reference's own modules produce (tests/golden/pipeline_rows.npz).
+  lowp         — the same launch mode with bf16 / fp16 matrix-core operands (opt-in speed mode, graded separately).
+  chained      — (--chained) the device-resident predict chain with real data flow between the stages.
   hbm_kernels  — the HBM-bound kernels of the path (selector scan, refiner volume, FC weight stream): algorithmic
                  bytes / HIP-event time against 8 TB/s.
   stages_ms    — per-stage GPU time of one query (eager launches).
@@ -204,24 +210,49 @@ def main():
         return
     # HBM traffic of the dominant kernel family cannot be read without rocprofv3: it is taken from the committed PMC
     # summary of the same command (profiles/r01_pmc_conv_traffic.json, produced with tools/rocpd_pmc.py), else null
-    traffic, traffic_src = None, None
+    traffic_json, traffic_src = {}, None
     for name in ("r02_pmc_conv_traffic.json", "r01_pmc_conv_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
-                traffic = json.load(f)["hbm_bytes_per_launch"]
+                traffic_json = json.load(f)
             traffic_src = "profiles/" + name
             break
-        except (OSError, KeyError, ValueError):
+        except (OSError, ValueError):
             pass
-    # two MFMA-bound kernel families: the conv family (conv_igemm / conv_patch / corr_patch + split-K reduce: the dominant one,
-    # same definition as round 1) and the own trunk (g6d_wino_conv3x3 + its reduce), whose matrix cores execute 1/2.25 of the
-    # direct-form FLOPs — both figures are given for it
-    conv_p = [p for p in prof if not p[3].startswith("wino3x3")]
-    wino_p = [p for p in prof if p[3].startswith("wino3x3")]
-    flops = sum(p[0] for p in conv_p)
-    ms = sum(p[1].elapsed_time(p[2]) for p in conv_p)
-    n_launch = max(len(conv_p), 1)
-    achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    tr_note = (f"STATIC, not measured in this run: {traffic_src} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+               "`bench.py --no-graph`, tools/profile_round.sh); HBM-side bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024")
+    # two MFMA-bound kernel families, both measured with HIP events around every launch (serialised eager re-run of the same
+    # steps after the graph-replay timed region when graphs are used):
+    #   conv      conv_igemm / conv_patch / corr_patch + split-K reduce (same definition as round 1); executed = direct-form FLOPs
+    #   winograd  wino_conv3x3_kernel (own VGG trunk + the conv layers g6d_conv_igemm routes to it) + its reduce; the matrix cores
+    #             execute 1/2.25 of the direct-form FLOPs: `achieved` / `frac` are the EXECUTED rate, the direct-form equivalent
+    #             is given beside it
+    how = "HIP events around every launch, " + ("serialised eager re-run of the same steps after the graph-replay timed region"
+                                                if use_graph else "inside the timed region")
+    fams = {}
+    for key, sel, kname in (("conv", lambda p: not p[3].startswith("wino3x3"),
+                             "g6d_conv_igemm family: conv_igemm / conv_patch / corr_patch kernels (fp32 v_mfma_f32_32x32x2_f32) incl. "
+                             "their split-K reduce"),
+                            ("winograd", lambda p: p[3].startswith("wino3x3"),
+                             "wino_conv3x3_kernel (Winograd F(2x2,3x3) on fp32 v_mfma_f32_32x32x2_f32): own VGG trunk (g6d_wino_conv3x3) + "
+                             "the stride-1 3x3 / 3x3x3 layers g6d_conv_igemm routes to it, incl. wino_reduce_kernel")):
+        pp = [p for p in prof if sel(p)]
+        if not pp:
+            continue
+        fl = sum(p[0] for p in pp)
+        ms = sum(p[1].elapsed_time(p[2]) for p in pp)
+        ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        tj = traffic_json if key == "conv" else traffic_json.get("winograd_family", {})
+        fams[key] = {"bound": "mfma", "kernel": kname, "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": tj.get("hbm_bytes_per_launch"), "traffic_source": tr_note,
+                     "launches_per_step": len(pp) / args.steps, "gflop_per_launch": fl / len(pp) / 1e9,
+                     "avg_launch_ms": ms / len(pp), "ms_per_step": ms / args.steps, "measured": how}
+        if key == "conv":
+            fams[key]["conv_ms_per_step"] = ms / args.steps
+        else:
+            fams[key].update(flops_counted="EXECUTED in the Winograd domain = direct-form / 2.25",
+                             achieved_direct_form_equivalent=2.25 * ach, gflop_direct_form_per_step=2.25 * fl / args.steps / 1e9)
+    dominant = max(fams, key=lambda k: fams[k]["ms_per_step"]) if fams else None
     result = {
         "metric": "query images/sec (detect+select+3x refine), 64 ref views",
         "value": n_queries / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps,
@@ -234,30 +265,13 @@ def main():
                                 else f"query-replicas x{world}"),
                    "launch": (f"hipGraph replay (1 graph = 1 query{', branches forked' if args.fork else ''}), {lanes} queries in flight "
                               "on separate streams") if use_graph else "eager"},
-        "roofline": {"bound": "mfma", "kernel": "g6d_conv_igemm family: conv_igemm / conv_patch / corr_patch kernels "
-                                                 "(fp32 v_mfma_f32_32x32x2_f32) incl. their split-K reduce",
-                     "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                     "traffic_unit": "HBM-side bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)",
-                     "traffic_source": f"STATIC, not measured in this run: {traffic_src} (separate rocprofv3 --pmc passes of "
-                                       "`bench.py --serial`, tools/profile_round.sh)",
-                     "launches_per_step": n_launch / args.steps, "gflop_per_launch": flops / n_launch / 1e9,
-                     "avg_launch_ms": ms / n_launch, "conv_ms_per_step": ms / args.steps,
-                     "measured": "HIP events around every g6d_conv_igemm / g6d_corr2d_patch launch, " +
-                                 ("serialised eager re-run of the same steps after the graph-replay timed region" if use_graph
-                                  else "inside the timed region")},
     }
-    if wino_p:
-        wf = sum(p[0] for p in wino_p)                  # executed (Winograd-domain) FLOPs = direct-form / 2.25
-        wms = sum(p[1].elapsed_time(p[2]) for p in wino_p)
-        result["roofline_winograd"] = {
-            "bound": "mfma", "kernel": "wino_conv3x3_kernel (Winograd F(2x2,3x3) on fp32 MFMA): the own VGG trunk (g6d_wino_conv3x3) and the "
-                                       "stride-1 3x3 / 3x3x3 layers g6d_conv_igemm routes to it (G6dConv.weight_wino), incl. the split reduce",
-            "achieved": wf / (wms * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s executed in the Winograd domain",
-            "frac": wf / (wms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-            "achieved_direct_form_equivalent": 2.25 * wf / (wms * 1e-3) / 1e12,
-            "launches_per_step": len(wino_p) / args.steps, "ms_per_step": wms / args.steps,
-            "gflop_direct_form_per_step": 2.25 * wf / args.steps / 1e9}
+    if dominant:
+        result["roofline"] = dict(fams[dominant], family=dominant,
+                                  note="dominant kernel family by serialised time; the other family follows as roofline_<name>")
+        for k, v in fams.items():
+            if k != dominant:
+                result["roofline_" + k] = v
     # HBM-bound kernels of the path (K5/K6 scan, K12/K13 volume, K15 FC): algorithmic bytes / HIP-event time
     hbm = {}
     for name, recs in prof_hbm.items():

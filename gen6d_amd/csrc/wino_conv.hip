@@ -475,8 +475,11 @@ int wino_run(WinoArgs& a, int mode, int kd, float* workspace, size_t workspace_b
       if (real != sp) continue;
       const double rounds = (double)((grid2 * sp + slots - 1) / slots);
       double t = rounds * (cps_ * 2.7 + 4.0);                                   // us: chunks + prologue / epilogue of a block
-      if (sp > 1) t += 6.0 + (sp + 1) * out_bytes / 3.0e6;                      // reduce launch + its traffic at ~3 TB/s
-      if (t < best * 0.97) { best = t; splits = sp; }                           // prefer fewer splits on near-ties
+      // a split writes sp partial images (4-byte stores per lane), the reduce reads them back and writes the result: charged
+      // at 2.5 TB/s plus the extra launch; a split must buy >= 15 % (measured: marginal splits cost a reduce launch and
+      // 3x the output traffic per query for a few us — profiles/r02_pmc_hbm.md)
+      if (sp > 1) t += 8.0 + (2 * sp + 1) * out_bytes / 2.5e6;
+      if (t < best * 0.85) { best = t; splits = sp; }
     }
   }
   const int cps = (nchunks + splits - 1) / splits;

@@ -10,6 +10,7 @@ G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
 RND = sys.argv[1] if len(sys.argv) > 1 else "r01"
 FAMILY = ("conv_igemm_kernel", "conv_patch_kernel", "corr_patch_kernel", "splitk_reduce")
+WFAMILY = ("wino_conv3x3_kernel", "wino_reduce_kernel")
 
 
 def rd(f):
@@ -20,13 +21,13 @@ def bench_line(log):
     return json.loads([l for l in open(os.path.join(G, log)) if l.startswith('{"metric')][0])
 
 
-def family_ms(stats_md):
+def family_ms(stats_md, family=FAMILY):
     ms, main = 0.0, 0
     for l in stats_md.splitlines():
         c = [x.strip() for x in l.strip("|").split("|")]
-        if len(c) >= 3 and any(k in c[0] for k in FAMILY):
+        if len(c) >= 3 and any(k in c[0] for k in family):
             ms += float(c[2])
-            if "splitk" not in c[0]:
+            if "splitk" not in c[0] and "reduce" not in c[0]:
                 main += int(c[1])
     return ms, main
 
@@ -35,7 +36,7 @@ def main():
     fin, ser = bench_line("prof_final.log"), bench_line("prof_serial.log")
     steps = ser["steps"]
     open(os.path.join(P, f"{RND}_bench_kernel_stats.md"), "w").write(
-        f"# rocprofv3 --kernel-trace --stats of `python bench.py --steps {steps} --warmup 4 --no-cpu-baseline` (1x MI355X)\n\n"
+        f"# rocprofv3 --kernel-trace --stats of `python bench.py --steps {steps} --warmup 4 --no-cpu-baseline --lowp ''` (1x MI355X)\n\n"
         f"Default launch mode ({fin['config']['launch']}): kernels of different queries overlap, so per-kernel durations are\n"
         "inflated by sharing the chip; the serialised run next to this file is the one to compare with the roofline.\n"
         "Produced by tools/profile_round.sh + tools/rocpd_stats.py from the rocpd database, cut to the timed region by the two\n"
@@ -43,40 +44,54 @@ def main():
         + rd("prof_final_stats.md"))
     sstats = rd("prof_serial_stats.md")
     ms, main = family_ms(sstats)
+    wms, wmain = family_ms(sstats, WFAMILY)
     r = ser["roofline"]
+    w = ser.get("roofline_winograd", {})
     gflop_step = r["gflop_per_launch"] * r["launches_per_step"]
+    wg = w.get("gflop_direct_form_per_step", 0.0)
     open(os.path.join(P, f"{RND}_bench_kernel_stats_serial.md"), "w").write(
-        f"# rocprofv3 --kernel-trace --stats of `python bench.py --steps {steps} --warmup 4 --no-cpu-baseline --serial` (1x MI355X)\n\n"
+        f"# rocprofv3 --kernel-trace --stats of `python bench.py --steps {steps} --warmup 4 --no-cpu-baseline --lowp '' --serial` (1x MI355X)\n\n"
         "Same workload, one query at a time, no graph replay (`--serial`), which is how bench.py's roofline pass runs: per-kernel\n"
-        "durations are not inflated by overlap and can be compared with the `roofline` object of the bench JSON.\n"
-        "g6d_conv_igemm family in the timed region: conv_igemm_kernel<...> + conv_patch_kernel<...> + corr_patch_kernel +\n"
-        f"splitk_reduce{{,_rows}}_kernel = {ms:.2f} ms = {ms / steps:.2f} ms per step ({main / steps:.0f} launches per step, "
-        f"{ms / main * 1e3:.1f} us per launch, {gflop_step:.1f} GFLOP per step -> {gflop_step / (ms / steps):.1f} TFLOP/s)\n"
-        f"vs. bench.py's HIP-event figure in the same profiled run: {r['conv_ms_per_step']:.2f} ms per step / "
-        f"{r['avg_launch_ms'] * 1e3:.1f} us per launch ({r['achieved']:.1f} TFLOP/s): the event brackets include the launch gap between\n"
-        "a conv and its split-K reduce and the profiler's per-dispatch overhead (without the profiler: see "
-        f"profiles/{RND}_bench.json).\n\n" + sstats)
+        "durations are not inflated by overlap and can be compared with the `roofline` objects of the bench JSON.\n\n"
+        "* conv family (conv_igemm_kernel<...> + conv_patch_kernel<...> + corr_patch_kernel + splitk_reduce{,_rows}_kernel) in the timed region:\n"
+        f"  {ms:.2f} ms = {ms / steps:.2f} ms per step ({main / steps:.0f} launches per step, {gflop_step:.1f} GFLOP per step -> "
+        f"{gflop_step / (ms / steps):.1f} TFLOP/s by kernel durations; bench.py's HIP-event figure in the same profiled run: "
+        f"{r['conv_ms_per_step']:.2f} ms per step, {r['achieved']:.1f} TFLOP/s — the event brackets include launch gaps and the profiler's per-dispatch overhead).\n"
+        "* Winograd family (wino_conv3x3_kernel<MODE,KD,NWN> + wino_reduce_kernel: the own VGG trunk and the conv layers routed to it):\n"
+        f"  {wms:.2f} ms = {wms / steps:.2f} ms per step ({wmain / steps:.0f} launches per step, {wg:.1f} GFLOP per step in DIRECT form = "
+        f"{wg / 2.25:.1f} GFLOP executed in the Winograd domain -> {wg / 2.25 / max(wms / steps, 1e-9):.1f} TFLOP/s executed, "
+        f"{wg / max(wms / steps, 1e-9):.1f} TFLOP/s direct-form equivalent; bench.py: {w.get('ms_per_step', 0):.2f} ms per step, "
+        f"{w.get('achieved', 0):.1f} TFLOP/s executed).\n\n" + sstats)
     traffic = json.load(open(os.path.join(G, "pmc_conv_traffic.json")))
     open(os.path.join(P, f"{RND}_pmc_hbm.md"), "w").write(
         "# HBM traffic counters (rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes, no other trace domains)\n\n"
-        "`python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-graph`, dispatches inside the timed region (3 steps). Unit: KB.\n"
+        "`python bench.py --steps 3 --warmup 2 --no-cpu-baseline --lowp '' --no-graph`, dispatches inside the timed region (3 steps). Unit: KB.\n"
         "gfx950 note (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports half the bytes of a wide coalesced stream — double it before comparing.\n\n"
         "Checks against algorithmic bytes (per dispatch, tables below):\n"
         "* `scan_kernel` (selector score maps): FETCH x2 vs algorithmic (168+42+10.5)/3 = 73.5 MB — the reference cache is read once.\n"
         "* `refiner_volume_kernel`: WRITE vs algorithmic 50.3 MB (mean|query 33.5 MB + std 16.8 MB).\n"
-        f"* conv family (tools/pmc_conv_traffic.py -> {RND}_pmc_conv_traffic.json): {traffic['hbm_bytes_per_launch'] / 1e6:.1f} MB HBM-side per launch "
-        "against 5.45 GFLOP per launch: far from HBM-bound.\n\n"
+        f"* conv family (tools/pmc_conv_traffic.py -> {RND}_pmc_conv_traffic.json): {traffic['hbm_bytes_per_launch'] / 1e6:.1f} MB HBM-side per launch; "
+        f"Winograd family: {traffic.get('winograd_family', {}).get('hbm_bytes_per_launch', 0) / 1e6:.1f} MB per launch — both far from HBM-bound.\n\n"
         "## FETCH_SIZE\n" + rd("pmc_fetch.md") + "\n## WRITE_SIZE\n" + rd("pmc_write.md"))
     open(os.path.join(P, f"{RND}_pmc_mfma.md"), "w").write(
         "# MFMA-busy counter (rocprofv3 --kernel-trace --pmc MfmaUtil, own pass)\n\n"
         "`python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-graph --serial`; `MfmaUtil` is rocprofv3's derived metric\n"
         "`sum(SQ_VALU_MFMA_BUSY_CYCLES) / (max(GRBM_GUI_ACTIVE) * SIMD_NUM) * 100` per dispatch; the last column is the mean over the\n"
-        "kernel's dispatches inside the timed region (small and large layers of one instantiation mixed).  For scale: the\n"
-        "32^3 x 256 -> 64 layer (conv_patch_kernel<1,0>) runs at 104 TFLOP/s = 66 % of the 157.3 TFLOP/s fp32 MFMA peak.\n\n"
+        "kernel's dispatches inside the timed region (small and large layers of one instantiation mixed).\n\n"
         + rd("pmc_mfmautil.md"))
     shutil.copy(os.path.join(G, "pmc_conv_traffic.json"), os.path.join(P, f"{RND}_pmc_conv_traffic.json"))
-    if os.path.exists(os.path.join(G, "bench_final.json")):
-        shutil.copy(os.path.join(G, "bench_final.json"), os.path.join(P, f"{RND}_bench.json"))
+    for src, dst in (("bench_final.json", "bench.json"), ("layer_table.md", "layer_table.md"), ("trunk_bench.md", "trunk_bench.md"),
+                     ("bench_gpus2.json", "bench_gpus2.json"), ("bench_gpus2_shard.json", "bench_gpus2_shard_refs.json"),
+                     ("bench_chained.json", "bench_chained.json")):
+        if os.path.exists(os.path.join(G, src)):
+            shutil.copy(os.path.join(G, src), os.path.join(P, f"{RND}_{dst}"))
+    if os.path.exists(os.path.join(G, "convbench_direct.log")):
+        open(os.path.join(P, f"{RND}_conv_microbench.md"), "w").write(
+            "# g6d_conv_igemm micro-benchmark (tools/conv_bench.py, HIP events, 10 reps per shape, 1x MI355X)\n\n"
+            "TFLOP/s are DIRECT-form FLOPs over time in both tables; a layer that runs on the Winograd kernel executes 1/2.25 of them.\n\n"
+            "## direct kernels (conv_igemm / conv_patch / corr_patch)\n\n```\n" + rd("convbench_direct.log") + "```\n\n"
+            "## with G6dConv.weight_wino set (eligible layers on the Winograd kernel; production routing rule applies)\n\n```\n"
+            + (rd("convbench_wino.log") if os.path.exists(os.path.join(G, "convbench_wino.log")) else "") + "```\n")
 
 
 if __name__ == "__main__":
