@@ -309,7 +309,6 @@ def main():
         lrows = torch.cat(lrows, 0).cpu()
         entry = {"dtype": mode, "value": args.steps / ldt, "unit": "images/s", "ms_per_step": ldt / args.steps * 1e3}
         if (args.sel_refs, args.det_refs) == (64, 32) and os.path.exists(gpath):
-            import numpy as np
             gold = torch.from_numpy(np.load(gpath)["rows"]).float()
             ref = torch.stack([gold[(args.warmup + i) % 4] for i in range(args.steps)])
             d = (lrows - ref).abs()
@@ -346,11 +345,16 @@ def main():
         t1 = time.perf_counter()
         res = chain.predict_many(qi[:n_c], qk[:n_c], lanes)
         cdt = time.perf_counter() - t1
-        host_p, _ = est.predict(imgs[0], Ks[0])
+        _, inter_h = est.predict(imgs[0], Ks[0])                      # the host-driven path (numpy pose algebra, 5+ syncs per query)
+        _, inter_d = est.predict_device(imgs[0], Ks[0])               # the same query through the eager device chain
         result["chained"] = {"value": n_c / cdt, "unit": "images/s", "ms_per_query": cdt / n_c * 1e3, "queries": n_c, "lanes": lanes,
                              "database": "procedural sphere, 66 reference views 480x640, 64/32 selected; build incl. rendering "
                                          f"{cbuild:.1f} s", "finite": bool(all(np.isfinite(p).all() for p, _ in res)),
-                             "first_pose_vs_host_driven_predict_maxabs": float(np.abs(res[0][0] - host_p).max())}
+                             "vs_host_driven_predict": {
+                                 "same_viewpoint": bool(inter_d["sel_ref_idx"] == inter_h["sel_ref_idx"]),
+                                 "pose_from_detection_and_selection_maxabs": float(np.abs(inter_d["refine_poses"][0] - inter_h["refine_poses"][0]).max()),
+                                 "after_1_refine_step_maxabs": float(np.abs(inter_d["refine_poses"][1] - inter_h["refine_poses"][1]).max()),
+                                 "note": "later steps diverge: the randomly initialised refiner amplifies single grey levels of the crops"}}
 
     def row_diff(got, ref):
         """Row layout: position(2, px), scale, ref_idx, angle, quaternion(4), offset(2), log2-scale."""
@@ -362,7 +366,6 @@ def main():
     # the four synthetic queries were produced from /root/reference by tests/golden/make_golden_r02.py (pipeline_rows.npz)
     default_cfg = (args.sel_refs, args.det_refs) == (64, 32) and not shard_refs
     if default_cfg and os.path.exists(gpath):
-        import numpy as np
         gold = torch.from_numpy(np.load(gpath)["rows"]).float()
         worst = {"ref_idx_equal": True, "max_abs_diff_row": 0.0, "max_rel_diff_row": 0.0}
         per_rank = args.steps
