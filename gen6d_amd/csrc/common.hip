@@ -2,6 +2,9 @@
 #include "g6d_common.h"
 #include <string.h>
 #include <stdio.h>
+#include <mutex>
+#include <set>
+#include <utility>
 
 static thread_local char g_err[256] = "";
 
@@ -15,6 +18,17 @@ int g6d_check_launch(const char* what) {
   if (e == hipSuccess) return G6D_OK;
   snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
   return G6D_ELAUNCH;
+}
+
+// Raise a kernel's dynamic-LDS limit once per (kernel, device): the attribute belongs to the device's copy of the code object,
+// so a process that drives several GPUs has to set it on each of them.
+void g6d_allow_lds(const void* func, int bytes) {
+  static std::mutex mu;
+  static std::set<std::pair<const void*, int>> done;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lock(mu);
+  if (done.insert({func, dev}).second) (void)hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
 extern "C" int g6d_abi_version(void) { return 3; }

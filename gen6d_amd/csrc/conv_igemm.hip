@@ -30,8 +30,7 @@
 
 int g6d_splitk_reduce_launch(const float* ws, int splits, int M, int Cout, const float* bias, int act, float* out,
                              int ld_out, double* stats, int rows_per_group, hipStream_t stream);
-// conv_igemm_ws.hip: warp-specialised variant (producer waves load, consumer waves run the MFMAs)
-int g6d_conv_igemm_ws_launch(const G6dConv& d, int M, int T, int nChunks, int bn, int splits, hipStream_t stream);
+int g6d_split_finish_max();
 // wino_conv.hip: eligible 3x3 / 3x3x3 stride-1 layers with pre-transformed filters (G6dConv.weight_wino) on the Winograd kernel
 bool g6d_wino_eligible(const G6dConv& d);
 int g6d_wino_launch(const G6dConv& d, hipStream_t stream);
@@ -52,7 +51,7 @@ __device__ __forceinline__ f32x4 ldg(const float* __restrict__ base, int elem_of
 template <int BM, int BN, int WGM, int WGN, int MODE, int MM>
 __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const G6dConv p, const int M, const int T,
                                                          const int nChunks, const int itersPerSplit,
-                                                         const int totalIters, const int splits) {
+                                                         const int totalIters, const int splits, const int finish) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int WM = BM / WGM, WN = BN / WGN;
   constexpr int MT = WM / 32, NT = WN / 32;
@@ -306,8 +305,8 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const G6dConv p, con
     for (int r = 0; r < 16; ++r) acc[0][0][r] += acc_odd[r];
   }
   const int Cout = p.Cout;
-  if (splits > 1) {
-    float* ws = p.workspace + (size_t)blockIdx.z * M * Cout;
+  if (splits > 1 && !finish) {      // many splits: row-major partials for the separate, chip-wide reduce kernel
+    float* ws = p.workspace + G6D_WS_COUNTERS + (size_t)blockIdx.z * M * Cout;
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -320,6 +319,54 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const G6dConv p, con
         }
       }
     return;
+  }
+  if (splits > 1) {
+    // partial tile -> workspace as [split][tile][(i, j, r/4)][thread] 16-byte pieces; the block that arrives last adds them in
+    // split order (ZU splits in flight: the partials of other XCDs come from HBM / Infinity Cache, ~1.5 us away) and goes on
+    // to the epilogue below
+    constexpr int TILE = BM * BN;                              // = MT * NT * 16 floats x 256 threads
+    constexpr int PIECES = MT * NT * 4;
+    constexpr int ZU = 16 / PIECES;                          // 16 pieces in flight: no more registers than the K loop needs
+    const int ntiles = gridDim.x * gridDim.y, tile = blockIdx.y * gridDim.x + blockIdx.x;
+    float* part = p.workspace + G6D_WS_COUNTERS + (size_t)tile * TILE + tid * 4;
+    const size_t zstride = (size_t)ntiles * TILE;
+    float* mine = part + blockIdx.z * zstride;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<f32x4*>(mine + ((i * NT + j) * 4 + q) * 1024) =
+              f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+    if (!g6d_split_arrive(reinterpret_cast<int*>(p.workspace) + tile, splits)) return;
+    f32x4 sum[PIECES];
+#pragma unroll
+    for (int k = 0; k < PIECES; ++k) sum[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int z0 = 0; z0 < splits; z0 += ZU) {
+      f32x4 v[ZU][PIECES];
+#pragma unroll
+      for (int u = 0; u < ZU; ++u) {
+        const float* src = part + (size_t)min(z0 + u, splits - 1) * zstride;
+#pragma unroll
+        for (int k = 0; k < PIECES; ++k) v[u][k] = *reinterpret_cast<const f32x4*>(src + k * 1024);
+      }
+#pragma unroll
+      for (int u = 0; u < ZU; ++u)
+        if (z0 + u < splits) {
+#pragma unroll
+          for (int k = 0; k < PIECES; ++k) sum[k] += v[u][k];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 t = sum[(i * NT + j) * 4 + q];
+          acc[i][j][4 * q] = t[0]; acc[i][j][4 * q + 1] = t[1]; acc[i][j][4 * q + 2] = t[2]; acc[i][j][4 * q + 3] = t[3];
+        }
   }
 
   const bool do_stats = p.stats != nullptr;
@@ -510,21 +557,16 @@ int launch_mm(const G6dConv& d, int M, int T, int nChunks, int splits, hipStream
   const int ips = (total + splits - 1) / splits;
   splits = (total + ips - 1) / ips;
   dim3 grid((M + BM - 1) / BM, (d.Cout + BN - 1) / BN, splits);
+  const int finish = splits > 1 && splits <= g6d_split_finish_max() && (int)(grid.x * grid.y) <= G6D_WS_COUNTERS &&
+                     d.workspace_bytes >= G6D_WS_COUNTER_BYTES + (size_t)splits * grid.x * grid.y * BM * BN * sizeof(float);
   const size_t lds_bytes = 2 * (size_t)(BM + BN) * LDS_K * sizeof(float);
-  static bool attr_done = false;   // per template instantiation
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WGM, WGN, MODE, MM>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    attr_done = true;
-  }
+  g6d_allow_lds(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WGM, WGN, MODE, MM>), (int)lds_bytes);
   hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, MODE, MM>), grid, dim3(256), lds_bytes, stream, d, M, T, nChunks,
-                     ips, total, splits);
+                     ips, total, splits, finish);
   int rc = g6d_check_launch("conv_igemm");
-  if (rc != G6D_OK) return rc;
-  if (splits > 1)
-    rc = g6d_splitk_reduce_launch(d.workspace, splits, M, d.Cout, d.bias, d.out_act, d.out, d.ld_out, d.stats,
+  if (rc != G6D_OK || splits == 1 || finish) return rc;
+  return g6d_splitk_reduce_launch(d.workspace + G6D_WS_COUNTERS, splits, M, d.Cout, d.bias, d.out_act, d.out, d.ld_out, d.stats,
                                   d.stat_rows_per_group, stream);
-  return rc;
 }
 
 template <int BM, int BN, int WGM, int WGN, int MODE>
@@ -543,6 +585,13 @@ int launch_cfg(const G6dConv& d, int M, int T, int nChunks, int splits, hipStrea
 }
 
 }  // namespace
+
+// Split launches with up to this many splits finish inside the kernel (g6d_common.h); above it the separate reduce kernel, which
+// spreads the partial sums over the whole chip, is the faster one.  G6D_SPLIT_FINISH_MAX overrides (0 = always separate).
+int g6d_split_finish_max() {
+  static const int v = []() { const char* e = getenv("G6D_SPLIT_FINISH_MAX"); return e ? atoi(e) : 16; }();
+  return v;
+}
 
 // Shared with corr_patch.hip: sum split-K partials [splits][M][Cout] into out with the common epilogue.
 int g6d_splitk_reduce_launch(const float* ws, int splits, int M, int Cout, const float* bias, int act, float* out,
@@ -629,21 +678,15 @@ extern "C" int g6d_conv_igemm(const G6dConv* desc, g6d_stream_t stream_) {
     }
   }
   if (splits > total) splits = total;
-  if (splits > 1) {
-    const size_t need = (size_t)splits * M * d.Cout * sizeof(float);
-    if (!d.workspace || d.workspace_bytes < need) {
+  if (splits > 1) {     // workspace = tile counters + [split][tile] partial tiles (g6d_common.h)
+    const size_t per = (size_t)blocks * bm * bn * sizeof(float);
+    const size_t room = d.workspace && d.workspace_bytes > G6D_WS_COUNTER_BYTES ? d.workspace_bytes - G6D_WS_COUNTER_BYTES : 0;
+    if (room < (size_t)splits * per || blocks > G6D_WS_COUNTERS) {
       if (d.split_k > 1) { g6d_set_error("conv: workspace too small for forced split_k"); return G6D_ENOSPC; }
-      size_t per = (size_t)M * d.Cout * sizeof(float);
-      splits = d.workspace ? (int)(d.workspace_bytes / per) : 1;
+      splits = blocks > G6D_WS_COUNTERS ? 1 : (int)(room / per);
       if (splits < 2) splits = 1;
     }
   }
-  // Warp-specialised variant for the 128-row tiles (all prologue modes except the per-image affine tables), opt-in with
-  // G6D_CONV_WS=1: it measures the same 90 TFLOP/s as the single-role kernel on the large layers and is slower with the
-  // multiplier prologue, i.e. moving the load path to other waves does not lift the limit.
-  static const bool use_ws = []() { const char* e = getenv("G6D_CONV_WS"); return e && e[0] == '1'; }();
-  if (use_ws && bm == 128 && !(d.in_scale && d.in_affine_per_n))
-    return g6d_conv_igemm_ws_launch(d, M, T, nChunks, bn, splits, stream);
   if (bm == 64) return launch_cfg<64, 64, 2, 2>(d, M, T, nChunks, splits, stream);
   if (bn == 32) return launch_cfg<128, 32, 4, 1>(d, M, T, nChunks, splits, stream);
   if (bn == 64) return launch_cfg<128, 64, 2, 2>(d, M, T, nChunks, splits, stream);

@@ -19,6 +19,7 @@
 
 int g6d_splitk_reduce_launch(const float* ws, int splits, int M, int Cout, const float* bias, int act, float* out,
                              int ld_out, double* stats, int rows_per_group, hipStream_t stream);
+int g6d_split_finish_max();
 
 namespace {
 
@@ -41,7 +42,7 @@ template <> struct TileGeo<2> { static constexpr int TN = 2, TD = 1, TH = 8, TW 
 template <int KIND, int MODE, int VAR>
 __global__ void __launch_bounds__(256) conv_patch_kernel(const G6dConv p, const int M, const int tiles_d, const int tiles_h,
                                                          const int tiles_w, const int chunks_per_split,
-                                                         const int total_chunks, const int splits) {
+                                                         const int total_chunks, const int splits, const int finish) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   using G = TileGeo<KIND>;
   constexpr int TN = G::TN, TD = G::TD, TH = G::TH, TW = G::TW, KD = G::KD, T = KD * 9;
@@ -273,8 +274,8 @@ __global__ void __launch_bounds__(256) conv_patch_kernel(const G6dConv p, const 
     ok = (n + on < p.N) & (d < D) & (h < H) & (w < W);
     return (((n + on) * D + d) * H + h) * W + w;
   };
-  if (splits > 1) {
-    float* ws = p.workspace + (size_t)blockIdx.z * M * Cout;
+  if (splits > 1 && !finish) {       // row-major partials for the separate reduce kernel
+    float* ws = p.workspace + G6D_WS_COUNTERS + (size_t)blockIdx.z * M * Cout;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -283,6 +284,32 @@ __global__ void __launch_bounds__(256) conv_patch_kernel(const G6dConv p, const 
         if (ok && cval) ws[(size_t)row * Cout + col] = acc[mt][r];
       }
     return;
+  }
+  if (splits > 1) {                   // lane-linear partial tile; the block that arrives last adds them up (g6d_common.h)
+    constexpr int TILE = 256 * 32;
+    const int ntiles = gridDim.x * gridDim.y, tile = blockIdx.y * gridDim.x + blockIdx.x;
+    float* part = p.workspace + G6D_WS_COUNTERS + (size_t)tile * TILE + tid * 4;
+    const size_t zstride = (size_t)ntiles * TILE;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      *reinterpret_cast<f32x4*>(part + blockIdx.z * zstride + k * 1024) =
+          f32x4{acc[k >> 2][4 * (k & 3)], acc[k >> 2][4 * (k & 3) + 1], acc[k >> 2][4 * (k & 3) + 2], acc[k >> 2][4 * (k & 3) + 3]};
+    if (!g6d_split_arrive(reinterpret_cast<int*>(p.workspace) + tile, splits)) return;
+    f32x4 sum[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sum[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < splits; ++z) {            // 8 pieces in flight: no more registers than the tap loop needs
+      f32x4 v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const f32x4*>(part + (size_t)z * zstride + k * 1024);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) sum[k] += v[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      acc[k >> 2][4 * (k & 3)] = sum[k][0]; acc[k >> 2][4 * (k & 3) + 1] = sum[k][1];
+      acc[k >> 2][4 * (k & 3) + 2] = sum[k][2]; acc[k >> 2][4 * (k & 3) + 3] = sum[k][3];
+    }
   }
   const bool do_stats = p.stats != nullptr;
   const int g0 = p.stat_rows_per_group > 0 ? n : 0;           // per-image groups only with one image per tile (host check)
@@ -329,25 +356,22 @@ int launch_patch(const G6dConv& d, int M, hipStream_t stream) {
   if (tiles * ntn < 200 && total_chunks >= 4 && d.workspace) {
     splits = (400 + tiles * ntn - 1) / (tiles * ntn);
     if (splits > total_chunks / 2) splits = total_chunks / 2;
-    const size_t per = (size_t)M * d.Cout * sizeof(float);
-    if ((size_t)splits * per > d.workspace_bytes) splits = (int)(d.workspace_bytes / per);
-    if (splits < 2) splits = 1;
+    const size_t per = (size_t)tiles * ntn * 256 * 32 * sizeof(float);      // tile-padded partials (>= M * Cout)
+    const size_t room = d.workspace_bytes > G6D_WS_COUNTER_BYTES ? d.workspace_bytes - G6D_WS_COUNTER_BYTES : 0;
+    if ((size_t)splits * per > room) splits = (int)(room / per);
+    if (splits < 2 || tiles * ntn > G6D_WS_COUNTERS) splits = 1;
   }
   const int cps = (total_chunks + splits - 1) / splits;
   splits = (total_chunks + cps - 1) / cps;
+  const int finish = splits > 1 && splits <= g6d_split_finish_max();
   const size_t lds_bytes = (size_t)(NPOS * LDS_K + 2 * BN * LDS_K) * sizeof(float);
   static const bool pipe = []() { const char* e = getenv("G6D_PATCH_PIPE"); return !(e && e[0] == '0'); }();
   const int var = d.math_mode == 1 ? 2 : d.math_mode == 2 ? 3 : (pipe ? 0 : 1);
   auto go = [&](auto V) {
     constexpr int VAR = decltype(V)::value;
-    static bool attr_done = false;      // per instantiation
-    if (!attr_done) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_patch_kernel<KIND, MODE, VAR>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-      attr_done = true;
-    }
+    g6d_allow_lds(reinterpret_cast<const void*>(&conv_patch_kernel<KIND, MODE, VAR>), (int)lds_bytes);
     hipLaunchKernelGGL((conv_patch_kernel<KIND, MODE, VAR>), dim3(tiles, ntn, splits), dim3(256), lds_bytes, stream, d, M,
-                       tiles_d, tiles_h, tiles_w, cps, total_chunks, splits);
+                       tiles_d, tiles_h, tiles_w, cps, total_chunks, splits, finish);
   };
   switch (var) {
     case 0: go(std::integral_constant<int, 0>{}); break;
@@ -356,8 +380,8 @@ int launch_patch(const G6dConv& d, int M, hipStream_t stream) {
     default: go(std::integral_constant<int, 3>{}); break;
   }
   int rc = g6d_check_launch("conv_patch");
-  if (rc != G6D_OK || splits == 1) return rc;
-  return g6d_splitk_reduce_launch(d.workspace, splits, M, d.Cout, d.bias, d.out_act, d.out, d.ld_out, d.stats,
+  if (rc != G6D_OK || splits == 1 || finish) return rc;
+  return g6d_splitk_reduce_launch(d.workspace + G6D_WS_COUNTERS, splits, M, d.Cout, d.bias, d.out_act, d.out, d.ld_out, d.stats,
                                   d.stat_rows_per_group, stream);
 }
 

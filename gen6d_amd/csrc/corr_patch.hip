@@ -29,7 +29,8 @@ template <int MM>     // 0 = fp32 MFMA; 1 / 2 = bf16 / fp16 operands (two 8-chan
 __global__ void __launch_bounds__(512) corr_patch_kernel(const float* __restrict__ in, const float* __restrict__ wgt,
                                                          float* __restrict__ out, int H, int W, int Cin, int ld_in,
                                                          int Cout, int kh, int kw, int ph, int pw, int ld_out,
-                                                         int units_per_split, int total_units, int splits, int tiles_x) {
+                                                         int units_per_split, int total_units, int splits, int tiles_x,
+                                                         float* __restrict__ ws, int finish) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int PW = TW + kw - 1;                       // patch width in positions
   const int patch_floats = TH * PW * LDS_K;
@@ -169,11 +170,42 @@ __global__ void __launch_bounds__(512) corr_patch_kernel(const float* __restrict
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
 
+  // split launches: finish == 0 leaves row-major partials [split][H*W][Cout] for the separate reduce kernel; otherwise the
+  // partial tile goes to the workspace lane-linearly and the block that arrives last adds them up (g6d_common.h)
+  bool partial = splits > 1;
+  if (splits > 1 && finish) {
+    constexpr int TILE = TH * TW * 32;                       // 512 threads x 16 floats
+    float* part = ws + G6D_WS_COUNTERS + (size_t)blockIdx.x * TILE + tid * 4;
+    const size_t zstride = (size_t)gridDim.x * TILE;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *reinterpret_cast<f32x4*>(part + blockIdx.z * zstride + q * 2048) = f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+    if (!g6d_split_arrive(reinterpret_cast<int*>(ws) + blockIdx.x, splits)) return;
+    f32x4 sum[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sum[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int z0 = 0; z0 < splits; z0 += 4) {      // 4 splits in flight: stays inside the 128 registers of two blocks per CU
+      f32x4 v[4][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[u][q] = *reinterpret_cast<const f32x4*>(part + (size_t)min(z0 + u, splits - 1) * zstride + q * 2048);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (z0 + u < splits) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) sum[q] += v[u][q];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { acc[4 * q] = sum[q][0]; acc[4 * q + 1] = sum[q][1]; acc[4 * q + 2] = sum[q][2]; acc[4 * q + 3] = sum[q][3]; }
+    partial = false;
+  }
   // epilogue: acc rows = output columns tx0 + (r&3) + 8*(r>>2) + 4*lh of image row ty0 + wave; acc column = co = li
   const int oy = ty0 + wave;
   if (oy < H && li < Cout) {
-    float* dst = splits > 1 ? out + (size_t)blockIdx.z * H * W * Cout : out;
-    const int ld = splits > 1 ? Cout : ld_out;
+    float* dst = partial ? ws + G6D_WS_COUNTERS + (size_t)blockIdx.z * H * W * Cout : out;
+    const int ld = partial ? Cout : ld_out;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int ox = tx0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -187,6 +219,7 @@ __global__ void __launch_bounds__(512) corr_patch_kernel(const float* __restrict
 // Declared in conv_igemm.hip: sums split-K partials [splits][M][Cout] into out (+bias, activation, statistics).
 int g6d_splitk_reduce_launch(const float* ws, int splits, int M, int Cout, const float* bias, int act, float* out,
                              int ld_out, double* stats, int rows_per_group, hipStream_t stream);
+int g6d_split_finish_max();
 
 // Stride-1 2-D cross-correlation without bias for Cout <= 32 (the detector's reference-as-filter correlation).
 //   in  [H][W][ld_in] channels-last, wgt [Cout][kh*kw][Cin], out [H*W][ld_out]; zero padding (ph, pw) with
@@ -206,11 +239,12 @@ extern "C" int g6d_corr2d_patch(const float* in, int H, int W, int Cin, int ld_i
   // pick the split count with the best last-round utilisation, preferring fewer splits on ties
   int splits = 1;
   {
-    const size_t per = (size_t)H * W * Cout * sizeof(float);
+    const size_t per = (size_t)tiles * TH * TW * 32 * sizeof(float);       // tile-padded partials (>= H*W*Cout)
+    const size_t room = workspace && workspace_bytes > G6D_WS_COUNTER_BYTES ? workspace_bytes - G6D_WS_COUNTER_BYTES : 0;
     int max_s = total_units / 2;
     if (max_s > 64) max_s = 64;
-    if (workspace && per > 0 && (size_t)max_s > workspace_bytes / per) max_s = (int)(workspace_bytes / per);
-    if (!workspace) max_s = 1;
+    if ((size_t)max_s > room / per) max_s = (int)(room / per);
+    if (max_s < 1 || tiles > G6D_WS_COUNTERS) max_s = 1;
     static const int slots = []() { const char* e = getenv("G6D_CORR_SLOTS"); return e ? atoi(e) : 512; }();   // two 58 KB blocks per CU
     double best = -1.0;
     for (int sp = 1; sp <= max_s; ++sp) {
@@ -224,22 +258,17 @@ extern "C" int g6d_corr2d_patch(const float* in, int H, int W, int Cin, int ld_i
   const int ups = (total_units + splits - 1) / splits;
   splits = (total_units + ups - 1) / ups;
   const size_t lds_bytes = (size_t)(TH * (TW + kw - 1) * LDS_K + 2 * 32 * LDS_K) * sizeof(float);
+  const int finish = splits > 1 && splits <= g6d_split_finish_max();
   auto go = [&](auto V) {
     constexpr int MM = decltype(V)::value;
-    static size_t attr_bytes = 0;       // per instantiation
-    if (lds_bytes > attr_bytes) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_patch_kernel<MM>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds_bytes);
-      attr_bytes = lds_bytes;
-    }
-    hipLaunchKernelGGL(corr_patch_kernel<MM>, dim3(tiles, 1, splits), dim3(512), lds_bytes, stream, in, wgt,
-                       splits > 1 ? workspace : out, H, W, Cin, ld_in, Cout, kh, kw, kh / 2, kw / 2, ld_out, ups, total_units,
-                       splits, tiles_x);
+    g6d_allow_lds(reinterpret_cast<const void*>(&corr_patch_kernel<MM>), 160 * 1024);      // the patch size depends on kw
+    hipLaunchKernelGGL(corr_patch_kernel<MM>, dim3(tiles, 1, splits), dim3(512), lds_bytes, stream, in, wgt, out, H, W, Cin,
+                       ld_in, Cout, kh, kw, kh / 2, kw / 2, ld_out, ups, total_units, splits, tiles_x, workspace, finish);
   };
   if (math_mode == 1) go(std::integral_constant<int, 1>{});
   else if (math_mode == 2) go(std::integral_constant<int, 2>{});
   else go(std::integral_constant<int, 0>{});
   int rc = g6d_check_launch("corr2d_patch");
-  if (rc != G6D_OK || splits == 1) return rc;
-  return g6d_splitk_reduce_launch(workspace, splits, H * W, Cout, nullptr, 0, out, ld_out, nullptr, 0, stream);
+  if (rc != G6D_OK || splits == 1 || finish) return rc;
+  return g6d_splitk_reduce_launch(workspace + G6D_WS_COUNTERS, splits, H * W, Cout, nullptr, 0, out, ld_out, nullptr, 0, stream);
 }

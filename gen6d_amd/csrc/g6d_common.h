@@ -34,6 +34,7 @@ __device__ __forceinline__ f32x16 g6d_mfma_lowp(f32x4 alo, f32x4 ahi, f32x4 blo,
 
 int g6d_check_launch(const char* what);   // returns G6D_OK or G6D_ELAUNCH, records the error string
 void g6d_set_error(const char* msg);
+void g6d_allow_lds(const void* func, int bytes);   // hipFuncAttributeMaxDynamicSharedMemorySize, once per (kernel, device)
 
 static inline bool g6d_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
@@ -52,6 +53,29 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// Split launches (a tile's reduction spread over gridDim.z blocks) finish inside the kernel: every block writes its partial
+// tile to the workspace, takes a ticket from the tile's counter, and the block that arrives last adds all partials (in
+// split order, so the sum does not depend on which block that was) and runs the layer's epilogue.  No second kernel, and the
+// partials are read back from L2 by the same lane mapping that wrote them (16-byte lane-linear rows).
+// The counters are the first G6D_WS_COUNTERS ints of the caller's workspace: zero before the first launch, left zero by
+// every launch (include/gen6d_hip.h, "workspace").
+#define G6D_WS_COUNTER_BYTES G6D_WORKSPACE_COUNTER_BYTES
+#define G6D_WS_COUNTERS (G6D_WS_COUNTER_BYTES / 4)
+__device__ __forceinline__ bool g6d_split_arrive(int* counter, int splits) {
+  __shared__ int s_last;
+  __threadfence();                       // release: this thread's partials are visible device-wide (all XCDs) ...
+  __syncthreads();                       // ... for every thread of the block, before the ticket is taken
+  if (threadIdx.x == 0) {
+    const int last = atomicAdd(counter, 1) == splits - 1;
+    if (last) *counter = 0;              // all blocks of the tile have arrived: re-arm for the next launch
+    s_last = last;
+  }
+  __syncthreads();
+  const bool last = s_last != 0;
+  if (last) __threadfence();             // acquire: drop stale lines before reading the other blocks' partials
+  return last;
+}
+
 __device__ __forceinline__ float apply_act(float v, int act) {
   if (act == 1) return fmaxf(v, 0.f);
   if (act == 2) return v > 0.f ? v : 0.1f * v;

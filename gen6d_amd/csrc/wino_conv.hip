@@ -30,6 +30,8 @@
 #include "g6d_common.h"
 #include <stdlib.h>
 
+int g6d_split_finish_max();      // conv_igemm.hip
+
 namespace {
 
 // Raw patch image in LDS: position (q, py, px) of quarter q at ((q*101 + py*10 + px) * 8) floats, its two 4-channel halves
@@ -58,7 +60,8 @@ struct WinoArgs {
   const float* in; const float* U; const float* bias; float* out_full; float* out_pool;
   int N, H, W, Cin, ld_in, Cout, ld_full, ld_pool, relu;      // N = images x depth slices (every slice is a 2-D map)
   int QH, QW;
-  int splits, chunks_per_split; float* ws;       // splits > 1: partial outputs [split][N][H][W][Cout] (no bias / ReLU / pool)
+  int splits, chunks_per_split; float* ws;       // splits > 1: tile counters + partial outputs (no bias / ReLU / pool)
+  int finish;                                    // 1: the last block of a tile sums the partials; 0: wino_reduce_kernel does
   // conv-family extras (zero / null for the trunk)
   int D;                                         // depth slices per image (1 for 2-D layers); KD = 3 pads in depth
   const float* mul; const float* in_scale; const float* in_shift; int in_relu;
@@ -270,9 +273,66 @@ __global__ void __launch_bounds__(128 * NWN, 1) wino_conv3x3_kernel(const WinoAr
 
   // ---------------------------------------------------------------- epilogue: A^T D A, bias, ReLU, stores, 2x2 max-pool
   const int co = n0 + wn * 32 + li;
-  const float bv = (p.bias && p.splits == 1) ? p.bias[co] : 0.f;
-  const bool do_relu = p.relu && p.splits == 1;
-  const bool do_stats = p.stats != nullptr && p.splits == 1;     // split launches: the reduce kernel owns the statistics
+  // output transform first: Y[r] = the 2x2 outputs {y00, y01, y10, y11} of accumulator row r (no bias yet)
+  f32x4 Y[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float sr[2][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      sr[0][j] = acc[0 + j][r] + acc[4 + j][r] + acc[8 + j][r];
+      sr[1][j] = acc[4 + j][r] - acc[8 + j][r] - acc[12 + j][r];
+    }
+    Y[r] = f32x4{sr[0][0] + sr[0][1] + sr[0][2], sr[0][1] - sr[0][2] - sr[0][3], sr[1][0] + sr[1][1] + sr[1][2], sr[1][1] - sr[1][2] - sr[1][3]};
+  }
+  if (p.splits > 1 && !p.finish) {        // many splits: row-major partial outputs for wino_reduce_kernel
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int q = 2 * wm + (r >> 3);
+      const int tyy = lh + 2 * ((r >> 2) & 1), txx = r & 3;
+      int n, oy0, ox0; bool qv;
+      quarter_of(p, q, n, oy0, ox0, qv);
+      const int oy = oy0 + 2 * tyy, ox = ox0 + 2 * txx;
+      if (qv) {
+        float* w = p.ws + G6D_WS_COUNTERS + (size_t)blockIdx.z * p.N * p.H * p.W * p.Cout;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+            if (oy + a < p.H && ox + b < p.W) w[((size_t)(n * p.H + oy + a) * p.W + ox + b) * p.Cout + co] = Y[r][2 * a + b];
+      }
+    }
+    return;
+  }
+  if (p.splits > 1) {
+    // the output transform is linear: partial OUTPUT tiles go to the workspace as [split][tile][r][thread] 16-byte pieces, and
+    // the block that arrives last adds them in split order (g6d_common.h) and carries on with bias / ReLU / pool / statistics
+    constexpr int TILE = THREADS * 64;
+    const int ntiles = gridDim.x * gridDim.y, tile = blockIdx.y * gridDim.x + blockIdx.x;
+    float* part = p.ws + G6D_WS_COUNTERS + (size_t)tile * TILE + tid * 4;
+    const size_t zstride = (size_t)ntiles * TILE;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) *reinterpret_cast<f32x4*>(part + blockIdx.z * zstride + r * (THREADS * 4)) = Y[r];
+    if (!g6d_split_arrive(reinterpret_cast<int*>(p.ws) + tile, p.splits)) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Y[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int z0 = 0; z0 < p.splits; z0 += 2) {
+      f32x4 v[2][16];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[u][r] = *reinterpret_cast<const f32x4*>(part + (size_t)min(z0 + u, p.splits - 1) * zstride + r * (THREADS * 4));
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Y[r] += v[0][r];
+      if (z0 + 1 < p.splits) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Y[r] += v[1][r];
+      }
+    }
+  }
+  const float bv = p.bias ? p.bias[co] : 0.f;
+  const bool do_relu = p.relu != 0;
+  const bool do_stats = p.stats != nullptr;
   const int Hp = p.H >> 1, Wp = p.W >> 1;
   float st1[2] = {0.f, 0.f}, st2[2] = {0.f, 0.f};       // statistics of this lane's column, per quarter of the wave
 #pragma unroll
@@ -282,31 +342,15 @@ __global__ void __launch_bounds__(128 * NWN, 1) wino_conv3x3_kernel(const WinoAr
     const int tyy = lh + 2 * ((r >> 2) & 1), txx = r & 3;
     int n, oy0, ox0; bool qv;
     quarter_of(p, q, n, oy0, ox0, qv);
-    float sr[2][4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      sr[0][j] = acc[0 + j][r] + acc[4 + j][r] + acc[8 + j][r];
-      sr[1][j] = acc[4 + j][r] - acc[8 + j][r] - acc[12 + j][r];
-    }
     float y[2][2];
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      y[a][0] = sr[a][0] + sr[a][1] + sr[a][2] + bv;
-      y[a][1] = sr[a][1] - sr[a][2] - sr[a][3] + bv;
-      if (do_relu) { y[a][0] = fmaxf(y[a][0], 0.f); y[a][1] = fmaxf(y[a][1], 0.f); }
-    }
-    const int oy = oy0 + 2 * tyy, ox = ox0 + 2 * txx;
-    if (p.splits > 1) {
-      if (qv) {
-        float* w = p.ws + (size_t)blockIdx.z * p.N * p.H * p.W * p.Cout;
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-          for (int b = 0; b < 2; ++b)
-            if (oy + a < p.H && ox + b < p.W) w[((size_t)(n * p.H + oy + a) * p.W + ox + b) * p.Cout + co] = y[a][b];
+      for (int b = 0; b < 2; ++b) {
+        y[a][b] = Y[r][2 * a + b] + bv;
+        if (do_relu) y[a][b] = fmaxf(y[a][b], 0.f);
       }
-      continue;
-    }
+    const int oy = oy0 + 2 * tyy, ox = ox0 + 2 * txx;
     if (p.out_full && qv) {
 #pragma unroll
       for (int a = 0; a < 2; ++a)
@@ -431,12 +475,7 @@ template <int MODE, int KD, int NWN>
 int wino_launch_t(WinoArgs& a, long long blocks, hipStream_t stream) {
   constexpr int THREADS = 128 * NWN;
   const size_t lds_bytes = (2 * (size_t)(WRAW_FLOATS + 16 * 32 * NWN * 8) + 4 * THREADS + (MODE == 0 ? 0 : (MODE == 2 ? 8 : 2) * a.Cin)) * sizeof(float);
-  static bool attr_done = false;      // per instantiation
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_conv3x3_kernel<MODE, KD, NWN>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
-  }
+  g6d_allow_lds(reinterpret_cast<const void*>(&wino_conv3x3_kernel<MODE, KD, NWN>), 160 * 1024);
   hipLaunchKernelGGL((wino_conv3x3_kernel<MODE, KD, NWN>), dim3((unsigned)blocks, a.Cout / (32 * NWN), a.splits), dim3(THREADS), lds_bytes,
                      stream, a);
   return g6d_check_launch("wino_conv3x3");
@@ -466,35 +505,40 @@ int wino_run(WinoArgs& a, int mode, int kd, float* workspace, size_t workspace_b
   static const int split_max = []() { const char* e = getenv("G6D_WINO_SPLIT_MAX"); return e ? atoi(e) : 32; }();
   const bool can_reduce = workspace && !(a.Cout & 3) && !(a.ld_full & 3) && !(a.ld_pool & 3) && (!a.out_full || g6d_aligned16(a.out_full)) &&
                           (!a.out_pool || g6d_aligned16(a.out_pool)) && (!a.bias || g6d_aligned16(a.bias)) && g6d_aligned16(workspace);
-  if (can_reduce && split_max > 1 && nchunks >= 4) {
+  const int finish_max = g6d_split_finish_max();
+  const size_t room = workspace && workspace_bytes > G6D_WS_COUNTER_BYTES ? workspace_bytes - G6D_WS_COUNTER_BYTES : 0;
+  const double tile_bytes = (double)grid2 * (128 * nwn) * 64 * sizeof(float);     // one partial image, padded to whole tiles
+  if (room > 0 && grid2 <= G6D_WS_COUNTERS && split_max > 1 && nchunks >= 4) {
     const double out_bytes = (double)a.N * a.H * a.W * a.Cout * sizeof(float);
     double best = 1e30;
     for (int sp = 1; sp <= split_max && sp <= nchunks / 2; ++sp) {
-      if ((double)sp * out_bytes > (double)workspace_bytes) break;
+      const bool fin = sp <= finish_max;
+      if (!fin && !can_reduce) break;
+      if ((double)sp * tile_bytes > (double)room) break;
       const int cps_ = (nchunks + sp - 1) / sp, real = (nchunks + cps_ - 1) / cps_;
       if (real != sp) continue;
       const double rounds = (double)((grid2 * sp + slots - 1) / slots);
       double t = rounds * (cps_ * 2.7 + 4.0);                                   // us: chunks + prologue / epilogue of a block
-      // a split writes sp partial images (4-byte stores per lane), the reduce reads them back and writes the result: charged
-      // at 2.5 TB/s plus the extra launch; a split must buy >= 15 % (measured: marginal splits cost a reduce launch and
-      // 3x the output traffic per query for a few us — profiles/r02_pmc_hbm.md)
-      if (sp > 1) t += 8.0 + (2 * sp + 1) * out_bytes / 2.5e6;
+      // a split writes sp partial images and reads them back: charged at 2.5 TB/s chip-wide, plus either the serial re-read of
+      // sp tiles (64 KB each) by the tile's last block or the extra launch of the reduce kernel; a split must buy >= 15 %
+      if (sp > 1) t += (fin ? 2.0 + 0.6 * sp : 8.0) + (2 * sp + 1) * out_bytes / 2.5e6;
       if (t < best * 0.85) { best = t; splits = sp; }
     }
   }
   const int cps = (nchunks + splits - 1) / splits;
   splits = (nchunks + cps - 1) / cps;
   a.splits = splits; a.chunks_per_split = cps; a.ws = workspace;
+  a.finish = splits > 1 && splits <= finish_max;
   int rc;
   if (kd == 3) rc = mode == 1 ? wino_launch_w<1, 3>(a, blocks, nwn, stream) : wino_launch_w<0, 3>(a, blocks, nwn, stream);
   else if (mode == 3) rc = wino_launch_w<3, 1>(a, blocks, nwn, stream);
   else if (mode == 2) rc = wino_launch_w<2, 1>(a, blocks, nwn, stream);
   else if (mode == 1) rc = wino_launch_w<1, 1>(a, blocks, nwn, stream);
   else rc = wino_launch_w<0, 1>(a, blocks, nwn, stream);
-  if (rc != G6D_OK || splits == 1) return rc;
+  if (rc != G6D_OK || splits == 1 || a.finish) return rc;
   const long long cells = (long long)a.N * ((a.H + 1) / 2) * ((a.W + 1) / 2) * (a.Cout / 4);
   hipLaunchKernelGGL(wino_reduce_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), a.stats ? 2 * a.Cout * sizeof(float) : 0, stream,
-                     workspace, splits, a.N, a.H, a.W, a.Cout, a.bias, a.relu, a.out_full, a.ld_full, a.out_pool, a.ld_pool, a.stats,
+                     workspace + G6D_WS_COUNTERS, splits, a.N, a.H, a.W, a.Cout, a.bias, a.relu, a.out_full, a.ld_full, a.out_pool, a.ld_pool, a.stats,
                      a.D, a.stats_per_image);
   return g6d_check_launch("wino_reduce");
 }

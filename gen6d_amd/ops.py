@@ -79,10 +79,11 @@ def marker(i):
 
 
 def workspace(device):
-    """Split-K scratch, one buffer per (device, stream): launches on different streams may overlap."""
+    """Split scratch, one buffer per (device, stream): launches on different streams may overlap.  Zero-filled once: its head
+    holds the per-tile arrival counters of the split launches, which every launch leaves at zero (include/gen6d_hip.h)."""
     key = (str(device), torch.cuda.current_stream(device).cuda_stream)
     if key not in _WS:
-        _WS[key] = torch.empty(WORKSPACE_BYTES // 4, dtype=torch.float32, device=device)
+        _WS[key] = torch.zeros(WORKSPACE_BYTES // 4, dtype=torch.float32, device=device)
     return _WS[key]
 
 

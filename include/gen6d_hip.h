@@ -56,6 +56,14 @@ int g6d_marker(int id, g6d_stream_t stream);
  *   out[m][co] = act( bias[co] + sum_{tap,ci} X(m,tap,ci) * weight[co][tap][ci] )
  *   X = relu?( (in * mul?) * in_scale + in_shift ), 0 outside the input
  * ---------------------------------------------------------------------------------------------------------------- */
+/* Workspace (g6d_conv_igemm, g6d_corr2d_patch, g6d_wino_conv3x3): layers whose grid would not fill 256 CUs split their
+ * reduction over more blocks.  The workspace holds G6D_WORKSPACE_COUNTER_BYTES of per-tile arrival counters followed by the
+ * partial tiles; the block of a tile that arrives last adds the partials and runs the epilogue (no second kernel up to
+ * 16 splits; beyond that a separate reduce kernel reads the partials).  Contract: 16-byte aligned, the first
+ * G6D_WORKSPACE_COUNTER_BYTES are ZERO before the first call (every call leaves them zero), and the buffer is not shared
+ * by launches that may run concurrently (one per stream).  NULL / 0 disables splitting. */
+#define G6D_WORKSPACE_COUNTER_BYTES 16384
+
 typedef struct G6dConv {
   const float* in;        /* [N][Di][Hi][Wi][ld_in] */
   const float* mul;       /* optional [Hi][Wi][Cin] (dense), broadcast over N and Di; NULL = none */
@@ -65,7 +73,7 @@ typedef struct G6dConv {
   const float* bias;      /* [Cout] or NULL */
   float* out;             /* [N*Do*Ho*Wo][ld_out] */
   double* stats;          /* optional [stat_groups][Cout][2] (sum, sumsq), caller-zeroed; NULL = none */
-  float* workspace;       /* split-K partial sums; may be NULL if workspace_bytes == 0 */
+  float* workspace;       /* split scratch (see "Workspace" below); may be NULL if workspace_bytes == 0 */
   size_t workspace_bytes;
   int32_t N, Di, Hi, Wi, Cin, ld_in;
   int32_t Do, Ho, Wo, Cout, ld_out;
@@ -95,7 +103,7 @@ int g6d_sizeof_conv_desc(void);
 /* Stride-1 2-D cross-correlation without bias for Cout <= 32 with input-patch reuse in LDS: the detector's
  * F.conv2d(que_x0, ref_x0, padding=7) (network/detector.py:224), where the generic kernel is bound by re-loading the
  * activation tile for every one of the 225 taps.  in [H][W][ld_in], wgt [Cout][kh*kw][Cin], out [H*W][ld_out],
- * "same" zero padding (kh, kw odd, kw <= 31).  workspace: split-K partials (splits*H*W*Cout floats). */
+ * "same" zero padding (kh, kw odd, kw <= 31).  workspace: split scratch (see "Workspace"). */
 int g6d_corr2d_patch(const float* in, int H, int W, int Cin, int ld_in, const float* wgt, int Cout, int kh, int kw,
                      float* out, int ld_out, float* workspace, size_t workspace_bytes, int math_mode /* as G6dConv.math_mode */,
                      g6d_stream_t stream);
@@ -140,7 +148,7 @@ int g6d_vgg_conv1_pool_nhwc(const float* in, int N, int H, int W, const float* w
  *        (the two 4-channel halves of a row are swapped for co & 8: bank-conflict-free LDS image, the copy is lane-linear)
  *   y = conv3x3_pad1(in) + bias[co];  relu != 0: y = max(y, 0)
  *   out_full (optional) [N][H][W][ld_full] = y;  out_pool (optional) [N][H/2][W/2][ld_pool] = maxpool2x2(y) (floor)
- *   workspace (optional): small maps split the channel chunks over more blocks; partial outputs (<= 32*N*H*W*Cout floats)
+ *   workspace (optional): small maps split the channel chunks over more blocks (see "Workspace")
  * Replaces the MIOpen convolutions of the trunk and the bias/ReLU/pool and layout passes around them. */
 int g6d_wino_conv3x3(const float* in, int N, int H, int W, int Cin, int ld_in, const float* U, const float* bias, int Cout,
                      int relu, float* out_full, int ld_full, float* out_pool, int ld_pool, float* workspace,

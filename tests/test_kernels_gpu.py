@@ -57,6 +57,11 @@ CONV_CASES = [
     dict(N=1, D=8, H=8, W=8, Cin=256, Cout=256, k=(3, 3, 3), s=(1, 1, 1), p=(1, 1, 1), stats=True, split=1),        # forced no split
     dict(N=1, D=8, H=8, W=8, Cin=256, Cout=256, k=(3, 3, 3), s=(1, 1, 1), p=(1, 1, 1), stats=True, split=7, act=2),
     dict(N=2, D=1, H=5, W=5, Cin=20, Cout=40, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), act=2),                        # odd sizes
+    # split launches: <= 16 splits finish inside the kernel (last block of a tile), more go through the reduce kernel
+    dict(N=1, D=1, H=10, W=10, Cin=512, Cout=96, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), stats=True, split=5, act=1),     # ragged tile, in-kernel
+    dict(N=3, D=1, H=11, W=13, Cin=256, Cout=200, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), stats=True, rpg=143, split=16), # groups straddle tiles
+    dict(N=1, D=4, H=4, W=4, Cin=256, Cout=512, k=(3, 3, 3), s=(2, 2, 2), p=(1, 1, 1), stats=True, split=24),            # reduce kernel
+    dict(N=1, D=8, H=8, W=8, Cin=128, Cout=32, k=(3, 3, 3), s=(2, 2, 2), p=(1, 1, 1), aff=True, relu=True, split=9),     # 128x32 tiles
     # shapes that take the LDS-patch kernel (conv_patch.hip): stride 1, 3x3(x3), Cout <= 64, >= 128 tiles
     dict(N=1, D=16, H=16, W=16, Cin=64, Cout=64, k=(3, 3, 3), s=(1, 1, 1), p=(1, 1, 1), aff=True, relu=True, stats=True),
     dict(N=1, D=16, H=24, W=16, Cin=100, Cout=48, k=(3, 3, 3), s=(1, 1, 1), p=(1, 1, 1), act=1, stats=True, ld_out=64),
@@ -383,15 +388,6 @@ def test_corr2d_patch(ops, H, W, Cin, Cout, k):
     ref_ops.corr2d_patch(_d(x), _d(w), ref, k)
     _check(out, ref, 2e-5, "corr2d_patch")
     assert (obuf[..., Cout:] == -5.0).all()
-
-
-def test_conv_warp_specialised_variant():
-    """The opt-in producer/consumer variant (G6D_CONV_WS=1, read once per process) passes the same conv cases."""
-    import os, subprocess, sys
-    env = dict(os.environ, G6D_CONV_WS="1")
-    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k", "test_conv_igemm"],
-                         env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
 
 
 # ---------------------------------------------------------------------------------------------------- own VGG trunk

@@ -9,7 +9,7 @@ import json
 import sqlite3
 import sys
 
-MAIN = ("conv_igemm_kernel", "conv_patch_kernel", "corr_patch_kernel", "conv_igemm_ws_kernel")
+MAIN = ("conv_igemm_kernel", "conv_patch_kernel", "corr_patch_kernel")
 FAMILY = MAIN + ("splitk_reduce",)
 WMAIN = ("wino_conv3x3_kernel",)
 WFAMILY = WMAIN + ("wino_reduce_kernel",)
