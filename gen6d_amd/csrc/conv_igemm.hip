@@ -14,8 +14,8 @@
 // Pipeline: double-buffered LDS, register-staged global prefetch of K step t+1 issued before the MFMAs of step t,
 // one barrier per K step.  The operand loader applies the fused prologue (elementwise multiplier, InstanceNorm
 // affine, ReLU; zero padding stays exactly zero); the epilogue adds bias/activation and accumulates the
-// InstanceNorm statistics of the output in fp64.  Small grids are split along K into a workspace and reduced by a
-// second kernel that carries the same epilogue.
+// InstanceNorm statistics of the output in fp64.  Small grids are split along K: partial tiles go to a workspace and the
+// block of a tile that arrives last adds them and runs the epilogue (g6d_common.h).
 #include "g6d_common.h"
 #include <type_traits>
 #include <stdlib.h>
@@ -28,9 +28,6 @@
                        // 6 = global loads consumed by a dummy add, no LDS stores, 7 = full kernel without the per-step barrier
 #endif
 
-int g6d_splitk_reduce_launch(const float* ws, int splits, int M, int Cout, const float* bias, int act, float* out,
-                             int ld_out, double* stats, int rows_per_group, hipStream_t stream);
-int g6d_split_finish_max();
 // wino_conv.hip: eligible 3x3 / 3x3x3 stride-1 layers with pre-transformed filters (G6dConv.weight_wino) on the Winograd kernel
 bool g6d_wino_eligible(const G6dConv& d);
 int g6d_wino_launch(const G6dConv& d, hipStream_t stream);
@@ -51,7 +48,7 @@ __device__ __forceinline__ f32x4 ldg(const float* __restrict__ base, int elem_of
 template <int BM, int BN, int WGM, int WGN, int MODE, int MM>
 __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const G6dConv p, const int M, const int T,
                                                          const int nChunks, const int itersPerSplit,
-                                                         const int totalIters, const int splits, const int finish) {
+                                                         const int totalIters, const int splits) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int WM = BM / WGM, WN = BN / WGN;
   constexpr int MT = WM / 32, NT = WN / 32;
@@ -305,21 +302,6 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const G6dConv p, con
     for (int r = 0; r < 16; ++r) acc[0][0][r] += acc_odd[r];
   }
   const int Cout = p.Cout;
-  if (splits > 1 && !finish) {      // many splits: row-major partials for the separate, chip-wide reduce kernel
-    float* ws = p.workspace + G6D_WS_COUNTERS + (size_t)blockIdx.z * M * Cout;
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int col = n0 + wn * WN + j * 32 + li;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (row < M && col < Cout) ws[(size_t)row * Cout + col] = acc[i][j][r];
-        }
-      }
-    return;
-  }
   if (splits > 1) {
     // partial tile -> workspace as [split][tile][(i, j, r/4)][thread] 16-byte pieces; the block that arrives last adds them in
     // split order (ZU splits in flight: the partials of other XCDs come from HBM / Infinity Cache, ~1.5 us away) and goes on
@@ -337,9 +319,10 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const G6dConv p, con
       for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-          *reinterpret_cast<f32x4*>(mine + ((i * NT + j) * 4 + q) * 1024) =
-              f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-    if (!g6d_split_arrive(reinterpret_cast<int*>(p.workspace) + tile, splits)) return;
+          g6d_store_wt(mine + ((i * NT + j) * 4 + q) * 1024,
+                       f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]});
+    if (!g6d_split_arrive(reinterpret_cast<int*>(p.workspace) + tile, splits, reinterpret_cast<int*>(lds))) return;
+    __syncthreads();                                           // the flag word is read; lds is reused below
     f32x4 sum[PIECES];
 #pragma unroll
     for (int k = 0; k < PIECES; ++k) sum[k] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -422,151 +405,17 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const G6dConv p, con
   }
 }
 
-// Sum split-K partials, then the same epilogue as above.  Thread = one row x 4 columns (16-byte loads, 4 splits in
-// flight); block = 32 column-quads x 8 rows, looping over 4 row groups (32 rows x 128 columns per block).
-__global__ void __launch_bounds__(256) splitk_reduce_rows_kernel(const float* __restrict__ ws, int splits, int M, int Cout,
-                                                            const float* __restrict__ bias, int act,
-                                                            float* __restrict__ out, int ld_out, double* stats, int rpg) {
-  __shared__ float sred[128 * 2];
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const int col = blockIdx.y * 128 + tx * 4;
-  const int r0 = blockIdx.x * 32;
-  const int rlast = min(r0 + 32, M) - 1;
-  const int g0 = rpg > 0 ? r0 / rpg : 0;
-  const bool one_group = rpg <= 0 || (rlast / rpg) == g0;
-  sred[threadIdx.x] = 0.f;
-  __syncthreads();
-  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
-  const bool vec = (Cout & 3) == 0;
-  const size_t zstride = (size_t)M * Cout;
-  if (col < Cout) {
-    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < 4; ++k) if (bias && col + k < Cout) bv[k] = bias[col + k];
-    for (int i = 0; i < 4; ++i) {
-      const int row = r0 + ty + 8 * i;
-      if (row >= M) break;
-      const float* src = ws + (size_t)row * Cout + col;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (vec) {
-        f32x4 a0 = v, a1 = v, a2 = v, a3 = v;
-        int z = 0;
-        for (; z + 4 <= splits; z += 4) {
-          a0 += *reinterpret_cast<const f32x4*>(src + (size_t)z * zstride);
-          a1 += *reinterpret_cast<const f32x4*>(src + (size_t)(z + 1) * zstride);
-          a2 += *reinterpret_cast<const f32x4*>(src + (size_t)(z + 2) * zstride);
-          a3 += *reinterpret_cast<const f32x4*>(src + (size_t)(z + 3) * zstride);
-        }
-        for (; z < splits; ++z) a0 += *reinterpret_cast<const f32x4*>(src + (size_t)z * zstride);
-        v = (a0 + a1) + (a2 + a3);
-      } else {
-        for (int k = 0; k < 4; ++k)
-          if (col + k < Cout) for (int z = 0; z < splits; ++z) v[k] += src[(size_t)z * zstride + k];
-      }
-      for (int k = 0; k < 4; ++k) {
-        if (col + k >= Cout) break;
-        const float o = apply_act(v[k] + bv[k], act);
-        out[(size_t)row * ld_out + col + k] = o;
-        if (stats) {
-          if (one_group) { s1[k] += o; s2[k] += o * o; }
-          else {
-            double* st = stats + ((size_t)(row / rpg) * Cout + col + k) * 2;
-            atomicAdd(st, (double)o); atomicAdd(st + 1, (double)o * o);
-          }
-        }
-      }
-    }
-  }
-  if (stats && one_group) {
-    for (int k = 0; k < 4; ++k) { atomicAdd(&sred[(tx * 4 + k) * 2], s1[k]); atomicAdd(&sred[(tx * 4 + k) * 2 + 1], s2[k]); }
-    __syncthreads();
-    if (threadIdx.x < 128 && blockIdx.y * 128 + threadIdx.x < Cout) {
-      double* st = stats + ((size_t)g0 * Cout + blockIdx.y * 128 + threadIdx.x) * 2;
-      atomicAdd(st, (double)sred[threadIdx.x * 2]);
-      atomicAdd(st + 1, (double)sred[threadIdx.x * 2 + 1]);
-    }
-  }
-}
-
-// Variant for many splits / few output rows.  Block = 32 column-quads x 8 split lanes working on
-// 8 rows x 128 columns: the sum over splits is spread over the 8 lanes (16-byte loads) and combined through LDS, so the
-// small-M layers (few output tiles, many splits) still expose thousands of independent loads.
-__global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ ws, int splits, int M, int Cout,
-                                                            const float* __restrict__ bias, int act,
-                                                            float* __restrict__ out, int ld_out, double* stats, int rpg) {
-  __shared__ f32x4 part[8][8][32];       // [row][split lane][column quad]
-  __shared__ float sred[128 * 2];
-  const int tx = threadIdx.x & 31, tz = threadIdx.x >> 5;
-  const int col = blockIdx.y * 128 + tx * 4;
-  const int r0 = blockIdx.x * 8;
-  const int rlast = min(r0 + 8, M) - 1;
-  const int g0 = rpg > 0 ? r0 / rpg : 0;
-  const bool one_group = rpg <= 0 || (rlast / rpg) == g0;
-  sred[threadIdx.x] = 0.f;
-  const bool vec = (Cout & 3) == 0;
-  const size_t zstride = (size_t)M * Cout;
-#pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    const int row = r0 + r;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (row < M && col < Cout) {
-      const float* src = ws + (size_t)row * Cout + col;
-      if (vec) {
-        for (int z = tz; z < splits; z += 8) v += *reinterpret_cast<const f32x4*>(src + (size_t)z * zstride);
-      } else {
-        for (int k = 0; k < 4; ++k)
-          if (col + k < Cout) for (int z = tz; z < splits; z += 8) v[k] += src[(size_t)z * zstride + k];
-      }
-    }
-    part[r][tz][tx] = v;
-  }
-  __syncthreads();
-  // thread (tz = row, tx = column quad) finishes one output quad
-  const int row = r0 + tz;
-  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
-  if (row < M && col < Cout) {
-    f32x4 v = part[tz][0][tx];
-#pragma unroll
-    for (int z = 1; z < 8; ++z) v += part[tz][z][tx];
-    for (int k = 0; k < 4; ++k) {
-      if (col + k >= Cout) break;
-      const float o = apply_act(v[k] + (bias ? bias[col + k] : 0.f), act);
-      out[(size_t)row * ld_out + col + k] = o;
-      if (stats) {
-        if (one_group) { s1[k] = o; s2[k] = o * o; }
-        else {
-          double* st = stats + ((size_t)(row / rpg) * Cout + col + k) * 2;
-          atomicAdd(st, (double)o); atomicAdd(st + 1, (double)o * o);
-        }
-      }
-    }
-  }
-  if (stats && one_group) {
-    for (int k = 0; k < 4; ++k) { atomicAdd(&sred[(tx * 4 + k) * 2], s1[k]); atomicAdd(&sred[(tx * 4 + k) * 2 + 1], s2[k]); }
-    __syncthreads();
-    if (threadIdx.x < 128 && blockIdx.y * 128 + threadIdx.x < Cout) {
-      double* st = stats + ((size_t)g0 * Cout + blockIdx.y * 128 + threadIdx.x) * 2;
-      atomicAdd(st, (double)sred[threadIdx.x * 2]);
-      atomicAdd(st + 1, (double)sred[threadIdx.x * 2 + 1]);
-    }
-  }
-}
-
 template <int BM, int BN, int WGM, int WGN, int MODE, int MM>
 int launch_mm(const G6dConv& d, int M, int T, int nChunks, int splits, hipStream_t stream) {
   const int total = T * nChunks;
   const int ips = (total + splits - 1) / splits;
   splits = (total + ips - 1) / ips;
   dim3 grid((M + BM - 1) / BM, (d.Cout + BN - 1) / BN, splits);
-  const int finish = splits > 1 && splits <= g6d_split_finish_max() && (int)(grid.x * grid.y) <= G6D_WS_COUNTERS &&
-                     d.workspace_bytes >= G6D_WS_COUNTER_BYTES + (size_t)splits * grid.x * grid.y * BM * BN * sizeof(float);
   const size_t lds_bytes = 2 * (size_t)(BM + BN) * LDS_K * sizeof(float);
   g6d_allow_lds(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WGM, WGN, MODE, MM>), (int)lds_bytes);
   hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, MODE, MM>), grid, dim3(256), lds_bytes, stream, d, M, T, nChunks,
-                     ips, total, splits, finish);
-  int rc = g6d_check_launch("conv_igemm");
-  if (rc != G6D_OK || splits == 1 || finish) return rc;
-  return g6d_splitk_reduce_launch(d.workspace + G6D_WS_COUNTERS, splits, M, d.Cout, d.bias, d.out_act, d.out, d.ld_out, d.stats,
-                                  d.stat_rows_per_group, stream);
+                     ips, total, splits);
+  return g6d_check_launch("conv_igemm");
 }
 
 template <int BM, int BN, int WGM, int WGN, int MODE>
@@ -585,28 +434,6 @@ int launch_cfg(const G6dConv& d, int M, int T, int nChunks, int splits, hipStrea
 }
 
 }  // namespace
-
-// Split launches with up to this many splits finish inside the kernel (g6d_common.h); above it the separate reduce kernel, which
-// spreads the partial sums over the whole chip, is the faster one.  G6D_SPLIT_FINISH_MAX overrides (0 = always separate).
-int g6d_split_finish_max() {
-  static const int v = []() { const char* e = getenv("G6D_SPLIT_FINISH_MAX"); return e ? atoi(e) : 16; }();
-  return v;
-}
-
-// Shared with corr_patch.hip: sum split-K partials [splits][M][Cout] into out with the common epilogue.
-int g6d_splitk_reduce_launch(const float* ws, int splits, int M, int Cout, const float* bias, int act, float* out,
-                             int ld_out, double* stats, int rows_per_group, hipStream_t stream) {
-  if (splits > 16) {
-    dim3 g2((M + 7) / 8, (Cout + 127) / 128);
-    hipLaunchKernelGGL(splitk_reduce_kernel, g2, dim3(256), 0, stream, ws, splits, M, Cout, bias, act, out, ld_out, stats,
-                       rows_per_group);
-  } else {
-    dim3 g2((M + 31) / 32, (Cout + 127) / 128);
-    hipLaunchKernelGGL(splitk_reduce_rows_kernel, g2, dim3(256), 0, stream, ws, splits, M, Cout, bias, act, out, ld_out,
-                       stats, rows_per_group);
-  }
-  return g6d_check_launch("splitk_reduce");
-}
 
 // Which kernel family g6d_conv_igemm will run this descriptor on: 0 generic implicit GEMM, 1 LDS-patch kernel, 2 Winograd kernel
 // (no launch; bench.py uses it to book the executed FLOPs of a launch in the right roofline family).

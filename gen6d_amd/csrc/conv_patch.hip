@@ -17,9 +17,6 @@
 #define LDS_K 36
 #define BN 64
 
-int g6d_splitk_reduce_launch(const float* ws, int splits, int M, int Cout, const float* bias, int act, float* out,
-                             int ld_out, double* stats, int rows_per_group, hipStream_t stream);
-int g6d_split_finish_max();
 
 namespace {
 
@@ -42,7 +39,7 @@ template <> struct TileGeo<2> { static constexpr int TN = 2, TD = 1, TH = 8, TW 
 template <int KIND, int MODE, int VAR>
 __global__ void __launch_bounds__(256) conv_patch_kernel(const G6dConv p, const int M, const int tiles_d, const int tiles_h,
                                                          const int tiles_w, const int chunks_per_split,
-                                                         const int total_chunks, const int splits, const int finish) {
+                                                         const int total_chunks, const int splits) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   using G = TileGeo<KIND>;
   constexpr int TN = G::TN, TD = G::TD, TH = G::TH, TW = G::TW, KD = G::KD, T = KD * 9;
@@ -274,17 +271,6 @@ __global__ void __launch_bounds__(256) conv_patch_kernel(const G6dConv p, const 
     ok = (n + on < p.N) & (d < D) & (h < H) & (w < W);
     return (((n + on) * D + d) * H + h) * W + w;
   };
-  if (splits > 1 && !finish) {       // row-major partials for the separate reduce kernel
-    float* ws = p.workspace + G6D_WS_COUNTERS + (size_t)blockIdx.z * M * Cout;
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        bool ok; const int row = out_row(mt, r, ok);
-        if (ok && cval) ws[(size_t)row * Cout + col] = acc[mt][r];
-      }
-    return;
-  }
   if (splits > 1) {                   // lane-linear partial tile; the block that arrives last adds them up (g6d_common.h)
     constexpr int TILE = 256 * 32;
     const int ntiles = gridDim.x * gridDim.y, tile = blockIdx.y * gridDim.x + blockIdx.x;
@@ -292,9 +278,10 @@ __global__ void __launch_bounds__(256) conv_patch_kernel(const G6dConv p, const 
     const size_t zstride = (size_t)ntiles * TILE;
 #pragma unroll
     for (int k = 0; k < 8; ++k)
-      *reinterpret_cast<f32x4*>(part + blockIdx.z * zstride + k * 1024) =
-          f32x4{acc[k >> 2][4 * (k & 3)], acc[k >> 2][4 * (k & 3) + 1], acc[k >> 2][4 * (k & 3) + 2], acc[k >> 2][4 * (k & 3) + 3]};
-    if (!g6d_split_arrive(reinterpret_cast<int*>(p.workspace) + tile, splits)) return;
+      g6d_store_wt(part + blockIdx.z * zstride + k * 1024,
+                   f32x4{acc[k >> 2][4 * (k & 3)], acc[k >> 2][4 * (k & 3) + 1], acc[k >> 2][4 * (k & 3) + 2], acc[k >> 2][4 * (k & 3) + 3]});
+    if (!g6d_split_arrive(reinterpret_cast<int*>(p.workspace) + tile, splits, reinterpret_cast<int*>(lds))) return;
+    __syncthreads();                                           // the flag word is read; lds is reused below
     f32x4 sum[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) sum[k] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -363,7 +350,6 @@ int launch_patch(const G6dConv& d, int M, hipStream_t stream) {
   }
   const int cps = (total_chunks + splits - 1) / splits;
   splits = (total_chunks + cps - 1) / cps;
-  const int finish = splits > 1 && splits <= g6d_split_finish_max();
   const size_t lds_bytes = (size_t)(NPOS * LDS_K + 2 * BN * LDS_K) * sizeof(float);
   static const bool pipe = []() { const char* e = getenv("G6D_PATCH_PIPE"); return !(e && e[0] == '0'); }();
   const int var = d.math_mode == 1 ? 2 : d.math_mode == 2 ? 3 : (pipe ? 0 : 1);
@@ -371,7 +357,7 @@ int launch_patch(const G6dConv& d, int M, hipStream_t stream) {
     constexpr int VAR = decltype(V)::value;
     g6d_allow_lds(reinterpret_cast<const void*>(&conv_patch_kernel<KIND, MODE, VAR>), (int)lds_bytes);
     hipLaunchKernelGGL((conv_patch_kernel<KIND, MODE, VAR>), dim3(tiles, ntn, splits), dim3(256), lds_bytes, stream, d, M,
-                       tiles_d, tiles_h, tiles_w, cps, total_chunks, splits, finish);
+                       tiles_d, tiles_h, tiles_w, cps, total_chunks, splits);
   };
   switch (var) {
     case 0: go(std::integral_constant<int, 0>{}); break;
@@ -380,9 +366,7 @@ int launch_patch(const G6dConv& d, int M, hipStream_t stream) {
     default: go(std::integral_constant<int, 3>{}); break;
   }
   int rc = g6d_check_launch("conv_patch");
-  if (rc != G6D_OK || splits == 1 || finish) return rc;
-  return g6d_splitk_reduce_launch(d.workspace + G6D_WS_COUNTERS, splits, M, d.Cout, d.bias, d.out_act, d.out, d.ld_out, d.stats,
-                                  d.stat_rows_per_group, stream);
+  return rc;
 }
 
 template <int KIND>

@@ -10,7 +10,7 @@
 //            wave w owns output row w of the tile: lane i -> column i, one 32x32 accumulator tile
 //   unit   = (channel chunk of 32, ky): patch stage [8][32+kw-1][36 floats] (single buffer); per kx one weight tile
 //            [32 co][36] double-buffered; 16 MFMAs (v_mfma_f32_32x32x2_f32) per wave per kx
-//   split  = units are split across gridDim.z; partial tiles go to a workspace and the common split-K reduce adds them.
+//   split  = units are split across gridDim.z; partial tiles go to a workspace, the last block of a tile adds them (g6d_common.h).
 #include "g6d_common.h"
 #include <stdlib.h>
 #include <type_traits>
@@ -30,7 +30,7 @@ __global__ void __launch_bounds__(512) corr_patch_kernel(const float* __restrict
                                                          float* __restrict__ out, int H, int W, int Cin, int ld_in,
                                                          int Cout, int kh, int kw, int ph, int pw, int ld_out,
                                                          int units_per_split, int total_units, int splits, int tiles_x,
-                                                         float* __restrict__ ws, int finish) {
+                                                         float* __restrict__ ws) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int PW = TW + kw - 1;                       // patch width in positions
   const int patch_floats = TH * PW * LDS_K;
@@ -170,17 +170,16 @@ __global__ void __launch_bounds__(512) corr_patch_kernel(const float* __restrict
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
 
-  // split launches: finish == 0 leaves row-major partials [split][H*W][Cout] for the separate reduce kernel; otherwise the
-  // partial tile goes to the workspace lane-linearly and the block that arrives last adds them up (g6d_common.h)
-  bool partial = splits > 1;
-  if (splits > 1 && finish) {
+  // split launches: the partial tile goes to the workspace lane-linearly and the block that arrives last adds them up
+  // (g6d_common.h)
+  if (splits > 1) {
     constexpr int TILE = TH * TW * 32;                       // 512 threads x 16 floats
     float* part = ws + G6D_WS_COUNTERS + (size_t)blockIdx.x * TILE + tid * 4;
     const size_t zstride = (size_t)gridDim.x * TILE;
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-      *reinterpret_cast<f32x4*>(part + blockIdx.z * zstride + q * 2048) = f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
-    if (!g6d_split_arrive(reinterpret_cast<int*>(ws) + blockIdx.x, splits)) return;
+      g6d_store_wt(part + blockIdx.z * zstride + q * 2048, f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]});
+    if (!g6d_split_arrive(reinterpret_cast<int*>(ws) + blockIdx.x, splits, reinterpret_cast<int*>(lds))) return;
     f32x4 sum[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) sum[q] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -199,27 +198,19 @@ __global__ void __launch_bounds__(512) corr_patch_kernel(const float* __restrict
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) { acc[4 * q] = sum[q][0]; acc[4 * q + 1] = sum[q][1]; acc[4 * q + 2] = sum[q][2]; acc[4 * q + 3] = sum[q][3]; }
-    partial = false;
   }
   // epilogue: acc rows = output columns tx0 + (r&3) + 8*(r>>2) + 4*lh of image row ty0 + wave; acc column = co = li
   const int oy = ty0 + wave;
   if (oy < H && li < Cout) {
-    float* dst = partial ? ws + G6D_WS_COUNTERS + (size_t)blockIdx.z * H * W * Cout : out;
-    const int ld = partial ? Cout : ld_out;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int ox = tx0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (ox < W) dst[((size_t)oy * W + ox) * ld + li] = acc[r];
+      if (ox < W) out[((size_t)oy * W + ox) * ld_out + li] = acc[r];
     }
   }
 }
 
 }  // namespace
-
-// Declared in conv_igemm.hip: sums split-K partials [splits][M][Cout] into out (+bias, activation, statistics).
-int g6d_splitk_reduce_launch(const float* ws, int splits, int M, int Cout, const float* bias, int act, float* out,
-                             int ld_out, double* stats, int rows_per_group, hipStream_t stream);
-int g6d_split_finish_max();
 
 // Stride-1 2-D cross-correlation without bias for Cout <= 32 (the detector's reference-as-filter correlation).
 //   in  [H][W][ld_in] channels-last, wgt [Cout][kh*kw][Cin], out [H*W][ld_out]; zero padding (ph, pw) with
@@ -258,17 +249,14 @@ extern "C" int g6d_corr2d_patch(const float* in, int H, int W, int Cin, int ld_i
   const int ups = (total_units + splits - 1) / splits;
   splits = (total_units + ups - 1) / ups;
   const size_t lds_bytes = (size_t)(TH * (TW + kw - 1) * LDS_K + 2 * 32 * LDS_K) * sizeof(float);
-  const int finish = splits > 1 && splits <= g6d_split_finish_max();
   auto go = [&](auto V) {
     constexpr int MM = decltype(V)::value;
     g6d_allow_lds(reinterpret_cast<const void*>(&corr_patch_kernel<MM>), 160 * 1024);      // the patch size depends on kw
     hipLaunchKernelGGL(corr_patch_kernel<MM>, dim3(tiles, 1, splits), dim3(512), lds_bytes, stream, in, wgt, out, H, W, Cin,
-                       ld_in, Cout, kh, kw, kh / 2, kw / 2, ld_out, ups, total_units, splits, tiles_x, workspace, finish);
+                       ld_in, Cout, kh, kw, kh / 2, kw / 2, ld_out, ups, total_units, splits, tiles_x, workspace);
   };
   if (math_mode == 1) go(std::integral_constant<int, 1>{});
   else if (math_mode == 2) go(std::integral_constant<int, 2>{});
   else go(std::integral_constant<int, 0>{});
-  int rc = g6d_check_launch("corr2d_patch");
-  if (rc != G6D_OK || splits == 1 || finish) return rc;
-  return g6d_splitk_reduce_launch(workspace + G6D_WS_COUNTERS, splits, H * W, Cout, nullptr, 0, out, ld_out, nullptr, 0, stream);
+  return g6d_check_launch("corr2d_patch");
 }

@@ -276,7 +276,11 @@ __global__ void __launch_bounds__(64) attention_kernel(const float* __restrict__
 // first FC layer reads 67 MB of weights for 33 MFLOP): every thread keeps four independent 16-byte weight loads in
 // flight so that two resident blocks per CU cover the HBM latency-bandwidth product (~64 KB per CU).
 #define GEMV_THREADS 512
-#define GEMV_UNROLL 4
+// out[b][o] = act(bias[o] + sum_k x[b][k] * W[o][k]), B <= 8 rows of x (the refiner's regressor: B = 1, K = 32768 -> 512 is a
+// 64 MB weight stream).  One block per output row; UNROLL 16-byte weight loads per thread are requested before the first is
+// used (16 at K >= 32768: the whole row is in flight at once, one memory latency per block instead of four), streamed past
+// the caches (read once); x is re-read by every block and stays in L2.
+template <int UNROLL>
 __global__ void __launch_bounds__(GEMV_THREADS) linear_gemv_kernel(const float* __restrict__ x, int B, int K,
                                                                    const float* __restrict__ W,
                                                                    const float* __restrict__ bias, int act,
@@ -288,24 +292,32 @@ __global__ void __launch_bounds__(GEMV_THREADS) linear_gemv_kernel(const float* 
 #pragma unroll
   for (int b = 0; b < 8; ++b) acc[b] = 0.f;
   constexpr int STEP = GEMV_THREADS * 4;
-  for (int k0 = threadIdx.x * 4; k0 < K; k0 += STEP * GEMV_UNROLL) {
-    f32x4 wv[GEMV_UNROLL];
+  for (int k0 = threadIdx.x * 4; k0 < K; k0 += STEP * UNROLL) {
+    f32x4 wv[UNROLL];
 #pragma unroll
-    for (int u = 0; u < GEMV_UNROLL; ++u) {
+    for (int u = 0; u < UNROLL; ++u) {
       const int kk = k0 + u * STEP;
-      wv[u] = *reinterpret_cast<const f32x4*>(w + (kk < K ? kk : 0));
-      if (kk >= K) wv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      wv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(w + (kk < K ? kk : 0)));
     }
+    if (B == 1) {
+      f32x4 xv[UNROLL];
 #pragma unroll
-    for (int u = 0; u < GEMV_UNROLL; ++u) {
-      const int kk = k0 + u * STEP;
-      const int kc = kk < K ? kk : 0;
+      for (int u = 0; u < UNROLL; ++u) { const int kk = k0 + u * STEP; xv[u] = *reinterpret_cast<const f32x4*>(x + (kk < K ? kk : 0)); }
 #pragma unroll
-      for (int b = 0; b < 8; ++b)
-        if (b < B) {
-          f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)b * K + kc);
-          acc[b] += wv[u][0] * xv[0] + wv[u][1] * xv[1] + wv[u][2] * xv[2] + wv[u][3] * xv[3];
-        }
+      for (int u = 0; u < UNROLL; ++u)
+        if (k0 + u * STEP < K) acc[0] += wv[u][0] * xv[u][0] + wv[u][1] * xv[u][1] + wv[u][2] * xv[u][2] + wv[u][3] * xv[u][3];
+    } else {
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) {
+        const int kk = k0 + u * STEP;
+        if (kk >= K) continue;
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+          if (b < B) {
+            f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)b * K + kk);
+            acc[b] += wv[u][0] * xv[0] + wv[u][1] * xv[1] + wv[u][2] * xv[2] + wv[u][3] * xv[3];
+          }
+      }
     }
   }
 #pragma unroll
@@ -457,6 +469,9 @@ extern "C" int g6d_linear_gemv(const float* x, int B, int K, const float* W, con
   if (!x || !W || !out || B <= 0 || B > 8 || K <= 0 || (K & 3) || O <= 0 || !g6d_aligned16(x) || !g6d_aligned16(W)) {
     g6d_set_error("linear_gemv: bad args"); return G6D_EINVAL;
   }
-  hipLaunchKernelGGL(linear_gemv_kernel, dim3(O), dim3(GEMV_THREADS), 0, STREAM(stream), x, B, K, W, bias, act, out, O);
+  if (K >= GEMV_THREADS * 4 * 16)
+    hipLaunchKernelGGL(linear_gemv_kernel<16>, dim3(O), dim3(GEMV_THREADS), 0, STREAM(stream), x, B, K, W, bias, act, out, O);
+  else
+    hipLaunchKernelGGL(linear_gemv_kernel<4>, dim3(O), dim3(GEMV_THREADS), 0, STREAM(stream), x, B, K, W, bias, act, out, O);
   return g6d_check_launch("linear_gemv");
 }

@@ -56,24 +56,31 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 // Split launches (a tile's reduction spread over gridDim.z blocks) finish inside the kernel: every block writes its partial
 // tile to the workspace, takes a ticket from the tile's counter, and the block that arrives last adds all partials (in
 // split order, so the sum does not depend on which block that was) and runs the layer's epilogue.  No second kernel, and the
-// partials are read back from L2 by the same lane mapping that wrote them (16-byte lane-linear rows).
+// partials are read back by the same lane mapping that wrote them (16-byte lane-linear rows).
+// Visibility across CUs / XCDs (their L2s are not coherent with each other): the partials are stored write-through (sc1),
+// every wave drains its stores, one lane takes the ticket with an agent-scope atomic, and the last block's lane 0 issues ONE
+// agent-scope acquire (drops the CU's stale L1 lines) before the block reads the slabs with plain loads — the hand-off of
+// MI355X_MICROARCH.md "inter-workgroup visibility"; no release fence (an L2 write-back per block) and no fence per thread.
 // The counters are the first G6D_WS_COUNTERS ints of the caller's workspace: zero before the first launch, left zero by
-// every launch (include/gen6d_hip.h, "workspace").
+// every launch (include/gen6d_hip.h, "Workspace").  `flag` is one free LDS word of the kernel's single LDS array.
 #define G6D_WS_COUNTER_BYTES G6D_WORKSPACE_COUNTER_BYTES
 #define G6D_WS_COUNTERS (G6D_WS_COUNTER_BYTES / 4)
-__device__ __forceinline__ bool g6d_split_arrive(int* counter, int splits) {
-  __shared__ int s_last;
-  __threadfence();                       // release: this thread's partials are visible device-wide (all XCDs) ...
-  __syncthreads();                       // ... for every thread of the block, before the ticket is taken
+__device__ __forceinline__ void g6d_store_wt(float* p, f32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ bool g6d_split_arrive(int* counter, int splits, int* flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's write-through stores have been acknowledged
+  __syncthreads();                                       // ... and every other wave's; the kernel's LDS is free from here on
   if (threadIdx.x == 0) {
-    const int last = atomicAdd(counter, 1) == splits - 1;
-    if (last) *counter = 0;              // all blocks of the tile have arrived: re-arm for the next launch
-    s_last = last;
+    const int last = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == splits - 1;
+    if (last) {
+      __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-arm for the next launch
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    *flag = last;
   }
   __syncthreads();
-  const bool last = s_last != 0;
-  if (last) __threadfence();             // acquire: drop stale lines before reading the other blocks' partials
-  return last;
+  return *flag != 0;
 }
 
 __device__ __forceinline__ float apply_act(float v, int act) {

@@ -21,7 +21,7 @@
 //            accumulators).  Two LDS stages, one barrier per chunk; per wave and chunk 64 MFMAs against 32 ds_read_b128.
 //   split  = small maps do not fill 256 CUs with 64-tile blocks and a block's K loop is serial (2-3 us per chunk): the
 //            channel chunks are then split over gridDim.z; partial OUTPUT tiles (the output transform is linear) go to a
-//            workspace and a small second kernel adds them and applies bias / ReLU / max-pool.
+//            workspace and the block of a tile that arrives last adds them and applies bias / ReLU / max-pool / statistics.
 //   K trick = as in conv_igemm.hip: lane-half h reads channels 4h..4h+3 of the chunk with one ds_read_b128 per operand;
 //            MFMA s consumes channel s (lanes 0-31) and 4+s (lanes 32-63) for both operands.
 //
@@ -29,8 +29,6 @@
 // Winograd solver the trunk ran on before).
 #include "g6d_common.h"
 #include <stdlib.h>
-
-int g6d_split_finish_max();      // conv_igemm.hip
 
 namespace {
 
@@ -61,7 +59,6 @@ struct WinoArgs {
   int N, H, W, Cin, ld_in, Cout, ld_full, ld_pool, relu;      // N = images x depth slices (every slice is a 2-D map)
   int QH, QW;
   int splits, chunks_per_split; float* ws;       // splits > 1: tile counters + partial outputs (no bias / ReLU / pool)
-  int finish;                                    // 1: the last block of a tile sums the partials; 0: wino_reduce_kernel does
   // conv-family extras (zero / null for the trunk)
   int D;                                         // depth slices per image (1 for 2-D layers); KD = 3 pads in depth
   const float* mul; const float* in_scale; const float* in_shift; int in_relu;
@@ -285,25 +282,6 @@ __global__ void __launch_bounds__(128 * NWN, 1) wino_conv3x3_kernel(const WinoAr
     }
     Y[r] = f32x4{sr[0][0] + sr[0][1] + sr[0][2], sr[0][1] - sr[0][2] - sr[0][3], sr[1][0] + sr[1][1] + sr[1][2], sr[1][1] - sr[1][2] - sr[1][3]};
   }
-  if (p.splits > 1 && !p.finish) {        // many splits: row-major partial outputs for wino_reduce_kernel
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int q = 2 * wm + (r >> 3);
-      const int tyy = lh + 2 * ((r >> 2) & 1), txx = r & 3;
-      int n, oy0, ox0; bool qv;
-      quarter_of(p, q, n, oy0, ox0, qv);
-      const int oy = oy0 + 2 * tyy, ox = ox0 + 2 * txx;
-      if (qv) {
-        float* w = p.ws + G6D_WS_COUNTERS + (size_t)blockIdx.z * p.N * p.H * p.W * p.Cout;
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-          for (int b = 0; b < 2; ++b)
-            if (oy + a < p.H && ox + b < p.W) w[((size_t)(n * p.H + oy + a) * p.W + ox + b) * p.Cout + co] = Y[r][2 * a + b];
-      }
-    }
-    return;
-  }
   if (p.splits > 1) {
     // the output transform is linear: partial OUTPUT tiles go to the workspace as [split][tile][r][thread] 16-byte pieces, and
     // the block that arrives last adds them in split order (g6d_common.h) and carries on with bias / ReLU / pool / statistics
@@ -312,8 +290,8 @@ __global__ void __launch_bounds__(128 * NWN, 1) wino_conv3x3_kernel(const WinoAr
     float* part = p.ws + G6D_WS_COUNTERS + (size_t)tile * TILE + tid * 4;
     const size_t zstride = (size_t)ntiles * TILE;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) *reinterpret_cast<f32x4*>(part + blockIdx.z * zstride + r * (THREADS * 4)) = Y[r];
-    if (!g6d_split_arrive(reinterpret_cast<int*>(p.ws) + tile, p.splits)) return;
+    for (int r = 0; r < 16; ++r) g6d_store_wt(part + blockIdx.z * zstride + r * (THREADS * 4), Y[r]);
+    if (!g6d_split_arrive(reinterpret_cast<int*>(p.ws) + tile, p.splits, reinterpret_cast<int*>(lds))) return;
 #pragma unroll
     for (int r = 0; r < 16; ++r) Y[r] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int z0 = 0; z0 < p.splits; z0 += 2) {
@@ -406,70 +384,6 @@ __global__ void __launch_bounds__(128 * NWN, 1) wino_conv3x3_kernel(const WinoAr
   }
 }
 
-// Second half of a split launch: thread = one 2x2 output cell x 4 channels; sums the partial outputs of all splits, adds the
-// bias, applies ReLU, writes the full-resolution result and / or the max-pooled one, and accumulates the InstanceNorm statistics of
-// the result (float partials per block in LDS, one fp64 atomic per channel and block; a block that straddles two statistics
-// groups falls back to per-thread atomics).  Images here are N x D slices; a statistics group is an image (D slices) or everything.
-__global__ void __launch_bounds__(256) wino_reduce_kernel(const float* __restrict__ ws, int splits, int N, int H, int W, int Cout,
-                                                          const float* __restrict__ bias, int relu, float* __restrict__ out_full,
-                                                          int ld_full, float* __restrict__ out_pool, int ld_pool,
-                                                          double* __restrict__ stats, int D, int stats_per_image) {
-  extern __shared__ float sred[];                        // [Cout][2] when stats
-  const int c4 = Cout >> 2, Hc = (H + 1) >> 1, Wc = (W + 1) >> 1;
-  const long long total = (long long)N * Hc * Wc * c4;
-  const long long i0 = (long long)blockIdx.x * 256, i = i0 + threadIdx.x;
-  const long long per_img = (long long)Hc * Wc * c4;
-  int g_first = 0, g_last = 0;
-  if (stats) {
-    for (int k = threadIdx.x; k < 2 * Cout; k += 256) sred[k] = 0.f;
-    if (stats_per_image) {
-      g_first = (int)(i0 / per_img) / D;
-      g_last = (int)(min(i0 + 255, total - 1) / per_img) / D;
-    }
-    __syncthreads();
-  }
-  const bool one_group = g_first == g_last;
-  if (i < total) {
-    const int c = (int)(i % c4) * 4; long long t = i / c4;
-    const int cx = (int)(t % Wc); t /= Wc;
-    const int cy = (int)(t % Hc); const int n = (int)(t / Hc);
-    const size_t zstride = (size_t)N * H * W * Cout;
-    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-    if (bias) bv = *reinterpret_cast<const f32x4*>(bias + c);
-    f32x4 m = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f}, s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const int oy = 2 * cy + a, ox = 2 * cx + b;
-        if (oy >= H || ox >= W) continue;
-        const float* src = ws + ((size_t)(n * H + oy) * W + ox) * Cout + c;
-        f32x4 v = bv;
-        for (int z = 0; z < splits; ++z) v += *reinterpret_cast<const f32x4*>(src + (size_t)z * zstride);
-        if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-        if (out_full) *reinterpret_cast<f32x4*>(out_full + ((size_t)(n * H + oy) * W + ox) * ld_full + c) = v;
-        m[0] = fmaxf(m[0], v[0]); m[1] = fmaxf(m[1], v[1]); m[2] = fmaxf(m[2], v[2]); m[3] = fmaxf(m[3], v[3]);
-        s1 += v; s2 += v * v;
-      }
-    if (out_pool && cy < (H >> 1) && cx < (W >> 1))
-      *reinterpret_cast<f32x4*>(out_pool + ((size_t)(n * (H >> 1) + cy) * (W >> 1) + cx) * ld_pool + c) = m;
-    if (stats) {
-      if (one_group) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { atomicAdd(&sred[(c + k) * 2], s1[k]); atomicAdd(&sred[(c + k) * 2 + 1], s2[k]); }
-      } else {
-        double* st = stats + ((size_t)(stats_per_image ? n / D : 0) * Cout + c) * 2;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { atomicAdd(st + 2 * k, (double)s1[k]); atomicAdd(st + 2 * k + 1, (double)s2[k]); }
-      }
-    }
-  }
-  if (stats && one_group) {
-    __syncthreads();
-    for (int k = threadIdx.x; k < 2 * Cout; k += 256) atomicAdd(stats + (size_t)g_first * Cout * 2 + k, (double)sred[k]);
-  }
-}
-
 // ---- launch: tile width, split over the chunks, instantiation
 template <int MODE, int KD, int NWN>
 int wino_launch_t(WinoArgs& a, long long blocks, hipStream_t stream) {
@@ -497,50 +411,39 @@ int wino_run(WinoArgs& a, int mode, int kd, float* workspace, size_t workspace_b
   // Split of the (kd, chunk) list over gridDim.z.  One 64-channel block per CU is resident (512 registers per lane, ~100 KB
   // of LDS) and runs a serial loop of ~2.7 us per chunk, so a launch takes ceil(grid / 256) rounds of (chunks per block)
   // steps: small grids leave CUs idle and grids just above a multiple of 256 pay a nearly empty last round.  Pick the split
-  // count with the smallest modelled time (rounds x block time + the reduce pass over the partial outputs).
+  // count with the smallest modelled time: rounds x block time + the hand-off (partial images written and read back, the
+  // serial re-read of a tile's sp slabs of 64 KB by its last block).  The constants can be overridden for measurements.
   const int nchunks = kd * (a.Cin / 8);
   int splits = 1;
   const long long grid2 = blocks * (a.Cout / (32 * nwn));
   const int slots = 256 * (nwn == 1 ? 2 : 1);
   static const int split_max = []() { const char* e = getenv("G6D_WINO_SPLIT_MAX"); return e ? atoi(e) : 32; }();
-  const bool can_reduce = workspace && !(a.Cout & 3) && !(a.ld_full & 3) && !(a.ld_pool & 3) && (!a.out_full || g6d_aligned16(a.out_full)) &&
-                          (!a.out_pool || g6d_aligned16(a.out_pool)) && (!a.bias || g6d_aligned16(a.bias)) && g6d_aligned16(workspace);
-  const int finish_max = g6d_split_finish_max();
+  static const double m_gain = []() { const char* e = getenv("G6D_WINO_SPLIT_GAIN"); return e ? atof(e) : 0.85; }();
+  static const double m_fix = []() { const char* e = getenv("G6D_WINO_SPLIT_FIX"); return e ? atof(e) : 2.0; }();
+  static const double m_per = []() { const char* e = getenv("G6D_WINO_SPLIT_PER"); return e ? atof(e) : 0.6; }();
   const size_t room = workspace && workspace_bytes > G6D_WS_COUNTER_BYTES ? workspace_bytes - G6D_WS_COUNTER_BYTES : 0;
   const double tile_bytes = (double)grid2 * (128 * nwn) * 64 * sizeof(float);     // one partial image, padded to whole tiles
   if (room > 0 && grid2 <= G6D_WS_COUNTERS && split_max > 1 && nchunks >= 4) {
     const double out_bytes = (double)a.N * a.H * a.W * a.Cout * sizeof(float);
     double best = 1e30;
     for (int sp = 1; sp <= split_max && sp <= nchunks / 2; ++sp) {
-      const bool fin = sp <= finish_max;
-      if (!fin && !can_reduce) break;
       if ((double)sp * tile_bytes > (double)room) break;
       const int cps_ = (nchunks + sp - 1) / sp, real = (nchunks + cps_ - 1) / cps_;
       if (real != sp) continue;
       const double rounds = (double)((grid2 * sp + slots - 1) / slots);
       double t = rounds * (cps_ * 2.7 + 4.0);                                   // us: chunks + prologue / epilogue of a block
-      // a split writes sp partial images and reads them back: charged at 2.5 TB/s chip-wide, plus either the serial re-read of
-      // sp tiles (64 KB each) by the tile's last block or the extra launch of the reduce kernel; a split must buy >= 15 %
-      if (sp > 1) t += (fin ? 2.0 + 0.6 * sp : 8.0) + (2 * sp + 1) * out_bytes / 2.5e6;
-      if (t < best * 0.85) { best = t; splits = sp; }
+      if (sp > 1) t += m_fix + m_per * sp + (2 * sp + 1) * out_bytes / 2.5e6;  // hand-off; partial traffic at 2.5 TB/s chip-wide
+      if (t < best * m_gain) { best = t; splits = sp; }                        // a further split must buy >= 15 %
     }
   }
   const int cps = (nchunks + splits - 1) / splits;
   splits = (nchunks + cps - 1) / cps;
   a.splits = splits; a.chunks_per_split = cps; a.ws = workspace;
-  a.finish = splits > 1 && splits <= finish_max;
-  int rc;
-  if (kd == 3) rc = mode == 1 ? wino_launch_w<1, 3>(a, blocks, nwn, stream) : wino_launch_w<0, 3>(a, blocks, nwn, stream);
-  else if (mode == 3) rc = wino_launch_w<3, 1>(a, blocks, nwn, stream);
-  else if (mode == 2) rc = wino_launch_w<2, 1>(a, blocks, nwn, stream);
-  else if (mode == 1) rc = wino_launch_w<1, 1>(a, blocks, nwn, stream);
-  else rc = wino_launch_w<0, 1>(a, blocks, nwn, stream);
-  if (rc != G6D_OK || splits == 1 || a.finish) return rc;
-  const long long cells = (long long)a.N * ((a.H + 1) / 2) * ((a.W + 1) / 2) * (a.Cout / 4);
-  hipLaunchKernelGGL(wino_reduce_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), a.stats ? 2 * a.Cout * sizeof(float) : 0, stream,
-                     workspace + G6D_WS_COUNTERS, splits, a.N, a.H, a.W, a.Cout, a.bias, a.relu, a.out_full, a.ld_full, a.out_pool, a.ld_pool, a.stats,
-                     a.D, a.stats_per_image);
-  return g6d_check_launch("wino_reduce");
+  if (kd == 3) return mode == 1 ? wino_launch_w<1, 3>(a, blocks, nwn, stream) : wino_launch_w<0, 3>(a, blocks, nwn, stream);
+  if (mode == 3) return wino_launch_w<3, 1>(a, blocks, nwn, stream);
+  if (mode == 2) return wino_launch_w<2, 1>(a, blocks, nwn, stream);
+  if (mode == 1) return wino_launch_w<1, 1>(a, blocks, nwn, stream);
+  return wino_launch_w<0, 1>(a, blocks, nwn, stream);
 }
 
 }  // namespace
