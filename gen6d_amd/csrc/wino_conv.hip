@@ -29,6 +29,7 @@
 // Winograd solver the trunk ran on before).
 #include "g6d_common.h"
 #include <stdlib.h>
+#include <stdio.h>
 
 namespace {
 
@@ -54,10 +55,17 @@ namespace {
 // Epilogue additions for those layers: per-(group, channel) sum / sum of squares of the outputs for the following
 // InstanceNorm (float partials per block, one fp64 atomic per channel and run of equal groups).
 
+// One map size of a launch.  A launch may cover up to WINO_MAX_SEG sizes (the scales of the detector's image pyramid run the
+// same layer): their quarters form ONE flat list, so the small scales fill the blocks the large ones leave over instead of
+// being four under-filled launches.  Offsets are in floats from the launch's common base pointers.
+#define WINO_MAX_SEG 4
+struct WinoSeg { int qstart, N, H, W, QH, QW, in_off, full_off, pool_off, ld_in, ld_full, ld_pool; };
+
 struct WinoArgs {
   const float* in; const float* U; const float* bias; float* out_full; float* out_pool;
-  int N, H, W, Cin, ld_in, Cout, ld_full, ld_pool, relu;      // N = images x depth slices (every slice is a 2-D map)
+  int N, H, W, Cin, ld_in, Cout, ld_full, ld_pool, relu;      // N = images x depth slices (every slice is a 2-D map); = seg[0]
   int QH, QW;
+  int nseg, qtotal; WinoSeg seg[WINO_MAX_SEG];
   int splits, chunks_per_split; float* ws;       // splits > 1: tile counters + partial outputs (no bias / ReLU / pool)
   // conv-family extras (zero / null for the trunk)
   int D;                                         // depth slices per image (1 for 2-D layers); KD = 3 pads in depth
@@ -69,17 +77,27 @@ __device__ __forceinline__ f32x4 ldg4(const float* __restrict__ base, int elem_o
   return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + ((unsigned)elem_off << 2));
 }
 
-// quarter q of this block -> image, first output row / column, validity.  The quarters (8x8 output pixels) of all images
-// form one flat list, four consecutive ones per block: no block-level padding on odd quarter counts, and small maps
-// (<= 8x8 pixels = one quarter per image) simply put four images into a block.
-__device__ __forceinline__ void quarter_of(const WinoArgs& p, int q, int& n, int& oy0, int& ox0, bool& valid) {
+// quarter q of this block -> segment geometry, image, first output row / column, validity.  The quarters (8x8 output pixels)
+// of all images of all segments form one flat list, four consecutive ones per block: no block-level padding on odd quarter
+// counts, and small maps (<= 8x8 pixels = one quarter per image) simply put four images into a block.
+struct QGeo { int n, oy0, ox0; bool valid; int H, W, ld_in, ld_full, ld_pool, in_off, full_off, pool_off; };
+__device__ __forceinline__ QGeo quarter_of(const WinoArgs& p, int q) {
   const int Q = blockIdx.x * 4 + q;
-  const int per = p.QH * p.QW;
-  valid = Q < p.N * per;
-  n = valid ? Q / per : 0;
-  const int r = valid ? Q - n * per : 0;
-  const int qy = r / p.QW, qx = r - qy * p.QW;
-  oy0 = 8 * qy; ox0 = 8 * qx;
+  int sidx = 0;
+#pragma unroll
+  for (int k = 1; k < WINO_MAX_SEG; ++k) sidx = (k < p.nseg && Q >= p.seg[k].qstart) ? k : sidx;
+  const WinoSeg& sg = p.seg[sidx];
+  QGeo g;
+  g.valid = Q < p.qtotal;
+  const int Ql = g.valid ? Q - sg.qstart : 0;
+  const int per = sg.QH * sg.QW;
+  g.n = Ql / per;
+  const int r = Ql - g.n * per;
+  const int qy = r / sg.QW, qx = r - qy * sg.QW;
+  g.oy0 = 8 * qy; g.ox0 = 8 * qx;
+  g.H = sg.H; g.W = sg.W; g.ld_in = sg.ld_in; g.ld_full = sg.ld_full; g.ld_pool = sg.ld_pool;
+  g.in_off = sg.in_off; g.full_off = sg.full_off; g.pool_off = sg.pool_off;
+  return g;
 }
 
 template <int MODE, int KD, int NWN>
@@ -108,11 +126,11 @@ __global__ void __launch_bounds__(128 * NWN, 1) wino_conv3x3_kernel(const WinoAr
     const int idx = tid + THREADS * j;
     const int q = idx / 200, r = idx - q * 200, pp = r >> 1, half = r & 1;
     const int py = pp / 10, px = pp - py * 10;
-    int n, oy0, ox0; bool qv;
-    quarter_of(p, q < 4 ? q : 0, n, oy0, ox0, qv);
-    const int iy = oy0 + py - 1, ix = ox0 + px - 1;
-    pval[j] = (idx < 800) & qv & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
-    poff[j] = pval[j] ? ((n * p.H + iy) * p.W + ix) * p.ld_in + 4 * half : 0;
+    const QGeo g = quarter_of(p, q < 4 ? q : 0);
+    const int n = g.n;
+    const int iy = g.oy0 + py - 1, ix = g.ox0 + px - 1;
+    pval[j] = (idx < 800) & g.valid & ((unsigned)iy < (unsigned)g.H) & ((unsigned)ix < (unsigned)g.W);
+    poff[j] = pval[j] ? g.in_off + ((n * g.H + iy) * g.W + ix) * g.ld_in + 4 * half : 0;
     lsto[j] = (q * WQ_PIX + pp) * WRAW_LD + 4 * (half ^ ((py >> 1) & 1));
     live[j] = idx < 800;
     if constexpr (MODE == 3) moff[j] = pval[j] ? (iy * p.W + ix) * p.Cin + 4 * half : 0;
@@ -154,7 +172,7 @@ __global__ void __launch_bounds__(128 * NWN, 1) wino_conv3x3_kernel(const WinoAr
     constexpr int G = MODE == 2 ? 4 : 1;
     for (int i = tid; i < G * p.Cin; i += THREADS) {
       int g = 0;
-      if constexpr (MODE == 2) { int n, oy0, ox0; bool qv; quarter_of(p, i / p.Cin, n, oy0, ox0, qv); g = n / p.D; }
+      if constexpr (MODE == 2) g = quarter_of(p, i / p.Cin).n / p.D;
       const int c = MODE == 2 ? i % p.Cin : i;
       lds[AFF0 + i] = p.in_scale[g * p.Cin + c];
       lds[AFF0 + G * p.Cin + i] = p.in_shift[g * p.Cin + c];
@@ -311,15 +329,15 @@ __global__ void __launch_bounds__(128 * NWN, 1) wino_conv3x3_kernel(const WinoAr
   const float bv = p.bias ? p.bias[co] : 0.f;
   const bool do_relu = p.relu != 0;
   const bool do_stats = p.stats != nullptr;
-  const int Hp = p.H >> 1, Wp = p.W >> 1;
+  const QGeo geo[2] = {quarter_of(p, 2 * wm), quarter_of(p, 2 * wm + 1)};      // the wave's two quarters
   float st1[2] = {0.f, 0.f}, st2[2] = {0.f, 0.f};       // statistics of this lane's column, per quarter of the wave
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     // accumulator row r of the 32x32 tile = tile (r&3) + 8*(r>>2) + 4*lh of the wave's 32
-    const int q = 2 * wm + (r >> 3);
+    const QGeo& g = geo[r >> 3];
     const int tyy = lh + 2 * ((r >> 2) & 1), txx = r & 3;
-    int n, oy0, ox0; bool qv;
-    quarter_of(p, q, n, oy0, ox0, qv);
+    const int n = g.n; const bool qv = g.valid;
+    const int Hp = g.H >> 1, Wp = g.W >> 1;
     float y[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -328,21 +346,21 @@ __global__ void __launch_bounds__(128 * NWN, 1) wino_conv3x3_kernel(const WinoAr
         y[a][b] = Y[r][2 * a + b] + bv;
         if (do_relu) y[a][b] = fmaxf(y[a][b], 0.f);
       }
-    const int oy = oy0 + 2 * tyy, ox = ox0 + 2 * txx;
+    const int oy = g.oy0 + 2 * tyy, ox = g.ox0 + 2 * txx;
     if (p.out_full && qv) {
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
-          if (oy + a < p.H && ox + b < p.W) {
-            p.out_full[((size_t)(n * p.H + oy + a) * p.W + ox + b) * p.ld_full + co] = y[a][b];
+          if (oy + a < g.H && ox + b < g.W) {
+            p.out_full[(size_t)g.full_off + ((size_t)(n * g.H + oy + a) * g.W + ox + b) * g.ld_full + co] = y[a][b];
             if (do_stats) { st1[r >> 3] += y[a][b]; st2[r >> 3] += y[a][b] * y[a][b]; }
           }
     }
     if (p.out_pool && qv) {
       const int py = oy >> 1, px = ox >> 1;
       if (py < Hp && px < Wp)
-        p.out_pool[((size_t)(n * Hp + py) * Wp + px) * p.ld_pool + co] = fmaxf(fmaxf(y[0][0], y[0][1]), fmaxf(y[1][0], y[1][1]));
+        p.out_pool[(size_t)g.pool_off + ((size_t)(n * Hp + py) * Wp + px) * g.ld_pool + co] = fmaxf(fmaxf(y[0][0], y[0][1]), fmaxf(y[1][0], y[1][1]));
     }
   }
   if (do_stats) {
@@ -364,10 +382,9 @@ __global__ void __launch_bounds__(128 * NWN, 1) wino_conv3x3_kernel(const WinoAr
       double a1 = 0.0, a2 = 0.0;
       int cur = -1;
       for (int q = 0; q < 4; ++q) {
-        int n, oy0, ox0; bool qv;
-        quarter_of(p, q, n, oy0, ox0, qv);
-        if (!qv) break;
-        const int g = p.stats_per_image ? n / p.D : 0;
+        const QGeo qg = quarter_of(p, q);
+        if (!qg.valid) break;
+        const int g = p.stats_per_image ? qg.n / p.D : 0;
         if (g != cur && cur >= 0) {
           double* st = p.stats + ((size_t)cur * p.Cout + n0 + tid) * 2;
           atomicAdd(st, a1); atomicAdd(st + 1, a2); a1 = a2 = 0.0;
@@ -402,9 +419,23 @@ int wino_launch_w(WinoArgs& a, long long blocks, int nwn, hipStream_t stream) {
 
 // Fills the geometry / split fields of `a` and launches.  kd = 1 or 3; mode as the kernel's MODE.
 int wino_run(WinoArgs& a, int mode, int kd, float* workspace, size_t workspace_bytes, hipStream_t stream) {
-  a.QH = (a.H + 7) / 8; a.QW = (a.W + 7) / 8;
-  const long long blocks = ((long long)a.N * a.QH * a.QW + 3) / 4;
-  if (blocks > 0x7fffffffll) { g6d_set_error("wino_conv3x3: grid too large"); return G6D_EINVAL; }
+  if (a.nseg == 0) {          // one map size: the launch's own fields
+    a.nseg = 1;
+    a.seg[0] = WinoSeg{0, a.N, a.H, a.W, 0, 0, 0, 0, 0, a.ld_in, a.ld_full, a.ld_pool};
+  }
+  long long quarters = 0;
+  double out_elems = 0.0;
+  for (int k = 0; k < a.nseg; ++k) {
+    WinoSeg& g = a.seg[k];
+    g.QH = (g.H + 7) / 8; g.QW = (g.W + 7) / 8;
+    g.qstart = (int)quarters;
+    quarters += (long long)g.N * g.QH * g.QW;
+    out_elems += (double)g.N * g.H * g.W;
+  }
+  a.QH = a.seg[0].QH; a.QW = a.seg[0].QW;
+  const long long blocks = (quarters + 3) / 4;
+  if (blocks > 0x3fffffffll) { g6d_set_error("wino_conv3x3: grid too large"); return G6D_EINVAL; }
+  a.qtotal = (int)quarters;
   // 32-channel (two-wave) blocks only for channel counts that are not multiples of 64: two of them share a CU, so they do not
   // spread a small grid over more CUs — the split over the chunks below does
   const int nwn = (a.Cout & 63) ? 1 : 2;
@@ -424,7 +455,7 @@ int wino_run(WinoArgs& a, int mode, int kd, float* workspace, size_t workspace_b
   const size_t room = workspace && workspace_bytes > G6D_WS_COUNTER_BYTES ? workspace_bytes - G6D_WS_COUNTER_BYTES : 0;
   const double tile_bytes = (double)grid2 * (128 * nwn) * 64 * sizeof(float);     // one partial image, padded to whole tiles
   if (room > 0 && grid2 <= G6D_WS_COUNTERS && split_max > 1 && nchunks >= 4) {
-    const double out_bytes = (double)a.N * a.H * a.W * a.Cout * sizeof(float);
+    const double out_bytes = out_elems * a.Cout * sizeof(float);
     double best = 1e30;
     for (int sp = 1; sp <= split_max && sp <= nchunks / 2; ++sp) {
       if ((double)sp * tile_bytes > (double)room) break;
@@ -439,6 +470,9 @@ int wino_run(WinoArgs& a, int mode, int kd, float* workspace, size_t workspace_b
   const int cps = (nchunks + splits - 1) / splits;
   splits = (nchunks + cps - 1) / cps;
   a.splits = splits; a.chunks_per_split = cps; a.ws = workspace;
+  static const bool debug = []() { const char* e = getenv("G6D_WINO_DEBUG"); return e && e[0] == '1'; }();
+  if (debug) fprintf(stderr, "wino %d seg, N=%d %dx%dx%d->%d kd=%d mode=%d: grid %lld x %d splits of %d chunks\n", a.nseg, a.N, a.H, a.W, a.Cin,
+                     a.Cout, kd, mode, grid2, splits, cps);
   if (kd == 3) return mode == 1 ? wino_launch_w<1, 3>(a, blocks, nwn, stream) : wino_launch_w<0, 3>(a, blocks, nwn, stream);
   if (mode == 3) return wino_launch_w<3, 1>(a, blocks, nwn, stream);
   if (mode == 2) return wino_launch_w<2, 1>(a, blocks, nwn, stream);
@@ -467,6 +501,45 @@ extern "C" int g6d_wino_conv3x3(const float* in, int N, int H, int W, int Cin, i
   a.in = in; a.U = U; a.bias = bias; a.out_full = out_full; a.out_pool = out_pool;
   a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.ld_in = ld_in; a.Cout = Cout; a.ld_full = ld_full; a.ld_pool = ld_pool; a.relu = relu;
   a.D = 1;
+  return wino_run(a, 0, 1, workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream));
+}
+
+// The same layer over up to 4 map sizes in ONE launch (G6dWinoSeg, include/gen6d_hip.h): the scales of the detector's image
+// pyramid (network/detector.py:236-241) run every trunk layer with the same filters.
+extern "C" int g6d_wino_conv3x3_multi(const G6dWinoSeg* segs, int nseg, int Cin, const float* U, const float* bias, int Cout, int relu,
+                                      float* workspace, size_t workspace_bytes, g6d_stream_t stream) {
+  if (!segs || nseg < 1 || nseg > WINO_MAX_SEG || !U || Cin <= 0 || (Cin & 7) || Cout <= 0 || (Cout & 63) || !g6d_aligned16(U)) {
+    g6d_set_error("wino_conv3x3_multi: bad args (1..4 segments, Cin % 8 == 0, Cout % 64 == 0)"); return G6D_EINVAL;
+  }
+  WinoArgs a = {};
+  const bool want_full = segs[0].out_full != nullptr, want_pool = segs[0].out_pool != nullptr;
+  if (!want_full && !want_pool) { g6d_set_error("wino_conv3x3_multi: no output"); return G6D_EINVAL; }
+  // common base pointers: the lowest address of each kind; the kernel addresses with 32-bit float offsets from them
+  const float* in0 = segs[0].in; float* f0 = segs[0].out_full; float* p0 = segs[0].out_pool;
+  for (int k = 0; k < nseg; ++k) {
+    const G6dWinoSeg& g = segs[k];
+    if (!g.in || (g.out_full != nullptr) != want_full || (g.out_pool != nullptr) != want_pool || g.N <= 0 || g.H <= 0 || g.W <= 0 ||
+        (g.ld_in & 3) || g.ld_in < Cin || (want_full && g.ld_full < Cout) || (want_pool && (g.ld_pool < Cout || g.H < 2 || g.W < 2)) ||
+        !g6d_aligned16(g.in)) {
+      g6d_set_error("wino_conv3x3_multi: bad segment (all segments give the same kinds of output)"); return G6D_EINVAL;
+    }
+    if (g.in < in0) in0 = g.in;
+    if (want_full && g.out_full < f0) f0 = g.out_full;
+    if (want_pool && g.out_pool < p0) p0 = g.out_pool;
+  }
+  a.in = in0; a.U = U; a.bias = bias; a.out_full = f0; a.out_pool = p0;
+  a.Cin = Cin; a.Cout = Cout; a.relu = relu; a.D = 1;
+  a.nseg = nseg;
+  for (int k = 0; k < nseg; ++k) {
+    const G6dWinoSeg& g = segs[k];
+    const long long io = g.in - in0, fo = want_full ? g.out_full - f0 : 0, po = want_pool ? g.out_pool - p0 : 0;
+    if (io + (long long)g.N * g.H * g.W * g.ld_in >= (1ll << 30) || fo + (long long)g.N * g.H * g.W * g.ld_full >= (1ll << 31) ||
+        po + (long long)g.N * g.H * g.W * g.ld_pool >= (1ll << 31)) {
+      g6d_set_error("wino_conv3x3_multi: segments must lie within 2^30 floats of each other (allocate them from one buffer)"); return G6D_EINVAL;
+    }
+    a.seg[k] = WinoSeg{0, g.N, g.H, g.W, 0, 0, (int)io, (int)fo, (int)po, g.ld_in, g.ld_full, g.ld_pool};
+  }
+  a.N = segs[0].N; a.H = segs[0].H; a.W = segs[0].W; a.ld_in = segs[0].ld_in; a.ld_full = segs[0].ld_full; a.ld_pool = segs[0].ld_pool;
   return wino_run(a, 0, 1, workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream));
 }
 

@@ -9,6 +9,12 @@ LIB_PATH = os.environ.get("G6D_LIB_PATH") or os.path.join(_HERE, "libgen6d_hip.s
 G6D_ERRORS = {-1: "G6D_EINVAL", -2: "G6D_ENOSPC", -3: "G6D_ELAUNCH"}
 
 
+class G6dWinoSeg(C.Structure):
+    """include/gen6d_hip.h: one map size of g6d_wino_conv3x3_multi."""
+    _fields_ = [("in_", C.c_void_p), ("out_full", C.c_void_p), ("out_pool", C.c_void_p),
+                ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("ld_in", C.c_int32), ("ld_full", C.c_int32), ("ld_pool", C.c_int32)]
+
+
 class G6dConv(C.Structure):
     _fields_ = [
         ("in_", C.c_void_p), ("mul", C.c_void_p), ("in_scale", C.c_void_p), ("in_shift", C.c_void_p),
@@ -40,6 +46,7 @@ SIGNATURES = {
     "g6d_vgg_conv1_pool": [_P, _I, _I, _I, _P, _P, _I, _I, _P, _P],
     "g6d_vgg_conv1_pool_nhwc": [_P, _I, _I, _I, _P, _P, _I, _I, _P, _P],
     "g6d_wino_conv3x3": [_P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _P, _I, _P, C.c_size_t, _P],
+    "g6d_wino_conv3x3_multi": [_P, _I, _I, _P, _P, _I, _I, _P, C.c_size_t, _P],
     "g6d_l2norm_rows": [_P, _I, _I, _I, _P],
     "g6d_nchw_to_nhwc": [_P, _I, _I, _I, _I, _I, _P, _I, _P],
     "g6d_selector_ref_sums": [_P, _I, _I, _I, _P, _P, _P],

@@ -74,6 +74,37 @@ def vgg_taps_cl(packed, x, taps):
     return {k: v for k, v in out.items() if v is not None and (k in taps or k == "c7_pre")}
 
 
+def vgg_taps_cl_multi(packed, xs, taps):
+    """vgg_taps_cl for several image sizes at once (the scales of the detector's pyramid): every Winograd layer is ONE launch
+    over all sizes (ops.wino_conv3x3_multi).  xs: list of normalised [1,3,h_i,w_i] images -> list of tap dicts."""
+    w0, b0 = packed[0]
+    dev = xs[0].device
+    cur = ops.alloc_like_segments([(x.shape[0], x.shape[2] // 2, x.shape[3] // 2, w0.shape[0]) for x in xs], dev)
+    for x, o in zip(xs, cur):
+        ops.vgg_conv1_pool_nhwc(x.contiguous(), w0, b0, out=o)                          # conv0 + ReLU + pool, per size
+    _, cur = ops.wino_conv3x3_multi(cur, *packed[1], relu=True, full=False, pool=True)
+    cur, _ = ops.wino_conv3x3_multi(cur, *packed[2], relu=True)
+    c3, cur = ops.wino_conv3x3_multi(cur, *packed[3], relu=True, full="c3" in taps, pool=True)
+    cur, _ = ops.wino_conv3x3_multi(cur, *packed[4], relu=True)
+    c5, cur = ops.wino_conv3x3_multi(cur, *packed[5], relu=True, full="c5" in taps, pool=True)
+    cur, _ = ops.wino_conv3x3_multi(cur, *packed[6], relu=True)
+    c7, p7 = ops.wino_conv3x3_multi(cur, *packed[7], relu=False, full=True, pool="p7" in taps)
+    outs = []
+    for i in range(len(xs)):
+        d = {"c3": c3, "c5": c5, "c7_pre": c7, "p7": p7}
+        outs.append({k: v[i] for k, v in d.items() if v is not None and (k in taps or k == "c7_pre")})
+    return outs
+
+
+def trunk_features_multi(packed, imgs_list, keys):
+    """trunk_features (no L2 normalisation) for a list of [1,3,h_i,w_i] images of different sizes -> list of lists of
+    [1,1,h_l,w_l,C] maps.  One launch per layer for all sizes on the own trunk; the library trunk runs them one by one."""
+    if not _OWN_TRUNK or len(imgs_list) > 4:
+        return [trunk_features(packed, im, keys, False) for im in imgs_list]
+    taps = vgg_taps_cl_multi(packed, [img_norm(im) for im in imgs_list], set(keys))
+    return [[t[k].unsqueeze(1) for k in keys] for t in taps]
+
+
 def trunk_features(packed, imgs, keys, l2norm):
     """Normalised images [n,3,h,w] in [0,1] -> channels-last 5-D feature maps [n,1,h_l,w_l,C] for `keys`, optionally
     L2-normalised over C (F.normalize, reference selector.py:118 / refiner.py:69-71)."""

@@ -16,8 +16,13 @@ import torch
 import torch.nn.functional as F
 
 from .. import ops, parallel, specs
-from .backbone import pack_trunk, trunk_features
+import os
+
+from .backbone import pack_trunk, trunk_features, trunk_features_multi
 from .params import ParamBank, fold_vgg
+
+# G6D_TRUNK_MULTI=0: one trunk pass per pyramid scale (A/B aid); default: one launch per layer over all scales
+_TRUNK_MULTI = os.environ.get("G6D_TRUNK_MULTI", "1") != "0"
 
 
 class Detector(ParamBank):
@@ -79,7 +84,10 @@ class Detector(ParamBank):
 
     # ------------------------------------------------------------------ detection
     def _scores_one_scale(self, que_img, scale_idx, stacked, hs, ws):
-        x0, x1, x2 = self.extract_feats(que_img)
+        self._scores_from_feats(self.extract_feats(que_img), scale_idx, stacked, hs, ws)
+
+    def _scores_from_feats(self, feats, scale_idx, stacked, hs, ws):
+        x0, x1, x2 = feats
         rfn = self.ref_center_feats[0].shape[0]
         maps = []
         for x, wref, k in zip((x0, x1, x2), self.ref_center_feats, self.ref_ksize):
@@ -101,16 +109,21 @@ class Detector(ParamBank):
         dev = que_img.device
         rfn = self.ref_center_feats[0].shape[0]
         stacked = torch.empty((hs * ws, rfn, 12), dtype=torch.float32, device=dev)
-        def one_scale(si, scale):
+        def resized(scale):
             ht, wt = int(np.round(hq * 2 ** scale)), int(np.round(wq * 2 ** scale))
             if ht % 32 != 0: ht = (ht // 32 + 1) * 32
             if wt % 32 != 0: wt = (wt // 32 + 1) * 32
-            cur = F.interpolate(que_img, size=(ht, wt), mode="bilinear")
-            self._scores_one_scale(cur, si, stacked, hs, ws)
+            return F.interpolate(que_img, size=(ht, wt), mode="bilinear")
 
         # the scales are independent until `stacked` is complete: largest first on the main stream
         order = sorted(enumerate(self.cfg["detection_scales"]), key=lambda t: -t[1])
-        ops.fork_join([(lambda si=si, sc=sc: one_scale(si, sc)) for si, sc in order], dev)
+        if _TRUNK_MULTI and len(order) <= 4:
+            # every trunk layer is ONE launch over the whole pyramid (the small scales fill the blocks the large ones leave
+            # over); the correlations of the scales then run side by side
+            feats = trunk_features_multi(pk["vgg"], [resized(sc) for _, sc in order], ("c5", "c7_pre", "p7"))
+            ops.fork_join([(lambda si=si, f=f: self._scores_from_feats(f, si, stacked, hs, ws)) for (si, _), f in zip(order, feats)], dev)
+        else:
+            ops.fork_join([(lambda si=si, sc=sc: self._scores_one_scale(resized(sc), si, stacked, hs, ws)) for si, sc in order], dev)
         feats = ops.detector_score_mlp_max(stacked, *pk["mlp"])               # [P,64], max over the local references
         if self.world > 1:
             parallel.all_reduce_(feats, "max", self.group)

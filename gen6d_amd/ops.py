@@ -289,8 +289,9 @@ def vgg_conv1_pool(x, w_oihw, bias):
     return out
 
 
-def vgg_conv1_pool_nhwc(x, w_oihw, bias):
-    """As vgg_conv1_pool with a channels-last result [N,H//2,W//2,64] (the input layout of wino_conv3x3)."""
+def vgg_conv1_pool_nhwc(x, w_oihw, bias, out=None):
+    """As vgg_conv1_pool with a channels-last result [N,H//2,W//2,64] (the input layout of wino_conv3x3); `out`: a contiguous
+    destination of that shape (a slice of the buffer the scales of a pyramid share)."""
     _need_gpu(x, w_oihw, bias)
     if x.dtype != torch.float32 or x.dim() != 4 or not x.is_contiguous() or not w_oihw.is_contiguous():
         raise ValueError("vgg_conv1_pool_nhwc: x and w must be contiguous float32 NCHW / OIHW")
@@ -298,7 +299,10 @@ def vgg_conv1_pool_nhwc(x, w_oihw, bias):
     Cout = w_oihw.shape[0]
     if tuple(w_oihw.shape) != (Cout, Cin, 3, 3) or bias.numel() != Cout:
         raise ValueError("vgg_conv1_pool_nhwc: weight / bias shape mismatch")
-    out = torch.empty((N, H // 2, W // 2, Cout), dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty((N, H // 2, W // 2, Cout), dtype=torch.float32, device=x.device)
+    elif tuple(out.shape) != (N, H // 2, W // 2, Cout) or not out.is_contiguous() or out.dtype != torch.float32:
+        raise ValueError("vgg_conv1_pool_nhwc: out must be contiguous float32 [N,H/2,W/2,Cout]")
     _lib.check(_lib.load().g6d_vgg_conv1_pool_nhwc(_ptr(x), N, H, W, _ptr(w_oihw), _ptr(bias), Cin, Cout, _ptr(out), _stream()),
                "g6d_vgg_conv1_pool_nhwc")
     return out
@@ -331,6 +335,54 @@ def wino_conv3x3(x, U, bias, relu=True, full=True, pool=False):
         # direct-form FLOPs / 2.25 = multiplications actually executed in the Winograd domain (what the matrix cores do)
         PROFILE.append((flops / 2.25, e0, e1, f"wino3x3 N={N} in={H}x{W}x{Cin} out={Cout}{' full' if full else ''}{' pool' if pool else ''}"))
     return y, yp
+
+
+def alloc_like_segments(shapes, device):
+    """One flat float32 buffer cut into contiguous tensors of `shapes` (16-byte aligned starts): the segments of a
+    wino_conv3x3_multi launch are addressed with 32-bit offsets from a common base."""
+    sizes = [int(torch.Size(sh).numel()) for sh in shapes]
+    starts, tot = [], 0
+    for n in sizes:
+        starts.append(tot)
+        tot += (n + 3) // 4 * 4
+    buf = torch.empty((max(tot, 1),), dtype=torch.float32, device=device)
+    return [buf[st:st + n].view(sh) for st, n, sh in zip(starts, sizes, shapes)]
+
+
+def wino_conv3x3_multi(xs, U, bias, relu=True, full=True, pool=False):
+    """One trunk layer over several map sizes in ONE launch (the scales of the detector's image pyramid): xs = dense
+    channels-last [N_i,H_i,W_i,Cin] tensors cut from one buffer (alloc_like_segments / the outputs of the previous layer).
+    Returns (list of y_i or None, list of maxpool2x2(y_i) or None)."""
+    _need_gpu(U, bias, *xs)
+    if not 1 <= len(xs) <= 4:
+        raise ValueError("wino_conv3x3_multi: 1..4 segments")
+    Cin, Cout = xs[0].shape[3], U.shape[2]
+    if tuple(U.shape) != (Cin // 8, 16, Cout, 8) or not U.is_contiguous() or bias.numel() != Cout:
+        raise ValueError(f"wino_conv3x3_multi: U must be contiguous {(Cin // 8, 16, Cout, 8)}")
+    for x in xs:
+        if x.dim() != 4 or x.dtype != torch.float32 or not x.is_contiguous() or x.shape[3] != Cin:
+            raise ValueError("wino_conv3x3_multi: segments must be contiguous float32 [N,H,W,Cin]")
+    dev = xs[0].device
+    ys = alloc_like_segments([(x.shape[0], x.shape[1], x.shape[2], Cout) for x in xs], dev) if full else None
+    yps = alloc_like_segments([(x.shape[0], x.shape[1] // 2, x.shape[2] // 2, Cout) for x in xs], dev) if pool else None
+    segs = (_lib.G6dWinoSeg * len(xs))()
+    flops = 0.0
+    for i, x in enumerate(xs):
+        N, H, W, _ = x.shape
+        segs[i] = _lib.G6dWinoSeg(in_=x.data_ptr(), out_full=ys[i].data_ptr() if full else None,
+                                  out_pool=yps[i].data_ptr() if pool else None, N=N, H=H, W=W, ld_in=Cin, ld_full=Cout, ld_pool=Cout)
+        flops += 2.0 * N * H * W * Cout * 9 * Cin
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    ws = workspace(dev)
+    _lib.check(_lib.load().g6d_wino_conv3x3_multi(segs, len(xs), Cin, _ptr(U), _ptr(bias), Cout, int(relu), _ptr(ws), ws.numel() * 4,
+                                                 _stream()), "g6d_wino_conv3x3_multi")
+    if PROFILE is not None:
+        e1.record()
+        sizes = "+".join(f"{x.shape[0]}x{x.shape[1]}x{x.shape[2]}" for x in xs)
+        PROFILE.append((flops / 2.25, e0, e1, f"wino3x3 multi in={sizes}x{Cin} out={Cout}{' full' if full else ''}{' pool' if pool else ''}"))
+    return ys, yps
 
 
 def l2norm_rows(x):

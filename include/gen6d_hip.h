@@ -154,6 +154,19 @@ int g6d_wino_conv3x3(const float* in, int N, int H, int W, int Cin, int ld_in, c
                      int relu, float* out_full, int ld_full, float* out_pool, int ld_pool, float* workspace,
                      size_t workspace_bytes, g6d_stream_t stream);
 
+/* The same layer over up to 4 map sizes in one launch: the scales of the detector's image pyramid (network/detector.py:236-241)
+ * share every trunk layer's filters, and the quarters of all segments form one flat work list, so the small scales fill the
+ * blocks the large ones leave over.  All segments give the same kinds of output (out_full / out_pool both set or both NULL
+ * across segments), and their buffers lie within 2^30 floats of each other (allocate them from one buffer). */
+typedef struct G6dWinoSeg {
+  const float* in;        /* [N][H][W][ld_in] */
+  float* out_full;        /* [N][H][W][ld_full] or NULL */
+  float* out_pool;        /* [N][H/2][W/2][ld_pool] or NULL */
+  int32_t N, H, W, ld_in, ld_full, ld_pool;
+} G6dWinoSeg;
+int g6d_wino_conv3x3_multi(const G6dWinoSeg* segs, int nseg, int Cin, const float* U, const float* bias, int Cout, int relu,
+                           float* workspace, size_t workspace_bytes, g6d_stream_t stream);
+
 /* In-place L2 normalisation over C of channels-last rows x[rows][ld] (F.normalize eps 1e-12, network/selector.py:118,
  * network/refiner.py:69-71). */
 int g6d_l2norm_rows(float* x, int rows, int C, int ld, g6d_stream_t stream);

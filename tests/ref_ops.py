@@ -104,8 +104,21 @@ def vgg_conv1_pool(x, w_oihw, bias):
     return F.max_pool2d(F.relu(F.conv2d(x, w_oihw, bias, padding=1)), 2, 2)
 
 
-def vgg_conv1_pool_nhwc(x, w_oihw, bias):
-    return vgg_conv1_pool(x, w_oihw, bias).permute(0, 2, 3, 1).contiguous()
+def vgg_conv1_pool_nhwc(x, w_oihw, bias, out=None):
+    y = vgg_conv1_pool(x, w_oihw, bias).permute(0, 2, 3, 1).contiguous()
+    if out is None:
+        return y
+    out.copy_(y)
+    return out
+
+
+def alloc_like_segments(shapes, device):
+    return [torch.empty(sh, dtype=torch.float32, device=device) for sh in shapes]
+
+
+def wino_conv3x3_multi(xs, U, bias, relu=True, full=True, pool=False):
+    res = [wino_conv3x3(x, U, bias, relu, full, pool) for x in xs]
+    return ([r[0] for r in res] if full else None), ([r[1] for r in res] if pool else None)
 
 
 def wino_conv3x3(x, U, bias, relu=True, full=True, pool=False):

@@ -441,6 +441,59 @@ def test_wino_conv3x3_channel_slice_input(ops):
     _check(y.permute(0, 3, 1, 2), ref, 3e-5, "wino slice")
 
 
+WINO_MULTI_CASES = [
+    # segment sizes (N, H, W), Cin, Cout, relu, full, pool
+    ([(1, 44, 58), (1, 30, 40), (1, 22, 30), (1, 16, 20)], 512, 512, False, True, True),     # detector pyramid, 1/16 level, c7_pre + p7
+    ([(1, 22, 30), (1, 16, 20)], 64, 128, True, False, True),                                # pooled output only, blocks straddle segments
+    ([(2, 9, 7), (1, 8, 8), (3, 5, 13)], 128, 64, True, True, False),                        # ragged sizes, several images per segment
+    ([(1, 88, 116), (1, 60, 80), (1, 44, 60), (1, 32, 40)], 256, 512, True, True, False),    # 1/8 level: un-split
+]
+
+
+@pytest.mark.parametrize("sizes,Cin,Cout,relu,full,pool", WINO_MULTI_CASES)
+def test_wino_conv3x3_multi(ops, sizes, Cin, Cout, relu, full, pool):
+    """One launch over several map sizes (flat quarter list across segments) against F.conv2d per segment in float64."""
+    import torch.nn.functional as F
+    from gen6d_amd.network.backbone import winograd_filters
+    g = torch.Generator().manual_seed(4242 + Cin + len(sizes))
+    w = _rand(g, Cout, Cin, 3, 3, scale=(2.0 / (9 * Cin)) ** 0.5 * 1.7)
+    b = _rand(g, Cout, scale=0.3)
+    xs_cpu = [_rand(g, n, h, ww, Cin) for n, h, ww in sizes]
+    xs = ops.alloc_like_segments([tuple(x.shape) for x in xs_cpu], torch.device("cuda"))
+    for d, x in zip(xs, xs_cpu):
+        d.copy_(x)
+    for rep in range(2):                                   # twice: the split counters must be left re-armed
+        ys, yps = ops.wino_conv3x3_multi(xs, winograd_filters(w).cuda(), b.cuda(), relu=relu, full=full, pool=pool)
+        assert (ys is not None) == full and (yps is not None) == pool
+        for i, x in enumerate(xs_cpu):
+            ref = F.conv2d(x.double().permute(0, 3, 1, 2), w.double(), b.double(), padding=1)
+            if relu:
+                ref = F.relu(ref)
+            if full:
+                _check(ys[i].permute(0, 3, 1, 2), ref, 3e-5, f"wino multi full seg {i}")
+            if pool:
+                _check(yps[i].permute(0, 3, 1, 2), F.max_pool2d(ref, 2, 2), 3e-5, f"wino multi pool seg {i}")
+
+
+def test_trunk_multi_equals_per_scale(ops):
+    """The pyramid trunk (one launch per layer over all scales) gives the per-scale trunk's features."""
+    from gen6d_amd import synth
+    from gen6d_amd.network import name2network, backbone as B
+    from gen6d_amd.network.params import fold_vgg
+    net = name2network["detector"]({"name": "t"}).eval()
+    net.load_state_dict(synth.synth_state_dict("detector"))
+    packed = B.pack_trunk(fold_vgg(net.cuda(), "backbone.features"))
+    g = torch.Generator().manual_seed(9)
+    imgs = [torch.rand((1, 3, h, w), generator=g).cuda() for h, w in [(160, 224), (96, 128), (64, 96), (32, 64)]]
+    keys = ("c5", "c7_pre", "p7")
+    multi = B.trunk_features_multi(packed, imgs, keys)
+    for im, fm in zip(imgs, multi):
+        single = B.trunk_features(packed, im, keys, False)
+        for a, b_ in zip(fm, single):
+            assert a.shape == b_.shape
+            assert (a - b_).abs().max().item() <= 1e-5 * max(1.0, b_.abs().max().item())
+
+
 def test_wino_rejects_bad_args(ops):
     x = torch.zeros((1, 8, 8, 12), device="cuda")
     with pytest.raises((RuntimeError, ValueError)):

@@ -1,0 +1,32 @@
+#!/usr/bin/env python
+"""Own-trunk layer times at the detector / crop map sizes (one line per layer); run under different G6D_WINO_SPLIT_* settings to
+compare split choices.  G6D_WINO_DEBUG=1 prints the chosen split of every launch to stderr."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gen6d_amd import ops  # noqa: E402
+from gen6d_amd.network import backbone as B  # noqa: E402
+from trunk_bench import LAYERS, timeit  # noqa: E402
+
+
+def main():
+    dev = torch.device("cuda")
+    reps = int(os.environ.get("REPS", "20"))
+    tot = 0.0
+    for n, h, w in [(1, 704, 928), (1, 480, 640), (1, 352, 480), (1, 256, 320), (7, 128, 128), (1, 128, 128)]:
+        for cin, cout, ds, pool in LAYERS:
+            hh, ww = h // ds, w // ds
+            x = torch.randn((n, hh, ww, cin), device=dev)
+            U = B.winograd_filters(torch.randn((cout, cin, 3, 3), device=dev) * 0.05)
+            b = torch.randn((cout,), device=dev) * 0.1
+            t = timeit(lambda: ops.wino_conv3x3(x, U, b, relu=True, full=not pool, pool=pool), reps)
+            tot += t
+            print(f"{n}x{hh}x{ww} {cin}->{cout}{' pool' if pool else ''}: {t:.1f}")
+    print(f"total {tot:.1f}")
+
+
+if __name__ == "__main__":
+    main()
