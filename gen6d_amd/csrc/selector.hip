@@ -86,9 +86,116 @@ __global__ void __launch_bounds__(64) vps_kernel(const float* __restrict__ score
   if (lane == 0) vps[d] = acc;
 }
 
+// All pyramid levels of one query in ONE launch: block kinds
+//   [0, nlev*D)            level l = b / D, hypothesis d = b % D: the HW_l rows of refs_l[d] against the query rows (16 waves x 4 rows
+//                          in flight, 16-byte loads: 128 KB of reference rows requested per block and pass), scores kept in LDS,
+//                          then vps_l[d] = sum_hw S * (S / max_hw S) by wave 0 — the score map only goes to memory if the caller
+//                          wants it;
+//   [nlev*D, +nlev*C/16)   InstanceNorm affine of the product for 16 channels of level l: 64 position lanes, fp64.
+// Largest level first, so that its blocks (HW_0 = 256 rows = 512 KB each) start before the short ones fill in.
+struct SelLevel { const float* que; const float* refs; const double* r1; const double* r2; float* score_map; float* vps;
+                  float* scale; float* shift; int HW; int pad; };
+struct SelArgs { SelLevel lv[3]; int nlev, D, C; double inv_dg, eps; };
+#define SEL_MAX_HW 1024
+
+__global__ void __launch_bounds__(1024) selector_levels_kernel(const SelArgs a) {
+  __shared__ double sm[64][16 + 1], se[64][16 + 1];
+  __shared__ float sc[SEL_MAX_HW];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int b = blockIdx.x;
+  if (b < a.nlev * a.D) {
+    const int l = b / a.D, d = b - l * a.D;
+    const SelLevel& L = a.lv[l];
+    const int HW = L.HW, C = a.C;
+    const float* refs = L.refs + (size_t)d * HW * C;
+    for (int row0 = wave * 4; row0 < HW; row0 += 64) {
+      float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int row = row0 + u;
+        if (row < HW) {
+          const float* r = refs + (size_t)row * C;
+          const float* q = L.que + (size_t)row * C;
+          for (int c = lane * 4; c < C; c += 256) {
+            const f32x4 rv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(r + c));     // streamed once per query
+            const f32x4 qv = *reinterpret_cast<const f32x4*>(q + c);
+            s[u] += rv[0] * qv[0] + rv[1] * qv[1] + rv[2] * qv[2] + rv[3] * qv[3];
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float t = wave_sum(s[u]);
+        if (lane == 0 && row0 + u < HW) { sc[row0 + u] = t; if (L.score_map) L.score_map[(size_t)d * HW + row0 + u] = t; }
+      }
+    }
+    __syncthreads();
+    if (wave == 0) {
+      float mx = -INFINITY;
+      for (int p = lane; p < HW; p += 64) mx = fmaxf(mx, sc[p]);
+      mx = wave_max(mx);
+      float acc = 0.f;
+      for (int p = lane; p < HW; p += 64) { const float v = sc[p]; acc += v * (v / mx); }
+      acc = wave_sum(acc);
+      if (lane == 0) L.vps[d] = acc;
+    }
+    return;
+  }
+  b -= a.nlev * a.D;
+  const int groups = (a.C + 15) / 16;
+  const int l = b / groups, cg = b - l * groups;
+  const SelLevel& L = a.lv[l];
+  const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+  const int c = cg * 16 + cl;
+  double m = 0, e = 0;
+  if (c < a.C)
+    for (int p = pl; p < L.HW; p += 64) {
+      const double q = L.que[(size_t)p * a.C + c];
+      m += q * L.r1[(size_t)p * a.C + c];
+      e += q * q * L.r2[(size_t)p * a.C + c];
+    }
+  sm[pl][cl] = m; se[pl][cl] = e;
+  __syncthreads();
+  if (pl == 0 && c < a.C) {
+    m = 0; e = 0;
+#pragma unroll
+    for (int k = 0; k < 64; ++k) { m += sm[k][cl]; e += se[k][cl]; }
+    const double inv_n = a.inv_dg / (double)L.HW;
+    m *= inv_n; e *= inv_n;
+    double var = e - m * m; if (var < 0) var = 0;
+    const double rs = 1.0 / sqrt(var + a.eps);
+    L.scale[c] = (float)rs; L.shift[c] = (float)(-m * rs);
+  }
+}
+
 }  // namespace
 
 #define STREAM(s) reinterpret_cast<hipStream_t>(s)
+
+// network/selector.py:183-195 + 28,49,63 for all pyramid levels of a query at once.  Per level l < nlev (<= 3): que[l] [HW_l][C],
+// refs[l] [D][HW_l][C], r1[l] / r2[l] [HW_l][C] (g6d_selector_ref_sums) -> vps [nlev][D], scale / shift [nlev][C] (the
+// InstanceNorm3d affine of the never-materialised product over Dg * HW_l values; Dg = global hypothesis count, = D unless the
+// references are sharded), score_maps[l] [D][HW_l] only where the pointer is non-NULL.
+extern "C" int g6d_selector_levels(int nlev, const float* const* que, const float* const* refs, const double* const* r1,
+                                   const double* const* r2, const int* HW, int D, int Dg, int C, double eps, float* const* score_maps,
+                                   float* vps, float* scale, float* shift, g6d_stream_t stream) {
+  if (nlev < 1 || nlev > 3 || !que || !refs || !r1 || !r2 || !HW || !vps || !scale || !shift || D <= 0 || Dg <= 0 || C <= 0 || (C & 3)) {
+    g6d_set_error("selector_levels: bad args"); return G6D_EINVAL;
+  }
+  SelArgs a = {};
+  a.nlev = nlev; a.D = D; a.C = C; a.inv_dg = 1.0 / (double)Dg; a.eps = eps;
+  for (int l = 0; l < nlev; ++l) {
+    if (!que[l] || !refs[l] || !r1[l] || !r2[l] || HW[l] <= 0 || HW[l] > SEL_MAX_HW || !g6d_aligned16(que[l]) || !g6d_aligned16(refs[l]) ||
+        (long long)D * HW[l] > (1ll << 30)) {
+      g6d_set_error("selector_levels: bad level (HW <= 1024, 16-byte aligned operands)"); return G6D_EINVAL;
+    }
+    a.lv[l] = SelLevel{que[l], refs[l], r1[l], r2[l], score_maps ? score_maps[l] : nullptr, vps + (size_t)l * D, scale + (size_t)l * C,
+                       shift + (size_t)l * C, HW[l], 0};
+  }
+  const int blocks = nlev * D + nlev * ((C + 15) / 16);
+  hipLaunchKernelGGL(selector_levels_kernel, dim3(blocks), dim3(1024), 0, STREAM(stream), a);
+  return g6d_check_launch("selector_levels");
+}
 
 extern "C" int g6d_selector_ref_sums(const float* refs, int D, int HW, int C, double* r1, double* r2, g6d_stream_t stream) {
   if (!refs || !r1 || !r2 || D <= 0 || HW <= 0 || C <= 0) { g6d_set_error("selector_ref_sums: bad args"); return G6D_EINVAL; }

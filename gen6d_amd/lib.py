@@ -52,6 +52,7 @@ SIGNATURES = {
     "g6d_selector_ref_sums": [_P, _I, _I, _I, _P, _P, _P],
     "g6d_selector_prod_affine": [_P, _P, _P, _I, _I, _I, _D, _P, _P, _P],
     "g6d_selector_scan": [_P, _P, _I, _I, _I, _P, _P, _P],
+    "g6d_selector_levels": [_I, _P, _P, _P, _P, _P, _I, _I, _I, _D, _P, _P, _P, _P, _P],
     "g6d_refiner_volume": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "g6d_detector_assemble": [_P, _P, _P, _I, _I, _I, C.POINTER(C.c_float), _F, _I, _I, _I, _I, _P, _P],
     "g6d_detector_score_mlp_max": [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P],

@@ -146,17 +146,14 @@ class ViewpointSelector(ParamBank):
         self.ref_pose_embed = v.contiguous()
 
     # ------------------------------------------------------------------ query
-    def _level(self, l, q, cat):
-        """One pyramid level: q [1,1,h,w,512] query features; writes channels [256l,256l+256) of cat [D,1,4,4,768];
-        returns vps [D]."""
+    def _level(self, l, q, cat, scale, shift):
+        """One pyramid level: q [1,1,h,w,512] query features, (scale, shift) [1,512] the InstanceNorm affine of the
+        query x reference product; writes channels [256l,256l+256) of cat [D,1,4,4,768]."""
         pk = self._pack()
-        cache, (r1, r2) = self.ref_feats_cache[l], self.ref_sums[l]
+        cache = self.ref_feats_cache[l]
         D, _, h, w, _ = cache.shape
         dev = cache.device
         Dg = self.rfn * self.an                                              # global hypothesis count
-        q2 = q.view(h * w, 512)
-        _, vps = ops.selector_scan(q2, cache.view(D, h * w, 512))
-        scale, shift = ops.selector_prod_affine(q2, r1, r2, Dg)
         x, mul, relu = cache, q.view(h, w, 512), False
         layers = _CORR[l]
         for li, (idx, has_in, has_relu, has_pool) in enumerate(layers):
@@ -180,7 +177,6 @@ class ViewpointSelector(ParamBank):
                 x, scale, shift, relu = pooled, None, None, False
             else:
                 x, relu = out, bool(has_relu)
-        return vps
 
     def _query_one(self, que_img):
         pk = self._pack()
@@ -191,9 +187,15 @@ class ViewpointSelector(ParamBank):
         ops.stats_arena_begin(dev)
         qf = self.get_feats(que_img)
         cat = torch.empty((D, 1, 4, 4, 768), dtype=torch.float32, device=dev)
-        levels = [(lambda l=l: self._level(l, qf[l], cat)) for l in range(3)]
+        # score maps -> viewpoint scores and the product's InstanceNorm statistics of all three levels: one streaming launch
+        caches = [c.view(c.shape[0], c.shape[2] * c.shape[3], 512) for c in self.ref_feats_cache]
+        vps, psc, psh, _ = ops.selector_levels([qf[l].view(-1, 512) for l in range(3)], caches, self.ref_sums, Dg)     # [3,D], [3,512]
+        levels = [(lambda l=l: self._level(l, qf[l], cat, psc[l:l + 1], psh[l:l + 1])) for l in range(3)]
         # collectives must be issued in the same order on every rank: no stream fork in sharded mode
-        vps = torch.stack(ops.fork_join(levels, dev) if self.world == 1 else [f() for f in levels], 0)           # [3,D]
+        if self.world == 1:
+            ops.fork_join(levels, dev)
+        else:
+            for f in levels: f()
 
         # corr_feats_conv: 1x1x1 768->512, IN3d, ReLU, (AvgPool commuted) 512->512   selector.py:71-77,197-200
         y = torch.empty((D, 1, 4, 4, 512), dtype=torch.float32, device=dev)

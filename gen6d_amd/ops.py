@@ -445,6 +445,31 @@ def selector_scan(que, refs):
     return smap, vps
 
 
+def selector_levels(ques, refs, sums, Dg, eps=1e-5, want_maps=False):
+    """All pyramid levels of one query in one launch: ques[l] [HW_l,C], refs[l] [D,HW_l,C], sums[l] = (r1, r2) of
+    selector_ref_sums -> vps [L,D], scale [L,C], shift [L,C] (the InstanceNorm affine of the product over Dg*HW_l values) and, if
+    want_maps, the score maps [D,HW_l] (otherwise None: they never leave the chip)."""
+    L = len(ques)
+    _need_gpu(*ques, *refs)
+    D, _, Cc = refs[0].shape
+    dev = ques[0].device
+    for q, r in zip(ques, refs):
+        if not (q.is_contiguous() and r.is_contiguous()) or r.shape[0] != D or r.shape[2] != Cc or tuple(q.shape) != tuple(r.shape[1:]):
+            raise ValueError("selector_levels: operands must be contiguous [HW,C] / [D,HW,C]")
+    vps = torch.empty((L, D), dtype=torch.float32, device=dev)
+    scale = torch.empty((L, Cc), dtype=torch.float32, device=dev)
+    shift = torch.empty_like(scale)
+    maps = [torch.empty((D, r.shape[1]), dtype=torch.float32, device=dev) for r in refs] if want_maps else None
+    arr = lambda ts: (C.c_void_p * L)(*[t.data_ptr() if t is not None else None for t in ts])
+    hw = (C.c_int * L)(*[r.shape[1] for r in refs])
+    nbytes = sum(4.0 * (D * r.shape[1] * Cc + r.shape[1] * Cc + D) + 16.0 * r.shape[1] * Cc for r in refs)   # refs + que + vps, r1/r2 (fp64)
+    _timed_hbm("selector_levels", nbytes,
+               lambda: _lib.check(_lib.load().g6d_selector_levels(L, arr(ques), arr(refs), arr([s_[0] for s_ in sums]), arr([s_[1] for s_ in sums]),
+                                                                  hw, D, int(Dg), Cc, float(eps), arr(maps) if maps else None, _ptr(vps),
+                                                                  _ptr(scale), _ptr(shift), _stream()), "g6d_selector_levels"))
+    return vps, scale, shift, maps
+
+
 def refiner_volume(feats, projs, rot_in, lin, h_in, w_in, mean_in, std):
     """feats [rfn+1,fh,fw,C], projs [rfn+1,3,4], rot_in [3,3], lin [sn] -> mean_in [sn^3,2C], std [sn^3,C] (written)."""
     _need_gpu(feats, projs, rot_in, lin, mean_in, std)

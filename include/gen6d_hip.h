@@ -192,6 +192,13 @@ int g6d_selector_prod_affine(const float* que, const double* r1, const double* r
                              float* scale, float* shift, g6d_stream_t stream);
 int g6d_selector_scan(const float* que, const float* refs, int D, int HW, int C, float* score_map, float* vps,
                       g6d_stream_t stream);
+/* g6d_selector_scan + g6d_selector_prod_affine for all (<= 3) pyramid levels of a query in ONE launch; per-level operands as
+ * above, HW[l] <= 1024; vps [nlev][D], scale / shift [nlev][C]; score_maps may be NULL, or hold NULL for levels whose map is not
+ * wanted (the viewpoint score only needs vps); Dg = global hypothesis count of the InstanceNorm statistics (= D unless the
+ * references are sharded over ranks). */
+int g6d_selector_levels(int nlev, const float* const* que, const float* const* refs, const double* const* r1,
+                        const double* const* r2, const int* HW, int D, int Dg, int C, double eps, float* const* score_maps,
+                        float* vps, float* scale, float* shift, g6d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Refiner feature-volume construction (network/refiner.py:183-206,208-247; network/operator.py:4-17), fused:

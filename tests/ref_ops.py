@@ -177,6 +177,13 @@ def selector_scan(que, refs):
     return smap, vps
 
 
+def selector_levels(ques, refs, sums, Dg, eps=1e-5, want_maps=False):
+    res = [selector_scan(q, r) for q, r in zip(ques, refs)]
+    aff = [selector_prod_affine(q, s[0], s[1], Dg, eps) for q, s in zip(ques, sums)]
+    return (torch.stack([r[1] for r in res], 0), torch.cat([a[0] for a in aff], 0), torch.cat([a[1] for a in aff], 0),
+            [r[0] for r in res] if want_maps else None)
+
+
 def refiner_volume(feats, projs, rot_in, lin, h_in, w_in, mean_in, std):
     V, fh, fw, C = feats.shape
     sn = lin.numel()

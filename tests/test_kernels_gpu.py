@@ -265,6 +265,31 @@ def test_selector_similarity(ops):
     _check(smap, rsmap, 2e-6); _check(vps, rvps, 1e-5)
 
 
+@pytest.mark.parametrize("want_maps", [False, True])
+def test_selector_levels(ops, want_maps):
+    """All three pyramid levels in one launch (scores, viewpoint scores, product statistics) against the materialised product."""
+    g = torch.Generator().manual_seed(18)
+    D, C, Dg = 45, 512, 45
+    hws = [256, 64, 16]
+    refs = [torch.nn.functional.normalize(_rand(g, D, hw, C), dim=2) for hw in hws]
+    ques = [torch.nn.functional.normalize(_rand(g, hw, C) + 0.3, dim=1) for hw in hws]
+    sums = [ops.selector_ref_sums(r.cuda()) for r in refs]
+    vps, sc, sh, maps = ops.selector_levels([q.cuda() for q in ques], [r.cuda() for r in refs], sums, Dg, want_maps=want_maps)
+    assert (maps is not None) == want_maps
+    for l, (q, r) in enumerate(zip(ques, refs)):
+        prod = _d(r) * _d(q)[None]
+        mean, var = prod.mean((0, 1)), prod.var((0, 1), unbiased=False)
+        _check(sc[l], 1 / torch.sqrt(var + 1e-5), 1e-5, f"scale level {l}")
+        _check(sh[l], -mean / torch.sqrt(var + 1e-5), 1e-5, f"shift level {l}")
+        rsmap, rvps = ref_ops.selector_scan(_d(q), _d(r))
+        _check(vps[l], rvps, 1e-5, f"vps level {l}")
+        if want_maps:
+            _check(maps[l], rsmap, 2e-6, f"score map level {l}")
+        # same numbers as the per-level entry points
+        smap1, vps1 = ops.selector_scan(q.cuda(), r.cuda())
+        assert torch.equal(vps1, vps[l])
+
+
 @pytest.mark.parametrize("rfn", [6, 1, 8])
 def test_refiner_volume(ops, rfn):
     from gen6d_amd import synth
