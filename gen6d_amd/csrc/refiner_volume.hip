@@ -18,7 +18,7 @@ namespace {
 // (0 for taps outside the map: grid_sample padding_mode='zeros', align_corners=False).
 struct Taps { int o00, o01, o10, o11; float w00, w01, w10, w11; };
 
-__device__ __forceinline__ Taps project_view(int fh, int fw, int C, const float* __restrict__ P, float vx, float vy,
+__device__ __forceinline__ Taps project_view(int fh, int fw, int C, const float (&P)[12], float vx, float vy,
                                              float vz, float h_in, float w_in) {
   float X = vx * P[0] + vy * P[1] + vz * P[2] + P[3];
   float Y = vx * P[4] + vy * P[5] + vz * P[6] + P[7];
@@ -70,12 +70,18 @@ __device__ __forceinline__ f32x4 gather_view(const float* __restrict__ fmap, con
   return acc;
 }
 
-__global__ void __launch_bounds__(256, 4) refiner_volume_kernel(const float* __restrict__ feats,
-                                                             const float* __restrict__ projs,
-                                                             const float* __restrict__ rot,
+// Projections: either projs [rfn+1][3][4] (K @ pose per view, query last), or — projs == NULL — intrinsics and poses given
+// separately (ref_Ks [rfn][3][3], ref_poses [rfn][3][4], K_in [3][3], pose_in [3][4]) and multiplied here, one view per lane;
+// rot = 3x3 with row stride rot_ld (3: dense; 4: the rotation part of pose_in in place).
+struct VolViews { const float* projs; const float* ref_Ks; const float* ref_poses; const float* K_in; const float* pose_in;
+                  const float* rot; int rot_ld; };
+
+__global__ void __launch_bounds__(256, 4) refiner_volume_kernel(const float* __restrict__ feats, const VolViews vw,
                                                              const float* __restrict__ lin, int rfn, int fh, int fw,
                                                              int C, float h_in, float w_in, int sn,
                                                              float* __restrict__ mean_in, float* __restrict__ stdv) {
+  const float* __restrict__ rot = vw.rot;
+  const int rl = vw.rot_ld;
   const int nvox = sn * sn * sn;
   int half = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;         // one half-wave per voxel
   const int l32 = threadIdx.x & 31;
@@ -83,15 +89,27 @@ __global__ void __launch_bounds__(256, 4) refiner_volume_kernel(const float* __r
   if (!live) half = nvox - 1;
   const int k = half % sn, j = (half / sn) % sn, i = half / (sn * sn);
   const float g0 = lin[i], g1 = lin[j], g2 = lin[k];
-  const float vx = g0 * rot[0] + g1 * rot[3] + g2 * rot[6];
-  const float vy = g0 * rot[1] + g1 * rot[4] + g2 * rot[7];
-  const float vz = g0 * rot[2] + g1 * rot[5] + g2 * rot[8];
+  const float vx = g0 * rot[0] + g1 * rot[rl] + g2 * rot[2 * rl];
+  const float vy = g0 * rot[1] + g1 * rot[rl + 1] + g2 * rot[2 * rl + 1];
+  const float vz = g0 * rot[2] + g1 * rot[rl + 2] + g2 * rot[2 * rl + 2];
   const size_t fsz = (size_t)fh * fw * C;
   const float inv_n = 1.f / (float)rfn, inv_n1 = 1.f / (float)(rfn > 1 ? rfn - 1 : 1);
   // lane v of the half-wave projects the voxel into view v (views 0..rfn-1 = references, view rfn = query); every
   // lane then fetches the 8 footprint values of each view with shuffles instead of redoing the 9 projections
   const int myview = l32 <= rfn ? l32 : rfn;
-  const Taps mine = project_view(fh, fw, C, projs + myview * 12, vx, vy, vz, h_in, w_in);
+  float P[12];
+  if (vw.projs) {
+#pragma unroll
+    for (int e = 0; e < 12; ++e) P[e] = vw.projs[myview * 12 + e];
+  } else {
+    const float* K = myview < rfn ? vw.ref_Ks + myview * 9 : vw.K_in;
+    const float* T = myview < rfn ? vw.ref_poses + myview * 12 : vw.pose_in;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) P[r * 4 + c] = K[r * 3] * T[c] + K[r * 3 + 1] * T[4 + c] + K[r * 3 + 2] * T[8 + c];
+  }
+  const Taps mine = project_view(fh, fw, C, P, vx, vy, vz, h_in, w_in);
   for (int c = l32 * 4; c < C; c += 128) {           // (uniform trip count per half-wave pair: C is a kernel argument)
     f32x4 s[MAX_RFN];
     f32x4 sum = {0.f, 0.f, 0.f, 0.f};
@@ -123,8 +141,27 @@ extern "C" int g6d_refiner_volume(const float* feats, const float* projs, const 
     g6d_set_error("refiner_volume: bad args (1 <= rfn <= 8, C % 4 == 0)"); return G6D_EINVAL;
   }
   const long long threads = (long long)sn * sn * sn * 32;
+  const VolViews vw = {projs, nullptr, nullptr, nullptr, nullptr, rot_in, 3};
   hipLaunchKernelGGL(refiner_volume_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream), feats, projs, rot_in, lin, rfn, fh, fw, C, (float)h_in, (float)w_in, sn,
+                     reinterpret_cast<hipStream_t>(stream), feats, vw, lin, rfn, fh, fw, C, (float)h_in, (float)w_in, sn,
                      mean_in, stdv);
   return g6d_check_launch("refiner_volume");
+}
+
+// The same with intrinsics and poses given separately: the projections ref_Ks[r] @ ref_poses[r], K_in @ pose_in of
+// network/refiner.py:208-226 are formed inside the kernel (one view per lane), and the volume is rotated by the rotation part of
+// pose_in read in place — no matrix-product, concatenation or copy launches in front of the kernel.
+extern "C" int g6d_refiner_volume_kp(const float* feats, const float* ref_Ks, const float* ref_poses, const float* K_in,
+                                     const float* pose_in, const float* lin, int rfn, int fh, int fw, int C, int h_in, int w_in, int sn,
+                                     float* mean_in, float* stdv, g6d_stream_t stream) {
+  if (!feats || !ref_Ks || !ref_poses || !K_in || !pose_in || !lin || !mean_in || !stdv || rfn < 1 || rfn > MAX_RFN || (C & 3) ||
+      sn < 1 || sn > 256 || !g6d_aligned16(feats) || !g6d_aligned16(mean_in) || !g6d_aligned16(stdv)) {
+    g6d_set_error("refiner_volume_kp: bad args (1 <= rfn <= 8, C % 4 == 0)"); return G6D_EINVAL;
+  }
+  const long long threads = (long long)sn * sn * sn * 32;
+  const VolViews vw = {nullptr, ref_Ks, ref_poses, K_in, pose_in, pose_in, 4};
+  hipLaunchKernelGGL(refiner_volume_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), feats, vw, lin, rfn, fh, fw, C, (float)h_in, (float)w_in, sn,
+                     mean_in, stdv);
+  return g6d_check_launch("refiner_volume_kp");
 }

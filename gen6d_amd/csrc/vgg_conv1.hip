@@ -30,6 +30,11 @@
 #define C1_TAPS 27
 #define C1_THREADS (C1_PTX * C1_PTY * (C1_COUT / 16))
 
+// optional input normalisation (x - mean[c]) / std[c] applied while the tile is staged (torchvision Normalize of
+// network/pretrain_models.py / dataset code: the images arrive in [0,1]); the zero padding stays zero, as in the reference
+// where the padding follows the normalisation
+struct Conv1Norm { float mean[C1_CIN], std[C1_CIN]; int on; };
+
 struct Conv1Smem {
   float in[C1_CIN][C1_IH][C1_IWP];
   float w[C1_TAPS][C1_COUT];           // tap-major: the 16 channels of one pass are contiguous
@@ -38,13 +43,15 @@ struct Conv1Smem {
 
 // Phase 1: stage the zero-padded input tile of image n whose pooled origin is (px0, py0), and the weights.
 G6D_HD void conv1_stage(Conv1Smem& s, int tid, const float* in, const float* w_oihw, const float* bias, int n, int H, int W,
-                        int px0, int py0) {
+                        int px0, int py0, const Conv1Norm& nm) {
   const int gx0 = 2 * px0 - 1, gy0 = 2 * py0 - 1;
   for (int i = tid; i < C1_CIN * C1_IH * C1_IW; i += C1_THREADS) {
     const int col = i % C1_IW, r = (i / C1_IW) % C1_IH, c = i / (C1_IW * C1_IH);
     const int gy = gy0 + r, gx = gx0 + col;
     const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
-    s.in[c][r][col] = ok ? in[((size_t)(n * C1_CIN + c) * H + gy) * W + gx] : 0.f;
+    float v = ok ? in[((size_t)(n * C1_CIN + c) * H + gy) * W + gx] : 0.f;
+    if (nm.on && ok) v = (v - nm.mean[c]) / nm.std[c];
+    s.in[c][r][col] = v;
   }
   for (int i = tid; i < C1_TAPS * C1_COUT; i += C1_THREADS) {
     const int co = i % C1_COUT, t = i / C1_COUT;
@@ -107,23 +114,28 @@ namespace {
 __global__ void __launch_bounds__(C1_THREADS) vgg_conv1_pool_kernel(const float* __restrict__ in,
                                                                     const float* __restrict__ w_oihw,
                                                                     const float* __restrict__ bias, int H, int W, int Ho,
-                                                                    int Wo, float* __restrict__ out, int nhwc) {
+                                                                    int Wo, float* __restrict__ out, int nhwc, const Conv1Norm nm) {
   __shared__ Conv1Smem s;
   const int px0 = blockIdx.x * C1_PTX, py0 = blockIdx.y * C1_PTY, n = blockIdx.z;
-  conv1_stage(s, threadIdx.x, in, w_oihw, bias, n, H, W, px0, py0);
+  conv1_stage(s, threadIdx.x, in, w_oihw, bias, n, H, W, px0, py0, nm);
   __syncthreads();
   conv1_compute(s, threadIdx.x, out, n, Ho, Wo, px0, py0, nhwc != 0);
 }
 
 int conv1_launch(const float* in, int N, int H, int W, const float* w_oihw, const float* bias, int Cin, int Cout, float* out,
-                 int nhwc, g6d_stream_t stream) {
+                 int nhwc, g6d_stream_t stream, const float* mean = nullptr, const float* stdv = nullptr) {
   if (!in || !w_oihw || !bias || !out || N <= 0 || N > 65535 || H < 2 || W < 2 || Cin != C1_CIN || Cout != C1_COUT ||
       (long long)N * Cout * (H / 2) * (W / 2) >= (1ll << 31)) {
     g6d_set_error("vgg_conv1_pool: bad args (3 -> 64 channels, H, W >= 2)"); return G6D_EINVAL;
   }
   const int Ho = H / 2, Wo = W / 2;
+  Conv1Norm nm = {};
+  if (mean && stdv) {
+    for (int c = 0; c < C1_CIN; ++c) { nm.mean[c] = mean[c]; nm.std[c] = stdv[c]; }
+    nm.on = 1;
+  }
   hipLaunchKernelGGL(vgg_conv1_pool_kernel, dim3((Wo + C1_PTX - 1) / C1_PTX, (Ho + C1_PTY - 1) / C1_PTY, N), dim3(C1_THREADS),
-                     0, reinterpret_cast<hipStream_t>(stream), in, w_oihw, bias, H, W, Ho, Wo, out, nhwc);
+                     0, reinterpret_cast<hipStream_t>(stream), in, w_oihw, bias, H, W, Ho, Wo, out, nhwc, nm);
   return g6d_check_launch("vgg_conv1_pool");
 }
 
@@ -141,16 +153,26 @@ extern "C" int g6d_vgg_conv1_pool_nhwc(const float* in, int N, int H, int W, con
   return conv1_launch(in, N, H, W, w_oihw, bias, Cin, Cout, out, 1, stream);
 }
 
+// As g6d_vgg_conv1_pool_nhwc on an image in [0,1]: (x - mean[c]) / std[c] (HOST arrays of 3 floats: torchvision Normalize) is
+// applied while the input tile is staged, so the normalised image is never written.
+extern "C" int g6d_vgg_conv1_pool_nhwc_norm(const float* in, int N, int H, int W, const float* w_oihw, const float* bias, int Cin,
+                                            int Cout, const float* mean_host, const float* std_host, float* out, g6d_stream_t stream) {
+  if (!mean_host || !std_host) { g6d_set_error("vgg_conv1_pool_nhwc_norm: mean / std missing"); return G6D_EINVAL; }
+  return conv1_launch(in, N, H, W, w_oihw, bias, Cin, Cout, out, 1, stream, mean_host, std_host);
+}
+
 #else   // ---- host emulation of the two phases, thread by thread (tests only) -------------------------------------
 
 extern "C" int g6d_conv1_emulate(const float* in, int N, int H, int W, const float* w_oihw, const float* bias, float* out,
-                                 int nhwc) {
+                                 int nhwc, const float* mean, const float* stdv) {
   const int Ho = H / 2, Wo = W / 2;
   Conv1Smem* s = new Conv1Smem;
+  Conv1Norm nm = {};
+  if (mean && stdv) { for (int c = 0; c < C1_CIN; ++c) { nm.mean[c] = mean[c]; nm.std[c] = stdv[c]; } nm.on = 1; }
   for (int n = 0; n < N; ++n)
     for (int by = 0; by < (Ho + C1_PTY - 1) / C1_PTY; ++by)
       for (int bx = 0; bx < (Wo + C1_PTX - 1) / C1_PTX; ++bx) {
-        for (int tid = 0; tid < C1_THREADS; ++tid) conv1_stage(*s, tid, in, w_oihw, bias, n, H, W, bx * C1_PTX, by * C1_PTY);
+        for (int tid = 0; tid < C1_THREADS; ++tid) conv1_stage(*s, tid, in, w_oihw, bias, n, H, W, bx * C1_PTX, by * C1_PTY, nm);
         for (int tid = 0; tid < C1_THREADS; ++tid) conv1_compute(*s, tid, out, n, Ho, Wo, bx * C1_PTX, by * C1_PTY, nhwc != 0);
       }
   delete s;

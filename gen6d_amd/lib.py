@@ -45,6 +45,7 @@ SIGNATURES = {
     "g6d_bias_relu_pool_nchw": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
     "g6d_vgg_conv1_pool": [_P, _I, _I, _I, _P, _P, _I, _I, _P, _P],
     "g6d_vgg_conv1_pool_nhwc": [_P, _I, _I, _I, _P, _P, _I, _I, _P, _P],
+    "g6d_vgg_conv1_pool_nhwc_norm": [_P, _I, _I, _I, _P, _P, _I, _I, _P, _P, _P, _P],
     "g6d_wino_conv3x3": [_P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _P, _I, _P, C.c_size_t, _P],
     "g6d_wino_conv3x3_multi": [_P, _I, _I, _P, _P, _I, _I, _P, C.c_size_t, _P],
     "g6d_l2norm_rows": [_P, _I, _I, _I, _P],
@@ -54,6 +55,7 @@ SIGNATURES = {
     "g6d_selector_scan": [_P, _P, _I, _I, _I, _P, _P, _P],
     "g6d_selector_levels": [_I, _P, _P, _P, _P, _P, _I, _I, _I, _D, _P, _P, _P, _P, _P],
     "g6d_refiner_volume": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P],
+    "g6d_refiner_volume_kp": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "g6d_detector_assemble": [_P, _P, _P, _I, _I, _I, C.POINTER(C.c_float), _F, _I, _I, _I, _I, _P, _P],
     "g6d_detector_score_mlp_max": [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "g6d_detector_decode": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P],

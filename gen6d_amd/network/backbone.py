@@ -58,11 +58,15 @@ def pack_trunk(folded):
     return [folded[0]] + [(winograd_filters(w), b) for w, b in folded[1:]]
 
 
-def vgg_taps_cl(packed, x, taps):
-    """Own trunk, channels-last: x [n,3,h,w] normalised image -> {'c3': [n,h/4,w/4,256] post-ReLU, 'c5': [n,h/8,w/8,512]
-    post-ReLU, 'c7_pre': [n,h/16,w/16,512] pre-ReLU, 'p7': max-pool of c7_pre} (only the requested taps + c7_pre)."""
+_IMG_NORM = (tuple(specs.IMAGENET_MEAN), tuple(specs.IMAGENET_STD))
+
+
+def vgg_taps_cl(packed, x, taps, norm=None):
+    """Own trunk, channels-last: x [n,3,h,w] normalised image (or an image in [0,1] with norm = (mean, std): the first layer
+    normalises while it stages its input) -> {'c3': [n,h/4,w/4,256] post-ReLU, 'c5': [n,h/8,w/8,512] post-ReLU,
+    'c7_pre': [n,h/16,w/16,512] pre-ReLU, 'p7': max-pool of c7_pre} (only the requested taps + c7_pre)."""
     w0, b0 = packed[0]
-    x = ops.vgg_conv1_pool_nhwc(x.contiguous(), w0, b0)                         # conv0 + ReLU + pool
+    x = ops.vgg_conv1_pool_nhwc(x.contiguous(), w0, b0, norm=norm)              # (normalise +) conv0 + ReLU + pool
     _, x = ops.wino_conv3x3(x, *packed[1], relu=True, full=False, pool=True)    # conv1 + ReLU + pool
     x, _ = ops.wino_conv3x3(x, *packed[2], relu=True)                           # conv2
     c3, x = ops.wino_conv3x3(x, *packed[3], relu=True, full="c3" in taps, pool=True)
@@ -74,14 +78,15 @@ def vgg_taps_cl(packed, x, taps):
     return {k: v for k, v in out.items() if v is not None and (k in taps or k == "c7_pre")}
 
 
-def vgg_taps_cl_multi(packed, xs, taps):
+def vgg_taps_cl_multi(packed, xs, taps, norm=None):
     """vgg_taps_cl for several image sizes at once (the scales of the detector's pyramid): every Winograd layer is ONE launch
-    over all sizes (ops.wino_conv3x3_multi).  xs: list of normalised [1,3,h_i,w_i] images -> list of tap dicts."""
+    over all sizes (ops.wino_conv3x3_multi).  xs: list of [1,3,h_i,w_i] images (normalised, or in [0,1] with norm) -> list of
+    tap dicts."""
     w0, b0 = packed[0]
     dev = xs[0].device
     cur = ops.alloc_like_segments([(x.shape[0], x.shape[2] // 2, x.shape[3] // 2, w0.shape[0]) for x in xs], dev)
     for x, o in zip(xs, cur):
-        ops.vgg_conv1_pool_nhwc(x.contiguous(), w0, b0, out=o)                          # conv0 + ReLU + pool, per size
+        ops.vgg_conv1_pool_nhwc(x.contiguous(), w0, b0, out=o, norm=norm)               # conv0 + ReLU + pool, per size
     _, cur = ops.wino_conv3x3_multi(cur, *packed[1], relu=True, full=False, pool=True)
     cur, _ = ops.wino_conv3x3_multi(cur, *packed[2], relu=True)
     c3, cur = ops.wino_conv3x3_multi(cur, *packed[3], relu=True, full="c3" in taps, pool=True)
@@ -101,16 +106,15 @@ def trunk_features_multi(packed, imgs_list, keys):
     [1,1,h_l,w_l,C] maps.  One launch per layer for all sizes on the own trunk; the library trunk runs them one by one."""
     if not _OWN_TRUNK or len(imgs_list) > 4:
         return [trunk_features(packed, im, keys, False) for im in imgs_list]
-    taps = vgg_taps_cl_multi(packed, [img_norm(im) for im in imgs_list], set(keys))
+    taps = vgg_taps_cl_multi(packed, imgs_list, set(keys), norm=_IMG_NORM)
     return [[t[k].unsqueeze(1) for k in keys] for t in taps]
 
 
 def trunk_features(packed, imgs, keys, l2norm):
     """Normalised images [n,3,h,w] in [0,1] -> channels-last 5-D feature maps [n,1,h_l,w_l,C] for `keys`, optionally
     L2-normalised over C (F.normalize, reference selector.py:118 / refiner.py:69-71)."""
-    x = img_norm(imgs)
     if _OWN_TRUNK:
-        t = vgg_taps_cl(packed, x, set(keys))
+        t = vgg_taps_cl(packed, imgs, set(keys), norm=_IMG_NORM)
         outs = []
         for k in keys:
             f = t[k]
@@ -118,7 +122,7 @@ def trunk_features(packed, imgs, keys, l2norm):
                 ops.l2norm_rows(f)                  # in place: a tap is never the input of a later layer
             outs.append(f.unsqueeze(1))
         return outs
-    t = vgg_taps(packed, x, set(keys))
+    t = vgg_taps(packed, img_norm(imgs), set(keys))
     outs = []
     for k in keys:
         f = t[k].contiguous()

@@ -21,6 +21,17 @@ _K3, _P3 = (3, 3, 3), (1, 1, 1)
 _K2, _P2 = (1, 3, 3), (0, 1, 1)
 
 
+_LIN = {}
+
+
+def _linspace(sn, dev):
+    """torch.linspace(-1, 1, sn) cached per (sn, device): a constant of the configuration, not a launch per step."""
+    key = (sn, str(dev))
+    if key not in _LIN:
+        _LIN[key] = torch.linspace(-1, 1, sn, dtype=torch.float32, device=dev)
+    return _LIN[key]
+
+
 class VolumeRefiner(ParamBank):
     default_cfg = {"refiner_sample_num": 32}
 
@@ -139,6 +150,9 @@ class VolumeRefiner(ParamBank):
         x = ops.linear_gemv(code.reshape(1, -1), pk["fc0"][0], pk["fc0"][1], act=2)
         x = ops.linear_gemv(x, pk["fc1"][0], pk["fc1"][1], act=2)
         o = ops.linear_gemv(x, pk["heads"][0], pk["heads"][1])
+        if o.shape[0] == 1:
+            ops.l2norm_rows(o[:, 0:4])              # F.normalize(quaternion) in place (one row of four values)
+            return o[:, 0:4], o[:, 4:6], o[:, 6:7]
         return F.normalize(o[:, 0:4], dim=1), o[:, 4:6], o[:, 6:7]
 
     def _step(self, *a, **k):
@@ -154,12 +168,13 @@ class VolumeRefiner(ParamBank):
         rfn = ref_imgs.shape[0]
         h_in, w_in = ref_imgs.shape[-2:]
         feats = self.run_feature_net(torch.cat([ref_imgs, que_img], 0))                  # query last
-        projs = torch.cat([ref_Ks @ ref_poses, (K_in @ pose_in)[None]], 0).contiguous()
-        lin = torch.linspace(-1, 1, sn, dtype=torch.float32, device=dev)
+        lin = _linspace(sn, dev)
         C = feats.shape[-1]
         mean_in = torch.empty((sn ** 3, 2 * C), dtype=torch.float32, device=dev)
         std = torch.empty((sn ** 3, C), dtype=torch.float32, device=dev)
-        ops.refiner_volume(feats.contiguous(), projs, pose_in[:, :3].contiguous(), lin, h_in, w_in, mean_in, std)
+        # projections K @ pose and the volume's rotation are formed inside the kernel (reference refiner.py:208-226)
+        ops.refiner_volume_kp(feats.contiguous(), ref_Ks.contiguous(), ref_poses.contiguous(), K_in.contiguous(), pose_in.contiguous(),
+                              lin, h_in, w_in, mean_in, std)
         return self.run_regressor(self.run_volume_net(mean_in, std, sn))
 
     def forward(self, data):

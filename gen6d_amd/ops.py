@@ -289,9 +289,10 @@ def vgg_conv1_pool(x, w_oihw, bias):
     return out
 
 
-def vgg_conv1_pool_nhwc(x, w_oihw, bias, out=None):
+def vgg_conv1_pool_nhwc(x, w_oihw, bias, out=None, norm=None):
     """As vgg_conv1_pool with a channels-last result [N,H//2,W//2,64] (the input layout of wino_conv3x3); `out`: a contiguous
-    destination of that shape (a slice of the buffer the scales of a pyramid share)."""
+    destination of that shape (a slice of the buffer the scales of a pyramid share); `norm` = (mean, std) 3-tuples: x is an
+    image in [0,1] and (x - mean) / std is applied inside the kernel."""
     _need_gpu(x, w_oihw, bias)
     if x.dtype != torch.float32 or x.dim() != 4 or not x.is_contiguous() or not w_oihw.is_contiguous():
         raise ValueError("vgg_conv1_pool_nhwc: x and w must be contiguous float32 NCHW / OIHW")
@@ -303,6 +304,11 @@ def vgg_conv1_pool_nhwc(x, w_oihw, bias, out=None):
         out = torch.empty((N, H // 2, W // 2, Cout), dtype=torch.float32, device=x.device)
     elif tuple(out.shape) != (N, H // 2, W // 2, Cout) or not out.is_contiguous() or out.dtype != torch.float32:
         raise ValueError("vgg_conv1_pool_nhwc: out must be contiguous float32 [N,H/2,W/2,Cout]")
+    if norm is not None:
+        m, sd = (C.c_float * 3)(*norm[0]), (C.c_float * 3)(*norm[1])
+        _lib.check(_lib.load().g6d_vgg_conv1_pool_nhwc_norm(_ptr(x), N, H, W, _ptr(w_oihw), _ptr(bias), Cin, Cout, m, sd, _ptr(out),
+                                                            _stream()), "g6d_vgg_conv1_pool_nhwc_norm")
+        return out
     _lib.check(_lib.load().g6d_vgg_conv1_pool_nhwc(_ptr(x), N, H, W, _ptr(w_oihw), _ptr(bias), Cin, Cout, _ptr(out), _stream()),
                "g6d_vgg_conv1_pool_nhwc")
     return out
@@ -485,6 +491,25 @@ def refiner_volume(feats, projs, rot_in, lin, h_in, w_in, mean_in, std):
                lambda: _lib.check(_lib.load().g6d_refiner_volume(_ptr(feats), _ptr(projs), _ptr(rot_in), _ptr(lin), V - 1, fh,
                                                                  fw, Cc, int(h_in), int(w_in), sn, _ptr(mean_in), _ptr(std),
                                                                  _stream()), "g6d_refiner_volume"))
+    return mean_in, std
+
+
+def refiner_volume_kp(feats, ref_Ks, ref_poses, K_in, pose_in, lin, h_in, w_in, mean_in, std):
+    """refiner_volume with the projections formed inside the kernel: feats [rfn+1,fh,fw,C] (query last), ref_Ks [rfn,3,3],
+    ref_poses [rfn,3,4], K_in [3,3], pose_in [3,4] (also the volume's rotation) -> mean_in [sn^3,2C], std [sn^3,C]."""
+    _need_gpu(feats, ref_Ks, ref_poses, K_in, pose_in, lin, mean_in, std)
+    V, fh, fw, Cc = feats.shape
+    sn = lin.numel()
+    for t in (feats, ref_Ks, ref_poses, K_in, pose_in, lin, mean_in, std):
+        if not t.is_contiguous() or t.dtype != torch.float32:
+            raise ValueError("refiner_volume_kp: operands must be contiguous float32")
+    if (tuple(mean_in.shape) != (sn ** 3, 2 * Cc) or tuple(std.shape) != (sn ** 3, Cc) or tuple(ref_Ks.shape) != (V - 1, 3, 3) or
+            tuple(ref_poses.shape) != (V - 1, 3, 4) or tuple(K_in.shape) != (3, 3) or tuple(pose_in.shape) != (3, 4)):
+        raise ValueError("refiner_volume_kp: shape mismatch")
+    _timed_hbm("refiner_volume", 4.0 * (V * fh * fw * Cc + 3 * sn ** 3 * Cc),
+               lambda: _lib.check(_lib.load().g6d_refiner_volume_kp(_ptr(feats), _ptr(ref_Ks), _ptr(ref_poses), _ptr(K_in), _ptr(pose_in),
+                                                                    _ptr(lin), V - 1, fh, fw, Cc, int(h_in), int(w_in), sn, _ptr(mean_in),
+                                                                    _ptr(std), _stream()), "g6d_refiner_volume_kp"))
     return mean_in, std
 
 

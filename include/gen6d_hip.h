@@ -139,6 +139,10 @@ int g6d_vgg_conv1_pool(const float* in, int N, int H, int W, const float* w_oihw
 /* The same layer with a channels-last result [N][H/2][W/2][64] (input of g6d_wino_conv3x3). */
 int g6d_vgg_conv1_pool_nhwc(const float* in, int N, int H, int W, const float* w_oihw, const float* bias, int Cin, int Cout,
                             float* out, g6d_stream_t stream);
+/* The same on an image in [0,1]: torchvision Normalize ((x - mean[c]) / std[c]; mean, std: HOST arrays of 3 floats) applied
+ * while the input tile is staged — replaces the two elementwise passes of img_norm in front of every trunk call. */
+int g6d_vgg_conv1_pool_nhwc_norm(const float* in, int N, int H, int W, const float* w_oihw, const float* bias, int Cin, int Cout,
+                                 const float* mean_host, const float* std_host, float* out, g6d_stream_t stream);
 
 /* The 3x3 layers 64->128 ... 512->512 of the VGG-11-BN trunks (reference network/pretrain_models.py:9-31,61-72:
  * vgg11_bn features[4..28], BatchNorm folded) as Winograd F(2x2,3x3) on fp32 MFMA with the trunk's bias, ReLU and 2x2
@@ -214,6 +218,11 @@ int g6d_selector_levels(int nlev, const float* const* que, const float* const* r
  * ---------------------------------------------------------------------------------------------------------------- */
 int g6d_refiner_volume(const float* feats, const float* projs, const float* rot_in, const float* lin, int rfn, int fh,
                        int fw, int C, int h_in, int w_in, int sn, float* mean_in, float* std, g6d_stream_t stream);
+/* The same with intrinsics and poses given separately (ref_Ks [rfn][3][3], ref_poses [rfn][3][4], K_in [3][3], pose_in [3][4]):
+ * the projections K @ pose of network/refiner.py:208-226 are formed inside the kernel and the rotation is read from pose_in. */
+int g6d_refiner_volume_kp(const float* feats, const float* ref_Ks, const float* ref_poses, const float* K_in, const float* pose_in,
+                          const float* lin, int rfn, int fh, int fw, int C, int h_in, int w_in, int sn, float* mean_in, float* stdv,
+                          g6d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Detector score assembly (network/detector.py:225-229,243-245,207-216): for one detection scale, take the three raw

@@ -104,7 +104,9 @@ def vgg_conv1_pool(x, w_oihw, bias):
     return F.max_pool2d(F.relu(F.conv2d(x, w_oihw, bias, padding=1)), 2, 2)
 
 
-def vgg_conv1_pool_nhwc(x, w_oihw, bias, out=None):
+def vgg_conv1_pool_nhwc(x, w_oihw, bias, out=None, norm=None):
+    if norm is not None:
+        x = (x - torch.tensor(norm[0], dtype=x.dtype).view(1, 3, 1, 1)) / torch.tensor(norm[1], dtype=x.dtype).view(1, 3, 1, 1)
     y = vgg_conv1_pool(x, w_oihw, bias).permute(0, 2, 3, 1).contiguous()
     if out is None:
         return y
@@ -175,6 +177,11 @@ def selector_scan(que, refs):
     smap = (refs * que[None]).sum(2)
     vps = (smap * (smap / smap.max(1, keepdim=True)[0])).sum(1)
     return smap, vps
+
+
+def refiner_volume_kp(feats, ref_Ks, ref_poses, K_in, pose_in, lin, h_in, w_in, mean_in, std):
+    projs = torch.cat([ref_Ks @ ref_poses, (K_in @ pose_in)[None]], 0)
+    return refiner_volume(feats, projs, pose_in[:, :3], lin, h_in, w_in, mean_in, std)
 
 
 def selector_levels(ques, refs, sums, Dg, eps=1e-5, want_maps=False):

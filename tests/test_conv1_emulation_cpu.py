@@ -19,20 +19,25 @@ def emu(tmp_path_factory):
     subprocess.run(["g++", "-O2", "-x", "c++", "-std=c++17", "-DG6D_CONV1_HOST_EMU", "-Wno-unknown-pragmas", "-shared", "-fPIC",
                     SRC, "-o", so], check=True)
     lib = C.CDLL(so)
-    lib.g6d_conv1_emulate.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    lib.g6d_conv1_emulate.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                      C.c_void_p]
     lib.g6d_conv1_emulate.restype = C.c_int
     return lib
 
 
-@pytest.mark.parametrize("nhwc", [0, 1])
+@pytest.mark.parametrize("nhwc,norm", [(0, False), (1, False), (1, True)])
 @pytest.mark.parametrize("N,H,W", [(1, 16, 16), (2, 50, 70), (1, 33, 67), (1, 2, 2), (1, 18, 130)])
-def test_emulated_kernel_matches_torch(emu, N, H, W, nhwc):
+def test_emulated_kernel_matches_torch(emu, N, H, W, nhwc, norm):
     g = torch.Generator().manual_seed(11)
     x = torch.randn((N, 3, H, W), generator=g)
+    mean, std = (C.c_float * 3)(0.485, 0.456, 0.406), (C.c_float * 3)(0.229, 0.224, 0.225)
     w = torch.randn((64, 3, 3, 3), generator=g) * 0.3
     b = torch.randn((64,), generator=g) * 0.2
     out = torch.full((N, H // 2, W // 2, 64) if nhwc else (N, 64, H // 2, W // 2), float("nan"))
-    assert emu.g6d_conv1_emulate(x.data_ptr(), N, H, W, w.data_ptr(), b.data_ptr(), out.data_ptr(), nhwc) == 0
+    assert emu.g6d_conv1_emulate(x.data_ptr(), N, H, W, w.data_ptr(), b.data_ptr(), out.data_ptr(), nhwc,
+                                 mean if norm else None, std if norm else None) == 0
+    if norm:       # the padding stays zero: normalise first, then the zero-padded convolution
+        x = (x - torch.tensor(list(mean)).view(1, 3, 1, 1)) / torch.tensor(list(std)).view(1, 3, 1, 1)
     if nhwc:
         out = out.permute(0, 3, 1, 2)
     ref = F.max_pool2d(F.relu(F.conv2d(x.double(), w.double(), b.double(), padding=1)), 2, 2)

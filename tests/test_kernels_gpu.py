@@ -307,6 +307,12 @@ def test_refiner_volume(ops, rfn):
     # bilinear weights are computed from fp32 coordinates; 1e-4 of the feature range covers that
     _check(mean_in, rm, 2e-4, "mean|query")
     _check(std, rs, 2e-4, "std")
+    # the variant that forms K @ pose inside the kernel and reads the rotation from pose_in
+    m2 = torch.empty_like(mean_in); s2 = torch.empty_like(std)
+    ops.refiner_volume_kp(feats.cuda(), case["ref_Ks"][0].contiguous().cuda(), case["ref_poses"][0].contiguous().cuda(),
+                          case["Ks_in"][0].contiguous().cuda(), case["poses_in"][0].contiguous().cuda(), lin.cuda(), 128, 128, m2, s2)
+    _check(m2, rm, 2e-4, "mean|query (kp)")
+    _check(s2, rs, 2e-4, "std (kp)")
 
 
 def test_detector_glue(ops):
