@@ -223,19 +223,19 @@ def main():
                "`bench.py --no-graph`, tools/profile_round.sh); HBM-side bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024")
     # two MFMA-bound kernel families, both measured with HIP events around every launch (serialised eager re-run of the same
     # steps after the graph-replay timed region when graphs are used):
-    #   conv      conv_igemm / conv_patch / corr_patch + split-K reduce (same definition as round 1); executed = direct-form FLOPs
-    #   winograd  wino_conv3x3_kernel (own VGG trunk + the conv layers g6d_conv_igemm routes to it) + its reduce; the matrix cores
+    #   conv      conv_igemm / conv_patch / corr_patch (split launches finish inside the kernel); executed = direct-form FLOPs
+    #   winograd  wino_conv3x3_kernel (own VGG trunk + the conv layers g6d_conv_igemm routes to it); the matrix cores
     #             execute 1/2.25 of the direct-form FLOPs: `achieved` / `frac` are the EXECUTED rate, the direct-form equivalent
     #             is given beside it
     how = "HIP events around every launch, " + ("serialised eager re-run of the same steps after the graph-replay timed region"
                                                 if use_graph else "inside the timed region")
     fams = {}
     for key, sel, kname in (("conv", lambda p: not p[3].startswith("wino3x3"),
-                             "g6d_conv_igemm family: conv_igemm / conv_patch / corr_patch kernels (fp32 v_mfma_f32_32x32x2_f32) incl. "
-                             "their split-K reduce"),
+                             "g6d_conv_igemm family: conv_igemm / conv_patch / corr_patch kernels (fp32 v_mfma_f32_32x32x2_f32); split "
+                             "launches add their partial tiles inside the kernel"),
                             ("winograd", lambda p: p[3].startswith("wino3x3"),
                              "wino_conv3x3_kernel (Winograd F(2x2,3x3) on fp32 v_mfma_f32_32x32x2_f32): own VGG trunk (g6d_wino_conv3x3) + "
-                             "the stride-1 3x3 / 3x3x3 layers g6d_conv_igemm routes to it, incl. wino_reduce_kernel")):
+                             "the stride-1 3x3 / 3x3x3 layers g6d_conv_igemm routes to it; the detector's pyramid runs each layer as one launch")):
         pp = [p for p in prof if sel(p)]
         if not pp:
             continue

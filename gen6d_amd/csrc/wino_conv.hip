@@ -30,6 +30,14 @@
 #include "g6d_common.h"
 #include <stdlib.h>
 #include <stdio.h>
+#include <algorithm>
+
+#ifndef WINO_ABLATE
+#define WINO_ABLATE 0   // profiling builds only (tools/wino_ablate.sh; results are wrong by construction): 1 = no barrier in the chunk
+                        // loop, 2 = no global loads / LDS stores of the next chunk, 3 = no input transform (raw values as fragments),
+                        // 4 = no fragment reads from LDS, 5 = all of them (matrix cores only)
+#endif
+#define WABL(n) (WINO_ABLATE == (n) || WINO_ABLATE == 5)
 
 namespace {
 
@@ -66,6 +74,7 @@ struct WinoArgs {
   int N, H, W, Cin, ld_in, Cout, ld_full, ld_pool, relu;      // N = images x depth slices (every slice is a 2-D map); = seg[0]
   int QH, QW;
   int nseg, qtotal; WinoSeg seg[WINO_MAX_SEG];
+  unsigned in_bytes;                              // extent of the input tensor(s) from `in` (< 2^31): bound of the buffer loads
   int splits, chunks_per_split; float* ws;       // splits > 1: tile counters + partial outputs (no bias / ReLU / pool)
   // conv-family extras (zero / null for the trunk)
   int D;                                         // depth slices per image (1 for 2-D layers); KD = 3 pads in depth
@@ -138,6 +147,7 @@ __global__ void __launch_bounds__(128 * NWN, 1) wino_conv3x3_kernel(const WinoAr
     if constexpr (KD == 3) { const int dd = n % p.D; dbits |= (unsigned)(dd > 0) << (2 * j) | (unsigned)(dd < p.D - 1) << (2 * j + 1); }
   }
   const int slice = p.H * p.W * p.ld_in;                     // KD = 3: one depth step
+  const auto in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
   f32x4 rp[NPR], rm[MODE == 3 ? NPR : 1];
   bool rv[NPR];                                               // validity of the piece for the chunk it was loaded for
   auto load_piece = [&](int j, int chunk) {
@@ -146,17 +156,24 @@ __global__ void __launch_bounds__(128 * NWN, 1) wino_conv3x3_kernel(const WinoAr
     int off = poff[j] + cc * 8;
     if constexpr (KD == 3) { v &= kd == 1 || ((dbits >> (2 * j + (kd >> 1))) & 1u) != 0; off += (kd - 1) * slice; }
     rv[j] = v;
-    rp[j] = ldg4(p.in, v ? off : 0);
+    if constexpr (MODE == 0) {
+      // bounds-checked buffer load: pieces outside the image (zero padding, masked quarters) ask for an offset beyond the
+      // tensor and get zeros from the hardware — no select when the piece goes to LDS
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      const u32x4 raw = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, v ? (unsigned)off << 2 : 0x80000000u, 0, 0));
+      rp[j] = __builtin_bit_cast(f32x4, raw);
+    } else {
+      rp[j] = ldg4(p.in, v ? off : 0);
+    }
     if constexpr (MODE == 3) rm[j] = ldg4(p.mul, v ? moff[j] + cc * 8 : 0);
   };
   auto load_raw = [&](int chunk) {
 #pragma unroll
     for (int j = 0; j < NPR; ++j) load_piece(j, chunk);
   };
-  auto store_raw = [&](int st, int chunk) {   // unconditional stores (a branch would serialise them behind one vmcnt(0) each); the
-    const int cc = KD == 3 ? chunk % nc8 : chunk;          // idle pieces of the last round go to a scratch row behind the stages
-#pragma unroll
-    for (int j = 0; j < NPR; ++j) {
+  auto store_piece = [&](int j, int st, int chunk) {   // unconditional stores (a branch would serialise them behind one vmcnt(0) each);
+    const int cc = KD == 3 ? chunk % nc8 : chunk;       // the idle pieces of the last round go to a scratch row behind the stages
+    {
       f32x4 v = rp[j];
       if constexpr (MODE == 3) v *= rm[j];
       if constexpr (MODE != 0) {
@@ -165,8 +182,13 @@ __global__ void __launch_bounds__(128 * NWN, 1) wino_conv3x3_kernel(const WinoAr
         v = v * sc + sh;
         if (p.in_relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
       }
-      *reinterpret_cast<f32x4*>(lds + (live[j] ? st * WSTAGE + lsto[j] : 2 * WSTAGE + 4 * tid)) = rv[j] ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (MODE == 0) *reinterpret_cast<f32x4*>(lds + (live[j] ? st * WSTAGE + lsto[j] : 2 * WSTAGE + 4 * tid)) = v;
+      else *reinterpret_cast<f32x4*>(lds + (live[j] ? st * WSTAGE + lsto[j] : 2 * WSTAGE + 4 * tid)) = rv[j] ? v : f32x4{0.f, 0.f, 0.f, 0.f};
     }
+  };
+  auto store_raw = [&](int st, int chunk) {
+#pragma unroll
+    for (int j = 0; j < NPR; ++j) store_piece(j, st, chunk);
   };
   if constexpr (MODE != 0) {                  // InstanceNorm affine tables -> LDS: [G][Cin] scales, then [G][Cin] shifts
     constexpr int G = MODE == 2 ? 4 : 1;
@@ -183,15 +205,17 @@ __global__ void __launch_bounds__(128 * NWN, 1) wino_conv3x3_kernel(const WinoAr
   // Direct-to-LDS copy in inline asm: with the builtin, hipcc books the copy on the LDS counter as well and then waits
   // lgkmcnt(0) in front of every fragment use (it cannot count mixed event types), which exposes the LDS latency of the
   // fragment requests just issued.  M0 = LDS byte address of the wave's 1 KB destination, each lane lands at +16*lane.
-  const float* ubase = p.U + (size_t)n0 * 8 + lane * 4;
+  const float* ubase = p.U + (size_t)n0 * 8;                 // wave-uniform; each lane adds 16 bytes x lane
+  const unsigned lane16 = lane * 16;
   const unsigned lds_addr0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)lds;
   auto glds = [&](int chunk, int st, int idx) {
     const int ab = idx / NWN, h = idx % NWN;
-    const float* g = ubase + ((size_t)(chunk * 16 + ab) * p.Cout + h * 32) * 8;
+    // wave-uniform source: a 64-bit base per chunk plus a 32-bit piece offset (two scalar adds per piece)
+    const char* g = reinterpret_cast<const char*>(ubase) + (size_t)chunk * ((size_t)p.Cout * 512) + (unsigned)((ab * p.Cout + h * 32) * 32);
     const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr0 + 4u * (unsigned)(st * WSTAGE + WRAW_FLOATS + (ab * 32 * NWN + h * 32) * 8));
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(lane16), "s"(g), "s"(dst) : "memory");
   };
   auto load_u = [&](int chunk, int st) {
 #pragma unroll
@@ -228,59 +252,87 @@ __global__ void __launch_bounds__(128 * NWN, 1) wino_conv3x3_kernel(const WinoAr
 #pragma unroll
   for (int j = 0; j < 4; ++j) { vD[j] = f32x4{0.f, 0.f, 0.f, 0.f}; uD[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
+  // One step of the input transform V = B^T d B of (a,b) group `grp` (row combination a = grp of the raw rows, then the four column
+  // combinations): 16 steps of two floats each, so that a step fits into one MFMA gap.  Steps 0-7 fill rw, steps 8-15 the fragments.
+  auto xstep = [&](int grp, int h, const f32x4 (&dd)[4][4], f32x4 (&rw)[4], f32x4 (&vv)[4]) {
+    const int j = (h & 7) >> 1, o = 2 * (h & 1);
+    if (h < 8) {
+      if (WABL(3)) { rw[j][o] = dd[grp][j][o]; rw[j][o + 1] = dd[grp][j][o + 1]; return; }
+#pragma unroll
+      for (int e = o; e < o + 2; ++e)
+        rw[j][e] = grp == 0 ? dd[0][j][e] - dd[2][j][e] : grp == 1 ? dd[1][j][e] + dd[2][j][e] : grp == 2 ? dd[2][j][e] - dd[1][j][e]
+                                                                                                     : dd[1][j][e] - dd[3][j][e];
+    } else {
+      if (WABL(3)) { vv[j][o] = rw[j][o]; vv[j][o + 1] = rw[j][o + 1]; return; }
+#pragma unroll
+      for (int e = o; e < o + 2; ++e)
+        vv[j][e] = j == 0 ? rw[0][e] - rw[2][e] : j == 1 ? rw[1][e] + rw[2][e] : j == 2 ? rw[2][e] - rw[1][e] : rw[1][e] - rw[3][e];
+    }
+  };
+
   for (int cc = c_first; cc <= c_last; ++cc) {
     const int c = cc - c_first;                   // stage parity counts from the block's first chunk
     const float* S = lds + (c & 1) * WSTAGE;
     const int cn = min(cc + 1, c_last);           // the last chunk re-requests itself into the idle stage: no branches
-    f32x4 d[4][4], ub[3][4];
-    auto rd_d = [&](int i, int j) { d[i][j] = *reinterpret_cast<const f32x4*>(S + (i < 2 ? abase01 : abase23) + (i * 10 + j) * WRAW_LD); };
-    auto rd_u = [&](int g, int j) { ub[g % 3][j] = *reinterpret_cast<const f32x4*>(S + bbase + (g * 4 + j) * USTRIDE); };
+    f32x4 d[4][4], ub[3][4], vA[4], vB[4], rw[4];
+    auto rd_d = [&](int i, int j) { if (!WABL(4)) d[i][j] = *reinterpret_cast<const f32x4*>(S + (i < 2 ? abase01 : abase23) + (i * 10 + j) * WRAW_LD); };
+    auto rd_u = [&](int g, int j) { if (!WABL(4)) ub[g % 3][j] = *reinterpret_cast<const f32x4*>(S + bbase + (g * 4 + j) * USTRIDE); };
+    // A chunk is 64 MFMAs = 64 gaps of 64 cycles on the SIMD's matrix pipe; a lone wave hides about a dozen single-issue
+    // instructions per gap, but only if they are spread out (a burst between two groups stalls the pipe, and a direct-to-LDS
+    // piece costs 100+ cycles in a gap that already carries loads — MI355X_MICROARCH.md, per-instruction constants).  Every gap
+    // therefore gets its own small share, pinned by a scheduling barrier:
+    //   deferred group (gaps 0-15):  raw global loads of chunk c+1 (longest way to go), the 16 raw-tile reads and the filter
+    //                                fragments of groups 0 and 1, the transform of group 0 in the last four gaps
+    //   group 0 (16-31):             fragments of group 2, transform of group 1, raw pieces of chunk c+1 -> LDS (last gaps)
+    //   group 1 (32-47):             the 8 direct-to-LDS filter pieces of chunk c+1 (every other gap; issued AFTER the raw
+    //                                pieces were consumed, so the compiler's own load counting never waits for them), fragments of
+    //                                group 3, transform of group 2
+    //   group 2 (48-63):             transform of group 3 into the deferred operands
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       // consecutive MFMAs go to DIFFERENT accumulators (k & 3): instructions issued between two MFMAs on the same accumulator
-      // stretch the dependent pair (MI355X_MICROARCH.md, per-instruction constants)
+      // stretch the dependent pair
       acc[12 + (k & 3)] = __builtin_amdgcn_mfma_f32_32x32x2f32(vD[k & 3][k >> 2], uD[k & 3][k >> 2], acc[12 + (k & 3)], 0, 0, 0);
-      if (k < 8) glds(cn, (c & 1) ^ 1, wave * 8 + k);           // global requests first: they have the longest way to go
-      if (k < NPR) load_piece(k, cn);
-      if (k < 4) {}
-      else if (k < 6) { rd_d(0, 2 * (k - 4)); rd_d(0, 2 * (k - 4) + 1); }
-      else if (k < 8) { rd_d(2, 2 * (k - 6)); rd_d(2, 2 * (k - 6) + 1); }
-      else if (k < 10) { rd_u(0, 2 * (k - 8)); rd_u(0, 2 * (k - 8) + 1); }
-      else if (k < 12) { rd_d(1, 2 * (k - 10)); rd_d(1, 2 * (k - 10) + 1); }
-      else if (k < 14) { rd_d(3, 2 * (k - 12)); rd_d(3, 2 * (k - 12) + 1); }
-      else { rd_u(1, 2 * (k - 14)); rd_u(1, 2 * (k - 14) + 1); }
+      if (!WABL(2) && k < NPR) load_piece(k, cn);
+      // LDS requests, two per gap, in the order of first use: raw rows 0 and 2 (transform of group 0), the filter fragments of group
+      // 0, raw row 1, the fragments of group 1, raw row 3
+      if (k >= 2 && k < 14) {
+        const int u = k - 2, j0 = 2 * (u & 1);
+        if (u < 2) { rd_d(0, j0); rd_d(0, j0 + 1); }
+        else if (u < 4) { rd_d(2, j0); rd_d(2, j0 + 1); }
+        else if (u < 6) { rd_u(0, j0); rd_u(0, j0 + 1); }
+        else if (u < 8) { rd_d(1, j0); rd_d(1, j0 + 1); }
+        else if (u < 10) { rd_u(1, j0); rd_u(1, j0 + 1); }
+        else { rd_d(3, j0); rd_d(3, j0 + 1); }
+      }
+      if (k >= 8) { xstep(0, 2 * (k - 8), d, rw, vA); xstep(0, 2 * (k - 8) + 1, d, rw, vA); }
       __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      if (i < 2) { rd_u(i + 2, 0); rd_u(i + 2, 1); rd_u(i + 2, 2); rd_u(i + 2, 3); }
-      __builtin_amdgcn_sched_barrier(0);          // the requests stay in front of this group's MFMAs
-      f32x4 rw[4], v[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) rw[j] = i == 0 ? d[0][j] - d[2][j] : i == 1 ? d[1][j] + d[2][j] : d[2][j] - d[1][j];
-      v[0] = rw[0] - rw[2];
-      v[1] = rw[1] + rw[2];
-      v[2] = rw[2] - rw[1];
-      v[3] = rw[1] - rw[3];
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)           // accumulator changes fastest
-          acc[i * 4 + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j][s], ub[i % 3][j][s], acc[i * 4 + j], 0, 0, 0);
+    for (int m = 0; m < 16; ++m) {                 // group 0 on vA; prepares vB (group 1)
+      acc[m & 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(vA[m & 3][m >> 2], ub[0][m & 3][m >> 2], acc[m & 3], 0, 0, 0);
+      if (m < 2) { rd_u(2, 2 * m); rd_u(2, 2 * m + 1); }
+      xstep(1, m, d, rw, vB);
+      if (!WABL(2) && m >= 16 - NPR) store_piece(m - (16 - NPR), (c & 1) ^ 1, cn);
       __builtin_amdgcn_sched_barrier(0);
     }
-    {   // operands of the deferred group 3 of this chunk
-      f32x4 rw[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { rw[j] = d[1][j] - d[3][j]; uD[j] = ub[0][j]; }     // ub[3 % 3] holds the group-3 fragments
-      vD[0] = rw[0] - rw[2];
-      vD[1] = rw[1] + rw[2];
-      vD[2] = rw[2] - rw[1];
-      vD[3] = rw[1] - rw[3];
+    for (int m = 0; m < 16; ++m) {                 // group 1 on vB; prepares vA (group 2)
+      acc[4 + (m & 3)] = __builtin_amdgcn_mfma_f32_32x32x2f32(vB[m & 3][m >> 2], ub[1][m & 3][m >> 2], acc[4 + (m & 3)], 0, 0, 0);
+      if (!WABL(2) && !(m & 1)) glds(cn, (c & 1) ^ 1, wave * 8 + (m >> 1));
+      if (m == 1 || m == 3) { rd_u(3, m - 1); rd_u(3, m); }
+      xstep(2, m, d, rw, vA);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    store_raw((c & 1) ^ 1, cn);
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {                 // group 2 on vA; prepares the deferred operands (group 3)
+      acc[8 + (m & 3)] = __builtin_amdgcn_mfma_f32_32x32x2f32(vA[m & 3][m >> 2], ub[2][m & 3][m >> 2], acc[8 + (m & 3)], 0, 0, 0);
+      xstep(3, m, d, rw, vD);
+      if (m >= 12) uD[m - 12] = ub[0][m - 12];     // ub[3 % 3] holds the group-3 fragments
+      __builtin_amdgcn_sched_barrier(0);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the direct-to-LDS filter tiles of the next chunk have landed
-    __syncthreads();
+    if (!WABL(1)) __syncthreads();
   }
 #pragma unroll
   for (int k = 0; k < 16; ++k)
@@ -423,10 +475,11 @@ int wino_run(WinoArgs& a, int mode, int kd, float* workspace, size_t workspace_b
     a.nseg = 1;
     a.seg[0] = WinoSeg{0, a.N, a.H, a.W, 0, 0, 0, 0, 0, a.ld_in, a.ld_full, a.ld_pool};
   }
-  long long quarters = 0;
+  long long quarters = 0, in_extent = 0;
   double out_elems = 0.0;
   for (int k = 0; k < a.nseg; ++k) {
     WinoSeg& g = a.seg[k];
+    in_extent = std::max(in_extent, (long long)g.in_off + (long long)g.N * g.H * g.W * g.ld_in);
     g.QH = (g.H + 7) / 8; g.QW = (g.W + 7) / 8;
     g.qstart = (int)quarters;
     quarters += (long long)g.N * g.QH * g.QW;
@@ -436,6 +489,8 @@ int wino_run(WinoArgs& a, int mode, int kd, float* workspace, size_t workspace_b
   const long long blocks = (quarters + 3) / 4;
   if (blocks > 0x3fffffffll) { g6d_set_error("wino_conv3x3: grid too large"); return G6D_EINVAL; }
   a.qtotal = (int)quarters;
+  if (in_extent * 4 >= (1ll << 31)) { g6d_set_error("wino_conv3x3: input tensor exceeds 2^31 bytes"); return G6D_EINVAL; }
+  a.in_bytes = (unsigned)(in_extent * 4);
   // 32-channel (two-wave) blocks only for channel counts that are not multiples of 64: two of them share a CU, so they do not
   // spread a small grid over more CUs — the split over the chunks below does
   const int nwn = (a.Cout & 63) ? 1 : 2;
@@ -494,7 +549,7 @@ extern "C" int g6d_wino_conv3x3(const float* in, int N, int H, int W, int Cin, i
                                 float* workspace, size_t workspace_bytes, g6d_stream_t stream) {
   if (!in || !U || (!out_full && !out_pool) || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 7) || (ld_in & 3) || ld_in < Cin ||
       Cout <= 0 || (Cout & 63) || (out_full && ld_full < Cout) || (out_pool && (ld_pool < Cout || H < 2 || W < 2)) ||
-      !g6d_aligned16(in) || !g6d_aligned16(U) || (long long)N * H * W * ld_in >= (1ll << 30)) {
+      !g6d_aligned16(in) || !g6d_aligned16(U) || (long long)N * H * W * ld_in >= (1ll << 29)) {
     g6d_set_error("wino_conv3x3: bad args (Cin % 8 == 0, Cout % 64 == 0, 16-byte aligned operands)"); return G6D_EINVAL;
   }
   WinoArgs a = {};
@@ -533,7 +588,7 @@ extern "C" int g6d_wino_conv3x3_multi(const G6dWinoSeg* segs, int nseg, int Cin,
   for (int k = 0; k < nseg; ++k) {
     const G6dWinoSeg& g = segs[k];
     const long long io = g.in - in0, fo = want_full ? g.out_full - f0 : 0, po = want_pool ? g.out_pool - p0 : 0;
-    if (io + (long long)g.N * g.H * g.W * g.ld_in >= (1ll << 30) || fo + (long long)g.N * g.H * g.W * g.ld_full >= (1ll << 31) ||
+    if (io + (long long)g.N * g.H * g.W * g.ld_in >= (1ll << 29) || fo + (long long)g.N * g.H * g.W * g.ld_full >= (1ll << 31) ||
         po + (long long)g.N * g.H * g.W * g.ld_pool >= (1ll << 31)) {
       g6d_set_error("wino_conv3x3_multi: segments must lie within 2^30 floats of each other (allocate them from one buffer)"); return G6D_EINVAL;
     }
@@ -565,7 +620,7 @@ bool g6d_wino_eligible(const G6dConv& d) {
   const double min_work = mw ? atof(mw) : 1.5e8;
   const double M = (double)d.N * d.Di * d.Hi * d.Wi, K = (double)d.kd * d.Cin;
   if (min_work > 0 && (K < 128 || M * K * d.Cout < min_work)) return false;
-  return (long long)d.N * d.Di * d.Hi * d.Wi * d.ld_in < (1ll << 30);
+  return (long long)d.N * d.Di * d.Hi * d.Wi * d.ld_in < (1ll << 29);      // 2^31 bytes: the bound of the buffer loads
 }
 
 int g6d_wino_launch(const G6dConv& d, hipStream_t stream) {

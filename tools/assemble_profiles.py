@@ -9,8 +9,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
 RND = sys.argv[1] if len(sys.argv) > 1 else "r01"
-FAMILY = ("conv_igemm_kernel", "conv_patch_kernel", "corr_patch_kernel", "splitk_reduce")
-WFAMILY = ("wino_conv3x3_kernel", "wino_reduce_kernel")
+FAMILY = ("conv_igemm_kernel", "conv_patch_kernel", "corr_patch_kernel")      # split launches finish inside these kernels
+WFAMILY = ("wino_conv3x3_kernel",)
 
 
 def rd(f):
@@ -45,19 +45,22 @@ def main():
     sstats = rd("prof_serial_stats.md")
     ms, main = family_ms(sstats)
     wms, wmain = family_ms(sstats, WFAMILY)
-    r = ser["roofline"]
-    w = ser.get("roofline_winograd", {})
+    fams = {ser["roofline"].get("family", "conv"): ser["roofline"]}
+    for k in ("conv", "winograd"):
+        if "roofline_" + k in ser:
+            fams[k] = ser["roofline_" + k]
+    r, w = fams["conv"], fams.get("winograd", {})
     gflop_step = r["gflop_per_launch"] * r["launches_per_step"]
     wg = w.get("gflop_direct_form_per_step", 0.0)
     open(os.path.join(P, f"{RND}_bench_kernel_stats_serial.md"), "w").write(
         f"# rocprofv3 --kernel-trace --stats of `python bench.py --steps {steps} --warmup 4 --no-cpu-baseline --lowp '' --serial` (1x MI355X)\n\n"
         "Same workload, one query at a time, no graph replay (`--serial`), which is how bench.py's roofline pass runs: per-kernel\n"
         "durations are not inflated by overlap and can be compared with the `roofline` objects of the bench JSON.\n\n"
-        "* conv family (conv_igemm_kernel<...> + conv_patch_kernel<...> + corr_patch_kernel + splitk_reduce{,_rows}_kernel) in the timed region:\n"
+        "* conv family (conv_igemm_kernel<...> + conv_patch_kernel<...> + corr_patch_kernel; split launches finish in-kernel) in the timed region:\n"
         f"  {ms:.2f} ms = {ms / steps:.2f} ms per step ({main / steps:.0f} launches per step, {gflop_step:.1f} GFLOP per step -> "
         f"{gflop_step / (ms / steps):.1f} TFLOP/s by kernel durations; bench.py's HIP-event figure in the same profiled run: "
         f"{r['conv_ms_per_step']:.2f} ms per step, {r['achieved']:.1f} TFLOP/s — the event brackets include launch gaps and the profiler's per-dispatch overhead).\n"
-        "* Winograd family (wino_conv3x3_kernel<MODE,KD,NWN> + wino_reduce_kernel: the own VGG trunk and the conv layers routed to it):\n"
+        "* Winograd family (wino_conv3x3_kernel<MODE,KD,NWN>: the own VGG trunk and the conv layers routed to it):\n"
         f"  {wms:.2f} ms = {wms / steps:.2f} ms per step ({wmain / steps:.0f} launches per step, {wg:.1f} GFLOP per step in DIRECT form = "
         f"{wg / 2.25:.1f} GFLOP executed in the Winograd domain -> {wg / 2.25 / max(wms / steps, 1e-9):.1f} TFLOP/s executed, "
         f"{wg / max(wms / steps, 1e-9):.1f} TFLOP/s direct-form equivalent; bench.py: {w.get('ms_per_step', 0):.2f} ms per step, "
@@ -68,7 +71,8 @@ def main():
         "`python bench.py --steps 3 --warmup 2 --no-cpu-baseline --lowp '' --no-graph`, dispatches inside the timed region (3 steps). Unit: KB.\n"
         "gfx950 note (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports half the bytes of a wide coalesced stream — double it before comparing.\n\n"
         "Checks against algorithmic bytes (per dispatch, tables below):\n"
-        "* `scan_kernel` (selector score maps): FETCH x2 vs algorithmic (168+42+10.5)/3 = 73.5 MB — the reference cache is read once.\n"
+        "* `selector_levels_kernel` (score maps + viewpoint scores + product statistics of the three levels, one launch): FETCH x2 vs\n"
+        "  algorithmic 168 + 42 + 10.5 = 220.5 MB of reference cache (+ 3.3 MB of fp64 R1/R2 sums) — the cache is read once.\n"
         "* `refiner_volume_kernel`: WRITE vs algorithmic 50.3 MB (mean|query 33.5 MB + std 16.8 MB).\n"
         f"* conv family (tools/pmc_conv_traffic.py -> {RND}_pmc_conv_traffic.json): {traffic['hbm_bytes_per_launch'] / 1e6:.1f} MB HBM-side per launch; "
         f"Winograd family: {traffic.get('winograd_family', {}).get('hbm_bytes_per_launch', 0) / 1e6:.1f} MB per launch — both far from HBM-bound.\n\n"

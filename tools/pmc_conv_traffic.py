@@ -2,7 +2,7 @@
 """HBM-side traffic of the g6d_conv_igemm kernel family from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE, each
 collected on its own with --kernel-trace only) of `bench.py --steps K --warmup W --no-cpu-baseline --no-graph`:
 bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 summed over the family's dispatches between the g6d markers, divided by the
-number of g6d_conv_igemm / g6d_corr2d_patch launches (main kernels; their split-K reduce kernels count into the bytes).
+number of g6d_conv_igemm / g6d_corr2d_patch launches (split launches write and re-read their partial tiles inside the kernel).
 gfx950: FETCH_SIZE reports half the bytes of a wide coalesced stream (MI355X_MICROARCH.md, HBM section).
 Usage: python tools/pmc_conv_traffic.py <fetch.db> <write.db> <steps> <out.json>"""
 import json
@@ -10,9 +10,9 @@ import sqlite3
 import sys
 
 MAIN = ("conv_igemm_kernel", "conv_patch_kernel", "corr_patch_kernel")
-FAMILY = MAIN + ("splitk_reduce",)
+FAMILY = MAIN                      # split launches finish inside the kernels: no reduce kernels any more
 WMAIN = ("wino_conv3x3_kernel",)
-WFAMILY = WMAIN + ("wino_reduce_kernel",)
+WFAMILY = WMAIN
 
 
 def family_sum(db, counter, FAMILY=FAMILY, MAIN=MAIN):
@@ -36,15 +36,15 @@ def main():
     write_kb, _ = family_sum(write_db, "WRITE_SIZE")
     res = {
         "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `bench.py --steps "
-                  f"{steps} --warmup 2 --no-cpu-baseline --no-graph`, kernels conv_igemm / conv_patch / corr_patch + "
-                  "splitk_reduce{,_rows} inside the timed region; bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 "
+                  f"{steps} --warmup 2 --no-cpu-baseline --no-graph`, kernels conv_igemm / conv_patch / corr_patch "
+                  "inside the timed region; bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 "
                   "(gfx950: FETCH_SIZE counts half of a wide coalesced stream, MI355X_MICROARCH.md HBM section)",
         "fetch_kb_total": fetch_kb, "write_kb_total": write_kb, "steps": steps, "launches": launches,
         "hbm_bytes_per_launch": (2 * fetch_kb + write_kb) * 1024 / max(launches, 1),
     }
     wf, wl = family_sum(fetch_db, "FETCH_SIZE", WFAMILY, WMAIN)
     ww, _ = family_sum(write_db, "WRITE_SIZE", WFAMILY, WMAIN)
-    res["winograd_family"] = {"kernels": "wino_conv3x3_kernel + wino_reduce_kernel (own trunk and the conv layers routed to it)",
+    res["winograd_family"] = {"kernels": "wino_conv3x3_kernel (own trunk and the conv layers routed to it)",
                               "fetch_kb_total": wf, "write_kb_total": ww, "launches": wl,
                               "hbm_bytes_per_launch": (2 * wf + ww) * 1024 / max(wl, 1)}
     with open(out, "w") as f:
