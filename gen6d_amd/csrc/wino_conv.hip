@@ -86,6 +86,24 @@ __device__ __forceinline__ f32x4 ldg4(const float* __restrict__ base, int elem_o
   return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + ((unsigned)elem_off << 2));
 }
 
+typedef float f32x2w __attribute__((ext_vector_type(2)));
+#define f32x2 f32x2w
+__device__ __forceinline__ f32x2 lo2(const f32x4& x) { return __builtin_shufflevector(x, x, 0, 1); }
+__device__ __forceinline__ f32x2 hi2(const f32x4& x) { return __builtin_shufflevector(x, x, 2, 3); }
+__device__ __forceinline__ f32x4 cat2(f32x2 a, f32x2 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3); }
+// a - b on two floats in one instruction (the compiler scalarises a two-float subtraction; the packed add takes the negation as
+// an operand modifier).  Register-only, consumed a whole MFMA group later.
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 // quarter q of this block -> segment geometry, image, first output row / column, validity.  The quarters (8x8 output pixels)
 // of all images of all segments form one flat list, four consecutive ones per block: no block-level padding on odd quarter
 // counts, and small maps (<= 8x8 pixels = one quarter per image) simply put four images into a block.
@@ -115,8 +133,8 @@ __global__ void __launch_bounds__(128 * NWN, 1) wino_conv3x3_kernel(const WinoAr
   constexpr int THREADS = 128 * NWN;
   constexpr int NPR = (800 + THREADS - 1) / THREADS;          // raw-patch pieces per thread and chunk (4 or 7)
   constexpr int WU_FLOATS = 16 * 32 * NWN * 8;                // [ab][co][8], lane-linear image of the global layout
-  constexpr int WSTAGE = WRAW_FLOATS + WU_FLOATS;
-  constexpr int AFF0 = 2 * WSTAGE + 4 * THREADS;              // affine tables behind the stages and the scratch row
+  constexpr int WSTAGE = WRAW_FLOATS + WU_FLOATS + 4 * THREADS;   // raw patch, filter image, scratch row for the idle pieces of the last round
+  constexpr int AFF0 = 2 * WSTAGE;                            // affine tables behind the stages
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / NWN, wn = wave % NWN;
@@ -140,11 +158,16 @@ __global__ void __launch_bounds__(128 * NWN, 1) wino_conv3x3_kernel(const WinoAr
     const int iy = g.oy0 + py - 1, ix = g.ox0 + px - 1;
     pval[j] = (idx < 800) & g.valid & ((unsigned)iy < (unsigned)g.H) & ((unsigned)ix < (unsigned)g.W);
     poff[j] = pval[j] ? g.in_off + ((n * g.H + iy) * g.W + ix) * g.ld_in + 4 * half : 0;
-    lsto[j] = (q * WQ_PIX + pp) * WRAW_LD + 4 * (half ^ ((py >> 1) & 1));
     live[j] = idx < 800;
+    lsto[j] = live[j] ? (q * WQ_PIX + pp) * WRAW_LD + 4 * (half ^ ((py >> 1) & 1)) : WRAW_FLOATS + WU_FLOATS + 4 * tid;
     if constexpr (MODE == 3) moff[j] = pval[j] ? (iy * p.W + ix) * p.Cin + 4 * half : 0;
     if constexpr (MODE != 0) aoff[j] = (MODE == 2 ? (q < 4 ? q : 0) * p.Cin : 0) + 4 * half;
     if constexpr (KD == 3) { const int dd = n % p.D; dbits |= (unsigned)(dd > 0) << (2 * j) | (unsigned)(dd < p.D - 1) << (2 * j + 1); }
+  }
+  unsigned pboff[MODE == 0 && KD == 1 ? NPR : 1];            // byte offsets of the pieces for the buffer loads (beyond the tensor: zero)
+  if constexpr (MODE == 0 && KD == 1) {
+#pragma unroll
+    for (int j = 0; j < NPR; ++j) pboff[j] = pval[j] ? (unsigned)poff[j] << 2 : 0x80000000u;
   }
   const int slice = p.H * p.W * p.ld_in;                     // KD = 3: one depth step
   const auto in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
@@ -158,9 +181,12 @@ __global__ void __launch_bounds__(128 * NWN, 1) wino_conv3x3_kernel(const WinoAr
     rv[j] = v;
     if constexpr (MODE == 0) {
       // bounds-checked buffer load: pieces outside the image (zero padding, masked quarters) ask for an offset beyond the
-      // tensor and get zeros from the hardware — no select when the piece goes to LDS
+      // tensor and get zeros from the hardware — no select when the piece goes to LDS; for 2-D layers the lane offset is a
+      // constant of the piece and the chunk's channel offset is the instruction's scalar offset: no vector-ALU work at all
       typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-      const u32x4 raw = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, v ? (unsigned)off << 2 : 0x80000000u, 0, 0));
+      u32x4 raw;
+      if constexpr (KD == 1) raw = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, pboff[j], cc * 32, 0));
+      else raw = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, v ? (unsigned)off << 2 : 0x80000000u, 0, 0));
       rp[j] = __builtin_bit_cast(f32x4, raw);
     } else {
       rp[j] = ldg4(p.in, v ? off : 0);
@@ -182,8 +208,9 @@ __global__ void __launch_bounds__(128 * NWN, 1) wino_conv3x3_kernel(const WinoAr
         v = v * sc + sh;
         if (p.in_relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
       }
-      if constexpr (MODE == 0) *reinterpret_cast<f32x4*>(lds + (live[j] ? st * WSTAGE + lsto[j] : 2 * WSTAGE + 4 * tid)) = v;
-      else *reinterpret_cast<f32x4*>(lds + (live[j] ? st * WSTAGE + lsto[j] : 2 * WSTAGE + 4 * tid)) = rv[j] ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4* dst = reinterpret_cast<f32x4*>(__builtin_assume_aligned(lds + st * WSTAGE + lsto[j], 16));
+      if constexpr (MODE == 0) *dst = v;
+      else *dst = rv[j] ? v : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
   auto store_raw = [&](int st, int chunk) {
@@ -252,85 +279,75 @@ __global__ void __launch_bounds__(128 * NWN, 1) wino_conv3x3_kernel(const WinoAr
 #pragma unroll
   for (int j = 0; j < 4; ++j) { vD[j] = f32x4{0.f, 0.f, 0.f, 0.f}; uD[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-  // One step of the input transform V = B^T d B of (a,b) group `grp` (row combination a = grp of the raw rows, then the four column
-  // combinations): 16 steps of two floats each, so that a step fits into one MFMA gap.  Steps 0-7 fill rw, steps 8-15 the fragments.
-  auto xstep = [&](int grp, int h, const f32x4 (&dd)[4][4], f32x4 (&rw)[4], f32x4 (&vv)[4]) {
-    const int j = (h & 7) >> 1, o = 2 * (h & 1);
-    if (h < 8) {
-      if (WABL(3)) { rw[j][o] = dd[grp][j][o]; rw[j][o + 1] = dd[grp][j][o + 1]; return; }
+  // Input transform V = B^T d B of (a,b) group `grp` (row combination a = grp of the raw rows, then the four column combinations)
+  // as 16 packed two-float adds.  On this matrix pipe fp32 MFMAs and vector-ALU instructions do not overlap (measured,
+  // tools/ubench/mfma_fill.hip: every VALU instruction beside v_mfma_f32_32x32x2_f32 costs its 4 issue cycles, the first one in an
+  // MFMA gap 14; a packed add costs the same as a scalar one; LDS reads, scalar instructions and loads are nearly free): the
+  // kernel therefore keeps the VALU count minimal and in ONE burst per group instead of spreading it over the gaps.
+  auto xform = [&](int grp, const f32x4 (&dd)[4][4], f32x4 (&vv)[4]) {
+    if (WABL(3)) {
 #pragma unroll
-      for (int e = o; e < o + 2; ++e)
-        rw[j][e] = grp == 0 ? dd[0][j][e] - dd[2][j][e] : grp == 1 ? dd[1][j][e] + dd[2][j][e] : grp == 2 ? dd[2][j][e] - dd[1][j][e]
-                                                                                                     : dd[1][j][e] - dd[3][j][e];
-    } else {
-      if (WABL(3)) { vv[j][o] = rw[j][o]; vv[j][o + 1] = rw[j][o + 1]; return; }
-#pragma unroll
-      for (int e = o; e < o + 2; ++e)
-        vv[j][e] = j == 0 ? rw[0][e] - rw[2][e] : j == 1 ? rw[1][e] + rw[2][e] : j == 2 ? rw[2][e] - rw[1][e] : rw[1][e] - rw[3][e];
+      for (int q = 0; q < 4; ++q) vv[q] = dd[grp][q];
+      return;
     }
+    f32x2 rl[4], rh[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 &a = dd[grp == 0 ? 0 : grp == 2 ? 2 : 1][q], &b = dd[grp == 0 ? 2 : grp == 1 ? 2 : grp == 2 ? 1 : 3][q];
+      if (grp == 1) { rl[q] = pk_add(lo2(a), lo2(b)); rh[q] = pk_add(hi2(a), hi2(b)); }
+      else { rl[q] = pk_sub(lo2(a), lo2(b)); rh[q] = pk_sub(hi2(a), hi2(b)); }
+    }
+    vv[0] = cat2(pk_sub(rl[0], rl[2]), pk_sub(rh[0], rh[2]));
+    vv[1] = cat2(pk_add(rl[1], rl[2]), pk_add(rh[1], rh[2]));
+    vv[2] = cat2(pk_sub(rl[2], rl[1]), pk_sub(rh[2], rh[1]));
+    vv[3] = cat2(pk_sub(rl[1], rl[3]), pk_sub(rh[1], rh[3]));
   };
 
   for (int cc = c_first; cc <= c_last; ++cc) {
     const int c = cc - c_first;                   // stage parity counts from the block's first chunk
     const float* S = lds + (c & 1) * WSTAGE;
     const int cn = min(cc + 1, c_last);           // the last chunk re-requests itself into the idle stage: no branches
-    f32x4 d[4][4], ub[3][4], vA[4], vB[4], rw[4];
+    f32x4 d[4][4], ub[3][4], v[4];
     auto rd_d = [&](int i, int j) { if (!WABL(4)) d[i][j] = *reinterpret_cast<const f32x4*>(S + (i < 2 ? abase01 : abase23) + (i * 10 + j) * WRAW_LD); };
     auto rd_u = [&](int g, int j) { if (!WABL(4)) ub[g % 3][j] = *reinterpret_cast<const f32x4*>(S + bbase + (g * 4 + j) * USTRIDE); };
-    // A chunk is 64 MFMAs = 64 gaps of 64 cycles on the SIMD's matrix pipe; a lone wave hides about a dozen single-issue
-    // instructions per gap, but only if they are spread out (a burst between two groups stalls the pipe, and a direct-to-LDS
-    // piece costs 100+ cycles in a gap that already carries loads — MI355X_MICROARCH.md, per-instruction constants).  Every gap
-    // therefore gets its own small share, pinned by a scheduling barrier:
-    //   deferred group (gaps 0-15):  raw global loads of chunk c+1 (longest way to go), the 16 raw-tile reads and the filter
-    //                                fragments of groups 0 and 1, the transform of group 0 in the last four gaps
-    //   group 0 (16-31):             fragments of group 2, transform of group 1, raw pieces of chunk c+1 -> LDS (last gaps)
-    //   group 1 (32-47):             the 8 direct-to-LDS filter pieces of chunk c+1 (every other gap; issued AFTER the raw
-    //                                pieces were consumed, so the compiler's own load counting never waits for them), fragments of
-    //                                group 3, transform of group 2
-    //   group 2 (48-63):             transform of group 3 into the deferred operands
+    // deferred group of chunk c-1 (gaps 0-15): every request of the chunk is issued in its shadow — the direct-to-LDS filter
+    // pieces and the raw loads of chunk c+1 (the pieces first: invisible to the compiler's load counting, they must be OLDER
+    // than the loads it waits for), the 16 raw-tile reads and the filter fragments of groups 0 and 1 of chunk c
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       // consecutive MFMAs go to DIFFERENT accumulators (k & 3): instructions issued between two MFMAs on the same accumulator
       // stretch the dependent pair
       acc[12 + (k & 3)] = __builtin_amdgcn_mfma_f32_32x32x2f32(vD[k & 3][k >> 2], uD[k & 3][k >> 2], acc[12 + (k & 3)], 0, 0, 0);
-      if (!WABL(2) && k < NPR) load_piece(k, cn);
-      // LDS requests, two per gap, in the order of first use: raw rows 0 and 2 (transform of group 0), the filter fragments of group
-      // 0, raw row 1, the fragments of group 1, raw row 3
-      if (k >= 2 && k < 14) {
-        const int u = k - 2, j0 = 2 * (u & 1);
-        if (u < 2) { rd_d(0, j0); rd_d(0, j0 + 1); }
-        else if (u < 4) { rd_d(2, j0); rd_d(2, j0 + 1); }
-        else if (u < 6) { rd_u(0, j0); rd_u(0, j0 + 1); }
-        else if (u < 8) { rd_d(1, j0); rd_d(1, j0 + 1); }
-        else if (u < 10) { rd_u(1, j0); rd_u(1, j0 + 1); }
+      if (!WABL(2)) {
+        if (k < 8) glds(cn, (c & 1) ^ 1, wave * 8 + k);
+        else if (k - 8 < NPR) load_piece(k - 8, cn);
+      }
+      if (k < 12) {                                // LDS requests in the order of first use: rows 0, 2, fragments 0, row 1, fragments 1, row 3
+        const int j0 = 2 * (k & 1);
+        if (k < 2) { rd_d(0, j0); rd_d(0, j0 + 1); }
+        else if (k < 4) { rd_d(2, j0); rd_d(2, j0 + 1); }
+        else if (k < 6) { rd_u(0, j0); rd_u(0, j0 + 1); }
+        else if (k < 8) { rd_d(1, j0); rd_d(1, j0 + 1); }
+        else if (k < 10) { rd_u(1, j0); rd_u(1, j0 + 1); }
         else { rd_d(3, j0); rd_d(3, j0 + 1); }
       }
-      if (k >= 8) { xstep(0, 2 * (k - 8), d, rw, vA); xstep(0, 2 * (k - 8) + 1, d, rw, vA); }
       __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
-    for (int m = 0; m < 16; ++m) {                 // group 0 on vA; prepares vB (group 1)
-      acc[m & 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(vA[m & 3][m >> 2], ub[0][m & 3][m >> 2], acc[m & 3], 0, 0, 0);
-      if (m < 2) { rd_u(2, 2 * m); rd_u(2, 2 * m + 1); }
-      xstep(1, m, d, rw, vB);
-      if (!WABL(2) && m >= 16 - NPR) store_piece(m - (16 - NPR), (c & 1) ^ 1, cn);
+    for (int i = 0; i < 3; ++i) {
+      xform(i, d, v);                              // one VALU burst, then 16 MFMAs with the remaining requests in their gaps
+      if (i == 2 && !WABL(2)) store_raw((c & 1) ^ 1, cn);      // raw pieces of chunk c+1 -> LDS: requested ~40 gaps ago
       __builtin_amdgcn_sched_barrier(0);
-    }
 #pragma unroll
-    for (int m = 0; m < 16; ++m) {                 // group 1 on vB; prepares vA (group 2)
-      acc[4 + (m & 3)] = __builtin_amdgcn_mfma_f32_32x32x2f32(vB[m & 3][m >> 2], ub[1][m & 3][m >> 2], acc[4 + (m & 3)], 0, 0, 0);
-      if (!WABL(2) && !(m & 1)) glds(cn, (c & 1) ^ 1, wave * 8 + (m >> 1));
-      if (m == 1 || m == 3) { rd_u(3, m - 1); rd_u(3, m); }
-      xstep(2, m, d, rw, vA);
-      __builtin_amdgcn_sched_barrier(0);
+      for (int m = 0; m < 16; ++m) {
+        acc[i * 4 + (m & 3)] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[m & 3][m >> 2], ub[i][m & 3][m >> 2], acc[i * 4 + (m & 3)], 0, 0, 0);
+        if (i < 2 && m < 2) { rd_u(i + 2, 2 * m); rd_u(i + 2, 2 * m + 1); }
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
+    xform(3, d, vD);                               // operands of this chunk's deferred group
 #pragma unroll
-    for (int m = 0; m < 16; ++m) {                 // group 2 on vA; prepares the deferred operands (group 3)
-      acc[8 + (m & 3)] = __builtin_amdgcn_mfma_f32_32x32x2f32(vA[m & 3][m >> 2], ub[2][m & 3][m >> 2], acc[8 + (m & 3)], 0, 0, 0);
-      xstep(3, m, d, rw, vD);
-      if (m >= 12) uD[m - 12] = ub[0][m - 12];     // ub[3 % 3] holds the group-3 fragments
-      __builtin_amdgcn_sched_barrier(0);
-    }
+    for (int q = 0; q < 4; ++q) uD[q] = ub[0][q];  // ub[3 % 3] holds the group-3 fragments
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the direct-to-LDS filter tiles of the next chunk have landed
     if (!WABL(1)) __syncthreads();
   }
@@ -457,7 +474,7 @@ __global__ void __launch_bounds__(128 * NWN, 1) wino_conv3x3_kernel(const WinoAr
 template <int MODE, int KD, int NWN>
 int wino_launch_t(WinoArgs& a, long long blocks, hipStream_t stream) {
   constexpr int THREADS = 128 * NWN;
-  const size_t lds_bytes = (2 * (size_t)(WRAW_FLOATS + 16 * 32 * NWN * 8) + 4 * THREADS + (MODE == 0 ? 0 : (MODE == 2 ? 8 : 2) * a.Cin)) * sizeof(float);
+  const size_t lds_bytes = (2 * (size_t)(WRAW_FLOATS + 16 * 32 * NWN * 8 + 4 * THREADS) + (MODE == 0 ? 0 : (MODE == 2 ? 8 : 2) * a.Cin)) * sizeof(float);
   g6d_allow_lds(reinterpret_cast<const void*>(&wino_conv3x3_kernel<MODE, KD, NWN>), 160 * 1024);
   hipLaunchKernelGGL((wino_conv3x3_kernel<MODE, KD, NWN>), dim3((unsigned)blocks, a.Cout / (32 * NWN), a.splits), dim3(THREADS), lds_bytes,
                      stream, a);

@@ -7,6 +7,6 @@ make -s
 mkdir -p _abl
 OTHERS=$(ls *.o | grep -v wino_conv.o)
 for a in ${ABL:-1 2 3 4 5}; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -DWINO_ABLATE=$a -c wino_conv.hip -o _abl/wino_$a.o
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -fno-slp-vectorize -DWINO_ABLATE=$a -c wino_conv.hip -o _abl/wino_$a.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OTHERS _abl/wino_$a.o -o _abl/libgen6d_w$a.so
 done
