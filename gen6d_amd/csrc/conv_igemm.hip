@@ -403,6 +403,10 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const G6dConv p, con
       atomicAdd(st + 1, (double)sred[tid * 2 + 1]);
     }
   }
+  if (do_stats && p.fin_scale) {
+    __syncthreads();                                     // sred (= lds) is no longer read
+    g6d_finalize_stats(g6d_fin_of(p), gridDim.x * gridDim.y, reinterpret_cast<int*>(lds));
+  }
 }
 
 template <int BM, int BN, int WGM, int WGN, int MODE, int MM>
@@ -459,6 +463,9 @@ extern "C" int g6d_conv_igemm(const G6dConv* desc, g6d_stream_t stream_) {
     g6d_set_error("conv: operand pointers must be 16-byte aligned"); return G6D_EINVAL;
   }
   if (d.mul && !d.in_scale) { g6d_set_error("conv: mul requires in_scale/in_shift"); return G6D_EINVAL; }
+  if (d.fin_scale && (!d.stats || !d.fin_shift || !d.fin_counter || d.fin_count <= 0 || d.fin_groups <= 0)) {
+    g6d_set_error("conv: fin_scale needs stats, fin_shift, fin_counter, fin_count > 0 and fin_groups"); return G6D_EINVAL;
+  }
   if ((long long)d.N * d.Di * d.Hi * d.Wi * d.ld_in >= (1ll << 30) || (long long)d.Cout * d.kd * d.kh * d.kw * d.Cin >= (1ll << 30)) {
     g6d_set_error("conv: tensor exceeds 2^30 elements (32-bit byte offsets)"); return G6D_EINVAL;
   }

@@ -328,6 +328,10 @@ __global__ void __launch_bounds__(256) conv_patch_kernel(const G6dConv p, const 
       atomicAdd(st, (double)sred[tid * 2]);
       atomicAdd(st + 1, (double)sred[tid * 2 + 1]);
     }
+    if (p.fin_scale) {
+      __syncthreads();
+      g6d_finalize_stats(g6d_fin_of(p), gridDim.x * gridDim.y, reinterpret_cast<int*>(lds));
+    }
   }
 }
 

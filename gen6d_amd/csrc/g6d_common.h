@@ -83,6 +83,36 @@ __device__ __forceinline__ bool g6d_split_arrive(int* counter, int splits, int* 
   return *flag != 0;
 }
 
+// InstanceNorm finalisation by the last block of a statistics-producing launch (G6dConv.fin_*): every block that has
+// issued its (sum, sumsq) atomics drains them and takes a ticket; the block that draws the last one reads the completed
+// table with agent-scope loads and writes the affine of the following InstanceNorm.  `nblocks` = blocks that run the
+// epilogue (tiles; of a split launch only the tile finishers); `flag` = one free word of the kernel's LDS array.
+struct G6dFin { float* scale; float* shift; int* counter; const double* stats; double inv_count, eps; int n; };
+__device__ __forceinline__ void g6d_finalize_stats(const G6dFin& f, int nblocks, int* flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's atomics have been acknowledged
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int last = __hip_atomic_fetch_add(f.counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nblocks - 1;
+    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    *flag = last;
+  }
+  __syncthreads();
+  if (*flag == 0) return;
+  for (int i = threadIdx.x; i < f.n; i += blockDim.x) {
+    const double s1 = __hip_atomic_load(f.stats + 2 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double s2 = __hip_atomic_load(f.stats + 2 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double mean = s1 * f.inv_count;
+    double var = s2 * f.inv_count - mean * mean;
+    if (var < 0) var = 0;
+    const double rs = 1.0 / sqrt(var + f.eps);
+    f.scale[i] = (float)rs;
+    f.shift[i] = (float)(-mean * rs);
+  }
+}
+__device__ __forceinline__ G6dFin g6d_fin_of(const G6dConv& d) {
+  return G6dFin{d.fin_scale, d.fin_shift, reinterpret_cast<int*>(d.fin_counter), d.stats, 1.0 / d.fin_count, d.fin_eps, d.fin_groups * d.Cout};
+}
+
 __device__ __forceinline__ float apply_act(float v, int act) {
   if (act == 1) return fmaxf(v, 0.f);
   if (act == 2) return v > 0.f ? v : 0.1f * v;

@@ -80,6 +80,7 @@ struct WinoArgs {
   int D;                                         // depth slices per image (1 for 2-D layers); KD = 3 pads in depth
   const float* mul; const float* in_scale; const float* in_shift; int in_relu;
   double* stats; int stats_per_image;            // [groups][Cout][2]; groups = images (N / D) or 1
+  G6dFin fin;                                    // fin.scale != NULL: the last block finalises the statistics
 };
 
 __device__ __forceinline__ f32x4 ldg4(const float* __restrict__ base, int elem_off) {
@@ -467,6 +468,10 @@ __global__ void __launch_bounds__(128 * NWN, 1) wino_conv3x3_kernel(const WinoAr
         atomicAdd(st, a1); atomicAdd(st + 1, a2);
       }
     }
+    if (p.fin.scale) {                          // InstanceNorm finalisation by the launch's last block (G6dConv.fin_*)
+      __syncthreads();
+      g6d_finalize_stats(p.fin, gridDim.x * gridDim.y, reinterpret_cast<int*>(lds));
+    }
   }
 }
 
@@ -647,6 +652,8 @@ int g6d_wino_launch(const G6dConv& d, hipStream_t stream) {
   a.ld_pool = 0; a.relu = d.out_act == 1;
   a.mul = d.mul; a.in_scale = d.in_scale; a.in_shift = d.in_shift; a.in_relu = d.in_relu;
   a.stats = d.stats; a.stats_per_image = d.stat_rows_per_group > 0;
+  if (d.fin_scale)
+    a.fin = G6dFin{d.fin_scale, d.fin_shift, reinterpret_cast<int*>(d.fin_counter), d.stats, 1.0 / d.fin_count, d.fin_eps, d.fin_groups * d.Cout};
   const int mode = d.mul ? 3 : (!d.in_scale ? 0 : (d.in_affine_per_n ? 2 : 1));
   return wino_run(a, mode, d.kd, d.workspace, d.workspace_bytes, stream);
 }

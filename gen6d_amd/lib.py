@@ -28,6 +28,8 @@ class G6dConv(C.Structure):
         ("in_relu", C.c_int32), ("in_affine_per_n", C.c_int32), ("out_act", C.c_int32),
         ("stat_rows_per_group", C.c_int32), ("split_k", C.c_int32), ("math_mode", C.c_int32),
         ("weight_wino", C.c_void_p),
+        ("fin_scale", C.c_void_p), ("fin_shift", C.c_void_p), ("fin_counter", C.c_void_p),
+        ("fin_count", C.c_double), ("fin_eps", C.c_double), ("fin_groups", C.c_int32), ("reserved_", C.c_int32),
     ]
 
 

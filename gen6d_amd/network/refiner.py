@@ -77,13 +77,11 @@ class VolumeRefiner(ParamBank):
             _, _, hh, ww, _ = x.shape
             y0 = torch.empty((n, 1, hh, ww, w0.shape[0]), dtype=torch.float32, device=dev)
             s0 = ops.new_stats(n, w0.shape[0], dev)
-            ops.conv(x, w0, b0, y0, ksize=_K2, pad=_P2, stats=s0, rows_per_group=hh * ww, w_wino=u0)
-            sc0, sh0 = ops.stats_finalize(s0, hh * ww)
+            sc0, sh0 = ops.conv(x, w0, b0, y0, ksize=_K2, pad=_P2, stats=s0, rows_per_group=hh * ww, w_wino=u0, finalize=hh * ww)
             y1 = torch.empty((n, 1, hh, ww, w1.shape[0]), dtype=torch.float32, device=dev)
             s1 = ops.new_stats(n, w1.shape[0], dev)
-            ops.conv(y0, w1, b1, y1, ksize=_K2, pad=_P2, in_scale=sc0, in_shift=sh0, in_relu=True, per_n=True,
-                     stats=s1, rows_per_group=hh * ww, w_wino=u1)
-            sc1, sh1 = ops.stats_finalize(s1, hh * ww)
+            sc1, sh1 = ops.conv(y0, w1, b1, y1, ksize=_K2, pad=_P2, in_scale=sc0, in_shift=sh0, in_relu=True, per_n=True,
+                                stats=s1, rows_per_group=hh * ww, w_wino=u1, finalize=hh * ww)
             return y1, sc1, sh1
 
         hq, wq = h // 4, w // 4
@@ -113,12 +111,13 @@ class VolumeRefiner(ParamBank):
         dev = mean_in.device
         vox = sn ** 3
 
-        def c3(x, wb, out, stride=1, aff=None, stats_c=None):
+        def c3(x, wb, out, stride=1, aff=None, stats_c=None, count=None):
+            """3x3x3 conv; with stats_c: returns the affine (scale, shift) of the InstanceNorm that follows (count values)."""
             st = ops.new_stats(1, stats_c, dev) if stats_c else None
             sc, sh = aff if aff is not None else (None, None)
-            ops.conv(x, wb[0], wb[1], out, ksize=_K3, stride=(stride,) * 3, pad=_P3, in_scale=sc, in_shift=sh,
-                     in_relu=aff is not None, stats=st, w_wino=getattr(wb, "u", None) if stride == 1 else None)
-            return st
+            return ops.conv(x, wb[0], wb[1], out, ksize=_K3, stride=(stride,) * 3, pad=_P3, in_scale=sc, in_shift=sh,
+                            in_relu=aff is not None, stats=st, w_wino=getattr(wb, "u", None) if stride == 1 else None,
+                            finalize=count if stats_c else None)
 
         def buf(s, c):
             return torch.empty((1, s, s, s, c), dtype=torch.float32, device=dev)
@@ -126,8 +125,8 @@ class VolumeRefiner(ParamBank):
         cat = buf(sn, 128)
         def embed(name, x, sl):
             y = buf(sn, 64)
-            st = c3(x, pk[name][0], y, stats_c=64)
-            c3(y, pk[name][1], cat[..., sl], aff=ops.stats_finalize(st, vox))
+            aff = c3(x, pk[name][0], y, stats_c=64, count=vox)
+            c3(y, pk[name][1], cat[..., sl], aff=aff)
 
         embed("v_mean_embed", mean_in.view(1, sn, sn, sn, 256), slice(0, 64))
         embed("v_var_embed", std.view(1, sn, sn, sn, 128), slice(64, 128))
@@ -136,13 +135,12 @@ class VolumeRefiner(ParamBank):
                                  ("v_conv4", 256, 1)):
             s = s // stride
             y = buf(s, co)
-            st = c3(x, pk[name], y, stride=stride, aff=aff, stats_c=co)
-            x, aff = y, ops.stats_finalize(st, s ** 3)
+            x, aff = y, c3(x, pk[name], y, stride=stride, aff=aff, stats_c=co, count=s ** 3)
         s = s // 2
         y = buf(s, 512)
-        st = c3(x, pk["v_conv5"][0], y, stride=2, aff=aff, stats_c=512)
+        aff = c3(x, pk["v_conv5"][0], y, stride=2, aff=aff, stats_c=512, count=s ** 3)
         code = buf(s, 512)
-        c3(y, pk["v_conv5"][1], code, aff=ops.stats_finalize(st, s ** 3))
+        c3(y, pk["v_conv5"][1], code, aff=aff)
         return code.view(s ** 3, 512)
 
     def run_regressor(self, code):

@@ -163,13 +163,18 @@ class ViewpointSelector(ParamBank):
             last = li == len(layers) - 1
             out = cat[..., 256 * l:256 * l + 256] if last else torch.empty((D, 1, h, w, co), dtype=torch.float32, device=dev)
             stats = ops.new_stats(1, co, dev) if has_in else None
-            ops.conv(x, wgt, bias, out, ksize=_K133, pad=_P011, mul=mul, in_scale=scale, in_shift=shift, in_relu=relu, stats=stats,
-                     w_wino=wu)
+            # InstanceNorm finalisation inside the producing launch, unless the statistics still have to be summed over ranks
+            fin = Dg * h * w if (has_in and not last and self.world == 1) else None
+            res = ops.conv(x, wgt, bias, out, ksize=_K133, pad=_P011, mul=mul, in_scale=scale, in_shift=shift, in_relu=relu, stats=stats,
+                           w_wino=wu, finalize=fin)
             mul = None
             if last:
                 break
-            self._allreduce([stats])
-            scale, shift = ops.stats_finalize(stats, Dg * h * w)
+            if fin is not None:
+                scale, shift = res
+            else:
+                self._allreduce([stats])
+                scale, shift = ops.stats_finalize(stats, Dg * h * w)
             if has_pool:
                 h, w = h // 2, w // 2
                 pooled = torch.empty((D, 1, h, w, co), dtype=torch.float32, device=dev)
@@ -200,9 +205,12 @@ class ViewpointSelector(ParamBank):
         # corr_feats_conv: 1x1x1 768->512, IN3d, ReLU, (AvgPool commuted) 512->512   selector.py:71-77,197-200
         y = torch.empty((D, 1, 4, 4, 512), dtype=torch.float32, device=dev)
         st = ops.new_stats(1, 512, dev)
-        ops.conv(cat, pk["fuse0"][0], pk["fuse0"][1], y, stats=st)
-        self._allreduce([st])
-        sc, sh = ops.stats_finalize(st, Dg * 16)
+        if self.world == 1:
+            sc, sh = ops.conv(cat, pk["fuse0"][0], pk["fuse0"][1], y, stats=st, finalize=Dg * 16)
+        else:
+            ops.conv(cat, pk["fuse0"][0], pk["fuse0"][1], y, stats=st)
+            self._allreduce([st])
+            sc, sh = ops.stats_finalize(st, Dg * 16)
         pooled = torch.empty((D, 1, 1, 1, 512), dtype=torch.float32, device=dev)
         ops.affine_act_pool(y, pooled, sc, sh, relu=True, pool=2)
         feats = torch.zeros((D, FEAT_LD), dtype=torch.float32, device=dev)
@@ -241,12 +249,11 @@ class ViewpointSelector(ParamBank):
             ops.layernorm(mrg, a["ln"][0], a["ln"][1], xm[:, 512:])
             y0 = torch.empty((rfn, 512), dtype=torch.float32, device=dev)
             s0 = ops.new_stats(1, 512, dev)
-            ops.conv(tok(xm), a["mlp0"][0], a["mlp0"][1], tok(y0), stats=s0)
-            sc0, sh0 = ops.stats_finalize(s0, rfn)
+            sc0, sh0 = ops.conv(tok(xm), a["mlp0"][0], a["mlp0"][1], tok(y0), stats=s0, finalize=rfn)
             y1 = torch.empty((rfn, 512), dtype=torch.float32, device=dev)
             s1 = ops.new_stats(1, 512, dev)
-            ops.conv(tok(y0), a["mlp3"][0], a["mlp3"][1], tok(y1), in_scale=sc0, in_shift=sh0, in_relu=True, stats=s1)
-            sc1, sh1 = ops.stats_finalize(s1, rfn)
+            sc1, sh1 = ops.conv(tok(y0), a["mlp3"][0], a["mlp3"][1], tok(y1), in_scale=sc0, in_shift=sh0, in_relu=True, stats=s1,
+                                finalize=rfn)
             xn = torch.empty((rfn, 1024), dtype=torch.float32, device=dev)
             ops.affine_act_add(y1, xn[:, :512], sc1, sh1, relu=True, residual=xm[:, :512])
             xm = xn

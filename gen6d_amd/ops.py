@@ -133,9 +133,17 @@ def _cl5(t, name):
     return N, D, H, W, Cc, ld
 
 
+# G6D_FUSED_FINALIZE=0: InstanceNorm finalisation as a separate g6d_stats_finalize launch after the producing conv (A/B aid);
+# default: the conv's last block does it (G6dConv.fin_*)
+FUSED_FINALIZE = _os.environ.get("G6D_FUSED_FINALIZE", "1") != "0"
+
+
 def conv(x, w, bias, out, ksize=(1, 1, 1), stride=(1, 1, 1), pad=(0, 0, 0), mul=None, in_scale=None, in_shift=None,
-         in_relu=False, per_n=False, out_act=0, stats=None, rows_per_group=0, split_k=0, w_wino=None):
-    """Implicit-GEMM convolution (g6d_conv_igemm). x [N,Di,Hi,Wi,Cin], w [Cout,taps,Cin], out [N,Do,Ho,Wo,Cout] views."""
+         in_relu=False, per_n=False, out_act=0, stats=None, rows_per_group=0, split_k=0, w_wino=None, finalize=None, eps=1e-5):
+    """Implicit-GEMM convolution (g6d_conv_igemm). x [N,Di,Hi,Wi,Cin], w [Cout,taps,Cin], out [N,Do,Ho,Wo,Cout] views.
+    stats [G,Cout,2] fp64 (zeroed): per-(group, channel) sum / sum of squares of the output are accumulated into it.
+    finalize=count: additionally turn the completed statistics into the affine of the following InstanceNorm (count values
+    per group) inside the same launch and return (scale, shift) [G,Cout] instead of out."""
     _need_gpu(x, w, out)
     N, Di, Hi, Wi, Cin, ld_in = _cl5(x, "conv.x")
     No, Do, Ho, Wo, Cout, ld_out = _cl5(out, "conv.out")
@@ -163,6 +171,16 @@ def conv(x, w, bias, out, ksize=(1, 1, 1), stride=(1, 1, 1), pad=(0, 0, 0), mul=
         in_relu=int(in_relu), in_affine_per_n=int(per_n), out_act=int(out_act),
         stat_rows_per_group=int(rows_per_group), split_k=int(split_k), math_mode=int(MATH_MODE),
         weight_wino=w_wino.data_ptr() if w_wino is not None else None)
+    fin = None
+    if finalize is not None:
+        if stats is None:
+            raise ValueError("conv: finalize needs stats")
+        if FUSED_FINALIZE:
+            G = stats.shape[0]
+            fin = (torch.empty((G, Cout), dtype=torch.float32, device=x.device), torch.empty((G, Cout), dtype=torch.float32, device=x.device))
+            cnt = new_counter(x.device)
+            d.fin_scale, d.fin_shift, d.fin_counter = fin[0].data_ptr(), fin[1].data_ptr(), cnt.data_ptr()
+            d.fin_count, d.fin_eps, d.fin_groups = float(finalize), float(eps), G
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -173,8 +191,10 @@ def conv(x, w, bias, out, ksize=(1, 1, 1), stride=(1, 1, 1), pad=(0, 0, 0), mul=
         PROFILE.append((fl / 2.25 if fam == 2 else fl, e0, e1,            # Winograd kernel: FLOPs executed in the transform domain
                         ("wino3x3 " if fam == 2 else "") + f"conv N={N} in={Di}x{Hi}x{Wi}x{Cin} out={Do}x{Ho}x{Wo}x{Cout} k={kd}x{kh}x{kw} s={stride[0]}{stride[1]}{stride[2]}"
                         f"{' mul' if mul is not None else ''}{' aff' if in_scale is not None else ''}{' stats' if stats is not None else ''}"))
-        return out
-    _lib.check(_lib.load().g6d_conv_igemm(C.byref(d), _stream()), "g6d_conv_igemm")
+    else:
+        _lib.check(_lib.load().g6d_conv_igemm(C.byref(d), _stream()), "g6d_conv_igemm")
+    if finalize is not None:
+        return fin if fin is not None else stats_finalize(stats, finalize, eps)
     return out
 
 
@@ -224,6 +244,16 @@ def new_stats(groups, channels, device):
         return torch.zeros((groups, channels, 2), dtype=torch.float64, device=device)
     t = a[0][a[1]:a[1] + n].view(groups, channels, 2)
     a[1] += n
+    return t
+
+
+def new_counter(device):
+    """One zeroed int32 (an arrival counter of a launch that finalises its statistics): a slot of the query's arena."""
+    a = None if _os.environ.get("G6D_NO_ARENA") else _CUR_ARENA
+    if a is None or a[0].device != torch.device(device) or a[1] + 1 > ARENA_DOUBLES:
+        return torch.zeros((2,), dtype=torch.int32, device=device)
+    t = a[0][a[1]:a[1] + 1].view(torch.int32)
+    a[1] += 1
     return t
 
 

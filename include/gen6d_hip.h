@@ -92,6 +92,17 @@ typedef struct G6dConv {
                                    (stride 1, "same" padding, maps >= 6x6, Cin % 8 == 0, Cout % 32 == 0, fp32), the launch runs on
                                    the Winograd kernel (2.25x fewer multiplications) with the same prologue / epilogue semantics;
                                    otherwise `weight` is used.  NULL = never. */
+  /* Optional InstanceNorm finalisation inside the launch (needs `stats`): the block that finishes last turns the completed
+     (sum, sumsq) table into the affine of the FOLLOWING InstanceNorm — scale = 1/sqrt(var + eps), shift = -mean * scale with
+     mean = sum / fin_count, var = sumsq / fin_count - mean^2 — instead of a separate g6d_stats_finalize launch.
+     fin_scale / fin_shift: [fin_groups][Cout] floats; fin_counter: one int32, ZERO before the launch (left non-zero).
+     NULL fin_scale = off.  Not for statistics that are still to be summed over ranks. */
+  float* fin_scale;
+  float* fin_shift;
+  int32_t* fin_counter;
+  double fin_count, fin_eps;
+  int32_t fin_groups;
+  int32_t reserved_;
 } G6dConv;
 
 int g6d_conv_igemm(const G6dConv* desc, g6d_stream_t stream);

@@ -25,7 +25,7 @@ def _act(v, act):
 
 
 def conv(x, w, bias, out, ksize=(1, 1, 1), stride=(1, 1, 1), pad=(0, 0, 0), mul=None, in_scale=None, in_shift=None,
-         in_relu=False, per_n=False, out_act=0, stats=None, rows_per_group=0, split_k=0, w_wino=None):
+         in_relu=False, per_n=False, out_act=0, stats=None, rows_per_group=0, split_k=0, w_wino=None, finalize=None, eps=1e-5):
     N, Di, Hi, Wi, Cin = x.shape
     Cout = w.shape[0]
     v = x
@@ -44,6 +44,8 @@ def conv(x, w, bias, out, ksize=(1, 1, 1), stride=(1, 1, 1), pad=(0, 0, 0), mul=
         g = y.reshape(M // rpg, rpg, Cout).double()
         stats[:, :, 0] += g.sum(1)
         stats[:, :, 1] += (g * g).sum(1)
+    if finalize is not None:
+        return stats_finalize(stats, finalize, eps)
     return out
 
 

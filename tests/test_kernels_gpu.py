@@ -143,10 +143,12 @@ def _run_conv_case(ops, case, wino):
     outbuf = torch.full((N, Do, Ho, Wo, ld_out), -777.0, device=dev)
     out = outbuf[..., :Cout]
     stats = ops.new_stats(G, Cout, dev) if c.get("stats") else None
-    ops.conv(xv, w.to(dev), bias.to(dev), out, ksize=k, stride=s, pad=p, mul=mul.to(dev) if mul is not None else None,
-             in_scale=sc.to(dev) if sc is not None else None, in_shift=sh.to(dev) if sh is not None else None,
-             in_relu=bool(c.get("relu")), per_n=bool(c.get("per_n")), out_act=c.get("act", 0), stats=stats,
-             rows_per_group=rpg, split_k=c.get("split", 0), w_wino=_wino_u(w, k).to(dev) if wino else None)
+    count = float(rpg if rpg else M)
+    res = ops.conv(xv, w.to(dev), bias.to(dev), out, ksize=k, stride=s, pad=p, mul=mul.to(dev) if mul is not None else None,
+                   in_scale=sc.to(dev) if sc is not None else None, in_shift=sh.to(dev) if sh is not None else None,
+                   in_relu=bool(c.get("relu")), per_n=bool(c.get("per_n")), out_act=c.get("act", 0), stats=stats,
+                   rows_per_group=rpg, split_k=c.get("split", 0), w_wino=_wino_u(w, k).to(dev) if wino else None,
+                   finalize=count if stats is not None else None)          # InstanceNorm affine from the launch's last block
     torch.cuda.synchronize()
     ref = torch.empty((N, Do, Ho, Wo, Cout), dtype=torch.float64)
     rstats = torch.zeros((G, Cout, 2), dtype=torch.float64) if c.get("stats") else None
@@ -159,6 +161,12 @@ def _run_conv_case(ops, case, wino):
     if stats is not None:
         _check(stats[..., 0], rstats[..., 0], 4e-5 if wino else 2e-5, "stats sum")
         _check(stats[..., 1], rstats[..., 1], 4e-5 if wino else 2e-5, "stats sumsq")
+        # the fused finalisation equals the stand-alone kernel on the same table, and the reference formula
+        sc_f, sh_f = res
+        sc_k, sh_k = ops.stats_finalize(stats, count)
+        assert torch.equal(sc_f, sc_k) and torch.equal(sh_f, sh_k), "fused InstanceNorm finalisation differs from g6d_stats_finalize"
+        rsc, rsh = ref_ops.stats_finalize(rstats, count)
+        _check(sc_f, rsc.double(), 1e-4, "finalised scale"); _check(sh_f, rsh.double(), 1e-4, "finalised shift")
 
 
 def _wino_u(w_taps, k):
