@@ -48,7 +48,8 @@ __device__ __forceinline__ f32x4 ldg(const float* __restrict__ base, int elem_of
 template <int BM, int BN, int WGM, int WGN, int MODE, int MM>
 __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const G6dConv p, const int M, const int T,
                                                          const int nChunks, const int itersPerSplit,
-                                                         const int totalIters, const int splits) {
+                                                         const int totalIters, const int splits, const unsigned in_bytes,
+                                                         const unsigned w_bytes, const unsigned mul_bytes) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int WM = BM / WGM, WN = BN / WGN;
   constexpr int MT = WM / 32, NT = WN / 32;
@@ -67,39 +68,52 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const G6dConv p, con
   const int it_end = min(totalIters, it_begin + itersPerSplit);
 
   const int Cin = p.Cin, khw = p.kh * p.kw;
-  const float* __restrict__ gin = p.in;
-  const float* __restrict__ gmul = p.mul;
-  const float* __restrict__ gw = p.weight;
   const float* __restrict__ gsc = p.in_scale;
   const float* __restrict__ gsh = p.in_shift;
   const int relu = p.in_relu;
 
-  // ---- per-thread rows of the activation tile: decode the output position once.  abase is the (possibly virtual,
-  //      i.e. out-of-range) element offset of input voxel (n, iz0, iy0, ix0); every tap adds a uniform offset.
-  int az0[RA], ay0[RA], ax0[RA], abase[RA], mbase[RA], nbase[RA];
+  // ---- per-thread rows of the activation tile: decode the output position once.  On this matrix pipe every vector-ALU
+  //      instruction beside an fp32 MFMA is paid in full (tools/ubench/mfma_fill.hip), so the per-K-step work of the loader is
+  //      reduced to a few bit operations: a row keeps three bitmasks — which kz / ky / kx taps fall inside the input for it —
+  //      and ONE constant byte offset; the tap and channel-chunk offsets are uniform and go into the scalar offset of a
+  //      bounds-checked buffer load; an invalid (padding / masked) row asks for an offset beyond the tensor and the hardware
+  //      returns zeros.  The buffer base sits `pad` elements in front of the tensor so that the row offsets of the first
+  //      output positions (virtual, in the zero padding) are not negative.
+  const int pad_a = ((p.pd * p.Hi + p.ph) * p.Wi + p.pw) * p.ld_in;       // elements between the buffer base and p.in
+  const int pad_m = (p.ph * p.Wi + p.pw) * Cin;
+  unsigned amz[RA], amy[RA], amx[RA], avoff[RA], mvoff[MUL ? RA : 1];
+  int nbase[PER_N ? RA : 1];
 #pragma unroll
   for (int j = 0; j < RA; ++j) {
-    int m = m0 + lrow + 32 * j;
+    const int m = m0 + lrow + 32 * j;
+    amz[j] = amy[j] = amx[j] = 0u; avoff[j] = 0u;
+    if constexpr (MUL) mvoff[j] = 0u;
+    if constexpr (PER_N) nbase[j] = 0;
     if (m < M) {
-      int ow = m % p.Wo; int t1 = m / p.Wo;
-      int oh = t1 % p.Ho; int t2 = t1 / p.Ho;
-      int od = t2 % p.Do; int n = t2 / p.Do;
-      az0[j] = od * p.sd - p.pd; ay0[j] = oh * p.sh - p.ph; ax0[j] = ow * p.sw - p.pw;
-      abase[j] = (((n * p.Di + az0[j]) * p.Hi + ay0[j]) * p.Wi + ax0[j]) * p.ld_in;
-      mbase[j] = (ay0[j] * p.Wi + ax0[j]) * Cin;
-      nbase[j] = n * Cin;
-    } else {
-      az0[j] = -(1 << 28); ay0[j] = 0; ax0[j] = 0; abase[j] = 0; mbase[j] = 0; nbase[j] = 0;   // never valid
+      const int ow = m % p.Wo, t1 = m / p.Wo;
+      const int oh = t1 % p.Ho, t2 = t1 / p.Ho;
+      const int od = t2 % p.Do, n = t2 / p.Do;
+      const int az0 = od * p.sd - p.pd, ay0 = oh * p.sh - p.ph, ax0 = ow * p.sw - p.pw;
+      for (int k = 0; k < p.kd; ++k) amz[j] |= (unsigned)((unsigned)(az0 + k) < (unsigned)p.Di) << k;
+      for (int k = 0; k < p.kh; ++k) amy[j] |= (unsigned)((unsigned)(ay0 + k) < (unsigned)p.Hi) << k;
+      for (int k = 0; k < p.kw; ++k) amx[j] |= (unsigned)((unsigned)(ax0 + k) < (unsigned)p.Wi) << k;
+      avoff[j] = (unsigned)((((n * p.Di + az0) * p.Hi + ay0) * p.Wi + ax0) * p.ld_in + pad_a + 4 * lseg) << 2;
+      if constexpr (MUL) mvoff[j] = (unsigned)((ay0 * p.Wi + ax0) * Cin + pad_m + 4 * lseg) << 2;
+      if constexpr (PER_N) nbase[j] = n * Cin;
     }
   }
-  // ---- per-thread rows of the weight tile
-  int boff[RB]; bool bval[RB];
+  // ---- per-thread rows of the weight tile: constant byte offset, beyond the tensor for rows >= Cout
+  unsigned bvoff[RB];
 #pragma unroll
   for (int j = 0; j < RB; ++j) {
-    int co = n0 + lrow + 32 * j;
-    bval[j] = co < p.Cout;
-    boff[j] = (bval[j] ? co : 0) * T * Cin;
+    const int co = n0 + lrow + 32 * j;
+    bvoff[j] = co < p.Cout ? (unsigned)(co * T * Cin + 4 * lseg) << 2 : 0x80000000u;
   }
+  const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in) - pad_a, 0, in_bytes, 0x00020000);
+  const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.weight), 0, w_bytes, 0x00020000);
+  const auto rs_mul = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(MUL ? p.mul - pad_m : p.in), 0, mul_bytes, 0x00020000);
+  // channels of the last (partial) chunk that exist for this thread: all of them unless Cin % 32 != 0
+  const unsigned thr_last = 4 * lseg < Cin - 32 * (nChunks - 1) ? 0xffffffffu : 0u;
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -112,7 +126,7 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const G6dConv p, con
   // Two register sets: the global loads of K step t+2 are issued during step t and written to LDS during step t+1,
   // which gives every load ~1.6 K steps (>3000 cycles) to land while needing only two LDS stages.
   f32x4 ra[2][RA], rm[2][MUL ? RA : 1], rb[2][RB], rsc[2][PER_N ? RA : 1], rsh[2][PER_N ? RA : 1];
-  bool va[2][RA], vb[2][RB];
+  unsigned va[2][AFF ? RA : 1];            // row validity masks (all ones / zero) of the staged tile, for the zeroing after the affine
 
   // K position of the tile being LOADED = (channel chunk cc, tap = (kz,ky,kx)); taps vary FASTEST so that consecutive
   // K steps read the same channel chunk at positions shifted by one tap: the shifted window is still in L1/L2, whereas a
@@ -129,32 +143,38 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const G6dConv p, con
     tap = w3 ? 0 : tap; cc += w3;
   };
 
-  // All loads are unconditional (clamped to element 0 when masked, also beyond the K range) so that they pipeline;
-  // masking happens when the row is written to LDS.  A branch around a load makes hipcc wait for each one separately.
-  int toff = 0, moff = 0, cch = 0, woff = 0; bool cv = false;
-  auto begin_step = [&](auto S) {                 // uniform per-K-step offsets
+  // All loads are unconditional so that they pipeline (a branch around a load makes hipcc wait for each one separately).
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  auto bload = [&](const auto& rs, unsigned voff, int soff) {
+    return __builtin_bit_cast(f32x4, __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0)));
+  };
+  int toff = 0, moff = 0, cch = 0, woff = 0;      // uniform per-K-step byte offsets (scalar registers)
+  unsigned cm = 0;                                // per-thread mask of the step: 0 beyond the K range / for missing channels
+  bool cv = false;
+  auto begin_step = [&](auto S) {
     constexpr int s = decltype(S)::value;
+    const bool live = lt < it_end;
     cch = cc * BK + 4 * lseg;
-    cv = (cch < Cin) & (lt < it_end);
-    toff = ((kz * p.Hi + ky) * p.Wi + kx) * p.ld_in + cch;
-    moff = (ky * p.Wi + kx) * Cin + cch;
-    woff = tap * Cin + cch;
+    cv = (cch < Cin) & live;
+    cm = live ? (cc == nChunks - 1 ? thr_last : 0xffffffffu) : 0u;
+    toff = live ? (((kz * p.Hi + ky) * p.Wi + kx) * p.ld_in + cc * BK) << 2 : 0;
+    moff = live ? ((ky * p.Wi + kx) * Cin + cc * BK) << 2 : 0;
+    woff = live ? (tap * Cin + cc * BK) << 2 : 0;
     if constexpr (AFF && !PER_N) { rsc[s][0] = ldg(gsc, cv ? cch : 0); rsh[s][0] = ldg(gsh, cv ? cch : 0); }
   };
   auto load_a = [&](auto S, int j) {
     constexpr int s = decltype(S)::value;
-    const bool v = cv & ((unsigned)(az0[j] + kz) < (unsigned)p.Di) & ((unsigned)(ay0[j] + ky) < (unsigned)p.Hi) &
-                   ((unsigned)(ax0[j] + kx) < (unsigned)p.Wi);
-    va[s][j] = v;
-    ra[s][j] = ldg(gin, v ? abase[j] + toff : 0);
-    if constexpr (MUL) rm[s][j] = ldg(gmul, v ? mbase[j] + moff : 0);
+    // all ones if tap (kz, ky, kx) of this row lies inside the input and the step / channel is live
+    const unsigned m = (unsigned)__builtin_amdgcn_sbfe(amz[j], kz, 1) & (unsigned)__builtin_amdgcn_sbfe(amy[j], ky, 1) &
+                       (unsigned)__builtin_amdgcn_sbfe(amx[j], kx, 1) & cm;
+    if constexpr (AFF) va[s][j] = m;
+    ra[s][j] = bload(rs_in, (avoff[j] & m) | (~m & 0x80000000u), toff);
+    if constexpr (MUL) rm[s][j] = bload(rs_mul, (mvoff[j] & m) | (~m & 0x80000000u), moff);
     if constexpr (PER_N) { rsc[s][j] = ldg(gsc, cv ? nbase[j] + cch : 0); rsh[s][j] = ldg(gsh, cv ? nbase[j] + cch : 0); }
   };
   auto load_b = [&](auto S, int j) {
     constexpr int s = decltype(S)::value;
-    const bool v = bval[j] & cv;
-    vb[s][j] = v;
-    rb[s][j] = ldg(gw, v ? boff[j] + woff : 0);
+    rb[s][j] = bload(rs_w, bvoff[j], woff);      // channels beyond Cin meet zero activations; rows beyond Cout are out of range
   };
   auto store_a = [&](auto S, float* As, int j) {
     constexpr int s = decltype(S)::value;
@@ -162,14 +182,19 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const G6dConv p, con
     if constexpr (MUL) v *= rm[s][j];
     if constexpr (AFF) {
       v = v * rsc[s][PER_N ? j : 0] + rsh[s][PER_N ? j : 0];
-      if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+      if (relu) {         // ONE v_max per value (fmaxf() costs a second, canonicalising v_max)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) asm("v_max_f32 %0, 0, %1" : "=v"(v[e]) : "v"(v[e]));
+      }
+      u32x4 b = __builtin_bit_cast(u32x4, v);       // zero padding stays exactly zero: it follows the norm in the reference
+      b &= va[s][j];
+      v = __builtin_bit_cast(f32x4, b);
     }
-    v = va[s][j] ? v : f32x4{0.f, 0.f, 0.f, 0.f};
     *reinterpret_cast<f32x4*>(As + (lrow + 32 * j) * LDS_K + 4 * lseg) = v;
   };
   auto store_b = [&](auto S, float* Bs, int j) {
     constexpr int s = decltype(S)::value;
-    *reinterpret_cast<f32x4*>(Bs + (lrow + 32 * j) * LDS_K + 4 * lseg) = vb[s][j] ? rb[s][j] : f32x4{0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<f32x4*>(Bs + (lrow + 32 * j) * LDS_K + 4 * lseg) = rb[s][j];
   };
 
   f32x4 dummy = {0.f, 0.f, 0.f, 0.f};   // G6D_ABLATE == 6 only
@@ -417,8 +442,13 @@ int launch_mm(const G6dConv& d, int M, int T, int nChunks, int splits, hipStream
   dim3 grid((M + BM - 1) / BM, (d.Cout + BN - 1) / BN, splits);
   const size_t lds_bytes = 2 * (size_t)(BM + BN) * LDS_K * sizeof(float);
   g6d_allow_lds(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WGM, WGN, MODE, MM>), (int)lds_bytes);
+  // extents of the buffer-load descriptors (the activation and multiplier descriptors start `pad` elements in front of the tensor)
+  const long long pad_a = ((long long)(d.pd * d.Hi + d.ph) * d.Wi + d.pw) * d.ld_in, pad_m = (long long)(d.ph * d.Wi + d.pw) * d.Cin;
+  const unsigned in_bytes = (unsigned)(((long long)d.N * d.Di * d.Hi * d.Wi * d.ld_in + pad_a) * 4);
+  const unsigned w_bytes = (unsigned)((long long)d.Cout * T * d.Cin * 4);
+  const unsigned mul_bytes = (unsigned)(((long long)d.Hi * d.Wi * d.Cin + pad_m) * 4);
   hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, MODE, MM>), grid, dim3(256), lds_bytes, stream, d, M, T, nChunks,
-                     ips, total, splits);
+                     ips, total, splits, in_bytes, w_bytes, mul_bytes);
   return g6d_check_launch("conv_igemm");
 }
 
@@ -466,8 +496,9 @@ extern "C" int g6d_conv_igemm(const G6dConv* desc, g6d_stream_t stream_) {
   if (d.fin_scale && (!d.stats || !d.fin_shift || !d.fin_counter || d.fin_count <= 0 || d.fin_groups <= 0)) {
     g6d_set_error("conv: fin_scale needs stats, fin_shift, fin_counter, fin_count > 0 and fin_groups"); return G6D_EINVAL;
   }
-  if ((long long)d.N * d.Di * d.Hi * d.Wi * d.ld_in >= (1ll << 30) || (long long)d.Cout * d.kd * d.kh * d.kw * d.Cin >= (1ll << 30)) {
-    g6d_set_error("conv: tensor exceeds 2^30 elements (32-bit byte offsets)"); return G6D_EINVAL;
+  if ((long long)d.N * d.Di * d.Hi * d.Wi * d.ld_in + ((long long)(d.pd * d.Hi + d.ph) * d.Wi + d.pw) * d.ld_in >= (1ll << 29) ||
+      (long long)d.Cout * d.kd * d.kh * d.kw * d.Cin >= (1ll << 29) || d.kd > 32 || d.kh > 32 || d.kw > 32) {
+    g6d_set_error("conv: tensor exceeds 2^31 bytes (buffer-load offsets) or kernel extent > 32"); return G6D_EINVAL;
   }
   const long long Mll = (long long)d.N * d.Do * d.Ho * d.Wo;
   if (Mll > (1ll << 30)) { g6d_set_error("conv: M too large"); return G6D_EINVAL; }
