@@ -25,13 +25,28 @@ __device__ __forceinline__ f32x4 ldg4(const float* __restrict__ base, int elem_o
   return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + ((unsigned)elem_off << 2));
 }
 
+// One map of a launch.  A launch may cover up to CORR_MAX_SEG maps (the scales of the detector's image pyramid are correlated with
+// the same reference filters): their tiles form ONE flat list, so the launch fills the chip with fewer splits than four separate
+// launches.  Offsets in floats from the launch's common base pointers.
+#define CORR_MAX_SEG 4
+struct CorrSeg { int tile0, H, W, tiles_x, in_off, out_off, ld_in, ld_out; };
+struct CorrArgs { int nseg; CorrSeg seg[CORR_MAX_SEG]; };
+
 template <int MM>     // 0 = fp32 MFMA; 1 / 2 = bf16 / fp16 operands (two 8-channel groups per v_mfma_f32_32x32x16_*)
-__global__ void __launch_bounds__(512) corr_patch_kernel(const float* __restrict__ in, const float* __restrict__ wgt,
-                                                         float* __restrict__ out, int H, int W, int Cin, int ld_in,
-                                                         int Cout, int kh, int kw, int ph, int pw, int ld_out,
-                                                         int units_per_split, int total_units, int splits, int tiles_x,
+__global__ void __launch_bounds__(512) corr_patch_kernel(const float* __restrict__ in_base, const float* __restrict__ wgt,
+                                                         float* __restrict__ out_base, const CorrArgs sa, int Cin,
+                                                         int Cout, int kh, int kw, int ph, int pw,
+                                                         int units_per_split, int total_units, int splits,
                                                          float* __restrict__ ws) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  int sidx = 0;
+#pragma unroll
+  for (int k = 1; k < CORR_MAX_SEG; ++k) sidx = (k < sa.nseg && (int)blockIdx.x >= sa.seg[k].tile0) ? k : sidx;
+  const CorrSeg& sg = sa.seg[sidx];
+  const int H = sg.H, W = sg.W, tiles_x = sg.tiles_x, ld_in = sg.ld_in, ld_out = sg.ld_out;
+  const float* __restrict__ in = in_base + sg.in_off;
+  float* __restrict__ out = out_base + sg.out_off;
+  const int tile = blockIdx.x - sg.tile0;
   const int PW = TW + kw - 1;                       // patch width in positions
   const int patch_floats = TH * PW * LDS_K;
   // one patch buffer: the next unit's patch waits in registers during the kw taps and is written between two barriers
@@ -43,7 +58,7 @@ __global__ void __launch_bounds__(512) corr_patch_kernel(const float* __restrict
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
-  const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
+  const int ty0 = (tile / tiles_x) * TH, tx0 = (tile % tiles_x) * TW;
   const int u_begin = blockIdx.z * units_per_split, u_end = min(total_units, u_begin + units_per_split);
   const int T = kh * kw;
 
@@ -212,19 +227,17 @@ __global__ void __launch_bounds__(512) corr_patch_kernel(const float* __restrict
 
 }  // namespace
 
-// Stride-1 2-D cross-correlation without bias for Cout <= 32 (the detector's reference-as-filter correlation).
-//   in  [H][W][ld_in] channels-last, wgt [Cout][kh*kw][Cin], out [H*W][ld_out]; zero padding (ph, pw) with
-//   H_out = H, W_out = W (i.e. 2*ph = kh-1, 2*pw = kw-1).  workspace: split-K partials.
-extern "C" int g6d_corr2d_patch(const float* in, int H, int W, int Cin, int ld_in, const float* wgt, int Cout, int kh,
-                                int kw, float* out, int ld_out, float* workspace, size_t workspace_bytes, int math_mode,
-                                g6d_stream_t stream_) {
-  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-  if (!in || !wgt || !out || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 3) || (ld_in & 3) || ld_in < Cin || Cout <= 0 ||
-      Cout > 32 || ld_out < Cout || !(kh & 1) || !(kw & 1) || kw > 31 || !g6d_aligned16(in) || !g6d_aligned16(wgt) ||
-      (long long)H * W * ld_in >= (1ll << 30) || (long long)Cout * kh * kw * Cin >= (1ll << 30)) {
-    g6d_set_error("corr2d_patch: bad args (Cout <= 32, odd kernel <= 31, Cin % 4 == 0)"); return G6D_EINVAL;
+namespace {
+
+int corr_run(const float* in_base, float* out_base, CorrArgs& sa, int Cin, const float* wgt, int Cout, int kh, int kw, float* workspace,
+             size_t workspace_bytes, int math_mode, hipStream_t stream) {
+  int tiles = 0;
+  for (int k = 0; k < sa.nseg; ++k) {
+    CorrSeg& g = sa.seg[k];
+    g.tiles_x = (g.W + TW - 1) / TW;
+    g.tile0 = tiles;
+    tiles += g.tiles_x * ((g.H + TH - 1) / TH);
   }
-  const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH, tiles = tiles_x * tiles_y;
   const int total_units = ((Cin + 31) / 32) * kh;
   // split the (chunk, ky) units so that the grid fills whole rounds of the chip (256 CUs x 2 resident blocks):
   // pick the split count with the best last-round utilisation, preferring fewer splits on ties
@@ -252,11 +265,61 @@ extern "C" int g6d_corr2d_patch(const float* in, int H, int W, int Cin, int ld_i
   auto go = [&](auto V) {
     constexpr int MM = decltype(V)::value;
     g6d_allow_lds(reinterpret_cast<const void*>(&corr_patch_kernel<MM>), 160 * 1024);      // the patch size depends on kw
-    hipLaunchKernelGGL(corr_patch_kernel<MM>, dim3(tiles, 1, splits), dim3(512), lds_bytes, stream, in, wgt, out, H, W, Cin,
-                       ld_in, Cout, kh, kw, kh / 2, kw / 2, ld_out, ups, total_units, splits, tiles_x, workspace);
+    hipLaunchKernelGGL(corr_patch_kernel<MM>, dim3(tiles, 1, splits), dim3(512), lds_bytes, stream, in_base, wgt, out_base, sa, Cin,
+                       Cout, kh, kw, kh / 2, kw / 2, ups, total_units, splits, workspace);
   };
   if (math_mode == 1) go(std::integral_constant<int, 1>{});
   else if (math_mode == 2) go(std::integral_constant<int, 2>{});
   else go(std::integral_constant<int, 0>{});
   return g6d_check_launch("corr2d_patch");
+}
+
+}  // namespace
+
+// Stride-1 2-D cross-correlation without bias for Cout <= 32 (the detector's reference-as-filter correlation).
+//   in  [H][W][ld_in] channels-last, wgt [Cout][kh*kw][Cin], out [H*W][ld_out]; zero padding (ph, pw) with
+//   H_out = H, W_out = W (i.e. 2*ph = kh-1, 2*pw = kw-1).  workspace: split scratch (include/gen6d_hip.h, "Workspace").
+extern "C" int g6d_corr2d_patch(const float* in, int H, int W, int Cin, int ld_in, const float* wgt, int Cout, int kh,
+                                int kw, float* out, int ld_out, float* workspace, size_t workspace_bytes, int math_mode,
+                                g6d_stream_t stream_) {
+  if (!in || !wgt || !out || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 3) || (ld_in & 3) || ld_in < Cin || Cout <= 0 ||
+      Cout > 32 || ld_out < Cout || !(kh & 1) || !(kw & 1) || kw > 31 || !g6d_aligned16(in) || !g6d_aligned16(wgt) ||
+      (long long)H * W * ld_in >= (1ll << 30) || (long long)Cout * kh * kw * Cin >= (1ll << 30)) {
+    g6d_set_error("corr2d_patch: bad args (Cout <= 32, odd kernel <= 31, Cin % 4 == 0)"); return G6D_EINVAL;
+  }
+  if (math_mode < 0 || math_mode > 2) { g6d_set_error("corr2d_patch: math_mode must be 0, 1 or 2"); return G6D_EINVAL; }
+  CorrArgs sa = {};
+  sa.nseg = 1;
+  sa.seg[0] = CorrSeg{0, H, W, 0, 0, 0, ld_in, ld_out};
+  return corr_run(in, out, sa, Cin, wgt, Cout, kh, kw, workspace, workspace_bytes, math_mode, reinterpret_cast<hipStream_t>(stream_));
+}
+
+// The same correlation for up to 4 maps in ONE launch (G6dCorrSeg, include/gen6d_hip.h): the scales of the detector's image
+// pyramid against the same reference filters (network/detector.py:236-241 around 222-224).
+extern "C" int g6d_corr2d_patch_multi(const G6dCorrSeg* segs, int nseg, int Cin, const float* wgt, int Cout, int kh, int kw,
+                                      float* workspace, size_t workspace_bytes, int math_mode, g6d_stream_t stream_) {
+  if (!segs || nseg < 1 || nseg > CORR_MAX_SEG || !wgt || Cin <= 0 || (Cin & 3) || Cout <= 0 || Cout > 32 || !(kh & 1) || !(kw & 1) ||
+      kw > 31 || !g6d_aligned16(wgt) || (long long)Cout * kh * kw * Cin >= (1ll << 30) || math_mode < 0 || math_mode > 2) {
+    g6d_set_error("corr2d_patch_multi: bad args (1..4 maps, Cout <= 32, odd kernel <= 31, Cin % 4 == 0)"); return G6D_EINVAL;
+  }
+  const float* in0 = segs[0].in; float* out0 = segs[0].out;
+  for (int k = 0; k < nseg; ++k) {
+    const G6dCorrSeg& g = segs[k];
+    if (!g.in || !g.out || g.H <= 0 || g.W <= 0 || (g.ld_in & 3) || g.ld_in < Cin || g.ld_out < Cout || !g6d_aligned16(g.in)) {
+      g6d_set_error("corr2d_patch_multi: bad map"); return G6D_EINVAL;
+    }
+    if (g.in < in0) in0 = g.in;
+    if (g.out < out0) out0 = g.out;
+  }
+  CorrArgs sa = {};
+  sa.nseg = nseg;
+  for (int k = 0; k < nseg; ++k) {
+    const G6dCorrSeg& g = segs[k];
+    const long long io = g.in - in0, oo = g.out - out0;
+    if (io + (long long)g.H * g.W * g.ld_in >= (1ll << 30) || oo + (long long)g.H * g.W * g.ld_out >= (1ll << 31)) {
+      g6d_set_error("corr2d_patch_multi: maps must lie within 2^30 floats of each other (allocate them from one buffer)"); return G6D_EINVAL;
+    }
+    sa.seg[k] = CorrSeg{0, g.H, g.W, 0, (int)io, (int)oo, g.ld_in, g.ld_out};
+  }
+  return corr_run(in0, out0, sa, Cin, wgt, Cout, kh, kw, workspace, workspace_bytes, math_mode, reinterpret_cast<hipStream_t>(stream_));
 }

@@ -15,6 +15,11 @@ class G6dWinoSeg(C.Structure):
                 ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("ld_in", C.c_int32), ("ld_full", C.c_int32), ("ld_pool", C.c_int32)]
 
 
+class G6dCorrSeg(C.Structure):
+    """include/gen6d_hip.h: one map of g6d_corr2d_patch_multi."""
+    _fields_ = [("in_", C.c_void_p), ("out", C.c_void_p), ("H", C.c_int32), ("W", C.c_int32), ("ld_in", C.c_int32), ("ld_out", C.c_int32)]
+
+
 class G6dConv(C.Structure):
     _fields_ = [
         ("in_", C.c_void_p), ("mul", C.c_void_p), ("in_scale", C.c_void_p), ("in_shift", C.c_void_p),
@@ -41,6 +46,7 @@ SIGNATURES = {
     "g6d_conv_igemm": [C.POINTER(G6dConv), _P],
     "g6d_conv_plan": [C.POINTER(G6dConv)],
     "g6d_corr2d_patch": [_P, _I, _I, _I, _I, _P, _I, _I, _I, _P, _I, _P, C.c_size_t, _I, _P],
+    "g6d_corr2d_patch_multi": [_P, _I, _I, _P, _I, _I, _I, _P, C.c_size_t, _I, _P],
     "g6d_stats_finalize": [_P, _I, _D, _D, _P, _P, _P],
     "g6d_affine_act_pool": [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P],
     "g6d_upsample_bilinear": [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P],

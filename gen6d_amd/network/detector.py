@@ -86,6 +86,31 @@ class Detector(ParamBank):
     def _scores_one_scale(self, que_img, scale_idx, stacked, hs, ws):
         self._scores_from_feats(self.extract_feats(que_img), scale_idx, stacked, hs, ws)
 
+    def _scores_from_pyramid(self, feats, scale_ids, stacked, hs, ws):
+        """All scales at once: the 15x15 and the 7x7 correlation level are ONE launch each over the maps of all scales (the tiles
+        of all maps form one work list: fewer splits, the small maps fill the chip the large one leaves over); the 3x3 level and
+        the assembly stay per scale."""
+        rfn = self.ref_center_feats[0].shape[0]
+        dev = stacked.device
+        maps = [[None] * 3 for _ in feats]
+        for l, (wref, k) in enumerate(zip(self.ref_center_feats, self.ref_ksize)):
+            xs = [f[l] for f in feats]
+            if k >= 7 and rfn <= 32 and len(xs) <= 4:
+                outs = ops.alloc_like_segments([(1, 1, x.shape[2], x.shape[3], rfn) for x in xs], dev)
+                ops.corr2d_patch_multi(xs, wref, outs, k)
+            else:
+                outs = [torch.empty((1, 1, x.shape[2], x.shape[3], rfn), dtype=torch.float32, device=dev) for x in xs]
+                for x, o in zip(xs, outs):
+                    if k >= 7 and rfn <= 32:
+                        ops.corr2d_patch(x, wref, o, k)
+                    else:
+                        ops.conv(x, wref, None, o, ksize=(1, k, k), pad=(0, k // 2, k // 2))
+            for i, o in enumerate(outs):
+                maps[i][l] = o.reshape(o.shape[2] * o.shape[3], rfn)
+        for f, si, m in zip(feats, scale_ids, maps):
+            ops.detector_assemble(m[0], m[1], m[2], f[0].shape[2], f[0].shape[3], self.cfg["vgg_score_stats"],
+                                  float(self.cfg["vgg_score_max"]), hs, ws, si, stacked)
+
     def _scores_from_feats(self, feats, scale_idx, stacked, hs, ws):
         x0, x1, x2 = feats
         rfn = self.ref_center_feats[0].shape[0]
@@ -121,7 +146,7 @@ class Detector(ParamBank):
             # every trunk layer is ONE launch over the whole pyramid (the small scales fill the blocks the large ones leave
             # over); the correlations of the scales then run side by side
             feats = trunk_features_multi(pk["vgg"], [resized(sc) for _, sc in order], ("c5", "c7_pre", "p7"))
-            ops.fork_join([(lambda si=si, f=f: self._scores_from_feats(f, si, stacked, hs, ws)) for (si, _), f in zip(order, feats)], dev)
+            self._scores_from_pyramid(feats, [si for si, _ in order], stacked, hs, ws)
         else:
             ops.fork_join([(lambda si=si, sc=sc: self._scores_one_scale(resized(sc), si, stacked, hs, ws)) for si, sc in order], dev)
         feats = ops.detector_score_mlp_max(stacked, *pk["mlp"])               # [P,64], max over the local references

@@ -218,6 +218,37 @@ def corr2d_patch(x, w, out, k):
     return out
 
 
+def corr2d_patch_multi(xs, w, outs, k):
+    """corr2d_patch for several maps in ONE launch (the scales of the detector's pyramid against the same reference filters):
+    xs[i] [1,1,H_i,W_i,Cin] and outs[i] [1,1,H_i,W_i,Cout] views, each list cut from one buffer (alloc_like_segments)."""
+    _need_gpu(w, *xs, *outs)
+    if not 1 <= len(xs) <= 4 or len(outs) != len(xs):
+        raise ValueError("corr2d_patch_multi: 1..4 maps")
+    Cout, _, Cin = w.shape
+    segs = (_lib.G6dCorrSeg * len(xs))()
+    flops, sizes = 0.0, []
+    for i, (x, o) in enumerate(zip(xs, outs)):
+        N, D, H, W, Cx, ld_in = _cl5(x, "corr2d_multi.x")
+        _, _, Ho, Wo, Co, ld_out = _cl5(o, "corr2d_multi.out")
+        if N * D != 1 or (Ho, Wo) != (H, W) or Cx != Cin or Co != Cout:
+            raise ValueError("corr2d_patch_multi: shape mismatch")
+        segs[i] = _lib.G6dCorrSeg(in_=x.data_ptr(), out=o.data_ptr(), H=H, W=W, ld_in=ld_in, ld_out=ld_out)
+        flops += 2.0 * H * W * Cout * k * k * Cin
+        sizes.append(f"{H}x{W}")
+    if tuple(w.shape) != (Cout, k * k, Cin) or not w.is_contiguous():
+        raise ValueError("corr2d_patch_multi: filter shape mismatch")
+    ws = workspace(w.device)
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.check(_lib.load().g6d_corr2d_patch_multi(segs, len(xs), Cin, _ptr(w), Cout, k, k, _ptr(ws), ws.numel() * 4, int(MATH_MODE),
+                                                 _stream()), "g6d_corr2d_patch_multi")
+    if PROFILE is not None:
+        e1.record()
+        PROFILE.append((flops, e0, e1, f"corr2d_patch multi in={'+'.join(sizes)}x{Cin} out={Cout} k={k}x{k}"))
+    return outs
+
+
 _ARENA = {}          # (device, stream) -> [buffer, bump offset]
 _CUR_ARENA = None    # arena of the query being enqueued (host-side state; set by stats_arena_begin)
 ARENA_DOUBLES = 1 << 17

@@ -118,6 +118,15 @@ int g6d_sizeof_conv_desc(void);
 int g6d_corr2d_patch(const float* in, int H, int W, int Cin, int ld_in, const float* wgt, int Cout, int kh, int kw,
                      float* out, int ld_out, float* workspace, size_t workspace_bytes, int math_mode /* as G6dConv.math_mode */,
                      g6d_stream_t stream);
+/* The same correlation for up to 4 maps in one launch: the scales of the detector's image pyramid against the same reference
+ * filters; the tiles of all maps form one flat work list (fewer splits, one launch).  Buffers within 2^30 floats of each other. */
+typedef struct G6dCorrSeg {
+  const float* in;        /* [H][W][ld_in] */
+  float* out;             /* [H*W][ld_out] */
+  int32_t H, W, ld_in, ld_out;
+} G6dCorrSeg;
+int g6d_corr2d_patch_multi(const G6dCorrSeg* segs, int nseg, int Cin, const float* wgt, int Cout, int kh, int kw,
+                           float* workspace, size_t workspace_bytes, int math_mode, g6d_stream_t stream);
 
 /* InstanceNorm finalisation: stats[g][c] = (sum, sumsq) over `count` elements ->
  * scale = 1/sqrt(var+eps), shift = -mean*scale (biased variance; torch InstanceNorm{1,2,3}d, eps 1e-5,

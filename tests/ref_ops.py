@@ -53,6 +53,12 @@ def corr2d_patch(x, w, out, k):
     return conv(x, w, None, out, ksize=(1, k, k), pad=(0, k // 2, k // 2))
 
 
+def corr2d_patch_multi(xs, w, outs, k):
+    for x, o in zip(xs, outs):
+        corr2d_patch(x, w, o, k)
+    return outs
+
+
 def stats_arena_begin(device):
     pass
 

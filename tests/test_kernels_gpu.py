@@ -480,6 +480,31 @@ def test_wino_conv3x3_channel_slice_input(ops):
     _check(y.permute(0, 3, 1, 2), ref, 3e-5, "wino slice")
 
 
+@pytest.mark.parametrize("k,sizes,Cin,Cout", [(15, [(88, 116), (60, 80), (44, 60), (32, 40)], 512, 32), (7, [(22, 29), (15, 20), (11, 15), (8, 10)], 512, 32),
+                                             (7, [(9, 33), (8, 8)], 100, 5)])
+def test_corr2d_patch_multi(ops, k, sizes, Cin, Cout):
+    """One launch over several maps (flat tile list across maps, common split) equals the per-map launches and the fp64 reference."""
+    g = torch.Generator().manual_seed(600 + k + Cin)
+    w = _rand(g, Cout, k * k, Cin, scale=(1.0 / (k * k * Cin)) ** 0.5)
+    xs_cpu = [_rand(g, 1, 1, h, ww, Cin) for h, ww in sizes]
+    dev = torch.device("cuda")
+    xs = ops.alloc_like_segments([tuple(x.shape) for x in xs_cpu], dev)
+    for d_, x in zip(xs, xs_cpu):
+        d_.copy_(x)
+    outs = ops.alloc_like_segments([(1, 1, h, ww, Cout) for h, ww in sizes], dev)
+    for rep in range(2):                                   # twice: the split counters must be left re-armed
+        for o in outs:
+            o.fill_(-3.0)
+        ops.corr2d_patch_multi(xs, w.cuda(), outs, k)
+        for x, o, xc in zip(xs, outs, xs_cpu):
+            ref = torch.empty(tuple(o.shape), dtype=torch.float64)
+            ref_ops.corr2d_patch(_d(xc), _d(w), ref, k)
+            _check(o, ref, 2e-5, "corr2d multi")
+            single = torch.empty_like(o)
+            ops.corr2d_patch(x, w.cuda(), single, k)
+            assert (o - single).abs().max().item() <= 1e-5 * max(1.0, single.abs().max().item())
+
+
 WINO_MULTI_CASES = [
     # segment sizes (N, H, W), Cin, Cout, relu, full, pool
     ([(1, 44, 58), (1, 30, 40), (1, 22, 30), (1, 16, 20)], 512, 512, False, True, True),     # detector pyramid, 1/16 level, c7_pre + p7
