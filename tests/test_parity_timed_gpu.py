@@ -2,7 +2,7 @@
 
   (a) the headline detector call — 480x640 query vs 32 references — against the reference's own output
       (tests/golden/det_head.npz) and the oracle in fp32 + fp64, arg-max cell bit-exact         detector.py:232-266
-  (b) the timed LAUNCH MODE: TensorPipeline.capture(lanes=3) with 12 queries kept in flight through query_graph;
+  (b) the timed LAUNCH MODE: TensorPipeline.capture(lanes=4) (bench.py's default; 3 as well) with 12 queries kept in flight through query_graph;
       every row equals the eager row and the reference's own rows (tests/golden/pipeline_rows.npz), arg-max exact,
       plus one oracle query end to end
   (c) selector at 128x5 and 64x36 (both measured in the selector sweep) against the reference's own logits
@@ -95,8 +95,9 @@ def _row_err(got, ref):
     return float((d / ref.double().abs().clamp(min=1.0)).max())
 
 
-def test_three_lane_graph_replay_matches_eager_and_reference(golden):
-    """bench.py's launch mode: three captured copies of the query, 12 queries in flight (every (image, lane) pair),
+@pytest.mark.parametrize("lanes", [4, 3])
+def test_lane_graph_replay_matches_eager_and_reference(golden, lanes):
+    """bench.py's launch mode (default: four lanes): captured copies of the query, 12 queries in flight (every (image, lane) pair),
     static buffers reused while other lanes run.  A cross-lane race on shared scratch (split-K workspaces, statistics
     arenas, side streams) would show up as a row that differs from the eager row."""
     from gen6d_amd import ops
@@ -113,7 +114,6 @@ def test_three_lane_graph_replay_matches_eager_and_reference(golden):
     old_serial = ops.SERIAL
     ops.SERIAL = True                                 # bench default: whole queries in flight, no intra-query forks
     try:
-        lanes = 3
         pipe.capture(lanes=lanes)
         busy = [None] * lanes
         outs = []
@@ -141,8 +141,8 @@ def test_three_lane_graph_replay_matches_eager_and_reference(golden):
         assert e <= 1e-4, f"image {j} lane {lane}: graph row differs from the eager row by {e:.2e} (relative)"
         assert int(row[3]) == int(gold[j, 3]), f"image {j} lane {lane}: viewpoint arg-max {int(row[3])} != reference {int(gold[j, 3])}"
         worst_g = max(worst_g, _row_err(row, gold[j]))
-    record("test_three_lane_graph_replay", "graph row vs eager row (max over 24 queries, relative)", worst_e, 1e-4)
-    record("test_three_lane_graph_replay", "graph row vs reference golden rows (relative to max(1,|ref|))", worst_g, 2e-3)
+    record(f"test_lane_graph_replay[{lanes}]", "graph row vs eager row (max over 24 queries, relative)", worst_e, 1e-4)
+    record(f"test_lane_graph_replay[{lanes}]", "graph row vs reference golden rows (relative to max(1,|ref|))", worst_g, 2e-3)
     assert worst_g <= 2e-3, worst_g
     # one query end to end through the oracle as well (same arg-max, same row)
     st = PO.build_state(pipe.state_dicts, pipe.det_refs, pipe.sel_case)
@@ -150,7 +150,7 @@ def test_three_lane_graph_replay_matches_eager_and_reference(golden):
     got = [o for j, lane, o in outs if j == 1][0].cpu()[0]
     assert int(got[3]) == int(row_o[0, 3]) == int(logits_o.argmax(1)[0])
     e = _row_err(got, row_o[0])
-    record("test_three_lane_graph_replay", "graph row vs oracle row (image 1)", e, 2e-3)
+    record(f"test_lane_graph_replay[{lanes}]", "graph row vs oracle row (image 1)", e, 2e-3)
     assert e <= 2e-3
 
 
