@@ -79,7 +79,7 @@ class DeviceChain:
         return {"pose": pose, "det": det5, "sel": sel, "logits": logits[0], "refine_poses": poses, "crop": crop}
 
     # ------------------------------------------------------------------ hipGraph lanes
-    def capture(self, img_shape, lanes=4, warmup=2):
+    def capture(self, img_shape, lanes=3, warmup=2):
         """One captured copy of the whole chain per lane (own static input / output buffers, shared read-only reference state)."""
         d = self.dev
         old_serial, ops.SERIAL = ops.SERIAL, True          # whole queries in flight; no intra-query stream forks (DESIGN.md §5)
@@ -117,7 +117,7 @@ class DeviceChain:
             row = torch.cat([out["pose"].reshape(12), out["det"], out["sel"]])
         return row, stream
 
-    def predict_many(self, que_imgs, que_Ks, lanes=4):
+    def predict_many(self, que_imgs, que_Ks, lanes=3):
         """Queries [(H,W,3) uint8 numpy or device tensors], intrinsics [3,3] -> list of (pose [3,4] float32 numpy, inter dict).
         Several queries are kept in flight (one captured graph per lane); ONE host synchronisation at the end."""
         imgs = [q if torch.is_tensor(q) else torch.from_numpy(np.ascontiguousarray(q)) for q in que_imgs]

@@ -352,7 +352,7 @@ class Gen6DEstimator:
                  "refine_poses": [p.cpu().numpy() for p in out["refine_poses"]]}
         return out["pose"].cpu().numpy().astype(np.float32), inter
 
-    def predict_many(self, que_imgs, que_Ks, lanes=4):
+    def predict_many(self, que_imgs, que_Ks, lanes=3):
         """Several queries in flight at once (one captured hipGraph of the whole chain per lane), one synchronisation at the
         end: [(pose, inter)] in query order (BASELINE configs[4]: batched multi-query stream)."""
         return self.device_chain().predict_many(que_imgs, que_Ks, lanes)

@@ -49,7 +49,7 @@ def compute_metrics(object_pts, diameter, pose_gt_list, pose_pr_list, Ks, scale=
 
 
 # ------------------------------------------------------------------------------------------------ streaming evaluation
-def run_queries(estimator, que_database, que_ids, lanes=4, prefetch=6, decode_threads=4, on_result=None):
+def run_queries(estimator, que_database, que_ids, lanes=3, prefetch=6, decode_threads=4, on_result=None):
     """All queries of `que_ids` through the device chain: returns (poses [q,3,4] float32, seconds, inter list).
     Decode + upload run `prefetch` images ahead in `decode_threads` host threads; `lanes` captured graphs keep that many
     queries in flight; results are read back one lane at a time (one synchronisation per query, at the END of the chain)."""
@@ -138,7 +138,7 @@ def main(argv=None):
     ap.add_argument("--object_name", type=str, default="synthetic/blob")
     ap.add_argument("--symmetric", action="store_true")
     ap.add_argument("--split_type", type=str, default=None)
-    ap.add_argument("--lanes", type=int, default=4)
+    ap.add_argument("--lanes", type=int, default=3)
     ap.add_argument("--prefetch", type=int, default=6)
     ap.add_argument("--max_queries", type=int, default=0)
     args = ap.parse_args(argv)

@@ -7,7 +7,7 @@ unset G6D_PARITY_LOG
 timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err; tail -c 400 gpurun_out/bench_final.json | head -c 300; echo
 timeout 300 python bench.py --gpus 2 --steps 12 --warmup 3 --no-cpu-baseline --lowp "" > gpurun_out/bench_gpus2.json 2> gpurun_out/bench_gpus2.err
 timeout 300 python bench.py --gpus 2 --shard-refs --steps 12 --warmup 3 --no-cpu-baseline --lowp "" > gpurun_out/bench_gpus2_shard.json 2> gpurun_out/bench_gpus2_shard.err
-timeout 600 python bench.py --chained --steps 12 --warmup 3 --no-cpu-baseline --lowp "" > gpurun_out/bench_chained.json 2> gpurun_out/bench_chained.err
+timeout 600 python bench.py --chained --steps 16 --warmup 4 --no-cpu-baseline --lowp "" > gpurun_out/bench_chained.json 2> gpurun_out/bench_chained.err
 python - <<PY
 import json
 for f in ("bench_final", "bench_gpus2", "bench_gpus2_shard", "bench_chained"):
