@@ -300,7 +300,10 @@ def main():
     #      the headline.  Same pipeline, same launch mode, matrix-core operands rounded to bf16 / fp16 in the conv / correlation
     #      kernels (fp32 accumulation, fp32 InstanceNorm statistics, fp32 trunk).
     lowp = {}
-    for mode in [m for m in args.lowp.split(",") if m] if (use_graph and world == 1) else []:
+    modes = [m for m in args.lowp.split(",") if m] if (use_graph and world == 1) else []
+    # the first re-captured pass after the serialised eager roofline pass measures ~15 % low whatever its type (bf16 first: 169 /
+    # fp16 205; fp16 first: fp16 low, bf16 205): one throwaway pass of the first mode precedes the reported ones
+    for pi, mode in enumerate(modes[:1] + modes):
         with ops.math_mode(mode):
             pipe.capture(lanes=lanes)
         lane_busy[:] = [None] * lanes
@@ -323,7 +326,8 @@ def main():
                 "detection_cell_px": float(d[:, 0:2].max()), "max_abs_diff_row": float(d.max()),
                 "max_rel_diff_row": float((d / ref.abs().clamp(min=1.0)).max()),
                 "vs_fp32_path_max_rel": float(((lrows - got_rows[:args.steps]).abs() / got_rows[:args.steps].abs().clamp(min=1.0)).max())}
-        lowp[mode] = entry
+        if pi > 0:
+            lowp[mode] = entry
     if lowp:
         result["lowp"] = lowp
 
