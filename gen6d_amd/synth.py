@@ -89,18 +89,51 @@ def rotated_copies(imgs, an):
     """[rfn,h,w,3] uint8 -> [an,rfn,h,w,3]: in-plane rotations about the image centre (bilinear, zero fill).
 
     Angles follow the reference for an=5 (estimator.py:152: -pi/2..pi/2) and are spread over (-pi,pi] otherwise.
-    """
+    Bit-reproducible on any host by construction (round 3): source coordinates are formed with element-wise float64
+    numpy operations (no BLAS, no vectorised transcendental), quantised to 1/256 pixel, and the four taps are blended in
+    integer arithmetic.  Round 2 went through affine_grid (an sgemm) + grid_sample + round(), whose uint8 results differed
+    between the build container's and the GPU box's CPU - the unexplained 7.7e-4 of r02_parity.md."""
     rfn, h, w, _ = imgs.shape
     angles = np.linspace(-np.pi / 2, np.pi / 2, an) if an == 5 else np.linspace(-np.pi, np.pi, an, endpoint=False)
-    x = torch.from_numpy(imgs).permute(0, 3, 1, 2).float()
-    out = []
-    for a in angles:
-        c, s = math.cos(a), math.sin(a)
-        theta = torch.tensor([[c, -s, 0.0], [s, c, 0.0]]).repeat(rfn, 1, 1)
-        grid = torch.nn.functional.affine_grid(theta, x.shape, align_corners=False)
-        out.append(torch.nn.functional.grid_sample(x, grid, mode="bilinear", padding_mode="zeros", align_corners=False))
-    out = torch.stack(out, 0).round().clamp(0, 255).to(torch.uint8)
-    return out.permute(0, 1, 3, 4, 2).contiguous().numpy()
+    src = np.zeros((rfn, h + 2, w + 2, 3), np.int64)                    # one-pixel zero border = the zero fill
+    src[:, 1:-1, 1:-1] = imgs
+    X = ((2.0 * np.arange(w, dtype=np.float64) + 1.0) / w - 1.0)[None, :]
+    Y = ((2.0 * np.arange(h, dtype=np.float64) + 1.0) / h - 1.0)[:, None]
+    out = np.empty((an, rfn, h, w, 3), np.uint8)
+    for k, a in enumerate(angles):
+        c, s = math.cos(float(a)), math.sin(float(a))
+        px = ((c * X - s * Y + 1.0) * w - 1.0) * 0.5                     # source pixel coordinates (align_corners=False)
+        py = ((s * X + c * Y + 1.0) * h - 1.0) * 0.5
+        fx = np.floor(px * 256.0 + 0.5).astype(np.int64)
+        fy = np.floor(py * 256.0 + 0.5).astype(np.int64)
+        x0, wx = fx >> 8, (fx & 255)[None, :, :, None]
+        y0, wy = fy >> 8, (fy & 255)[None, :, :, None]
+        x0c, x1c = np.clip(x0 + 1, 0, w + 1), np.clip(x0 + 2, 0, w + 1)  # +1: border offset; fully outside -> border zeros
+        y0c, y1c = np.clip(y0 + 1, 0, h + 1), np.clip(y0 + 2, 0, h + 1)
+        inside = ((x0 >= -1) & (x0 <= w - 1) & (y0 >= -1) & (y0 <= h - 1))[None, :, :, None]
+        v = (src[:, y0c, x0c] * (256 - wx) * (256 - wy) + src[:, y0c, x1c] * wx * (256 - wy) +
+             src[:, y1c, x0c] * (256 - wx) * wy + src[:, y1c, x1c] * wx * wy + 32768) >> 16
+        out[k] = np.where(inside, v, 0).astype(np.uint8)
+    return out
+
+
+def fingerprint(*objs):
+    """SHA-256 over the raw bytes of tensors / arrays / (nested) dicts of them, keys in sorted order: how the golden fixtures
+    pin the synthetic inputs and weights they were generated from (tests assert the same hash on the GPU box)."""
+    import hashlib
+    hsh = hashlib.sha256()
+
+    def feed(o):
+        if isinstance(o, dict):
+            for k in sorted(o):
+                hsh.update(str(k).encode()); feed(o[k])
+        elif isinstance(o, (list, tuple)):
+            for v in o: feed(v)
+        else:
+            a = o.detach().cpu().numpy() if torch.is_tensor(o) else np.asarray(o)
+            hsh.update(str(a.dtype).encode()); hsh.update(str(a.shape).encode()); hsh.update(np.ascontiguousarray(a).tobytes())
+    feed(list(objs))
+    return hsh.hexdigest()
 
 
 def imgs_to_tensor(imgs_u8):

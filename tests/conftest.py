@@ -40,9 +40,9 @@ def pytest_collection_modifyitems(config, items):
 
 
 def pytest_sessionstart(session):
-    """Achieved parity errors of the GPU tests are appended to gpurun_out/parity_r02.jsonl (tools/parity_table.py turns
-    them into profiles/r02_parity.md)."""
-    os.environ.setdefault("G6D_PARITY_LOG", os.path.join(ROOT, "gpurun_out", "parity_r02.jsonl"))
+    """Achieved parity errors of the GPU tests are appended to gpurun_out/parity_r03.jsonl (tools/parity_table.py turns
+    them into profiles/r03_parity.md)."""
+    os.environ.setdefault("G6D_PARITY_LOG", os.path.join(ROOT, "gpurun_out", "parity_r03.jsonl"))
 
 
 
@@ -53,3 +53,14 @@ def golden():
     def load(name):
         return dict(np.load(os.path.join(GOLDEN, name + ".npz")))
     return load
+
+
+def assert_pinned(g, inputs, weights, what=""):
+    """The synthetic inputs / weights regenerated on THIS host are bit-identical to the ones the reference ran on when the
+    fixture was made (make_golden*.py store their SHA-256): with that, `HIP vs golden` compares like with like and can be held
+    to the same bar as `HIP vs oracle` (round 2's rotated copies went through an sgemm + grid_sample and
+    differed between the build container and the GPU box)."""
+    from gen6d_amd import synth
+    got_i, got_w = synth.fingerprint(inputs), synth.fingerprint(weights)
+    assert got_i == str(g["sha_inputs"]), f"{what}: synthetic inputs differ from the ones the golden fixture was generated from"
+    assert got_w == str(g["sha_weights"]), f"{what}: synthetic weights differ from the ones the golden fixture was generated from"

@@ -177,6 +177,7 @@ def main():
             out = net({"ref_imgs_info": {"imgs": case["ref_imgs"]}, "que_imgs_info": {"imgs": case["que_imgs"]}})
             pos, scl = net.parse_detection(out["scores"], out["select_pr_scale"], out["select_pr_offset"], 8)
         np.savez_compressed(os.path.join(HERE, tag + ".npz"), rfn=rfn, hq=hq, wq=wq, positions=pos.numpy(),
+                            sha_inputs=synth.fingerprint(case), sha_weights=synth.fingerprint(synth.synth_state_dict("detector")),
                             scales=scl.numpy(), **np_({k: out[k] for k in ("scores", "select_pr_offset",
                                                                            "select_pr_scale", "que_select_id")}))
         print(tag, "pos", pos.numpy(), "scale", scl.numpy())
@@ -192,6 +193,7 @@ def main():
                        "que_imgs_info": {"imgs": case["que_imgs"]}, "eval": True})
             embed = net.ref_pose_embed
         np.savez_compressed(os.path.join(HERE, tag + ".npz"), rfn=rfn, an=an, logits=out["ref_vp_logits"].numpy(),
+                            sha_inputs=synth.fingerprint(case), sha_weights=synth.fingerprint(synth.synth_state_dict("selector", an=an)),
                             angles=out["angles_pr"].numpy(), pose_embed=embed.numpy()[:, :16])
         print(tag, "argmax", out["ref_vp_logits"].argmax(1).numpy(), "logits[:4]", out["ref_vp_logits"][0, :4].numpy())
 
@@ -209,7 +211,8 @@ def main():
         mean, std, vin, _ = net.construct_feature_volume(data["que_imgs_info"], data["ref_imgs_info"], net.feature_net, 32)
         qf = net.feature_net(case["que_imgs"])
     sl = (slice(None), slice(0, 8), slice(None, None, 4), slice(None, None, 4), slice(None, None, 4))
-    np.savez_compressed(os.path.join(HERE, "ref_step.npz"), **np_(out), vol_mean=mean[sl].numpy(), vol_std=std[sl].numpy(),
+    np.savez_compressed(os.path.join(HERE, "ref_step.npz"), **np_(out), sha_inputs=synth.fingerprint(case),
+                        sha_weights=synth.fingerprint(synth.synth_state_dict("refiner")), vol_mean=mean[sl].numpy(), vol_std=std[sl].numpy(),
                         vol_in=vin[sl].numpy(), que_feats=qf[:, :8].numpy())
     print("ref_step", np_(out))
 

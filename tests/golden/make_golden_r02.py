@@ -42,7 +42,8 @@ def det_head(n2n, synth):
     with torch.no_grad():
         out = net({"ref_imgs_info": {"imgs": case["ref_imgs"]}, "que_imgs_info": {"imgs": case["que_imgs"]}})
         pos, scl = net.parse_detection(out["scores"], out["select_pr_scale"], out["select_pr_offset"], 8)
-    save("det_head", rfn=32, hq=480, wq=640, positions=pos.numpy(), scales=scl.numpy(),
+    save("det_head", rfn=32, hq=480, wq=640, sha_inputs=synth.fingerprint(case),
+         sha_weights=synth.fingerprint(synth.synth_state_dict("detector")), positions=pos.numpy(), scales=scl.numpy(),
          **np_({k: out[k] for k in ("scores", "select_pr_offset", "select_pr_scale", "que_select_id")}))
 
 
@@ -55,7 +56,8 @@ def _selector(n2n, synth, tag, rfn, an):
         out = net({"ref_imgs": case["ref_imgs"], "ref_imgs_info": {"poses": case["ref_poses"]},
                    "object_center": case["object_center"], "object_vert": case["object_vert"],
                    "que_imgs_info": {"imgs": case["que_imgs"]}, "eval": True})
-    save(tag, rfn=rfn, an=an, logits=out["ref_vp_logits"].numpy(), angles=out["angles_pr"].numpy())
+    save(tag, rfn=rfn, an=an, logits=out["ref_vp_logits"].numpy(), angles=out["angles_pr"].numpy(),
+         sha_inputs=synth.fingerprint(case), sha_weights=synth.fingerprint(synth.synth_state_dict("selector", an=an)))
     print(tag, f"{time.time() - t0:.1f}s argmax", out["ref_vp_logits"].argmax(1).numpy())
 
 
@@ -77,7 +79,8 @@ def ref_grids(n2n, synth):
     with torch.no_grad():
         out = net({"que_imgs_info": {"imgs": case["que_imgs"], "Ks_in": case["Ks_in"], "poses_in": case["poses_in"]},
                    "ref_imgs_info": {"imgs": case["ref_imgs"], "Ks": case["ref_Ks"], "poses": case["ref_poses"]}})
-    save("ref_grids", grids=out["grids"][:, ::7].numpy(), stride=7, **np_({k: out[k] for k in ("rotation", "offset", "scale")}))
+    save("ref_grids", grids=out["grids"][:, ::7].numpy(), stride=7, sha_inputs=synth.fingerprint(case),
+         sha_weights=synth.fingerprint(synth.synth_state_dict("refiner")), **np_({k: out[k] for k in ("rotation", "offset", "scale")}))
 
 
 def pipeline_rows(n2n, synth):
@@ -115,6 +118,8 @@ def pipeline_rows(n2n, synth):
             logits_all.append(logits)
             print("query", j, rows[-1].numpy().round(4))
     save("pipeline_rows", rows=torch.cat(rows, 0).numpy(), logits=torch.cat(logits_all, 0).numpy(),
+         sha_inputs=synth.fingerprint(sel_case, det_refs, rc, iter_poses, fulls, crops),
+         sha_weights=synth.fingerprint([synth.synth_state_dict(k, an=an) for k in ("detector", "selector", "refiner")]),
          cfg=np.asarray([sel_rfn, det_rfn, an, iters]))
 
 

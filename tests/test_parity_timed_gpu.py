@@ -16,7 +16,8 @@ import torch
 from gen6d_amd import synth
 from oracle import gen6d_oracle as O
 from parity_log import record
-from test_networks_gpu import _accept, _net
+from conftest import assert_pinned
+from test_networks_gpu import _accept, _net, _vs_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -31,11 +32,10 @@ def test_detector_headline_480x640x32(golden):
         o32 = O.detector_detect(sd, case["que_imgs"], O.detector_ref_feats(sd, case["ref_imgs"]))
         o64 = O.detector_detect(sd64, case["que_imgs"].double(), O.detector_ref_feats(sd64, case["ref_imgs"].double()))
         p64, s64 = O.detector_parse(o64)
+    assert_pinned(g, case, sd, "det_head")
     for k in ("scores", "select_pr_offset", "select_pr_scale"):
         _accept(out[k], o32[k], o64[k], what=f"480x640x32/{k}", relative=True)
-        err = np.abs(out[k].cpu().numpy() - g[k]).max() / max(np.abs(g[k]).max(), 1.0)
-        record("test_detector_headline_480x640x32", f"{k} vs reference golden", err, 2e-3, note="relative to range")
-        assert err <= 2e-3, (k, err)
+        _vs_golden(out[k], g[k], o32[k], o64[k], what=f"480x640x32/{k}", relative=True)
     sel = out["que_select_id"].cpu().numpy()
     assert np.array_equal(sel, g["que_select_id"]) and np.array_equal(sel, o64["que_select_id"].numpy())
     np.testing.assert_allclose(out["positions"].cpu().numpy(), g["positions"], rtol=1e-3, atol=5e-2)
@@ -53,6 +53,7 @@ def test_selector_sweep_sizes(golden, tag, fp64_state):
     case = synth.selector_case(rfn, an)
     net = _net("selector", selector_angle_num=an)
     sd = synth.synth_state_dict("selector", an=an); sd64 = O.to_double(sd)
+    assert_pinned(g, case, sd, tag)
     with torch.no_grad():
         out = net({"ref_imgs": case["ref_imgs"].cuda(), "ref_imgs_info": {"poses": case["ref_poses"].cuda()},
                    "object_center": case["object_center"].cuda(), "object_vert": case["object_vert"].cuda(),
@@ -69,25 +70,25 @@ def test_selector_sweep_sizes(golden, tag, fp64_state):
     _accept(out["ref_vp_logits"], l32, l64, what=f"{tag}/logits")
     _accept(out["angles_pr"], a32, a64, what=f"{tag}/angles")
     got = out["ref_vp_logits"].cpu().numpy()
-    err = np.abs(got - g["logits"]).max()
-    record("test_selector_sweep_sizes", f"{tag}/logits vs reference golden", err, 5e-3)
-    assert err <= 5e-3
+    _vs_golden(out["ref_vp_logits"], g["logits"], l32, l64, what=f"{tag}/logits")
+    _vs_golden(out["angles_pr"], g["angles"], a32, a64, what=f"{tag}/angles")
     assert np.array_equal(got.argmax(1), g["logits"].argmax(1)) and np.array_equal(got.argmax(1), l64.argmax(1).numpy())
 
 
 def test_selector_headline_vs_reference_golden(golden):
     g = golden("sel_head")
     case = synth.selector_case(64, 5)
+    assert_pinned(g, case, synth.synth_state_dict("selector"), "sel_head")
     net = _net("selector")
     with torch.no_grad():
         out = net({"ref_imgs": case["ref_imgs"].cuda(), "ref_imgs_info": {"poses": case["ref_poses"].cuda()},
                    "object_center": case["object_center"].cuda(), "object_vert": case["object_vert"].cuda(),
                    "que_imgs_info": {"imgs": case["que_imgs"].cuda()}, "eval": True})
     got = out["ref_vp_logits"].cpu().numpy()
-    err = np.abs(got - g["logits"]).max()
-    record("test_selector_headline_vs_reference_golden", "64x5 logits vs reference golden", err, 5e-3)
-    assert err <= 5e-3 and np.array_equal(got.argmax(1), g["logits"].argmax(1))
-    np.testing.assert_allclose(out["angles_pr"].cpu().numpy(), g["angles"], atol=5e-3)
+    # no oracle pair here: the flat north_star bar (1e-4 on logits) — the reference's fp32 noise at this size is ~2e-5
+    _vs_golden(out["ref_vp_logits"], g["logits"], what="64x5 logits")
+    _vs_golden(out["angles_pr"], g["angles"], what="64x5 angles")
+    assert np.array_equal(got.argmax(1), g["logits"].argmax(1))
 
 
 def _row_err(got, ref):
@@ -109,6 +110,8 @@ def test_lane_graph_replay_matches_eager_and_reference(golden, lanes):
     pipe.build()
     fulls = synth.imgs_to_tensor(synth.synth_images(4, 480, 640, seed=100)).to(dev)
     crops = synth.imgs_to_tensor(synth.synth_images(4, 128, 128, seed=200)).to(dev)
+    assert_pinned(g, [pipe.sel_case, pipe.det_refs, pipe.ref_case, [p.cpu() for p in pipe.iter_poses], fulls.cpu(), crops.cpu()],
+                  [pipe.state_dicts[k] for k in ("detector", "selector", "refiner")], "pipeline_rows")
     eager = [pipe.query(fulls[j:j + 1], crops[j:j + 1]).clone() for j in range(4)]
     torch.cuda.synchronize()
     old_serial = ops.SERIAL
@@ -142,8 +145,8 @@ def test_lane_graph_replay_matches_eager_and_reference(golden, lanes):
         assert int(row[3]) == int(gold[j, 3]), f"image {j} lane {lane}: viewpoint arg-max {int(row[3])} != reference {int(gold[j, 3])}"
         worst_g = max(worst_g, _row_err(row, gold[j]))
     record(f"test_lane_graph_replay[{lanes}]", "graph row vs eager row (max over 24 queries, relative)", worst_e, 1e-4)
-    record(f"test_lane_graph_replay[{lanes}]", "graph row vs reference golden rows (relative to max(1,|ref|))", worst_g, 2e-3)
-    assert worst_g <= 2e-3, worst_g
+    record(f"test_lane_graph_replay[{lanes}]", "graph row vs reference golden rows (relative to max(1,|ref|))", worst_g, 1e-4)
+    assert worst_g <= 1e-4, worst_g
     # one query end to end through the oracle as well (same arg-max, same row)
     st = PO.build_state(pipe.state_dicts, pipe.det_refs, pipe.sel_case)
     row_o, logits_o = PO.query(pipe.state_dicts, st, pipe.ref_case, [p.cpu() for p in pipe.iter_poses], fulls[1:2].cpu(), crops[1:2].cpu())
@@ -215,6 +218,7 @@ def test_refiner_forward_grids(golden):
         out = net({"que_imgs_info": {"imgs": c["que_imgs"].cuda(), "Ks_in": c["Ks_in"].cuda(), "poses_in": c["poses_in"].cuda()},
                    "ref_imgs_info": {"imgs": c["ref_imgs"].cuda(), "Ks": c["ref_Ks"].cuda(), "poses": c["ref_poses"].cuda()}})
     assert out["grids"].shape == (1, 32 ** 3, 3)
+    assert_pinned(g, c, synth.synth_state_dict("refiner"), "ref_grids")
     np.testing.assert_allclose(out["grids"][:, ::int(g["stride"])].cpu().numpy(), g["grids"], atol=1e-5)
     for k in ("rotation", "offset", "scale"):
-        np.testing.assert_allclose(out[k].cpu().numpy(), g[k], rtol=1e-3, atol=1e-3)
+        _vs_golden(out[k], g[k], what=f"ref_grids/{k}")
