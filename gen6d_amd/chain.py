@@ -19,13 +19,17 @@ from . import ops
 
 
 class DeviceChain:
+    # constants of Gen6DEstimator.predict's refinement call (reference estimator.py:212-213 `refine_que_imgs(..., size=128,
+    # ref_num=6, ref_even=True)`, margin 0.05 at network/refiner.py:281); the refiner crop size is NOT cfg['ref_resolution']
     REF_NUM = 6
     MARGIN = 0.05
+    REFINE_SIZE = 128
 
     def __init__(self, est, even_num=128):
         self.est = est
         self.dev = est.device
-        self.size = int(est.cfg["ref_resolution"])
+        self.size = int(est.cfg["ref_resolution"])                      # selector crop (estimator.py:184)
+        self.refine_size = int(est.cfg.get("refine_size", self.REFINE_SIZE))
         self.refine_iter = int(est.cfg["refine_iter"]) if est.refiner is not None else 0
         info = est.ref_info
         f = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.dev)
@@ -65,13 +69,13 @@ class DeviceChain:
             pose, sel = ops.chain_pose_from_selection(det5, logits[0].contiguous(), angles[0].contiguous(), self.ref_poses, self.ref_Ks,
                                                       que_K9, self.center)
             poses = [pose]
-            R = self.REF_NUM
+            R, rs = self.REF_NUM, self.refine_size
             for _ in range(self.refine_iter):
-                geo, idx = ops.chain_refine_prepare(pose.reshape(12), que_K9, self.norm, size, self.MARGIN, self.sub_poses, self.sub_Ks, R)
+                geo, idx = ops.chain_refine_prepare(pose.reshape(12), que_K9, self.norm, rs, self.MARGIN, self.sub_poses, self.sub_Ks, R)
                 hinv = geo[33 + 21 * R:].view(1 + R, 9)
-                imgs = torch.empty((1 + R, 3, size, size), dtype=torch.float32, device=self.dev)
-                ops.warp_batch(None, que_img, None, hinv[0:1], size, size, out=imgs[0:1])
-                ops.warp_batch(self.stack, None, idx, hinv[1:], size, size, out=imgs[1:])
+                imgs = torch.empty((1 + R, 3, rs, rs), dtype=torch.float32, device=self.dev)
+                ops.warp_batch(None, que_img, None, hinv[0:1], rs, rs, out=imgs[0:1])
+                ops.warp_batch(self.stack, None, idx, hinv[1:], rs, rs, out=imgs[1:])
                 rot, off, scl = est.refiner._step(imgs[0:1], geo[0:9].view(3, 3), geo[9:21].view(3, 4), imgs[1:],
                                                   geo[33:33 + 9 * R].view(R, 3, 3), geo[33 + 9 * R:33 + 21 * R].view(R, 3, 4))
                 pose = ops.chain_refine_update(rot[0].contiguous(), off[0].contiguous(), scl[0].contiguous(), geo, self.norm)
@@ -113,6 +117,11 @@ class DeviceChain:
         with torch.cuda.stream(stream):
             g_img.copy_(que_img, non_blocking=True)
             g_K.copy_(que_K, non_blocking=True)
+            # the sources were allocated on the caller's stream and are consumed on the lane's: tell the caching allocator, or it
+            # may hand their blocks to the next query's upload while this copy is still pending
+            for t in (que_img, que_K):
+                if t.is_cuda:
+                    t.record_stream(stream)
             graph.replay()
             row = torch.cat([out["pose"].reshape(12), out["det"], out["sel"]])
         return row, stream

@@ -42,8 +42,9 @@ __device__ __forceinline__ f32x4 ldg(const float* __restrict__ base, int elem_of
   return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + ((unsigned)elem_off << 2));
 }
 
-// MODE: 0 = plain operand, 1 = affine(+ReLU) with one table, 2 = affine(+ReLU) with a table per batch index n,
-//       3 = elementwise multiplier + affine (selector product).
+// MODE: 0 = plain operand, 1 = affine(+ReLU) with one table, 2 = affine(+ReLU) with a table per image group (n / in_affine_per_n),
+//       3 = elementwise multiplier + affine with one table (selector product), 4 = multiplier + a table per image group (the
+//       selector product of a BATCH of queries: multiplier and table of query n / k, input image n % k — G6dConv.in_image_mod).
 // MM: 0 = fp32 MFMA (default); 1 / 2 = bf16 / fp16 operands, fp32 accumulation (G6dConv.math_mode, g6d_common.h).
 template <int BM, int BN, int WGM, int WGN, int MODE, int MM>
 __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const G6dConv p, const int M, const int T,
@@ -55,7 +56,7 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const G6dConv p, con
   constexpr int MT = WM / 32, NT = WN / 32;
   constexpr int RA = BM / 32, RB = BN / 32;
   constexpr int STAGE = (BM + BN) * LDS_K;
-  constexpr bool AFF = MODE != 0, PER_N = MODE == 2, MUL = MODE == 3;
+  constexpr bool AFF = MODE != 0, PER_N = MODE == 2 || MODE == 4, MUL = MODE == 3 || MODE == 4;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -97,9 +98,13 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const G6dConv p, con
       for (int k = 0; k < p.kd; ++k) amz[j] |= (unsigned)((unsigned)(az0 + k) < (unsigned)p.Di) << k;
       for (int k = 0; k < p.kh; ++k) amy[j] |= (unsigned)((unsigned)(ay0 + k) < (unsigned)p.Hi) << k;
       for (int k = 0; k < p.kw; ++k) amx[j] |= (unsigned)((unsigned)(ax0 + k) < (unsigned)p.Wi) << k;
-      avoff[j] = (unsigned)((((n * p.Di + az0) * p.Hi + ay0) * p.Wi + ax0) * p.ld_in + pad_a + 4 * lseg) << 2;
-      if constexpr (MUL) mvoff[j] = (unsigned)((ay0 * p.Wi + ax0) * Cin + pad_m + 4 * lseg) << 2;
-      if constexpr (PER_N) nbase[j] = n * Cin;
+      const int n_in = p.in_image_mod > 0 ? n % p.in_image_mod : n;          // query batches share the input images
+      avoff[j] = (unsigned)((((n_in * p.Di + az0) * p.Hi + ay0) * p.Wi + ax0) * p.ld_in + pad_a + 4 * lseg) << 2;
+      if constexpr (MUL) {
+        const int mg = p.mul_group_images > 0 ? n / p.mul_group_images : 0;    // the image group's own multiplier map
+        mvoff[j] = (unsigned)(((mg * p.Hi + ay0) * p.Wi + ax0) * Cin + pad_m + 4 * lseg) << 2;
+      }
+      if constexpr (PER_N) nbase[j] = (n / p.in_affine_per_n) * Cin;
     }
   }
   // ---- per-thread rows of the weight tile: constant byte offset, beyond the tensor for rows >= Cout
@@ -444,9 +449,11 @@ int launch_mm(const G6dConv& d, int M, int T, int nChunks, int splits, hipStream
   g6d_allow_lds(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WGM, WGN, MODE, MM>), (int)lds_bytes);
   // extents of the buffer-load descriptors (the activation and multiplier descriptors start `pad` elements in front of the tensor)
   const long long pad_a = ((long long)(d.pd * d.Hi + d.ph) * d.Wi + d.pw) * d.ld_in, pad_m = (long long)(d.ph * d.Wi + d.pw) * d.Cin;
-  const unsigned in_bytes = (unsigned)(((long long)d.N * d.Di * d.Hi * d.Wi * d.ld_in + pad_a) * 4);
+  const long long n_in = d.in_image_mod > 0 ? d.in_image_mod : d.N;
+  const long long n_mul = d.mul_group_images > 0 ? (d.N + d.mul_group_images - 1) / d.mul_group_images : 1;
+  const unsigned in_bytes = (unsigned)((n_in * d.Di * d.Hi * d.Wi * d.ld_in + pad_a) * 4);
   const unsigned w_bytes = (unsigned)((long long)d.Cout * T * d.Cin * 4);
-  const unsigned mul_bytes = (unsigned)(((long long)d.Hi * d.Wi * d.Cin + pad_m) * 4);
+  const unsigned mul_bytes = (unsigned)((n_mul * d.Hi * d.Wi * d.Cin + pad_m) * 4);
   hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, MODE, MM>), grid, dim3(256), lds_bytes, stream, d, M, T, nChunks,
                      ips, total, splits, in_bytes, w_bytes, mul_bytes);
   return g6d_check_launch("conv_igemm");
@@ -461,7 +468,8 @@ int launch_mode(const G6dConv& d, int M, int T, int nChunks, int splits, hipStre
 
 template <int BM, int BN, int WGM, int WGN>
 int launch_cfg(const G6dConv& d, int M, int T, int nChunks, int splits, hipStream_t stream) {
-  if (d.mul) return launch_mode<BM, BN, WGM, WGN, 3>(d, M, T, nChunks, splits, stream);
+  if (d.mul) return d.in_affine_per_n ? launch_mode<BM, BN, WGM, WGN, 4>(d, M, T, nChunks, splits, stream)
+                                      : launch_mode<BM, BN, WGM, WGN, 3>(d, M, T, nChunks, splits, stream);
   if (!d.in_scale) return launch_mode<BM, BN, WGM, WGN, 0>(d, M, T, nChunks, splits, stream);
   if (d.in_affine_per_n) return launch_mode<BM, BN, WGM, WGN, 2>(d, M, T, nChunks, splits, stream);
   return launch_mode<BM, BN, WGM, WGN, 1>(d, M, T, nChunks, splits, stream);
@@ -493,10 +501,18 @@ extern "C" int g6d_conv_igemm(const G6dConv* desc, g6d_stream_t stream_) {
     g6d_set_error("conv: operand pointers must be 16-byte aligned"); return G6D_EINVAL;
   }
   if (d.mul && !d.in_scale) { g6d_set_error("conv: mul requires in_scale/in_shift"); return G6D_EINVAL; }
+  if (d.in_affine_per_n < 0 || d.in_image_mod < 0 || d.mul_group_images < 0 || (d.mul_group_images > 0 && !d.mul) ||
+      d.in_image_mod > d.N) {
+    g6d_set_error("conv: in_affine_per_n / in_image_mod / mul_group_images must be >= 0 (mul_group_images needs mul; in_image_mod <= N)");
+    return G6D_EINVAL;
+  }
+  if ((long long)(d.mul_group_images > 0 ? (d.N + d.mul_group_images - 1) / d.mul_group_images : 1) * d.Hi * d.Wi * d.Cin >= (1ll << 29)) {
+    g6d_set_error("conv: multiplier tensor exceeds 2^31 bytes"); return G6D_EINVAL;
+  }
   if (d.fin_scale && (!d.stats || !d.fin_shift || !d.fin_counter || d.fin_count <= 0 || d.fin_groups <= 0)) {
     g6d_set_error("conv: fin_scale needs stats, fin_shift, fin_counter, fin_count > 0 and fin_groups"); return G6D_EINVAL;
   }
-  if ((long long)d.N * d.Di * d.Hi * d.Wi * d.ld_in + ((long long)(d.pd * d.Hi + d.ph) * d.Wi + d.pw) * d.ld_in >= (1ll << 29) ||
+  if ((long long)(d.in_image_mod > 0 ? d.in_image_mod : d.N) * d.Di * d.Hi * d.Wi * d.ld_in + ((long long)(d.pd * d.Hi + d.ph) * d.Wi + d.pw) * d.ld_in >= (1ll << 29) ||
       (long long)d.Cout * d.kd * d.kh * d.kw * d.Cin >= (1ll << 29) || d.kd > 32 || d.kh > 32 || d.kw > 32) {
     g6d_set_error("conv: tensor exceeds 2^31 bytes (buffer-load offsets) or kernel extent > 32"); return G6D_EINVAL;
   }

@@ -85,7 +85,8 @@ __global__ void __launch_bounds__(256) conv_patch_kernel(const G6dConv p, const 
     poff[j] = pval[j] ? ((((n + pn) * D + iz) * H + iy) * W + ix) * p.ld_in : 0;
     pmul[j] = pval[j] ? (iy * W + ix) * Cin : 0;
   }
-  const int aff_off = p.in_affine_per_n ? n * Cin : 0;        // one (scale, shift) table per image: tiles of one image only
+  // one (scale, shift) table per image group: the images of a tile share a group (host check)
+  const int aff_off = p.in_affine_per_n ? (n / p.in_affine_per_n) * Cin : 0;
   f32x4 rp[NPL], rmul[MUL ? NPL : 1], rsc = {1.f, 1.f, 1.f, 1.f}, rsh = {0.f, 0.f, 0.f, 0.f};
   bool vp[NPL];
   auto load_patch = [&](int chunk) {
@@ -299,7 +300,8 @@ __global__ void __launch_bounds__(256) conv_patch_kernel(const G6dConv p, const 
     }
   }
   const bool do_stats = p.stats != nullptr;
-  const int g0 = p.stat_rows_per_group > 0 ? n : 0;           // per-image groups only with one image per tile (host check)
+  // statistics groups are whole images (or runs of whole images); the images of a tile share a group (host check)
+  const int g0 = p.stat_rows_per_group > 0 ? n / (p.stat_rows_per_group / (p.Do * p.Ho * p.Wo)) : 0;
   float* sred = lds;
   if (do_stats) {
     for (int i = tid; i < BN * 2; i += 256) sred[i] = 0.f;
@@ -386,8 +388,9 @@ int pick_kind(const G6dConv& d, double* eff_out, long long* tiles_out) {
   for (int kind = 0; kind < 3; ++kind) {
     if (k3 != (kind == 1)) continue;
     const int TN = kind == 2 ? 2 : 1, TD = kind == 1 ? 2 : 1, TH = 8, TW = kind == 0 ? 16 : 8;
-    if (TN > 1 && d.stats && d.stat_rows_per_group > 0) continue;       // per-image statistics need one image per tile
-    if (TN > 1 && d.in_scale && d.in_affine_per_n) continue;            // ... and so do per-image affine tables
+    // the TN images of a tile must share their statistics group and their affine table
+    if (TN > 1 && d.stats && d.stat_rows_per_group > 0 && (d.stat_rows_per_group / (d.Do * d.Ho * d.Wo)) % TN) continue;
+    if (TN > 1 && d.in_scale && d.in_affine_per_n % TN) continue;
     const long long tiles = (long long)((d.N + TN - 1) / TN) * ((d.Di + TD - 1) / TD) * ((d.Hi + TH - 1) / TH) *
                             ((d.Wi + TW - 1) / TW);
     const double eff = (double)d.N * d.Di * d.Hi * d.Wi / (double)(tiles * 128);
@@ -406,8 +409,9 @@ bool g6d_conv_patch_eligible(const G6dConv& d) {
   const bool k3 = d.kd == 3 && d.kh == 3 && d.kw == 3 && d.pd == 1 && d.ph == 1 && d.pw == 1;
   if (!(k2 || k3) || d.sd != 1 || d.sh != 1 || d.sw != 1) return false;
   if (d.mul && !k2) return false;
+  if (d.in_image_mod > 0 || d.mul_group_images > 0) return false;      // batched selector product: Winograd / generic kernel
   const int per_image = d.Do * d.Ho * d.Wo;
-  if (d.stats && d.stat_rows_per_group > 0 && d.stat_rows_per_group != per_image) return false;
+  if (d.stats && d.stat_rows_per_group > 0 && d.stat_rows_per_group % per_image) return false;   // groups = runs of whole images
   if (d.split_k > 0) return false;                                   // forced split counts go to the generic kernel
   double eff; long long tiles;
   if (pick_kind(d, &eff, &tiles) < 0) return false;

@@ -29,7 +29,7 @@ __device__ __forceinline__ f32x4 ldg4(const float* __restrict__ base, int elem_o
 // the same reference filters): their tiles form ONE flat list, so the launch fills the chip with fewer splits than four separate
 // launches.  Offsets in floats from the launch's common base pointers.
 #define CORR_MAX_SEG 4
-struct CorrSeg { int tile0, H, W, tiles_x, in_off, out_off, ld_in, ld_out; };
+struct CorrSeg { int tile0, H, W, tiles_x, in_off, out_off, ld_in, ld_out, N, tiles_img; };   // N images of H x W, tiles_img tiles each
 struct CorrArgs { int nseg; CorrSeg seg[CORR_MAX_SEG]; };
 
 template <int MM>     // 0 = fp32 MFMA; 1 / 2 = bf16 / fp16 operands (two 8-channel groups per v_mfma_f32_32x32x16_*)
@@ -44,9 +44,10 @@ __global__ void __launch_bounds__(512) corr_patch_kernel(const float* __restrict
   for (int k = 1; k < CORR_MAX_SEG; ++k) sidx = (k < sa.nseg && (int)blockIdx.x >= sa.seg[k].tile0) ? k : sidx;
   const CorrSeg& sg = sa.seg[sidx];
   const int H = sg.H, W = sg.W, tiles_x = sg.tiles_x, ld_in = sg.ld_in, ld_out = sg.ld_out;
-  const float* __restrict__ in = in_base + sg.in_off;
-  float* __restrict__ out = out_base + sg.out_off;
-  const int tile = blockIdx.x - sg.tile0;
+  const int tile_s = blockIdx.x - sg.tile0, img = tile_s / sg.tiles_img;       // image of the segment (a batch of queries at one scale)
+  const float* __restrict__ in = in_base + sg.in_off + (size_t)img * H * W * ld_in;
+  float* __restrict__ out = out_base + sg.out_off + (size_t)img * H * W * ld_out;
+  const int tile = tile_s - img * sg.tiles_img;
   const int PW = TW + kw - 1;                       // patch width in positions
   const int patch_floats = TH * PW * LDS_K;
   // one patch buffer: the next unit's patch waits in registers during the kw taps and is written between two barriers
@@ -236,7 +237,8 @@ int corr_run(const float* in_base, float* out_base, CorrArgs& sa, int Cin, const
     CorrSeg& g = sa.seg[k];
     g.tiles_x = (g.W + TW - 1) / TW;
     g.tile0 = tiles;
-    tiles += g.tiles_x * ((g.H + TH - 1) / TH);
+    g.tiles_img = g.tiles_x * ((g.H + TH - 1) / TH);
+    tiles += g.N * g.tiles_img;
   }
   const int total_units = ((Cin + 31) / 32) * kh;
   // split the (chunk, ky) units so that the grid fills whole rounds of the chip (256 CUs x 2 resident blocks):
@@ -290,7 +292,7 @@ extern "C" int g6d_corr2d_patch(const float* in, int H, int W, int Cin, int ld_i
   if (math_mode < 0 || math_mode > 2) { g6d_set_error("corr2d_patch: math_mode must be 0, 1 or 2"); return G6D_EINVAL; }
   CorrArgs sa = {};
   sa.nseg = 1;
-  sa.seg[0] = CorrSeg{0, H, W, 0, 0, 0, ld_in, ld_out};
+  sa.seg[0] = CorrSeg{0, H, W, 0, 0, 0, ld_in, ld_out, 1, 0};
   return corr_run(in, out, sa, Cin, wgt, Cout, kh, kw, workspace, workspace_bytes, math_mode, reinterpret_cast<hipStream_t>(stream_));
 }
 
@@ -305,7 +307,7 @@ extern "C" int g6d_corr2d_patch_multi(const G6dCorrSeg* segs, int nseg, int Cin,
   const float* in0 = segs[0].in; float* out0 = segs[0].out;
   for (int k = 0; k < nseg; ++k) {
     const G6dCorrSeg& g = segs[k];
-    if (!g.in || !g.out || g.H <= 0 || g.W <= 0 || (g.ld_in & 3) || g.ld_in < Cin || g.ld_out < Cout || !g6d_aligned16(g.in)) {
+    if (!g.in || !g.out || g.H <= 0 || g.W <= 0 || g.N <= 0 || (g.ld_in & 3) || g.ld_in < Cin || g.ld_out < Cout || !g6d_aligned16(g.in)) {
       g6d_set_error("corr2d_patch_multi: bad map"); return G6D_EINVAL;
     }
     if (g.in < in0) in0 = g.in;
@@ -316,10 +318,10 @@ extern "C" int g6d_corr2d_patch_multi(const G6dCorrSeg* segs, int nseg, int Cin,
   for (int k = 0; k < nseg; ++k) {
     const G6dCorrSeg& g = segs[k];
     const long long io = g.in - in0, oo = g.out - out0;
-    if (io + (long long)g.H * g.W * g.ld_in >= (1ll << 30) || oo + (long long)g.H * g.W * g.ld_out >= (1ll << 31)) {
+    if (io + (long long)g.N * g.H * g.W * g.ld_in >= (1ll << 30) || oo + (long long)g.N * g.H * g.W * g.ld_out >= (1ll << 31)) {
       g6d_set_error("corr2d_patch_multi: maps must lie within 2^30 floats of each other (allocate them from one buffer)"); return G6D_EINVAL;
     }
-    sa.seg[k] = CorrSeg{0, g.H, g.W, 0, (int)io, (int)oo, g.ld_in, g.ld_out};
+    sa.seg[k] = CorrSeg{0, g.H, g.W, 0, (int)io, (int)oo, g.ld_in, g.ld_out, g.N, 0};
   }
   return corr_run(in0, out0, sa, Cin, wgt, Cout, kh, kw, workspace, workspace_bytes, math_mode, reinterpret_cast<hipStream_t>(stream_));
 }

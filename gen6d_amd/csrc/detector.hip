@@ -14,6 +14,9 @@ __global__ void assemble_kernel(const float* __restrict__ s0, const float* __res
   const long long total = (long long)hs * ws * rfn;
   const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (i >= total) return;
+  // blockIdx.y = query of the batch: its level maps and its slab of `stacked` follow those of the previous query
+  s0 += (size_t)blockIdx.y * hc * wc * rfn; s1 += (size_t)blockIdx.y * (hc >> 1) * (wc >> 1) * rfn;
+  s2 += (size_t)blockIdx.y * (hc >> 2) * (wc >> 2) * rfn; stacked += (size_t)blockIdx.y * total * nch;
   const int r = (int)(i % rfn); const int pix = (int)(i / rfn);
   const int x = pix % ws, y = pix / ws;
   const float ry = (float)hc / (float)hs, rx = (float)wc / (float)ws;
@@ -85,6 +88,8 @@ __global__ void __launch_bounds__(256) decode_kernel(const float* __restrict__ s
   __shared__ float bv[256];
   __shared__ int bi[256];
   const int n = hs * ws;
+  scores += (size_t)blockIdx.x * n * ld_s; offset += (size_t)blockIdx.x * n * ld_o; scale += (size_t)blockIdx.x * n * ld_c;
+  result += blockIdx.x * 5;                              // blockIdx.x = query of the batch
   float best = -INFINITY; int idx = 0x7fffffff;
   for (int i = threadIdx.x; i < n; i += 256) {
     float v = scores[(size_t)i * ld_s];
@@ -115,15 +120,15 @@ __global__ void __launch_bounds__(256) decode_kernel(const float* __restrict__ s
 
 extern "C" int g6d_detector_assemble(const float* s0, const float* s1, const float* s2, int hc, int wc, int rfn,
                                      const float* mu_sigma, float clip, int hs, int ws, int scale_idx, int nch,
-                                     float* stacked, g6d_stream_t stream) {
+                                     float* stacked, int batch, g6d_stream_t stream) {
   if (!s0 || !s1 || !s2 || !mu_sigma || !stacked || hc <= 0 || wc <= 0 || (hc & 3) || (wc & 3) || rfn <= 0 ||
-      scale_idx < 0 || 3 * scale_idx + 3 > nch) {
+      scale_idx < 0 || 3 * scale_idx + 3 > nch || batch < 1 || batch > 65535) {
     g6d_set_error("detector_assemble: bad args (level-0 map must be a multiple of 4)"); return G6D_EINVAL;
   }
   LevelStats st;
   for (int l = 0; l < 3; ++l) { st.mu[l] = mu_sigma[2 * l]; st.sigma[l] = mu_sigma[2 * l + 1]; }
   const long long total = (long long)hs * ws * rfn;
-  hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, STREAM(stream), s0, s1, s2, hc,
+  hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)((total + 255) / 256), batch), dim3(256), 0, STREAM(stream), s0, s1, s2, hc,
                      wc, rfn, st, clip, hs, ws, scale_idx, nch, stacked);
   return g6d_check_launch("detector_assemble");
 }
@@ -140,9 +145,9 @@ extern "C" int g6d_detector_score_mlp_max(const float* stacked, int P, int rfn, 
 }
 
 extern "C" int g6d_detector_decode(const float* scores, int ld_s, const float* offset, int ld_o, const float* scale,
-                                   int ld_c, int hs, int ws, int pool_ratio, float* result, g6d_stream_t stream) {
-  if (!scores || !offset || !scale || !result || hs <= 0 || ws <= 0) { g6d_set_error("detector_decode: bad args"); return G6D_EINVAL; }
-  hipLaunchKernelGGL(decode_kernel, dim3(1), dim3(256), 0, STREAM(stream), scores, ld_s, offset, ld_o, scale, ld_c, hs, ws,
+                                   int ld_c, int hs, int ws, int pool_ratio, float* result, int batch, g6d_stream_t stream) {
+  if (!scores || !offset || !scale || !result || hs <= 0 || ws <= 0 || batch < 1) { g6d_set_error("detector_decode: bad args"); return G6D_EINVAL; }
+  hipLaunchKernelGGL(decode_kernel, dim3(batch), dim3(256), 0, STREAM(stream), scores, ld_s, offset, ld_o, scale, ld_c, hs, ws,
                      (float)pool_ratio, result);
   return g6d_check_launch("detector_decode");
 }

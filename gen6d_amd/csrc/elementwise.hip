@@ -35,7 +35,7 @@ __global__ void affine_act_pool_kernel(const float* __restrict__ in, int ld_in, 
     const bool has = scale != nullptr;
     f32x4 sc = {1, 1, 1, 1}, sh = {0, 0, 0, 0};
     if (has) {
-      const size_t o = (size_t)(per_n ? n : 0) * C + c;
+      const size_t o = (size_t)(per_n ? n / per_n : 0) * C + c;
       sc = *reinterpret_cast<const f32x4*>(scale + o); sh = *reinterpret_cast<const f32x4*>(shift + o);
     }
     f32x4 v;
@@ -65,7 +65,7 @@ __global__ void affine_act_avg_kernel(const float* __restrict__ in, int ld_in, c
   const bool has = scale != nullptr;
   f32x4 sc = {1, 1, 1, 1}, sh = {0, 0, 0, 0};
   if (has) {
-    const size_t o = (size_t)(per_n ? n : 0) * C + c;
+    const size_t o = (size_t)(per_n ? n / per_n : 0) * C + c;
     sc = *reinterpret_cast<const f32x4*>(scale + o); sh = *reinterpret_cast<const f32x4*>(shift + o);
   }
   f32x4 s = {0, 0, 0, 0};
@@ -91,7 +91,7 @@ __global__ void upsample_bilinear_kernel(const float* __restrict__ in, int ld_in
     const bool has = scale != nullptr;
     f32x4 sc = {1, 1, 1, 1}, sh = {0, 0, 0, 0};
     if (has) {
-      const size_t o = (size_t)(per_n ? n : 0) * C + c;
+      const size_t o = (size_t)(per_n ? n / per_n : 0) * C + c;
       sc = *reinterpret_cast<const f32x4*>(scale + o); sh = *reinterpret_cast<const f32x4*>(shift + o);
     }
     const float* b = in + (size_t)n * H * W * ld_in + c;
@@ -153,6 +153,12 @@ __global__ void __launch_bounds__(256) l2norm_rows_kernel(float* __restrict__ x,
   if (row >= rows) return;
   float* p = x + (size_t)row * ld;
   float s = 0.f;
+  if ((ld & 3) || (reinterpret_cast<uintptr_t>(x) & 15)) {      // rows not 16-byte aligned (e.g. the [qn][7] regressor rows): scalar accesses
+    for (int c = lane; c < C; c += 64) s += p[c] * p[c];
+    const float inv = 1.f / fmaxf(sqrtf(wave_sum(s)), 1e-12f);
+    for (int c = lane; c < C; c += 64) p[c] *= inv;
+    return;
+  }
   for (int c = lane * 4; c < C; c += 256) {
     const f32x4 v = *reinterpret_cast<const f32x4*>(p + c);
     s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
@@ -184,12 +190,14 @@ __global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* __restri
   }
 }
 
-// InstanceNorm2d(3) of vps[ch][D] over D (biased var, eps 1e-5); one block per channel.
+// InstanceNorm2d(3) of vps[ch][D] over D (biased var, eps 1e-5); one block per (channel, query of the batch): vps [batch][3][D],
+// feats [batch * D][ld].
 __global__ void __launch_bounds__(256) vps_norm_kernel(const float* __restrict__ vps, int D, float* __restrict__ feats,
                                                        int ld, int c_off) {
   __shared__ double red[2][4];
   const int ch = blockIdx.x;
-  const float* v = vps + (size_t)ch * D;
+  const float* v = vps + ((size_t)blockIdx.y * 3 + ch) * D;
+  feats += (size_t)blockIdx.y * D * ld;
   double s1 = 0, s2 = 0;
   for (int i = threadIdx.x; i < D; i += 256) { double x = v[i]; s1 += x; s2 += x * x; }
   s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
@@ -208,6 +216,7 @@ __global__ void max_an_add_kernel(const float* __restrict__ in, int ld_in, int r
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rfn * C) return;
   int c = i % C, r = i / C;
+  in += (size_t)blockIdx.y * rfn * an * ld_in; out += (size_t)blockIdx.y * rfn * ld_out;      // query of the batch; embed is shared
   float m = in[(size_t)(r * an) * ld_in + c];
   for (int a = 1; a < an; ++a) m = fmaxf(m, in[(size_t)(r * an + a) * ld_in + c]);
   out[(size_t)r * ld_out + c] = m + embed[(size_t)r * C + c];
@@ -230,12 +239,13 @@ __global__ void __launch_bounds__(64) layernorm_kernel(const float* __restrict__
 
 __global__ void affine_act_add_kernel(const float* __restrict__ in, int ld_in, const float* __restrict__ scale,
                                       const float* __restrict__ shift, int relu, const float* __restrict__ res,
-                                      int ld_res, int n, int C, float* __restrict__ out, int ld_out) {
+                                      int ld_res, int n, int C, float* __restrict__ out, int ld_out, int rows_per_group) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n * C) return;
   int c = i % C, r = i / C;
   float v = in[(size_t)r * ld_in + c];
-  if (scale) v = v * scale[c] + shift[c];
+  const int g = rows_per_group > 0 ? r / rows_per_group : 0;          // one affine table per run of rows (query of the batch)
+  if (scale) v = v * scale[(size_t)g * C + c] + shift[(size_t)g * C + c];
   if (relu) v = fmaxf(v, 0.f);
   if (res) v += res[(size_t)r * ld_res + c];
   out[(size_t)r * ld_out + c] = v;
@@ -249,6 +259,8 @@ __global__ void __launch_bounds__(64) attention_kernel(const float* __restrict__
   const int dh = C / heads;
   float* qs = sm; float* pr = sm + dh;
   const int h = blockIdx.x % heads, i = blockIdx.x / heads, lane = threadIdx.x;
+  // blockIdx.y = query of the batch: attention runs among the n tokens of one query
+  q += (size_t)blockIdx.y * n * ld; k += (size_t)blockIdx.y * n * ld; v += (size_t)blockIdx.y * n * ld; out += (size_t)blockIdx.y * n * ld_out;
   for (int d = lane; d < dh; d += 64) qs[d] = q[(size_t)i * ld + d * heads + h];
   __syncthreads();
   const float inv = 1.f / sqrtf((float)dh);
@@ -418,33 +430,33 @@ extern "C" int g6d_nchw_to_nhwc(const float* in, int N, int C, int H, int W, int
 }
 
 extern "C" int g6d_l2norm_rows(float* x, int rows, int C, int ld, g6d_stream_t stream) {
-  if (!x || rows <= 0 || C <= 0 || (C & 3) || (ld & 3) || ld < C || !g6d_aligned16(x)) {
-    g6d_set_error("l2norm_rows: bad args (C and ld multiples of 4, 16-byte aligned)"); return G6D_EINVAL;
+  if (!x || rows <= 0 || C <= 0 || ld < C || (!(ld & 3) && g6d_aligned16(x) && (C & 3))) {
+    g6d_set_error("l2norm_rows: bad args (C a multiple of 4 on the 16-byte aligned path)"); return G6D_EINVAL;
   }
   hipLaunchKernelGGL(l2norm_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, STREAM(stream), x, rows, C, ld);
   return g6d_check_launch("l2norm_rows");
 }
 
-extern "C" int g6d_vps_norm(const float* vps, int D, float* feats, int ld, int c_off, g6d_stream_t stream) {
-  if (!vps || !feats || D <= 0) { g6d_set_error("vps_norm: bad args"); return G6D_EINVAL; }
-  hipLaunchKernelGGL(vps_norm_kernel, dim3(3), dim3(256), 0, STREAM(stream), vps, D, feats, ld, c_off);
+extern "C" int g6d_vps_norm(const float* vps, int D, float* feats, int ld, int c_off, int batch, g6d_stream_t stream) {
+  if (!vps || !feats || D <= 0 || batch < 1 || batch > 65535) { g6d_set_error("vps_norm: bad args"); return G6D_EINVAL; }
+  hipLaunchKernelGGL(vps_norm_kernel, dim3(3, batch), dim3(256), 0, STREAM(stream), vps, D, feats, ld, c_off);
   return g6d_check_launch("vps_norm");
 }
 
 extern "C" int g6d_max_an_add(const float* in, int ld_in, int rfn, int an, int C, const float* embed, float* out,
-                              int ld_out, g6d_stream_t stream) {
-  if (!in || !embed || !out || rfn <= 0 || an <= 0 || C <= 0) { g6d_set_error("max_an_add: bad args"); return G6D_EINVAL; }
-  hipLaunchKernelGGL(max_an_add_kernel, dim3((rfn * C + 255) / 256), dim3(256), 0, STREAM(stream), in, ld_in, rfn, an, C,
+                              int ld_out, int batch, g6d_stream_t stream) {
+  if (!in || !embed || !out || rfn <= 0 || an <= 0 || C <= 0 || batch < 1 || batch > 65535) { g6d_set_error("max_an_add: bad args"); return G6D_EINVAL; }
+  hipLaunchKernelGGL(max_an_add_kernel, dim3((rfn * C + 255) / 256, batch), dim3(256), 0, STREAM(stream), in, ld_in, rfn, an, C,
                      embed, out, ld_out);
   return g6d_check_launch("max_an_add");
 }
 
 extern "C" int g6d_attention(const float* q, const float* k, const float* v, int ld, int n, int C, int heads, float* out,
-                             int ld_out, g6d_stream_t stream) {
-  if (!q || !k || !v || !out || n <= 0 || heads <= 0 || C % heads) { g6d_set_error("attention: bad args"); return G6D_EINVAL; }
+                             int ld_out, int batch, g6d_stream_t stream) {
+  if (!q || !k || !v || !out || n <= 0 || heads <= 0 || C % heads || batch < 1 || batch > 65535) { g6d_set_error("attention: bad args"); return G6D_EINVAL; }
   size_t lds = (size_t)(C / heads + n) * sizeof(float);
   if (lds > 60000) { g6d_set_error("attention: n too large"); return G6D_EINVAL; }
-  hipLaunchKernelGGL(attention_kernel, dim3(n * heads), dim3(64), lds, STREAM(stream), q, k, v, ld, n, C, heads, out, ld_out);
+  hipLaunchKernelGGL(attention_kernel, dim3(n * heads, batch), dim3(64), lds, STREAM(stream), q, k, v, ld, n, C, heads, out, ld_out);
   return g6d_check_launch("attention");
 }
 
@@ -457,10 +469,10 @@ extern "C" int g6d_layernorm(const float* in, int ld_in, int n, int C, const flo
 
 extern "C" int g6d_affine_act_add(const float* in, int ld_in, const float* scale, const float* shift, int relu,
                                   const float* residual, int ld_res, int n, int C, float* out, int ld_out,
-                                  g6d_stream_t stream) {
-  if (!in || !out || n <= 0 || C <= 0 || (scale && !shift)) { g6d_set_error("affine_act_add: bad args"); return G6D_EINVAL; }
+                                  int rows_per_group, g6d_stream_t stream) {
+  if (!in || !out || n <= 0 || C <= 0 || (scale && !shift) || rows_per_group < 0) { g6d_set_error("affine_act_add: bad args"); return G6D_EINVAL; }
   hipLaunchKernelGGL(affine_act_add_kernel, dim3((n * C + 255) / 256), dim3(256), 0, STREAM(stream), in, ld_in, scale,
-                     shift, relu, residual, ld_res, n, C, out, ld_out);
+                     shift, relu, residual, ld_res, n, C, out, ld_out, rows_per_group);
   return g6d_check_launch("affine_act_add");
 }
 

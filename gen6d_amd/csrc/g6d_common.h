@@ -93,7 +93,10 @@ __device__ __forceinline__ void g6d_finalize_stats(const G6dFin& f, int nblocks,
   __syncthreads();
   if (threadIdx.x == 0) {
     const int last = __hip_atomic_fetch_add(f.counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nblocks - 1;
-    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (last) {
+      __hip_atomic_store(f.counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-arm: zero at rest, like the split counters
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
     *flag = last;
   }
   __syncthreads();

@@ -80,9 +80,13 @@ __global__ void __launch_bounds__(256, 4) refiner_volume_kernel(const float* __r
                                                              const float* __restrict__ lin, int rfn, int fh, int fw,
                                                              int C, float h_in, float w_in, int sn,
                                                              float* __restrict__ mean_in, float* __restrict__ stdv) {
-  const float* __restrict__ rot = vw.rot;
+  // blockIdx.y = query of the batch (g6d_refiner_volume_kp): its views, cameras and volumes follow those of the previous query
+  const int bq = blockIdx.y;
+  const float* __restrict__ rot = vw.rot + bq * 12;
   const int rl = vw.rot_ld;
   const int nvox = sn * sn * sn;
+  feats += (size_t)bq * (rfn + 1) * fh * fw * C;
+  mean_in += (size_t)bq * nvox * 2 * C; stdv += (size_t)bq * nvox * C;
   int half = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;         // one half-wave per voxel
   const int l32 = threadIdx.x & 31;
   const bool live = half < nvox;                                   // (whole half-waves; keep them for the shuffles)
@@ -102,8 +106,8 @@ __global__ void __launch_bounds__(256, 4) refiner_volume_kernel(const float* __r
 #pragma unroll
     for (int e = 0; e < 12; ++e) P[e] = vw.projs[myview * 12 + e];
   } else {
-    const float* K = myview < rfn ? vw.ref_Ks + myview * 9 : vw.K_in;
-    const float* T = myview < rfn ? vw.ref_poses + myview * 12 : vw.pose_in;
+    const float* K = myview < rfn ? vw.ref_Ks + (bq * rfn + myview) * 9 : vw.K_in + bq * 9;
+    const float* T = myview < rfn ? vw.ref_poses + (bq * rfn + myview) * 12 : vw.pose_in + bq * 12;
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -153,14 +157,14 @@ extern "C" int g6d_refiner_volume(const float* feats, const float* projs, const 
 // pose_in read in place — no matrix-product, concatenation or copy launches in front of the kernel.
 extern "C" int g6d_refiner_volume_kp(const float* feats, const float* ref_Ks, const float* ref_poses, const float* K_in,
                                      const float* pose_in, const float* lin, int rfn, int fh, int fw, int C, int h_in, int w_in, int sn,
-                                     float* mean_in, float* stdv, g6d_stream_t stream) {
+                                     float* mean_in, float* stdv, int batch, g6d_stream_t stream) {
   if (!feats || !ref_Ks || !ref_poses || !K_in || !pose_in || !lin || !mean_in || !stdv || rfn < 1 || rfn > MAX_RFN || (C & 3) ||
-      sn < 1 || sn > 256 || !g6d_aligned16(feats) || !g6d_aligned16(mean_in) || !g6d_aligned16(stdv)) {
+      sn < 1 || sn > 256 || batch < 1 || batch > 65535 || !g6d_aligned16(feats) || !g6d_aligned16(mean_in) || !g6d_aligned16(stdv)) {
     g6d_set_error("refiner_volume_kp: bad args (1 <= rfn <= 8, C % 4 == 0)"); return G6D_EINVAL;
   }
   const long long threads = (long long)sn * sn * sn * 32;
   const VolViews vw = {nullptr, ref_Ks, ref_poses, K_in, pose_in, pose_in, 4};
-  hipLaunchKernelGGL(refiner_volume_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+  hipLaunchKernelGGL(refiner_volume_kernel, dim3((unsigned)((threads + 255) / 256), batch), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), feats, vw, lin, rfn, fh, fw, C, (float)h_in, (float)w_in, sn,
                      mean_in, stdv);
   return g6d_check_launch("refiner_volume_kp");

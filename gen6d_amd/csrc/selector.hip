@@ -86,73 +86,85 @@ __global__ void __launch_bounds__(64) vps_kernel(const float* __restrict__ score
   if (lane == 0) vps[d] = acc;
 }
 
-// All pyramid levels of one query in ONE launch: block kinds
-//   [0, nlev*D)            level l = b / D, hypothesis d = b % D: the HW_l rows of refs_l[d] against the query rows (16 waves x 4 rows
-//                          in flight, 16-byte loads: 128 KB of reference rows requested per block and pass), scores kept in LDS,
-//                          then vps_l[d] = sum_hw S * (S / max_hw S) by wave 0 — the score map only goes to memory if the caller
-//                          wants it;
-//   [nlev*D, +nlev*C/16)   InstanceNorm affine of the product for 16 channels of level l: 64 position lanes, fp64.
-// Largest level first, so that its blocks (HW_0 = 256 rows = 512 KB each) start before the short ones fill in.
-struct SelLevel { const float* que; const float* refs; const double* r1; const double* r2; float* score_map; float* vps;
-                  float* scale; float* shift; int HW; int pad; };
-struct SelArgs { SelLevel lv[3]; int nlev, D, C; double inv_dg, eps; };
+// All pyramid levels of a BATCH of queries in ONE launch (network/selector.py:165-175 takes [qn,...] queries): block kinds
+//   scan blocks    (level l, hypothesis d, part pt): rows [64 pt, 64 pt + 64) of refs_l[d] — 16 waves x 4 rows, 16-byte non-temporal
+//                  loads, 128 KB of reference rows requested per block — against the same rows of ALL qn queries (L2 resident):
+//                  the reference cache is streamed once per BATCH, and level 0 (HW = 256) is cut into four parts so that 256 CUs
+//                  are evenly loaded (round 2: one 512 KB block per level-0 hypothesis, 320 of them on 256 CUs).  Scores go to
+//                  score_maps[l][q][d][row];
+//   affine blocks  (query q, level l, 16 channels): InstanceNorm affine of the never-materialised product, 64 position lanes, fp64.
+// The largest level comes first.  vps_levels_kernel then reduces every (q, l, d) score row: vps = sum_hw S * (S / max_hw S).
+struct SelLevel { const float* que; const float* refs; const double* r1; const double* r2; float* score_map; int HW, parts, blk0, pad; };
+struct SelArgs { SelLevel lv[3]; int nlev, qn, D, C, scan_blocks; double inv_dg, eps; float* vps; float* scale; float* shift; };
 #define SEL_MAX_HW 1024
+#define SEL_MAX_QN 8
 
+// QN = compile-time bound of the batch (1, 2, 4, 8): the score accumulators of a wave are 4 rows x QN registers
+template <int QN>
 __global__ void __launch_bounds__(1024) selector_levels_kernel(const SelArgs a) {
   __shared__ double sm[64][16 + 1], se[64][16 + 1];
-  __shared__ float sc[SEL_MAX_HW];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int b = blockIdx.x;
-  if (b < a.nlev * a.D) {
-    const int l = b / a.D, d = b - l * a.D;
-    const SelLevel& L = a.lv[l];
-    const int HW = L.HW, C = a.C;
-    const float* refs = L.refs + (size_t)d * HW * C;
-    for (int row0 = wave * 4; row0 < HW; row0 += 64) {
-      float s[4] = {0.f, 0.f, 0.f, 0.f};
+  if (b < a.scan_blocks) {
+    int l = 0;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int row = row0 + u;
-        if (row < HW) {
-          const float* r = refs + (size_t)row * C;
-          const float* q = L.que + (size_t)row * C;
-          for (int c = lane * 4; c < C; c += 256) {
-            const f32x4 rv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(r + c));     // streamed once per query
-            const f32x4 qv = *reinterpret_cast<const f32x4*>(q + c);
-            s[u] += rv[0] * qv[0] + rv[1] * qv[1] + rv[2] * qv[2] + rv[3] * qv[3];
+    for (int k = 1; k < 3; ++k) l = (k < a.nlev && b >= a.lv[k].blk0) ? k : l;
+    const SelLevel& L = a.lv[l];
+    b -= L.blk0;
+    const int d = b / L.parts, pt = b - d * L.parts;
+    const int HW = L.HW, C = a.C, qn = a.qn;
+    const int row0 = pt * 64 + wave * 4;
+    if (row0 >= HW) return;
+    const float* refs = L.refs + ((size_t)d * HW + row0) * C;
+    const size_t qstride = (size_t)HW * C;
+    float s[4][QN];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int q = 0; q < QN; ++q) s[u][q] = 0.f;
+    for (int c = lane * 4; c < C; c += 256) {
+      f32x4 rv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)      // rows beyond HW re-read the last row (discarded below): unconditional loads pipeline
+        rv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(refs + (size_t)min(u, HW - 1 - row0) * C + c));
+#pragma unroll
+      for (int q = 0; q < QN; ++q) {
+        if (q < qn) {
+          const float* qr = L.que + q * qstride + (size_t)row0 * C + c;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const f32x4 qv = *reinterpret_cast<const f32x4*>(qr + (size_t)min(u, HW - 1 - row0) * C);
+            s[u][q] += rv[u][0] * qv[0] + rv[u][1] * qv[1] + rv[u][2] * qv[2] + rv[u][3] * qv[3];
           }
         }
       }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const float t = wave_sum(s[u]);
-        if (lane == 0 && row0 + u < HW) { sc[row0 + u] = t; if (L.score_map) L.score_map[(size_t)d * HW + row0 + u] = t; }
-      }
     }
-    __syncthreads();
-    if (wave == 0) {
-      float mx = -INFINITY;
-      for (int p = lane; p < HW; p += 64) mx = fmaxf(mx, sc[p]);
-      mx = wave_max(mx);
-      float acc = 0.f;
-      for (int p = lane; p < HW; p += 64) { const float v = sc[p]; acc += v * (v / mx); }
-      acc = wave_sum(acc);
-      if (lane == 0) L.vps[d] = acc;
+#pragma unroll
+    for (int q = 0; q < QN; ++q) {
+      if (q < qn) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float t = wave_sum(s[u][q]);
+          if (lane == 0 && row0 + u < HW) L.score_map[((size_t)q * a.D + d) * HW + row0 + u] = t;
+        }
+      }
     }
     return;
   }
-  b -= a.nlev * a.D;
+  b -= a.scan_blocks;
   const int groups = (a.C + 15) / 16;
-  const int l = b / groups, cg = b - l * groups;
+  const int q = b / (a.nlev * groups), r = b - q * (a.nlev * groups);
+  const int l = r / groups, cg = r - l * groups;
   const SelLevel& L = a.lv[l];
+  const float* que = L.que + (size_t)q * L.HW * a.C;
   const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
   const int c = cg * 16 + cl;
   double m = 0, e = 0;
   if (c < a.C)
     for (int p = pl; p < L.HW; p += 64) {
-      const double q = L.que[(size_t)p * a.C + c];
-      m += q * L.r1[(size_t)p * a.C + c];
-      e += q * q * L.r2[(size_t)p * a.C + c];
+      const double qv = que[(size_t)p * a.C + c];
+      m += qv * L.r1[(size_t)p * a.C + c];
+      e += qv * qv * L.r2[(size_t)p * a.C + c];
     }
   sm[pl][cl] = m; se[pl][cl] = e;
   __syncthreads();
@@ -164,37 +176,65 @@ __global__ void __launch_bounds__(1024) selector_levels_kernel(const SelArgs a) 
     m *= inv_n; e *= inv_n;
     double var = e - m * m; if (var < 0) var = 0;
     const double rs = 1.0 / sqrt(var + a.eps);
-    L.scale[c] = (float)rs; L.shift[c] = (float)(-m * rs);
+    a.scale[((size_t)q * a.nlev + l) * a.C + c] = (float)rs; a.shift[((size_t)q * a.nlev + l) * a.C + c] = (float)(-m * rs);
   }
+}
+
+// vps[q][l][d] = sum_hw S * (S / max_hw S) (network/selector.py:192-195); one wave per (q, l, d) score row.
+__global__ void __launch_bounds__(256) vps_levels_kernel(const SelArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int per_q = a.nlev * a.D;
+  if (w >= a.qn * per_q) return;
+  const int q = w / per_q, r = w - q * per_q, l = r / a.D, d = r - l * a.D;
+  const SelLevel& L = a.lv[l];
+  const float* s = L.score_map + ((size_t)q * a.D + d) * L.HW;
+  float mx = -INFINITY;
+  for (int p = lane; p < L.HW; p += 64) mx = fmaxf(mx, s[p]);
+  mx = wave_max(mx);
+  float acc = 0.f;
+  for (int p = lane; p < L.HW; p += 64) { const float v = s[p]; acc += v * (v / mx); }
+  acc = wave_sum(acc);
+  if (lane == 0) a.vps[w] = acc;
 }
 
 }  // namespace
 
 #define STREAM(s) reinterpret_cast<hipStream_t>(s)
 
-// network/selector.py:183-195 + 28,49,63 for all pyramid levels of a query at once.  Per level l < nlev (<= 3): que[l] [HW_l][C],
-// refs[l] [D][HW_l][C], r1[l] / r2[l] [HW_l][C] (g6d_selector_ref_sums) -> vps [nlev][D], scale / shift [nlev][C] (the
-// InstanceNorm3d affine of the never-materialised product over Dg * HW_l values; Dg = global hypothesis count, = D unless the
-// references are sharded), score_maps[l] [D][HW_l] only where the pointer is non-NULL.
-extern "C" int g6d_selector_levels(int nlev, const float* const* que, const float* const* refs, const double* const* r1,
+// network/selector.py:183-195 + 28,49,63 for all pyramid levels of a batch of qn <= 8 queries at once.  Per level l < nlev (<= 3):
+// que[l] [qn][HW_l][C], refs[l] [D][HW_l][C], r1[l] / r2[l] [HW_l][C] (g6d_selector_ref_sums), score_maps[l] [qn][D][HW_l] (written;
+// the cosine score maps of selector.py:192) -> vps [qn][nlev][D], scale / shift [qn][nlev][C] (the InstanceNorm3d affine of the
+// never-materialised product over Dg * HW_l values; Dg = global hypothesis count, = D unless the references are sharded).
+extern "C" int g6d_selector_levels(int nlev, int qn, const float* const* que, const float* const* refs, const double* const* r1,
                                    const double* const* r2, const int* HW, int D, int Dg, int C, double eps, float* const* score_maps,
                                    float* vps, float* scale, float* shift, g6d_stream_t stream) {
-  if (nlev < 1 || nlev > 3 || !que || !refs || !r1 || !r2 || !HW || !vps || !scale || !shift || D <= 0 || Dg <= 0 || C <= 0 || (C & 3)) {
-    g6d_set_error("selector_levels: bad args"); return G6D_EINVAL;
+  if (nlev < 1 || nlev > 3 || qn < 1 || qn > SEL_MAX_QN || !que || !refs || !r1 || !r2 || !HW || !score_maps || !vps || !scale || !shift ||
+      D <= 0 || Dg <= 0 || C <= 0 || (C & 3)) {
+    g6d_set_error("selector_levels: bad args (1 <= qn <= 8, score_maps required)"); return G6D_EINVAL;
   }
   SelArgs a = {};
-  a.nlev = nlev; a.D = D; a.C = C; a.inv_dg = 1.0 / (double)Dg; a.eps = eps;
+  a.nlev = nlev; a.qn = qn; a.D = D; a.C = C; a.inv_dg = 1.0 / (double)Dg; a.eps = eps; a.vps = vps; a.scale = scale; a.shift = shift;
+  int blk = 0;
   for (int l = 0; l < nlev; ++l) {
-    if (!que[l] || !refs[l] || !r1[l] || !r2[l] || HW[l] <= 0 || HW[l] > SEL_MAX_HW || !g6d_aligned16(que[l]) || !g6d_aligned16(refs[l]) ||
-        (long long)D * HW[l] > (1ll << 30)) {
+    if (!que[l] || !refs[l] || !r1[l] || !r2[l] || !score_maps[l] || HW[l] <= 0 || HW[l] > SEL_MAX_HW || !g6d_aligned16(que[l]) ||
+        !g6d_aligned16(refs[l]) || (long long)D * HW[l] > (1ll << 30)) {
       g6d_set_error("selector_levels: bad level (HW <= 1024, 16-byte aligned operands)"); return G6D_EINVAL;
     }
-    a.lv[l] = SelLevel{que[l], refs[l], r1[l], r2[l], score_maps ? score_maps[l] : nullptr, vps + (size_t)l * D, scale + (size_t)l * C,
-                       shift + (size_t)l * C, HW[l], 0};
+    const int parts = (HW[l] + 63) / 64;
+    a.lv[l] = SelLevel{que[l], refs[l], r1[l], r2[l], score_maps[l], HW[l], parts, blk, 0};
+    blk += D * parts;
   }
-  const int blocks = nlev * D + nlev * ((C + 15) / 16);
-  hipLaunchKernelGGL(selector_levels_kernel, dim3(blocks), dim3(1024), 0, STREAM(stream), a);
-  return g6d_check_launch("selector_levels");
+  a.scan_blocks = blk;
+  const int blocks = blk + qn * nlev * ((C + 15) / 16);
+  if (qn == 1) hipLaunchKernelGGL(selector_levels_kernel<1>, dim3(blocks), dim3(1024), 0, STREAM(stream), a);
+  else if (qn == 2) hipLaunchKernelGGL(selector_levels_kernel<2>, dim3(blocks), dim3(1024), 0, STREAM(stream), a);
+  else if (qn <= 4) hipLaunchKernelGGL(selector_levels_kernel<4>, dim3(blocks), dim3(1024), 0, STREAM(stream), a);
+  else hipLaunchKernelGGL(selector_levels_kernel<8>, dim3(blocks), dim3(1024), 0, STREAM(stream), a);
+  int rc = g6d_check_launch("selector_levels");
+  if (rc != G6D_OK) return rc;
+  hipLaunchKernelGGL(vps_levels_kernel, dim3((qn * nlev * D + 3) / 4), dim3(256), 0, STREAM(stream), a);
+  return g6d_check_launch("selector_vps_levels");
 }
 
 extern "C" int g6d_selector_ref_sums(const float* refs, int D, int HW, int C, double* r1, double* r2, g6d_stream_t stream) {

@@ -53,8 +53,10 @@ namespace {
 // The same kernel also runs the stride-1 3x3 / 3x3x3 layers of the selector, the refiner feature net and the refiner volume
 // net when g6d_conv_igemm finds pre-transformed filters in G6dConv.weight_wino (template parameters):
 //   MODE  operand prologue applied when the raw patch is written to LDS, as in conv_igemm.hip: 0 none, 1 InstanceNorm
-//         affine(+ReLU) with one table, 2 one table per image, 3 elementwise multiplier (selector query x reference
-//         product) + affine; zero padding stays exactly zero.  The affine tables sit in LDS (loaded once per block).
+//         affine(+ReLU) with one table, 2 one table per image group (image / aff_div; LDS holds the tables of the block's four
+//         quarters), 3 elementwise multiplier (selector query x reference product) + affine, tables per quarter as in 2 — a
+//         batch of queries shares the reference images (img_mod) while each query brings its own multiplier map (mul_div) and
+//         table; zero padding stays exactly zero.  The affine tables sit in LDS (loaded once per block).
 //   KD    3: 3x3x3 layers as a 2-D Winograd over (h, w) with the three depth taps folded into the reduction: chunk c =
 //         (kd, 8 input channels) reads depth slice d + kd - 1 — the transform-domain accumulators are shared, so the
 //         multiplication count drops from 27 to 12 per output.
@@ -79,7 +81,9 @@ struct WinoArgs {
   // conv-family extras (zero / null for the trunk)
   int D;                                         // depth slices per image (1 for 2-D layers); KD = 3 pads in depth
   const float* mul; const float* in_scale; const float* in_shift; int in_relu;
-  double* stats; int stats_per_image;            // [groups][Cout][2]; groups = images (N / D) or 1
+  int aff_div;                                   // MODE 2 / 3: image i uses affine table i / aff_div (0: one table)
+  int img_mod, mul_div;                          // > 0: image i reads input image i % img_mod / multiplier map i / mul_div (G6dConv)
+  double* stats; int stats_div;                  // [groups][Cout][2]; group of image i = i / stats_div (0: one group)
   G6dFin fin;                                    // fin.scale != NULL: the last block finalises the statistics
 };
 
@@ -158,11 +162,12 @@ __global__ void __launch_bounds__(128 * NWN, 1) wino_conv3x3_kernel(const WinoAr
     const int n = g.n;
     const int iy = g.oy0 + py - 1, ix = g.ox0 + px - 1;
     pval[j] = (idx < 800) & g.valid & ((unsigned)iy < (unsigned)g.H) & ((unsigned)ix < (unsigned)g.W);
-    poff[j] = pval[j] ? g.in_off + ((n * g.H + iy) * g.W + ix) * g.ld_in + 4 * half : 0;
+    const int n_in = p.img_mod > 0 ? ((n / p.D) % p.img_mod) * p.D + n % p.D : n;      // query batches share the input images
+    poff[j] = pval[j] ? g.in_off + ((n_in * g.H + iy) * g.W + ix) * g.ld_in + 4 * half : 0;
     live[j] = idx < 800;
     lsto[j] = live[j] ? (q * WQ_PIX + pp) * WRAW_LD + 4 * (half ^ ((py >> 1) & 1)) : WRAW_FLOATS + WU_FLOATS + 4 * tid;
-    if constexpr (MODE == 3) moff[j] = pval[j] ? (iy * p.W + ix) * p.Cin + 4 * half : 0;
-    if constexpr (MODE != 0) aoff[j] = (MODE == 2 ? (q < 4 ? q : 0) * p.Cin : 0) + 4 * half;
+    if constexpr (MODE == 3) moff[j] = pval[j] ? (((p.mul_div > 0 ? n / p.mul_div : 0) * p.H + iy) * p.W + ix) * p.Cin + 4 * half : 0;
+    if constexpr (MODE != 0) aoff[j] = (MODE >= 2 ? (q < 4 ? q : 0) * p.Cin : 0) + 4 * half;
     if constexpr (KD == 3) { const int dd = n % p.D; dbits |= (unsigned)(dd > 0) << (2 * j) | (unsigned)(dd < p.D - 1) << (2 * j + 1); }
   }
   unsigned pboff[MODE == 0 && KD == 1 ? NPR : 1];            // byte offsets of the pieces for the buffer loads (beyond the tensor: zero)
@@ -205,7 +210,7 @@ __global__ void __launch_bounds__(128 * NWN, 1) wino_conv3x3_kernel(const WinoAr
       if constexpr (MODE == 3) v *= rm[j];
       if constexpr (MODE != 0) {
         const f32x4 sc = *reinterpret_cast<const f32x4*>(lds + AFF0 + aoff[j] + cc * 8);
-        const f32x4 sh = *reinterpret_cast<const f32x4*>(lds + AFF0 + (MODE == 2 ? 4 : 1) * p.Cin + aoff[j] + cc * 8);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(lds + AFF0 + (MODE >= 2 ? 4 : 1) * p.Cin + aoff[j] + cc * 8);
         v = v * sc + sh;
         if (p.in_relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
       }
@@ -219,11 +224,11 @@ __global__ void __launch_bounds__(128 * NWN, 1) wino_conv3x3_kernel(const WinoAr
     for (int j = 0; j < NPR; ++j) store_piece(j, st, chunk);
   };
   if constexpr (MODE != 0) {                  // InstanceNorm affine tables -> LDS: [G][Cin] scales, then [G][Cin] shifts
-    constexpr int G = MODE == 2 ? 4 : 1;
+    constexpr int G = MODE >= 2 ? 4 : 1;
     for (int i = tid; i < G * p.Cin; i += THREADS) {
       int g = 0;
-      if constexpr (MODE == 2) g = quarter_of(p, i / p.Cin).n / p.D;
-      const int c = MODE == 2 ? i % p.Cin : i;
+      if constexpr (MODE >= 2) g = p.aff_div > 0 ? (quarter_of(p, i / p.Cin).n / p.D) / p.aff_div : 0;
+      const int c = MODE >= 2 ? i % p.Cin : i;
       lds[AFF0 + i] = p.in_scale[g * p.Cin + c];
       lds[AFF0 + G * p.Cin + i] = p.in_shift[g * p.Cin + c];
     }
@@ -454,7 +459,7 @@ __global__ void __launch_bounds__(128 * NWN, 1) wino_conv3x3_kernel(const WinoAr
       for (int q = 0; q < 4; ++q) {
         const QGeo qg = quarter_of(p, q);
         if (!qg.valid) break;
-        const int g = p.stats_per_image ? qg.n / p.D : 0;
+        const int g = p.stats_div > 0 ? (qg.n / p.D) / p.stats_div : 0;
         if (g != cur && cur >= 0) {
           double* st = p.stats + ((size_t)cur * p.Cout + n0 + tid) * 2;
           atomicAdd(st, a1); atomicAdd(st + 1, a2); a1 = a2 = 0.0;
@@ -479,7 +484,7 @@ __global__ void __launch_bounds__(128 * NWN, 1) wino_conv3x3_kernel(const WinoAr
 template <int MODE, int KD, int NWN>
 int wino_launch_t(WinoArgs& a, long long blocks, hipStream_t stream) {
   constexpr int THREADS = 128 * NWN;
-  const size_t lds_bytes = (2 * (size_t)(WRAW_FLOATS + 16 * 32 * NWN * 8 + 4 * THREADS) + (MODE == 0 ? 0 : (MODE == 2 ? 8 : 2) * a.Cin)) * sizeof(float);
+  const size_t lds_bytes = (2 * (size_t)(WRAW_FLOATS + 16 * 32 * NWN * 8 + 4 * THREADS) + (MODE == 0 ? 0 : (MODE >= 2 ? 8 : 2) * a.Cin)) * sizeof(float);
   g6d_allow_lds(reinterpret_cast<const void*>(&wino_conv3x3_kernel<MODE, KD, NWN>), 160 * 1024);
   hipLaunchKernelGGL((wino_conv3x3_kernel<MODE, KD, NWN>), dim3((unsigned)blocks, a.Cout / (32 * NWN), a.splits), dim3(THREADS), lds_bytes,
                      stream, a);
@@ -501,7 +506,8 @@ int wino_run(WinoArgs& a, int mode, int kd, float* workspace, size_t workspace_b
   double out_elems = 0.0;
   for (int k = 0; k < a.nseg; ++k) {
     WinoSeg& g = a.seg[k];
-    in_extent = std::max(in_extent, (long long)g.in_off + (long long)g.N * g.H * g.W * g.ld_in);
+    const long long n_in = a.img_mod > 0 ? std::min<long long>(g.N, (long long)a.img_mod * a.D) : g.N;     // images actually read
+    in_extent = std::max(in_extent, (long long)g.in_off + n_in * g.H * g.W * g.ld_in);
     g.QH = (g.H + 7) / 8; g.QW = (g.W + 7) / 8;
     g.qstart = (int)quarters;
     quarters += (long long)g.N * g.QH * g.QW;
@@ -550,7 +556,8 @@ int wino_run(WinoArgs& a, int mode, int kd, float* workspace, size_t workspace_b
   static const bool debug = []() { const char* e = getenv("G6D_WINO_DEBUG"); return e && e[0] == '1'; }();
   if (debug) fprintf(stderr, "wino %d seg, N=%d %dx%dx%d->%d kd=%d mode=%d: grid %lld x %d splits of %d chunks\n", a.nseg, a.N, a.H, a.W, a.Cin,
                      a.Cout, kd, mode, grid2, splits, cps);
-  if (kd == 3) return mode == 1 ? wino_launch_w<1, 3>(a, blocks, nwn, stream) : wino_launch_w<0, 3>(a, blocks, nwn, stream);
+  if (kd == 3) return mode == 2 ? wino_launch_w<2, 3>(a, blocks, nwn, stream)
+                    : mode == 1 ? wino_launch_w<1, 3>(a, blocks, nwn, stream) : wino_launch_w<0, 3>(a, blocks, nwn, stream);
   if (mode == 3) return wino_launch_w<3, 1>(a, blocks, nwn, stream);
   if (mode == 2) return wino_launch_w<2, 1>(a, blocks, nwn, stream);
   if (mode == 1) return wino_launch_w<1, 1>(a, blocks, nwn, stream);
@@ -630,9 +637,10 @@ bool g6d_wino_eligible(const G6dConv& d) {
   const bool k2 = d.kd == 1 && d.Di == 1 && d.pd == 0, k3 = d.kd == 3 && d.pd == 1;
   if (!(k2 || k3) || d.kh != 3 || d.kw != 3 || d.ph != 1 || d.pw != 1 || d.sd != 1 || d.sh != 1 || d.sw != 1) return false;
   if ((d.Cin & 7) || (d.Cout & 31) || d.Hi < 6 || d.Wi < 6 || d.out_act > 1 || d.split_k > 1) return false;
-  if (d.mul && (!k2 || !d.in_scale || d.in_affine_per_n)) return false;
-  if (k3 && d.in_scale && d.in_affine_per_n) return false;
-  if (d.stats && d.stat_rows_per_group > 0 && d.stat_rows_per_group != d.Do * d.Ho * d.Wo) return false;
+  if (d.mul && (!k2 || !d.in_scale)) return false;
+  if ((d.in_image_mod > 0 || d.mul_group_images > 0) && !k2) return false;
+  if (d.stats && d.stat_rows_per_group > 0 && d.stat_rows_per_group % (d.Do * d.Ho * d.Wo)) return false;   // groups = runs of whole images
+  if (d.in_scale && d.Cin > 1024) return false;                          // affine tables of the block's four quarters in LDS
   if (!g6d_aligned16(d.weight_wino) || (d.in_scale && ((d.Cin & 3) != 0))) return false;
   // Profitability (measured per layer, profiles/r02_layer_table.md): a block pays ~4 us of prologue / output transform and the
   // kernel holds a whole SIMD per wave, so layers with a short reduction (K = kd*Cin < 128: 64-channel inputs) or little total work
@@ -642,7 +650,8 @@ bool g6d_wino_eligible(const G6dConv& d) {
   const double min_work = mw ? atof(mw) : 1.5e8;
   const double M = (double)d.N * d.Di * d.Hi * d.Wi, K = (double)d.kd * d.Cin;
   if (min_work > 0 && (K < 128 || M * K * d.Cout < min_work)) return false;
-  return (long long)d.N * d.Di * d.Hi * d.Wi * d.ld_in < (1ll << 29);      // 2^31 bytes: the bound of the buffer loads
+  if ((long long)d.N * d.Di * ((d.Hi + 7) / 8) * ((d.Wi + 7) / 8) >= (1ll << 31)) return false;           // quarter list
+  return (long long)(d.in_image_mod > 0 ? d.in_image_mod : d.N) * d.Di * d.Hi * d.Wi * d.ld_in < (1ll << 29);      // 2^31 bytes: the bound of the buffer loads
 }
 
 int g6d_wino_launch(const G6dConv& d, hipStream_t stream) {
@@ -651,7 +660,8 @@ int g6d_wino_launch(const G6dConv& d, hipStream_t stream) {
   a.D = d.Di; a.N = d.N * d.Di; a.H = d.Hi; a.W = d.Wi; a.Cin = d.Cin; a.ld_in = d.ld_in; a.Cout = d.Cout; a.ld_full = d.ld_out;
   a.ld_pool = 0; a.relu = d.out_act == 1;
   a.mul = d.mul; a.in_scale = d.in_scale; a.in_shift = d.in_shift; a.in_relu = d.in_relu;
-  a.stats = d.stats; a.stats_per_image = d.stat_rows_per_group > 0;
+  a.stats = d.stats; a.stats_div = d.stat_rows_per_group > 0 ? d.stat_rows_per_group / (d.Do * d.Ho * d.Wo) : 0;
+  a.aff_div = d.in_affine_per_n; a.img_mod = d.in_image_mod; a.mul_div = d.mul_group_images > 0 ? d.mul_group_images * d.Di : 0;
   if (d.fin_scale)
     a.fin = G6dFin{d.fin_scale, d.fin_shift, reinterpret_cast<int*>(d.fin_counter), d.stats, 1.0 / d.fin_count, d.fin_eps, d.fin_groups * d.Cout};
   const int mode = d.mul ? 3 : (!d.in_scale ? 0 : (d.in_affine_per_n ? 2 : 1));

@@ -17,7 +17,8 @@ class G6dWinoSeg(C.Structure):
 
 class G6dCorrSeg(C.Structure):
     """include/gen6d_hip.h: one map of g6d_corr2d_patch_multi."""
-    _fields_ = [("in_", C.c_void_p), ("out", C.c_void_p), ("H", C.c_int32), ("W", C.c_int32), ("ld_in", C.c_int32), ("ld_out", C.c_int32)]
+    _fields_ = [("in_", C.c_void_p), ("out", C.c_void_p), ("H", C.c_int32), ("W", C.c_int32), ("ld_in", C.c_int32), ("ld_out", C.c_int32),
+                ("N", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class G6dConv(C.Structure):
@@ -34,7 +35,8 @@ class G6dConv(C.Structure):
         ("stat_rows_per_group", C.c_int32), ("split_k", C.c_int32), ("math_mode", C.c_int32),
         ("weight_wino", C.c_void_p),
         ("fin_scale", C.c_void_p), ("fin_shift", C.c_void_p), ("fin_counter", C.c_void_p),
-        ("fin_count", C.c_double), ("fin_eps", C.c_double), ("fin_groups", C.c_int32), ("reserved_", C.c_int32),
+        ("fin_count", C.c_double), ("fin_eps", C.c_double), ("fin_groups", C.c_int32),
+        ("in_image_mod", C.c_int32), ("mul_group_images", C.c_int32), ("reserved_", C.c_int32),
     ]
 
 
@@ -61,17 +63,17 @@ SIGNATURES = {
     "g6d_selector_ref_sums": [_P, _I, _I, _I, _P, _P, _P],
     "g6d_selector_prod_affine": [_P, _P, _P, _I, _I, _I, _D, _P, _P, _P],
     "g6d_selector_scan": [_P, _P, _I, _I, _I, _P, _P, _P],
-    "g6d_selector_levels": [_I, _P, _P, _P, _P, _P, _I, _I, _I, _D, _P, _P, _P, _P, _P],
+    "g6d_selector_levels": [_I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _D, _P, _P, _P, _P, _P],
     "g6d_refiner_volume": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P],
-    "g6d_refiner_volume_kp": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P],
-    "g6d_detector_assemble": [_P, _P, _P, _I, _I, _I, C.POINTER(C.c_float), _F, _I, _I, _I, _I, _P, _P],
+    "g6d_refiner_volume_kp": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P],
+    "g6d_detector_assemble": [_P, _P, _P, _I, _I, _I, C.POINTER(C.c_float), _F, _I, _I, _I, _I, _P, _I, _P],
     "g6d_detector_score_mlp_max": [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P],
-    "g6d_detector_decode": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P],
-    "g6d_vps_norm": [_P, _I, _P, _I, _I, _P],
-    "g6d_max_an_add": [_P, _I, _I, _I, _I, _P, _P, _I, _P],
-    "g6d_attention": [_P, _P, _P, _I, _I, _I, _I, _P, _I, _P],
+    "g6d_detector_decode": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _I, _P],
+    "g6d_vps_norm": [_P, _I, _P, _I, _I, _I, _P],
+    "g6d_max_an_add": [_P, _I, _I, _I, _I, _P, _P, _I, _I, _P],
+    "g6d_attention": [_P, _P, _P, _I, _I, _I, _I, _P, _I, _I, _P],
     "g6d_layernorm": [_P, _I, _I, _I, _P, _P, _F, _P, _I, _P],
-    "g6d_affine_act_add": [_P, _I, _P, _P, _I, _P, _I, _I, _I, _P, _I, _P],
+    "g6d_affine_act_add": [_P, _I, _P, _P, _I, _P, _I, _I, _I, _P, _I, _I, _P],
     "g6d_linear_gemv": [_P, _I, _I, _P, _P, _I, _I, _P, _P],
     "g6d_chain_crop_from_detection": [_P, _F, _P, _P],
     "g6d_chain_pose_from_selection": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P],

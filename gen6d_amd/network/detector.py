@@ -23,6 +23,10 @@ from .params import ParamBank, fold_vgg
 
 # G6D_TRUNK_MULTI=0: one trunk pass per pyramid scale (A/B aid); default: one launch per layer over all scales
 _TRUNK_MULTI = os.environ.get("G6D_TRUNK_MULTI", "1") != "0"
+# G6D_CORR3_MULTI=0: the 3x3 correlation level as one generic-conv launch per scale (round 2); default: one corr_patch launch over all
+# scales, like the 15x15 and 7x7 levels
+_CORR3_MULTI = os.environ.get("G6D_CORR3_MULTI", "1") != "0"
+MAX_BATCH = 8        # queries that share one set of launches (g6d_selector_levels / g6d_linear_gemv take <= 8)
 
 
 class Detector(ParamBank):
@@ -87,58 +91,63 @@ class Detector(ParamBank):
         self._scores_from_feats(self.extract_feats(que_img), scale_idx, stacked, hs, ws)
 
     def _scores_from_pyramid(self, feats, scale_ids, stacked, hs, ws):
-        """All scales at once: the 15x15 and the 7x7 correlation level are ONE launch each over the maps of all scales (the tiles
-        of all maps form one work list: fewer splits, the small maps fill the chip the large one leaves over); the 3x3 level and
-        the assembly stay per scale."""
+        """All scales (and all queries of the batch) at once: every correlation level is ONE launch over the maps of all scales
+        (the tiles of all maps form one work list: fewer splits, the small maps fill the chip the large one leaves over); the
+        assembly is one launch per scale.  feats[i][l]: [qn,1,h,w,512]."""
         rfn = self.ref_center_feats[0].shape[0]
         dev = stacked.device
+        qn = feats[0][0].shape[0]
         maps = [[None] * 3 for _ in feats]
         for l, (wref, k) in enumerate(zip(self.ref_center_feats, self.ref_ksize)):
             xs = [f[l] for f in feats]
-            if k >= 7 and rfn <= 32 and len(xs) <= 4:
-                outs = ops.alloc_like_segments([(1, 1, x.shape[2], x.shape[3], rfn) for x in xs], dev)
+            if rfn <= 32 and len(xs) <= 4 and (k >= 7 or _CORR3_MULTI):
+                outs = ops.alloc_like_segments([(qn, 1, x.shape[2], x.shape[3], rfn) for x in xs], dev)
                 ops.corr2d_patch_multi(xs, wref, outs, k)
             else:
-                outs = [torch.empty((1, 1, x.shape[2], x.shape[3], rfn), dtype=torch.float32, device=dev) for x in xs]
+                outs = [torch.empty((qn, 1, x.shape[2], x.shape[3], rfn), dtype=torch.float32, device=dev) for x in xs]
                 for x, o in zip(xs, outs):
-                    if k >= 7 and rfn <= 32:
+                    if k >= 7 and rfn <= 32 and qn == 1:
                         ops.corr2d_patch(x, wref, o, k)
                     else:
                         ops.conv(x, wref, None, o, ksize=(1, k, k), pad=(0, k // 2, k // 2))
             for i, o in enumerate(outs):
-                maps[i][l] = o.reshape(o.shape[2] * o.shape[3], rfn)
+                maps[i][l] = o.reshape(qn * o.shape[2] * o.shape[3], rfn)
         for f, si, m in zip(feats, scale_ids, maps):
             ops.detector_assemble(m[0], m[1], m[2], f[0].shape[2], f[0].shape[3], self.cfg["vgg_score_stats"],
-                                  float(self.cfg["vgg_score_max"]), hs, ws, si, stacked)
+                                  float(self.cfg["vgg_score_max"]), hs, ws, si, stacked, batch=qn)
 
     def _scores_from_feats(self, feats, scale_idx, stacked, hs, ws):
         x0, x1, x2 = feats
         rfn = self.ref_center_feats[0].shape[0]
+        qn = x0.shape[0]
         maps = []
         for x, wref, k in zip((x0, x1, x2), self.ref_center_feats, self.ref_ksize):
             _, _, h, w, _ = x.shape
-            o = torch.empty((1, 1, h, w, rfn), dtype=torch.float32, device=x.device)
-            if k >= 7 and rfn <= 32:       # 15x15 and 7x7 levels: input patch kept in LDS and walked by the kx taps
+            o = torch.empty((qn, 1, h, w, rfn), dtype=torch.float32, device=x.device)
+            if k >= 7 and rfn <= 32 and qn == 1:       # 15x15 and 7x7 levels: input patch kept in LDS and walked by the kx taps
                 ops.corr2d_patch(x, wref, o, k)
             else:
                 ops.conv(x, wref, None, o, ksize=(1, k, k), pad=(0, k // 2, k // 2))
-            maps.append(o.reshape(h * w, rfn))
+            maps.append(o.reshape(qn * h * w, rfn))
         hc, wc = x0.shape[2], x0.shape[3]
         ops.detector_assemble(maps[0], maps[1], maps[2], hc, wc, self.cfg["vgg_score_stats"],
-                              float(self.cfg["vgg_score_max"]), hs, ws, scale_idx, stacked)
+                              float(self.cfg["vgg_score_max"]), hs, ws, scale_idx, stacked, batch=qn)
 
-    def _detect_one(self, que_img):
+    def _detect_batch(self, que_imgs):
+        """que_imgs [qn,3,hq,wq]: the whole batch goes through every launch together (trunk pyramid segments of qn images,
+        correlation tiles of qn maps per scale, heads with M = qn*hs*ws) — reference API: detector.py:291-304 takes [qn,H,W,3]."""
         pk = self._pack()
-        _, _, hq, wq = que_img.shape
+        qn, _, hq, wq = que_imgs.shape
         hs, ws = hq // 8, wq // 8
-        dev = que_img.device
+        dev = que_imgs.device
         rfn = self.ref_center_feats[0].shape[0]
-        stacked = torch.empty((hs * ws, rfn, 12), dtype=torch.float32, device=dev)
+        P = hs * ws
+        stacked = torch.empty((qn * P, rfn, 12), dtype=torch.float32, device=dev)
         def resized(scale):
             ht, wt = int(np.round(hq * 2 ** scale)), int(np.round(wq * 2 ** scale))
             if ht % 32 != 0: ht = (ht // 32 + 1) * 32
             if wt % 32 != 0: wt = (wt // 32 + 1) * 32
-            return F.interpolate(que_img, size=(ht, wt), mode="bilinear")
+            return F.interpolate(que_imgs, size=(ht, wt), mode="bilinear")
 
         # the scales are independent until `stacked` is complete: largest first on the main stream
         order = sorted(enumerate(self.cfg["detection_scales"]), key=lambda t: -t[1])
@@ -149,15 +158,14 @@ class Detector(ParamBank):
             self._scores_from_pyramid(feats, [si for si, _ in order], stacked, hs, ws)
         else:
             ops.fork_join([(lambda si=si, sc=sc: self._scores_one_scale(resized(sc), si, stacked, hs, ws)) for si, sc in order], dev)
-        feats = ops.detector_score_mlp_max(stacked, *pk["mlp"])               # [P,64], max over the local references
+        feats = ops.detector_score_mlp_max(stacked, *pk["mlp"])               # [qn*P,64], max over the local references
         if self.world > 1:
             parallel.all_reduce_(feats, "max", self.group)
-        P = hs * ws
         k3, p3 = (1, 3, 3), (0, 1, 1)
-        a = torch.empty((1, 1, hs, ws, 192), dtype=torch.float32, device=dev)
-        ops.conv(feats.view(1, 1, hs, ws, 64), pk["h0"][0], pk["h0"][1], a, ksize=k3, pad=p3, out_act=1)
+        a = torch.empty((qn, 1, hs, ws, 192), dtype=torch.float32, device=dev)
+        ops.conv(feats.view(qn, 1, hs, ws, 64), pk["h0"][0], pk["h0"][1], a, ksize=k3, pad=p3, out_act=1)
         b = torch.empty_like(a)
-        o4 = torch.empty((1, 1, hs, ws, 4), dtype=torch.float32, device=dev)
+        o4 = torch.empty((qn, 1, hs, ws, 4), dtype=torch.float32, device=dev)
         col = 0
         for i in range(3):
             w1, b1 = pk["h1"][i]
@@ -166,9 +174,9 @@ class Detector(ParamBank):
             co = w2.shape[0]
             ops.conv(b[..., 64 * i:64 * i + 64], w2, b2, o4[..., col:col + co], ksize=k3, pad=p3)
             col += co
-        o4 = o4.view(P, 4)                                                     # score, scale, offset x, offset y
-        res = ops.detector_decode(o4[:, 0:1], o4[:, 2:4], o4[:, 1:2], hs, ws, self.pool_ratio)
-        return o4, res, (hs, ws)
+        o4 = o4.view(qn * P, 4)                                                # score, scale, offset x, offset y
+        res = ops.detector_decode(o4[:, 0:1], o4[:, 2:4], o4[:, 1:2], hs, ws, self.pool_ratio, batch=qn)
+        return o4.view(qn, hs, ws, 4), res.view(qn, 5), (hs, ws)
 
     def detect_impl(self, *a, **k):
         """cfg key 'math_mode' ('bf16' / 'fp16'; default fp32) selects the matrix-core operand precision of this network's conv /
@@ -180,12 +188,12 @@ class Detector(ParamBank):
         """que_imgs [qn,3,hq,wq] in [0,1] -> the reference's output dict (detector.py:232-266) plus
         'positions' [qn,2] and 'scales' [qn] already decoded on the device."""
         outs, results = [], []
-        for qi in range(que_imgs.shape[0]):
-            o4, res, (hs, ws) = self._detect_one(que_imgs[qi:qi + 1])
-            outs.append(o4.view(hs, ws, 4).permute(2, 0, 1))
+        for q0 in range(0, que_imgs.shape[0], MAX_BATCH):                      # the queries of a chunk share every launch
+            o4, res, _ = self._detect_batch(que_imgs[q0:q0 + MAX_BATCH].contiguous())
+            outs.append(o4.permute(0, 3, 1, 2))
             results.append(res)
-        o = torch.stack(outs, 0)                                               # qn,4,hs,ws
-        r = torch.stack(results, 0)
+        o = torch.cat(outs, 0)                                                 # qn,4,hs,ws
+        r = torch.cat(results, 0)
         return {"scores": o[:, 0:1], "select_pr_scale": o[:, 1:2], "select_pr_offset": o[:, 2:4],
                 "que_select_id": r[:, 3:5].round().long(), "pool_ratio": self.pool_ratio,
                 "positions": r[:, 0:2], "scales": r[:, 2]}

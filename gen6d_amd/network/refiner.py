@@ -17,6 +17,7 @@ from .backbone import pack_trunk, trunk_features
 from .operator import pose_apply_th
 from .params import ParamBank, fold_vgg
 
+MAX_BATCH = 8          # queries that share one set of launches (g6d_linear_gemv takes <= 8 right-hand sides)
 _K3, _P3 = (3, 3, 3), (1, 1, 1)
 _K2, _P2 = (1, 3, 3), (0, 1, 1)
 
@@ -106,30 +107,36 @@ class VolumeRefiner(ParamBank):
 
     # ------------------------------------------------------------------ 3-D volume net + regressor
     def run_volume_net(self, mean_in, std, sn):
-        """mean_in [sn^3,256], std [sn^3,128] -> code [ (sn/8)^3, 512 ] (reference refiner.py:136-143)."""
+        """mean_in [sn^3,256], std [sn^3,128] -> code [(sn/8)^3, 512] (reference refiner.py:136-143); or a batch of qn volumes
+        ([qn,sn^3,256], [qn,sn^3,128] -> [qn,(sn/8)^3,512]) through the same launches: every InstanceNorm3d keeps one statistics group
+        and one affine table per volume."""
         pk = self._pack()
         dev = mean_in.device
-        vox = sn ** 3
+        batched = mean_in.dim() == 3
+        qn = mean_in.shape[0] if batched else 1
+        pn = 1 if qn > 1 else 0                      # per-volume tables / groups only when there is more than one
 
         def c3(x, wb, out, stride=1, aff=None, stats_c=None, count=None):
             """3x3x3 conv; with stats_c: returns the affine (scale, shift) of the InstanceNorm that follows (count values)."""
-            st = ops.new_stats(1, stats_c, dev) if stats_c else None
+            st = ops.new_stats(qn, stats_c, dev) if stats_c else None
             sc, sh = aff if aff is not None else (None, None)
             return ops.conv(x, wb[0], wb[1], out, ksize=_K3, stride=(stride,) * 3, pad=_P3, in_scale=sc, in_shift=sh,
-                            in_relu=aff is not None, stats=st, w_wino=getattr(wb, "u", None) if stride == 1 else None,
-                            finalize=count if stats_c else None)
+                            in_relu=aff is not None, per_n=pn if aff is not None else 0, stats=st,
+                            rows_per_group=pn * (count or 0) if stats_c else 0,
+                            w_wino=getattr(wb, "u", None) if stride == 1 else None, finalize=count if stats_c else None)
 
         def buf(s, c):
-            return torch.empty((1, s, s, s, c), dtype=torch.float32, device=dev)
+            return torch.empty((qn, s, s, s, c), dtype=torch.float32, device=dev)
 
+        vox = sn ** 3
         cat = buf(sn, 128)
         def embed(name, x, sl):
             y = buf(sn, 64)
             aff = c3(x, pk[name][0], y, stats_c=64, count=vox)
             c3(y, pk[name][1], cat[..., sl], aff=aff)
 
-        embed("v_mean_embed", mean_in.view(1, sn, sn, sn, 256), slice(0, 64))
-        embed("v_var_embed", std.view(1, sn, sn, sn, 128), slice(64, 128))
+        embed("v_mean_embed", mean_in.view(qn, sn, sn, sn, 256), slice(0, 64))
+        embed("v_var_embed", std.view(qn, sn, sn, sn, 128), slice(64, 128))
         x, aff, s = cat, None, sn
         for name, co, stride in (("v_conv0", 64, 1), ("v_conv1", 128, 2), ("v_conv2", 128, 1), ("v_conv3", 256, 2),
                                  ("v_conv4", 256, 1)):
@@ -141,17 +148,18 @@ class VolumeRefiner(ParamBank):
         aff = c3(x, pk["v_conv5"][0], y, stride=2, aff=aff, stats_c=512, count=s ** 3)
         code = buf(s, 512)
         c3(y, pk["v_conv5"][1], code, aff=aff)
-        return code.view(s ** 3, 512)
+        return code.view(qn, s ** 3, 512) if batched else code.view(s ** 3, 512)
 
     def run_regressor(self, code):
+        """code [v,512] (one query) or [qn,v,512] -> rotation [qn,4] (unit quaternion), offset [qn,2], scale [qn,1]; the 67 MB FC
+        weight stream is read once for the whole batch (g6d_linear_gemv, B <= 8)."""
         pk = self._pack()
-        x = ops.linear_gemv(code.reshape(1, -1), pk["fc0"][0], pk["fc0"][1], act=2)
+        qn = code.shape[0] if code.dim() == 3 else 1
+        x = ops.linear_gemv(code.reshape(qn, -1), pk["fc0"][0], pk["fc0"][1], act=2)
         x = ops.linear_gemv(x, pk["fc1"][0], pk["fc1"][1], act=2)
         o = ops.linear_gemv(x, pk["heads"][0], pk["heads"][1])
-        if o.shape[0] == 1:
-            ops.l2norm_rows(o[:, 0:4])              # F.normalize(quaternion) in place (one row of four values)
-            return o[:, 0:4], o[:, 4:6], o[:, 6:7]
-        return F.normalize(o[:, 0:4], dim=1), o[:, 4:6], o[:, 6:7]
+        ops.l2norm_rows(o[:, 0:4])                  # F.normalize(quaternion) in place (rows of four values, row stride 7)
+        return o[:, 0:4], o[:, 4:6], o[:, 6:7]
 
     def _step(self, *a, **k):
         """cfg key 'math_mode' ('bf16' / 'fp16'; default fp32) selects the matrix-core operand precision of this network's conv /
@@ -160,18 +168,32 @@ class VolumeRefiner(ParamBank):
             return self._step_fp(*a, **k)
 
     def _step_fp(self, que_img, K_in, pose_in, ref_imgs, ref_Ks, ref_poses):
+        """One refinement step.  Single query: que_img [1,3,h,w], K_in [3,3], pose_in [3,4], ref_imgs [rfn,3,h,w], ref_Ks [rfn,3,3],
+        ref_poses [rfn,3,4].  Batch of qn <= MAX_BATCH queries (reference forward: refiner.py:249-269 takes [qn,...]): que_img
+        [qn,3,h,w], K_in [qn,3,3], pose_in [qn,3,4], ref_imgs [qn,rfn,3,h,w], ref_Ks [qn,rfn,3,3], ref_poses [qn,rfn,3,4] — the
+        (rfn+1)*qn crops share the trunk / feature-net launches, the qn volumes the volume-net launches and the FC weight stream."""
         sn = self.cfg["refiner_sample_num"]
         dev = que_img.device
         ops.stats_arena_begin(dev)
-        rfn = ref_imgs.shape[0]
+        batched = ref_imgs.dim() == 5
+        qn = ref_imgs.shape[0] if batched else 1
+        rfn = ref_imgs.shape[-4]
         h_in, w_in = ref_imgs.shape[-2:]
-        feats = self.run_feature_net(torch.cat([ref_imgs, que_img], 0))                  # query last
+        if batched:                                    # image order: (refs of query 0, query 0), (refs of query 1, query 1), ...
+            imgs = torch.cat([ref_imgs, que_img[:, None]], 1).reshape(qn * (rfn + 1), *ref_imgs.shape[-3:])
+        else:
+            imgs = torch.cat([ref_imgs, que_img], 0)                                         # query last
+        feats = self.run_feature_net(imgs)
         lin = _linspace(sn, dev)
         C = feats.shape[-1]
-        mean_in = torch.empty((sn ** 3, 2 * C), dtype=torch.float32, device=dev)
-        std = torch.empty((sn ** 3, C), dtype=torch.float32, device=dev)
+        lead = (qn,) if batched else ()
+        mean_in = torch.empty(lead + (sn ** 3, 2 * C), dtype=torch.float32, device=dev)
+        std = torch.empty(lead + (sn ** 3, C), dtype=torch.float32, device=dev)
+        feats = feats.contiguous()
+        if batched:
+            feats = feats.view(qn, rfn + 1, *feats.shape[1:])
         # projections K @ pose and the volume's rotation are formed inside the kernel (reference refiner.py:208-226)
-        ops.refiner_volume_kp(feats.contiguous(), ref_Ks.contiguous(), ref_poses.contiguous(), K_in.contiguous(), pose_in.contiguous(),
+        ops.refiner_volume_kp(feats, ref_Ks.contiguous(), ref_poses.contiguous(), K_in.contiguous(), pose_in.contiguous(),
                               lin, h_in, w_in, mean_in, std)
         return self.run_regressor(self.run_volume_net(mean_in, std, sn))
 
@@ -179,8 +201,13 @@ class VolumeRefiner(ParamBank):
         """Same dict contract as the reference (refiner.py:249-269)."""
         is_inference = data["inference"] if "inference" in data else False
         que, ref = data["que_imgs_info"], data["ref_imgs_info"]
-        outs = [self._step(que["imgs"][qi:qi + 1], que["Ks_in"][qi], que["poses_in"][qi], ref["imgs"][qi], ref["Ks"][qi],
-                           ref["poses"][qi]) for qi in range(que["imgs"].shape[0])]
+        qn_all = que["imgs"].shape[0]
+        if qn_all == 1:
+            outs = [self._step(que["imgs"], que["Ks_in"][0], que["poses_in"][0], ref["imgs"][0], ref["Ks"][0], ref["poses"][0])]
+        else:                                                                  # the queries of a chunk share every launch
+            outs = [self._step(que["imgs"][q0:q0 + MAX_BATCH], que["Ks_in"][q0:q0 + MAX_BATCH], que["poses_in"][q0:q0 + MAX_BATCH],
+                               ref["imgs"][q0:q0 + MAX_BATCH], ref["Ks"][q0:q0 + MAX_BATCH], ref["poses"][q0:q0 + MAX_BATCH])
+                    for q0 in range(0, qn_all, MAX_BATCH)]
         out = {"rotation": torch.cat([o[0] for o in outs], 0), "offset": torch.cat([o[1] for o in outs], 0),
                "scale": torch.cat([o[2] for o in outs], 0)}
         if not is_inference:

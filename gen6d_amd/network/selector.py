@@ -34,6 +34,7 @@ _CORR = (
     ((1, 1, 1, 0), (4, 0, 0, 0)),
 )
 _K133, _P011 = (1, 3, 3), (0, 1, 1)
+MAX_BATCH = 8          # queries that share one set of launches (g6d_selector_levels takes <= 8)
 FEAT_LD = 516          # 512 corr channels + 3 vps channels + 1 zero pad (16-byte rows)
 
 
@@ -146,28 +147,34 @@ class ViewpointSelector(ParamBank):
         self.ref_pose_embed = v.contiguous()
 
     # ------------------------------------------------------------------ query
-    def _level(self, l, q, cat, scale, shift):
-        """One pyramid level: q [1,1,h,w,512] query features, (scale, shift) [1,512] the InstanceNorm affine of the
-        query x reference product; writes channels [256l,256l+256) of cat [D,1,4,4,768]."""
+    def _level(self, l, q, cat, scale, shift, qn=1):
+        """One pyramid level for a batch of qn queries: q [qn,1,h,w,512] query features, (scale, shift) [qn,512] the InstanceNorm
+        affine of each query x reference product; writes channels [256l,256l+256) of cat [qn*D,1,4,4,768].  The qn*D hypothesis
+        images of the batch go through every launch together: image n = query n // D, hypothesis n % D; the first conv reads the
+        reference cache through `in_mod` (shared, not replicated) with the query's own feature map as multiplier, and every
+        InstanceNorm keeps one statistics group / affine table per query (`rows_per_group`, `per_n` = D)."""
         pk = self._pack()
         cache = self.ref_feats_cache[l]
         D, _, h, w, _ = cache.shape
         dev = cache.device
         Dg = self.rfn * self.an                                              # global hypothesis count
-        x, mul, relu = cache, q.view(h, w, 512), False
+        grp = D if qn > 1 else 0                                             # images per query group (0: the single-query launches of round 2)
+        x, mul, relu = cache, (q.view(qn, h, w, 512) if qn > 1 else q.view(h, w, 512)), False
+        first = True
         layers = _CORR[l]
         for li, (idx, has_in, has_relu, has_pool) in enumerate(layers):
             wgt, bias = pk["corr"][l][li]
             wu = pk["corr"][l][li].u
             co = wgt.shape[0]
             last = li == len(layers) - 1
-            out = cat[..., 256 * l:256 * l + 256] if last else torch.empty((D, 1, h, w, co), dtype=torch.float32, device=dev)
-            stats = ops.new_stats(1, co, dev) if has_in else None
+            out = cat[..., 256 * l:256 * l + 256] if last else torch.empty((qn * D, 1, h, w, co), dtype=torch.float32, device=dev)
+            stats = ops.new_stats(qn, co, dev) if has_in else None
             # InstanceNorm finalisation inside the producing launch, unless the statistics still have to be summed over ranks
             fin = Dg * h * w if (has_in and not last and self.world == 1) else None
             res = ops.conv(x, wgt, bias, out, ksize=_K133, pad=_P011, mul=mul, in_scale=scale, in_shift=shift, in_relu=relu, stats=stats,
-                           w_wino=wu, finalize=fin)
-            mul = None
+                           w_wino=wu, finalize=fin, per_n=grp if scale is not None else 0, rows_per_group=grp * h * w,
+                           in_mod=grp if first else 0, mul_group=grp if mul is not None else 0)
+            mul, first = None, False
             if last:
                 break
             if fin is not None:
@@ -176,26 +183,32 @@ class ViewpointSelector(ParamBank):
                 self._allreduce([stats])
                 scale, shift = ops.stats_finalize(stats, Dg * h * w)
             if has_pool:
+                pooled = torch.empty((qn * D, 1, h // 2, w // 2, co), dtype=torch.float32, device=dev)
+                ops.affine_act_pool(out, pooled, scale, shift, per_n=grp, relu=bool(has_relu), pool=1)
                 h, w = h // 2, w // 2
-                pooled = torch.empty((D, 1, h, w, co), dtype=torch.float32, device=dev)
-                ops.affine_act_pool(out, pooled, scale, shift, relu=bool(has_relu), pool=1)
                 x, scale, shift, relu = pooled, None, None, False
             else:
                 x, relu = out, bool(has_relu)
 
-    def _query_one(self, que_img):
+    def _query_batch(self, que_imgs):
+        """que_imgs [qn,3,128,128], qn <= MAX_BATCH -> logits [qn,rfn], angles [qn,rfn]; one set of launches for the whole batch
+        (the reference cache is streamed once per batch, the qn*D hypothesis images fill the conv grids)."""
         pk = self._pack()
         an = self.an
+        qn = que_imgs.shape[0]
         rfn_all, rfn = self.rfn, self.r_end - self.r_begin                  # global / local reference counts
         D, Dg = rfn * an, rfn_all * an
-        dev = que_img.device
+        dev = que_imgs.device
+        if self.world > 1 and qn > 1:
+            raise ValueError("reference-sharded selector: one query per call (collectives are issued per query)")
+        grp = D if qn > 1 else 0
         ops.stats_arena_begin(dev)
-        qf = self.get_feats(que_img)
-        cat = torch.empty((D, 1, 4, 4, 768), dtype=torch.float32, device=dev)
+        qf = self.get_feats(que_imgs)
+        cat = torch.empty((qn * D, 1, 4, 4, 768), dtype=torch.float32, device=dev)
         # score maps -> viewpoint scores and the product's InstanceNorm statistics of all three levels: one streaming launch
         caches = [c.view(c.shape[0], c.shape[2] * c.shape[3], 512) for c in self.ref_feats_cache]
-        vps, psc, psh, _ = ops.selector_levels([qf[l].view(-1, 512) for l in range(3)], caches, self.ref_sums, Dg)     # [3,D], [3,512]
-        levels = [(lambda l=l: self._level(l, qf[l], cat, psc[l:l + 1], psh[l:l + 1])) for l in range(3)]
+        vps, psc, psh, _ = ops.selector_levels([qf[l].view(qn, -1, 512) for l in range(3)], caches, self.ref_sums, Dg)  # [qn,3,D], [qn,3,512]
+        levels = [(lambda l=l: self._level(l, qf[l], cat, psc[:, l].contiguous(), psh[:, l].contiguous(), qn)) for l in range(3)]
         # collectives must be issued in the same order on every rank: no stream fork in sharded mode
         if self.world == 1:
             ops.fork_join(levels, dev)
@@ -203,73 +216,75 @@ class ViewpointSelector(ParamBank):
             for f in levels: f()
 
         # corr_feats_conv: 1x1x1 768->512, IN3d, ReLU, (AvgPool commuted) 512->512   selector.py:71-77,197-200
-        y = torch.empty((D, 1, 4, 4, 512), dtype=torch.float32, device=dev)
-        st = ops.new_stats(1, 512, dev)
+        y = torch.empty((qn * D, 1, 4, 4, 512), dtype=torch.float32, device=dev)
+        st = ops.new_stats(qn, 512, dev)
         if self.world == 1:
-            sc, sh = ops.conv(cat, pk["fuse0"][0], pk["fuse0"][1], y, stats=st, finalize=Dg * 16)
+            sc, sh = ops.conv(cat, pk["fuse0"][0], pk["fuse0"][1], y, stats=st, finalize=Dg * 16, rows_per_group=grp * 16)
         else:
             ops.conv(cat, pk["fuse0"][0], pk["fuse0"][1], y, stats=st)
             self._allreduce([st])
             sc, sh = ops.stats_finalize(st, Dg * 16)
-        pooled = torch.empty((D, 1, 1, 1, 512), dtype=torch.float32, device=dev)
-        ops.affine_act_pool(y, pooled, sc, sh, relu=True, pool=2)
-        feats = torch.zeros((D, FEAT_LD), dtype=torch.float32, device=dev)
-        ops.conv(pooled.view(1, 1, 1, D, 512), pk["fuse3"][0], pk["fuse3"][1], feats.view(1, 1, 1, D, FEAT_LD)[..., :512])
+        pooled = torch.empty((qn * D, 1, 1, 1, 512), dtype=torch.float32, device=dev)
+        ops.affine_act_pool(y, pooled, sc, sh, per_n=grp, relu=True, pool=2)
+        feats = torch.zeros((qn * D, FEAT_LD), dtype=torch.float32, device=dev)
+        ops.conv(pooled.view(1, 1, 1, qn * D, 512), pk["fuse3"][0], pk["fuse3"][1], feats.view(1, 1, 1, qn * D, FEAT_LD)[..., :512])
         if self.world == 1:
             ops.vps_norm(vps, feats, 512)                                               # selector.py:201-202
         else:                                                                           # norm over ALL hypotheses
-            vall = self._allgather_rows(vps.T.contiguous().view(rfn, an * 3), rfn_all).view(Dg, 3).T.contiguous()
+            vall = self._allgather_rows(vps[0].T.contiguous().view(rfn, an * 3), rfn_all).view(Dg, 3).T.contiguous()
             fall = torch.zeros((Dg, FEAT_LD), dtype=torch.float32, device=dev)
             ops.vps_norm(vall, fall, 512)
             feats[:, 512:515] = fall[self.r_begin * an:self.r_end * an, 512:515]
 
         # score_process + max over rotations + viewpoint embedding                     selector.py:204-205
-        t0 = torch.empty((1, 1, 1, D, 512), dtype=torch.float32, device=dev)
-        ops.conv(feats.view(1, 1, 1, D, FEAT_LD), pk["sp0"][0], pk["sp0"][1], t0, out_act=1)
+        t0 = torch.empty((1, 1, 1, qn * D, 512), dtype=torch.float32, device=dev)
+        ops.conv(feats.view(1, 1, 1, qn * D, FEAT_LD), pk["sp0"][0], pk["sp0"][1], t0, out_act=1)
         t1 = torch.empty_like(t0)
         ops.conv(t0, pk["sp2"][0], pk["sp2"][1], t1)
-        xl = torch.empty((rfn, 512), dtype=torch.float32, device=dev)
-        ops.max_an_add(t1.view(D, 512), rfn, an, self.ref_pose_embed[self.r_begin:self.r_end].contiguous(), xl)
+        xl = torch.empty((qn * rfn, 512), dtype=torch.float32, device=dev)
+        ops.max_an_add(t1.view(qn * D, 512), rfn, an, self.ref_pose_embed[self.r_begin:self.r_end].contiguous(), xl, batch=qn)
         feats_l, rfn_l = feats, rfn
         rfn = rfn_all                                                                   # the tail runs on ALL refs
-        xm = torch.empty((rfn, 1024), dtype=torch.float32, device=dev)                  # [x | msg]
+        xm = torch.empty((qn * rfn, 1024), dtype=torch.float32, device=dev)             # [x | msg]
         xm[:, :512] = self._allgather_rows(xl, rfn_all)
 
-        def tok(t):          # [n, C] (row-strided) -> conv view [1,1,1,n,C]
-            return t.as_strided((1, 1, 1, t.shape[0], t.shape[1]), (0, 0, 0, t.stride(0), 1), t.storage_offset())
+        def tok(t, n_tok=None):      # [qn*n, C] (row-strided) -> conv view [qn,1,1,n,C]: one image per query
+            n_tok = rfn if n_tok is None else n_tok
+            return t.as_strided((qn, 1, 1, n_tok, t.shape[1]), (n_tok * t.stride(0), 0, 0, t.stride(0), 1), t.storage_offset())
 
+        pn = 1 if qn > 1 else 0                      # InstanceNorm1d tables per query (image of the tok view)
         for i in range(2):                                                              # selector.py:207-209
             a = pk["att"][i]
-            qkv = torch.empty((rfn, 1536), dtype=torch.float32, device=dev)
+            qkv = torch.empty((qn * rfn, 1536), dtype=torch.float32, device=dev)
             ops.conv(tok(xm[:, :512]), a["qkv"][0], a["qkv"][1], tok(qkv))
-            att = torch.empty((rfn, 512), dtype=torch.float32, device=dev)
-            ops.attention(qkv[:, 0:512], qkv[:, 512:1024], qkv[:, 1024:1536], 8, att)
-            mrg = torch.empty((rfn, 512), dtype=torch.float32, device=dev)
+            att = torch.empty((qn * rfn, 512), dtype=torch.float32, device=dev)
+            ops.attention(qkv[:, 0:512], qkv[:, 512:1024], qkv[:, 1024:1536], 8, att, batch=qn)
+            mrg = torch.empty((qn * rfn, 512), dtype=torch.float32, device=dev)
             ops.conv(tok(att), a["merge"][0], a["merge"][1], tok(mrg))
             ops.layernorm(mrg, a["ln"][0], a["ln"][1], xm[:, 512:])
-            y0 = torch.empty((rfn, 512), dtype=torch.float32, device=dev)
-            s0 = ops.new_stats(1, 512, dev)
-            sc0, sh0 = ops.conv(tok(xm), a["mlp0"][0], a["mlp0"][1], tok(y0), stats=s0, finalize=rfn)
-            y1 = torch.empty((rfn, 512), dtype=torch.float32, device=dev)
-            s1 = ops.new_stats(1, 512, dev)
-            sc1, sh1 = ops.conv(tok(y0), a["mlp3"][0], a["mlp3"][1], tok(y1), in_scale=sc0, in_shift=sh0, in_relu=True, stats=s1,
-                                finalize=rfn)
-            xn = torch.empty((rfn, 1024), dtype=torch.float32, device=dev)
-            ops.affine_act_add(y1, xn[:, :512], sc1, sh1, relu=True, residual=xm[:, :512])
+            y0 = torch.empty((qn * rfn, 512), dtype=torch.float32, device=dev)
+            s0 = ops.new_stats(qn, 512, dev)
+            sc0, sh0 = ops.conv(tok(xm), a["mlp0"][0], a["mlp0"][1], tok(y0), stats=s0, finalize=rfn, rows_per_group=pn * rfn)
+            y1 = torch.empty((qn * rfn, 512), dtype=torch.float32, device=dev)
+            s1 = ops.new_stats(qn, 512, dev)
+            sc1, sh1 = ops.conv(tok(y0), a["mlp3"][0], a["mlp3"][1], tok(y1), in_scale=sc0, in_shift=sh0, in_relu=True, per_n=pn, stats=s1,
+                                finalize=rfn, rows_per_group=pn * rfn)
+            xn = torch.empty((qn * rfn, 1024), dtype=torch.float32, device=dev)
+            ops.affine_act_add(y1, xn[:, :512], sc1, sh1, relu=True, residual=xm[:, :512], rows_per_group=pn * rfn)
             xm = xn
-        p0 = torch.empty((rfn, 512), dtype=torch.float32, device=dev)
+        p0 = torch.empty((qn * rfn, 512), dtype=torch.float32, device=dev)
         ops.conv(tok(xm[:, :512]), pk["pred0"][0], pk["pred0"][1], tok(p0), out_act=1)
-        logits = torch.empty((rfn, 1), dtype=torch.float32, device=dev)
+        logits = torch.empty((qn * rfn, 1), dtype=torch.float32, device=dev)
         ops.conv(tok(p0), pk["pred2"][0], pk["pred2"][1], tok(logits))
 
         # angle head on the per-reference rows [an*516]                                 selector.py:212-214
-        a0 = torch.empty((rfn_l, 512), dtype=torch.float32, device=dev)
-        ops.conv(tok(feats_l.view(rfn_l, an * FEAT_LD)), pk["ang0"][0], pk["ang0"][1], tok(a0), out_act=1)
+        a0 = torch.empty((qn * rfn_l, 512), dtype=torch.float32, device=dev)
+        ops.conv(tok(feats_l.view(qn * rfn_l, an * FEAT_LD), rfn_l), pk["ang0"][0], pk["ang0"][1], tok(a0, rfn_l), out_act=1)
         a1 = torch.empty_like(a0)
-        ops.conv(tok(a0), pk["ang2"][0], pk["ang2"][1], tok(a1), out_act=1)
-        angles = torch.empty((rfn_l, 1), dtype=torch.float32, device=dev)
-        ops.conv(tok(a1), pk["ang4"][0], pk["ang4"][1], tok(angles))
-        return logits[:, 0], self._allgather_rows(angles, rfn_all)[:, 0]
+        ops.conv(tok(a0, rfn_l), pk["ang2"][0], pk["ang2"][1], tok(a1, rfn_l), out_act=1)
+        angles = torch.empty((qn * rfn_l, 1), dtype=torch.float32, device=dev)
+        ops.conv(tok(a1, rfn_l), pk["ang4"][0], pk["ang4"][1], tok(angles, rfn_l))
+        return logits.view(qn, rfn), self._allgather_rows(angles, rfn_all).view(qn, rfn_all)
 
     def compute_view_point_feats(self, *a, **k):
         """cfg key 'math_mode' ('bf16' / 'fp16'; default fp32) selects the matrix-core operand precision of this network's conv /
@@ -279,8 +294,9 @@ class ViewpointSelector(ParamBank):
 
     def _compute_view_point_feats_fp(self, que_imgs):
         """que_imgs [qn,3,h,w] in [0,1] -> logits [qn,rfn], angles [qn,rfn] (reference selector.py:177-215)."""
-        outs = [self._query_one(que_imgs[i:i + 1]) for i in range(que_imgs.shape[0])]
-        return torch.stack([o[0] for o in outs], 0), torch.stack([o[1] for o in outs], 0)
+        step = 1 if self.world > 1 else MAX_BATCH                               # the queries of a chunk share every launch
+        outs = [self._query_batch(que_imgs[i:i + step].contiguous()) for i in range(0, que_imgs.shape[0], step)]
+        return torch.cat([o[0] for o in outs], 0), torch.cat([o[1] for o in outs], 0)
 
     def forward(self, data):
         self.extract_ref_feats(data["ref_imgs"], data["ref_imgs_info"]["poses"], data["object_center"],

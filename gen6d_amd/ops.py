@@ -139,14 +139,22 @@ FUSED_FINALIZE = _os.environ.get("G6D_FUSED_FINALIZE", "1") != "0"
 
 
 def conv(x, w, bias, out, ksize=(1, 1, 1), stride=(1, 1, 1), pad=(0, 0, 0), mul=None, in_scale=None, in_shift=None,
-         in_relu=False, per_n=False, out_act=0, stats=None, rows_per_group=0, split_k=0, w_wino=None, finalize=None, eps=1e-5):
+         in_relu=False, per_n=False, out_act=0, stats=None, rows_per_group=0, split_k=0, w_wino=None, finalize=None, eps=1e-5,
+         in_mod=0, mul_group=0):
     """Implicit-GEMM convolution (g6d_conv_igemm). x [N,Di,Hi,Wi,Cin], w [Cout,taps,Cin], out [N,Do,Ho,Wo,Cout] views.
     stats [G,Cout,2] fp64 (zeroed): per-(group, channel) sum / sum of squares of the output are accumulated into it.
     finalize=count: additionally turn the completed statistics into the affine of the following InstanceNorm (count values
-    per group) inside the same launch and return (scale, shift) [G,Cout] instead of out."""
+    per group) inside the same launch and return (scale, shift) [G,Cout] instead of out.
+    per_n: False / 0 = one affine table; True / 1 = a table per image; k = a table per run of k images.
+    Query batches (G6dConv.in_image_mod / mul_group_images): in_mod = k — x holds k images and output image n reads x[n % k];
+    mul_group = k — mul is [N/k,Hi,Wi,Cin] and image n is multiplied by mul[n // k]."""
     _need_gpu(x, w, out)
-    N, Di, Hi, Wi, Cin, ld_in = _cl5(x, "conv.x")
+    Nx, Di, Hi, Wi, Cin, ld_in = _cl5(x, "conv.x")
     No, Do, Ho, Wo, Cout, ld_out = _cl5(out, "conv.out")
+    N = No if in_mod else Nx
+    if in_mod and Nx != in_mod:
+        raise ValueError("conv: with in_mod the input must hold exactly in_mod images")
+    per_n = int(per_n)
     kd, kh, kw = ksize
     if tuple(w.shape) != (Cout, kd * kh * kw, Cin) or not w.is_contiguous():
         raise ValueError(f"conv.w: expected contiguous {(Cout, kd * kh * kw, Cin)}, got {tuple(w.shape)}")
@@ -155,8 +163,10 @@ def conv(x, w, bias, out, ksize=(1, 1, 1), stride=(1, 1, 1), pad=(0, 0, 0), mul=
             raise ValueError(f"conv: output extent mismatch on axis {i}: in {di} k {k} s {s} p {p} -> out {do}")
     if No != N:
         raise ValueError("conv: batch mismatch")
-    if mul is not None and (tuple(mul.shape) != (Hi, Wi, Cin) or not mul.is_contiguous()):
-        raise ValueError("conv.mul: expected contiguous [Hi,Wi,Cin]")
+    if mul is not None:
+        want = ((N + mul_group - 1) // mul_group, Hi, Wi, Cin) if mul_group else (Hi, Wi, Cin)
+        if tuple(mul.shape) != want or not mul.is_contiguous():
+            raise ValueError(f"conv.mul: expected contiguous {want}")
     if w_wino is not None and (tuple(w_wino.shape) != (kd * (Cin // 8), 16, Cout, 8) or not w_wino.is_contiguous()):
         raise ValueError(f"conv.w_wino: expected contiguous {(kd * (Cin // 8), 16, Cout, 8)}, got {tuple(w_wino.shape)}")
     ws = workspace(x.device)
@@ -170,7 +180,7 @@ def conv(x, w, bias, out, ksize=(1, 1, 1), stride=(1, 1, 1), pad=(0, 0, 0), mul=
         kd=kd, kh=kh, kw=kw, sd=stride[0], sh=stride[1], sw=stride[2], pd=pad[0], ph=pad[1], pw=pad[2],
         in_relu=int(in_relu), in_affine_per_n=int(per_n), out_act=int(out_act),
         stat_rows_per_group=int(rows_per_group), split_k=int(split_k), math_mode=int(MATH_MODE),
-        weight_wino=w_wino.data_ptr() if w_wino is not None else None)
+        weight_wino=w_wino.data_ptr() if w_wino is not None else None, in_image_mod=int(in_mod), mul_group_images=int(mul_group))
     fin = None
     if finalize is not None:
         if stats is None:
@@ -219,8 +229,9 @@ def corr2d_patch(x, w, out, k):
 
 
 def corr2d_patch_multi(xs, w, outs, k):
-    """corr2d_patch for several maps in ONE launch (the scales of the detector's pyramid against the same reference filters):
-    xs[i] [1,1,H_i,W_i,Cin] and outs[i] [1,1,H_i,W_i,Cout] views, each list cut from one buffer (alloc_like_segments)."""
+    """corr2d_patch for several map sizes in ONE launch (the scales of the detector's pyramid against the same reference filters):
+    xs[i] [N,1,H_i,W_i,Cin] and outs[i] [N,1,H_i,W_i,Cout] dense tensors (N = queries of the batch at that scale), each list cut
+    from one buffer (alloc_like_segments)."""
     _need_gpu(w, *xs, *outs)
     if not 1 <= len(xs) <= 4 or len(outs) != len(xs):
         raise ValueError("corr2d_patch_multi: 1..4 maps")
@@ -229,12 +240,12 @@ def corr2d_patch_multi(xs, w, outs, k):
     flops, sizes = 0.0, []
     for i, (x, o) in enumerate(zip(xs, outs)):
         N, D, H, W, Cx, ld_in = _cl5(x, "corr2d_multi.x")
-        _, _, Ho, Wo, Co, ld_out = _cl5(o, "corr2d_multi.out")
-        if N * D != 1 or (Ho, Wo) != (H, W) or Cx != Cin or Co != Cout:
-            raise ValueError("corr2d_patch_multi: shape mismatch")
-        segs[i] = _lib.G6dCorrSeg(in_=x.data_ptr(), out=o.data_ptr(), H=H, W=W, ld_in=ld_in, ld_out=ld_out)
-        flops += 2.0 * H * W * Cout * k * k * Cin
-        sizes.append(f"{H}x{W}")
+        No, _, Ho, Wo, Co, ld_out = _cl5(o, "corr2d_multi.out")
+        if D != 1 or No != N or (Ho, Wo) != (H, W) or Cx != Cin or Co != Cout or (N > 1 and not (x.is_contiguous() and o.is_contiguous())):
+            raise ValueError("corr2d_patch_multi: shape mismatch (batched maps must be dense)")
+        segs[i] = _lib.G6dCorrSeg(in_=x.data_ptr(), out=o.data_ptr(), H=H, W=W, ld_in=ld_in, ld_out=ld_out, N=N)
+        flops += 2.0 * N * H * W * Cout * k * k * Cin
+        sizes.append(f"{N}x{H}x{W}" if N > 1 else f"{H}x{W}")
     if tuple(w.shape) != (Cout, k * k, Cin) or not w.is_contiguous():
         raise ValueError("corr2d_patch_multi: filter shape mismatch")
     ws = workspace(w.device)
@@ -306,7 +317,7 @@ def affine_act_pool(x, out, scale=None, shift=None, per_n=False, relu=False, poo
     _, _, _, _, Co, ld_out = _cl5(out, "affine_act_pool.out")
     if Co != Cc:
         raise ValueError("affine_act_pool: channel mismatch")
-    _lib.check(_lib.load().g6d_affine_act_pool(_ptr(x), ld_in, _ptr(scale), _ptr(shift), int(per_n), int(relu), int(pool),
+    _lib.check(_lib.load().g6d_affine_act_pool(_ptr(x), ld_in, _ptr(scale), _ptr(shift), int(per_n) * D, int(relu), int(pool),
                                               N * D, H, W, Cc, _ptr(out), ld_out, _stream()), "g6d_affine_act_pool")
     return out
 
@@ -317,7 +328,7 @@ def upsample_bilinear(x, out, factor, scale=None, shift=None, per_n=False):
     _, _, Ho, Wo, Co, ld_out = _cl5(out, "upsample.out")
     if (Ho, Wo, Co) != (H * factor, W * factor, Cc):
         raise ValueError("upsample: output shape mismatch")
-    _lib.check(_lib.load().g6d_upsample_bilinear(_ptr(x), ld_in, _ptr(scale), _ptr(shift), int(per_n), N * D, H, W, Cc,
+    _lib.check(_lib.load().g6d_upsample_bilinear(_ptr(x), ld_in, _ptr(scale), _ptr(shift), int(per_n) * D, N * D, H, W, Cc,
                                                 int(factor), _ptr(out), ld_out, _stream()), "g6d_upsample_bilinear")
     return out
 
@@ -453,11 +464,15 @@ def wino_conv3x3_multi(xs, U, bias, relu=True, full=True, pool=False):
 
 
 def l2norm_rows(x):
-    """In-place F.normalize over the last axis of a channels-last tensor whose rows are dense (ld = C)."""
+    """In-place F.normalize over the last axis of a channels-last tensor whose rows are dense (ld = C), or of a 2-D row-strided
+    view [rows, C] (ld = x.stride(0))."""
     _need_gpu(x)
+    Cc = x.shape[-1]
+    if x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1 and not x.is_contiguous():
+        _lib.check(_lib.load().g6d_l2norm_rows(_ptr(x), x.shape[0], Cc, x.stride(0), _stream()), "g6d_l2norm_rows")
+        return x
     if x.dtype != torch.float32 or not x.is_contiguous():
         raise ValueError("l2norm_rows: contiguous float32 expected")
-    Cc = x.shape[-1]
     _lib.check(_lib.load().g6d_l2norm_rows(_ptr(x), x.numel() // Cc, Cc, Cc, _stream()), "g6d_l2norm_rows")
     return x
 
@@ -513,28 +528,35 @@ def selector_scan(que, refs):
 
 
 def selector_levels(ques, refs, sums, Dg, eps=1e-5, want_maps=False):
-    """All pyramid levels of one query in one launch: ques[l] [HW_l,C], refs[l] [D,HW_l,C], sums[l] = (r1, r2) of
-    selector_ref_sums -> vps [L,D], scale [L,C], shift [L,C] (the InstanceNorm affine of the product over Dg*HW_l values) and, if
-    want_maps, the score maps [D,HW_l] (otherwise None: they never leave the chip)."""
+    """All pyramid levels of a batch of queries in one launch: ques[l] [qn,HW_l,C] (or [HW_l,C] for one query), refs[l] [D,HW_l,C],
+    sums[l] = (r1, r2) of selector_ref_sums -> vps [qn,L,D], scale [qn,L,C], shift [qn,L,C] (the InstanceNorm affine of the product
+    over Dg*HW_l values; a single 2-D query gives [L,D] / [L,C]) and, if want_maps, the score maps [qn,D,HW_l]."""
     L = len(ques)
     _need_gpu(*ques, *refs)
+    single = ques[0].dim() == 2
+    if single:
+        ques = [q.unsqueeze(0) for q in ques]
+    qn = ques[0].shape[0]
     D, _, Cc = refs[0].shape
     dev = ques[0].device
     for q, r in zip(ques, refs):
-        if not (q.is_contiguous() and r.is_contiguous()) or r.shape[0] != D or r.shape[2] != Cc or tuple(q.shape) != tuple(r.shape[1:]):
-            raise ValueError("selector_levels: operands must be contiguous [HW,C] / [D,HW,C]")
-    vps = torch.empty((L, D), dtype=torch.float32, device=dev)
-    scale = torch.empty((L, Cc), dtype=torch.float32, device=dev)
+        if not (q.is_contiguous() and r.is_contiguous()) or r.shape[0] != D or r.shape[2] != Cc or tuple(q.shape) != (qn,) + tuple(r.shape[1:]):
+            raise ValueError("selector_levels: operands must be contiguous [qn,HW,C] / [D,HW,C]")
+    vps = torch.empty((qn, L, D), dtype=torch.float32, device=dev)
+    scale = torch.empty((qn, L, Cc), dtype=torch.float32, device=dev)
     shift = torch.empty_like(scale)
-    maps = [torch.empty((D, r.shape[1]), dtype=torch.float32, device=dev) for r in refs] if want_maps else None
+    maps = [torch.empty((qn, D, r.shape[1]), dtype=torch.float32, device=dev) for r in refs]
     arr = lambda ts: (C.c_void_p * L)(*[t.data_ptr() if t is not None else None for t in ts])
     hw = (C.c_int * L)(*[r.shape[1] for r in refs])
-    nbytes = sum(4.0 * (D * r.shape[1] * Cc + r.shape[1] * Cc + D) + 16.0 * r.shape[1] * Cc for r in refs)   # refs + que + vps, r1/r2 (fp64)
+    # algorithmic bytes: the reference cache once per BATCH, query rows, score maps written and re-read, r1/r2 (fp64) per query
+    nbytes = sum(4.0 * (D * r.shape[1] * Cc + qn * (r.shape[1] * Cc + 2 * D * r.shape[1] + D)) + 16.0 * qn * r.shape[1] * Cc for r in refs)
     _timed_hbm("selector_levels", nbytes,
-               lambda: _lib.check(_lib.load().g6d_selector_levels(L, arr(ques), arr(refs), arr([s_[0] for s_ in sums]), arr([s_[1] for s_ in sums]),
-                                                                  hw, D, int(Dg), Cc, float(eps), arr(maps) if maps else None, _ptr(vps),
+               lambda: _lib.check(_lib.load().g6d_selector_levels(L, qn, arr(ques), arr(refs), arr([s_[0] for s_ in sums]), arr([s_[1] for s_ in sums]),
+                                                                  hw, D, int(Dg), Cc, float(eps), arr(maps), _ptr(vps),
                                                                   _ptr(scale), _ptr(shift), _stream()), "g6d_selector_levels"))
-    return vps, scale, shift, maps
+    if single:
+        return vps[0], scale[0], shift[0], ([m[0] for m in maps] if want_maps else None)
+    return vps, scale, shift, (maps if want_maps else None)
 
 
 def refiner_volume(feats, projs, rot_in, lin, h_in, w_in, mean_in, std):
@@ -557,35 +579,40 @@ def refiner_volume(feats, projs, rot_in, lin, h_in, w_in, mean_in, std):
 
 def refiner_volume_kp(feats, ref_Ks, ref_poses, K_in, pose_in, lin, h_in, w_in, mean_in, std):
     """refiner_volume with the projections formed inside the kernel: feats [rfn+1,fh,fw,C] (query last), ref_Ks [rfn,3,3],
-    ref_poses [rfn,3,4], K_in [3,3], pose_in [3,4] (also the volume's rotation) -> mean_in [sn^3,2C], std [sn^3,C]."""
+    ref_poses [rfn,3,4], K_in [3,3], pose_in [3,4] (also the volume's rotation) -> mean_in [sn^3,2C], std [sn^3,C]; or a batch of
+    queries in one launch: every operand and both outputs with a leading [B] axis."""
     _need_gpu(feats, ref_Ks, ref_poses, K_in, pose_in, lin, mean_in, std)
-    V, fh, fw, Cc = feats.shape
+    batched = feats.dim() == 5
+    B = feats.shape[0] if batched else 1
+    V, fh, fw, Cc = feats.shape[-4:]
     sn = lin.numel()
     for t in (feats, ref_Ks, ref_poses, K_in, pose_in, lin, mean_in, std):
         if not t.is_contiguous() or t.dtype != torch.float32:
             raise ValueError("refiner_volume_kp: operands must be contiguous float32")
-    if (tuple(mean_in.shape) != (sn ** 3, 2 * Cc) or tuple(std.shape) != (sn ** 3, Cc) or tuple(ref_Ks.shape) != (V - 1, 3, 3) or
-            tuple(ref_poses.shape) != (V - 1, 3, 4) or tuple(K_in.shape) != (3, 3) or tuple(pose_in.shape) != (3, 4)):
+    lead = (B,) if batched else ()
+    if (tuple(mean_in.shape) != lead + (sn ** 3, 2 * Cc) or tuple(std.shape) != lead + (sn ** 3, Cc) or tuple(ref_Ks.shape) != lead + (V - 1, 3, 3) or
+            tuple(ref_poses.shape) != lead + (V - 1, 3, 4) or tuple(K_in.shape) != lead + (3, 3) or tuple(pose_in.shape) != lead + (3, 4)):
         raise ValueError("refiner_volume_kp: shape mismatch")
-    _timed_hbm("refiner_volume", 4.0 * (V * fh * fw * Cc + 3 * sn ** 3 * Cc),
+    _timed_hbm("refiner_volume", 4.0 * B * (V * fh * fw * Cc + 3 * sn ** 3 * Cc),
                lambda: _lib.check(_lib.load().g6d_refiner_volume_kp(_ptr(feats), _ptr(ref_Ks), _ptr(ref_poses), _ptr(K_in), _ptr(pose_in),
                                                                     _ptr(lin), V - 1, fh, fw, Cc, int(h_in), int(w_in), sn, _ptr(mean_in),
-                                                                    _ptr(std), _stream()), "g6d_refiner_volume_kp"))
+                                                                    _ptr(std), B, _stream()), "g6d_refiner_volume_kp"))
     return mean_in, std
 
 
-def detector_assemble(s0, s1, s2, hc, wc, mu_sigma, clip, hs, ws, scale_idx, stacked):
-    """s_l [h_l*w_l, rfn] raw correlation maps of one scale -> channels 3*scale_idx.. of stacked [hs*ws, rfn, nch]."""
+def detector_assemble(s0, s1, s2, hc, wc, mu_sigma, clip, hs, ws, scale_idx, stacked, batch=1):
+    """s_l [batch*h_l*w_l, rfn] raw correlation maps of one scale (the maps of the queries one after the other) -> channels
+    3*scale_idx.. of stacked [batch*hs*ws, rfn, nch]."""
     _need_gpu(s0, s1, s2, stacked)
     rfn = s0.shape[1]
     P, rfn2, nch = stacked.shape
-    if P != hs * ws or rfn2 != rfn or not stacked.is_contiguous():
+    if P != batch * hs * ws or rfn2 != rfn or not stacked.is_contiguous() or not (s0.is_contiguous() and s1.is_contiguous() and s2.is_contiguous()):
         raise ValueError("detector_assemble: stacked shape mismatch")
-    if s0.shape[0] != hc * wc or s1.shape[0] != (hc // 2) * (wc // 2) or s2.shape[0] != (hc // 4) * (wc // 4):
+    if s0.shape[0] != batch * hc * wc or s1.shape[0] != batch * (hc // 2) * (wc // 2) or s2.shape[0] != batch * (hc // 4) * (wc // 4):
         raise ValueError("detector_assemble: level map sizes do not match")
     ms = (C.c_float * 6)(*[float(v) for pair in mu_sigma for v in pair])
     _lib.check(_lib.load().g6d_detector_assemble(_ptr(s0), _ptr(s1), _ptr(s2), hc, wc, rfn, ms, float(clip), hs, ws,
-                                                int(scale_idx), nch, _ptr(stacked), _stream()), "g6d_detector_assemble")
+                                                int(scale_idx), nch, _ptr(stacked), int(batch), _stream()), "g6d_detector_assemble")
     return stacked
 
 
@@ -598,40 +625,49 @@ def detector_score_mlp_max(stacked, w0, b0, w1, b1):
     return out
 
 
-def detector_decode(scores, offset, scale, hs, ws, pool_ratio):
-    """scores [P,1], offset [P,2], scale [P,1] (row-strided views allowed) -> result [5]."""
+def detector_decode(scores, offset, scale, hs, ws, pool_ratio, batch=1):
+    """scores [P,1], offset [P,2], scale [P,1] (row-strided views allowed), P = batch*hs*ws -> result [5] ([batch,5] for batch > 1)."""
     _need_gpu(scores, offset, scale)
-    res = torch.empty((5,), dtype=torch.float32, device=scores.device)
+    if scores.shape[0] != batch * hs * ws:
+        raise ValueError("detector_decode: row count mismatch")
+    res = torch.empty((batch, 5), dtype=torch.float32, device=scores.device)
     _lib.check(_lib.load().g6d_detector_decode(_ptr(scores), scores.stride(0), _ptr(offset), offset.stride(0), _ptr(scale),
-                                              scale.stride(0), hs, ws, int(pool_ratio), _ptr(res), _stream()),
+                                              scale.stride(0), hs, ws, int(pool_ratio), _ptr(res), int(batch), _stream()),
                "g6d_detector_decode")
-    return res
+    return res[0] if batch == 1 else res
 
 
 def vps_norm(vps, feats, c_off):
-    """vps [3,D] -> InstanceNorm over D -> feats[:, c_off:c_off+3] (feats [D,ld] contiguous)."""
+    """vps [3,D] (or [qn,3,D]) -> InstanceNorm over D -> feats[:, c_off:c_off+3] (feats [qn*D,ld] contiguous)."""
     _need_gpu(vps, feats)
-    _lib.check(_lib.load().g6d_vps_norm(_ptr(vps.contiguous()), vps.shape[1], _ptr(feats), feats.stride(0), int(c_off), _stream()),
+    batch = vps.shape[0] if vps.dim() == 3 else 1
+    D = vps.shape[-1]
+    if feats.shape[0] != batch * D:
+        raise ValueError("vps_norm: feats rows != batch * D")
+    _lib.check(_lib.load().g6d_vps_norm(_ptr(vps.contiguous()), D, _ptr(feats), feats.stride(0), int(c_off), batch, _stream()),
                "g6d_vps_norm")
     return feats
 
 
-def max_an_add(x, rfn, an, embed, out):
-    """x [rfn*an, C] (row stride allowed) -> out[r] = max_a x[r*an+a] + embed[r]."""
+def max_an_add(x, rfn, an, embed, out, batch=1):
+    """x [batch*rfn*an, C] (row stride allowed) -> out[b*rfn+r] = max_a x[(b*rfn+r)*an+a] + embed[r]."""
     _need_gpu(x, embed, out)
     Cc = x.shape[1]
+    if x.shape[0] != batch * rfn * an or out.shape[0] != batch * rfn:
+        raise ValueError("max_an_add: row count mismatch")
     _lib.check(_lib.load().g6d_max_an_add(_ptr(x), x.stride(0), rfn, an, Cc, _ptr(embed.contiguous()), _ptr(out),
-                                         out.stride(0), _stream()), "g6d_max_an_add")
+                                         out.stride(0), int(batch), _stream()), "g6d_max_an_add")
     return out
 
 
-def attention(q, k, v, heads, out):
+def attention(q, k, v, heads, out, batch=1):
+    """q, k, v [batch*n, C] -> out [batch*n, C]: attention among the n tokens of each query of the batch."""
     _need_gpu(q, k, v, out)
-    n, Cc = q.shape
-    if not (q.stride(0) == k.stride(0) == v.stride(0)):
-        raise ValueError("attention: q/k/v must share the row stride")
-    _lib.check(_lib.load().g6d_attention(_ptr(q), _ptr(k), _ptr(v), q.stride(0), n, Cc, heads, _ptr(out), out.stride(0),
-                                        _stream()), "g6d_attention")
+    rows, Cc = q.shape
+    if not (q.stride(0) == k.stride(0) == v.stride(0)) or rows % batch:
+        raise ValueError("attention: q/k/v must share the row stride; rows = batch * n")
+    _lib.check(_lib.load().g6d_attention(_ptr(q), _ptr(k), _ptr(v), q.stride(0), rows // batch, Cc, heads, _ptr(out), out.stride(0),
+                                        int(batch), _stream()), "g6d_attention")
     return out
 
 
@@ -643,12 +679,13 @@ def layernorm(x, gamma, beta, out, eps=1e-5):
     return out
 
 
-def affine_act_add(x, out, scale=None, shift=None, relu=False, residual=None):
+def affine_act_add(x, out, scale=None, shift=None, relu=False, residual=None, rows_per_group=0):
+    """out = relu?(x*scale+shift) (+ residual) on [n,C] rows; rows_per_group = k: row r uses table r // k of scale / shift [n/k,C]."""
     _need_gpu(x, out)
     n, Cc = x.shape
     _lib.check(_lib.load().g6d_affine_act_add(_ptr(x), x.stride(0), _ptr(scale), _ptr(shift), int(relu), _ptr(residual),
                                              residual.stride(0) if residual is not None else 0, n, Cc, _ptr(out),
-                                             out.stride(0), _stream()), "g6d_affine_act_add")
+                                             out.stride(0), int(rows_per_group), _stream()), "g6d_affine_act_add")
     return out
 
 

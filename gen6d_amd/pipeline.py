@@ -41,29 +41,42 @@ class TensorPipeline:
                            for i in range(self.refine_iter)]
 
     def query(self, que_full, que_crop):
-        """que_full [1,3,H,W] (detector input), que_crop [1,3,128,128] (selector/refiner input), device tensors.
-        Returns a [1,12] row: position(2), scale, ref_idx, angle, quaternion(4), offset(2), log2-scale."""
+        """que_full [qn,3,H,W] (detector input), que_crop [qn,3,128,128] (selector/refiner input), device tensors; the qn
+        queries of the call share every launch (qn <= 8 per chunk inside the networks).
+        Returns [qn,12] rows: position(2), scale, ref_idx, angle, quaternion(4), offset(2), log2-scale."""
         r = self.ref_dev
+        qn = que_crop.shape[0]
         with torch.no_grad():
             det = self.detector.detect_impl(que_full)
             logits, angles = self.selector.compute_view_point_feats(que_crop)
             idx = torch.argmax(logits, 1)
-            ang = angles[torch.arange(1, device=idx.device), idx]
+            ang = angles.gather(1, idx[:, None])
             for it in range(self.refine_iter):
-                rot, off, scl = self.refiner._step(que_crop, r["Ks_in"][0], self.iter_poses[it][0], r["ref_imgs"][0],
-                                                   r["ref_Ks"][0], r["ref_poses"][0])
-        return torch.cat([det["positions"], det["scales"][:, None], idx[:, None].float(), ang[:, None], rot, off, scl], 1)
+                if qn == 1:
+                    rot, off, scl = self.refiner._step(que_crop, r["Ks_in"][0], self.iter_poses[it][0], r["ref_imgs"][0],
+                                                       r["ref_Ks"][0], r["ref_poses"][0])
+                else:                                  # every query of the batch with its own (here: the same canned) views / poses
+                    rots, offs, scls = [], [], []
+                    for q0 in range(0, qn, 8):
+                        n = min(8, qn - q0)
+                        ex = lambda t: t.expand(n, *t.shape[1:])
+                        o = self.refiner._step(que_crop[q0:q0 + n], ex(r["Ks_in"]).contiguous(), ex(self.iter_poses[it]).contiguous(),
+                                               ex(r["ref_imgs"]), ex(r["ref_Ks"]).contiguous(), ex(r["ref_poses"]).contiguous())
+                        rots.append(o[0]); offs.append(o[1]); scls.append(o[2])
+                    rot, off, scl = (torch.cat(t, 0) for t in (rots, offs, scls))
+        return torch.cat([det["positions"], det["scales"][:, None], idx[:, None].float(), ang, rot, off, scl], 1)
 
     # ------------------------------------------------------------------ hipGraph
-    def capture(self, full_shape=(1, 3, 480, 640), crop_shape=(1, 3, 128, 128), warmup=2, lanes=1):
-        """Capture one query (~800 kernel launches: MIOpen trunk + HIP kernels, with forked side streams) into a
+    def capture(self, full_shape=(1, 3, 480, 640), crop_shape=(1, 3, 128, 128), warmup=2, lanes=1, batch=None):
+        """Capture one query — or one batch of `batch` queries that share every launch — into a
         hipGraph with static input / output buffers.  `lanes` > 1 captures that many independent copies (own static
         buffers and intermediates, shared read-only reference state) so that `query_graph(..., lane=i)` can keep
         several queries in flight on different streams: the small grids of one query leave CUs idle that the next
         query fills."""
         d = self.device
+        if batch is not None:
+            full_shape, crop_shape = (batch,) + tuple(full_shape[1:]), (batch,) + tuple(crop_shape[1:])
         self._lanes = []
-        side = torch.cuda.Stream(device=d)
         for _ in range(lanes):
             g_full = torch.zeros(full_shape, dtype=torch.float32, device=d)
             g_crop = torch.zeros(crop_shape, dtype=torch.float32, device=d)
@@ -89,6 +102,9 @@ class TensorPipeline:
         with torch.cuda.stream(stream):
             g_full.copy_(que_full, non_blocking=True)
             g_crop.copy_(que_crop, non_blocking=True)
+            for t in (que_full, que_crop):           # allocated on the caller's stream, consumed on the lane's
+                if t.is_cuda:
+                    t.record_stream(stream)
             graph.replay()
             out = g_out.clone()
         return out, stream

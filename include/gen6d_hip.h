@@ -58,15 +58,15 @@ int g6d_marker(int id, g6d_stream_t stream);
  * ---------------------------------------------------------------------------------------------------------------- */
 /* Workspace (g6d_conv_igemm, g6d_corr2d_patch, g6d_wino_conv3x3): layers whose grid would not fill 256 CUs split their
  * reduction over more blocks.  The workspace holds G6D_WORKSPACE_COUNTER_BYTES of per-tile arrival counters followed by the
- * partial tiles; the block of a tile that arrives last adds the partials and runs the epilogue (no second kernel up to
- * 16 splits; beyond that a separate reduce kernel reads the partials).  Contract: 16-byte aligned, the first
+ * partial tiles; the block of a tile that arrives last adds the partials and runs the epilogue (no second kernel at any
+ * split count).  Contract: 16-byte aligned, the first
  * G6D_WORKSPACE_COUNTER_BYTES are ZERO before the first call (every call leaves them zero), and the buffer is not shared
  * by launches that may run concurrently (one per stream).  NULL / 0 disables splitting. */
 #define G6D_WORKSPACE_COUNTER_BYTES 16384
 
 typedef struct G6dConv {
   const float* in;        /* [N][Di][Hi][Wi][ld_in] */
-  const float* mul;       /* optional [Hi][Wi][Cin] (dense), broadcast over N and Di; NULL = none */
+  const float* mul;       /* optional [Hi][Wi][Cin] (dense), broadcast over N and Di (one per image group with mul_group_images); NULL = none */
   const float* in_scale;  /* optional [in_affine_groups][Cin]; NULL = none */
   const float* in_shift;  /* same shape as in_scale */
   const float* weight;    /* [Cout][kd*kh*kw][Cin] */
@@ -81,7 +81,8 @@ typedef struct G6dConv {
   int32_t sd, sh, sw;
   int32_t pd, ph, pw;
   int32_t in_relu;              /* apply ReLU after the input affine */
-  int32_t in_affine_per_n;      /* 0: one affine for all N; 1: affine indexed by the batch index n */
+  int32_t in_affine_per_n;      /* 0: one affine table for all N; k >= 1: image n uses table n / k (1 = a table per image; k = the
+                                   hypothesis count D when N = qn * D images of a batched selector call share one table per query) */
   int32_t out_act;              /* 0 none, 1 ReLU, 2 LeakyReLU(0.1) */
   int32_t stat_rows_per_group;  /* output rows per statistics group (0 = all rows in one group) */
   int32_t split_k;              /* 0 = choose automatically; 1 = never split; >1 = force */
@@ -95,13 +96,22 @@ typedef struct G6dConv {
   /* Optional InstanceNorm finalisation inside the launch (needs `stats`): the block that finishes last turns the completed
      (sum, sumsq) table into the affine of the FOLLOWING InstanceNorm — scale = 1/sqrt(var + eps), shift = -mean * scale with
      mean = sum / fin_count, var = sumsq / fin_count - mean^2 — instead of a separate g6d_stats_finalize launch.
-     fin_scale / fin_shift: [fin_groups][Cout] floats; fin_counter: one int32, ZERO before the launch (left non-zero).
+     fin_scale / fin_shift: [fin_groups][Cout] floats; fin_counter: one int32, ZERO before the launch (the launch leaves it zero).
      NULL fin_scale = off.  Not for statistics that are still to be summed over ranks. */
   float* fin_scale;
   float* fin_shift;
   int32_t* fin_counter;
   double fin_count, fin_eps;
   int32_t fin_groups;
+  /* Query batching (round 3; reference API: network/selector.py:165-175 takes [qn,...] queries).  N = qn * k images, image
+     n = q * k + d belongs to query q:
+       in_image_mod = k      image n READS input image n % k — `in` holds k images (the selector's reference cache, shared by the
+                             queries of the batch instead of being replicated); 0 = off (`in` holds N images)
+       mul_group_images = k  `mul` is [ceil(N / k)][Hi][Wi][Cin] and image n is multiplied by mul[n / k] (the query's own feature
+                             map); 0 = one multiplier for all images
+     together with in_affine_per_n = k and stat_rows_per_group = k * Do * Ho * Wo every query keeps its own InstanceNorm. */
+  int32_t in_image_mod;
+  int32_t mul_group_images;
   int32_t reserved_;
 } G6dConv;
 
@@ -118,12 +128,14 @@ int g6d_sizeof_conv_desc(void);
 int g6d_corr2d_patch(const float* in, int H, int W, int Cin, int ld_in, const float* wgt, int Cout, int kh, int kw,
                      float* out, int ld_out, float* workspace, size_t workspace_bytes, int math_mode /* as G6dConv.math_mode */,
                      g6d_stream_t stream);
-/* The same correlation for up to 4 maps in one launch: the scales of the detector's image pyramid against the same reference
- * filters; the tiles of all maps form one flat work list (fewer splits, one launch).  Buffers within 2^30 floats of each other. */
+/* The same correlation for up to 4 map sizes in one launch: the scales of the detector's image pyramid against the same reference
+ * filters, N maps (the queries of a batch, network/detector.py:291-304 takes [qn,H,W,3]) per size; the tiles of all maps form one
+ * flat work list (fewer splits, one launch).  Buffers within 2^30 floats of each other. */
 typedef struct G6dCorrSeg {
-  const float* in;        /* [H][W][ld_in] */
-  float* out;             /* [H*W][ld_out] */
+  const float* in;        /* [N][H][W][ld_in] */
+  float* out;             /* [N][H*W][ld_out] */
   int32_t H, W, ld_in, ld_out;
+  int32_t N, reserved_;   /* N >= 1 maps of this size, dense one after the other */
 } G6dCorrSeg;
 int g6d_corr2d_patch_multi(const G6dCorrSeg* segs, int nseg, int Cin, const float* wgt, int Cout, int kh, int kw,
                            float* workspace, size_t workspace_bytes, int math_mode, g6d_stream_t stream);
@@ -135,7 +147,8 @@ int g6d_stats_finalize(const double* stats, int n, double count, double eps, flo
 
 /* y = pool2x2?( relu?( x*scale[c] + shift[c] ) ) on [N][H][W][C] channels-last rows (D folded into N).
  * pool: 0 none, 1 = 2x2 max (MaxPool3d (1,2,2), network/selector.py:34,41,56), 2 = full-window mean over HxW
- * (AvgPool3d (1,4,4), selector.py:76).  scale/shift may be NULL (identity); affine_per_n selects [N][C] tables. */
+ * (AvgPool3d (1,4,4), selector.py:76).  scale/shift may be NULL (identity); affine_per_n = k >= 1: image n uses table n / k
+ * (as G6dConv.in_affine_per_n), 0: one table. */
 int g6d_affine_act_pool(const float* in, int ld_in, const float* scale, const float* shift, int affine_per_n, int relu,
                         int pool, int N, int H, int W, int C, float* out, int ld_out, g6d_stream_t stream);
 
@@ -192,7 +205,8 @@ int g6d_wino_conv3x3_multi(const G6dWinoSeg* segs, int nseg, int Cin, const floa
                            float* workspace, size_t workspace_bytes, g6d_stream_t stream);
 
 /* In-place L2 normalisation over C of channels-last rows x[rows][ld] (F.normalize eps 1e-12, network/selector.py:118,
- * network/refiner.py:69-71). */
+ * network/refiner.py:69-71,165).  16-byte accesses when x is 16-byte aligned and ld % 4 == 0 (then C % 4 == 0 is required),
+ * scalar accesses otherwise (the [qn][7] rows of the regressor output). */
 int g6d_l2norm_rows(float* x, int rows, int C, int ld, g6d_stream_t stream);
 
 /* NCHW (backbone output) -> channels-last, optionally L2-normalised over C (F.normalize eps 1e-12,
@@ -216,11 +230,11 @@ int g6d_selector_prod_affine(const float* que, const double* r1, const double* r
                              float* scale, float* shift, g6d_stream_t stream);
 int g6d_selector_scan(const float* que, const float* refs, int D, int HW, int C, float* score_map, float* vps,
                       g6d_stream_t stream);
-/* g6d_selector_scan + g6d_selector_prod_affine for all (<= 3) pyramid levels of a query in ONE launch; per-level operands as
- * above, HW[l] <= 1024; vps [nlev][D], scale / shift [nlev][C]; score_maps may be NULL, or hold NULL for levels whose map is not
- * wanted (the viewpoint score only needs vps); Dg = global hypothesis count of the InstanceNorm statistics (= D unless the
- * references are sharded over ranks). */
-int g6d_selector_levels(int nlev, const float* const* que, const float* const* refs, const double* const* r1,
+/* g6d_selector_scan + g6d_selector_prod_affine for all (<= 3) pyramid levels of a BATCH of qn <= 8 queries in ONE launch (+ a tiny
+ * reduction launch): the reference cache is streamed once per batch.  Per level l: que[l] [qn][HW_l][C], refs[l] [D][HW_l][C],
+ * r1[l] / r2[l] [HW_l][C], HW[l] <= 1024, score_maps[l] [qn][D][HW_l] (written; required); vps [qn][nlev][D], scale / shift
+ * [qn][nlev][C]; Dg = global hypothesis count of the InstanceNorm statistics (= D unless the references are sharded over ranks). */
+int g6d_selector_levels(int nlev, int qn, const float* const* que, const float* const* refs, const double* const* r1,
                         const double* const* r2, const int* HW, int D, int Dg, int C, double eps, float* const* score_maps,
                         float* vps, float* scale, float* shift, g6d_stream_t stream);
 
@@ -239,20 +253,23 @@ int g6d_selector_levels(int nlev, const float* const* que, const float* const* r
 int g6d_refiner_volume(const float* feats, const float* projs, const float* rot_in, const float* lin, int rfn, int fh,
                        int fw, int C, int h_in, int w_in, int sn, float* mean_in, float* std, g6d_stream_t stream);
 /* The same with intrinsics and poses given separately (ref_Ks [rfn][3][3], ref_poses [rfn][3][4], K_in [3][3], pose_in [3][4]):
- * the projections K @ pose of network/refiner.py:208-226 are formed inside the kernel and the rotation is read from pose_in. */
+ * the projections K @ pose of network/refiner.py:208-226 are formed inside the kernel and the rotation is read from pose_in.
+ * batch >= 1 queries in one launch (the reference's forward takes [qn,...], refiner.py:249-269): every operand and both outputs
+ * carry a leading [batch] axis (feats [batch][rfn+1][fh][fw][C], ... mean_in [batch][sn^3][2C], std [batch][sn^3][C]). */
 int g6d_refiner_volume_kp(const float* feats, const float* ref_Ks, const float* ref_poses, const float* K_in, const float* pose_in,
                           const float* lin, int rfn, int fh, int fw, int C, int h_in, int w_in, int sn, float* mean_in, float* stdv,
-                          g6d_stream_t stream);
+                          int batch, g6d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Detector score assembly (network/detector.py:225-229,243-245,207-216): for one detection scale, take the three raw
  * correlation maps (level l at 1/(8*2^l) resolution, channels-last [h_l*w_l][rfn]), nearest-upsample levels 1,2 to
  * level-0 size, normalise ((x-mu_l)/sigma_l), clip to +-clip, bilinear-resize (align_corners=False) to (hs,ws) and
- * write channels [3*scale_idx .. 3*scale_idx+2] of stacked [hs*ws][rfn][nch].
+ * write channels [3*scale_idx .. 3*scale_idx+2] of stacked [hs*ws][rfn][nch].  batch >= 1 queries (network/detector.py:291-304
+ * takes [qn,H,W,3]): s_l [batch][h_l*w_l][rfn], stacked [batch][hs*ws][rfn][nch].
  * ---------------------------------------------------------------------------------------------------------------- */
 int g6d_detector_assemble(const float* s0, const float* s1, const float* s2, int hc, int wc, int rfn,
                           const float* mu_sigma /* HOST pointer: {mu0,sigma0,mu1,sigma1,mu2,sigma2} */, float clip, int hs, int ws,
-                          int scale_idx, int nch, float* stacked, g6d_stream_t stream);
+                          int scale_idx, int nch, float* stacked, int batch, g6d_stream_t stream);
 
 /* score_conv + max over references (network/detector.py:159-163,246-247): per (pixel, ref) MLP nch->64 (ReLU) ->64,
  * then max over rfn.  w0 [64][nch], b0[64], w1[64][64], b1[64]; out [P][64]. */
@@ -260,28 +277,33 @@ int g6d_detector_score_mlp_max(const float* stacked, int P, int rfn, int nch, co
                                const float* w1, const float* b1, float* out, g6d_stream_t stream);
 
 /* arg-max + decode (network/detector.py:84-121): scores [hs*ws], offset [hs*ws][2], scale [hs*ws] (channels-last);
- * result[0..1] = position (x,y) px, result[2] = 2^scale, result[3..4] = (x,y) cell of the peak (as float). */
+ * result[0..1] = position (x,y) px, result[2] = 2^scale, result[3..4] = (x,y) cell of the peak (as float).
+ * batch >= 1 queries: the maps of query b start b*hs*ws rows after those of query 0, result [batch][5]. */
 int g6d_detector_decode(const float* scores, int ld_s, const float* offset, int ld_o, const float* scale, int ld_c,
-                        int hs, int ws, int pool_ratio, float* result, g6d_stream_t stream);
+                        int hs, int ws, int pool_ratio, float* result, int batch, g6d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Selector tail helpers (network/selector.py:201-214, network/attention.py:4-17,50-68).
  * ---------------------------------------------------------------------------------------------------------------- */
-/* InstanceNorm2d(3) of vps [3][D] over D, written to channels c_off..c_off+2 of feats [D][ld] (selector.py:201-202) */
-int g6d_vps_norm(const float* vps, int D, float* feats, int ld, int c_off, g6d_stream_t stream);
-/* x[r][c] = max_a in[(r*an+a)][c] + embed[r][c]   (selector.py:204-205) */
-int g6d_max_an_add(const float* in, int ld_in, int rfn, int an, int C, const float* embed, float* out, int ld_out,
+/* The tail helpers take `batch` >= 1 queries (selector.py:165-175 takes [qn,...]): row blocks of the queries follow each other.
+ * InstanceNorm2d(3) of vps [batch][3][D] over D, written to channels c_off..c_off+2 of feats [batch*D][ld] (selector.py:201-202) */
+int g6d_vps_norm(const float* vps, int D, float* feats, int ld, int c_off, int batch, g6d_stream_t stream);
+/* x[b*rfn+r][c] = max_a in[(b*rfn+r)*an+a][c] + embed[r][c]   (selector.py:204-205) */
+int g6d_max_an_add(const float* in, int ld_in, int rfn, int an, int C, const float* embed, float* out, int ld_out, int batch,
                    g6d_stream_t stream);
 /* multi-head attention over n tokens with the reference's head split c -> (d=c/heads, head=c%heads), scale
- * 1/sqrt(C/heads): q,k,v [n][ld] -> out [n][ld_out]  (attention.py:4-17,60-64) */
+ * 1/sqrt(C/heads): q,k,v [batch*n][ld] -> out [batch*n][ld_out], attention among the n tokens of one query
+ * (attention.py:4-17,60-64) */
 int g6d_attention(const float* q, const float* k, const float* v, int ld, int n, int C, int heads, float* out,
-                  int ld_out, g6d_stream_t stream);
+                  int ld_out, int batch, g6d_stream_t stream);
 /* LayerNorm over C per token with affine (attention.py:19-26): out may alias in */
 int g6d_layernorm(const float* in, int ld_in, int n, int C, const float* gamma, const float* beta, float eps,
                   float* out, int ld_out, g6d_stream_t stream);
-/* out = relu?(x*scale+shift) (+ residual) elementwise on [n][C] rows (selector.py:209) */
+/* out = relu?(x*scale+shift) (+ residual) elementwise on [n][C] rows (selector.py:209); rows_per_group = k > 0: row r uses
+ * table r / k of scale / shift [n/k][C] (one InstanceNorm1d per query of a batch), 0: one table */
 int g6d_affine_act_add(const float* in, int ld_in, const float* scale, const float* shift, int relu,
-                       const float* residual, int ld_res, int n, int C, float* out, int ld_out, g6d_stream_t stream);
+                       const float* residual, int ld_res, int n, int C, float* out, int ld_out, int rows_per_group,
+                       g6d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Inter-stage image warps of Gen6DEstimator.predict: cv2.warpAffine in transformation_crop

@@ -25,13 +25,20 @@ def _act(v, act):
 
 
 def conv(x, w, bias, out, ksize=(1, 1, 1), stride=(1, 1, 1), pad=(0, 0, 0), mul=None, in_scale=None, in_shift=None,
-         in_relu=False, per_n=False, out_act=0, stats=None, rows_per_group=0, split_k=0, w_wino=None, finalize=None, eps=1e-5):
-    N, Di, Hi, Wi, Cin = x.shape
+         in_relu=False, per_n=False, out_act=0, stats=None, rows_per_group=0, split_k=0, w_wino=None, finalize=None, eps=1e-5,
+         in_mod=0, mul_group=0):
+    N = out.shape[0] if in_mod else x.shape[0]
+    _, Di, Hi, Wi, Cin = x.shape
     Cout = w.shape[0]
     v = x
-    if mul is not None: v = v * mul[None, None]
+    if in_mod: v = x[torch.arange(N) % in_mod]                      # the queries of a batch share the input images
+    if mul is not None:
+        v = v * (mul[torch.arange(N) // mul_group][:, None] if mul_group else mul[None, None])
+    per_n = int(per_n)
     if in_scale is not None:
-        if per_n: v = v * in_scale.view(N, 1, 1, 1, Cin) + in_shift.view(N, 1, 1, 1, Cin)
+        if per_n:
+            g = torch.arange(N) // per_n                               # a table per run of per_n images
+            v = v * in_scale.reshape(-1, Cin)[g].view(N, 1, 1, 1, Cin) + in_shift.reshape(-1, Cin)[g].view(N, 1, 1, 1, Cin)
         else: v = v * in_scale.view(1, 1, 1, 1, Cin) + in_shift.view(1, 1, 1, 1, Cin)
     if in_relu: v = F.relu(v)
     w5 = w.view(Cout, ksize[0], ksize[1], ksize[2], Cin).permute(0, 4, 1, 2, 3)
@@ -54,7 +61,7 @@ def corr2d_patch(x, w, out, k):
 
 
 def corr2d_patch_multi(xs, w, outs, k):
-    for x, o in zip(xs, outs):
+    for x, o in zip(xs, outs):                                     # [N,1,H,W,C]: the conv reference handles the batch axis
         corr2d_patch(x, w, o, k)
     return outs
 
@@ -77,8 +84,11 @@ def stats_finalize(stats, count, eps=1e-5):
 def _aff(x, scale, shift, per_n, relu):
     N, C = x.shape[0], x.shape[-1]
     if scale is not None:
-        shp = (N, 1, 1, 1, C) if per_n else (1, 1, 1, 1, C)
-        x = x * scale.reshape(shp) + shift.reshape(shp)
+        if per_n:
+            g = torch.arange(N) // int(per_n)
+            x = x * scale.reshape(-1, C)[g].view(N, 1, 1, 1, C) + shift.reshape(-1, C)[g].view(N, 1, 1, 1, C)
+        else:
+            x = x * scale.reshape(1, 1, 1, 1, C) + shift.reshape(1, 1, 1, 1, C)
     return F.relu(x) if relu else x
 
 
@@ -188,11 +198,19 @@ def selector_scan(que, refs):
 
 
 def refiner_volume_kp(feats, ref_Ks, ref_poses, K_in, pose_in, lin, h_in, w_in, mean_in, std):
+    if feats.dim() == 5:                                            # a batch of queries
+        for b in range(feats.shape[0]):
+            refiner_volume_kp(feats[b], ref_Ks[b], ref_poses[b], K_in[b], pose_in[b], lin, h_in, w_in, mean_in[b], std[b])
+        return mean_in, std
     projs = torch.cat([ref_Ks @ ref_poses, (K_in @ pose_in)[None]], 0)
     return refiner_volume(feats, projs, pose_in[:, :3], lin, h_in, w_in, mean_in, std)
 
 
 def selector_levels(ques, refs, sums, Dg, eps=1e-5, want_maps=False):
+    if ques[0].dim() == 3:                                          # [qn,HW,C]: a batch of queries
+        per = [selector_levels([q[i] for q in ques], refs, sums, Dg, eps, want_maps) for i in range(ques[0].shape[0])]
+        maps = [torch.stack([p[3][l] for p in per], 0) for l in range(len(ques))] if want_maps else None
+        return torch.stack([p[0] for p in per], 0), torch.stack([p[1] for p in per], 0), torch.stack([p[2] for p in per], 0), maps
     res = [selector_scan(q, r) for q, r in zip(ques, refs)]
     aff = [selector_prod_affine(q, s[0], s[1], Dg, eps) for q, s in zip(ques, sums)]
     return (torch.stack([r[1] for r in res], 0), torch.cat([a[0] for a in aff], 0), torch.cat([a[1] for a in aff], 0),
@@ -217,7 +235,13 @@ def refiner_volume(feats, projs, rot_in, lin, h_in, w_in, mean_in, std):
     return mean_in, std
 
 
-def detector_assemble(s0, s1, s2, hc, wc, mu_sigma, clip, hs, ws, scale_idx, stacked):
+def detector_assemble(s0, s1, s2, hc, wc, mu_sigma, clip, hs, ws, scale_idx, stacked, batch=1):
+    if batch > 1:
+        for b in range(batch):
+            cut = lambda t, n: t[b * n:(b + 1) * n]
+            detector_assemble(cut(s0, hc * wc), cut(s1, (hc // 2) * (wc // 2)), cut(s2, (hc // 4) * (wc // 4)), hc, wc, mu_sigma, clip,
+                              hs, ws, scale_idx, cut(stacked, hs * ws))
+        return stacked
     rfn = s0.shape[1]
     maps = []
     for l, s in enumerate((s0, s1, s2)):
@@ -235,7 +259,11 @@ def detector_score_mlp_max(stacked, w0, b0, w1, b1):
     return (h @ w1.T + b1).max(1)[0]
 
 
-def detector_decode(scores, offset, scale, hs, ws, pool_ratio):
+def detector_decode(scores, offset, scale, hs, ws, pool_ratio, batch=1):
+    if batch > 1:
+        P = hs * ws
+        return torch.stack([detector_decode(scores[b * P:(b + 1) * P], offset[b * P:(b + 1) * P], scale[b * P:(b + 1) * P], hs, ws, pool_ratio)
+                            for b in range(batch)], 0)
     idx = int(torch.argmax(scores[:, 0]))
     x, y = idx % ws, idx // ws
     res = torch.empty(5, dtype=torch.float32, device=scores.device)
@@ -247,16 +275,27 @@ def detector_decode(scores, offset, scale, hs, ws, pool_ratio):
 
 
 def vps_norm(vps, feats, c_off):
+    if vps.dim() == 3:                                              # [qn,3,D]
+        D = vps.shape[-1]
+        for b in range(vps.shape[0]):
+            vps_norm(vps[b], feats[b * D:(b + 1) * D], c_off)
+        return feats
     feats[:, c_off:c_off + 3] = F.instance_norm(vps[None], eps=1e-5)[0].T
     return feats
 
 
-def max_an_add(x, rfn, an, embed, out):
-    out.copy_(x.reshape(rfn, an, -1).max(1)[0] + embed)
+def max_an_add(x, rfn, an, embed, out, batch=1):
+    out.copy_((x.reshape(batch, rfn, an, -1).max(2)[0] + embed[None]).reshape(batch * rfn, -1))
     return out
 
 
-def attention(q, k, v, heads, out):
+def attention(q, k, v, heads, out, batch=1):
+    if batch > 1:
+        n = q.shape[0] // batch
+        for b in range(batch):
+            sl = slice(b * n, (b + 1) * n)
+            attention(q[sl], k[sl], v[sl], heads, out[sl])
+        return out
     n, C = q.shape
     dh = C // heads
     qh, kh, vh = (t.reshape(n, dh, heads) for t in (q, k, v))
@@ -271,9 +310,14 @@ def layernorm(x, gamma, beta, out, eps=1e-5):
     return out
 
 
-def affine_act_add(x, out, scale=None, shift=None, relu=False, residual=None):
+def affine_act_add(x, out, scale=None, shift=None, relu=False, residual=None, rows_per_group=0):
     v = x
-    if scale is not None: v = v * scale.reshape(1, -1) + shift.reshape(1, -1)
+    if scale is not None:
+        if rows_per_group:
+            g = torch.arange(x.shape[0]) // rows_per_group
+            v = v * scale.reshape(-1, x.shape[1])[g] + shift.reshape(-1, x.shape[1])[g]
+        else:
+            v = v * scale.reshape(1, -1) + shift.reshape(1, -1)
     if relu: v = F.relu(v)
     if residual is not None: v = v + residual
     out.copy_(v)

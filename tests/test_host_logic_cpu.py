@@ -83,3 +83,31 @@ def test_tensor_pipeline_matches_oracle_pipeline():
     assert row.shape == (1, 12)
     assert int(row[0, 3]) == int(ref[0, 3])
     np.testing.assert_allclose(row.numpy(), ref.numpy(), rtol=2e-3, atol=2e-2)
+
+
+def test_batched_queries_equal_single_queries():
+    """qn = 3 queries through ONE set of launches (the query-batch path of every network: shared reference cache through
+    `in_mod`, per-query multiplier maps, per-query InstanceNorm groups / tables, batched tail and volume ops) give the rows of the
+    three single-query calls — on the CPU emulation of the ops, i.e. this checks the host orchestration of the batch."""
+    from gen6d_amd.pipeline import TensorPipeline
+    pipe = TensorPipeline("cpu", sel_rfn=6, det_rfn=6, refine_iter=1)
+    pipe.build()
+    fulls = synth.imgs_to_tensor(synth.synth_images(3, 64, 96, seed=100))
+    crops = synth.imgs_to_tensor(synth.synth_images(3, 128, 128, seed=200))
+    rows = pipe.query(fulls, crops)
+    assert rows.shape == (3, 12)
+    for j in range(3):
+        one = pipe.query(fulls[j:j + 1], crops[j:j + 1])
+        assert int(rows[j, 3]) == int(one[0, 3])
+        np.testing.assert_allclose(rows[j].numpy(), one[0].numpy(), rtol=1e-4, atol=1e-4)
+    # and the per-network [qn,...] contracts
+    with torch.no_grad():
+        logits, angles = pipe.selector.compute_view_point_feats(crops)
+        l1, a1 = pipe.selector.compute_view_point_feats(crops[1:2])
+        det = pipe.detector.detect_impl(fulls)
+        d1 = pipe.detector.detect_impl(fulls[2:3])
+    assert logits.shape == (3, 6) and angles.shape == (3, 6) and det["scores"].shape == (3, 1, 8, 12)
+    np.testing.assert_allclose(logits[1].numpy(), l1[0].numpy(), atol=1e-4)
+    np.testing.assert_allclose(angles[1].numpy(), a1[0].numpy(), atol=1e-4)
+    np.testing.assert_allclose(det["scores"][2].numpy(), d1["scores"][0].numpy(), atol=1e-4 * float(d1["scores"].abs().max()))
+    assert torch.equal(det["que_select_id"][2], d1["que_select_id"][0])

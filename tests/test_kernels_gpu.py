@@ -57,10 +57,10 @@ CONV_CASES = [
     dict(N=1, D=8, H=8, W=8, Cin=256, Cout=256, k=(3, 3, 3), s=(1, 1, 1), p=(1, 1, 1), stats=True, split=1),        # forced no split
     dict(N=1, D=8, H=8, W=8, Cin=256, Cout=256, k=(3, 3, 3), s=(1, 1, 1), p=(1, 1, 1), stats=True, split=7, act=2),
     dict(N=2, D=1, H=5, W=5, Cin=20, Cout=40, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), act=2),                        # odd sizes
-    # split launches: <= 16 splits finish inside the kernel (last block of a tile), more go through the reduce kernel
+    # split launches finish inside the kernel at every split count (the last block of a tile adds the partials)
     dict(N=1, D=1, H=10, W=10, Cin=512, Cout=96, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), stats=True, split=5, act=1),     # ragged tile, in-kernel
     dict(N=3, D=1, H=11, W=13, Cin=256, Cout=200, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), stats=True, rpg=143, split=16), # groups straddle tiles
-    dict(N=1, D=4, H=4, W=4, Cin=256, Cout=512, k=(3, 3, 3), s=(2, 2, 2), p=(1, 1, 1), stats=True, split=24),            # reduce kernel
+    dict(N=1, D=4, H=4, W=4, Cin=256, Cout=512, k=(3, 3, 3), s=(2, 2, 2), p=(1, 1, 1), stats=True, split=24),            # 24 splits, in-kernel
     dict(N=1, D=8, H=8, W=8, Cin=128, Cout=32, k=(3, 3, 3), s=(2, 2, 2), p=(1, 1, 1), aff=True, relu=True, split=9),     # 128x32 tiles
     # shapes that take the LDS-patch kernel (conv_patch.hip): stride 1, 3x3(x3), Cout <= 64, >= 128 tiles
     dict(N=1, D=16, H=16, W=16, Cin=64, Cout=64, k=(3, 3, 3), s=(1, 1, 1), p=(1, 1, 1), aff=True, relu=True, stats=True),
@@ -75,6 +75,17 @@ CONV_CASES = [
     dict(N=320, D=1, H=8, W=8, Cin=512, Cout=128, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), mul=True, aff=True, stats=True),
     dict(N=323, D=1, H=4, W=4, Cin=128, Cout=256, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), aff=True, relu=True),             # 4x4 maps stay on the generic kernel
     dict(N=320, D=1, H=4, W=4, Cin=512, Cout=256, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), mul=True, aff=True, stats=True),
+    # query batches (round 3): N = qn * k hypothesis images share the k input images (in_mod), every query has its own multiplier
+    # map (mul_group), InstanceNorm table (per_n = k) and statistics group (rpg = k * rows per image)
+    dict(N=120, D=1, H=4, W=4, Cin=512, Cout=256, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), mul=True, aff=True, per_n=40, in_mod=40, mul_group=40,
+         stats=True, rpg=40 * 16),                                                                                       # generic kernel, MODE 4
+    dict(N=46, D=1, H=4, W=4, Cin=128, Cout=256, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), aff=True, relu=True, per_n=23, stats=True, rpg=23 * 16),
+    dict(N=80, D=1, H=16, W=16, Cin=64, Cout=64, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), aff=True, relu=True, per_n=20, stats=True, rpg=20 * 256),  # LDS-patch kernel
+    dict(N=66, D=1, H=8, W=8, Cin=64, Cout=128, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), aff=True, relu=True, per_n=22, stats=True, rpg=22 * 64),    # 2 images / tile
+    dict(N=63, D=1, H=8, W=8, Cin=64, Cout=128, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), aff=True, relu=True, per_n=21, stats=True, rpg=21 * 64),    # odd group: 1 image / tile
+    dict(N=2, D=16, H=16, W=16, Cin=64, Cout=64, k=(3, 3, 3), s=(1, 1, 1), p=(1, 1, 1), aff=True, relu=True, per_n=1, stats=True, rpg=4096),       # batch of volumes
+    dict(N=3, D=8, H=8, W=8, Cin=64, Cout=128, k=(3, 3, 3), s=(2, 2, 2), p=(1, 1, 1), aff=True, relu=True, per_n=1, stats=True, rpg=64),
+    dict(N=3, D=1, H=1, W=64, Cin=512, Cout=512, k=(1, 1, 1), s=(1, 1, 1), p=(0, 0, 0), aff=True, relu=True, per_n=1, stats=True, rpg=64),        # selector tail, 3 queries
 ]
 
 
@@ -100,6 +111,14 @@ WINO_CONV_CASES = [
     dict(N=2, D=5, H=9, W=11, Cin=16, Cout=32, k=(3, 3, 3), s=(1, 1, 1), p=(1, 1, 1), act=1, stats=True, rpg=495),             # odd sizes, 32 output channels
     dict(N=3, D=1, H=4, W=4, Cin=128, Cout=256, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), aff=True, relu=True),                   # not eligible: 4x4 map
     dict(N=1, D=8, H=8, W=8, Cin=64, Cout=128, k=(3, 3, 3), s=(2, 2, 2), p=(1, 1, 1), stats=True),                             # not eligible: stride 2
+    # query batches on the Winograd kernel (tables of the block's four quarters in LDS; blocks straddle query groups)
+    dict(N=60, D=1, H=16, W=16, Cin=512, Cout=64, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), mul=True, aff=True, per_n=20, in_mod=20, mul_group=20,
+         stats=True, rpg=20 * 256),
+    dict(N=26, D=1, H=8, W=8, Cin=512, Cout=128, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), mul=True, aff=True, per_n=13, in_mod=13, mul_group=13,
+         stats=True, rpg=13 * 64),
+    dict(N=63, D=1, H=16, W=16, Cin=64, Cout=64, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), aff=True, relu=True, per_n=21, stats=True, rpg=21 * 256),
+    dict(N=2, D=16, H=16, W=16, Cin=128, Cout=64, k=(3, 3, 3), s=(1, 1, 1), p=(1, 1, 1), aff=True, relu=True, per_n=1, stats=True, rpg=4096),  # volumes of 2 queries
+    dict(N=3, D=8, H=8, W=8, Cin=256, Cout=256, k=(3, 3, 3), s=(1, 1, 1), p=(1, 1, 1), aff=True, relu=True, per_n=1, stats=True, rpg=512),
 ]
 
 
@@ -124,14 +143,15 @@ def _run_conv_case(ops, case, wino):
     k, s, p = c["k"], c["s"], c["p"]
     ld_in, ld_out = c.get("ld_in", Cin), c.get("ld_out", Cout)
     Do, Ho, Wo = [(i + 2 * pp - kk) // ss + 1 for i, kk, ss, pp in zip((D, H, W), k, s, p)]
-    xbuf = _rand(g, N, D, H, W, ld_in)
+    in_mod, mul_group, per_n = c.get("in_mod", 0), c.get("mul_group", 0), int(c.get("per_n", 0))
+    xbuf = _rand(g, in_mod or N, D, H, W, ld_in)
     off = 64 if ld_in >= Cin + 64 else 0
     x = xbuf[..., off:off + Cin]
     T = k[0] * k[1] * k[2]
     w = _rand(g, Cout, T, Cin, scale=(1.0 / (T * Cin)) ** 0.5)
     bias = _rand(g, Cout, scale=0.1)
-    mul = _rand(g, H, W, Cin) if c.get("mul") else None
-    groups_in = N if c.get("per_n") else 1
+    mul = (_rand(g, (N + mul_group - 1) // mul_group, H, W, Cin) if mul_group else _rand(g, H, W, Cin)) if c.get("mul") else None
+    groups_in = (N + per_n - 1) // per_n if per_n else 1
     sc = (0.5 + torch.rand((groups_in, Cin), generator=g)) if c.get("aff") else None
     sh = _rand(g, groups_in, Cin, scale=0.3) if c.get("aff") else None
     M = N * Do * Ho * Wo
@@ -146,15 +166,16 @@ def _run_conv_case(ops, case, wino):
     count = float(rpg if rpg else M)
     res = ops.conv(xv, w.to(dev), bias.to(dev), out, ksize=k, stride=s, pad=p, mul=mul.to(dev) if mul is not None else None,
                    in_scale=sc.to(dev) if sc is not None else None, in_shift=sh.to(dev) if sh is not None else None,
-                   in_relu=bool(c.get("relu")), per_n=bool(c.get("per_n")), out_act=c.get("act", 0), stats=stats,
+                   in_relu=bool(c.get("relu")), per_n=per_n, out_act=c.get("act", 0), stats=stats,
                    rows_per_group=rpg, split_k=c.get("split", 0), w_wino=_wino_u(w, k).to(dev) if wino else None,
-                   finalize=count if stats is not None else None)          # InstanceNorm affine from the launch's last block
+                   finalize=count if stats is not None else None,          # InstanceNorm affine from the launch's last block
+                   in_mod=in_mod, mul_group=mul_group)
     torch.cuda.synchronize()
     ref = torch.empty((N, Do, Ho, Wo, Cout), dtype=torch.float64)
     rstats = torch.zeros((G, Cout, 2), dtype=torch.float64) if c.get("stats") else None
     ref_ops.conv(_d(x), _d(w), _d(bias), ref, ksize=k, stride=s, pad=p, mul=_d(mul), in_scale=_d(sc), in_shift=_d(sh),
-                 in_relu=bool(c.get("relu")), per_n=bool(c.get("per_n")), out_act=c.get("act", 0), stats=rstats,
-                 rows_per_group=rpg)
+                 in_relu=bool(c.get("relu")), per_n=per_n, out_act=c.get("act", 0), stats=rstats,
+                 rows_per_group=rpg, in_mod=in_mod, mul_group=mul_group)
     _check(out, ref, 4e-5 if wino else 2e-5, "conv out")
     if ld_out != Cout:
         assert (outbuf[..., Cout:] == -777.0).all(), "conv wrote outside its channel slice"
@@ -226,6 +247,11 @@ def test_affine_act_pool(ops, pool, per_n, relu):
     out2 = torch.empty((N, 1, H, W, C), device="cuda")
     ops.affine_act_pool(x.cuda(), out2)
     _check(out2, x, 0)
+    if per_n:                                   # a table per run of 3 images (query groups of a batch)
+        sc3, sh3 = 0.5 + torch.rand((2, C), generator=g), _rand(g, 2, C)
+        ops.affine_act_pool(x.cuda(), out, sc3.cuda(), sh3.cuda(), per_n=3, relu=relu, pool=pool)
+        ref_ops.affine_act_pool(_d(x), ref, _d(sc3), _d(sh3), per_n=3, relu=relu, pool=pool)
+        _check(out, ref, 1e-6)
 
 
 @pytest.mark.parametrize("factor", [2, 4])
@@ -293,9 +319,30 @@ def test_selector_levels(ops, want_maps):
         _check(vps[l], rvps, 1e-5, f"vps level {l}")
         if want_maps:
             _check(maps[l], rsmap, 2e-6, f"score map level {l}")
-        # same numbers as the per-level entry points
+        # same numbers as the per-level entry points (the reduction over HW runs in another kernel: float reassociation)
         smap1, vps1 = ops.selector_scan(q.cuda(), r.cuda())
-        assert torch.equal(vps1, vps[l])
+        _check(vps1, vps[l].double().cpu(), 2e-6, "per-level entry point")
+
+
+@pytest.mark.parametrize("qn,D", [(2, 45), (4, 33), (7, 10)])
+def test_selector_levels_query_batch(ops, qn, D):
+    """qn queries against one streamed pass over the reference cache: every query's vps / product statistics / score maps equal
+    those of its own single-query call."""
+    g = torch.Generator().manual_seed(180 + qn)
+    C, Dg = 512, D
+    hws = [256, 64, 16]
+    refs = [torch.nn.functional.normalize(_rand(g, D, hw, C), dim=2).cuda() for hw in hws]
+    ques = [torch.nn.functional.normalize(_rand(g, qn, hw, C) + 0.3, dim=2).cuda() for hw in hws]
+    sums = [ops.selector_ref_sums(r) for r in refs]
+    vps, sc, sh, maps = ops.selector_levels(ques, refs, sums, Dg, want_maps=True)
+    assert vps.shape == (qn, 3, D) and sc.shape == (qn, 3, C) and maps[0].shape == (qn, D, 256)
+    for q in range(qn):
+        v1, sc1, sh1, m1 = ops.selector_levels([t[q].contiguous() for t in ques], refs, sums, Dg, want_maps=True)
+        assert torch.equal(v1, vps[q]) and torch.equal(sc1, sc[q]) and torch.equal(sh1, sh[q])
+        for l in range(3):
+            assert torch.equal(m1[l], maps[l][q])
+            rsmap, rvps = ref_ops.selector_scan(_d(ques[l][q]), _d(refs[l]))
+            _check(vps[q, l], rvps, 1e-5, f"vps q{q} l{l}")
 
 
 @pytest.mark.parametrize("rfn", [6, 1, 8])
@@ -321,6 +368,18 @@ def test_refiner_volume(ops, rfn):
                           case["Ks_in"][0].contiguous().cuda(), case["poses_in"][0].contiguous().cuda(), lin.cuda(), 128, 128, m2, s2)
     _check(m2, rm, 2e-4, "mean|query (kp)")
     _check(s2, rs, 2e-4, "std (kp)")
+    # a batch of 3 queries (own views, cameras and input poses) in one launch equals the three single launches
+    B = 3
+    fb = torch.stack([feats, feats.flip(0), feats * 0.5], 0).contiguous().cuda()
+    Kb = torch.stack([case["ref_Ks"][0]] * B, 0).contiguous().cuda()
+    Pb = torch.stack([case["ref_poses"][0], case["ref_poses"][0].flip(0), case["ref_poses"][0]], 0).contiguous().cuda()
+    Kin = torch.stack([case["Ks_in"][0]] * B, 0).contiguous().cuda()
+    pin = torch.stack([case["poses_in"][0], torch.from_numpy(synth.perturb_pose(case["poses_in"][0].numpy(), 3.0, 0.02)), case["poses_in"][0]], 0).contiguous().cuda()
+    mb = torch.empty((B, sn ** 3, 2 * C), device="cuda"); sb = torch.empty((B, sn ** 3, C), device="cuda")
+    ops.refiner_volume_kp(fb, Kb, Pb, Kin, pin, lin.cuda(), 128, 128, mb, sb)
+    for b in range(B):
+        ops.refiner_volume_kp(fb[b].contiguous(), Kb[b].contiguous(), Pb[b].contiguous(), Kin[b].contiguous(), pin[b].contiguous(), lin.cuda(), 128, 128, m2, s2)
+        assert torch.equal(mb[b], m2) and torch.equal(sb[b], s2), f"batched volume {b} differs from its single launch"
 
 
 def test_detector_glue(ops):
@@ -346,6 +405,19 @@ def test_detector_glue(ops):
     rres = ref_ops.detector_decode(_d(o4)[:, 0:1], _d(o4)[:, 2:4], _d(o4)[:, 1:2], hs, ws, 8)
     assert int(res[3].item()) == 37 % ws and int(res[4].item()) == 37 // ws
     _check(res, rres, 1e-6, "decode")
+    # a batch of 3 queries: level maps / stacked slabs / decode rows of the queries one after the other
+    B = 3
+    sb = [_rand(g, B * (hc >> l) * (wc >> l), rfn, scale=3 * stats[l][1]) + stats[l][0] for l in range(3)]
+    stb = torch.zeros((B * hs * ws, rfn, 12), device="cuda"); rstb = torch.zeros((B * hs * ws, rfn, 12), dtype=torch.float64)
+    for si in range(4):
+        ops.detector_assemble(sb[0].cuda(), sb[1].cuda(), sb[2].cuda(), hc, wc, stats, 10.0, hs, ws, si, stb, batch=B)
+        ref_ops.detector_assemble(_d(sb[0]), _d(sb[1]), _d(sb[2]), hc, wc, stats, 10.0, hs, ws, si, rstb, batch=B)
+    _check(stb, rstb, 1e-5, "assemble batch")
+    o4b = _rand(g, B * hs * ws, 4)
+    resb = ops.detector_decode(o4b.cuda()[:, 0:1], o4b.cuda()[:, 2:4], o4b.cuda()[:, 1:2], hs, ws, 8, batch=B)
+    rresb = ref_ops.detector_decode(_d(o4b)[:, 0:1], _d(o4b)[:, 2:4], _d(o4b)[:, 1:2], hs, ws, 8, batch=B)
+    assert resb.shape == (B, 5)
+    _check(resb, rresb, 1e-6, "decode batch")
 
 
 def test_selector_tail_ops(ops):
@@ -376,6 +448,28 @@ def test_selector_tail_ops(ops):
     ops.affine_act_add(x[:rfn].cuda(), o, sc.cuda(), sh.cuda(), relu=True, residual=emb.cuda())
     ref_ops.affine_act_add(_d(x[:rfn]), ro, _d(sc), _d(sh), relu=True, residual=_d(emb))
     _check(o, ro, 1e-6, "affine_act_add")
+    # ---- the same helpers on a batch of B queries (row blocks of the queries one after the other)
+    B = 3
+    vb = _rand(g, B, 3, D, scale=20) + 30
+    fb = torch.zeros((B * D, 516), device="cuda"); rfb = torch.zeros((B * D, 516), dtype=torch.float64)
+    ops.vps_norm(vb.cuda(), fb, 512); ref_ops.vps_norm(_d(vb), rfb, 512)
+    _check(fb, rfb, 1e-5, "vps_norm batch")
+    xb = _rand(g, B * D, C)
+    ob = torch.zeros((B * rfn, 1024), device="cuda"); rob = torch.zeros((B * rfn, C), dtype=torch.float64)
+    ops.max_an_add(xb.cuda(), rfn, an, emb.cuda(), ob[:, :512], batch=B); ref_ops.max_an_add(_d(xb), rfn, an, _d(emb), rob, batch=B)
+    _check(ob[:, :512], rob, 1e-6, "max_an_add batch")
+    qb = _rand(g, B * rfn, 1536).cuda()
+    ab = torch.empty((B * rfn, C), device="cuda"); rab = torch.empty((B * rfn, C), dtype=torch.float64)
+    ops.attention(qb[:, :512], qb[:, 512:1024], qb[:, 1024:], 8, ab, batch=B)
+    qbd = _d(qb)
+    ref_ops.attention(qbd[:, :512], qbd[:, 512:1024], qbd[:, 1024:], 8, rab, batch=B)
+    _check(ab, rab, 1e-5, "attention batch")
+    scb, shb = 0.5 + torch.rand((B, C), generator=g), _rand(g, B, C)
+    xr = _rand(g, B * rfn, C); res_ = _rand(g, B * rfn, C)
+    ob2 = torch.empty((B * rfn, C), device="cuda"); rob2 = torch.empty((B * rfn, C), dtype=torch.float64)
+    ops.affine_act_add(xr.cuda(), ob2, scb.cuda(), shb.cuda(), relu=True, residual=res_.cuda(), rows_per_group=rfn)
+    ref_ops.affine_act_add(_d(xr), rob2, _d(scb), _d(shb), relu=True, residual=_d(res_), rows_per_group=rfn)
+    _check(ob2, rob2, 1e-6, "affine_act_add batch")
 
 
 @pytest.mark.parametrize("B,K,O,act", [(1, 32768, 512, 2), (1, 512, 7, 0), (3, 1024, 40, 1)])
@@ -505,6 +599,28 @@ def test_corr2d_patch_multi(ops, k, sizes, Cin, Cout):
             assert (o - single).abs().max().item() <= 1e-5 * max(1.0, single.abs().max().item())
 
 
+def test_corr2d_patch_multi_query_batch(ops):
+    """Three queries per scale in one launch (G6dCorrSeg.N), incl. the 3x3 level that joined the multi launch in round 3."""
+    for k, sizes in ((7, [(22, 29), (15, 20), (11, 15), (8, 10)]), (3, [(11, 15), (8, 10), (6, 8), (4, 5)]), (15, [(24, 40), (16, 20)])):
+        g = torch.Generator().manual_seed(700 + k)
+        Cin, Cout, N = 512, 32, 3
+        w = _rand(g, Cout, k * k, Cin, scale=(1.0 / (k * k * Cin)) ** 0.5)
+        xs_cpu = [_rand(g, N, 1, h, ww, Cin) for h, ww in sizes]
+        dev = torch.device("cuda")
+        xs = ops.alloc_like_segments([tuple(x.shape) for x in xs_cpu], dev)
+        for d_, x in zip(xs, xs_cpu):
+            d_.copy_(x)
+        outs = ops.alloc_like_segments([(N, 1, h, ww, Cout) for h, ww in sizes], dev)
+        for rep in range(2):
+            for o in outs:
+                o.fill_(-3.0)
+            ops.corr2d_patch_multi(xs, w.cuda(), outs, k)
+            for o, xc in zip(outs, xs_cpu):
+                ref = torch.empty(tuple(o.shape), dtype=torch.float64)
+                ref_ops.corr2d_patch(_d(xc), _d(w), ref, k)
+                _check(o, ref, 2e-5, f"corr2d multi batch k={k}")
+
+
 WINO_MULTI_CASES = [
     # segment sizes (N, H, W), Cin, Cout, relu, full, pool
     ([(1, 44, 58), (1, 30, 40), (1, 22, 30), (1, 16, 20)], 512, 512, False, True, True),     # detector pyramid, 1/16 level, c7_pre + p7
@@ -582,6 +698,11 @@ def test_l2norm_rows(ops):
     x[0, 0, 0] = 0.0                                   # zero row: eps branch of F.normalize
     got = ops.l2norm_rows(x.cuda().clone())
     _check(got, F.normalize(x.double(), dim=-1), 1e-6, "l2norm_rows")
+    # row-strided view with rows that are not 16-byte aligned: the quaternions of a batch of regressor outputs [qn,7]
+    o = _rand(g, 5, 7).cuda()
+    want = torch.cat([F.normalize(o[:, :4].double().cpu(), dim=1), o[:, 4:].double().cpu()], 1)
+    ops.l2norm_rows(o[:, 0:4])
+    _check(o, want, 1e-6, "l2norm_rows strided")
 
 
 def test_own_trunk_matches_library_trunk(ops):

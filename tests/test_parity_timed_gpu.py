@@ -157,6 +157,58 @@ def test_lane_graph_replay_matches_eager_and_reference(golden, lanes):
     assert e <= 2e-3
 
 
+@pytest.mark.parametrize("batch,lanes", [(4, 2), (3, 1), (8, 1)])
+def test_batched_graph_replay_matches_single_queries_and_reference(golden, batch, lanes):
+    """bench.py's round-3 launch mode: one captured graph = one BATCH of queries that share every launch (detector pyramid segments
+    of `batch` images, the selector's qn*D hypothesis images over one pass of the reference cache, `batch` volumes), `lanes` batches
+    in flight.  Every row equals the single-query eager row (the batch changes tile / split choices and the order of the
+    statistics atomics, not the arithmetic: <= 1e-4 relative) and the reference's own golden row (arg-max exact, <= 1e-4);
+    images rotate against batch rows and lanes so that a skipped replay cannot pass."""
+    from gen6d_amd import ops
+    from gen6d_amd.pipeline import TensorPipeline
+    g = golden("pipeline_rows")
+    dev = torch.device("cuda", 0)
+    pipe = TensorPipeline(dev)
+    pipe.build()
+    fulls = synth.imgs_to_tensor(synth.synth_images(4, 480, 640, seed=100)).to(dev)
+    crops = synth.imgs_to_tensor(synth.synth_images(4, 128, 128, seed=200)).to(dev)
+    old_serial = ops.SERIAL
+    ops.SERIAL = True
+    try:
+        single = [pipe.query(fulls[j:j + 1], crops[j:j + 1]).clone() for j in range(4)]
+        eager_b = pipe.query(fulls[torch.arange(batch, device=dev) % 4], crops[torch.arange(batch, device=dev) % 4]).clone()
+        torch.cuda.synchronize()
+        pipe.capture(lanes=lanes, batch=batch)
+        busy, outs = [None] * lanes, []
+        for i in range(3 * lanes + 2):
+            lane = i % lanes
+            if busy[lane] is not None:
+                busy[lane].synchronize()
+            idx = [(i * batch + b + i // lanes) % 4 for b in range(batch)]
+            it = torch.tensor(idx, device=dev)
+            out, stream = pipe.query_graph(fulls[it], crops[it], lane)
+            ev = torch.cuda.Event(); ev.record(stream)
+            busy[lane] = ev
+            outs.append((idx, out))
+        torch.cuda.synchronize()
+    finally:
+        ops.SERIAL = old_serial
+    gold = torch.from_numpy(g["rows"]).float()
+    worst_s = worst_g = 0.0
+    for b in range(batch):
+        worst_s = max(worst_s, _row_err(eager_b[b].cpu(), single[b % 4].cpu()[0]))
+    for idx, out in outs:
+        rows = out.cpu()
+        for b, j in enumerate(idx):
+            assert int(rows[b, 3]) == int(gold[j, 3]), f"image {j} in batch row {b}: viewpoint arg-max {int(rows[b, 3])} != reference {int(gold[j, 3])}"
+            worst_s = max(worst_s, _row_err(rows[b], single[j].cpu()[0]))
+            worst_g = max(worst_g, _row_err(rows[b], gold[j]))
+    record(f"test_batched_graph_replay[{batch}x{lanes}]", "batched graph row vs single-query eager row (relative)", worst_s, 1e-4)
+    record(f"test_batched_graph_replay[{batch}x{lanes}]", "batched graph row vs reference golden rows (relative to max(1,|ref|))", worst_g, 1e-4)
+    assert worst_s <= 1e-4, worst_s
+    assert worst_g <= 1e-4, worst_g
+
+
 def test_three_lane_graph_replay_with_forked_branches():
     """bench.py --fork: the independent branches of one query run on side streams inside each lane's graph.  Side streams,
     their split-K workspaces and arenas are per lane: replaying the lanes concurrently must still reproduce
