@@ -60,6 +60,10 @@ namespace {
 //   KD    3: 3x3x3 layers as a 2-D Winograd over (h, w) with the three depth taps folded into the reduction: chunk c =
 //         (kd, 8 input channels) reads depth slice d + kd - 1 — the transform-domain accumulators are shared, so the
 //         multiplication count drops from 27 to 12 per output.
+//         25: a 15x15 "same" correlation (the detector's reference-as-filter level, network/detector.py:222-224) as 5x5 blocks of 3x3
+//         sub-filters: out = sum_{bi,bj} conv3x3(in shifted by (3bi-6, 3bj-6), w[3bi..3bi+2, 3bj..3bj+2]) — chunk c = (block, 8 input
+//         channels) reads the raw patch at the block's shift, all 25 blocks accumulate in the same transform-domain accumulators:
+//         225 taps cost 25 * 16 / 4 = 100 multiplications per output (2.25x fewer, as for a single 3x3).
 //   NWN   output-channel width of a block in 32s: 2 = 64 channels / 4 waves; 1 = 32 channels / 2 waves (two such blocks share a
 //         CU), used when 64-wide blocks would leave CUs idle (e.g. the 32^3 x 64 volume layers: 128 -> 256 blocks).
 // Epilogue additions for those layers: per-(group, channel) sum / sum of squares of the outputs for the following
@@ -153,6 +157,8 @@ __global__ void __launch_bounds__(128 * NWN, 1) wino_conv3x3_kernel(const WinoAr
   int poff[NPR], lsto[NPR], moff[MODE == 3 ? NPR : 1], aoff[MODE != 0 ? NPR : 1];
   bool pval[NPR], live[NPR];
   unsigned dbits = 0;                                          // KD = 3: bit 2j / 2j+1 = piece j has a slice below / above
+  unsigned smask[KD == 25 ? NPR : 1];                          // KD = 25: bits 0-4 / 8-12 = row / column of the piece inside the image under block shift b
+  int rstep[KD == 25 ? NPR : 1];                               //          floats per block step along y (3 rows of the piece's map)
 #pragma unroll
   for (int j = 0; j < NPR; ++j) {
     const int idx = tid + THREADS * j;
@@ -169,6 +175,15 @@ __global__ void __launch_bounds__(128 * NWN, 1) wino_conv3x3_kernel(const WinoAr
     if constexpr (MODE == 3) moff[j] = pval[j] ? (((p.mul_div > 0 ? n / p.mul_div : 0) * p.H + iy) * p.W + ix) * p.Cin + 4 * half : 0;
     if constexpr (MODE != 0) aoff[j] = (MODE >= 2 ? (q < 4 ? q : 0) * p.Cin : 0) + 4 * half;
     if constexpr (KD == 3) { const int dd = n % p.D; dbits |= (unsigned)(dd > 0) << (2 * j) | (unsigned)(dd < p.D - 1) << (2 * j + 1); }
+    if constexpr (KD == 25) {
+      unsigned m = 0;
+#pragma unroll
+      for (int b = 0; b < 5; ++b)
+        m |= (unsigned)((unsigned)(iy + 3 * b - 6) < (unsigned)g.H) << b | (unsigned)((unsigned)(ix + 3 * b - 6) < (unsigned)g.W) << (8 + b);
+      smask[j] = ((idx < 800) & g.valid) ? m : 0u;
+      rstep[j] = 3 * g.W * g.ld_in;
+      poff[j] = g.in_off + ((n * g.H + iy) * g.W + ix) * g.ld_in + 4 * half;      // the UNSHIFTED position (may lie outside: used under smask only)
+    }
   }
   unsigned pboff[MODE == 0 && KD == 1 ? NPR : 1];            // byte offsets of the pieces for the buffer loads (beyond the tensor: zero)
   if constexpr (MODE == 0 && KD == 1) {
@@ -180,10 +195,15 @@ __global__ void __launch_bounds__(128 * NWN, 1) wino_conv3x3_kernel(const WinoAr
   f32x4 rp[NPR], rm[MODE == 3 ? NPR : 1];
   bool rv[NPR];                                               // validity of the piece for the chunk it was loaded for
   auto load_piece = [&](int j, int chunk) {
-    const int kd = KD == 3 ? chunk / nc8 : 0, cc = KD == 3 ? chunk - kd * nc8 : chunk;
+    const int kd = KD != 1 ? chunk / nc8 : 0, cc = KD != 1 ? chunk - kd * nc8 : chunk;
     bool v = pval[j];
     int off = poff[j] + cc * 8;
     if constexpr (KD == 3) { v &= kd == 1 || ((dbits >> (2 * j + (kd >> 1))) & 1u) != 0; off += (kd - 1) * slice; }
+    if constexpr (KD == 25) {                      // block (bi, bj) of the 15x15 filter: the patch shifted by (3bi - 6, 3bj - 6)
+      const int bi = kd / 5, bj = kd - 5 * bi;
+      v = ((smask[j] >> bi) & (smask[j] >> (8 + bj)) & 1u) != 0;
+      off += (bi - 2) * rstep[j] + (bj - 2) * 3 * p.ld_in;
+    }
     rv[j] = v;
     if constexpr (MODE == 0) {
       // bounds-checked buffer load: pieces outside the image (zero padding, masked quarters) ask for an offset beyond the
@@ -204,7 +224,7 @@ __global__ void __launch_bounds__(128 * NWN, 1) wino_conv3x3_kernel(const WinoAr
     for (int j = 0; j < NPR; ++j) load_piece(j, chunk);
   };
   auto store_piece = [&](int j, int st, int chunk) {   // unconditional stores (a branch would serialise them behind one vmcnt(0) each);
-    const int cc = KD == 3 ? chunk % nc8 : chunk;       // the idle pieces of the last round go to a scratch row behind the stages
+    const int cc = KD != 1 ? chunk % nc8 : chunk;       // the idle pieces of the last round go to a scratch row behind the stages
     {
       f32x4 v = rp[j];
       if constexpr (MODE == 3) v *= rm[j];
@@ -556,6 +576,7 @@ int wino_run(WinoArgs& a, int mode, int kd, float* workspace, size_t workspace_b
   static const bool debug = []() { const char* e = getenv("G6D_WINO_DEBUG"); return e && e[0] == '1'; }();
   if (debug) fprintf(stderr, "wino %d seg, N=%d %dx%dx%d->%d kd=%d mode=%d: grid %lld x %d splits of %d chunks\n", a.nseg, a.N, a.H, a.W, a.Cin,
                      a.Cout, kd, mode, grid2, splits, cps);
+  if (kd == 25) return wino_launch_w<0, 25>(a, blocks, nwn, stream);
   if (kd == 3) return mode == 2 ? wino_launch_w<2, 3>(a, blocks, nwn, stream)
                     : mode == 1 ? wino_launch_w<1, 3>(a, blocks, nwn, stream) : wino_launch_w<0, 3>(a, blocks, nwn, stream);
   if (mode == 3) return wino_launch_w<3, 1>(a, blocks, nwn, stream);
@@ -625,6 +646,40 @@ extern "C" int g6d_wino_conv3x3_multi(const G6dWinoSeg* segs, int nseg, int Cin,
   }
   a.N = segs[0].N; a.H = segs[0].H; a.W = segs[0].W; a.ld_in = segs[0].ld_in; a.ld_full = segs[0].ld_full; a.ld_pool = segs[0].ld_pool;
   return wino_run(a, 0, 1, workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream));
+}
+
+// The detector's 15x15 reference-as-filter correlation (network/detector.py:222-224) on the Winograd kernel: 5x5 blocks of 3x3
+// sub-filters accumulated in the transform domain (KD = 25 above) — 2.25x fewer multiplications than the direct form of
+// g6d_corr2d_patch.  Maps as in g6d_corr2d_patch_multi (up to 4 sizes, N maps each); U = the 25 sub-filter banks transformed like
+// g6d_wino_conv3x3's, block-major: [25 * Cin/8][16][Cout][8], block b = 5 bi + bj holding w[:, 3bi..3bi+2, 3bj..3bj+2, :].
+extern "C" int g6d_corr2d_wino_multi(const G6dCorrSeg* segs, int nseg, int Cin, const float* U, int Cout, int kblocks, float* workspace,
+                                     size_t workspace_bytes, g6d_stream_t stream) {
+  if (!segs || nseg < 1 || nseg > WINO_MAX_SEG || !U || kblocks != 5 || Cin <= 0 || (Cin & 7) || Cout <= 0 || (Cout & 31) || !g6d_aligned16(U)) {
+    g6d_set_error("corr2d_wino_multi: bad args (1..4 map sizes, 15x15 = 5 blocks, Cin % 8 == 0, Cout % 32 == 0)"); return G6D_EINVAL;
+  }
+  WinoArgs a = {};
+  const float* in0 = segs[0].in; float* f0 = segs[0].out;
+  for (int k = 0; k < nseg; ++k) {
+    const G6dCorrSeg& g = segs[k];
+    if (!g.in || !g.out || g.N <= 0 || g.H <= 0 || g.W <= 0 || (g.ld_in & 3) || g.ld_in < Cin || g.ld_in != segs[0].ld_in || g.ld_out < Cout ||
+        !g6d_aligned16(g.in)) {
+      g6d_set_error("corr2d_wino_multi: bad map (all maps share ld_in)"); return G6D_EINVAL;
+    }
+    if (g.in < in0) in0 = g.in;
+    if (g.out < f0) f0 = g.out;
+  }
+  a.in = in0; a.U = U; a.bias = nullptr; a.out_full = f0; a.out_pool = nullptr;
+  a.Cin = Cin; a.Cout = Cout; a.relu = 0; a.D = 1; a.nseg = nseg;
+  for (int k = 0; k < nseg; ++k) {
+    const G6dCorrSeg& g = segs[k];
+    const long long io = g.in - in0, fo = g.out - f0;
+    if (io + (long long)g.N * g.H * g.W * g.ld_in >= (1ll << 29) || fo + (long long)g.N * g.H * g.W * g.ld_out >= (1ll << 31)) {
+      g6d_set_error("corr2d_wino_multi: maps must lie within 2^29 floats of each other (allocate them from one buffer)"); return G6D_EINVAL;
+    }
+    a.seg[k] = WinoSeg{0, g.N, g.H, g.W, 0, 0, (int)io, (int)fo, 0, g.ld_in, g.ld_out, 0};
+  }
+  a.N = segs[0].N; a.H = segs[0].H; a.W = segs[0].W; a.ld_in = segs[0].ld_in; a.ld_full = segs[0].ld_out; a.ld_pool = 0;
+  return wino_run(a, 0, kblocks * kblocks, workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream));
 }
 
 // ---- the conv family on the Winograd kernel (called by g6d_conv_igemm when G6dConv.weight_wino is set)

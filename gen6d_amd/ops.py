@@ -260,6 +260,39 @@ def corr2d_patch_multi(xs, w, outs, k):
     return outs
 
 
+def corr2d_wino_multi(xs, U, outs, kblocks=5):
+    """The 15x15 correlation level on the Winograd kernel (g6d_corr2d_wino_multi): xs[i] [N,1,H_i,W_i,Cin] and outs[i]
+    [N,1,H_i,W_i,Cout] dense tensors cut from one buffer each, U [kblocks^2 * Cin/8, 16, Cout, 8] (backbone.winograd_corr_filters)."""
+    _need_gpu(U, *xs, *outs)
+    if not 1 <= len(xs) <= 4 or len(outs) != len(xs):
+        raise ValueError("corr2d_wino_multi: 1..4 map sizes")
+    Cin, Cout = xs[0].shape[4], U.shape[2]
+    if tuple(U.shape) != (kblocks * kblocks * (Cin // 8), 16, Cout, 8) or not U.is_contiguous():
+        raise ValueError(f"corr2d_wino_multi: U must be contiguous {(kblocks * kblocks * (Cin // 8), 16, Cout, 8)}")
+    segs = (_lib.G6dCorrSeg * len(xs))()
+    flops, sizes = 0.0, []
+    k = 3 * kblocks
+    for i, (x, o) in enumerate(zip(xs, outs)):
+        N, D, H, W, Cx, ld_in = _cl5(x, "corr2d_wino.x")
+        No, _, Ho, Wo, Co, ld_out = _cl5(o, "corr2d_wino.out")
+        if D != 1 or No != N or (Ho, Wo) != (H, W) or Cx != Cin or Co != Cout or not (x.is_contiguous() and o.is_contiguous()):
+            raise ValueError("corr2d_wino_multi: shape mismatch (maps must be dense)")
+        segs[i] = _lib.G6dCorrSeg(in_=x.data_ptr(), out=o.data_ptr(), H=H, W=W, ld_in=ld_in, ld_out=ld_out, N=N)
+        flops += 2.0 * N * H * W * Cout * k * k * Cin
+        sizes.append(f"{N}x{H}x{W}" if N > 1 else f"{H}x{W}")
+    ws = workspace(U.device)
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.check(_lib.load().g6d_corr2d_wino_multi(segs, len(xs), Cin, _ptr(U), Cout, int(kblocks), _ptr(ws), ws.numel() * 4, _stream()),
+               "g6d_corr2d_wino_multi")
+    if PROFILE is not None:
+        e1.record()
+        # FLOPs executed in the Winograd domain = direct form / 2.25 (booked in the Winograd family)
+        PROFILE.append((flops / 2.25, e0, e1, f"wino3x3 corr multi in={'+'.join(sizes)}x{Cin} out={Cout} k={k}x{k} ({kblocks}x{kblocks} blocks of 3x3)"))
+    return outs
+
+
 _ARENA = {}          # (device, stream) -> [buffer, bump offset]
 _CUR_ARENA = None    # arena of the query being enqueued (host-side state; set by stats_arena_begin)
 ARENA_DOUBLES = 1 << 17

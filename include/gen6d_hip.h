@@ -140,6 +140,14 @@ typedef struct G6dCorrSeg {
 int g6d_corr2d_patch_multi(const G6dCorrSeg* segs, int nseg, int Cin, const float* wgt, int Cout, int kh, int kw,
                            float* workspace, size_t workspace_bytes, int math_mode, g6d_stream_t stream);
 
+/* The 15x15 level of the same correlation (network/detector.py:222-224) on the Winograd kernel of g6d_wino_conv3x3: the filter is
+ * cut into kblocks x kblocks (= 5 x 5) blocks of 3x3 taps, out = sum_b conv3x3(in shifted by (3bi-6, 3bj-6), w_b), and the 25 blocks
+ * accumulate in the F(2x2,3x3) transform domain: 2.25x fewer multiplications than g6d_corr2d_patch.  Maps as above (all with the
+ * same ld_in); U = the sub-filter banks transformed on the host like g6d_wino_conv3x3's U, block-major [25*Cin/8][16][Cout][8]
+ * (block b = 5*bi + bj holds w[:, 3bi..3bi+2, 3bj..3bj+2, :]); Cin % 8 == 0, Cout % 32 == 0. */
+int g6d_corr2d_wino_multi(const G6dCorrSeg* segs, int nseg, int Cin, const float* U, int Cout, int kblocks, float* workspace,
+                          size_t workspace_bytes, g6d_stream_t stream);
+
 /* InstanceNorm finalisation: stats[g][c] = (sum, sumsq) over `count` elements ->
  * scale = 1/sqrt(var+eps), shift = -mean*scale (biased variance; torch InstanceNorm{1,2,3}d, eps 1e-5,
  * network/selector.py:28-77, network/refiner.py:27-50,93-133). n = groups*channels. */

@@ -66,6 +66,28 @@ def corr2d_patch_multi(xs, w, outs, k):
     return outs
 
 
+def corr2d_wino_multi(xs, U, outs, kblocks=5):
+    """The block-wise Winograd ALGORITHM on the transformed filters (not F.conv2d): out = sum over the kblocks^2 blocks of the
+    3x3 Winograd convolution (wino_conv3x3 above) of the input shifted by (3bi - 3(kb-1)/2, 3bj - ...) — checks the host-side
+    block cut / transform / ordering (backbone.winograd_corr_filters) together with the algebra the kernel implements."""
+    kb = kblocks
+    for x, o in zip(xs, outs):
+        N, _, H, W, Cin = x.shape
+        nc = Cin // 8
+        acc = torch.zeros((N, H, W, U.shape[2]), dtype=x.dtype)
+        pad = 3 * (kb - 1) // 2 + 1                                     # + the 3x3 halo of every shifted window
+        xp = F.pad(x[:, 0], (0, 0, pad, pad, pad, pad))
+        zero_b = torch.zeros(U.shape[2], dtype=x.dtype)
+        for bi in range(kb):
+            for bj in range(kb):
+                b = bi * kb + bj
+                sh = xp[:, 3 * bi:3 * bi + H + 2, 3 * bj:3 * bj + W + 2]  # input shifted by (3bi - 6, 3bj - 6) with its halo, zero outside the image
+                y, _ = wino_conv3x3(sh.contiguous(), U[b * nc:(b + 1) * nc], zero_b, relu=False)
+                acc += y[:, 1:H + 1, 1:W + 1]
+        o.copy_(acc[:, None])
+    return outs
+
+
 def stats_arena_begin(device):
     pass
 

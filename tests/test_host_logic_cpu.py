@@ -111,3 +111,19 @@ def test_batched_queries_equal_single_queries():
     np.testing.assert_allclose(angles[1].numpy(), a1[0].numpy(), atol=1e-4)
     np.testing.assert_allclose(det["scores"][2].numpy(), d1["scores"][0].numpy(), atol=1e-4 * float(d1["scores"].abs().max()))
     assert torch.equal(det["que_select_id"][2], d1["que_select_id"][0])
+
+
+def test_detector_winograd_correlation_host_path(golden):
+    """32 reference views: the 15x15 correlation level takes the Winograd route (block-cut, transformed reference filters built at
+    load time) — emulated on the CPU by the block-wise Winograd algorithm on those filters — and must reproduce the reference's
+    golden detection (det_mid: 160x192 query vs 32 references)."""
+    g = golden("det_mid")
+    net = name2network["detector"]({"name": "t"}).eval()
+    net.load_state_dict(synth.synth_state_dict("detector"))
+    case = synth.detector_case(int(g["rfn"]), int(g["hq"]), int(g["wq"]))
+    with torch.no_grad():
+        out = net({"ref_imgs_info": {"imgs": case["ref_imgs"]}, "que_imgs_info": {"imgs": case["que_imgs"]}})
+    assert net.ref_wino15 is not None and tuple(net.ref_wino15.shape) == (25 * 64, 16, 32, 8)
+    for k in ("scores", "select_pr_offset", "select_pr_scale"):
+        np.testing.assert_allclose(out[k].numpy(), g[k], rtol=1e-3, atol=1e-3 * np.abs(g[k]).max())
+    assert np.array_equal(out["que_select_id"].numpy(), g["que_select_id"])

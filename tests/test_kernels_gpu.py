@@ -338,9 +338,11 @@ def test_selector_levels_query_batch(ops, qn, D):
     assert vps.shape == (qn, 3, D) and sc.shape == (qn, 3, C) and maps[0].shape == (qn, D, 256)
     for q in range(qn):
         v1, sc1, sh1, m1 = ops.selector_levels([t[q].contiguous() for t in ques], refs, sums, Dg, want_maps=True)
-        assert torch.equal(v1, vps[q]) and torch.equal(sc1, sc[q]) and torch.equal(sh1, sh[q])
+        # (not bit-equal: the batch-width template instantiations order the per-row FMA chains differently)
+        _check(vps[q], v1.double().cpu(), 2e-6, "vps vs single"); _check(sc[q], sc1.double().cpu(), 1e-6, "scale vs single")
+        _check(sh[q], sh1.double().cpu(), 1e-6, "shift vs single")
         for l in range(3):
-            assert torch.equal(m1[l], maps[l][q])
+            _check(maps[l][q], m1[l].double().cpu(), 2e-6, "score map vs single")
             rsmap, rvps = ref_ops.selector_scan(_d(ques[l][q]), _d(refs[l]))
             _check(vps[q, l], rvps, 1e-5, f"vps q{q} l{l}")
 
@@ -619,6 +621,37 @@ def test_corr2d_patch_multi_query_batch(ops):
                 ref = torch.empty(tuple(o.shape), dtype=torch.float64)
                 ref_ops.corr2d_patch(_d(xc), _d(w), ref, k)
                 _check(o, ref, 2e-5, f"corr2d multi batch k={k}")
+
+
+@pytest.mark.parametrize("N,sizes,Cin,Cout", [(1, [(88, 116), (60, 80), (44, 60), (32, 40)], 512, 32), (3, [(22, 30), (9, 13)], 64, 32),
+                                              (2, [(16, 16)], 128, 64)])
+def test_corr2d_wino_multi(ops, N, sizes, Cin, Cout):
+    """15x15 correlation as 5x5 blocks of 3x3 sub-filters accumulated in the Winograd domain (wino_conv3x3_kernel<0,25,*>) against
+    the fp64 direct correlation and the direct-form corr_patch kernel; twice, so the split counters are left re-armed."""
+    from gen6d_amd.network.backbone import winograd_corr_filters
+    g = torch.Generator().manual_seed(900 + Cin)
+    k = 15
+    w = _rand(g, Cout, k * k, Cin, scale=(1.0 / (k * k * Cin)) ** 0.5)
+    U = winograd_corr_filters(w, k).cuda()
+    xs_cpu = [_rand(g, N, 1, h, ww, Cin) for h, ww in sizes]
+    dev = torch.device("cuda")
+    xs = ops.alloc_like_segments([tuple(x.shape) for x in xs_cpu], dev)
+    for d_, x in zip(xs, xs_cpu):
+        d_.copy_(x)
+    outs = ops.alloc_like_segments([(N, 1, h, ww, Cout) for h, ww in sizes], dev)
+    for rep in range(2):
+        for o in outs:
+            o.fill_(-3.0)
+        ops.corr2d_wino_multi(xs, U, outs, 5)
+        for o, xc in zip(outs, xs_cpu):
+            ref = torch.empty(tuple(o.shape), dtype=torch.float64)
+            ref_ops.corr2d_patch(_d(xc), _d(w), ref, k)
+            _check(o, ref, 4e-5, "corr2d wino multi")
+    if Cout <= 32:
+        direct = ops.alloc_like_segments([(N, 1, h, ww, Cout) for h, ww in sizes], dev)
+        ops.corr2d_patch_multi(xs, w.cuda(), direct, k)
+        for o, d_ in zip(outs, direct):
+            assert (o - d_).abs().max().item() <= 4e-5 * max(1.0, d_.abs().max().item())
 
 
 WINO_MULTI_CASES = [
