@@ -13,6 +13,7 @@
 // and checks the emulation against torch (test infrastructure only; the library itself has no host compute path).
 #ifndef G6D_CONV1_HOST_EMU
 #include "g6d_common.h"
+#include <stdlib.h>
 #define G6D_HD __host__ __device__ __forceinline__
 #else
 #include <cmath>
@@ -122,6 +123,84 @@ __global__ void __launch_bounds__(C1_THREADS) vgg_conv1_pool_kernel(const float*
   conv1_compute(s, threadIdx.x, out, n, Ho, Wo, px0, py0, nhwc != 0);
 }
 
+
+// ---- round 3: the same layer on the matrix cores (channels-last result; the own trunk's first layer) ------------------------
+// The vector-pipe kernel above runs at ~14 TFLOP/s (250 us per query over the detector's pyramid, 4 % of the batched step).  As a
+// GEMM the layer is M = conv pixels, N = 64, K = 27 (padded to 28): 14 x v_mfma_f32_32x32x2_f32 per 32 pixels and 32 channels.
+//   block  = 4 waves, pooled tile 32 x 8 (conv 64 x 16 + halo staged in LDS as three planes, normalised while staged);
+//   wave   = 2 pooled rows = 8 groups of 8 pool windows; a group = 32 conv pixels: A row 4q + p = pixel p (dy = p >> 1, dx = p & 1) of
+//            pool window q, so that the 4 accumulator registers r = 4j .. 4j+3 of a lane are the four pixels of window 2j + lh:
+//            bias / ReLU / 2x2 max-pool are per-lane register arithmetic and a half-wave stores 32 consecutive channels;
+//   A      = one ds_read_b32 per lane and K step (lane half lh supplies k = 2s + lh), shared by the two 32-channel N tiles;
+//   B      = the lane's 2 x 14 filter values, in registers for the whole block.
+#define M1_PTX 32
+#define M1_PTY 8
+#define M1_IW (2 * M1_PTX + 2)
+#define M1_IH (2 * M1_PTY + 2)
+#define M1_IWP 80                       // row pitch = 16 mod 32: the two conv rows of a pool window hit disjoint banks
+
+__global__ void __launch_bounds__(256) vgg_conv1_pool_mfma_kernel(const float* __restrict__ in, const float* __restrict__ w_oihw,
+                                                                  const float* __restrict__ bias, int H, int W, int Ho, int Wo,
+                                                                  float* __restrict__ out, const Conv1Norm nm) {
+  __shared__ float tile[C1_CIN][M1_IH][M1_IWP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int px0 = blockIdx.x * M1_PTX, py0 = blockIdx.y * M1_PTY, n = blockIdx.z;
+  const int gx0 = 2 * px0 - 1, gy0 = 2 * py0 - 1;
+  for (int i = tid; i < C1_CIN * M1_IH * M1_IW; i += 256) {
+    const int col = i % M1_IW, r = (i / M1_IW) % M1_IH, c = i / (M1_IW * M1_IH);
+    const int gy = gy0 + r, gx = gx0 + col;
+    const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
+    float v = ok ? in[((size_t)(n * C1_CIN + c) * H + gy) * W + gx] : 0.f;
+    if (nm.on && ok) v = (v - nm.mean[c]) / nm.std[c];
+    tile[c][r][col] = v;
+  }
+  // filter values of this lane: K step s supplies k = 2s + lh (k = 27: zero padding of K), N tile t supplies channel li + 32 t
+  float wb[2][14];
+  int koff[14];
+#pragma unroll
+  for (int s = 0; s < 14; ++s) {
+    const int k = 2 * s + lh;
+    const int kk = k < C1_TAPS ? k : 0;
+    const int c = kk / 9, ky = (kk % 9) / 3, kx = kk % 3;
+    koff[s] = (c * M1_IH + ky) * M1_IWP + kx;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) wb[t][s] = k < C1_TAPS ? w_oihw[(li + 32 * t) * C1_TAPS + k] : 0.f;
+  }
+  const float b0 = bias[li], b1 = bias[li + 32];
+  __syncthreads();
+  const float* tbase = &tile[0][0][0];
+  const int q = li >> 2, p = li & 3;
+  const int lane_off = (p >> 1) * M1_IWP + 2 * q + (p & 1);          // pixel p of pool window q inside a group
+#pragma unroll 1
+  for (int g = 0; g < 8; ++g) {
+    const int ty = 2 * wave + (g >> 2), gx = g & 3;                    // pooled row of the tile, group of 8 windows along x
+    const float* a = tbase + (2 * ty) * M1_IWP + 16 * gx + lane_off;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+    for (int s = 0; s < 14; ++s) {
+      const float av = a[koff[s]];
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wb[0][s], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wb[1][s], acc1, 0, 0, 0);
+    }
+    const int py = py0 + ty;
+    if (py < Ho) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int px = px0 + 8 * gx + 2 * j + lh;                      // accumulator rows 8j + 4lh .. +3 = window 2j + lh
+        if (px < Wo) {
+          const float m0 = fmaxf(fmaxf(acc0[4 * j], acc0[4 * j + 1]), fmaxf(acc0[4 * j + 2], acc0[4 * j + 3])) + b0;   // max(a)+b == max(a+b)
+          const float m1 = fmaxf(fmaxf(acc1[4 * j], acc1[4 * j + 1]), fmaxf(acc1[4 * j + 2], acc1[4 * j + 3])) + b1;
+          float* o = out + ((size_t)(n * Ho + py) * Wo + px) * C1_COUT;
+          o[li] = fmaxf(m0, 0.f); o[li + 32] = fmaxf(m1, 0.f);         // relu(max) == max(relu)
+        }
+      }
+    }
+  }
+}
+
 int conv1_launch(const float* in, int N, int H, int W, const float* w_oihw, const float* bias, int Cin, int Cout, float* out,
                  int nhwc, g6d_stream_t stream, const float* mean = nullptr, const float* stdv = nullptr) {
   if (!in || !w_oihw || !bias || !out || N <= 0 || N > 65535 || H < 2 || W < 2 || Cin != C1_CIN || Cout != C1_COUT ||
@@ -133,6 +212,13 @@ int conv1_launch(const float* in, int N, int H, int W, const float* w_oihw, cons
   if (mean && stdv) {
     for (int c = 0; c < C1_CIN; ++c) { nm.mean[c] = mean[c]; nm.std[c] = stdv[c]; }
     nm.on = 1;
+  }
+  // channels-last results take the matrix-core kernel (G6D_CONV1_MFMA=0: the vector-pipe kernel, A/B aid)
+  static const bool use_mfma = []() { const char* e = getenv("G6D_CONV1_MFMA"); return !(e && e[0] == '0'); }();
+  if (nhwc && use_mfma) {
+    hipLaunchKernelGGL(vgg_conv1_pool_mfma_kernel, dim3((Wo + M1_PTX - 1) / M1_PTX, (Ho + M1_PTY - 1) / M1_PTY, N), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), in, w_oihw, bias, H, W, Ho, Wo, out, nm);
+    return g6d_check_launch("vgg_conv1_pool_mfma");
   }
   hipLaunchKernelGGL(vgg_conv1_pool_kernel, dim3((Wo + C1_PTX - 1) / C1_PTX, (Ho + C1_PTY - 1) / C1_PTY, N), dim3(C1_THREADS),
                      0, reinterpret_cast<hipStream_t>(stream), in, w_oihw, bias, H, W, Ho, Wo, out, nhwc, nm);

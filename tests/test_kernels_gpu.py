@@ -713,7 +713,7 @@ def test_wino_rejects_bad_args(ops):
         ops.wino_conv3x3(x, torch.zeros((1, 16, 64, 8), device="cuda"), torch.zeros(64, device="cuda"))
 
 
-@pytest.mark.parametrize("N,H,W", [(1, 128, 128), (2, 50, 70), (1, 33, 67)])
+@pytest.mark.parametrize("N,H,W", [(1, 128, 128), (2, 50, 70), (1, 33, 67), (3, 2, 2), (1, 352, 464)])
 def test_vgg_conv1_pool_nhwc(ops, N, H, W):
     import torch.nn.functional as F
     g = torch.Generator().manual_seed(5)
@@ -722,6 +722,14 @@ def test_vgg_conv1_pool_nhwc(ops, N, H, W):
     ref = F.max_pool2d(F.relu(F.conv2d(x.double(), w.double(), b.double(), padding=1)), 2, 2)
     assert out.shape == (N, H // 2, W // 2, 64)
     _check(out.permute(0, 3, 1, 2), ref, 1e-5, "conv1 nhwc")
+    # the variant that normalises the image while staging it (the trunk's entry), into a caller-provided destination
+    mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    xi = torch.rand((N, 3, H, W), generator=g)
+    dst = torch.full((N, H // 2, W // 2, 64), -5.0, device="cuda")
+    ops.vgg_conv1_pool_nhwc(xi.cuda(), w.cuda(), b.cuda(), out=dst, norm=(mean, std))
+    xn = (xi.double() - torch.tensor(mean, dtype=torch.float64).view(1, 3, 1, 1)) / torch.tensor(std, dtype=torch.float64).view(1, 3, 1, 1)
+    refn = F.max_pool2d(F.relu(F.conv2d(xn, w.double(), b.double(), padding=1)), 2, 2)
+    _check(dst.permute(0, 3, 1, 2), refn, 1e-5, "conv1 nhwc norm")
 
 
 def test_l2norm_rows(ops):
