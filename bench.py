@@ -107,7 +107,7 @@ def main():
     ap.add_argument("--cpu-reps", type=int, default=3, help="timed CPU-oracle runs after one warm-up (min is reported)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="torch CPU threads for the baseline (0 = best of {8,16,32,64,physical cores})")
     ap.add_argument("--no-graph", action="store_true", help="time the eager launch path instead of hipGraph replay")
-    ap.add_argument("--batch", type=int, default=4,
+    ap.add_argument("--batch", type=int, default=8,
                     help="queries per step: they go through every launch together (M dimension of the conv / correlation grids, one "
                          "pass over the selector's reference cache, one FC weight stream), 1..8")
     ap.add_argument("--lanes", type=int, default=2,
@@ -220,18 +220,24 @@ def main():
     stages = stage_times(pipe, fulls[0:1], crops[0:1]) if (rank == 0 and not shard_refs) else None   # (sharded stages hold collectives)
     rows = parallel.gather_rows(torch.cat(rows, 0), world * args.steps * B) if (world > 1 and not shard_refs) else torch.cat(rows, 0)
     n_queries = args.steps * B if shard_refs else world * args.steps * B
-    # latency of ONE query alone: a batch-1 graph on one lane, replays back to back (what a single camera stream would see)
-    single_ms = None
+    # latency of ONE query alone: a batch-1 graph on one lane, replays back to back (what a single camera stream would see); measured
+    # without and with the query's independent branches (selector levels, refiner feature branches) forked onto side streams
+    single_ms, single_detail = None, None
     if rank == 0 and use_graph:
-        pipe.capture(lanes=1, batch=1)
-        for i in range(3):
-            pipe.query_graph(fulls[i % 4:i % 4 + 1], crops[i % 4:i % 4 + 1], 0)
-        torch.cuda.synchronize()
-        ts = time.perf_counter()
-        for i in range(10):
-            pipe.query_graph(fulls[i % 4:i % 4 + 1], crops[i % 4:i % 4 + 1], 0)
-        torch.cuda.synchronize()
-        single_ms = (time.perf_counter() - ts) / 10 * 1e3
+        single_detail = {}
+        for tag, serial in (("one_stream", True), ("branches_forked", False)):
+            ops.SERIAL = serial
+            pipe.capture(lanes=1, batch=1)
+            for i in range(3):
+                pipe.query_graph(fulls[i % 4:i % 4 + 1], crops[i % 4:i % 4 + 1], 0)
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            for i in range(10):
+                pipe.query_graph(fulls[i % 4:i % 4 + 1], crops[i % 4:i % 4 + 1], 0)
+            torch.cuda.synchronize()
+            single_detail[tag] = (time.perf_counter() - ts) / 10 * 1e3
+        ops.SERIAL = no_fork
+        single_ms = min(single_detail.values())
         pipe.capture(lanes=lanes, batch=B)            # back to the timed configuration (the lowp passes re-capture anyway)
         lane_busy[:] = [None] * lanes
 
@@ -289,7 +295,7 @@ def main():
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
         "scaling": "strong" if shard_refs else "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "batch": B, "images_per_step": B, "single_query_ms": single_ms,
+        "batch": B, "images_per_step": B, "single_query_ms": single_ms, "single_query_ms_detail": single_detail,
         "config": {"workload": f"full tensor pipeline: detector 480x640 query vs {args.det_refs} refs (4 scales) + selector "
                                f"128x128 crop vs {args.sel_refs} refs x 5 rotations + 3 refiner steps (6 refs, 32^3 volume); "
                                "seeded synthetic weights", "sharding": (f"selector and detector references sharded x{world} (RCCL all-reduce/all-gather), refiner replicated" if shard_refs
