@@ -55,10 +55,14 @@ class DeviceChain:
         self._lanes = None
 
     # ------------------------------------------------------------------ one query, no host synchronisation
-    def query(self, que_img, que_K):
+    def query(self, que_img, que_K, use_feat_cache=False):
         """que_img uint8 [H,W,3] and que_K float32 [3,3], both on the device -> dict of device tensors:
-        'pose' [3,4], 'det' [5] (x, y, 2^scale, cell), 'sel' [2] (reference index, in-plane angle), 'logits' [rfn]."""
+        'pose' [3,4], 'det' [5] (x, y, 2^scale, cell), 'sel' [2] (reference index, in-plane angle), 'logits' [rfn].
+        With the refiner's cfg `ref_feat_cache_deg` > 0 the reference alignment angles are snapped to that grid (also inside a
+        captured graph); use_feat_cache=True (eager only: one 48-byte read-back per refinement step to form the cache keys) then
+        skips the warp + trunk + feature net of every reference crop whose (view, bucket) pair has been seen before."""
         est, size = self.est, self.size
+        astep = est.refiner.angle_step() if est.refiner is not None else 0.0
         with torch.no_grad():
             x = que_img.permute(2, 0, 1)[None].float().div_(255)
             det = est.detector.detect_impl(x.contiguous())
@@ -71,13 +75,26 @@ class DeviceChain:
             poses = [pose]
             R, rs = self.REF_NUM, self.refine_size
             for _ in range(self.refine_iter):
-                geo, idx = ops.chain_refine_prepare(pose.reshape(12), que_K9, self.norm, rs, self.MARGIN, self.sub_poses, self.sub_Ks, R)
+                prep = ops.chain_refine_prepare(pose.reshape(12), que_K9, self.norm, rs, self.MARGIN, self.sub_poses, self.sub_Ks, R,
+                                                angle_step=astep)
+                geo, idx = prep[0], prep[1]
                 hinv = geo[33 + 21 * R:].view(1 + R, 9)
                 imgs = torch.empty((1 + R, 3, rs, rs), dtype=torch.float32, device=self.dev)
                 ops.warp_batch(None, que_img, None, hinv[0:1], rs, rs, out=imgs[0:1])
-                ops.warp_batch(self.stack, None, idx, hinv[1:], rs, rs, out=imgs[1:])
-                rot, off, scl = est.refiner._step(imgs[0:1], geo[0:9].view(3, 3), geo[9:21].view(3, 4), imgs[1:],
-                                                  geo[33:33 + 9 * R].view(R, 3, 3), geo[33 + 9 * R:33 + 21 * R].view(R, 3, 4))
+                geo_K, geo_P = geo[33:33 + 9 * R].view(R, 3, 3), geo[33 + 9 * R:33 + 21 * R].view(R, 3, 4)
+                if use_feat_cache and astep > 0:
+                    kb = torch.stack([idx, prep[2]], 0).cpu().numpy()            # the step's only host round trip: 2 x R ints
+                    keys = [(id(self), int(kb[0, k]), int(kb[1, k]), rs) for k in range(R)]
+
+                    def make(miss):
+                        m = torch.tensor(miss, dtype=torch.long, device=self.dev)
+                        return ops.warp_batch(self.stack, None, idx[m].contiguous(), hinv[1:][m].contiguous(), rs, rs)
+                    ref_feats = est.refiner.cached_ref_feats(keys, make)
+                    rot, off, scl = est.refiner._step(imgs[0:1], geo[0:9].view(3, 3), geo[9:21].view(3, 4), None, geo_K, geo_P,
+                                                      ref_feats=ref_feats)
+                else:
+                    ops.warp_batch(self.stack, None, idx, hinv[1:], rs, rs, out=imgs[1:])
+                    rot, off, scl = est.refiner._step(imgs[0:1], geo[0:9].view(3, 3), geo[9:21].view(3, 4), imgs[1:], geo_K, geo_P)
                 pose = ops.chain_refine_update(rot[0].contiguous(), off[0].contiguous(), scl[0].contiguous(), geo, self.norm)
                 poses.append(pose)
         return {"pose": pose, "det": det5, "sel": sel, "logits": logits[0], "refine_poses": poses, "crop": crop}

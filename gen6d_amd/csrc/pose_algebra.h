@@ -235,8 +235,11 @@ PA_HD RefinePrep refine_prepare(const P34& pose_in_db, const M3& que_K, double n
   return r;
 }
 // One reference view aligned with the warped query (utils/database_utils.py:54-110, rectify_rot with input pose/K)
+// angle_step > 0 (round 3, reference-feature caching): the in-plane angle is snapped to multiples of angle_step (radians), so that
+// the aligned crop of a view is a function of (view, bucket) only and its features can be cached across refinement steps and queries;
+// *bucket receives round(angle / angle_step) (0 when angle_step <= 0).  angle_step = 0 is the reference's exact alignment.
 PA_HD void align_reference(const P34& ref_pose, const M3& ref_K, const P34& pose_warp, const M3& K_warp, double size, double margin,
-                           M3& K_new, P34& pose_new, M3& H) {
+                           M3& K_new, P34& pose_new, M3& H, double angle_step = 0.0, int* bucket = nullptr) {
   const V3 center{0, 0, 0};
   double cx, cy, cd;
   project_point(center, ref_pose, ref_K, cx, cy, cd);
@@ -246,6 +249,9 @@ PA_HD void align_reference(const P34& ref_pose, const M3& ref_K, const P34& pose
   const double scale = size * (1 - margin) / 2.0 * dist / f_look;
   double s, angle;
   scale_rotation_difference(ref_pose, pose_warp, ref_K, K_warp, center, s, angle);
+  int b = 0;
+  if (angle_step > 0) { b = (int)floor(angle / angle_step + 0.5); angle = b * angle_step; }
+  if (bucket) *bucket = b;
   P34 rect;
   look_at_crop_params(ref_K, ref_pose, cx, cy, angle, scale, size, size, K_new, pose_new, rect, H);
 }

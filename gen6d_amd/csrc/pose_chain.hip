@@ -43,7 +43,8 @@ __global__ void pose_from_selection_kernel(const float* __restrict__ det, const 
 __global__ void __launch_bounds__(128) refine_prepare_kernel(const float* __restrict__ pose_in, const float* __restrict__ que_K,
                                                             const float* __restrict__ norm, float size, float margin,
                                                             const float* __restrict__ sub_poses, const float* __restrict__ sub_Ks,
-                                                            int n_sub, int ref_num, float* __restrict__ geo, int* __restrict__ ref_idx) {
+                                                            int n_sub, int ref_num, float* __restrict__ geo, int* __restrict__ ref_idx,
+                                                            float angle_step, int* __restrict__ ref_bucket) {
   __shared__ double corr[128];
   __shared__ RefinePrep g;
   __shared__ int sel[8];
@@ -74,7 +75,9 @@ __global__ void __launch_bounds__(128) refine_prepare_kernel(const float* __rest
   if (t < ref_num) {
     const int i = sel[t];
     M3 K_new, H; P34 pose_new;
-    align_reference(ld_p34(sub_poses + 12 * i), ld_m3(sub_Ks + 9 * i), g.pose_warp, g.K_warp, size, margin, K_new, pose_new, H);
+    int bucket = 0;
+    align_reference(ld_p34(sub_poses + 12 * i), ld_m3(sub_Ks + 9 * i), g.pose_warp, g.K_warp, size, margin, K_new, pose_new, H, angle_step, &bucket);
+    if (ref_bucket) ref_bucket[t] = bucket;
     st_m3(geo + 33 + 9 * t, K_new);
     st_p34(geo + 33 + 9 * ref_num + 12 * t, pose_new);
     st_m3(geo + 33 + 21 * ref_num + 9 * (1 + t), inv3(H));
@@ -147,13 +150,13 @@ extern "C" int g6d_chain_pose_from_selection(const float* det, const float* logi
 
 extern "C" int g6d_chain_refine_prepare(const float* pose_in, const float* que_K, const float* norm, float size, float margin,
                                         const float* sub_poses, const float* sub_Ks, int n_sub, int ref_num, float* geo,
-                                        int* ref_idx, g6d_stream_t stream) {
+                                        int* ref_idx, float angle_step, int* ref_bucket, g6d_stream_t stream) {
   if (!pose_in || !que_K || !norm || size <= 0 || !sub_poses || !sub_Ks || n_sub <= 0 || n_sub > 128 || ref_num <= 0 ||
       ref_num > 8 || ref_num > n_sub || !geo || !ref_idx) {
     g6d_set_error("chain_refine_prepare: bad args (n_sub <= 128, ref_num <= 8)"); return G6D_EINVAL;
   }
   hipLaunchKernelGGL(refine_prepare_kernel, dim3(1), dim3(128), 0, CHAIN_STREAM(stream), pose_in, que_K, norm, size, margin, sub_poses,
-                     sub_Ks, n_sub, ref_num, geo, ref_idx);
+                     sub_Ks, n_sub, ref_num, geo, ref_idx, angle_step, ref_bucket);
   return g6d_check_launch("chain_refine_prepare");
 }
 

@@ -198,12 +198,11 @@ def select_reference_img_ids_refinement(db, center, ref_ids, sel_pose, ref_num=6
     return ids[np.argsort(-corr[0])[:ref_num]]
 
 
-def normalize_reference_views(db, ref_ids, size, margin, cache, rectify_rot=True, input_pose=None, input_K=None,
-                              with_masks=True):
-    """Crop every reference view so that the object is centred, fills `size*(1-margin)` pixels and is upright (or aligned
-    with `input_pose`).  Returns, in the reference's order (utils/database_utils.py:54-110): device images uint8
-    [rfn,size,size,3], masks float32 [rfn,size,size] in [0,1] (None when with_masks=False — the per-query refiner path
-    does not use them), Ks, poses, Hs."""
+def reference_view_params(db, ref_ids, size, margin, rectify_rot=True, input_pose=None, input_K=None, angle_step=0.0):
+    """The geometry of normalize_reference_views (utils/database_utils.py:54-110) without the image warps: per reference view the
+    new intrinsics, pose and source->crop homography.  angle_step > 0 (radians; reference-feature caching): the
+    in-plane alignment angle is snapped to multiples of angle_step, so that the crop of a view depends on (view, bucket) only; the
+    fourth result is then the bucket per view (None otherwise)."""
     center, diameter = get_object_center(db), get_diameter(db)
     poses = np.asarray([db.get_pose(i) for i in ref_ids])
     Ks = np.asarray([db.get_K(i) for i in ref_ids])
@@ -223,15 +222,30 @@ def normalize_reference_views(db, ref_ids, size, margin, cache, rectify_rot=True
         small = np.linalg.norm(v2, 2, 1) < 1e-5
         v2[small] += 1e-5 * np.sign(v2[small])
         angles = -np.arctan2(v2[:, 1], v2[:, 0]) - np.pi / 2
-    imgs, masks, Ks_new, poses_new, Hs = [], [], [], [], []
-    for k, i in enumerate(ref_ids):
+    buckets = None
+    if angle_step > 0:
+        buckets = np.floor(np.asarray(angles, np.float64) / angle_step + 0.5).astype(np.int64)
+        angles = buckets * angle_step
+    Ks_new, poses_new, Hs = [], [], []
+    for k in range(len(ref_ids)):
         K_new, pose_new, _, H = G.look_at_crop_params(Ks[k], poses[k], cens[k], angles[k], scales[k], size, size)
-        imgs.append(ops.warp_perspective(cache.get(db, i), H, size, size))
-        if with_masks:
-            masks.append(ops.warp_perspective(cache.get_mask(db, i), H, size, size, out_float=True)[..., 0])
         Ks_new.append(K_new); poses_new.append(pose_new); Hs.append(H)
-    return (torch.stack(imgs, 0), torch.stack(masks, 0) if with_masks else None, np.stack(Ks_new, 0).astype(np.float32),
-            np.stack(poses_new, 0).astype(np.float32), np.stack(Hs, 0))
+    return np.stack(Ks_new, 0).astype(np.float32), np.stack(poses_new, 0).astype(np.float32), np.stack(Hs, 0), buckets
+
+
+def normalize_reference_views(db, ref_ids, size, margin, cache, rectify_rot=True, input_pose=None, input_K=None,
+                              with_masks=True):
+    """Crop every reference view so that the object is centred, fills `size*(1-margin)` pixels and is upright (or aligned
+    with `input_pose`).  Returns, in the reference's order (utils/database_utils.py:54-110): device images uint8
+    [rfn,size,size,3], masks float32 [rfn,size,size] in [0,1] (None when with_masks=False — the per-query refiner path
+    does not use them), Ks, poses, Hs."""
+    Ks_new, poses_new, Hs, _ = reference_view_params(db, ref_ids, size, margin, rectify_rot, input_pose, input_K)
+    imgs, masks = [], []
+    for k, i in enumerate(ref_ids):
+        imgs.append(ops.warp_perspective(cache.get(db, i), Hs[k], size, size))
+        if with_masks:
+            masks.append(ops.warp_perspective(cache.get_mask(db, i), Hs[k], size, size, out_float=True)[..., 0])
+    return torch.stack(imgs, 0), torch.stack(masks, 0) if with_masks else None, Ks_new, poses_new, Hs
 
 
 class Gen6DEstimator:
@@ -339,13 +353,14 @@ class Gen6DEstimator:
             self._chain, self._chain_info = DeviceChain(self), self.ref_info
         return self._chain
 
-    def predict_device(self, que_img, que_K):
+    def predict_device(self, que_img, que_K, use_feat_cache=False):
         """`predict` without host round trips between the stages: que_img uint8 [H,W,3] (numpy or device tensor), que_K [3,3]
-        -> (pose [3,4] float32 numpy, inter) with one synchronisation at the end."""
+        -> (pose [3,4] float32 numpy, inter) with one synchronisation at the end.  use_feat_cache: reference-crop features are reused
+        across refinement steps and queries (needs the refiner's cfg ref_feat_cache_deg > 0; one tiny read-back per step)."""
         chain = self.device_chain()
         img = que_img if torch.is_tensor(que_img) else torch.from_numpy(np.ascontiguousarray(que_img))
         K = torch.from_numpy(np.ascontiguousarray(que_K, dtype=np.float32)).to(self.device)
-        out = chain.query(img.to(self.device), K)
+        out = chain.query(img.to(self.device), K, use_feat_cache=use_feat_cache)
         det, sel = out["det"].cpu().numpy(), out["sel"].cpu().numpy()
         inter = {"det_position": det[:2], "det_scale_r2q": float(det[2]), "det_que_img": None, "sel_angle_r2q": float(sel[1]),
                  "sel_scores": out["logits"].cpu().numpy(), "sel_ref_idx": int(sel[0]),

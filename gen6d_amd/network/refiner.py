@@ -33,14 +33,72 @@ def _linspace(sn, dev):
     return _LIN[key]
 
 
+class RefFeatureCache:
+    """Features of aligned reference crops ([fh,fw,C] device tensors) keyed by (database, view id, in-plane angle bucket, crop
+    size): with `ref_feat_cache_deg` > 0 the alignment angle of a reference view is snapped to that grid, so a (view, bucket) pair
+    always yields the same crop and its trunk + feature-net pass (6 of the 7 images of a refinement step) can be skipped when the
+    pair repeats — between the refinement steps of a query and between queries (the reference re-warps and
+    re-extracts all six views every step, refiner.py:289-313).  LRU-bounded (0.5 MB per entry)."""
+
+    def __init__(self, max_entries=2048):
+        from collections import OrderedDict
+        self.store, self.max_entries = OrderedDict(), max_entries
+        self.hits = self.misses = 0
+
+    def get(self, key):
+        f = self.store.get(key)
+        if f is None:
+            self.misses += 1
+            return None
+        self.store.move_to_end(key)
+        self.hits += 1
+        return f
+
+    def put(self, key, feat):
+        self.store[key] = feat
+        while len(self.store) > self.max_entries:
+            self.store.popitem(last=False)
+
+    def clear(self):
+        self.store.clear()
+        self.hits = self.misses = 0
+
+    @property
+    def hit_rate(self):
+        return self.hits / max(1, self.hits + self.misses)
+
+
 class VolumeRefiner(ParamBank):
-    default_cfg = {"refiner_sample_num": 32}
+    # ref_feat_cache_deg: 0 = the reference's exact alignment, nothing cached (default); > 0 = alignment angles snapped to this
+    # grid (degrees) and reference-crop features cached per (view, bucket) — opt-in: the snapped angle changes the crops
+    default_cfg = {"refiner_sample_num": 32, "ref_feat_cache_deg": 0.0}
 
     def __init__(self, cfg):
         self.cfg = {**self.default_cfg, **cfg}
         super().__init__(specs.refiner_rows())
         self.ref_database = None
         self.ref_ids = None
+        self.feat_cache = RefFeatureCache()
+
+    def load_state_dict(self, *a, **k):
+        self.feat_cache.clear()                      # cached features belong to the weights they were computed with
+        return super().load_state_dict(*a, **k)
+
+    def angle_step(self):
+        """Snap grid of the reference alignment in radians (0 = exact, no caching)."""
+        return float(np.radians(self.cfg.get("ref_feat_cache_deg") or 0.0))
+
+    def cached_ref_feats(self, keys, make_imgs):
+        """Features [len(keys),fh,fw,C] of the reference crops with cache keys `keys`; make_imgs(missing_positions) must return the
+        crops [m,3,h,w] in [0,1] of the positions that are not cached (they go through the feature net in one batch)."""
+        got = [self.feat_cache.get(k) for k in keys]
+        miss = [i for i, f in enumerate(got) if f is None]
+        if miss:
+            feats = self.run_feature_net(make_imgs(miss))
+            for j, i in enumerate(miss):
+                got[i] = feats[j].clone()
+                self.feat_cache.put(keys[i], got[i])
+        return torch.stack(got, 0)
 
     # ------------------------------------------------------------------ weights
     def _pack(self):
@@ -167,14 +225,17 @@ class VolumeRefiner(ParamBank):
         with ops.math_mode(self.cfg.get("math_mode"), inherit_if_none=True):
             return self._step_fp(*a, **k)
 
-    def _step_fp(self, que_img, K_in, pose_in, ref_imgs, ref_Ks, ref_poses):
-        """One refinement step.  Single query: que_img [1,3,h,w], K_in [3,3], pose_in [3,4], ref_imgs [rfn,3,h,w], ref_Ks [rfn,3,3],
+    def _step_fp(self, que_img, K_in, pose_in, ref_imgs, ref_Ks, ref_poses, ref_feats=None):
+        """One refinement step.  ref_feats [rfn,fh,fw,C] (single query only): features of the reference crops computed earlier
+        (cached_ref_feats) — ref_imgs is then ignored and only the query crop goes through the trunk + feature net.  Single query: que_img [1,3,h,w], K_in [3,3], pose_in [3,4], ref_imgs [rfn,3,h,w], ref_Ks [rfn,3,3],
         ref_poses [rfn,3,4].  Batch of qn <= MAX_BATCH queries (reference forward: refiner.py:249-269 takes [qn,...]): que_img
         [qn,3,h,w], K_in [qn,3,3], pose_in [qn,3,4], ref_imgs [qn,rfn,3,h,w], ref_Ks [qn,rfn,3,3], ref_poses [qn,rfn,3,4] — the
         (rfn+1)*qn crops share the trunk / feature-net launches, the qn volumes the volume-net launches and the FC weight stream."""
         sn = self.cfg["refiner_sample_num"]
         dev = que_img.device
         ops.stats_arena_begin(dev)
+        if ref_feats is not None:
+            return self._step_from_feats(que_img, K_in, pose_in, ref_feats, ref_Ks, ref_poses)
         batched = ref_imgs.dim() == 5
         qn = ref_imgs.shape[0] if batched else 1
         rfn = ref_imgs.shape[-4]
@@ -193,6 +254,19 @@ class VolumeRefiner(ParamBank):
         if batched:
             feats = feats.view(qn, rfn + 1, *feats.shape[1:])
         # projections K @ pose and the volume's rotation are formed inside the kernel (reference refiner.py:208-226)
+        ops.refiner_volume_kp(feats, ref_Ks.contiguous(), ref_poses.contiguous(), K_in.contiguous(), pose_in.contiguous(),
+                              lin, h_in, w_in, mean_in, std)
+        return self.run_regressor(self.run_volume_net(mean_in, std, sn))
+
+    def _step_from_feats(self, que_img, K_in, pose_in, ref_feats, ref_Ks, ref_poses):
+        sn = self.cfg["refiner_sample_num"]
+        dev = que_img.device
+        h_in, w_in = que_img.shape[-2:]
+        feats = torch.cat([ref_feats, self.run_feature_net(que_img)], 0).contiguous()     # query last
+        lin = _linspace(sn, dev)
+        C = feats.shape[-1]
+        mean_in = torch.empty((sn ** 3, 2 * C), dtype=torch.float32, device=dev)
+        std = torch.empty((sn ** 3, C), dtype=torch.float32, device=dev)
         ops.refiner_volume_kp(feats, ref_Ks.contiguous(), ref_poses.contiguous(), K_in.contiguous(), pose_in.contiguous(),
                               lin, h_in, w_in, mean_in, std)
         return self.run_regressor(self.run_volume_net(mean_in, std, sn))
@@ -224,6 +298,8 @@ class VolumeRefiner(ParamBank):
         cache = getattr(self, "image_cache", None)
         if ref_database is not self.ref_database and cache is not None and not cache.holds(ref_database):
             cache.clear()
+        if ref_database is not self.ref_database:
+            self.feat_cache.clear()
         self.ref_database = ref_database
         self.ref_ids = ref_ids
 
@@ -252,12 +328,23 @@ class VolumeRefiner(ParamBank):
             que_img = torch.from_numpy(np.ascontiguousarray(que_img)).to(dev)
         que_warp = ops.warp_perspective(que_img, H, size, size)
         ref_ids = E.select_reference_img_ids_refinement(db, center, self.ref_ids, pose_warp, ref_num, ref_even, even_num, cache)
-        ref_imgs, _, ref_Ks, ref_poses, _ = E.normalize_reference_views(db, ref_ids, size, margin, cache, True, pose_warp, K_warp,
-                                                                     with_masks=False)
         f = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+        que_t = que_warp.float().div_(255).permute(2, 0, 1)[None].contiguous()
+        step = self.angle_step()
         with torch.no_grad():
-            rot, off, scl = self._step(que_warp.float().div_(255).permute(2, 0, 1)[None].contiguous(), f(K_warp), f(pose_warp),
-                                       ref_imgs.float().div_(255).permute(0, 3, 1, 2).contiguous(), f(ref_Ks), f(ref_poses))
+            if step > 0:
+                # alignment angles snapped to the grid: the crop of a view depends on (view, bucket) only -> cached features
+                ref_Ks, ref_poses, Hs, buckets = E.reference_view_params(db, ref_ids, size, margin, True, pose_warp, K_warp, angle_step=step)
+                keys = [(id(self.ref_database), str(i), int(b), int(size)) for i, b in zip(ref_ids, buckets)]
+                make = lambda miss: torch.stack([ops.warp_perspective(cache.get(db, ref_ids[k]), Hs[k], size, size) for k in miss], 0) \
+                    .float().div_(255).permute(0, 3, 1, 2).contiguous()
+                ref_feats = self.cached_ref_feats(keys, make)
+                rot, off, scl = self._step(que_t, f(K_warp), f(pose_warp), None, f(ref_Ks), f(ref_poses), ref_feats=ref_feats)
+            else:
+                ref_imgs, _, ref_Ks, ref_poses, _ = E.normalize_reference_views(db, ref_ids, size, margin, cache, True, pose_warp, K_warp,
+                                                                             with_masks=False)
+                rot, off, scl = self._step(que_t, f(K_warp), f(pose_warp), ref_imgs.float().div_(255).permute(0, 3, 1, 2).contiguous(),
+                                           f(ref_Ks), f(ref_poses))
             out = torch.cat([rot[0], off[0], scl[0]]).cpu().numpy()
         quat, offset, scale_pr = out[:4], out[4:6], 2 ** out[6]
         pose_sim = G.compose_sim_pose(scale_pr, quat, offset, pose_warp, center)

@@ -779,15 +779,18 @@ def chain_pose_from_selection(det, logits, angles, ref_poses, ref_Ks, que_K, cen
     return pose, sel
 
 
-def chain_refine_prepare(pose_in, que_K, norm, size, margin, sub_poses, sub_Ks, ref_num):
-    """-> geo [42 + 30*ref_num] float32 (see include/gen6d_hip.h), ref_idx [ref_num] int32."""
+def chain_refine_prepare(pose_in, que_K, norm, size, margin, sub_poses, sub_Ks, ref_num, angle_step=0.0):
+    """-> geo [42 + 30*ref_num] float32 (see include/gen6d_hip.h), ref_idx [ref_num] int32; with angle_step > 0 (radians) the
+    alignment angles are snapped to its multiples and the third result is their buckets [ref_num] int32 (cache keys)."""
     _need_gpu(pose_in, que_K, norm, sub_poses, sub_Ks); _f32c(pose_in, que_K, norm, sub_poses, sub_Ks)
     geo = torch.empty((42 + 30 * ref_num,), dtype=torch.float32, device=pose_in.device)
     idx = torch.empty((ref_num,), dtype=torch.int32, device=pose_in.device)
+    bucket = torch.empty((ref_num,), dtype=torch.int32, device=pose_in.device) if angle_step > 0 else None
     _lib.check(_lib.load().g6d_chain_refine_prepare(_ptr(pose_in), _ptr(que_K), _ptr(norm), float(size), float(margin), _ptr(sub_poses),
-                                                   _ptr(sub_Ks), sub_poses.shape[0], int(ref_num), _ptr(geo), _ptr(idx), _stream()),
+                                                   _ptr(sub_Ks), sub_poses.shape[0], int(ref_num), _ptr(geo), _ptr(idx),
+                                                   float(angle_step), _ptr(bucket), _stream()),
                "g6d_chain_refine_prepare")
-    return geo, idx
+    return (geo, idx, bucket) if angle_step > 0 else (geo, idx)
 
 
 def chain_refine_update(rot, off, scl, geo, norm):

@@ -344,10 +344,13 @@ int g6d_chain_pose_from_selection(const float* det, const float* logits, const f
  * sub_poses [n_sub][12] / sub_Ks [n_sub][9] = normalised poses and intrinsics of the (FPS) reference subset, n_sub <= 128.
  * Writes ref_idx[ref_num] (the views most aligned with the warped input pose) and the record
  *   geo = K_warp[9] | pose_warp[12] | pose_rect[12] | ref_Ks[ref_num][9] | ref_poses[ref_num][12] | hinv[1+ref_num][9]
- * (42 + 30*ref_num floats; hinv[0] warps the query, hinv[1+k] reference k: inputs of g6d_warp_batch). */
+ * (42 + 30*ref_num floats; hinv[0] warps the query, hinv[1+k] reference k: inputs of g6d_warp_batch).
+ * angle_step > 0 (radians; reference-feature caching): the in-plane alignment angle of every reference view is
+ * snapped to multiples of angle_step, so that its aligned crop depends on (view, bucket) only; ref_bucket[ref_num] (optional)
+ * receives round(angle / angle_step).  angle_step = 0: the reference's exact alignment. */
 int g6d_chain_refine_prepare(const float* pose_in, const float* que_K, const float* norm, float size, float margin,
                              const float* sub_poses, const float* sub_Ks, int n_sub, int ref_num, float* geo, int* ref_idx,
-                             g6d_stream_t stream);
+                             float angle_step, int* ref_bucket, g6d_stream_t stream);
 /* Refiner outputs (rotation[4] w-first, offset[2], log2 scale[1]) + the step's geo record -> refined pose in the database frame
  * (refiner.py:327-341: compose_sim_pose, pose_sim_to_pose_rigid with the polar factor of the SVD, un-rectify, denormalise). */
 int g6d_chain_refine_update(const float* rot, const float* off, const float* scl, const float* geo, const float* norm,

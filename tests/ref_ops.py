@@ -392,7 +392,7 @@ def chain_pose_from_selection(det, logits, angles, ref_poses, ref_Ks, que_K, cen
     return torch.from_numpy(pose.astype(np.float32)), torch.tensor([float(i), float(an[i])])
 
 
-def chain_refine_prepare(pose_in, que_K, norm, size, margin, sub_poses, sub_Ks, ref_num):
+def chain_refine_prepare(pose_in, que_K, norm, size, margin, sub_poses, sub_Ks, ref_num, angle_step=0.0):
     import numpy as np
     from gen6d_amd import geometry as G
     nm = _np(norm); c0 = np.zeros(3)
@@ -403,16 +403,21 @@ def chain_refine_prepare(pose_in, que_K, norm, size, margin, sub_poses, sub_Ks, 
     K_warp, pose_warp, pose_rect, H = G.look_at_crop_params(K, in_pose, G.project_points(c0[None], in_pose, K)[0][0], 0, scale, size, size)
     sp, sk = _np(sub_poses).reshape(-1, 3, 4), _np(sub_Ks).reshape(-1, 3, 3)
     idx = np.argsort(-G.view_correlation(pose_warp[None].astype(np.float64), sp, c0)[0], kind="stable")[:ref_num]
-    Ks, poses, hinvs = [], [], [np.linalg.inv(H)]
+    Ks, poses, hinvs, buckets = [], [], [np.linalg.inv(H)], []
     for i in idx:
         cen = G.project_points(c0[None], sp[i], sk[i])[0][0]
         f_look = G.let_me_look_at(sp[i], sk[i], c0)[1]
         _, ang = G.scale_rotation_difference_from_cameras(sp[i][None], pose_warp[None].astype(np.float64), sk[i][None],
                                                           K_warp[None].astype(np.float64), c0)
-        Kn, pn, _, Hr = G.look_at_crop_params(sk[i], sp[i], cen, ang[0], size * (1 - margin) / 2.0 * np.linalg.norm(G.pose_inverse(sp[i])[:, 3]) / f_look,
+        a = float(ang[0])
+        if angle_step > 0:
+            buckets.append(int(np.floor(a / angle_step + 0.5))); a = buckets[-1] * angle_step
+        Kn, pn, _, Hr = G.look_at_crop_params(sk[i], sp[i], cen, a, size * (1 - margin) / 2.0 * np.linalg.norm(G.pose_inverse(sp[i])[:, 3]) / f_look,
                                               size, size)
         Ks.append(Kn); poses.append(pn); hinvs.append(np.linalg.inv(Hr))
     geo = np.concatenate([np.ravel(K_warp), np.ravel(pose_warp), np.ravel(pose_rect), np.ravel(Ks), np.ravel(poses), np.ravel(hinvs)])
+    if angle_step > 0:
+        return torch.from_numpy(geo.astype(np.float32)), torch.from_numpy(idx.astype(np.int32)), torch.tensor(buckets, dtype=torch.int32)
     return torch.from_numpy(geo.astype(np.float32)), torch.from_numpy(idx.astype(np.int32))
 
 

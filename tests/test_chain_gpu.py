@@ -48,6 +48,14 @@ def test_chain_kernels_match_host_algebra():
     np.testing.assert_allclose(g_dev.cpu().numpy(), g_ref.numpy(), rtol=2e-4, atol=2e-4)
     rot = torch.nn.functional.normalize(torch.from_numpy(rng.randn(4).astype(np.float32)), dim=0)
     off, scl = torch.tensor([0.03, -0.02]), torch.tensor([0.21])
+    # snapped alignment angles (reference-feature caching): same views, buckets equal to the host's, geometry of the snapped angle
+    step = float(np.radians(3.0))
+    gs_ref, is_ref, b_ref = ref_ops.chain_refine_prepare(pose_in, qK, norm, 128, 0.05, torch.from_numpy(sub).reshape(-1, 12), rk, 6, angle_step=step)
+    gs_dev, is_dev, b_dev = ops.chain_refine_prepare(pose_in.cuda(), qK.cuda(), norm.cuda(), 128, 0.05, _dev(sub.reshape(-1, 12)), rk.cuda(), 6,
+                                                    angle_step=step)
+    assert np.array_equal(is_dev.cpu().numpy(), is_ref.numpy()) and np.array_equal(b_dev.cpu().numpy(), b_ref.numpy())
+    np.testing.assert_allclose(gs_dev.cpu().numpy(), gs_ref.numpy(), rtol=2e-4, atol=2e-4)
+    assert not np.allclose(gs_dev.cpu().numpy(), g_dev.cpu().numpy(), atol=1e-6)        # snapping did change the alignment
     u_ref = ref_ops.chain_refine_update(rot, off, scl, g_ref, norm)
     u_dev = ops.chain_refine_update(rot.cuda(), off.cuda(), scl.cuda(), g_ref.cuda(), norm.cuda())
     np.testing.assert_allclose(u_dev.cpu().numpy(), u_ref.numpy(), atol=2e-5)
@@ -75,7 +83,7 @@ def test_warp_batch_matches_single_warps():
 @pytest.fixture(scope="module")
 def built():
     db = SyntheticDatabase(n_views=24, size=(96, 128), focal=140.0)
-    est = make_estimator("cuda", refine_iter=1)
+    est = make_estimator("cuda", refine_iter=1, damped=True)      # pose heads around the identity, like a trained refiner (weak #2)
     est.build(db, "all")
     return db, est
 
@@ -89,7 +97,9 @@ def test_predict_device_matches_host_driven_predict(built):
     assert inter_d["sel_ref_idx"] == inter_h["sel_ref_idx"]
     np.testing.assert_allclose(inter_d["det_position"], inter_h["det_position"], atol=1e-3)
     np.testing.assert_allclose(inter_d["refine_poses"][0], inter_h["refine_poses"][0], atol=2e-5)
-    np.testing.assert_allclose(pose_d, pose_h, atol=2e-2)           # one step of the randomly initialised refiner (see CPU test)
+    from parity_log import record
+    record("test_predict_device_matches_host_driven_predict", "refined pose: device chain vs host-driven predict (1 step)", float(np.abs(pose_d - pose_h).max()), 3e-4)
+    np.testing.assert_allclose(pose_d, pose_h, atol=3e-4)           # crops differ by single grey levels (float32 vs float64 homographies)
 
 
 def test_predict_many_three_lanes(built):
@@ -104,9 +114,8 @@ def test_predict_many_three_lanes(built):
     for (pe, ie), (pm, im_) in zip(eager, many):
         assert im_["sel_ref_idx"] == ie["sel_ref_idx"]
         np.testing.assert_allclose(im_["det_position"], ie["det_position"], atol=1e-3)
-        # replay vs eager: statistics atomics reorder (1e-5), a detection that moves by 1e-4 px flips the rounding of a few crop
-        # pixels, and the randomly initialised refiner amplifies single grey levels to ~1e-2 (same effect as in the CPU test)
-        np.testing.assert_allclose(pm, pe, atol=3e-2)
+        # replay vs eager: statistics atomics reorder (1e-5); a detection that moves by 1e-4 px can flip the rounding of a few crop pixels
+        np.testing.assert_allclose(pm, pe, atol=3e-4)
 
 
 def test_streaming_eval_driver(built):
@@ -121,7 +130,44 @@ def test_streaming_eval_driver(built):
     many = est.predict_many([db.get_image(i) for i in que_ids], [db.get_K(i) for i in que_ids], lanes=3)
     for i, (pm, im_) in enumerate(many):
         assert inters[i]["sel_ref_idx"] == im_["sel_ref_idx"]
-        np.testing.assert_allclose(poses[i], pm, atol=3e-2)
+        np.testing.assert_allclose(poses[i], pm, atol=3e-4)
     res = EV.compute_metrics(EV.get_ref_point_cloud(db), db.object_diameter, [db.get_pose(i) for i in que_ids], poses,
                              [db.get_K(i) for i in que_ids])
     assert set(res) == {"add-0.1d", "prj-5"} and all(0.0 <= v <= 1.0 for v in res.values())
+
+
+def test_reference_feature_cache_gpu():
+    """SURVEY.md 8f row 2 on the GPU: (a) the features of a reference crop do not depend on the batch it is extracted in (per-image
+    InstanceNorm) — cached == recomputed to 1e-6; (b) with snapped alignment angles the cached eager chain reproduces the uncached one
+    and the captured-graph lanes, later queries hit the cache."""
+    from parity_log import record
+    db = SyntheticDatabase(n_views=24, size=(96, 128), focal=140.0)
+    est = make_estimator("cuda", refine_iter=2, damped=True)
+    est.refiner.cfg["ref_feat_cache_deg"] = 3.0
+    est.build(db, "all")
+    _, que_ids = db.get_split("all")
+    imgs = synth.imgs_to_tensor(synth.synth_images(7, 128, 128, seed=77)).cuda()
+    with torch.no_grad():
+        f_all = est.refiner.run_feature_net(imgs)
+        f_refs = est.refiner.run_feature_net(imgs[:6].contiguous())
+        f_one = est.refiner.run_feature_net(imgs[2:3].contiguous())
+    e1 = (f_all[:6] - f_refs).abs().max().item() / f_all.abs().max().item()
+    e2 = (f_all[2:3] - f_one).abs().max().item() / f_all.abs().max().item()
+    record("test_reference_feature_cache_gpu", "reference features: batch of 7 vs batch of 6 / 1 (relative to max)", max(e1, e2), 1e-6)
+    assert max(e1, e2) <= 1e-6, (e1, e2)
+    fc = est.refiner.feat_cache
+    img, K = db.get_image(que_ids[1]), db.get_K(que_ids[1])
+    pose_u, _ = est.predict_device(img, K)                                     # snapped angles, nothing cached
+    assert len(fc.store) == 0
+    pose_c, _ = est.predict_device(img, K, use_feat_cache=True)
+    miss0 = fc.misses
+    pose_c2, _ = est.predict_device(img, K, use_feat_cache=True)
+    assert fc.misses == miss0 and fc.hits >= 12
+    e = float(np.abs(pose_c - pose_u).max())
+    record("test_reference_feature_cache_gpu", "pose: cached eager chain vs uncached (2 steps, damped head)", e, 1e-4)
+    assert e <= 1e-4 and np.abs(pose_c2 - pose_c).max() <= 1e-6
+    many = est.predict_many([img, img], [K, K], lanes=2)                       # captured graphs use the same snapped geometry
+    assert np.abs(many[0][0] - pose_u).max() <= 1e-4
+    pose_h, _ = est.predict(img, K)                                            # host-driven path with its own (view id, bucket) keys
+    record("test_reference_feature_cache_gpu", "pose: host-driven cached predict vs device chain", float(np.abs(pose_h - pose_u).max()), 3e-4)
+    assert np.abs(pose_h - pose_u).max() <= 3e-4

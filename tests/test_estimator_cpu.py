@@ -11,11 +11,14 @@ from gen6d_amd.network import name2network
 from gen6d_amd.synth_db import SyntheticDatabase
 
 
-def make_estimator(device="cpu", refine_iter=1):
+def make_estimator(device="cpu", refine_iter=1, damped=False):
+    """damped: the refiner's pose heads predict small residuals around the identity (synth.damp_refiner_head), as a trained
+    refiner does — estimator-level comparisons then hold to 1e-4 instead of being dominated by the random head's amplification."""
     mods = {}
     for k in ("detector", "selector", "refiner"):
         net = name2network[k]({"name": k + "_synth"}).eval()
-        net.load_state_dict(synth.synth_state_dict(k))
+        sd = synth.synth_state_dict(k)
+        net.load_state_dict(synth.damp_refiner_head(sd) if (damped and k == "refiner") else sd)
         mods[k] = net.to(device)
     return Gen6DEstimator({"ref_view_num": 8, "det_ref_view_num": 8, "refine_iter": refine_iter}, modules=mods)
 
@@ -67,3 +70,45 @@ def test_device_chain_matches_host_predict(monkeypatch):
     # one refinement step from the same pose: the crops differ by single grey levels (float32 vs float64 homographies), which
     # the randomly initialised refiner amplifies; iterating it is chaotic (see test_estimator_gpu.py), so one step is compared
     np.testing.assert_allclose(pose_d, pose_h, atol=2e-2)
+
+
+def test_reference_feature_cache(monkeypatch):
+    """with `ref_feat_cache_deg` > 0 the alignment angle of every reference view is snapped to that grid, so the
+    features of its aligned crop depend on (view, bucket) only and are reused between the refinement steps of a query and between
+    queries.  Cached results equal the uncached evaluation of the SAME (snapped) geometry; the host-driven predict and the device
+    chain agree; the second query hits the cache."""
+    ref_ops.patch_ops(monkeypatch)
+    db = SyntheticDatabase(n_views=24, size=(96, 128), focal=140.0)
+    est = make_estimator(refine_iter=2, damped=True)
+    est.refiner.cfg["ref_feat_cache_deg"] = 3.0
+    est.build(db, "all")
+    _, que_ids = db.get_split("all")
+    img, K = db.get_image(que_ids[1]), db.get_K(que_ids[1])
+    fc = est.refiner.feat_cache
+    pose_a, inter_a = est.predict(img, K)                        # cold cache: every (view, bucket) pair is computed once
+    cold_miss, cold_hit = fc.misses, fc.hits
+    assert cold_miss >= 6 and len(fc.store) == cold_miss
+    pose_b, inter_b = est.predict(img, K)                        # warm: no reference crop goes through the feature net again
+    assert fc.misses == cold_miss and fc.hits == cold_hit + 12
+    np.testing.assert_allclose(pose_b, pose_a, atol=1e-6)
+    # the same snapped geometry evaluated WITHOUT the cache (features recomputed from the crops every step)
+    feats_cached = {k: v.clone() for k, v in fc.store.items()}
+    fc.clear()
+    monkeypatch.setattr(est.refiner, "cached_ref_feats", lambda keys, make: est.refiner.run_feature_net(make(list(range(len(keys))))))
+    pose_u, _ = est.predict(img, K)
+    np.testing.assert_allclose(pose_u, pose_a, atol=1e-4)
+    monkeypatch.undo(); ref_ops.patch_ops(monkeypatch)
+    # device chain: snapped angles inside the chain kernels, eager run with the cache == run without it; keys are (view, bucket)
+    fc.clear()
+    pose_d0, _ = est.predict_device(img, K)
+    pose_d1, _ = est.predict_device(img, K, use_feat_cache=True)
+    pose_d2, _ = est.predict_device(img, K, use_feat_cache=True)
+    assert fc.hits >= 12 and 0.0 < fc.hit_rate < 1.0
+    # (two steps: a 1e-6 difference of the first step's pose can flip the uint8 rounding of single pixels of the next query crop)
+    np.testing.assert_allclose(pose_d1, pose_d0, atol=1e-4)
+    np.testing.assert_allclose(pose_d2, pose_d1, atol=1e-6)
+    # snapping is opt-in: the default configuration keeps the reference's exact alignment and caches nothing
+    est2 = make_estimator(refine_iter=1, damped=True)
+    est2.build(db, "all")
+    est2.predict(img, K)
+    assert est2.refiner.angle_step() == 0.0 and len(est2.refiner.feat_cache.store) == 0

@@ -17,23 +17,24 @@ def test_estimator_gpu_matches_cpu_emulation(monkeypatch):
     db = SyntheticDatabase(n_views=24, size=(96, 128), focal=140.0)
     _, que_ids = db.get_split("all")
     img, K = db.get_image(que_ids[1]), db.get_K(que_ids[1])
-    est = make_estimator("cuda", refine_iter=1)
+    est = make_estimator("cuda", refine_iter=1, damped=True)      # pose heads around the identity, like a trained refiner (weak #2)
     est.build(db, "all")
     pose, inter = est.predict(img, K)
     assert pose.shape == (3, 4) and np.isfinite(pose).all()
     with monkeypatch.context() as m:                      # the same flow with every op replaced by its reference
         ref_ops.patch_ops(m)
-        est_c = make_estimator("cpu", refine_iter=1)
+        est_c = make_estimator("cpu", refine_iter=1, damped=True)
         est_c.build(db, "all")
         pose_c, inter_c = est_c.predict(img, K)
     assert (np.abs(est.ref_info["imgs"].astype(int) - est_c.ref_info["imgs"].astype(int)) <= 1).all()
     assert inter["sel_ref_idx"] == inter_c["sel_ref_idx"]
     np.testing.assert_allclose(inter["det_position"], inter_c["det_position"], rtol=1e-3, atol=0.5)
     np.testing.assert_allclose(inter["det_scale_r2q"], inter_c["det_scale_r2q"], rtol=2e-2)
-    # With random weights the refiner residual is large and arbitrary, so iterating it is chaotic; after ONE step from the
-    # same detection/selection the two paths must still land on the same pose.
-    np.testing.assert_allclose(pose[:, :3], pose_c[:, :3], atol=3e-2)
-    np.testing.assert_allclose(pose[:, 3], pose_c[:, 3], rtol=3e-2, atol=3e-2)
+    # The refiner's pose heads are damped towards the identity update (synth.damp_refiner_head), as a trained refiner's are: the
+    # HIP path and the CPU emulation of the same flow then agree on the refined pose far below the round-2 bound of 3e-2.
+    from parity_log import record
+    record("test_estimator_gpu_matches_cpu_emulation", "refined pose (a13/a14): GPU estimator vs CPU emulation", float(np.abs(pose - pose_c).max()), 3e-4)
+    np.testing.assert_allclose(pose, pose_c, atol=3e-4)
 
 
 def test_estimator_loads_checkpoints_like_the_reference(tmp_path, monkeypatch):
