@@ -55,7 +55,7 @@ class DeviceChain:
         self._lanes = None
 
     # ------------------------------------------------------------------ one query, no host synchronisation
-    def query(self, que_img, que_K, use_feat_cache=False):
+    def query(self, que_img, que_K, use_feat_cache=False, pose_init=None, refine_iter=None):
         """que_img uint8 [H,W,3] and que_K float32 [3,3], both on the device -> dict of device tensors:
         'pose' [3,4], 'det' [5] (x, y, 2^scale, cell), 'sel' [2] (reference index, in-plane angle), 'logits' [rfn].
         With the refiner's cfg `ref_feat_cache_deg` > 0 the reference alignment angles are snapped to that grid (also inside a
@@ -64,17 +64,24 @@ class DeviceChain:
         est, size = self.est, self.size
         astep = est.refiner.angle_step() if est.refiner is not None else 0.0
         with torch.no_grad():
-            x = que_img.permute(2, 0, 1)[None].float().div_(255)
-            det = est.detector.detect_impl(x.contiguous())
-            det5 = torch.cat([det["positions"][0], det["scales"][0:1], det["que_select_id"][0].float()]).contiguous()
-            crop = ops.warp_batch(None, que_img, None, ops.chain_crop_from_detection(det5, size), size, size)
-            logits, angles = est.selector.compute_view_point_feats(crop)
             que_K9 = que_K.reshape(9).contiguous()
-            pose, sel = ops.chain_pose_from_selection(det5, logits[0].contiguous(), angles[0].contiguous(), self.ref_poses, self.ref_Ks,
-                                                      que_K9, self.center)
+            if pose_init is None:
+                x = que_img.permute(2, 0, 1)[None].float().div_(255)
+                det = est.detector.detect_impl(x.contiguous())
+                det5 = torch.cat([det["positions"][0], det["scales"][0:1], det["que_select_id"][0].float()]).contiguous()
+                crop = ops.warp_batch(None, que_img, None, ops.chain_crop_from_detection(det5, size), size, size)
+                logits, angles = est.selector.compute_view_point_feats(crop)
+                pose, sel = ops.chain_pose_from_selection(det5, logits[0].contiguous(), angles[0].contiguous(), self.ref_poses, self.ref_Ks,
+                                                          que_K9, self.center)
+            else:
+                # tracking (reference predict.py:56-59, estimator.py:207-208): the previous frame's pose — a DEVICE tensor, no read-back —
+                # replaces detection + selection
+                pose = pose_init.reshape(3, 4).to(self.dev, torch.float32).contiguous()
+                det5 = sel = crop = None
+                logits = [None]
             poses = [pose]
             R, rs = self.REF_NUM, self.refine_size
-            for _ in range(self.refine_iter):
+            for _ in range(self.refine_iter if refine_iter is None else int(refine_iter)):
                 prep = ops.chain_refine_prepare(pose.reshape(12), que_K9, self.norm, rs, self.MARGIN, self.sub_poses, self.sub_Ks, R,
                                                 angle_step=astep)
                 geo, idx = prep[0], prep[1]

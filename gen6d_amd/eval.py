@@ -23,8 +23,10 @@ from . import estimator as E
 
 
 # ------------------------------------------------------------------------------------------------ metrics on the device
-def compute_metrics(object_pts, diameter, pose_gt_list, pose_pr_list, Ks, scale=1.0, symmetric=False, device=None):
-    """reference utils/pose_utils.py:149-215 for all queries at once: {'add-0.1d', 'prj-5'[, 'add-0.1d-sym']}."""
+def compute_metrics(object_pts, diameter, pose_gt_list, pose_pr_list, Ks, scale=1.0, symmetric=False, device=None, return_errors=False):
+    """reference utils/pose_utils.py:149-215 for all queries at once: {'add-0.1d', 'prj-5'[, 'add-0.1d-sym']}; return_errors: also
+    the per-query (projection error px, ADD error) arrays (compute_pose_errors, pose_utils.py:149-175).  Checked against the
+    reference's own function through tests/golden/geometry.npz (tests/test_eval_cpu.py)."""
     dev = device or ("cuda" if torch.cuda.is_available() else "cpu")
     f = lambda a: torch.from_numpy(np.ascontiguousarray(np.asarray(a), dtype=np.float64)).to(dev)
     pts, gt, pr, K = f(object_pts), f(pose_gt_list), f(pose_pr_list), f(Ks)
@@ -49,7 +51,81 @@ def compute_metrics(object_pts, diameter, pose_gt_list, pose_pr_list, Ks, scale=
         step = max(1, int((256 << 20) // max(8 * n * n, 1)))
         sym = torch.cat([torch.cdist(p3_pr[i:i + step], p3_gt[i:i + step]).min(2)[0].mean(1) for i in range(0, p3_pr.shape[0], step)]) * scale
         res["add-0.1d-sym"] = float((sym < diameter * 0.1).double().mean())
+    if return_errors:
+        return res, prj_err.cpu().numpy(), obj_err.cpu().numpy()
     return res
+
+
+# ------------------------------------------------------------------------------------------------ image decode / video tracking
+def decode_image(path):
+    """JPEG / PNG file -> uint8 [H,W,3] (the reference reads frames with skimage.io.imread, eval.py:123 via database.get_image and
+    predict.py:51; PIL is the decoder underneath).  Runs in the prefetch threads of run_queries (PIL releases the GIL while decoding)."""
+    from PIL import Image
+    with Image.open(path) as im:
+        return np.ascontiguousarray(np.asarray(im.convert("RGB")))
+
+
+class JpegFolderDatabase:
+    """A database whose images live as JPEG files on disk (LINEMOD / GenMOP layout: one file per view) and are decoded on every
+    get_image — the I/O the reference's eval loop pays per query.  Wraps any database object for poses / intrinsics / splits;
+    `export` writes the wrapped database's images as JPEGs once."""
+
+    def __init__(self, database, folder, quality=95, export=True):
+        import os
+        from PIL import Image
+        self.database, self.folder = database, folder
+        os.makedirs(folder, exist_ok=True)
+        if export:
+            for i in database.get_img_ids():
+                path = os.path.join(folder, f"{i}.jpg")
+                if not os.path.exists(path):
+                    Image.fromarray(np.asarray(database.get_image(i))).save(path, quality=quality)
+
+    def get_image(self, i):
+        import os
+        return decode_image(os.path.join(self.folder, f"{i}.jpg"))
+
+    def __getattr__(self, name):                    # poses, intrinsics, splits, object geometry: the wrapped database's
+        return getattr(self.database, name)
+
+
+def pseudo_K(h, w):
+    """predict.py:53-56: intrinsics assumed for an uncalibrated video frame."""
+    f = np.sqrt(h ** 2 + w ** 2)
+    return np.asarray([[f, 0, w / 2], [0, f, h / 2], [0, 0, 1]], np.float32)
+
+
+def track_frames(estimator, frames, Ks=None, device_resident=True):
+    """The video loop of the reference's predict.py:49-60: the first frame is detected + selected + refined `refine_iter` times,
+    every later frame starts from the previous frame's pose and is refined ONCE (`pose_init`, refine_iter = 1).  frames: iterable of
+    uint8 [H,W,3] arrays (or file paths -> decode_image); Ks: intrinsics per frame (None: predict.py's pseudo K).
+    device_resident: the pose stays on the GPU from frame to frame (DeviceChain.query(pose_init=...): no host round trip per frame,
+    one synchronisation at the end); otherwise the host-driven `predict(img, K, pose_init)` of the reference's loop.
+    Returns poses [n,3,4] float32.  (The box smoothing + cv2.solvePnP of predict.py:66-72 is visualisation, not on this path.)"""
+    frames = list(frames)
+    imgs = [decode_image(f) if isinstance(f, (str, bytes)) or hasattr(f, "__fspath__") else np.asarray(f) for f in frames]
+    Ks = [pseudo_K(*im.shape[:2]) if Ks is None else np.asarray(Ks[i], np.float32) for i, im in enumerate(imgs)]
+    if not device_resident:
+        poses, pose, it0 = [], None, estimator.cfg["refine_iter"]
+        try:
+            for im, K in zip(imgs, Ks):
+                if pose is not None:
+                    estimator.cfg["refine_iter"] = 1        # predict.py:58: "we only refine one time after initialization"
+                pose, _ = estimator.predict(im, K, pose_init=pose)
+                poses.append(pose)
+        finally:
+            estimator.cfg["refine_iter"] = it0
+        return np.stack(poses, 0).astype(np.float32)
+    chain = estimator.device_chain()
+    dev = estimator.device
+    out, pose = [], None
+    for im, K in zip(imgs, Ks):
+        r = chain.query(torch.from_numpy(np.ascontiguousarray(im)).to(dev, non_blocking=True),
+                        torch.from_numpy(np.ascontiguousarray(K, dtype=np.float32)).to(dev, non_blocking=True), pose_init=pose,
+                        refine_iter=None if pose is None else 1)
+        pose = r["pose"]
+        out.append(pose)
+    return torch.stack(out, 0).cpu().numpy().astype(np.float32)
 
 
 # ------------------------------------------------------------------------------------------------ streaming evaluation
@@ -146,8 +222,14 @@ def main(argv=None):
     ap.add_argument("--lanes", type=int, default=3)
     ap.add_argument("--prefetch", type=int, default=6)
     ap.add_argument("--max_queries", type=int, default=0)
+    ap.add_argument("--jpeg_dir", type=str, default=None,
+                    help="serve the query images from JPEG files in this folder (written once from the database): every query then pays "
+                         "a real JPEG decode in the prefetch threads, as the reference's loop does on LINEMOD / GenMOP")
+    ap.add_argument("--json", type=str, default=None, help="also write the summary (metrics, images/s, build seconds) to this file")
     args = ap.parse_args(argv)
     ref_db, que_db, ref_split, que_split = open_databases(args.object_name)
+    if args.jpeg_dir:
+        que_db = JpegFolderDatabase(que_db, args.jpeg_dir)
     if args.cfg == "synth":
         from . import synth
         from .network import name2network
@@ -176,6 +258,12 @@ def main(argv=None):
     print(msg)
     print(f"build {build_s:.2f} s; {len(que_ids)} queries in {secs:.2f} s = {len(que_ids) / secs:.1f} images/s "
           f"(decode + upload + detect + select + {est.cfg['refine_iter']} x refine, {args.lanes} queries in flight)")
+    if args.json:
+        import json
+        with open(args.json, "w") as f:
+            json.dump({"object": args.object_name, "cfg": args.cfg, "metrics": res, "queries": len(que_ids), "seconds": secs,
+                       "images_per_s": len(que_ids) / secs, "build_s": build_s, "lanes": args.lanes, "prefetch": args.prefetch,
+                       "jpeg_decode": bool(args.jpeg_dir), "refine_iter": est.cfg["refine_iter"]}, f, indent=1)
     return res
 
 

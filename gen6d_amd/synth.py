@@ -44,7 +44,7 @@ def synth_state_dict(kind, seed=1234, an=5):
     return sd
 
 
-def damp_refiner_head(sd, gain=0.02):
+def damp_refiner_head(sd, gain=1e-3):
     """Copy of a refiner state_dict whose pose heads (regressor.fcr / fct / fcs, reference refiner.py:157-166) are scaled by `gain`
     and biased to the identity update (quaternion (1,0,0,0), zero offset, zero log-scale): a TRAINED refiner predicts small
     residuals around the identity, whereas the seeded random head produces O(1) residuals and amplifies single grey levels of the

@@ -171,3 +171,28 @@ def test_reference_feature_cache_gpu():
     pose_h, _ = est.predict(img, K)                                            # host-driven path with its own (view id, bucket) keys
     record("test_reference_feature_cache_gpu", "pose: host-driven cached predict vs device chain", float(np.abs(pose_h - pose_u).max()), 3e-4)
     assert np.abs(pose_h - pose_u).max() <= 3e-4
+
+
+def test_streaming_eval_with_real_jpeg_decode_and_tracking(built, tmp_path):
+    """f4 on the GPU: (a) run_queries over a database served from JPEG files (PIL decode in the prefetch threads, pinned upload,
+    three lanes) gives the poses of predict_many on the decoded images and the reference's metrics are finite; (b) the
+    device-resident tracking loop (predict.py:49-60) follows the host-driven one."""
+    from gen6d_amd import eval as EV
+    db, est = built
+    jdb = EV.JpegFolderDatabase(db, str(tmp_path / "jpg"))
+    _, que_ids = db.get_split("all")
+    que_ids = list(que_ids)[:7]
+    poses, secs, inters = EV.run_queries(est, jdb, que_ids, lanes=3, prefetch=4, decode_threads=3)
+    imgs = [jdb.get_image(i) for i in que_ids]
+    many = est.predict_many(imgs, [db.get_K(i) for i in que_ids], lanes=3)
+    for i, (pm, im_) in enumerate(many):
+        assert inters[i]["sel_ref_idx"] == im_["sel_ref_idx"]
+        np.testing.assert_allclose(poses[i], pm, atol=3e-4)
+    res, prj, obj = EV.compute_metrics(EV.get_ref_point_cloud(db), db.object_diameter, [db.get_pose(i) for i in que_ids], poses,
+                                       [db.get_K(i) for i in que_ids], return_errors=True)
+    assert np.isfinite(prj).all() and np.isfinite(obj).all() and set(res) == {"add-0.1d", "prj-5"}
+    frames, Ks = imgs[:3], [db.get_K(i) for i in que_ids[:3]]
+    host = EV.track_frames(est, frames, Ks, device_resident=False)
+    dev = EV.track_frames(est, frames, Ks, device_resident=True)
+    np.testing.assert_allclose(dev[0], host[0], atol=3e-4)                       # frame 0: detect + select + one step
+    assert np.isfinite(dev).all() and np.abs(dev - host).max() < 5e-2            # later frames compound (see tests/test_eval_cpu.py)

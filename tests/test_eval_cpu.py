@@ -42,3 +42,70 @@ def test_point_cloud_fallbacks():
     assert EV.get_ref_point_cloud(A()).shape == (5, 3)
     pc = EV.get_ref_point_cloud(B())
     np.testing.assert_allclose(np.linalg.norm(pc - B.object_center, axis=1), 1.0, atol=1e-5)
+
+
+def test_metrics_match_the_references_own_function(golden):
+    """the checker is the reference's `compute_metrics_impl` / `compute_pose_errors` themselves
+    (utils/pose_utils.py:149-215), run by tests/golden/make_golden.py on seeded poses and stored in geometry.npz."""
+    g = golden("geometry")
+    res, prj, obj = EV.compute_metrics(g["met_pts"], float(g["met_diameter"]), g["met_gt"], g["met_pr"], g["met_Ks"], symmetric=True,
+                                       device="cpu", return_errors=True)
+    np.testing.assert_allclose(prj, g["met_prj_err"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(obj, g["met_obj_err"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose([res["add-0.1d"], res["prj-5"], res["add-0.1d-sym"]], g["met_res"], atol=1e-12)
+    res2 = EV.compute_metrics(g["met_pts"], float(g["met_diameter"]), g["met_gt"], g["met_pr"], g["met_Ks"], scale=2.5, device="cpu")
+    np.testing.assert_allclose([res2["add-0.1d"], res2["prj-5"]], g["met_res_scale25"], atol=1e-12)
+    assert 0 < res["add-0.1d"] < res["add-0.1d-sym"] < 1          # the fixture separates the three numbers
+
+
+def test_symmetric_metric_is_chunked():
+    """4096 model points x many queries must not build one [q,n,n] tensor (140 GB on LINEMOD eggbox / glue)."""
+    rng = np.random.RandomState(1)
+    poses, Ks = synth.fibonacci_cameras(40, radius=3.0, focal=300.0, size=256)
+    pts = rng.randn(4096, 3).astype(np.float32) * 0.2
+    prs = [synth.perturb_pose(p, 1.0, 0.01) for p in poses]
+    res = EV.compute_metrics(pts, 0.8, poses, prs, Ks, symmetric=True, device="cpu")      # 40 x 4096 x 4096 x 8 B = 5.4 GB unchunked
+    assert 0.0 <= res["add-0.1d-sym"] <= 1.0
+
+
+def test_jpeg_decode_source_and_tracking_loop(tmp_path, monkeypatch):
+    """f4: (a) a database served from JPEG files decodes every query image with PIL (the I/O of the reference's eval loop,
+    eval.py:121-126) and round-trips the pixels to JPEG accuracy; (b) `track_frames` reproduces predict.py:49-60 — frame 0 goes through
+    detection + selection + refine_iter steps, later frames start from the previous pose with ONE refinement step — identically in the
+    host-driven and the device-resident variant."""
+    import ref_ops
+    import torch
+    from gen6d_amd.synth_db import SyntheticDatabase
+    from test_estimator_cpu import make_estimator
+    ref_ops.patch_ops(monkeypatch)
+    db = SyntheticDatabase(n_views=24, size=(96, 128), focal=140.0)
+    jdb = EV.JpegFolderDatabase(db, str(tmp_path / "jpg"))
+    ids = db.get_img_ids()
+    a, b = db.get_image(ids[3]), jdb.get_image(ids[3])
+    assert b.dtype == np.uint8 and b.shape == a.shape and np.abs(a.astype(int) - b.astype(int)).mean() < 3.0
+    assert np.array_equal(jdb.get_K(ids[3]), db.get_K(ids[3])) and jdb.get_img_ids() == ids
+    assert np.array_equal(EV.decode_image(str(tmp_path / "jpg" / f"{ids[3]}.jpg")), b)
+    np.testing.assert_allclose(EV.pseudo_K(96, 128), [[160, 0, 64], [0, 160, 48], [0, 0, 1]])
+    est = make_estimator(refine_iter=2, damped=True)
+    est.build(db, "all")
+    _, que_ids = db.get_split("all")
+    frames = [db.get_image(que_ids[1]), db.get_image(que_ids[1]), db.get_image(que_ids[2])]
+    Ks = [db.get_K(que_ids[1]), db.get_K(que_ids[1]), db.get_K(que_ids[2])]
+    calls = []
+    orig = est.refiner.refine_que_imgs
+    monkeypatch.setattr(est.refiner, "refine_que_imgs", lambda *a_, **k_: (calls.append(1), orig(*a_, **k_))[1])
+    host = EV.track_frames(est, frames, Ks, device_resident=False)
+    assert host.shape == (3, 3, 4) and len(calls) == 2 + 1 + 1 and est.cfg["refine_iter"] == 2       # 2 steps, then 1 per frame
+    first, _ = est.predict(frames[0], Ks[0])
+    np.testing.assert_allclose(host[0], first, atol=1e-6)
+    # device-resident loop: same schedule (2 steps, then 1 per frame from the previous DEVICE pose).  Successive refinement steps of the
+    # seeded random volume net amplify a 4e-5 difference of the first step ~30x per step (single flipped grey levels of the next crop,
+    # 8 stacked InstanceNorms), so the two loops are compared step by step from a COMMON pose, then end to end loosely
+    chain = est.device_chain()
+    it = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    one = chain.query(it(frames[1]), it(Ks[1]), pose_init=it(host[0]), refine_iter=1)
+    assert one["det"] is None and len(one["refine_poses"]) == 2
+    np.testing.assert_allclose(one["pose"].numpy(), host[1], atol=2e-4)            # frame 1 from frame 0's pose: one step
+    dev = EV.track_frames(est, frames, Ks, device_resident=True)
+    assert dev.shape == (3, 3, 4) and np.isfinite(dev).all()
+    np.testing.assert_allclose(dev, host, atol=5e-2)
