@@ -259,14 +259,23 @@ class VolumeRefiner(ParamBank):
         return self.run_regressor(self.run_volume_net(mean_in, std, sn))
 
     def _step_from_feats(self, que_img, K_in, pose_in, ref_feats, ref_Ks, ref_poses):
+        """The step with the reference crops' features given (cache hits): only the query crop(s) pass the trunk + feature net.
+        Single query: ref_feats [rfn,fh,fw,C]; batch: ref_feats [qn,rfn,fh,fw,C] with the [qn,...] operands of _step_fp."""
         sn = self.cfg["refiner_sample_num"]
         dev = que_img.device
         h_in, w_in = que_img.shape[-2:]
-        feats = torch.cat([ref_feats, self.run_feature_net(que_img)], 0).contiguous()     # query last
+        batched = ref_feats.dim() == 5
+        qf = self.run_feature_net(que_img)                                               # [qn,fh,fw,C]
+        if batched:
+            feats = torch.cat([ref_feats, qf[:, None]], 1).contiguous()                  # [qn,rfn+1,fh,fw,C], query last
+            lead = (ref_feats.shape[0],)
+        else:
+            feats = torch.cat([ref_feats, qf], 0).contiguous()
+            lead = ()
         lin = _linspace(sn, dev)
         C = feats.shape[-1]
-        mean_in = torch.empty((sn ** 3, 2 * C), dtype=torch.float32, device=dev)
-        std = torch.empty((sn ** 3, C), dtype=torch.float32, device=dev)
+        mean_in = torch.empty(lead + (sn ** 3, 2 * C), dtype=torch.float32, device=dev)
+        std = torch.empty(lead + (sn ** 3, C), dtype=torch.float32, device=dev)
         ops.refiner_volume_kp(feats, ref_Ks.contiguous(), ref_poses.contiguous(), K_in.contiguous(), pose_in.contiguous(),
                               lin, h_in, w_in, mean_in, std)
         return self.run_regressor(self.run_volume_net(mean_in, std, sn))

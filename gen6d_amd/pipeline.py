@@ -34,19 +34,24 @@ class TensorPipeline:
             self.detector.load_impl(self.det_refs.to(d))
             self.selector.extract_ref_feats(self.sel_case["ref_imgs"].to(d), self.sel_case["ref_poses"].to(d),
                                             self.sel_case["object_center"].to(d), self.sel_case["object_vert"].to(d))
+        self.ref_feats = None                        # features of the canned reference crops (query(..., cached_refs=True))
         self.ref_case = synth.refiner_case()
         self.ref_dev = {k: v.to(d) for k, v in self.ref_case.items()}
         # a slightly different input pose per refinement iteration (no cross-iteration caching possible)
         self.iter_poses = [torch.from_numpy(synth.perturb_pose(self.ref_case["poses_in"][0].numpy(), 2.0 * i, 0.01 * i))[None].to(d)
                            for i in range(self.refine_iter)]
 
-    def query(self, que_full, que_crop):
+    def query(self, que_full, que_crop, cached_refs=False):
         """que_full [qn,3,H,W] (detector input), que_crop [qn,3,128,128] (selector/refiner input), device tensors; the qn
         queries of the call share every launch (qn <= 8 per chunk inside the networks).
         Returns [qn,12] rows: position(2), scale, ref_idx, angle, quaternion(4), offset(2), log2-scale."""
         r = self.ref_dev
         qn = que_crop.shape[0]
         with torch.no_grad():
+            if cached_refs and getattr(self, "ref_feats", None) is None:
+                # reference-feature caching (SURVEY.md 8f row 2): the canned reference crops are the same in every step of every
+                # query, i.e. every (view, bucket) key hits — their features are computed once
+                self.ref_feats = self.refiner.run_feature_net(r["ref_imgs"][0]).clone()
             det = self.detector.detect_impl(que_full)
             logits, angles = self.selector.compute_view_point_feats(que_crop)
             idx = torch.argmax(logits, 1)
@@ -54,20 +59,21 @@ class TensorPipeline:
             for it in range(self.refine_iter):
                 if qn == 1:
                     rot, off, scl = self.refiner._step(que_crop, r["Ks_in"][0], self.iter_poses[it][0], r["ref_imgs"][0],
-                                                       r["ref_Ks"][0], r["ref_poses"][0])
+                                                       r["ref_Ks"][0], r["ref_poses"][0], ref_feats=self.ref_feats if cached_refs else None)
                 else:                                  # every query of the batch with its own (here: the same canned) views / poses
                     rots, offs, scls = [], [], []
                     for q0 in range(0, qn, 8):
                         n = min(8, qn - q0)
                         ex = lambda t: t.expand(n, *t.shape[1:])
                         o = self.refiner._step(que_crop[q0:q0 + n], ex(r["Ks_in"]).contiguous(), ex(self.iter_poses[it]).contiguous(),
-                                               ex(r["ref_imgs"]), ex(r["ref_Ks"]).contiguous(), ex(r["ref_poses"]).contiguous())
+                                               ex(r["ref_imgs"]), ex(r["ref_Ks"]).contiguous(), ex(r["ref_poses"]).contiguous(),
+                                               ref_feats=self.ref_feats[None].expand(n, *self.ref_feats.shape) if cached_refs else None)
                         rots.append(o[0]); offs.append(o[1]); scls.append(o[2])
                     rot, off, scl = (torch.cat(t, 0) for t in (rots, offs, scls))
         return torch.cat([det["positions"], det["scales"][:, None], idx[:, None].float(), ang, rot, off, scl], 1)
 
     # ------------------------------------------------------------------ hipGraph
-    def capture(self, full_shape=(1, 3, 480, 640), crop_shape=(1, 3, 128, 128), warmup=2, lanes=1, batch=None):
+    def capture(self, full_shape=(1, 3, 480, 640), crop_shape=(1, 3, 128, 128), warmup=2, lanes=1, batch=None, cached_refs=False):
         """Capture one query — or one batch of `batch` queries that share every launch — into a
         hipGraph with static input / output buffers.  `lanes` > 1 captures that many independent copies (own static
         buffers and intermediates, shared read-only reference state) so that `query_graph(..., lane=i)` can keep
@@ -84,11 +90,11 @@ class TensorPipeline:
             stream.wait_stream(torch.cuda.current_stream(d))
             with torch.cuda.stream(stream):
                 for _ in range(warmup):                  # MIOpen find, workspaces and allocator warm-up off-graph
-                    self.query(g_full, g_crop)
+                    self.query(g_full, g_crop, cached_refs)
             torch.cuda.synchronize(d)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=stream):
-                g_out = self.query(g_full, g_crop)
+                g_out = self.query(g_full, g_crop, cached_refs)
             self._lanes.append((graph, stream, g_full, g_crop, g_out))
         torch.cuda.synchronize(d)
         return self._lanes
