@@ -358,7 +358,7 @@ def main():
                 "ref_idx_equal": bool((lrows[:, 3].long() == ref[:, 3].long()).all()),
                 "detection_cell_px": float(d[:, 0:2].max()), "max_abs_diff_row": float(d.max()),
                 "max_rel_diff_row": float((d / ref.abs().clamp(min=1.0)).max()),
-                "vs_fp32_path_max_rel": float(((lrows - got_rows[:args.steps]).abs() / got_rows[:args.steps].abs().clamp(min=1.0)).max())}
+                "vs_fp32_path_max_rel": float(((lrows - got_rows[:lrows.shape[0]]).abs() / got_rows[:lrows.shape[0]].abs().clamp(min=1.0)).max())}
         if pi > 0:
             lowp[mode] = entry
     if lowp:

@@ -98,8 +98,8 @@ def test_predict_device_matches_host_driven_predict(built):
     np.testing.assert_allclose(inter_d["det_position"], inter_h["det_position"], atol=1e-3)
     np.testing.assert_allclose(inter_d["refine_poses"][0], inter_h["refine_poses"][0], atol=2e-5)
     from parity_log import record
-    record("test_predict_device_matches_host_driven_predict", "refined pose: device chain vs host-driven predict (1 step)", float(np.abs(pose_d - pose_h).max()), 3e-4)
-    np.testing.assert_allclose(pose_d, pose_h, atol=3e-4)           # crops differ by single grey levels (float32 vs float64 homographies)
+    record("test_predict_device_matches_host_driven_predict", "refined pose: device chain vs host-driven predict (1 step)", float(np.abs(pose_d - pose_h).max()), 1e-4)
+    np.testing.assert_allclose(pose_d, pose_h, atol=1e-4)           # crops differ by single grey levels (float32 vs float64 homographies)
 
 
 def test_predict_many_three_lanes(built):
@@ -153,8 +153,10 @@ def test_reference_feature_cache_gpu():
         f_one = est.refiner.run_feature_net(imgs[2:3].contiguous())
     e1 = (f_all[:6] - f_refs).abs().max().item() / f_all.abs().max().item()
     e2 = (f_all[2:3] - f_one).abs().max().item() / f_all.abs().max().item()
-    record("test_reference_feature_cache_gpu", "reference features: batch of 7 vs batch of 6 / 1 (relative to max)", max(e1, e2), 1e-6)
-    assert max(e1, e2) <= 1e-6, (e1, e2)
+    # per-image InstanceNorm: the features of a crop do not depend on its batch; what differs is the split / tile choice of the conv
+    # launches with N (fp32 reassociation, measured 1.3e-6 of the feature range)
+    record("test_reference_feature_cache_gpu", "reference features: batch of 7 vs batch of 6 / 1 (relative to max)", max(e1, e2), 5e-6)
+    assert max(e1, e2) <= 5e-6, (e1, e2)
     fc = est.refiner.feat_cache
     img, K = db.get_image(que_ids[1]), db.get_K(que_ids[1])
     pose_u, _ = est.predict_device(img, K)                                     # snapped angles, nothing cached
