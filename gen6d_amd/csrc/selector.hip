@@ -6,6 +6,7 @@
 //     mean_c = (1/N) sum_hw q_c(hw) R1_c(hw),  E[x^2]_c = (1/N) sum_hw q_c(hw)^2 R2_c(hw),
 //     R1 = sum_d r, R2 = sum_d r^2,  N = D*HW.
 #include "g6d_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -100,12 +101,58 @@ struct SelArgs { SelLevel lv[3]; int nlev, qn, D, C, scan_blocks; double inv_dg,
 #define SEL_MAX_QN 8
 
 // QN = compile-time bound of the batch (1, 2, 4, 8): the score accumulators of a wave are 4 rows x QN registers
-template <int QN>
-__global__ void __launch_bounds__(1024) selector_levels_kernel(const SelArgs a) {
+// ROWQ (C == 512, batches): a wave owns ONE location row of a level and a chunk of SEL_DC hypotheses; the row of every query sits in
+// registers (2 x 16 bytes per lane and query) and the wave streams the SEL_DC reference rows of that location past them, four 2 KB
+// rows in flight.  Without it (the layout above) every block re-reads the rows of all QN queries from L2 for each hypothesis — at
+// QN = 8 that is 8x the reference bytes through L2 and the launch drops from 0.54 to 0.14 of the HBM rate (measured, round 3).
+#define SEL_DC 20
+template <int QN, bool ROWQ>
+__global__ void __launch_bounds__(ROWQ ? 512 : 1024) selector_levels_kernel(const SelArgs a) {
+  constexpr int WAVES = ROWQ ? 8 : 16, NPL = WAVES * 4;          // ROWQ: 512-thread blocks (256 registers per lane: QN = 8 needs ~140)
   __shared__ double sm[64][16 + 1], se[64][16 + 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int b = blockIdx.x;
-  if (b < a.scan_blocks) {
+  if (ROWQ && b < a.scan_blocks) {
+    int l = 0;
+#pragma unroll
+    for (int k = 1; k < 3; ++k) l = (k < a.nlev && b >= a.lv[k].blk0) ? k : l;
+    const SelLevel& L = a.lv[l];
+    const int HW = L.HW, qn = a.qn, D = a.D;
+    const int u = (b - L.blk0) * WAVES + wave;                   // unit = (hypothesis chunk, row): consecutive waves -> consecutive rows
+    const int dch = u / HW, row = u - dch * HW;
+    const int d0 = dch * SEL_DC;
+    if (d0 >= D) return;
+    f32x4 qv[QN][2];
+#pragma unroll
+    for (int q = 0; q < QN; ++q) {
+      const float* qr = L.que + ((size_t)min(q, qn - 1) * HW + row) * 512 + lane * 4;
+      qv[q][0] = *reinterpret_cast<const f32x4*>(qr); qv[q][1] = *reinterpret_cast<const f32x4*>(qr + 256);
+    }
+    const float* rbase = L.refs + (size_t)row * 512 + lane * 4;
+    const size_t dstride = (size_t)HW * 512;
+    const int dn = min(SEL_DC, D - d0);
+    for (int dd = 0; dd < dn; dd += 4) {
+      f32x4 rv[4][2];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {                                // hypotheses beyond the chunk re-read its last one (discarded)
+        const float* r = rbase + (size_t)(d0 + min(dd + k, dn - 1)) * dstride;
+        rv[k][0] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(r));
+        rv[k][1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(r + 256));
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int q = 0; q < QN; ++q) {
+          float s = rv[k][0][0] * qv[q][0][0] + rv[k][0][1] * qv[q][0][1] + rv[k][0][2] * qv[q][0][2] + rv[k][0][3] * qv[q][0][3] +
+                    rv[k][1][0] * qv[q][1][0] + rv[k][1][1] * qv[q][1][1] + rv[k][1][2] * qv[q][1][2] + rv[k][1][3] * qv[q][1][3];
+          s = wave_sum(s);
+          if (lane == 0 && q < qn && dd + k < dn) L.score_map[((size_t)q * D + d0 + dd + k) * HW + row] = s;
+        }
+      }
+    }
+    return;
+  }
+  if (!ROWQ && b < a.scan_blocks) {
     int l = 0;
 #pragma unroll
     for (int k = 1; k < 3; ++k) l = (k < a.nlev && b >= a.lv[k].blk0) ? k : l;
@@ -161,7 +208,7 @@ __global__ void __launch_bounds__(1024) selector_levels_kernel(const SelArgs a) 
   const int c = cg * 16 + cl;
   double m = 0, e = 0;
   if (c < a.C)
-    for (int p = pl; p < L.HW; p += 64) {
+    for (int p = pl; p < L.HW; p += NPL) {
       const double qv = que[(size_t)p * a.C + c];
       m += qv * L.r1[(size_t)p * a.C + c];
       e += qv * qv * L.r2[(size_t)p * a.C + c];
@@ -171,7 +218,7 @@ __global__ void __launch_bounds__(1024) selector_levels_kernel(const SelArgs a) 
   if (pl == 0 && c < a.C) {
     m = 0; e = 0;
 #pragma unroll
-    for (int k = 0; k < 64; ++k) { m += sm[k][cl]; e += se[k][cl]; }
+    for (int k = 0; k < NPL; ++k) { m += sm[k][cl]; e += se[k][cl]; }
     const double inv_n = a.inv_dg / (double)L.HW;
     m *= inv_n; e *= inv_n;
     double var = e - m * m; if (var < 0) var = 0;
@@ -225,12 +272,23 @@ extern "C" int g6d_selector_levels(int nlev, int qn, const float* const* que, co
     a.lv[l] = SelLevel{que[l], refs[l], r1[l], r2[l], score_maps[l], HW[l], parts, blk, 0};
     blk += D * parts;
   }
+  // query rows in registers (ROWQ) for batches with C == 512 (G6D_SEL_ROWQ=0: never, =1: also for a single query; A/B aid)
+  static const int rowq_env = []() { const char* e = getenv("G6D_SEL_ROWQ"); return e ? atoi(e) : -1; }();
+  const bool rowq = C == 512 && (rowq_env < 0 ? qn > 1 : rowq_env == 1 || (rowq_env != 0 && qn > 1));
+  if (rowq) {
+    blk = 0;
+    const int nch = (D + SEL_DC - 1) / SEL_DC;
+    for (int l = 0; l < nlev; ++l) { a.lv[l].blk0 = blk; blk += (HW[l] * nch + 7) / 8; }
+  }
   a.scan_blocks = blk;
   const int blocks = blk + qn * nlev * ((C + 15) / 16);
-  if (qn == 1) hipLaunchKernelGGL(selector_levels_kernel<1>, dim3(blocks), dim3(1024), 0, STREAM(stream), a);
-  else if (qn == 2) hipLaunchKernelGGL(selector_levels_kernel<2>, dim3(blocks), dim3(1024), 0, STREAM(stream), a);
-  else if (qn <= 4) hipLaunchKernelGGL(selector_levels_kernel<4>, dim3(blocks), dim3(1024), 0, STREAM(stream), a);
-  else hipLaunchKernelGGL(selector_levels_kernel<8>, dim3(blocks), dim3(1024), 0, STREAM(stream), a);
+#define SEL_LAUNCH(QN_, RQ_) hipLaunchKernelGGL((selector_levels_kernel<QN_, RQ_>), dim3(blocks), dim3(RQ_ ? 512 : 1024), 0, STREAM(stream), a)
+  if (rowq) {
+    if (qn == 1) SEL_LAUNCH(1, true); else if (qn == 2) SEL_LAUNCH(2, true); else if (qn <= 4) SEL_LAUNCH(4, true); else SEL_LAUNCH(8, true);
+  } else {
+    if (qn == 1) SEL_LAUNCH(1, false); else if (qn == 2) SEL_LAUNCH(2, false); else if (qn <= 4) SEL_LAUNCH(4, false); else SEL_LAUNCH(8, false);
+  }
+#undef SEL_LAUNCH
   int rc = g6d_check_launch("selector_levels");
   if (rc != G6D_OK) return rc;
   hipLaunchKernelGGL(vps_levels_kernel, dim3((qn * nlev * D + 3) / 4), dim3(256), 0, STREAM(stream), a);
