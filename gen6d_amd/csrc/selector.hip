@@ -141,13 +141,31 @@ __global__ void __launch_bounds__(ROWQ ? 512 : 1024) selector_levels_kernel(cons
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
+        // the QN dot products of this reference row, reduced over the wave TOGETHER: every exchange step halves the number of
+        // values a lane carries (lane bit 5 keeps the odd / even query of a pair, bit 4 of the next pair, ...), so QN = 8 values cost
+        // 4 + 2 + 1 + 3 cross-lane exchanges instead of 8 x 6 (the exchanges go through the LDS crossbar and bounded this kernel)
+        float v[QN];
 #pragma unroll
-        for (int q = 0; q < QN; ++q) {
-          float s = rv[k][0][0] * qv[q][0][0] + rv[k][0][1] * qv[q][0][1] + rv[k][0][2] * qv[q][0][2] + rv[k][0][3] * qv[q][0][3] +
-                    rv[k][1][0] * qv[q][1][0] + rv[k][1][1] * qv[q][1][1] + rv[k][1][2] * qv[q][1][2] + rv[k][1][3] * qv[q][1][3];
-          s = wave_sum(s);
-          if (lane == 0 && q < qn && dd + k < dn) L.score_map[((size_t)q * D + d0 + dd + k) * HW + row] = s;
+        for (int q = 0; q < QN; ++q)
+          v[q] = rv[k][0][0] * qv[q][0][0] + rv[k][0][1] * qv[q][0][1] + rv[k][0][2] * qv[q][0][2] + rv[k][0][3] * qv[q][0][3] +
+                 rv[k][1][0] * qv[q][1][0] + rv[k][1][1] * qv[q][1][1] + rv[k][1][2] * qv[q][1][2] + rv[k][1][3] * qv[q][1][3];
+        int bit = 32;
+#pragma unroll
+        for (int nv = QN; nv > 1; nv >>= 1, bit >>= 1) {
+          const bool hi = (lane & bit) != 0;
+#pragma unroll
+          for (int i = 0; i < nv / 2; ++i) {
+            const float keep = hi ? v[2 * i + 1] : v[2 * i], send = hi ? v[2 * i] : v[2 * i + 1];
+            v[i] = keep + __shfl_xor(send, bit, 64);
+          }
         }
+        float t = v[0];
+        for (int o = bit; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+        // lane bits 5, 4, 3 (as far as used) spell the query index, least significant first
+        int qi = 0;
+#pragma unroll
+        for (int sft = 0, nv = QN; nv > 1; nv >>= 1, ++sft) qi |= ((lane >> (5 - sft)) & 1) << sft;
+        if ((lane & (64 / QN - 1)) == 0 && qi < qn && dd + k < dn) L.score_map[((size_t)qi * D + d0 + dd + k) * HW + row] = t;
       }
     }
     return;
