@@ -36,11 +36,13 @@ def main():
     fin, ser = bench_line("prof_final.log"), bench_line("prof_serial.log")
     steps = ser["steps"]
     open(os.path.join(P, f"{RND}_bench_kernel_stats.md"), "w").write(
-        f"# rocprofv3 --kernel-trace --stats of `python bench.py --steps {steps} --warmup 4 --no-cpu-baseline --lowp ''` (1x MI355X)\n\n"
-        f"Default launch mode ({fin['config']['launch']}): kernels of different queries overlap, so per-kernel durations are\n"
-        "inflated by sharing the chip; the serialised run next to this file is the one to compare with the roofline.\n"
+        f"# rocprofv3 --kernel-trace --stats of `python bench.py --steps {steps} --warmup 2 --no-cpu-baseline --no-cached --lowp ''` (1x MI355X)\n\n"
+        f"Default launch mode ({fin['config']['launch']}): a step = one batch of {fin.get('batch', 1)} queries.  Where the two batches in\n"
+        "flight overlap, per-kernel durations are inflated by sharing the chip (sum of durations > wall time of the region); the\n"
+        "serialised run next to this file is the one to compare with the roofline.\n"
         "Produced by tools/profile_round.sh + tools/rocpd_stats.py from the rocpd database, cut to the timed region by the two\n"
-        f"g6d_marker_kernel launches.  bench.py under the profiler: {fin['value']:.1f} images/s ({fin['ms_per_step']:.2f} ms per query).\n\n"
+        f"g6d_marker_kernel launches.  bench.py under the profiler: {fin['value']:.1f} images/s ({fin['ms_per_step']:.2f} ms per step of "
+        f"{fin.get('batch', 1)} queries = {fin['ms_per_step'] / fin.get('batch', 1):.2f} ms per query).\n\n"
         + rd("prof_final_stats.md"))
     sstats = rd("prof_serial_stats.md")
     ms, main = family_ms(sstats)
@@ -53,9 +55,10 @@ def main():
     gflop_step = r["gflop_per_launch"] * r["launches_per_step"]
     wg = w.get("gflop_direct_form_per_step", 0.0)
     open(os.path.join(P, f"{RND}_bench_kernel_stats_serial.md"), "w").write(
-        f"# rocprofv3 --kernel-trace --stats of `python bench.py --steps {steps} --warmup 4 --no-cpu-baseline --lowp '' --serial` (1x MI355X)\n\n"
-        "Same workload, one query at a time, no graph replay (`--serial`), which is how bench.py's roofline pass runs: per-kernel\n"
-        "durations are not inflated by overlap and can be compared with the `roofline` objects of the bench JSON.\n\n"
+        f"# rocprofv3 --kernel-trace --stats of `python bench.py --steps {steps} --warmup 2 --no-cpu-baseline --no-cached --lowp '' --serial` (1x MI355X)\n\n"
+        f"Same workload, one BATCH of {ser.get('batch', 1)} queries at a time, no graph replay (`--serial`), which is how bench.py's roofline pass\n"
+        "runs: per-kernel durations are not inflated by overlap and can be compared with the `roofline` objects of the bench JSON.\n"
+        f"A step = {ser.get('batch', 1)} queries: divide the per-step figures by {ser.get('batch', 1)} for per-query numbers.\n\n"
         "* conv family (conv_igemm_kernel<...> + conv_patch_kernel<...> + corr_patch_kernel; split launches finish in-kernel) in the timed region:\n"
         f"  {ms:.2f} ms = {ms / steps:.2f} ms per step ({main / steps:.0f} launches per step, {gflop_step:.1f} GFLOP per step -> "
         f"{gflop_step / (ms / steps):.1f} TFLOP/s by kernel durations; bench.py's HIP-event figure in the same profiled run: "
@@ -68,18 +71,18 @@ def main():
     traffic = json.load(open(os.path.join(G, "pmc_conv_traffic.json")))
     open(os.path.join(P, f"{RND}_pmc_hbm.md"), "w").write(
         "# HBM traffic counters (rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes, no other trace domains)\n\n"
-        "`python bench.py --steps 3 --warmup 2 --no-cpu-baseline --lowp '' --no-graph`, dispatches inside the timed region (3 steps). Unit: KB.\n"
+        "`python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-cached --lowp '' --no-graph`, dispatches inside the timed region (2 steps = 2 batches of 8 queries). Unit: KB.\n"
         "gfx950 note (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports half the bytes of a wide coalesced stream — double it before comparing.\n\n"
         "Checks against algorithmic bytes (per dispatch, tables below):\n"
-        "* `selector_levels_kernel` (score maps + viewpoint scores + product statistics of the three levels, one launch): FETCH x2 vs\n"
-        "  algorithmic 168 + 42 + 10.5 = 220.5 MB of reference cache (+ 3.3 MB of fp64 R1/R2 sums) — the cache is read once.\n"
-        "* `refiner_volume_kernel`: WRITE vs algorithmic 50.3 MB (mean|query 33.5 MB + std 16.8 MB).\n"
+        "* `selector_levels_kernel` (score maps + product statistics of the three levels for the 8 queries of a batch, one launch): FETCH x2 vs\n"
+        "  algorithmic 168 + 42 + 10.5 = 220.5 MB of reference cache, read ONCE per batch (+ 8 x 3.3 MB of fp64 R1/R2 sums, 8 x 0.7 MB of query rows).\n"
+        "* `refiner_volume_kernel`: WRITE vs algorithmic 8 x 50.3 MB per launch (mean|query 33.5 MB + std 16.8 MB per query).\n"
         f"* conv family (tools/pmc_conv_traffic.py -> {RND}_pmc_conv_traffic.json): {traffic['hbm_bytes_per_launch'] / 1e6:.1f} MB HBM-side per launch; "
         f"Winograd family: {traffic.get('winograd_family', {}).get('hbm_bytes_per_launch', 0) / 1e6:.1f} MB per launch — both far from HBM-bound.\n\n"
         "## FETCH_SIZE\n" + rd("pmc_fetch.md") + "\n## WRITE_SIZE\n" + rd("pmc_write.md"))
     open(os.path.join(P, f"{RND}_pmc_mfma.md"), "w").write(
         "# MFMA-busy counter (rocprofv3 --kernel-trace --pmc MfmaUtil, own pass)\n\n"
-        "`python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-graph --serial`; `MfmaUtil` is rocprofv3's derived metric\n"
+        "`python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-cached --lowp '' --no-graph --serial` (batches of 8 queries); `MfmaUtil` is rocprofv3's derived metric\n"
         "`sum(SQ_VALU_MFMA_BUSY_CYCLES) / (max(GRBM_GUI_ACTIVE) * SIMD_NUM) * 100` per dispatch, i.e. chip-wide: a launch whose grid\n"
         "fills half the CUs cannot exceed 50.  `per dispatch` is the plain mean over the kernel's dispatches inside the timed region\n"
         "(small and large layers of one instantiation mixed), the last column weights every dispatch with its duration.\n"
@@ -87,6 +90,8 @@ def main():
         + rd("pmc_mfmautil.md"))
     shutil.copy(os.path.join(G, "pmc_conv_traffic.json"), os.path.join(P, f"{RND}_pmc_conv_traffic.json"))
     for src, dst in (("bench_final.json", "bench.json"), ("layer_table.md", "layer_table.md"), ("trunk_bench.md", "trunk_bench.md"),
+                     ("layer_table_b8.md", "layer_table_batch8.md"), ("layer_table_b1.md", "layer_table_batch1.md"),
+                     ("batch_sweep_all.txt", "batch_sweep.txt"), ("prof_b1_serial_stats.md", "kernel_stats_single_query.md"),
                      ("bench_gpus2.json", "bench_gpus2.json"), ("bench_gpus2_shard.json", "bench_gpus2_shard_refs.json"),
                      ("bench_chained.json", "bench_chained.json")):
         if os.path.exists(os.path.join(G, src)):
