@@ -31,6 +31,7 @@
 #include <stdlib.h>
 #include <stdio.h>
 #include <algorithm>
+#include <type_traits>
 
 #ifndef WINO_ABLATE
 #define WINO_ABLATE 0   // profiling builds only (tools/wino_ablate.sh; results are wrong by construction): 1 = no barrier in the chunk
@@ -89,6 +90,7 @@ struct WinoArgs {
   int img_mod, mul_div;                          // > 0: image i reads input image i % img_mod / multiplier map i / mul_div (G6dConv)
   double* stats; int stats_div;                  // [groups][Cout][2]; group of image i = i / stats_div (0: one group)
   G6dFin fin;                                    // fin.scale != NULL: the last block finalises the statistics
+  int mm;                                        // 0: fp32 kernel; 1 / 2: wino16_conv3x3_kernel with bf16 / fp16 operands (U holds 16-bit filters)
 };
 
 __device__ __forceinline__ f32x4 ldg4(const float* __restrict__ base, int elem_off) {
@@ -500,6 +502,216 @@ __global__ void __launch_bounds__(128 * NWN, 1) wino_conv3x3_kernel(const WinoAr
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Reduced-precision trunk (G6dConv.math_mode semantics: 1 = bf16, 2 = fp16 operands, fp32 accumulation; opt-in speed mode, graded
+// separately): the same F(2x2,3x3) formulation on v_mfma_f32_32x32x16_{bf16,f16}.  One K step of that instruction is 16 input
+// channels, so a chunk is a PAIR of the fp32 kernel's 8-channel chunks:
+//   raw patch  two 8-channel planes, each in the conflict-free layout of the fp32 kernel; lane half h transforms plane h (all 8 of
+//              its channels: two 16-byte reads per patch position), in fp32 registers, and rounds the transformed values to the
+//              operand type when they are packed into the A operand (8 values = channels 16 c + 8 h .. + 7);
+//   filters    transformed and ROUNDED ON THE HOST: U16[chunk][ab][co][16] in the operand type, 32 bytes per (ab, co) row — the same
+//              row size as the fp32 image, so the direct-to-LDS copy, the swizzle (halves swapped for co & 8) and the fragment read
+//              (one ds_read_b128 = the 8 channels of lane half h) are unchanged, and a chunk pair fits the 32 KB filter slot;
+//   MFMAs      16 per chunk (one per (a,b) position) of 8 passes instead of 2 x 64 of 16 passes: the loop is bound by the input
+//              transform (~200 vector instructions) and by streaming 58 KB per chunk into LDS, not by the matrix pipe.
+// Epilogue as the fp32 trunk kernel (output transform, bias, ReLU, full / pooled fp32 outputs, chunk split with in-kernel hand-off).
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 b16x4 __attribute__((ext_vector_type(4)));
+
+template <int MM, int NWN>
+__global__ void __launch_bounds__(128 * NWN, 1) wino16_conv3x3_kernel(const WinoArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int THREADS = 128 * NWN;
+  constexpr int NPR = (1600 + THREADS - 1) / THREADS;         // 16-byte raw pieces per thread and chunk: 2 planes x 4 quarters x 100 x 2
+  constexpr int WU_FLOATS = 16 * 32 * NWN * 8;                // [ab][co][16 x 2 bytes]
+  constexpr int WSTAGE = 2 * WRAW_FLOATS + WU_FLOATS + 4 * THREADS;
+  using hv4 = typename std::conditional<MM == 1, b16x4, h16x4>::type;
+  using hv8 = typename std::conditional<MM == 1, bf16x8, f16x8>::type;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / NWN, wn = wave % NWN;
+  const int li = lane & 31, lh = lane >> 5;
+  const int n0 = blockIdx.y * (32 * NWN);
+  const int nc16 = p.Cin >> 4;
+  const int c_first = blockIdx.z * p.chunks_per_split;
+  const int c_last = min(nc16, c_first + p.chunks_per_split) - 1;
+
+  unsigned pboff[NPR]; int lsto[NPR];
+#pragma unroll
+  for (int j = 0; j < NPR; ++j) {
+    const int idx = tid + THREADS * j;
+    const int plane = idx / 800, r0 = idx - plane * 800;
+    const int q = r0 / 200, r = r0 - q * 200, pp = r >> 1, half = r & 1;
+    const int py = pp / 10, px = pp - py * 10;
+    const QGeo g = quarter_of(p, q < 4 ? q : 0);
+    const int iy = g.oy0 + py - 1, ix = g.ox0 + px - 1;
+    const bool v = (idx < 1600) & g.valid & ((unsigned)iy < (unsigned)g.H) & ((unsigned)ix < (unsigned)g.W);
+    pboff[j] = v ? (unsigned)(g.in_off + ((g.n * g.H + iy) * g.W + ix) * g.ld_in + 8 * plane + 4 * half) << 2 : 0x80000000u;
+    lsto[j] = idx < 1600 ? plane * WRAW_FLOATS + (q * WQ_PIX + pp) * WRAW_LD + 4 * (half ^ ((py >> 1) & 1))
+                         : 2 * WRAW_FLOATS + WU_FLOATS + 4 * tid;
+  }
+  const auto in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  f32x4 rp[NPR];
+  auto load_raw = [&](int chunk) {
+#pragma unroll
+    for (int j = 0; j < NPR; ++j)
+      rp[j] = __builtin_bit_cast(f32x4, __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, pboff[j], chunk * 64, 0)));
+  };
+  auto store_raw = [&](int st) {
+#pragma unroll
+    for (int j = 0; j < NPR; ++j)
+      *reinterpret_cast<f32x4*>(__builtin_assume_aligned(lds + st * WSTAGE + lsto[j], 16)) = rp[j];
+  };
+  const char* ubase = reinterpret_cast<const char*>(p.U) + (size_t)n0 * 32;       // 32 bytes per (ab, co) row
+  const unsigned lane16 = lane * 16;
+  const unsigned lds_addr0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)lds;
+  auto glds = [&](int chunk, int st, int idx) {
+    const int ab = idx / NWN, h = idx % NWN;
+    const char* g = ubase + (size_t)chunk * ((size_t)p.Cout * 512) + (unsigned)((ab * p.Cout + h * 32) * 32);
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr0 + 4u * (unsigned)(st * WSTAGE + 2 * WRAW_FLOATS + (ab * 32 * NWN + h * 32) * 8));
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(lane16), "s"(g), "s"(dst) : "memory");
+  };
+  auto load_u = [&](int chunk, int st) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) glds(chunk, st, wave * 8 + k);
+  };
+  const int tl = li & 15, ty = tl >> 2, tx = tl & 3;
+  const int apos = lh * WRAW_FLOATS + ((2 * wm + (li >> 4)) * WQ_PIX + (2 * ty) * 10 + 2 * tx) * WRAW_LD;     // lane half h reads plane h
+  const int bbase = 2 * WRAW_FLOATS + (wn * 32 + li) * 8 + 4 * (lh ^ ((li >> 3) & 1));
+  constexpr int USTRIDE = 32 * NWN * 8;
+
+  f32x16 acc[16];
+#pragma unroll
+  for (int a = 0; a < 16; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+
+  load_u(c_first, 0);
+  load_raw(c_first);
+  store_raw(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // V = B^T d B of (a,b) group `grp` on 4 channels (the fp32 kernel's transform)
+  auto xform = [&](int grp, const f32x4 (&dd)[4][4], f32x4 (&vv)[4]) {
+    f32x2 rl[4], rh[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 &a = dd[grp == 0 ? 0 : grp == 2 ? 2 : 1][q], &b = dd[grp == 0 ? 2 : grp == 1 ? 2 : grp == 2 ? 1 : 3][q];
+      if (grp == 1) { rl[q] = pk_add(lo2(a), lo2(b)); rh[q] = pk_add(hi2(a), hi2(b)); }
+      else { rl[q] = pk_sub(lo2(a), lo2(b)); rh[q] = pk_sub(hi2(a), hi2(b)); }
+    }
+    vv[0] = cat2(pk_sub(rl[0], rl[2]), pk_sub(rh[0], rh[2]));
+    vv[1] = cat2(pk_add(rl[1], rl[2]), pk_add(rh[1], rh[2]));
+    vv[2] = cat2(pk_sub(rl[2], rl[1]), pk_sub(rh[2], rh[1]));
+    vv[3] = cat2(pk_sub(rl[1], rl[3]), pk_sub(rh[1], rh[3]));
+  };
+
+  for (int cc = c_first; cc <= c_last; ++cc) {
+    const int c = cc - c_first;
+    const float* S = lds + (c & 1) * WSTAGE;
+    if (cc < c_last) {                            // the copies of the next chunk first (they must be older than the loads hipcc counts)
+      load_u(cc + 1, (c & 1) ^ 1);
+      load_raw(cc + 1);
+    }
+    hv4 vh[16][2];                                // transformed patch, rounded: [a*4 + b][4-channel half of the lane's plane]
+#pragma unroll
+    for (int hs = 0; hs < 2; ++hs) {
+      f32x4 d[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          d[i][j] = *reinterpret_cast<const f32x4*>(S + apos + 4 * (hs ^ (ty & 1) ^ (i >> 1)) + (i * 10 + j) * WRAW_LD);
+#pragma unroll
+      for (int grp = 0; grp < 4; ++grp) {
+        f32x4 v[4];
+        xform(grp, d, v);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) vh[grp * 4 + q][hs] = __builtin_convertvector(v[q], hv4);
+      }
+    }
+#pragma unroll
+    for (int ab = 0; ab < 16; ++ab) {
+      const f32x4 uraw = *reinterpret_cast<const f32x4*>(S + bbase + ab * USTRIDE);
+      const hv8 a8 = __builtin_shufflevector(vh[ab][0], vh[ab][1], 0, 1, 2, 3, 4, 5, 6, 7);
+      const hv8 b8 = __builtin_bit_cast(hv8, uraw);
+      if constexpr (MM == 1) acc[ab] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, b8, acc[ab], 0, 0, 0);
+      else acc[ab] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a8, b8, acc[ab], 0, 0, 0);
+    }
+    if (cc < c_last) store_raw((c & 1) ^ 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ---------------------------------------------------------------- epilogue (as the fp32 trunk kernel, without statistics)
+  const int co = n0 + wn * 32 + li;
+  f32x4 Y[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float sr[2][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      sr[0][j] = acc[0 + j][r] + acc[4 + j][r] + acc[8 + j][r];
+      sr[1][j] = acc[4 + j][r] - acc[8 + j][r] - acc[12 + j][r];
+    }
+    Y[r] = f32x4{sr[0][0] + sr[0][1] + sr[0][2], sr[0][1] - sr[0][2] - sr[0][3], sr[1][0] + sr[1][1] + sr[1][2], sr[1][1] - sr[1][2] - sr[1][3]};
+  }
+  if (p.splits > 1) {
+    constexpr int TILE = THREADS * 64;
+    const int ntiles = gridDim.x * gridDim.y, tile = blockIdx.y * gridDim.x + blockIdx.x;
+    float* part = p.ws + G6D_WS_COUNTERS + (size_t)tile * TILE + tid * 4;
+    const size_t zstride = (size_t)ntiles * TILE;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) g6d_store_wt(part + blockIdx.z * zstride + r * (THREADS * 4), Y[r]);
+    if (!g6d_split_arrive(reinterpret_cast<int*>(p.ws) + tile, p.splits, reinterpret_cast<int*>(lds))) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Y[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < p.splits; ++z) {
+      f32x4 v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = *reinterpret_cast<const f32x4*>(part + (size_t)z * zstride + r * (THREADS * 4));
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Y[r] += v[r];
+    }
+  }
+  const float bv = p.bias ? p.bias[co] : 0.f;
+  const bool do_relu = p.relu != 0;
+  const QGeo geo[2] = {quarter_of(p, 2 * wm), quarter_of(p, 2 * wm + 1)};
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const QGeo& g = geo[r >> 3];
+    const int tyy = lh + 2 * ((r >> 2) & 1), txx = r & 3;
+    const int n = g.n; const bool qv = g.valid;
+    const int Hp = g.H >> 1, Wp = g.W >> 1;
+    float y[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        y[a][b] = Y[r][2 * a + b] + bv;
+        if (do_relu) y[a][b] = fmaxf(y[a][b], 0.f);
+      }
+    const int oy = g.oy0 + 2 * tyy, ox = g.ox0 + 2 * txx;
+    if (p.out_full && qv) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          if (oy + a < g.H && ox + b < g.W)
+            p.out_full[(size_t)g.full_off + ((size_t)(n * g.H + oy + a) * g.W + ox + b) * g.ld_full + co] = y[a][b];
+    }
+    if (p.out_pool && qv) {
+      const int py = oy >> 1, px = ox >> 1;
+      if (py < Hp && px < Wp)
+        p.out_pool[(size_t)g.pool_off + ((size_t)(n * Hp + py) * Wp + px) * g.ld_pool + co] = fmaxf(fmaxf(y[0][0], y[0][1]), fmaxf(y[1][0], y[1][1]));
+    }
+  }
+}
+
 // ---- launch: tile width, split over the chunks, instantiation
 template <int MODE, int KD, int NWN>
 int wino_launch_t(WinoArgs& a, long long blocks, hipStream_t stream) {
@@ -547,7 +759,7 @@ int wino_run(WinoArgs& a, int mode, int kd, float* workspace, size_t workspace_b
   // steps: small grids leave CUs idle and grids just above a multiple of 256 pay a nearly empty last round.  Pick the split
   // count with the smallest modelled time: rounds x block time + the hand-off (partial images written and read back, the
   // serial re-read of a tile's sp slabs of 64 KB by its last block).  The constants can be overridden for measurements.
-  const int nchunks = kd * (a.Cin / 8);
+  const int nchunks = a.mm ? a.Cin / 16 : kd * (a.Cin / 8);       // the 16-bit kernel's chunk is a pair of 8-channel chunks
   int splits = 1;
   const long long grid2 = blocks * (a.Cout / (32 * nwn));
   const int slots = 256 * (nwn == 1 ? 2 : 1);
@@ -565,7 +777,7 @@ int wino_run(WinoArgs& a, int mode, int kd, float* workspace, size_t workspace_b
       const int cps_ = (nchunks + sp - 1) / sp, real = (nchunks + cps_ - 1) / cps_;
       if (real != sp) continue;
       const double rounds = (double)((grid2 * sp + slots - 1) / slots);
-      double t = rounds * (cps_ * 2.7 + 4.0);                                   // us: chunks + prologue / epilogue of a block
+      double t = rounds * (cps_ * (a.mm ? 1.2 : 2.7) + 4.0);                    // us: chunks + prologue / epilogue of a block
       if (sp > 1) t += m_fix + m_per * sp + (2 * sp + 1) * out_bytes / 2.5e6;  // hand-off; partial traffic at 2.5 TB/s chip-wide
       if (t < best * m_gain) { best = t; splits = sp; }                        // a further split must buy >= 15 %
     }
@@ -576,6 +788,17 @@ int wino_run(WinoArgs& a, int mode, int kd, float* workspace, size_t workspace_b
   static const bool debug = []() { const char* e = getenv("G6D_WINO_DEBUG"); return e && e[0] == '1'; }();
   if (debug) fprintf(stderr, "wino %d seg, N=%d %dx%dx%d->%d kd=%d mode=%d: grid %lld x %d splits of %d chunks\n", a.nseg, a.N, a.H, a.W, a.Cin,
                      a.Cout, kd, mode, grid2, splits, cps);
+  if (a.mm) {                                   // reduced-precision trunk kernel (MODE 0, 2-D only)
+    if (nwn != 2) { g6d_set_error("wino16: Cout % 64 == 0 expected"); return G6D_EINVAL; }
+    const size_t lds16 = 2 * (size_t)(2 * WRAW_FLOATS + 16 * 64 * 8 + 4 * 256) * sizeof(float);
+    auto go = [&](auto V) {
+      constexpr int MM = decltype(V)::value;
+      g6d_allow_lds(reinterpret_cast<const void*>(&wino16_conv3x3_kernel<MM, 2>), 160 * 1024);
+      hipLaunchKernelGGL((wino16_conv3x3_kernel<MM, 2>), dim3((unsigned)blocks, a.Cout / 64, a.splits), dim3(256), lds16, stream, a);
+    };
+    if (a.mm == 1) go(std::integral_constant<int, 1>{}); else go(std::integral_constant<int, 2>{});
+    return g6d_check_launch("wino16_conv3x3");
+  }
   if (kd == 25) return wino_launch_w<0, 25>(a, blocks, nwn, stream);
   if (kd == 3) return mode == 2 ? wino_launch_w<2, 3>(a, blocks, nwn, stream)
                     : mode == 1 ? wino_launch_w<1, 3>(a, blocks, nwn, stream) : wino_launch_w<0, 3>(a, blocks, nwn, stream);
@@ -641,6 +864,45 @@ extern "C" int g6d_wino_conv3x3_multi(const G6dWinoSeg* segs, int nseg, int Cin,
     if (io + (long long)g.N * g.H * g.W * g.ld_in >= (1ll << 29) || fo + (long long)g.N * g.H * g.W * g.ld_full >= (1ll << 31) ||
         po + (long long)g.N * g.H * g.W * g.ld_pool >= (1ll << 31)) {
       g6d_set_error("wino_conv3x3_multi: segments must lie within 2^30 floats of each other (allocate them from one buffer)"); return G6D_EINVAL;
+    }
+    a.seg[k] = WinoSeg{0, g.N, g.H, g.W, 0, 0, (int)io, (int)fo, (int)po, g.ld_in, g.ld_full, g.ld_pool};
+  }
+  a.N = segs[0].N; a.H = segs[0].H; a.W = segs[0].W; a.ld_in = segs[0].ld_in; a.ld_full = segs[0].ld_full; a.ld_pool = segs[0].ld_pool;
+  return wino_run(a, 0, 1, workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream));
+}
+
+// Reduced-precision variant of g6d_wino_conv3x3_multi (math_mode 1 = bf16, 2 = fp16 operands, fp32 accumulation and outputs): U16 =
+// the filters transformed AND rounded on the host, [Cin/16][16][Cout][16] 16-bit values in the layout of g6d_wino_conv3x3's U with a
+// chunk of 16 input channels (rows with co & 8 carry their two 16-byte halves swapped); Cin % 16 == 0, Cout % 64 == 0.
+extern "C" int g6d_wino16_conv3x3_multi(const G6dWinoSeg* segs, int nseg, int Cin, const void* U16, const float* bias, int Cout, int relu,
+                                        int math_mode, float* workspace, size_t workspace_bytes, g6d_stream_t stream) {
+  if (!segs || nseg < 1 || nseg > WINO_MAX_SEG || !U16 || Cin <= 0 || (Cin & 15) || Cout <= 0 || (Cout & 63) || !g6d_aligned16(U16) ||
+      (math_mode != 1 && math_mode != 2)) {
+    g6d_set_error("wino16_conv3x3_multi: bad args (1..4 segments, Cin % 16 == 0, Cout % 64 == 0, math_mode 1 or 2)"); return G6D_EINVAL;
+  }
+  WinoArgs a = {};
+  const bool want_full = segs[0].out_full != nullptr, want_pool = segs[0].out_pool != nullptr;
+  if (!want_full && !want_pool) { g6d_set_error("wino16_conv3x3_multi: no output"); return G6D_EINVAL; }
+  const float* in0 = segs[0].in; float* f0 = segs[0].out_full; float* p0 = segs[0].out_pool;
+  for (int k = 0; k < nseg; ++k) {
+    const G6dWinoSeg& g = segs[k];
+    if (!g.in || (g.out_full != nullptr) != want_full || (g.out_pool != nullptr) != want_pool || g.N <= 0 || g.H <= 0 || g.W <= 0 ||
+        (g.ld_in & 3) || g.ld_in < Cin || (want_full && g.ld_full < Cout) || (want_pool && (g.ld_pool < Cout || g.H < 2 || g.W < 2)) ||
+        !g6d_aligned16(g.in)) {
+      g6d_set_error("wino16_conv3x3_multi: bad segment"); return G6D_EINVAL;
+    }
+    if (g.in < in0) in0 = g.in;
+    if (want_full && g.out_full < f0) f0 = g.out_full;
+    if (want_pool && g.out_pool < p0) p0 = g.out_pool;
+  }
+  a.in = in0; a.U = reinterpret_cast<const float*>(U16); a.bias = bias; a.out_full = f0; a.out_pool = p0;
+  a.Cin = Cin; a.Cout = Cout; a.relu = relu; a.D = 1; a.nseg = nseg; a.mm = math_mode;
+  for (int k = 0; k < nseg; ++k) {
+    const G6dWinoSeg& g = segs[k];
+    const long long io = g.in - in0, fo = want_full ? g.out_full - f0 : 0, po = want_pool ? g.out_pool - p0 : 0;
+    if (io + (long long)g.N * g.H * g.W * g.ld_in >= (1ll << 29) || fo + (long long)g.N * g.H * g.W * g.ld_full >= (1ll << 31) ||
+        po + (long long)g.N * g.H * g.W * g.ld_pool >= (1ll << 31)) {
+      g6d_set_error("wino16_conv3x3_multi: segments must lie within 2^29 floats of each other (allocate them from one buffer)"); return G6D_EINVAL;
     }
     a.seg[k] = WinoSeg{0, g.N, g.H, g.W, 0, 0, (int)io, (int)fo, (int)po, g.ld_in, g.ld_full, g.ld_pool};
   }

@@ -59,6 +59,7 @@ SIGNATURES = {
     "g6d_vgg_conv1_pool_nhwc_norm": [_P, _I, _I, _I, _P, _P, _I, _I, _P, _P, _P, _P],
     "g6d_wino_conv3x3": [_P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _P, _I, _P, C.c_size_t, _P],
     "g6d_wino_conv3x3_multi": [_P, _I, _I, _P, _P, _I, _I, _P, C.c_size_t, _P],
+    "g6d_wino16_conv3x3_multi": [_P, _I, _I, _P, _P, _I, _I, _I, _P, C.c_size_t, _P],
     "g6d_l2norm_rows": [_P, _I, _I, _I, _P],
     "g6d_nchw_to_nhwc": [_P, _I, _I, _I, _I, _I, _P, _I, _P],
     "g6d_selector_ref_sums": [_P, _I, _I, _I, _P, _P, _P],

@@ -42,6 +42,21 @@ def winograd_filters(w):
     return U
 
 
+def winograd_filters16(w, dtype):
+    """[Cout,Cin,3,3] -> U16 [Cin/16,16,Cout,16] in `dtype` (torch.float16 / torch.bfloat16) for g6d_wino16_conv3x3_multi: the
+    Winograd-domain filters (G g G^T, computed in fp64) ROUNDED to the operand type, a chunk = 16 input channels, rows with co & 8
+    carry their two 8-channel halves swapped (the same LDS swizzle as winograd_filters)."""
+    co, ci = w.shape[:2]
+    if ci % 16 or co % 64:
+        raise ValueError("winograd_filters16: Cin % 16 == 0 and Cout % 64 == 0 expected")
+    G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64, device=w.device)
+    U = torch.einsum("ai,ocij,bj->ocab", G, w.double(), G)                            # [co,ci,4,4]
+    U = U.reshape(co, ci // 16, 16, 16).permute(1, 3, 0, 2).contiguous()              # [chunk][ab][co][16]
+    swap = (torch.arange(co, device=w.device) & 8) != 0
+    U[:, :, swap] = torch.cat([U[:, :, swap, 8:], U[:, :, swap, :8]], -1)
+    return U.to(dtype).contiguous()
+
+
 def winograd_filters_taps(w_taps, kd=1):
     """[Cout, kd*9, Cin] (the tap-major layout of ParamBank.conv_w) -> [kd*Cin/8, 16, Cout, 8]: one winograd_filters block per
     depth tap, stacked along the chunk axis (the K loop of the kernel walks depth taps outermost)."""
@@ -62,11 +77,40 @@ def winograd_corr_filters(w_taps, k):
     return torch.cat([winograd_filters(w[bi, bj].contiguous()) for bi in range(kb) for bj in range(kb)], 0).contiguous()
 
 
+class TrunkLayer(tuple):
+    """(U, bias) of a Winograd trunk layer as the fp32 kernel takes them; `.u16(dtype)` = the 16-bit filters of the reduced-precision
+    kernel, built from the folded fp32 weights on first use (ops.MATH_MODE 1 / 2)."""
+
+    def __new__(cls, U, b, w):
+        t = super().__new__(cls, (U, b))
+        t._w, t._u16 = w, {}
+        return t
+
+    def u16(self, dtype):
+        if dtype not in self._u16:
+            self._u16[dtype] = winograd_filters16(self._w, dtype)
+        return self._u16[dtype]
+
+
+_LOWP_DTYPE = {1: torch.bfloat16, 2: torch.float16}
+# G6D_LOWP_TRUNK=0: in the reduced-precision mode the trunk stays on the fp32 Winograd kernel (rounds 1-2); default: 16-bit kernel
+_LOWP_TRUNK = os.environ.get("G6D_LOWP_TRUNK", "1") != "0"
+
+
+def _wino_layer(xs, layer, relu=True, full=True, pool=False):
+    """One trunk layer over the segments xs on the kernel of the current math mode: fp32 Winograd, or (ops.MATH_MODE 1 / 2, Cin % 16
+    == 0) the 16-bit one."""
+    mm = ops.MATH_MODE
+    if mm and _LOWP_TRUNK and hasattr(layer, "u16") and xs[0].shape[3] % 16 == 0:
+        return ops.wino16_conv3x3_multi(xs, layer.u16(_LOWP_DTYPE[mm]), layer[1], relu=relu, full=full, pool=pool)
+    return ops.wino_conv3x3_multi(xs, layer[0], layer[1], relu=relu, full=full, pool=pool)
+
+
 def pack_trunk(folded):
     """fold_vgg(...) output -> what the active trunk implementation consumes."""
     if not _OWN_TRUNK:
         return folded
-    return [folded[0]] + [(winograd_filters(w), b) for w, b in folded[1:]]
+    return [folded[0]] + [TrunkLayer(winograd_filters(w), b, w) for w, b in folded[1:]]
 
 
 _IMG_NORM = (tuple(specs.IMAGENET_MEAN), tuple(specs.IMAGENET_STD))
@@ -76,6 +120,8 @@ def vgg_taps_cl(packed, x, taps, norm=None):
     """Own trunk, channels-last: x [n,3,h,w] normalised image (or an image in [0,1] with norm = (mean, std): the first layer
     normalises while it stages its input) -> {'c3': [n,h/4,w/4,256] post-ReLU, 'c5': [n,h/8,w/8,512] post-ReLU,
     'c7_pre': [n,h/16,w/16,512] pre-ReLU, 'p7': max-pool of c7_pre} (only the requested taps + c7_pre)."""
+    if ops.MATH_MODE and _LOWP_TRUNK:
+        return vgg_taps_cl_multi(packed, [x], taps, norm=norm)[0]               # reduced precision: the multi-segment 16-bit kernel
     w0, b0 = packed[0]
     x = ops.vgg_conv1_pool_nhwc(x.contiguous(), w0, b0, norm=norm)              # (normalise +) conv0 + ReLU + pool
     _, x = ops.wino_conv3x3(x, *packed[1], relu=True, full=False, pool=True)    # conv1 + ReLU + pool
@@ -98,13 +144,13 @@ def vgg_taps_cl_multi(packed, xs, taps, norm=None):
     cur = ops.alloc_like_segments([(x.shape[0], x.shape[2] // 2, x.shape[3] // 2, w0.shape[0]) for x in xs], dev)
     for x, o in zip(xs, cur):
         ops.vgg_conv1_pool_nhwc(x.contiguous(), w0, b0, out=o, norm=norm)               # conv0 + ReLU + pool, per size
-    _, cur = ops.wino_conv3x3_multi(cur, *packed[1], relu=True, full=False, pool=True)
-    cur, _ = ops.wino_conv3x3_multi(cur, *packed[2], relu=True)
-    c3, cur = ops.wino_conv3x3_multi(cur, *packed[3], relu=True, full="c3" in taps, pool=True)
-    cur, _ = ops.wino_conv3x3_multi(cur, *packed[4], relu=True)
-    c5, cur = ops.wino_conv3x3_multi(cur, *packed[5], relu=True, full="c5" in taps, pool=True)
-    cur, _ = ops.wino_conv3x3_multi(cur, *packed[6], relu=True)
-    c7, p7 = ops.wino_conv3x3_multi(cur, *packed[7], relu=False, full=True, pool="p7" in taps)
+    _, cur = _wino_layer(cur, packed[1], relu=True, full=False, pool=True)
+    cur, _ = _wino_layer(cur, packed[2], relu=True)
+    c3, cur = _wino_layer(cur, packed[3], relu=True, full="c3" in taps, pool=True)
+    cur, _ = _wino_layer(cur, packed[4], relu=True)
+    c5, cur = _wino_layer(cur, packed[5], relu=True, full="c5" in taps, pool=True)
+    cur, _ = _wino_layer(cur, packed[6], relu=True)
+    c7, p7 = _wino_layer(cur, packed[7], relu=False, full=True, pool="p7" in taps)
     outs = []
     for i in range(len(xs)):
         d = {"c3": c3, "c5": c5, "c7_pre": c7, "p7": p7}

@@ -496,6 +496,42 @@ def wino_conv3x3_multi(xs, U, bias, relu=True, full=True, pool=False):
     return ys, yps
 
 
+def wino16_conv3x3_multi(xs, U16, bias, relu=True, full=True, pool=False):
+    """wino_conv3x3_multi with 16-bit matrix-core operands (MATH_MODE 1 = bf16, 2 = fp16; fp32 activations in and out): U16
+    [Cin/16,16,Cout,16] in torch.bfloat16 / torch.float16 (backbone.winograd_filters16).  xs as wino_conv3x3_multi."""
+    _need_gpu(U16, bias, *xs)
+    if not 1 <= len(xs) <= 4:
+        raise ValueError("wino16_conv3x3_multi: 1..4 segments")
+    mm = {torch.bfloat16: 1, torch.float16: 2}.get(U16.dtype)
+    Cin, Cout = xs[0].shape[3], U16.shape[2]
+    if mm is None or tuple(U16.shape) != (Cin // 16, 16, Cout, 16) or not U16.is_contiguous() or bias.numel() != Cout:
+        raise ValueError(f"wino16_conv3x3_multi: U16 must be contiguous bfloat16 / float16 {(Cin // 16, 16, Cout, 16)}")
+    for x in xs:
+        if x.dim() != 4 or x.dtype != torch.float32 or not x.is_contiguous() or x.shape[3] != Cin:
+            raise ValueError("wino16_conv3x3_multi: segments must be contiguous float32 [N,H,W,Cin]")
+    dev = xs[0].device
+    ys = alloc_like_segments([(x.shape[0], x.shape[1], x.shape[2], Cout) for x in xs], dev) if full else None
+    yps = alloc_like_segments([(x.shape[0], x.shape[1] // 2, x.shape[2] // 2, Cout) for x in xs], dev) if pool else None
+    segs = (_lib.G6dWinoSeg * len(xs))()
+    flops = 0.0
+    for i, x in enumerate(xs):
+        N, H, W, _ = x.shape
+        segs[i] = _lib.G6dWinoSeg(in_=x.data_ptr(), out_full=ys[i].data_ptr() if full else None,
+                                  out_pool=yps[i].data_ptr() if pool else None, N=N, H=H, W=W, ld_in=Cin, ld_full=Cout, ld_pool=Cout)
+        flops += 2.0 * N * H * W * Cout * 9 * Cin
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    ws = workspace(dev)
+    _lib.check(_lib.load().g6d_wino16_conv3x3_multi(segs, len(xs), Cin, _ptr(U16), _ptr(bias), Cout, int(relu), mm, _ptr(ws), ws.numel() * 4,
+                                                   _stream()), "g6d_wino16_conv3x3_multi")
+    if PROFILE is not None:
+        e1.record()
+        sizes = "+".join(f"{x.shape[0]}x{x.shape[1]}x{x.shape[2]}" for x in xs)
+        PROFILE.append((flops / 2.25, e0, e1, f"wino3x3 {'bf16' if mm == 1 else 'fp16'} multi in={sizes}x{Cin} out={Cout}{' full' if full else ''}{' pool' if pool else ''}"))
+    return ys, yps
+
+
 def l2norm_rows(x):
     """In-place F.normalize over the last axis of a channels-last tensor whose rows are dense (ld = C), or of a 2-D row-strided
     view [rows, C] (ld = x.stride(0))."""

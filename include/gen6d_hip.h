@@ -212,6 +212,13 @@ typedef struct G6dWinoSeg {
 int g6d_wino_conv3x3_multi(const G6dWinoSeg* segs, int nseg, int Cin, const float* U, const float* bias, int Cout, int relu,
                            float* workspace, size_t workspace_bytes, g6d_stream_t stream);
 
+/* Reduced-precision variant of g6d_wino_conv3x3_multi (opt-in speed mode as G6dConv.math_mode: 1 = bf16, 2 = fp16 operands, fp32
+ * accumulation, fp32 activations in and out) on v_mfma_f32_32x32x16_{bf16,f16}: a chunk is 16 input channels, U16 = the filters
+ * transformed AND rounded on the host, [Cin/16][16][Cout][16] 16-bit values (32 bytes per (a,b,co) row; rows with co & 8 carry their
+ * two 16-byte halves swapped, as in g6d_wino_conv3x3's U); Cin % 16 == 0, Cout % 64 == 0. */
+int g6d_wino16_conv3x3_multi(const G6dWinoSeg* segs, int nseg, int Cin, const void* U16, const float* bias, int Cout, int relu,
+                             int math_mode, float* workspace, size_t workspace_bytes, g6d_stream_t stream);
+
 /* In-place L2 normalisation over C of channels-last rows x[rows][ld] (F.normalize eps 1e-12, network/selector.py:118,
  * network/refiner.py:69-71,165).  16-byte accesses when x is 16-byte aligned and ld % 4 == 0 (then C % 4 == 0 is required),
  * scalar accesses otherwise (the [qn][7] rows of the regressor output). */

@@ -188,6 +188,34 @@ def wino_conv3x3(x, U, bias, relu=True, full=True, pool=False):
     return (y.contiguous() if full else None), yp
 
 
+def wino16_conv3x3_multi(xs, U16, bias, relu=True, full=True, pool=False):
+    """The 16-bit kernel's arithmetic restated: F(2x2,3x3) with the host-rounded filters U16 and the transformed input ROUNDED to the
+    same type before the products (fp32 transform, exact products of 16-bit values, wide accumulation)."""
+    dt16 = U16.dtype
+    Cout = U16.shape[2]
+    U = U16.double().clone()
+    swap = (torch.arange(Cout) & 8) != 0
+    U[:, :, swap] = torch.cat([U[:, :, swap, 8:], U[:, :, swap, :8]], -1)                # undo the LDS swizzle
+    outs = []
+    BT = torch.tensor([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=torch.float32)
+    AT = torch.tensor([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=torch.float64)
+    for x in xs:
+        N, H, W, Cin = x.shape
+        Ht, Wt = (H + 1) // 2, (W + 1) // 2
+        xp = F.pad(x.float(), (0, 0, 1, 2 * Wt + 1 - W, 1, 2 * Ht + 1 - H))
+        d = xp.unfold(1, 4, 2).unfold(2, 4, 2)                                           # [N,Ht,Wt,C,4,4]
+        V = torch.einsum("ai,ntucij,bj->ntuabc", BT, d, BT).to(dt16).double()            # fp32 transform, rounded operand
+        U4 = U.permute(1, 2, 0, 3).reshape(4, 4, Cout, Cin)                              # [a][b][co][chunk*16 + k]
+        M = torch.einsum("ntuabc,aboc->ntuabo", V, U4)
+        Y = torch.einsum("pa,ntuabo,qb->ntupqo", AT, M, AT)
+        y = Y.permute(0, 1, 3, 2, 4, 5).reshape(N, 2 * Ht, 2 * Wt, Cout)[:, :H, :W] + bias.double()
+        if relu:
+            y = F.relu(y)
+        yp = F.max_pool2d(y.permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1).contiguous() if pool else None
+        outs.append((y.to(x.dtype).contiguous() if full else None, yp.to(x.dtype) if pool else None))
+    return ([o[0] for o in outs] if full else None), ([o[1] for o in outs] if pool else None)
+
+
 def l2norm_rows(x):
     x.copy_(F.normalize(x, dim=-1))
     return x

@@ -111,3 +111,52 @@ def test_detector_headline_lowp(golden, mode):
     record("test_detector_headline_lowp", f"{mode} 480x640x32 scores vs reference golden", err, 5e-2, note="relative to range")
     assert np.array_equal(out["que_select_id"].cpu().numpy(), g["que_select_id"])
     assert err <= 5e-2
+
+
+WINO16_CASES = [
+    # segment sizes (N, H, W), Cin, Cout, relu, full, pool
+    ([(1, 44, 58), (1, 30, 40), (1, 22, 30), (1, 16, 20)], 512, 512, False, True, True),     # detector pyramid, 1/16 level
+    ([(2, 22, 30), (3, 16, 20)], 64, 128, True, False, True),                                # pooled output only, batches
+    ([(2, 9, 7), (1, 8, 8), (3, 5, 13)], 128, 64, True, True, False),                        # ragged sizes
+    ([(4, 64, 64)], 64, 128, True, False, True),                                             # selector / refiner first Winograd layer
+    ([(7, 8, 8)], 512, 512, False, True, False),                                             # small maps: chunk split
+]
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+@pytest.mark.parametrize("sizes,Cin,Cout,relu,full,pool", WINO16_CASES)
+def test_wino16_conv3x3_multi(mode, sizes, Cin, Cout, relu, full, pool):
+    """The trunk's 16-bit Winograd kernel (wino16_conv3x3_kernel: v_mfma_f32_32x32x16_{bf16,f16}, host-rounded filters) against
+    (a) the restatement of its own arithmetic (tests/ref_ops.py: fp32 input transform rounded to the operand type, exact products,
+    wide accumulation) — tight, and (b) the float64 convolution with the operand-rounding bound of the type."""
+    import ref_ops
+    from gen6d_amd import ops
+    from gen6d_amd.network.backbone import winograd_filters16
+    dt = {"bf16": torch.bfloat16, "fp16": torch.float16}[mode]
+    g = torch.Generator().manual_seed(300 + Cin + Cout)
+    w = _rand(g, Cout, Cin, 3, 3, scale=(2.0 / (9 * Cin)) ** 0.5 * 2)
+    b = _rand(g, Cout, scale=0.2)
+    U16 = winograd_filters16(w, dt)
+    xs_cpu = [F.relu(_rand(g, n, h, ww, Cin)) for n, h, ww in sizes]
+    xs = ops.alloc_like_segments([tuple(x.shape) for x in xs_cpu], torch.device("cuda"))
+    for d_, x in zip(xs, xs_cpu):
+        d_.copy_(x)
+    for rep in range(2):                                   # twice: split counters re-armed
+        ys, yps = ops.wino16_conv3x3_multi(xs, U16.cuda(), b.cuda(), relu=relu, full=full, pool=pool)
+        rys, ryps = ref_ops.wino16_conv3x3_multi([x.double() for x in xs_cpu], U16, b, relu=relu, full=full, pool=pool)
+        for i, x in enumerate(xs_cpu):
+            ref = F.conv2d(x.double().permute(0, 3, 1, 2), w.double(), b.double(), padding=1)
+            if relu:
+                ref = F.relu(ref)
+            refp = F.max_pool2d(ref, 2, 2).permute(0, 2, 3, 1)
+            ref = ref.permute(0, 2, 3, 1)
+            rng = ref.abs().max().item()
+            if full:
+                e_own = (ys[i].cpu().double() - rys[i].double()).abs().max().item() / rng
+                e_ref = (ys[i].cpu().double() - ref).abs().max().item() / rng
+                assert e_own <= 3e-4 and e_ref <= TOL[mode], (i, e_own, e_ref)
+            if pool:
+                e_own = (yps[i].cpu().double() - ryps[i].double()).abs().max().item() / rng
+                e_ref = (yps[i].cpu().double() - refp).abs().max().item() / rng
+                assert e_own <= 3e-4 and e_ref <= TOL[mode], (i, e_own, e_ref)
+    record("test_wino16_conv3x3_multi", f"{mode} {sizes} {Cin}->{Cout}", e_ref, TOL[mode], note="relative to range")
