@@ -33,6 +33,9 @@ def main():
     ]
     print(f"# batch of {B} quer{'y' if B == 1 else 'ies'} per launch; us columns are per launch, totals also per query")
     ops.SERIAL = True
+    if os.environ.get("LOWP"):                          # LOWP=fp16 / bf16: the reduced-precision mode's table
+        ops.MATH_MODE = {"bf16": 1, "fp16": 2}[os.environ["LOWP"]]
+        print(f"# reduced-precision matrix-core mode: {os.environ['LOWP']}")
     reps = 5
     with torch.no_grad():
         for name, fn in stages:
