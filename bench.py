@@ -195,6 +195,14 @@ def main():
     torch.cuda.synchronize()
     parallel.barrier()
     torch.cuda.synchronize()
+    coll_log = None
+    if shard_refs:
+        # per-collective log of ONE extra query (outside the timed region: logging synchronises the stream around every collective)
+        parallel.COLLECTIVE_LOG = []
+        step(0)
+        torch.cuda.synchronize()
+        coll_log, parallel.COLLECTIVE_LOG = parallel.COLLECTIVE_LOG, None
+        parallel.barrier()
     if not use_graph:
         ops.PROFILE, ops.PROFILE_HBM = [], {}
     ops.marker(1)
@@ -325,6 +333,17 @@ def main():
     result["hbm_kernels"] = hbm
     result["stages_ms"] = stages
     result["ranks_seen"], result["backend"] = ranks_seen, parallel.backend_name()
+    if coll_log is not None:
+        kinds = {}
+        for kind, nb, sec in coll_log:
+            k = kinds.setdefault(kind, {"count": 0, "bytes": 0, "us": 0.0})
+            k["count"] += 1; k["bytes"] += nb; k["us"] += sec * 1e6
+        result["collectives_per_query"] = {
+            "total": len(coll_log), "total_us": sum(c[2] for c in coll_log) * 1e6,
+            "by_kind": {k: {"count": v["count"], "mean_bytes": v["bytes"] / v["count"], "mean_us": v["us"] / v["count"]} for k, v in kinds.items()},
+            "how": "one extra query with a stream synchronisation around every data-path collective (rank 0's view); "
+                   + ("RCCL: enqueued on device tensors, no host staging" if parallel.backend_name() == "nccl" else
+                      "gloo: every collective is staged through host memory (ranks share one GPU on this lease; RCCL refuses that)")}
     result["build_s"] = {"value": build_s, "what": "TensorPipeline.build: detector reference filters + selector reference cache "
                                                    "(trunk over 32 + 320 crops, R1/R2 sums, viewpoint embedding), incl. first-use "
                                                    "library initialisation; reference: 0.57 s + 9.8 s on 8 CPU threads (BASELINE.md §2)"}

@@ -81,23 +81,51 @@ def gather_rows(local_rows, n_items):
     return torch.cat(out, 0).to(out_device)
 
 
+# When set to a list, every data-path collective appends (kind, bytes, seconds): `bench.py --shard-refs` reports the count per query
+# and the mean time per collective.  Host wall time around the call: with RCCL the call only ENQUEUES on the stream (no host staging,
+# no synchronisation), so a stream synchronisation brackets the call while logging; under gloo the tensor goes through the host.
+COLLECTIVE_LOG = None
+
+
+def _timed(kind, t, fn):
+    if COLLECTIVE_LOG is None:
+        return fn()
+    import time
+    if t.is_cuda:
+        torch.cuda.synchronize(t.device)
+    t0 = time.perf_counter()
+    out = fn()
+    if t.is_cuda:
+        torch.cuda.synchronize(t.device)
+    COLLECTIVE_LOG.append((kind, t.numel() * t.element_size(), time.perf_counter() - t0))
+    return out
+
+
 def all_reduce_(t, op="sum", group=None):
-    """In-place all-reduce of a tensor that may live on the GPU (RCCL) or must be staged through the host (gloo)."""
+    """In-place all-reduce of a tensor that may live on the GPU (RCCL: issued on the device tensor, stream-ordered, no host staging)
+    or must be staged through the host (gloo)."""
     if not dist.is_initialized():
         return t
     rop = dist.ReduceOp.SUM if op == "sum" else dist.ReduceOp.MAX
     dev = _coll_device(t.device)
-    if str(dev) == "cpu" and t.is_cuda:
-        h = t.cpu()
-        dist.all_reduce(h, op=rop, group=group)
-        t.copy_(h)
-    else:
-        dist.all_reduce(t, op=rop, group=group)
-    return t
+
+    def run():
+        if str(dev) == "cpu" and t.is_cuda:
+            h = t.cpu()
+            dist.all_reduce(h, op=rop, group=group)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=rop, group=group)
+        return t
+    return _timed("all_reduce_" + op, t, run)
 
 
 def all_gather_ragged_rows(rows, n_total, world, group=None):
     """[n_local, F] per rank (contiguous shard_range slices) -> [n_total, F] in global order."""
+    return _timed("all_gather_rows", rows, lambda: _all_gather_ragged_rows(rows, n_total, world, group))
+
+
+def _all_gather_ragged_rows(rows, n_total, world, group=None):
     out_device = rows.device
     rows = rows.to(_coll_device(rows.device))
     cap = (n_total + world - 1) // world
