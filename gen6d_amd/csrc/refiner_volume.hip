@@ -8,7 +8,6 @@
 // The rfn+1 projections of a voxel are spread over the lanes of its half-wave (lane v = view v) and exchanged with
 // shuffles: done redundantly by all 32 lanes they were ~600 VALU instructions per voxel, as long as the gathers.
 #include "g6d_common.h"
-#include <stdlib.h>
 
 #define MAX_RFN 8
 
@@ -80,7 +79,7 @@ struct VolViews { const float* projs; const float* ref_Ks; const float* ref_pose
 __global__ void __launch_bounds__(256, 4) refiner_volume_kernel(const float* __restrict__ feats, const VolViews vw,
                                                              const float* __restrict__ lin, int rfn, int fh, int fw,
                                                              int C, float h_in, float w_in, int sn,
-                                                             float* __restrict__ mean_in, float* __restrict__ stdv, int brick) {
+                                                             float* __restrict__ mean_in, float* __restrict__ stdv) {
   // blockIdx.y = query of the batch (g6d_refiner_volume_kp): its views, cameras and volumes follow those of the previous query
   const int bq = blockIdx.y;
   const float* __restrict__ rot = vw.rot + bq * 12;
@@ -92,15 +91,7 @@ __global__ void __launch_bounds__(256, 4) refiner_volume_kernel(const float* __r
   const int l32 = threadIdx.x & 31;
   const bool live = half < nvox;                                   // (whole half-waves; keep them for the shuffles)
   if (!live) half = nvox - 1;
-  int k = half % sn, j = (half / sn) % sn, i = half / (sn * sn);
-  if (brick && !(sn & 1)) {
-    // the 8 voxels of a block form a 2x2x2 brick instead of a run of 8 along k: their footprints in EVERY view overlap (neighbouring
-    // voxels share bilinear taps), so most of the block's 224 row gathers hit lines another half-wave of the block just brought in
-    const int hb = sn >> 1, b = half >> 3, w = half & 7;
-    const int bk = b % hb, bj = (b / hb) % hb, bi = b / (hb * hb);
-    i = 2 * bi + (w >> 2); j = 2 * bj + ((w >> 1) & 1); k = 2 * bk + (w & 1);
-    half = (i * sn + j) * sn + k;
-  }
+  const int k = half % sn, j = (half / sn) % sn, i = half / (sn * sn);
   const float g0 = lin[i], g1 = lin[j], g2 = lin[k];
   const float vx = g0 * rot[0] + g1 * rot[rl] + g2 * rot[2 * rl];
   const float vy = g0 * rot[1] + g1 * rot[rl + 1] + g2 * rot[2 * rl + 1];
@@ -144,12 +135,6 @@ __global__ void __launch_bounds__(256, 4) refiner_volume_kernel(const float* __r
   }
 }
 
-// G6D_VOL_BRICK=0: voxels of a block along k (rounds 1-2); default: 2x2x2 bricks
-int vol_brick() {
-  static const int on = []() { const char* e = getenv("G6D_VOL_BRICK"); return (e && e[0] == '0') ? 0 : 1; }();
-  return on;
-}
-
 }  // namespace
 
 extern "C" int g6d_refiner_volume(const float* feats, const float* projs, const float* rot_in,
@@ -163,7 +148,7 @@ extern "C" int g6d_refiner_volume(const float* feats, const float* projs, const 
   const VolViews vw = {projs, nullptr, nullptr, nullptr, nullptr, rot_in, 3};
   hipLaunchKernelGGL(refiner_volume_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), feats, vw, lin, rfn, fh, fw, C, (float)h_in, (float)w_in, sn,
-                     mean_in, stdv, vol_brick());
+                     mean_in, stdv);
   return g6d_check_launch("refiner_volume");
 }
 
@@ -181,6 +166,6 @@ extern "C" int g6d_refiner_volume_kp(const float* feats, const float* ref_Ks, co
   const VolViews vw = {nullptr, ref_Ks, ref_poses, K_in, pose_in, pose_in, 4};
   hipLaunchKernelGGL(refiner_volume_kernel, dim3((unsigned)((threads + 255) / 256), batch), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), feats, vw, lin, rfn, fh, fw, C, (float)h_in, (float)w_in, sn,
-                     mean_in, stdv, vol_brick());
+                     mean_in, stdv);
   return g6d_check_launch("refiner_volume_kp");
 }
