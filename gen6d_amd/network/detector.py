@@ -108,6 +108,14 @@ class Detector(ParamBank):
         maps = [[None] * 3 for _ in feats]
         for l, (wref, k) in enumerate(zip(self.ref_center_feats, self.ref_ksize)):
             xs = [f[l] for f in feats]
+            # one launch over all scales addresses the maps with 32-bit offsets from a common base: maps that do not come out of one
+            # buffer (the library trunk of G6D_OWN_TRUNK=0 allocates every scale on its own) are gathered into one first
+            ptrs = [x.data_ptr() for x in xs]
+            if max(ptrs) - min(ptrs) >= (1 << 31) or not all(x.is_contiguous() for x in xs):
+                seg = ops.alloc_like_segments([tuple(x.shape) for x in xs], dev)
+                for d_, x in zip(seg, xs):
+                    d_.copy_(x)
+                xs = seg
             if k == 15 and self.ref_wino15 is not None and ops.MATH_MODE == 0 and len(xs) <= 4:
                 outs = ops.alloc_like_segments([(qn, 1, x.shape[2], x.shape[3], rfn) for x in xs], dev)
                 ops.corr2d_wino_multi([x.contiguous() for x in xs], self.ref_wino15, outs, 5)
