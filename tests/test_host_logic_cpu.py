@@ -127,3 +127,36 @@ def test_detector_winograd_correlation_host_path(golden):
     for k in ("scores", "select_pr_offset", "select_pr_scale"):
         np.testing.assert_allclose(out[k].numpy(), g[k], rtol=1e-3, atol=1e-3 * np.abs(g[k]).max())
     assert np.array_equal(out["que_select_id"].numpy(), g["que_select_id"])
+
+
+def test_more_queries_than_one_launch_batch():
+    """qn = 9 > MAX_BATCH (8): the networks cut the call into chunks of <= 8 queries that share a set of launches each; the [qn, ...]
+    results are those of the single-query calls (selector and refiner forward; CPU emulation of the ops)."""
+    an, rfn = 5, 4
+    sel = name2network["selector"]({"name": "t", "selector_angle_num": an}).eval()
+    sel.load_state_dict(synth.synth_state_dict("selector", an=an))
+    case = synth.selector_case(rfn, an)
+    ques = synth.imgs_to_tensor(synth.synth_images(9, 128, 128, seed=31))
+    with torch.no_grad():
+        sel.extract_ref_feats(case["ref_imgs"], case["ref_poses"], case["object_center"], case["object_vert"])
+        logits, angles = sel.compute_view_point_feats(ques)
+        assert logits.shape == (9, rfn) and angles.shape == (9, rfn)
+        for j in (0, 7, 8):                                          # last of the first chunk, the lone query of the second
+            l1, a1 = sel.compute_view_point_feats(ques[j:j + 1])
+            np.testing.assert_allclose(logits[j].numpy(), l1[0].numpy(), atol=1e-4)
+            np.testing.assert_allclose(angles[j].numpy(), a1[0].numpy(), atol=1e-4)
+    ref = name2network["refiner"]({"name": "t"}).eval()
+    ref.load_state_dict(synth.synth_state_dict("refiner"))
+    c = synth.refiner_case()
+    n = 3
+    data = {"que_imgs_info": {"imgs": synth.imgs_to_tensor(synth.synth_images(n, 128, 128, seed=41)), "Ks_in": c["Ks_in"].expand(n, 3, 3),
+                              "poses_in": torch.stack([torch.from_numpy(synth.perturb_pose(c["poses_in"][0].numpy(), 1.0 * i, 0.01 * i)) for i in range(n)])},
+            "ref_imgs_info": {"imgs": c["ref_imgs"].expand(n, *c["ref_imgs"].shape[1:]), "Ks": c["ref_Ks"].expand(n, 6, 3, 3),
+                              "poses": c["ref_poses"].expand(n, 6, 3, 4)}, "inference": True}
+    with torch.no_grad():
+        out = ref(data)
+        assert out["rotation"].shape == (n, 4) and out["offset"].shape == (n, 2) and out["scale"].shape == (n, 1)
+        one = ref({"que_imgs_info": {k: v[1:2] for k, v in data["que_imgs_info"].items()},
+                   "ref_imgs_info": {k: v[1:2] for k, v in data["ref_imgs_info"].items()}, "inference": True})
+    for k in ("rotation", "offset", "scale"):
+        np.testing.assert_allclose(out[k][1].numpy(), one[k][0].numpy(), atol=2e-4)
