@@ -438,15 +438,19 @@ def main():
         qi = [imgs[i % 8] for i in range(n_c + lanes)]
         qk = [Ks[i % 8] for i in range(n_c + lanes)]
         chain = est.device_chain()
-        clanes = min(lanes, 3)        # the chain measured best with three queries in flight (141 vs 127 images/s with four)
-        chain.predict_many(qi[:clanes], qk[:clanes], clanes)              # capture + warm-up
+        clanes = min(lanes, 3)
+        cb = min(B, 4)                # queries per captured chain graph (they share every launch)
+        n_c = max(n_c, 6 * cb * clanes)
+        qi = [imgs[i % 8] for i in range(n_c)]
+        qk = [Ks[i % 8] for i in range(n_c)]
+        chain.predict_many(qi[:cb * clanes], qk[:cb * clanes], clanes, batch=cb)              # capture + warm-up
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        res = chain.predict_many(qi[:n_c], qk[:n_c], clanes)
+        res = chain.predict_many(qi[:n_c], qk[:n_c], clanes, batch=cb)
         cdt = time.perf_counter() - t1
         _, inter_h = est.predict(imgs[0], Ks[0])                      # the host-driven path (numpy pose algebra, 5+ syncs per query)
         _, inter_d = est.predict_device(imgs[0], Ks[0])               # the same query through the eager device chain
-        result["chained"] = {"value": n_c / cdt, "unit": "images/s", "ms_per_query": cdt / n_c * 1e3, "queries": n_c, "lanes": clanes,
+        result["chained"] = {"value": n_c / cdt, "unit": "images/s", "ms_per_query": cdt / n_c * 1e3, "queries": n_c, "lanes": clanes, "batch": cb,
                              "database": "procedural sphere, 66 reference views 480x640, 64/32 selected; build incl. rendering "
                                          f"{cbuild:.1f} s", "finite": bool(all(np.isfinite(p).all() for p, _ in res)),
                              "vs_host_driven_predict": {

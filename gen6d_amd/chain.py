@@ -106,69 +106,113 @@ class DeviceChain:
                 poses.append(pose)
         return {"pose": pose, "det": det5, "sel": sel, "logits": logits[0], "refine_poses": poses, "crop": crop}
 
+    # ------------------------------------------------------------------ a batch of queries, no host synchronisation
+    def query_batch(self, que_imgs, que_Ks):
+        """que_imgs uint8 [B,H,W,3], que_Ks float32 [B,3,3] on the device (B <= 8) -> dict of device tensors: 'pose' [B,3,4], 'det'
+        [B,5], 'sel' [B,2], 'logits' [B,rfn], 'refine_poses' (list of [B,3,4]).  The B queries share every launch (round 3): the
+        networks' batched paths, one launch of every chain kernel (blockIdx = query), one warp launch per stage for all crops —
+        the estimator-level counterpart of `TensorPipeline.query` with the data flow between the stages real."""
+        est, size = self.est, self.size
+        astep = est.refiner.angle_step() if est.refiner is not None else 0.0
+        B = que_imgs.shape[0]
+        with torch.no_grad():
+            ar = torch.arange(B, dtype=torch.int32, device=self.dev)
+            K9 = que_Ks.reshape(B, 9).contiguous()
+            x = que_imgs.permute(0, 3, 1, 2).float().div_(255)
+            det = est.detector.detect_impl(x.contiguous())
+            det5 = torch.cat([det["positions"], det["scales"][:, None], det["que_select_id"].float()], 1).contiguous()
+            crop = ops.warp_batch(que_imgs, None, ar, ops.chain_crop_from_detection(det5, size), size, size)
+            logits, angles = est.selector.compute_view_point_feats(crop)
+            pose, sel = ops.chain_pose_from_selection(det5, logits.contiguous(), angles.contiguous(), self.ref_poses, self.ref_Ks, K9,
+                                                      self.center)
+            poses = [pose]
+            R, rs = self.REF_NUM, self.refine_size
+            for _ in range(self.refine_iter):
+                prep = ops.chain_refine_prepare(pose.reshape(B, 12), K9, self.norm, rs, self.MARGIN, self.sub_poses, self.sub_Ks, R,
+                                                angle_step=astep)
+                geo, idx = prep[0], prep[1]
+                hinv = geo[:, 33 + 21 * R:].reshape(B, 1 + R, 9)
+                que_crops = ops.warp_batch(que_imgs, None, ar, hinv[:, 0].contiguous(), rs, rs)
+                ref_crops = ops.warp_batch(self.stack, None, idx.reshape(-1), hinv[:, 1:].reshape(B * R, 9).contiguous(), rs, rs)
+                rot, off, scl = est.refiner._step(que_crops, geo[:, 0:9].reshape(B, 3, 3), geo[:, 9:21].reshape(B, 3, 4),
+                                                  ref_crops.view(B, R, 3, rs, rs), geo[:, 33:33 + 9 * R].reshape(B, R, 3, 3),
+                                                  geo[:, 33 + 9 * R:33 + 21 * R].reshape(B, R, 3, 4))
+                pose = ops.chain_refine_update(rot.contiguous(), off.contiguous(), scl.contiguous(), geo, self.norm)
+                poses.append(pose)
+        return {"pose": pose, "det": det5, "sel": sel, "logits": logits, "refine_poses": poses, "crop": crop}
+
     # ------------------------------------------------------------------ hipGraph lanes
-    def capture(self, img_shape, lanes=3, warmup=2):
-        """One captured copy of the whole chain per lane (own static input / output buffers, shared read-only reference state)."""
+    def capture(self, img_shape, lanes=3, warmup=2, batch=1):
+        """One captured copy of the whole chain per lane (own static input / output buffers, shared read-only reference state); a
+        lane's graph processes `batch` queries that share every launch."""
         d = self.dev
         old_serial, ops.SERIAL = ops.SERIAL, True          # whole queries in flight; no intra-query stream forks (DESIGN.md §5)
         try:
-            self._lanes = []
+            self._lanes, self._batch = [], int(batch)
             for _ in range(lanes):
-                g_img = torch.zeros(img_shape, dtype=torch.uint8, device=d)
-                g_K = torch.eye(3, dtype=torch.float32, device=d)
-                g_K[0, 0] = g_K[1, 1] = 500.0; g_K[0, 2] = img_shape[1] / 2; g_K[1, 2] = img_shape[0] / 2
+                g_img = torch.zeros((batch,) + tuple(img_shape), dtype=torch.uint8, device=d)
+                g_K = torch.eye(3, dtype=torch.float32, device=d).repeat(batch, 1, 1)
+                g_K[:, 0, 0] = g_K[:, 1, 1] = 500.0; g_K[:, 0, 2] = img_shape[1] / 2; g_K[:, 1, 2] = img_shape[0] / 2
                 stream = torch.cuda.Stream(device=d)
                 stream.wait_stream(torch.cuda.current_stream(d))
                 with torch.cuda.stream(stream):
                     for _ in range(warmup):
-                        self.query(g_img, g_K)
+                        self.query_batch(g_img, g_K)
                 torch.cuda.synchronize(d)
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph, stream=stream):
-                    out = self.query(g_img, g_K)
-                keep = torch.cat([out["pose"].reshape(12), out["det"], out["sel"]])
-                self._lanes.append((graph, stream, g_img, g_K, out, keep))
+                    out = self.query_batch(g_img, g_K)
+                self._lanes.append((graph, stream, g_img, g_K, out, None))
             torch.cuda.synchronize(d)
         finally:
             ops.SERIAL = old_serial
         return self
 
     def enqueue(self, lane, que_img, que_K):
-        """Replay lane `lane` on its stream for this query; returns (row [19] = pose(12) | det(5) | sel(2), stream).  The caller
-        synchronises (event on the stream) before reusing the lane."""
+        """Replay lane `lane` on its stream: que_img uint8 [H,W,3] (batch 1) or [B,H,W,3] with B <= the captured batch (the rest of the
+        lane's slots keep their previous content and are ignored), que_K [3,3] / [B,3,3]; returns (rows [B,19] = pose(12) | det(5) |
+        sel(2) — [19] for a single image —, stream).  The caller synchronises (event on the stream) before reusing the lane."""
         graph, stream, g_img, g_K, out, _ = self._lanes[lane]
+        single = que_img.dim() == 3
+        if single:
+            que_img, que_K = que_img[None], que_K[None]
+        n = que_img.shape[0]
         stream.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(stream):
-            g_img.copy_(que_img, non_blocking=True)
-            g_K.copy_(que_K, non_blocking=True)
+            g_img[:n].copy_(que_img, non_blocking=True)
+            g_K[:n].copy_(que_K, non_blocking=True)
             # the sources were allocated on the caller's stream and are consumed on the lane's: tell the caching allocator, or it
             # may hand their blocks to the next query's upload while this copy is still pending (ADVICE r02)
             for t in (que_img, que_K):
                 if t.is_cuda:
                     t.record_stream(stream)
             graph.replay()
-            row = torch.cat([out["pose"].reshape(12), out["det"], out["sel"]])
-        return row, stream
+            rows = torch.cat([out["pose"].reshape(-1, 12), out["det"], out["sel"]], 1)[:n]
+        return (rows[0] if single else rows), stream
 
-    def predict_many(self, que_imgs, que_Ks, lanes=3):
+    def predict_many(self, que_imgs, que_Ks, lanes=3, batch=1):
         """Queries [(H,W,3) uint8 numpy or device tensors], intrinsics [3,3] -> list of (pose [3,4] float32 numpy, inter dict).
-        Several queries are kept in flight (one captured graph per lane); ONE host synchronisation at the end."""
+        `lanes` captured graphs of `batch` queries each are kept in flight; ONE host synchronisation at the end."""
         imgs = [q if torch.is_tensor(q) else torch.from_numpy(np.ascontiguousarray(q)) for q in que_imgs]
-        if self._lanes is None or len(self._lanes) != lanes or tuple(self._lanes[0][2].shape) != tuple(imgs[0].shape):
-            self.capture(tuple(imgs[0].shape), lanes)
+        batch = max(1, min(8, int(batch)))
+        if (self._lanes is None or len(self._lanes) != lanes or getattr(self, "_batch", 1) != batch or
+                tuple(self._lanes[0][2].shape[1:]) != tuple(imgs[0].shape)):
+            self.capture(tuple(imgs[0].shape), lanes, batch=batch)
         busy, rows = [None] * lanes, []
-        for i, (img, K) in enumerate(zip(imgs, que_Ks)):
-            lane = i % lanes
+        for bi, i0 in enumerate(range(0, len(imgs), batch)):
+            lane = bi % lanes
             if busy[lane] is not None:
                 busy[lane].synchronize()
-            K_t = K if torch.is_tensor(K) else torch.from_numpy(np.ascontiguousarray(K, dtype=np.float32))
-            row, stream = self.enqueue(lane, img.to(self.dev, non_blocking=True), K_t.to(self.dev, non_blocking=True))
+            ib = torch.stack([im.to(self.dev, non_blocking=True) for im in imgs[i0:i0 + batch]], 0)
+            kb = torch.stack([(K if torch.is_tensor(K) else torch.from_numpy(np.ascontiguousarray(K, dtype=np.float32))).to(self.dev, non_blocking=True)
+                              for K in que_Ks[i0:i0 + batch]], 0)
+            r, stream = self.enqueue(lane, ib, kb)
             ev = torch.cuda.Event(); ev.record(stream)
             busy[lane] = ev
-            rows.append(row)
+            rows.append(r)
         torch.cuda.synchronize(self.dev)
         out = []
-        for r in torch.stack(rows, 0).cpu().numpy():
+        for r in torch.cat(rows, 0).cpu().numpy():
             out.append((r[:12].reshape(3, 4).astype(np.float32),
                         {"det_position": r[12:14], "det_scale_r2q": float(r[14]), "sel_ref_idx": int(r[17]), "sel_angle_r2q": float(r[18])}))
         return out

@@ -18,8 +18,11 @@ __device__ __forceinline__ void st_m3(float* p, const M3& a) { for (int i = 0; i
 __device__ __forceinline__ void st_p34(float* p, const P34& a) { for (int i = 0; i < 12; ++i) p[i] = (float)a.m[i]; }
 
 // detection -> inverse crop transform (estimator.py:184 transformation_crop(que_img, position, 1/scale_r2q, 0, size))
+// Every chain kernel takes a batch of queries: blockIdx.x = query; per-query operands and results are dense arrays with the query as
+// leading axis, the reference state (poses, intrinsics, centre, normalisation) is shared.
 __global__ void crop_from_detection_kernel(const float* __restrict__ det, float size, float* __restrict__ hinv) {
   if (threadIdx.x != 0) return;
+  det += 5 * blockIdx.x; hinv += 9 * blockIdx.x;
   st_m3(hinv, inv3(crop_transform(det[0], det[1], 1.0 / (double)det[2], 0.0, size)));
 }
 
@@ -30,6 +33,8 @@ __global__ void pose_from_selection_kernel(const float* __restrict__ det, const 
                                            const float* __restrict__ center, float* __restrict__ pose_out,
                                            float* __restrict__ sel_out) {
   if (threadIdx.x != 0) return;
+  const int q = blockIdx.x;
+  det += 5 * q; logits += (size_t)rfn * q; angles += (size_t)rfn * q; que_K += 9 * q; pose_out += 12 * q; sel_out += 2 * q;
   int best = 0;
   for (int r = 1; r < rfn; ++r) if (logits[r] > logits[best]) best = r;
   const V3 c{center[0], center[1], center[2]};
@@ -49,6 +54,11 @@ __global__ void __launch_bounds__(128) refine_prepare_kernel(const float* __rest
   __shared__ RefinePrep g;
   __shared__ int sel[8];
   const int t = threadIdx.x;
+  {
+    const int q = blockIdx.x;                                    // query of the batch
+    pose_in += 12 * q; que_K += 9 * q; geo += (size_t)(42 + 30 * ref_num) * q; ref_idx += ref_num * q;
+    if (ref_bucket) ref_bucket += ref_num * q;
+  }
   const V3 noff{norm[1], norm[2], norm[3]};
   if (t == 0) {
     g = refine_prepare(ld_p34(pose_in), ld_m3(que_K), norm[0], noff, size, margin);
@@ -86,8 +96,10 @@ __global__ void __launch_bounds__(128) refine_prepare_kernel(const float* __rest
 
 // refiner outputs -> refined pose (refiner.py:327-341)
 __global__ void refine_update_kernel(const float* __restrict__ rot, const float* __restrict__ off, const float* __restrict__ scl_,
-                                     const float* __restrict__ geo, const float* __restrict__ norm, float* __restrict__ pose_out) {
+                                     const float* __restrict__ geo, int geo_stride, const float* __restrict__ norm,
+                                     float* __restrict__ pose_out) {
   if (threadIdx.x != 0) return;
+  rot += 4 * blockIdx.x; off += 2 * blockIdx.x; scl_ += blockIdx.x; geo += (size_t)geo_stride * blockIdx.x; pose_out += 12 * blockIdx.x;
   RefinePrep g;
   g.K_warp = ld_m3(geo); g.pose_warp = ld_p34(geo + 9); g.pose_rect = ld_p34(geo + 21);
   const double q[4] = {rot[0], rot[1], rot[2], rot[3]};
@@ -131,39 +143,39 @@ __global__ void __launch_bounds__(256) warp_batch_kernel(const unsigned char* __
 
 #define CHAIN_STREAM(s) reinterpret_cast<hipStream_t>(s)
 
-extern "C" int g6d_chain_crop_from_detection(const float* det, float size, float* hinv, g6d_stream_t stream) {
-  if (!det || !hinv || size <= 0) { g6d_set_error("chain_crop_from_detection: bad args"); return G6D_EINVAL; }
-  hipLaunchKernelGGL(crop_from_detection_kernel, dim3(1), dim3(64), 0, CHAIN_STREAM(stream), det, size, hinv);
+extern "C" int g6d_chain_crop_from_detection(const float* det, float size, float* hinv, int batch, g6d_stream_t stream) {
+  if (!det || !hinv || size <= 0 || batch < 1) { g6d_set_error("chain_crop_from_detection: bad args"); return G6D_EINVAL; }
+  hipLaunchKernelGGL(crop_from_detection_kernel, dim3(batch), dim3(64), 0, CHAIN_STREAM(stream), det, size, hinv);
   return g6d_check_launch("chain_crop_from_detection");
 }
 
 extern "C" int g6d_chain_pose_from_selection(const float* det, const float* logits, const float* angles, int rfn,
                                              const float* ref_poses, const float* ref_Ks, const float* que_K, const float* center,
-                                             float* pose_out, float* sel_out, g6d_stream_t stream) {
-  if (!det || !logits || !angles || rfn <= 0 || !ref_poses || !ref_Ks || !que_K || !center || !pose_out || !sel_out) {
+                                             float* pose_out, float* sel_out, int batch, g6d_stream_t stream) {
+  if (!det || !logits || !angles || rfn <= 0 || !ref_poses || !ref_Ks || !que_K || !center || !pose_out || !sel_out || batch < 1) {
     g6d_set_error("chain_pose_from_selection: bad args"); return G6D_EINVAL;
   }
-  hipLaunchKernelGGL(pose_from_selection_kernel, dim3(1), dim3(64), 0, CHAIN_STREAM(stream), det, logits, angles, rfn, ref_poses,
+  hipLaunchKernelGGL(pose_from_selection_kernel, dim3(batch), dim3(64), 0, CHAIN_STREAM(stream), det, logits, angles, rfn, ref_poses,
                      ref_Ks, que_K, center, pose_out, sel_out);
   return g6d_check_launch("chain_pose_from_selection");
 }
 
 extern "C" int g6d_chain_refine_prepare(const float* pose_in, const float* que_K, const float* norm, float size, float margin,
                                         const float* sub_poses, const float* sub_Ks, int n_sub, int ref_num, float* geo,
-                                        int* ref_idx, float angle_step, int* ref_bucket, g6d_stream_t stream) {
+                                        int* ref_idx, float angle_step, int* ref_bucket, int batch, g6d_stream_t stream) {
   if (!pose_in || !que_K || !norm || size <= 0 || !sub_poses || !sub_Ks || n_sub <= 0 || n_sub > 128 || ref_num <= 0 ||
-      ref_num > 8 || ref_num > n_sub || !geo || !ref_idx) {
+      ref_num > 8 || ref_num > n_sub || !geo || !ref_idx || batch < 1) {
     g6d_set_error("chain_refine_prepare: bad args (n_sub <= 128, ref_num <= 8)"); return G6D_EINVAL;
   }
-  hipLaunchKernelGGL(refine_prepare_kernel, dim3(1), dim3(128), 0, CHAIN_STREAM(stream), pose_in, que_K, norm, size, margin, sub_poses,
+  hipLaunchKernelGGL(refine_prepare_kernel, dim3(batch), dim3(128), 0, CHAIN_STREAM(stream), pose_in, que_K, norm, size, margin, sub_poses,
                      sub_Ks, n_sub, ref_num, geo, ref_idx, angle_step, ref_bucket);
   return g6d_check_launch("chain_refine_prepare");
 }
 
-extern "C" int g6d_chain_refine_update(const float* rot, const float* off, const float* scl, const float* geo, const float* norm,
-                                       float* pose_out, g6d_stream_t stream) {
-  if (!rot || !off || !scl || !geo || !norm || !pose_out) { g6d_set_error("chain_refine_update: bad args"); return G6D_EINVAL; }
-  hipLaunchKernelGGL(refine_update_kernel, dim3(1), dim3(64), 0, CHAIN_STREAM(stream), rot, off, scl, geo, norm, pose_out);
+extern "C" int g6d_chain_refine_update(const float* rot, const float* off, const float* scl, const float* geo, int geo_floats,
+                                       const float* norm, float* pose_out, int batch, g6d_stream_t stream) {
+  if (!rot || !off || !scl || !geo || !norm || !pose_out || batch < 1 || geo_floats < 33) { g6d_set_error("chain_refine_update: bad args"); return G6D_EINVAL; }
+  hipLaunchKernelGGL(refine_update_kernel, dim3(batch), dim3(64), 0, CHAIN_STREAM(stream), rot, off, scl, geo, geo_floats, norm, pose_out);
   return g6d_check_launch("chain_refine_update");
 }
 

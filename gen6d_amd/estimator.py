@@ -367,10 +367,11 @@ class Gen6DEstimator:
                  "refine_poses": [p.cpu().numpy() for p in out["refine_poses"]]}
         return out["pose"].cpu().numpy().astype(np.float32), inter
 
-    def predict_many(self, que_imgs, que_Ks, lanes=3):
-        """Several queries in flight at once (one captured hipGraph of the whole chain per lane), one synchronisation at the
-        end: [(pose, inter)] in query order (BASELINE configs[4]: batched multi-query stream)."""
-        return self.device_chain().predict_many(que_imgs, que_Ks, lanes)
+    def predict_many(self, que_imgs, que_Ks, lanes=3, batch=1):
+        """Several queries in flight at once (one captured hipGraph of the whole chain per lane, `batch` queries per graph sharing
+        every launch), one synchronisation at the end: [(pose, inter)] in query order (BASELINE configs[4]: batched multi-query
+        stream)."""
+        return self.device_chain().predict_many(que_imgs, que_Ks, lanes, batch)
 
 
 name2estimator = {"gen6d": Gen6DEstimator}

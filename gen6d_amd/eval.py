@@ -129,16 +129,19 @@ def track_frames(estimator, frames, Ks=None, device_resident=True):
 
 
 # ------------------------------------------------------------------------------------------------ streaming evaluation
-def run_queries(estimator, que_database, que_ids, lanes=3, prefetch=6, decode_threads=4, on_result=None):
+def run_queries(estimator, que_database, que_ids, lanes=3, prefetch=6, decode_threads=4, on_result=None, batch=1):
     """All queries of `que_ids` through the device chain: returns (poses [q,3,4] float32, seconds, inter list).
-    Decode + upload run `prefetch` images ahead in `decode_threads` host threads; `lanes` captured graphs keep that many
-    queries in flight; results are read back one lane at a time (one synchronisation per query, at the END of the chain)."""
+    Decode + upload run `prefetch` images ahead in `decode_threads` host threads; `lanes` captured graphs of `batch` queries each
+    (the queries of a graph share every launch) keep lanes x batch queries in flight; results are read back one lane at a time (one
+    synchronisation per batch, at the END of the chain)."""
     chain = estimator.device_chain()
     dev = estimator.device
+    batch = max(1, min(8, int(batch)))
+    prefetch = max(prefetch, 2 * batch)
 
     def fetch(i):
         img = np.ascontiguousarray(que_database.get_image(i))               # JPEG decode happens here (database's reader)
-        t = torch.from_numpy(img)
+        t = torch.from_numpy(img.copy() if not img.flags.writeable else img)
         if dev.type == "cuda":
             t = t.pin_memory()
         return t, torch.from_numpy(np.ascontiguousarray(que_database.get_K(i), dtype=np.float32))
@@ -147,31 +150,41 @@ def run_queries(estimator, que_database, que_ids, lanes=3, prefetch=6, decode_th
     t0 = time.perf_counter()
     with ThreadPoolExecutor(decode_threads) as pool:
         futs = [pool.submit(fetch, i) for i in que_ids[:prefetch]]
-        busy = [None] * lanes                                               # (event, row, query index)
+        busy = [None] * lanes                                               # (event, rows, first query index, count)
 
         def finish(slot):
-            ev, row, qi = busy[slot]
+            ev, rows, q0, n = busy[slot]
             ev.synchronize()
-            r = row.cpu().numpy()
-            poses[qi] = r[:12].reshape(3, 4).astype(np.float32)
-            inters[qi] = {"det_position": r[12:14], "det_scale_r2q": float(r[14]), "sel_ref_idx": int(r[17]), "sel_angle_r2q": float(r[18])}
-            if on_result is not None:
-                on_result(qi, poses[qi], inters[qi])
+            rr = rows.cpu().numpy()
+            for k in range(n):
+                r, qi = rr[k], q0 + k
+                poses[qi] = r[:12].reshape(3, 4).astype(np.float32)
+                inters[qi] = {"det_position": r[12:14], "det_scale_r2q": float(r[14]), "sel_ref_idx": int(r[17]), "sel_angle_r2q": float(r[18])}
+                if on_result is not None:
+                    on_result(qi, poses[qi], inters[qi])
             busy[slot] = None
 
-        for qi in range(len(que_ids)):
-            img, K = futs[qi].result()
-            futs[qi] = None                       # only the `prefetch` images ahead stay alive (pinned host memory)
-            if qi + prefetch < len(que_ids):
-                futs.append(pool.submit(fetch, que_ids[qi + prefetch]))
-            if chain._lanes is None or len(chain._lanes) != lanes or tuple(chain._lanes[0][2].shape) != tuple(img.shape):
-                chain.capture(tuple(img.shape), lanes)
-            slot = qi % lanes
+        for bi, q0 in enumerate(range(0, len(que_ids), batch)):
+            n = min(batch, len(que_ids) - q0)
+            imgs, Ks = [], []
+            for qi in range(q0, q0 + n):
+                img, K = futs[qi].result()
+                futs[qi] = None                       # only the `prefetch` images ahead stay alive (pinned host memory)
+                if qi + prefetch < len(que_ids):
+                    futs.append(pool.submit(fetch, que_ids[qi + prefetch]))
+                imgs.append(img); Ks.append(K)
+            shape = tuple(imgs[0].shape)
+            if (chain._lanes is None or len(chain._lanes) != lanes or getattr(chain, "_batch", 1) != batch or
+                    tuple(chain._lanes[0][2].shape[1:]) != shape):
+                chain.capture(shape, lanes, batch=batch)
+            slot = bi % lanes
             if busy[slot] is not None:
                 finish(slot)
-            row, stream = chain.enqueue(slot, img.to(dev, non_blocking=True), K.to(dev, non_blocking=True))
+            ib = torch.stack([im.to(dev, non_blocking=True) for im in imgs], 0)
+            kb = torch.stack([K.to(dev, non_blocking=True) for K in Ks], 0)
+            rows, stream = chain.enqueue(slot, ib, kb)
             ev = torch.cuda.Event(); ev.record(stream)
-            busy[slot] = (ev, row, qi)
+            busy[slot] = (ev, rows, q0, n)
         for slot in range(lanes):
             if busy[slot] is not None:
                 finish(slot)
@@ -219,8 +232,9 @@ def main(argv=None):
     ap.add_argument("--object_name", type=str, default="synthetic/blob")
     ap.add_argument("--symmetric", action="store_true")
     ap.add_argument("--split_type", type=str, default=None)
-    ap.add_argument("--lanes", type=int, default=3)
-    ap.add_argument("--prefetch", type=int, default=6)
+    ap.add_argument("--lanes", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=4, help="queries per captured graph (they share every launch), 1..8")
+    ap.add_argument("--prefetch", type=int, default=12)
     ap.add_argument("--max_queries", type=int, default=0)
     ap.add_argument("--jpeg_dir", type=str, default=None,
                     help="serve the query images from JPEG files in this folder (written once from the database): every query then pays "
@@ -250,19 +264,19 @@ def main(argv=None):
     _, que_ids = E.get_database_split(que_db, que_split)
     if args.max_queries:
         que_ids = que_ids[:args.max_queries]
-    poses, secs, _ = run_queries(est, que_db, list(que_ids), args.lanes, args.prefetch)
+    poses, secs, _ = run_queries(est, que_db, list(que_ids), args.lanes, args.prefetch, batch=args.batch)
     res = compute_metrics(get_ref_point_cloud(ref_db), E.get_diameter(que_db), [que_db.get_pose(i) for i in que_ids], poses,
                           [que_db.get_K(i) for i in que_ids], symmetric=args.symmetric)
     name = est.cfg.get("name", "gen6d") + (args.split_type or "")
     msg = f"{args.object_name:10} {name:20} " + " ".join(f"{k} {v:.4f}" for k, v in res.items())
     print(msg)
     print(f"build {build_s:.2f} s; {len(que_ids)} queries in {secs:.2f} s = {len(que_ids) / secs:.1f} images/s "
-          f"(decode + upload + detect + select + {est.cfg['refine_iter']} x refine, {args.lanes} queries in flight)")
+          f"(decode + upload + detect + select + {est.cfg['refine_iter']} x refine, {args.lanes} graphs of {args.batch} queries in flight)")
     if args.json:
         import json
         with open(args.json, "w") as f:
             json.dump({"object": args.object_name, "cfg": args.cfg, "metrics": res, "queries": len(que_ids), "seconds": secs,
-                       "images_per_s": len(que_ids) / secs, "build_s": build_s, "lanes": args.lanes, "prefetch": args.prefetch,
+                       "images_per_s": len(que_ids) / secs, "build_s": build_s, "lanes": args.lanes, "batch": args.batch, "prefetch": args.prefetch,
                        "jpeg_decode": bool(args.jpeg_dir), "refine_iter": est.cfg["refine_iter"]}, f, indent=1)
     return res
 

@@ -77,10 +77,10 @@ SIGNATURES = {
     "g6d_layernorm": [_P, _I, _I, _I, _P, _P, _F, _P, _I, _P],
     "g6d_affine_act_add": [_P, _I, _P, _P, _I, _P, _I, _I, _I, _P, _I, _I, _P],
     "g6d_linear_gemv": [_P, _I, _I, _P, _P, _I, _I, _P, _P],
-    "g6d_chain_crop_from_detection": [_P, _F, _P, _P],
-    "g6d_chain_pose_from_selection": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P],
-    "g6d_chain_refine_prepare": [_P, _P, _P, _F, _F, _P, _P, _I, _I, _P, _P, _F, _P, _P],
-    "g6d_chain_refine_update": [_P, _P, _P, _P, _P, _P, _P],
+    "g6d_chain_crop_from_detection": [_P, _F, _P, _I, _P],
+    "g6d_chain_pose_from_selection": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P],
+    "g6d_chain_refine_prepare": [_P, _P, _P, _F, _F, _P, _P, _I, _I, _P, _P, _F, _P, _I, _P],
+    "g6d_chain_refine_update": [_P, _P, _P, _P, _I, _P, _P, _I, _P],
     "g6d_warp_batch": [_P, _P, _P, _I, _I, _I, _I, _P, _P, _I, _I, _P],
     "g6d_warp_perspective": [_P, _I, _I, _I, C.POINTER(C.c_float), _P, _I, _I, _I, _F, _P],
 }

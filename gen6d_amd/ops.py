@@ -797,44 +797,63 @@ def _f32c(*ts):
 
 
 def chain_crop_from_detection(det, size):
-    """det [5] (g6d_detector_decode result) -> hinv [1,9] of the selector crop."""
+    """det [5] (g6d_detector_decode result) or [B,5] -> hinv [B,9] of the selector crops."""
     _need_gpu(det); _f32c(det)
-    hinv = torch.empty((1, 9), dtype=torch.float32, device=det.device)
-    _lib.check(_lib.load().g6d_chain_crop_from_detection(_ptr(det), float(size), _ptr(hinv), _stream()), "g6d_chain_crop_from_detection")
+    B = det.shape[0] if det.dim() == 2 else 1
+    hinv = torch.empty((B, 9), dtype=torch.float32, device=det.device)
+    _lib.check(_lib.load().g6d_chain_crop_from_detection(_ptr(det), float(size), _ptr(hinv), B, _stream()), "g6d_chain_crop_from_detection")
     return hinv
 
 
 def chain_pose_from_selection(det, logits, angles, ref_poses, ref_Ks, que_K, center):
-    """-> pose [3,4], sel [2] = (reference index, in-plane angle), all on the device."""
+    """-> pose [3,4], sel [2] = (reference index, in-plane angle), all on the device; batch: det [B,5], logits / angles [B,rfn],
+    que_K [B,9] -> pose [B,3,4], sel [B,2]."""
     _need_gpu(det, logits, angles, ref_poses, ref_Ks, que_K, center); _f32c(det, logits, angles, ref_poses, ref_Ks, que_K, center)
-    pose = torch.empty((3, 4), dtype=torch.float32, device=det.device)
-    sel = torch.empty((2,), dtype=torch.float32, device=det.device)
-    _lib.check(_lib.load().g6d_chain_pose_from_selection(_ptr(det), _ptr(logits), _ptr(angles), logits.numel(), _ptr(ref_poses),
-                                                        _ptr(ref_Ks), _ptr(que_K), _ptr(center), _ptr(pose), _ptr(sel), _stream()),
+    batched = det.dim() == 2
+    B = det.shape[0] if batched else 1
+    rfn = logits.shape[-1]
+    if logits.numel() != B * rfn or angles.numel() != B * rfn or que_K.numel() != 9 * B:
+        raise ValueError("chain_pose_from_selection: per-query operands must share the batch size")
+    pose = torch.empty((B, 3, 4), dtype=torch.float32, device=det.device)
+    sel = torch.empty((B, 2), dtype=torch.float32, device=det.device)
+    _lib.check(_lib.load().g6d_chain_pose_from_selection(_ptr(det), _ptr(logits), _ptr(angles), rfn, _ptr(ref_poses),
+                                                        _ptr(ref_Ks), _ptr(que_K), _ptr(center), _ptr(pose), _ptr(sel), B, _stream()),
                "g6d_chain_pose_from_selection")
-    return pose, sel
+    return (pose, sel) if batched else (pose[0], sel[0])
 
 
 def chain_refine_prepare(pose_in, que_K, norm, size, margin, sub_poses, sub_Ks, ref_num, angle_step=0.0):
     """-> geo [42 + 30*ref_num] float32 (see include/gen6d_hip.h), ref_idx [ref_num] int32; with angle_step > 0 (radians) the
-    alignment angles are snapped to its multiples and the third result is their buckets [ref_num] int32 (cache keys)."""
+    alignment angles are snapped to its multiples and the third result is their buckets [ref_num] int32 (cache keys).
+    Batch: pose_in [B,12], que_K [B,9] -> geo [B,42+30*ref_num], ref_idx [B,ref_num] (, buckets [B,ref_num])."""
     _need_gpu(pose_in, que_K, norm, sub_poses, sub_Ks); _f32c(pose_in, que_K, norm, sub_poses, sub_Ks)
-    geo = torch.empty((42 + 30 * ref_num,), dtype=torch.float32, device=pose_in.device)
-    idx = torch.empty((ref_num,), dtype=torch.int32, device=pose_in.device)
-    bucket = torch.empty((ref_num,), dtype=torch.int32, device=pose_in.device) if angle_step > 0 else None
+    batched = pose_in.dim() == 2
+    B = pose_in.shape[0] if batched else 1
+    if pose_in.numel() != 12 * B or que_K.numel() != 9 * B:
+        raise ValueError("chain_refine_prepare: pose_in [B,12] and que_K [B,9] expected")
+    geo = torch.empty((B, 42 + 30 * ref_num), dtype=torch.float32, device=pose_in.device)
+    idx = torch.empty((B, ref_num), dtype=torch.int32, device=pose_in.device)
+    bucket = torch.empty((B, ref_num), dtype=torch.int32, device=pose_in.device) if angle_step > 0 else None
     _lib.check(_lib.load().g6d_chain_refine_prepare(_ptr(pose_in), _ptr(que_K), _ptr(norm), float(size), float(margin), _ptr(sub_poses),
                                                    _ptr(sub_Ks), sub_poses.shape[0], int(ref_num), _ptr(geo), _ptr(idx),
-                                                   float(angle_step), _ptr(bucket), _stream()),
+                                                   float(angle_step), _ptr(bucket), B, _stream()),
                "g6d_chain_refine_prepare")
+    if not batched:
+        geo, idx, bucket = geo[0], idx[0], (bucket[0] if bucket is not None else None)
     return (geo, idx, bucket) if angle_step > 0 else (geo, idx)
 
 
 def chain_refine_update(rot, off, scl, geo, norm):
+    """rot [4] / off [2] / scl [1] + geo record -> pose [3,4]; batch: rot [B,4], off [B,2], scl [B,1], geo [B,G] -> pose [B,3,4]."""
     _need_gpu(rot, off, scl, geo, norm); _f32c(rot, off, scl, geo, norm)
-    pose = torch.empty((3, 4), dtype=torch.float32, device=geo.device)
-    _lib.check(_lib.load().g6d_chain_refine_update(_ptr(rot), _ptr(off), _ptr(scl), _ptr(geo), _ptr(norm), _ptr(pose), _stream()),
-               "g6d_chain_refine_update")
-    return pose
+    batched = geo.dim() == 2
+    B = geo.shape[0] if batched else 1
+    if rot.numel() != 4 * B or off.numel() != 2 * B or scl.numel() != B:
+        raise ValueError("chain_refine_update: refiner outputs must share the batch size of geo")
+    pose = torch.empty((B, 3, 4), dtype=torch.float32, device=geo.device)
+    _lib.check(_lib.load().g6d_chain_refine_update(_ptr(rot), _ptr(off), _ptr(scl), _ptr(geo), geo.shape[-1], _ptr(norm), _ptr(pose), B,
+                                                  _stream()), "g6d_chain_refine_update")
+    return pose if batched else pose[0]
 
 
 def warp_batch(stack, single, idx, hinv, dh, dw, out=None):

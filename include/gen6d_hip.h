@@ -336,16 +336,19 @@ int g6d_warp_perspective(const unsigned char* src, int sh, int sw, int ch, const
  * network calls, as single-launch kernels on device buffers (float32 in memory, float64 arithmetic), so that
  * detect -> crop -> select -> pose -> 3 x refine is one chain of launches without host synchronisation (hipGraph-capturable).
  * All pointers are DEVICE pointers.  3x3 matrices are row-major [9], poses row-major [3][4] = [12].
+ * Every kernel takes a `batch` of queries (round 3): per-query operands and results are dense arrays with the query as leading axis
+ * (det [batch][5], logits / angles [batch][rfn], que_K [batch][9], poses [batch][12], geo [batch][42+30*ref_num], ...); the reference
+ * state (ref_poses, ref_Ks, center, norm, sub_poses, sub_Ks) is shared by the queries.
  * ---------------------------------------------------------------------------------------------------------------- */
 /* det = result of g6d_detector_decode (x, y, 2^scale, ...) -> hinv[9]: destination->source map of
  * transformation_crop(que_img, position, 1/scale_r2q, 0, size) (estimator.py:184, utils/base_utils.py:646-655) */
-int g6d_chain_crop_from_detection(const float* det, float size, float* hinv, g6d_stream_t stream);
+int g6d_chain_crop_from_detection(const float* det, float size, float* hinv, int batch, g6d_stream_t stream);
 /* arg-max viewpoint (first maximum) + estimate_pose_from_similarity_transform_compose (estimator.py:193-206,
  * utils/pose_utils.py:12-49,104-111): logits/angles [rfn], ref_poses [rfn][12], ref_Ks [rfn][9] -> pose_out[12],
  * sel_out[2] = (selected reference index, its in-plane angle) */
 int g6d_chain_pose_from_selection(const float* det, const float* logits, const float* angles, int rfn, const float* ref_poses,
                                   const float* ref_Ks, const float* que_K, const float* center, float* pose_out, float* sel_out,
-                                  g6d_stream_t stream);
+                                  int batch, g6d_stream_t stream);
 /* Geometry of one refinement step before the network (network/refiner.py:275-313, utils/database_utils.py:54-139 on the
  * NormalizedDatabase): pose_in[12] in the database frame, que_K[9], norm[4] = (NormalizedDatabase.scale, offset xyz),
  * sub_poses [n_sub][12] / sub_Ks [n_sub][9] = normalised poses and intrinsics of the (FPS) reference subset, n_sub <= 128.
@@ -357,11 +360,11 @@ int g6d_chain_pose_from_selection(const float* det, const float* logits, const f
  * receives round(angle / angle_step).  angle_step = 0: the reference's exact alignment. */
 int g6d_chain_refine_prepare(const float* pose_in, const float* que_K, const float* norm, float size, float margin,
                              const float* sub_poses, const float* sub_Ks, int n_sub, int ref_num, float* geo, int* ref_idx,
-                             float angle_step, int* ref_bucket, g6d_stream_t stream);
+                             float angle_step, int* ref_bucket, int batch, g6d_stream_t stream);
 /* Refiner outputs (rotation[4] w-first, offset[2], log2 scale[1]) + the step's geo record -> refined pose in the database frame
  * (refiner.py:327-341: compose_sim_pose, pose_sim_to_pose_rigid with the polar factor of the SVD, un-rectify, denormalise). */
-int g6d_chain_refine_update(const float* rot, const float* off, const float* scl, const float* geo, const float* norm,
-                            float* pose_out, g6d_stream_t stream);
+int g6d_chain_refine_update(const float* rot, const float* off, const float* scl, const float* geo, int geo_floats /* per query */,
+                            const float* norm, float* pose_out, int batch, g6d_stream_t stream);
 /* Batched g6d_warp_perspective with homographies and source selection in device memory, output in the layout the networks
  * take: dst [B][ch][dh][dw] float = rint(bilinear)/255 (the uint8 image cv2.warpPerspective would return, scaled to [0,1]);
  * image b reads `single` when idx == NULL or idx[b] < 0, else stack[idx[b]] (uint8 [.][sh][sw][ch]); hinv [B][9]. */

@@ -405,6 +405,8 @@ def _np(t):
 def chain_crop_from_detection(det, size):
     import numpy as np
     from gen6d_amd import geometry as G
+    if det.dim() == 2:
+        return torch.cat([chain_crop_from_detection(d_, size) for d_ in det], 0)
     d = _np(det)
     M = np.concatenate([G.crop_transform(d[:2], 1 / d[2], 0, size), [[0, 0, 1]]], 0)
     return torch.from_numpy(np.linalg.inv(M).reshape(1, 9).astype(np.float32))
@@ -413,6 +415,9 @@ def chain_crop_from_detection(det, size):
 def chain_pose_from_selection(det, logits, angles, ref_poses, ref_Ks, que_K, center):
     import numpy as np
     from gen6d_amd import geometry as G
+    if det.dim() == 2:
+        rs = [chain_pose_from_selection(det[b], logits[b], angles[b], ref_poses, ref_Ks, que_K[b], center) for b in range(det.shape[0])]
+        return torch.stack([r[0] for r in rs], 0), torch.stack([r[1] for r in rs], 0)
     d, lg, an = _np(det), _np(logits), _np(angles)
     i = int(np.argmax(lg))
     pose = G.estimate_pose_from_similarity_transform_compose(d[:2], d[2], an[i], _np(ref_poses)[i].reshape(3, 4), _np(ref_Ks)[i].reshape(3, 3),
@@ -423,6 +428,9 @@ def chain_pose_from_selection(det, logits, angles, ref_poses, ref_Ks, que_K, cen
 def chain_refine_prepare(pose_in, que_K, norm, size, margin, sub_poses, sub_Ks, ref_num, angle_step=0.0):
     import numpy as np
     from gen6d_amd import geometry as G
+    if pose_in.dim() == 2:
+        rs = [chain_refine_prepare(pose_in[b], que_K[b], norm, size, margin, sub_poses, sub_Ks, ref_num, angle_step) for b in range(pose_in.shape[0])]
+        return tuple(torch.stack([r[k] for r in rs], 0) for k in range(len(rs[0])))
     nm = _np(norm); c0 = np.zeros(3)
     in_pose = G.normalize_pose(_np(pose_in).reshape(3, 4), nm[0], nm[1:]).astype(np.float64)
     K = _np(que_K).reshape(3, 3)
@@ -452,6 +460,8 @@ def chain_refine_prepare(pose_in, que_K, norm, size, margin, sub_poses, sub_Ks, 
 def chain_refine_update(rot, off, scl, geo, norm):
     import numpy as np
     from gen6d_amd import geometry as G
+    if geo.dim() == 2:
+        return torch.stack([chain_refine_update(rot[b], off[b], scl[b], geo[b], norm) for b in range(geo.shape[0])], 0)
     g, nm, c0 = _np(geo), _np(norm), np.zeros(3)
     K_warp, pose_warp, pose_rect = g[:9].reshape(3, 3), g[9:21].reshape(3, 4), g[21:33].reshape(3, 4)
     sim = G.compose_sim_pose(2 ** float(_np(scl)[0]), _np(rot), _np(off), pose_warp, c0)

@@ -198,3 +198,29 @@ def test_streaming_eval_with_real_jpeg_decode_and_tracking(built, tmp_path):
     dev = EV.track_frames(est, frames, Ks, device_resident=True)
     np.testing.assert_allclose(dev[0], host[0], atol=3e-4)                       # frame 0: detect + select + one step
     assert np.isfinite(dev).all() and np.abs(dev - host).max() < 5e-2            # later frames compound (see tests/test_eval_cpu.py)
+
+
+def test_predict_many_batched_graphs(built):
+    """Captured chain graphs of 4 queries each (two in flight): every result equals the single-query graphs' (batch = 1) and the
+    eager chain's; a ragged tail (7 queries = 4 + 3) uses only the first slots of the last graph."""
+    from parity_log import record
+    db, est = built
+    _, que_ids = db.get_split("all")
+    qs = [que_ids[i % len(que_ids)] for i in range(7)]
+    imgs, Ks = [db.get_image(i) for i in qs], [db.get_K(i) for i in qs]
+    single = est.predict_many(imgs, Ks, lanes=2, batch=1)
+    batched = est.predict_many(imgs, Ks, lanes=2, batch=4)
+    assert len(batched) == 7
+    worst = 0.0
+    for (p1, i1), (pb, ib) in zip(single, batched):
+        assert ib["sel_ref_idx"] == i1["sel_ref_idx"]
+        np.testing.assert_allclose(ib["det_position"], i1["det_position"], atol=1e-3)
+        worst = max(worst, float(np.abs(pb - p1).max()))
+    record("test_predict_many_batched_graphs", "pose: chain graphs of 4 queries vs single-query graphs", worst, 3e-4)
+    assert worst <= 3e-4
+    # streaming driver on batches
+    from gen6d_amd import eval as EV
+    poses, secs, inters = EV.run_queries(est, db, qs, lanes=2, prefetch=8, decode_threads=2, batch=4)
+    for i, (pb, ib) in enumerate(batched):
+        assert inters[i]["sel_ref_idx"] == ib["sel_ref_idx"]
+        np.testing.assert_allclose(poses[i], pb, atol=3e-4)

@@ -112,3 +112,25 @@ def test_reference_feature_cache(monkeypatch):
     est2.build(db, "all")
     est2.predict(img, K)
     assert est2.refiner.angle_step() == 0.0 and len(est2.refiner.feat_cache.store) == 0
+
+
+def test_device_chain_batch_matches_single_queries(monkeypatch):
+    """DeviceChain.query_batch: B queries through one launch of every chain kernel / network stage (blockIdx = query, the
+    networks' batched paths, one warp launch per stage) give the poses, detections and selections of the single-query chain."""
+    ref_ops.patch_ops(monkeypatch)
+    db = SyntheticDatabase(n_views=24, size=(96, 128), focal=140.0)
+    est = make_estimator(refine_iter=1, damped=True)
+    est.build(db, "all")
+    _, que_ids = db.get_split("all")
+    ids = [que_ids[1], que_ids[4], que_ids[2]]
+    imgs = torch.stack([torch.from_numpy(np.ascontiguousarray(db.get_image(i))) for i in ids], 0)
+    Ks = torch.stack([torch.from_numpy(np.ascontiguousarray(db.get_K(i), dtype=np.float32)) for i in ids], 0)
+    chain = est.device_chain()
+    outb = chain.query_batch(imgs, Ks)
+    assert outb["pose"].shape == (3, 3, 4) and outb["det"].shape == (3, 5) and outb["sel"].shape == (3, 2) and outb["logits"].shape == (3, 8)
+    for b in range(3):
+        one = chain.query(imgs[b], Ks[b])
+        assert int(outb["sel"][b, 0]) == int(one["sel"][0])
+        np.testing.assert_allclose(outb["det"][b].numpy(), one["det"].numpy(), rtol=1e-5, atol=1e-3)
+        np.testing.assert_allclose(outb["refine_poses"][0][b].numpy(), one["refine_poses"][0].numpy(), atol=1e-5)
+        np.testing.assert_allclose(outb["pose"][b].numpy(), one["pose"].numpy(), atol=1e-4)
