@@ -107,6 +107,7 @@ def main():
                     help="additionally time the device-resident predict chain (gen6d_amd/chain.py: detection -> crop -> selection "
                          "-> pose -> 3 x refine with every inter-stage warp and the pose algebra on the GPU, one captured graph "
                          "per lane) on a procedural 480x640 database with REAL data flow between the stages; reported as `chained`")
+    ap.add_argument("--chain-batch", type=int, default=8, help="queries per captured graph of the --chained measurement")
     ap.add_argument("--cpu-reps", type=int, default=3, help="timed CPU-oracle runs after one warm-up (min is reported)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="torch CPU threads for the baseline (0 = best of {8,16,32,64,physical cores})")
     ap.add_argument("--no-graph", action="store_true", help="time the eager launch path instead of hipGraph replay")
@@ -439,7 +440,7 @@ def main():
         qk = [Ks[i % 8] for i in range(n_c + lanes)]
         chain = est.device_chain()
         clanes = min(lanes, 3)
-        cb = min(B, 4)                # queries per captured chain graph (they share every launch)
+        cb = min(B, args.chain_batch)  # queries per captured chain graph (they share every launch)
         n_c = max(n_c, 6 * cb * clanes)
         qi = [imgs[i % 8] for i in range(n_c)]
         qk = [Ks[i % 8] for i in range(n_c)]
