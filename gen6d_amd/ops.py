@@ -295,7 +295,7 @@ def corr2d_wino_multi(xs, U, outs, kblocks=5):
 
 _ARENA = {}          # (device, stream) -> [buffer, bump offset]
 _CUR_ARENA = None    # arena of the query being enqueued (host-side state; set by stats_arena_begin)
-ARENA_DOUBLES = 1 << 17
+ARENA_DOUBLES = 1 << 19      # 4 MB: a batch of 8 queries needs ~140 K accumulators in the refiner step (56 images x 1024 channels x 2)
 
 
 def stats_arena_begin(device):
