@@ -1,7 +1,6 @@
 // HBM-bound glue kernels: InstanceNorm finalisation, affine/ReLU/pool, bilinear up-sampling, layout change with
 // L2 normalisation, token-wise tails of the selector.  All channels-last, 16-byte accesses along C.
 #include "g6d_common.h"
-#include <stdlib.h>
 
 namespace {
 
@@ -348,64 +347,6 @@ __global__ void __launch_bounds__(GEMV_THREADS) linear_gemv_kernel(const float* 
   }
 }
 
-// Batches (B > 1, round 3): R output rows per block against the SAME slice of the x rows, which every block otherwise re-reads from
-// L2 once per weight element and right-hand side — with B = 8 that was 8x the weight bytes through L2 and the launch ran at 0.17 of the
-// HBM rate.  A thread holds its 4-float slice of the B right-hand sides in registers per K slice and streams R weight rows past it.
-template <int R>
-__global__ void __launch_bounds__(GEMV_THREADS) linear_gemv_rows_kernel(const float* __restrict__ x, int B, int K,
-                                                                        const float* __restrict__ W,
-                                                                        const float* __restrict__ bias, int act,
-                                                                        float* __restrict__ out, int O) {
-  __shared__ float red[R][8][GEMV_THREADS / 64];
-  const int o0 = blockIdx.x * R;
-  float acc[R][8];
-#pragma unroll
-  for (int r = 0; r < R; ++r)
-#pragma unroll
-    for (int b = 0; b < 8; ++b) acc[r][b] = 0.f;
-  constexpr int STEP = GEMV_THREADS * 4;
-  for (int k0 = threadIdx.x * 4; k0 < K; k0 += STEP * 4) {
-    f32x4 wv[4][R];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int kk = k0 + u * STEP;
-#pragma unroll
-      for (int r = 0; r < R; ++r)
-        wv[u][r] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(W + (size_t)min(o0 + r, O - 1) * K + (kk < K ? kk : 0)));
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int kk = k0 + u * STEP;
-      if (kk >= K) continue;
-#pragma unroll
-      for (int b = 0; b < 8; ++b)
-        if (b < B) {
-          const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)b * K + kk);
-#pragma unroll
-          for (int r = 0; r < R; ++r) acc[r][b] += wv[u][r][0] * xv[0] + wv[u][r][1] * xv[1] + wv[u][r][2] * xv[2] + wv[u][r][3] * xv[3];
-        }
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < R; ++r)
-#pragma unroll
-    for (int b = 0; b < 8; ++b) {
-      const float s = wave_sum(acc[r][b]);
-      if ((threadIdx.x & 63) == 0) red[r][b][threadIdx.x >> 6] = s;
-    }
-  __syncthreads();
-  if (threadIdx.x < R * 8) {
-    const int r = threadIdx.x >> 3, b = threadIdx.x & 7;
-    if (b < B && o0 + r < O) {
-      float s = 0.f;
-#pragma unroll
-      for (int i = 0; i < GEMV_THREADS / 64; ++i) s += red[r][b][i];
-      if (bias) s += bias[o0 + r];
-      out[(size_t)b * O + o0 + r] = apply_act(s, act);
-    }
-  }
-}
-
 inline int grid_for(long long total, int block) {
   long long g = (total + block - 1) / block;
   return (int)(g > 65535 * 16 ? 65535 * 16 : (g < 1 ? 1 : g));
@@ -540,10 +481,7 @@ extern "C" int g6d_linear_gemv(const float* x, int B, int K, const float* W, con
   if (!x || !W || !out || B <= 0 || B > 8 || K <= 0 || (K & 3) || O <= 0 || !g6d_aligned16(x) || !g6d_aligned16(W)) {
     g6d_set_error("linear_gemv: bad args"); return G6D_EINVAL;
   }
-  static const bool rows_on = []() { const char* e = getenv("G6D_GEMV_ROWS"); return !(e && e[0] == '0'); }();
-  if (B > 1 && rows_on && K >= GEMV_THREADS * 4 * 4 && O >= 512)      // batches: 4 output rows per block share the x slices
-    hipLaunchKernelGGL(linear_gemv_rows_kernel<4>, dim3((O + 3) / 4), dim3(GEMV_THREADS), 0, STREAM(stream), x, B, K, W, bias, act, out, O);
-  else if (K >= GEMV_THREADS * 4 * 16)
+  if (K >= GEMV_THREADS * 4 * 16)
     hipLaunchKernelGGL(linear_gemv_kernel<16>, dim3(O), dim3(GEMV_THREADS), 0, STREAM(stream), x, B, K, W, bias, act, out, O);
   else
     hipLaunchKernelGGL(linear_gemv_kernel<4>, dim3(O), dim3(GEMV_THREADS), 0, STREAM(stream), x, B, K, W, bias, act, out, O);

@@ -474,7 +474,7 @@ def test_selector_tail_ops(ops):
     _check(ob2, rob2, 1e-6, "affine_act_add batch")
 
 
-@pytest.mark.parametrize("B,K,O,act", [(1, 32768, 512, 2), (1, 512, 7, 0), (3, 1024, 40, 1), (8, 32768, 512, 2), (5, 8192, 514, 0)])
+@pytest.mark.parametrize("B,K,O,act", [(1, 32768, 512, 2), (1, 512, 7, 0), (3, 1024, 40, 1)])
 def test_linear_gemv(ops, B, K, O, act):
     g = torch.Generator().manual_seed(12)
     x, W, b = _rand(g, B, K), _rand(g, O, K, scale=K ** -0.5), _rand(g, O, scale=0.1)
