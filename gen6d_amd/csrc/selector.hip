@@ -96,16 +96,15 @@ __global__ void __launch_bounds__(64) vps_kernel(const float* __restrict__ score
 //   affine blocks  (query q, level l, 16 channels): InstanceNorm affine of the never-materialised product, 64 position lanes, fp64.
 // The largest level comes first.  vps_levels_kernel then reduces every (q, l, d) score row: vps = sum_hw S * (S / max_hw S).
 struct SelLevel { const float* que; const float* refs; const double* r1; const double* r2; float* score_map; int HW, parts, blk0, pad; };
-struct SelArgs { SelLevel lv[3]; int nlev, qn, D, C, scan_blocks; double inv_dg, eps; float* vps; float* scale; float* shift; };
+struct SelArgs { SelLevel lv[3]; int nlev, qn, D, C, scan_blocks, dc; double inv_dg, eps; float* vps; float* scale; float* shift; };   // dc: hypotheses per ROWQ unit
 #define SEL_MAX_HW 1024
 #define SEL_MAX_QN 8
 
 // QN = compile-time bound of the batch (1, 2, 4, 8): the score accumulators of a wave are 4 rows x QN registers
-// ROWQ (C == 512, batches): a wave owns ONE location row of a level and a chunk of SEL_DC hypotheses; the row of every query sits in
-// registers (2 x 16 bytes per lane and query) and the wave streams the SEL_DC reference rows of that location past them, four 2 KB
+// ROWQ (C == 512, batches): a wave owns ONE location row of a level and a chunk of `dc` hypotheses; the row of every query sits in
+// registers (2 x 16 bytes per lane and query) and the wave streams the dc reference rows of that location past them, four 2 KB
 // rows in flight.  Without it (the layout above) every block re-reads the rows of all QN queries from L2 for each hypothesis — at
 // QN = 8 that is 8x the reference bytes through L2 and the launch drops from 0.54 to 0.14 of the HBM rate (measured, round 3).
-#define SEL_DC 20
 template <int QN, bool ROWQ>
 __global__ void __launch_bounds__(ROWQ ? 512 : 1024) selector_levels_kernel(const SelArgs a) {
   constexpr int WAVES = ROWQ ? 8 : 16, NPL = WAVES * 4;          // ROWQ: 512-thread blocks (256 registers per lane: QN = 8 needs ~140)
@@ -120,7 +119,7 @@ __global__ void __launch_bounds__(ROWQ ? 512 : 1024) selector_levels_kernel(cons
     const int HW = L.HW, qn = a.qn, D = a.D;
     const int u = (b - L.blk0) * WAVES + wave;                   // unit = (hypothesis chunk, row): consecutive waves -> consecutive rows
     const int dch = u / HW, row = u - dch * HW;
-    const int d0 = dch * SEL_DC;
+    const int d0 = dch * a.dc;
     if (d0 >= D) return;
     f32x4 qv[QN][2];
 #pragma unroll
@@ -130,7 +129,7 @@ __global__ void __launch_bounds__(ROWQ ? 512 : 1024) selector_levels_kernel(cons
     }
     const float* rbase = L.refs + (size_t)row * 512 + lane * 4;
     const size_t dstride = (size_t)HW * 512;
-    const int dn = min(SEL_DC, D - d0);
+    const int dn = min(a.dc, D - d0);
     for (int dd = 0; dd < dn; dd += 4) {
       f32x4 rv[4][2];
 #pragma unroll
@@ -294,8 +293,20 @@ extern "C" int g6d_selector_levels(int nlev, int qn, const float* const* que, co
   static const int rowq_env = []() { const char* e = getenv("G6D_SEL_ROWQ"); return e ? atoi(e) : -1; }();
   const bool rowq = C == 512 && (rowq_env < 0 ? qn > 1 : rowq_env == 1 || (rowq_env != 0 && qn > 1));
   if (rowq) {
+    // hypotheses per unit: all units are equal-sized, so the launch takes ceil(blocks / resident blocks) rounds of `dc` rows — pick the
+    // chunk count with the fewest row-rounds (D = 320: 12 chunks of 27 = 504 blocks = ONE round of the 512 resident 8-wave blocks)
+    long long rows_all = 0;
+    for (int l = 0; l < nlev; ++l) rows_all += HW[l];
+    int best_nch = 1; long long best_cost = -1;
+    for (int nch = 1; nch <= 64 && nch <= D; ++nch) {
+      const int dc = (D + nch - 1) / nch;
+      const long long blocks_ = (rows_all * nch + 7) / 8, rounds = (blocks_ + 511) / 512;
+      const long long cost = rounds * (dc + 2);                       // + per-unit set-up (query rows into registers)
+      if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_nch = nch; }
+    }
+    a.dc = (D + best_nch - 1) / best_nch;
+    const int nch = (D + a.dc - 1) / a.dc;
     blk = 0;
-    const int nch = (D + SEL_DC - 1) / SEL_DC;
     for (int l = 0; l < nlev; ++l) { a.lv[l].blk0 = blk; blk += (HW[l] * nch + 7) / 8; }
   }
   a.scan_blocks = blk;
