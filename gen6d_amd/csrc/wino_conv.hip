@@ -515,6 +515,116 @@ __global__ void __launch_bounds__(128 * NWN, 1) wino_conv3x3_kernel(const WinoAr
 //   MFMAs      16 per chunk (one per (a,b) position) of 8 passes instead of 2 x 64 of 16 passes: the loop is bound by the input
 //              transform (~200 vector instructions) and by streaming 58 KB per chunk into LDS, not by the matrix pipe.
 // Epilogue as the fp32 trunk kernel (output transform, bias, ReLU, full / pooled fp32 outputs, chunk split with in-kernel hand-off).
+// Epilogue shared by the 16-bit kernels (the fp32 kernel keeps its own, identical copy inline: it is scheduled by hand): output
+// transform A^T D A, chunk-split hand-off, bias, ReLU, full / pooled stores, per-(group, channel) statistics and their finalisation.
+template <int THREADS, int NWN>
+__device__ __forceinline__ void wino_epilogue(const WinoArgs& p, f32x16 (&acc)[16], float* lds, int tid, int wm, int wn, int li, int lh, int n0) {
+  const int co = n0 + wn * 32 + li;
+  f32x4 Y[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float sr[2][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      sr[0][j] = acc[0 + j][r] + acc[4 + j][r] + acc[8 + j][r];
+      sr[1][j] = acc[4 + j][r] - acc[8 + j][r] - acc[12 + j][r];
+    }
+    Y[r] = f32x4{sr[0][0] + sr[0][1] + sr[0][2], sr[0][1] - sr[0][2] - sr[0][3], sr[1][0] + sr[1][1] + sr[1][2], sr[1][1] - sr[1][2] - sr[1][3]};
+  }
+  if (p.splits > 1) {
+    constexpr int TILE = THREADS * 64;
+    const int ntiles = gridDim.x * gridDim.y, tile = blockIdx.y * gridDim.x + blockIdx.x;
+    float* part = p.ws + G6D_WS_COUNTERS + (size_t)tile * TILE + tid * 4;
+    const size_t zstride = (size_t)ntiles * TILE;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) g6d_store_wt(part + blockIdx.z * zstride + r * (THREADS * 4), Y[r]);
+    if (!g6d_split_arrive(reinterpret_cast<int*>(p.ws) + tile, p.splits, reinterpret_cast<int*>(lds))) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Y[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < p.splits; ++z) {
+      f32x4 v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = *reinterpret_cast<const f32x4*>(part + (size_t)z * zstride + r * (THREADS * 4));
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Y[r] += v[r];
+    }
+  }
+  const float bv = p.bias ? p.bias[co] : 0.f;
+  const bool do_relu = p.relu != 0;
+  const bool do_stats = p.stats != nullptr;
+  const QGeo geo[2] = {quarter_of(p, 2 * wm), quarter_of(p, 2 * wm + 1)};
+  float st1[2] = {0.f, 0.f}, st2[2] = {0.f, 0.f};
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const QGeo& g = geo[r >> 3];
+    const int tyy = lh + 2 * ((r >> 2) & 1), txx = r & 3;
+    const int n = g.n; const bool qv = g.valid;
+    const int Hp = g.H >> 1, Wp = g.W >> 1;
+    float y[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        y[a][b] = Y[r][2 * a + b] + bv;
+        if (do_relu) y[a][b] = fmaxf(y[a][b], 0.f);
+      }
+    const int oy = g.oy0 + 2 * tyy, ox = g.ox0 + 2 * txx;
+    if (p.out_full && qv) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          if (oy + a < g.H && ox + b < g.W) {
+            p.out_full[(size_t)g.full_off + ((size_t)(n * g.H + oy + a) * g.W + ox + b) * g.ld_full + co] = y[a][b];
+            if (do_stats) { st1[r >> 3] += y[a][b]; st2[r >> 3] += y[a][b] * y[a][b]; }
+          }
+    }
+    if (p.out_pool && qv) {
+      const int py = oy >> 1, px = ox >> 1;
+      if (py < Hp && px < Wp)
+        p.out_pool[(size_t)g.pool_off + ((size_t)(n * Hp + py) * Wp + px) * g.ld_pool + co] = fmaxf(fmaxf(y[0][0], y[0][1]), fmaxf(y[1][0], y[1][1]));
+    }
+  }
+  if (do_stats) {
+    float* sred = lds;
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      st1[h] += __shfl_xor(st1[h], 32, 64);
+      st2[h] += __shfl_xor(st2[h], 32, 64);
+      if (lh == 0) {
+        sred[((2 * wm + h) * 32 * NWN + wn * 32 + li) * 2] = st1[h];
+        sred[((2 * wm + h) * 32 * NWN + wn * 32 + li) * 2 + 1] = st2[h];
+      }
+    }
+    __syncthreads();
+    if (tid < 32 * NWN) {
+      double a1 = 0.0, a2 = 0.0;
+      int cur = -1;
+      for (int q = 0; q < 4; ++q) {
+        const QGeo qg = quarter_of(p, q);
+        if (!qg.valid) break;
+        const int g = p.stats_div > 0 ? (qg.n / p.D) / p.stats_div : 0;
+        if (g != cur && cur >= 0) {
+          double* st = p.stats + ((size_t)cur * p.Cout + n0 + tid) * 2;
+          atomicAdd(st, a1); atomicAdd(st + 1, a2); a1 = a2 = 0.0;
+        }
+        cur = g;
+        a1 += (double)sred[(q * 32 * NWN + tid) * 2];
+        a2 += (double)sred[(q * 32 * NWN + tid) * 2 + 1];
+      }
+      if (cur >= 0) {
+        double* st = p.stats + ((size_t)cur * p.Cout + n0 + tid) * 2;
+        atomicAdd(st, a1); atomicAdd(st + 1, a2);
+      }
+    }
+    if (p.fin.scale) {
+      __syncthreads();
+      g6d_finalize_stats(p.fin, gridDim.x * gridDim.y, reinterpret_cast<int*>(lds));
+    }
+  }
+}
+
 typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 b16x4 __attribute__((ext_vector_type(4)));
 
@@ -647,69 +757,178 @@ __global__ void __launch_bounds__(128 * NWN, 1) wino16_conv3x3_kernel(const Wino
     __syncthreads();
   }
 
-  // ---------------------------------------------------------------- epilogue (as the fp32 trunk kernel, without statistics)
-  const int co = n0 + wn * 32 + li;
-  f32x4 Y[16];
+  wino_epilogue<THREADS, NWN>(p, acc, lds, tid, wm, wn, li, lh, n0);
+}
+
+// The conv family on the 16-bit kernel (G6dConv.weight_wino16, math_mode 1 / 2): the stride-1 3x3 / 3x3x3 layers of the selector, the
+// refiner feature net and the volume net with the operand prologues of the fp32 kernel — MODE 0 none, 1 InstanceNorm affine(+ReLU)
+// with one table, 2 one table per image group (tables of the block's four quarters in LDS), 3 query x reference multiplier + tables
+// per quarter, shared input images / per-group multiplier maps of a query batch — applied in fp32 when the raw piece is written to
+// LDS (zero padding stays exactly zero), KD = 3 with the depth taps folded into the reduction, statistics / finalisation epilogue.
+// Same chunk (16 channels = two planes), filters and MFMA scheme as wino16_conv3x3_kernel; loads are plain (selected) global loads.
+template <int MM, int MODE, int KD>
+__global__ void __launch_bounds__(256, 1) wino16_conv_kernel(const WinoArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int NWN = 2, THREADS = 256, NPR = 7;
+  constexpr int WU_FLOATS = 16 * 32 * NWN * 8;
+  constexpr int WSTAGE = 2 * WRAW_FLOATS + WU_FLOATS + 4 * THREADS;
+  constexpr int AFF0 = 2 * WSTAGE;
+  using hv4 = typename std::conditional<MM == 1, b16x4, h16x4>::type;
+  using hv8 = typename std::conditional<MM == 1, bf16x8, f16x8>::type;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / NWN, wn = wave % NWN;
+  const int li = lane & 31, lh = lane >> 5;
+  const int n0 = blockIdx.y * (32 * NWN);
+  const int nc16 = p.Cin >> 4;
+  const int c_first = blockIdx.z * p.chunks_per_split;
+  const int c_last = min(KD * nc16, c_first + p.chunks_per_split) - 1;
+
+  int poff[NPR], lsto[NPR], moff[MODE == 3 ? NPR : 1], aoff[MODE != 0 ? NPR : 1];
+  bool pval[NPR];
+  unsigned dbits = 0;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    float sr[2][4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      sr[0][j] = acc[0 + j][r] + acc[4 + j][r] + acc[8 + j][r];
-      sr[1][j] = acc[4 + j][r] - acc[8 + j][r] - acc[12 + j][r];
-    }
-    Y[r] = f32x4{sr[0][0] + sr[0][1] + sr[0][2], sr[0][1] - sr[0][2] - sr[0][3], sr[1][0] + sr[1][1] + sr[1][2], sr[1][1] - sr[1][2] - sr[1][3]};
+  for (int j = 0; j < NPR; ++j) {
+    const int idx = tid + THREADS * j;
+    const int plane = idx / 800, r0 = idx - plane * 800;
+    const int q = r0 / 200, r = r0 - q * 200, pp = r >> 1, half = r & 1;
+    const int py = pp / 10, px = pp - py * 10;
+    const QGeo g = quarter_of(p, q < 4 ? q : 0);
+    const int n = g.n;
+    const int iy = g.oy0 + py - 1, ix = g.ox0 + px - 1;
+    pval[j] = (idx < 1600) & g.valid & ((unsigned)iy < (unsigned)g.H) & ((unsigned)ix < (unsigned)g.W);
+    const int n_in = p.img_mod > 0 ? ((n / p.D) % p.img_mod) * p.D + n % p.D : n;
+    poff[j] = pval[j] ? g.in_off + ((n_in * g.H + iy) * g.W + ix) * g.ld_in + 8 * plane + 4 * half : 0;
+    lsto[j] = idx < 1600 ? plane * WRAW_FLOATS + (q * WQ_PIX + pp) * WRAW_LD + 4 * (half ^ ((py >> 1) & 1))
+                         : 2 * WRAW_FLOATS + WU_FLOATS + 4 * tid;
+    if constexpr (MODE == 3) moff[j] = pval[j] ? (((p.mul_div > 0 ? n / p.mul_div : 0) * p.H + iy) * p.W + ix) * p.Cin + 8 * plane + 4 * half : 0;
+    if constexpr (MODE != 0) aoff[j] = idx < 1600 ? (MODE >= 2 ? q * p.Cin : 0) + 8 * plane + 4 * half : 0;
+    if constexpr (KD == 3) { const int dd = n % p.D; dbits |= (unsigned)(dd > 0) << (2 * j) | (unsigned)(dd < p.D - 1) << (2 * j + 1); }
   }
-  if (p.splits > 1) {
-    constexpr int TILE = THREADS * 64;
-    const int ntiles = gridDim.x * gridDim.y, tile = blockIdx.y * gridDim.x + blockIdx.x;
-    float* part = p.ws + G6D_WS_COUNTERS + (size_t)tile * TILE + tid * 4;
-    const size_t zstride = (size_t)ntiles * TILE;
+  const int slice = p.H * p.W * p.ld_in;
+  f32x4 rp[NPR], rm[MODE == 3 ? NPR : 1];
+  bool rv[NPR];
+  auto load_raw = [&](int chunk) {
+    const int kd = KD == 3 ? chunk / nc16 : 0, cc = KD == 3 ? chunk - kd * nc16 : chunk;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) g6d_store_wt(part + blockIdx.z * zstride + r * (THREADS * 4), Y[r]);
-    if (!g6d_split_arrive(reinterpret_cast<int*>(p.ws) + tile, p.splits, reinterpret_cast<int*>(lds))) return;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) Y[r] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int z = 0; z < p.splits; ++z) {
-      f32x4 v[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) v[r] = *reinterpret_cast<const f32x4*>(part + (size_t)z * zstride + r * (THREADS * 4));
-#pragma unroll
-      for (int r = 0; r < 16; ++r) Y[r] += v[r];
+    for (int j = 0; j < NPR; ++j) {
+      bool v = pval[j];
+      int off = poff[j] + cc * 16;
+      if constexpr (KD == 3) { v &= kd == 1 || ((dbits >> (2 * j + (kd >> 1))) & 1u) != 0; off += (kd - 1) * slice; }
+      rv[j] = v;
+      rp[j] = ldg4(p.in, v ? off : 0);
+      if constexpr (MODE == 3) rm[j] = ldg4(p.mul, v ? moff[j] + cc * 16 : 0);
     }
-  }
-  const float bv = p.bias ? p.bias[co] : 0.f;
-  const bool do_relu = p.relu != 0;
-  const QGeo geo[2] = {quarter_of(p, 2 * wm), quarter_of(p, 2 * wm + 1)};
+  };
+  auto store_raw = [&](int st, int chunk) {
+    const int cc = KD == 3 ? chunk % nc16 : chunk;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const QGeo& g = geo[r >> 3];
-    const int tyy = lh + 2 * ((r >> 2) & 1), txx = r & 3;
-    const int n = g.n; const bool qv = g.valid;
-    const int Hp = g.H >> 1, Wp = g.W >> 1;
-    float y[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        y[a][b] = Y[r][2 * a + b] + bv;
-        if (do_relu) y[a][b] = fmaxf(y[a][b], 0.f);
+    for (int j = 0; j < NPR; ++j) {
+      f32x4 v = rp[j];
+      if constexpr (MODE == 3) v *= rm[j];
+      if constexpr (MODE != 0) {
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(lds + AFF0 + aoff[j] + cc * 16);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(lds + AFF0 + (MODE >= 2 ? 4 : 1) * p.Cin + aoff[j] + cc * 16);
+        v = v * sc + sh;
+        if (p.in_relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
       }
-    const int oy = g.oy0 + 2 * tyy, ox = g.ox0 + 2 * txx;
-    if (p.out_full && qv) {
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-          if (oy + a < g.H && ox + b < g.W)
-            p.out_full[(size_t)g.full_off + ((size_t)(n * g.H + oy + a) * g.W + ox + b) * g.ld_full + co] = y[a][b];
+      *reinterpret_cast<f32x4*>(__builtin_assume_aligned(lds + st * WSTAGE + lsto[j], 16)) = rv[j] ? v : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    if (p.out_pool && qv) {
-      const int py = oy >> 1, px = ox >> 1;
-      if (py < Hp && px < Wp)
-        p.out_pool[(size_t)g.pool_off + ((size_t)(n * Hp + py) * Wp + px) * g.ld_pool + co] = fmaxf(fmaxf(y[0][0], y[0][1]), fmaxf(y[1][0], y[1][1]));
+  };
+  if constexpr (MODE != 0) {
+    constexpr int G = MODE >= 2 ? 4 : 1;
+    for (int i = tid; i < G * p.Cin; i += THREADS) {
+      int g = 0;
+      if constexpr (MODE >= 2) g = p.aff_div > 0 ? (quarter_of(p, i / p.Cin).n / p.D) / p.aff_div : 0;
+      const int c = MODE >= 2 ? i % p.Cin : i;
+      lds[AFF0 + i] = p.in_scale[g * p.Cin + c];
+      lds[AFF0 + G * p.Cin + i] = p.in_shift[g * p.Cin + c];
     }
+    __syncthreads();
   }
+  const char* ubase = reinterpret_cast<const char*>(p.U) + (size_t)n0 * 32;
+  const unsigned lane16 = lane * 16;
+  const unsigned lds_addr0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)lds;
+  auto glds = [&](int chunk, int st, int idx) {
+    const int ab = idx / NWN, h = idx % NWN;
+    const char* g = ubase + (size_t)chunk * ((size_t)p.Cout * 512) + (unsigned)((ab * p.Cout + h * 32) * 32);
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr0 + 4u * (unsigned)(st * WSTAGE + 2 * WRAW_FLOATS + (ab * 32 * NWN + h * 32) * 8));
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(lane16), "s"(g), "s"(dst) : "memory");
+  };
+  auto load_u = [&](int chunk, int st) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) glds(chunk, st, wave * 8 + k);
+  };
+  const int tl = li & 15, ty = tl >> 2, tx = tl & 3;
+  const int apos = lh * WRAW_FLOATS + ((2 * wm + (li >> 4)) * WQ_PIX + (2 * ty) * 10 + 2 * tx) * WRAW_LD;
+  const int bbase = 2 * WRAW_FLOATS + (wn * 32 + li) * 8 + 4 * (lh ^ ((li >> 3) & 1));
+  constexpr int USTRIDE = 32 * NWN * 8;
+
+  f32x16 acc[16];
+#pragma unroll
+  for (int a = 0; a < 16; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+
+  load_u(c_first, 0);
+  load_raw(c_first);
+  store_raw(0, c_first);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  auto xform = [&](int grp, const f32x4 (&dd)[4][4], f32x4 (&vv)[4]) {
+    f32x2 rl[4], rh[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 &a = dd[grp == 0 ? 0 : grp == 2 ? 2 : 1][q], &b = dd[grp == 0 ? 2 : grp == 1 ? 2 : grp == 2 ? 1 : 3][q];
+      if (grp == 1) { rl[q] = pk_add(lo2(a), lo2(b)); rh[q] = pk_add(hi2(a), hi2(b)); }
+      else { rl[q] = pk_sub(lo2(a), lo2(b)); rh[q] = pk_sub(hi2(a), hi2(b)); }
+    }
+    vv[0] = cat2(pk_sub(rl[0], rl[2]), pk_sub(rh[0], rh[2]));
+    vv[1] = cat2(pk_add(rl[1], rl[2]), pk_add(rh[1], rh[2]));
+    vv[2] = cat2(pk_sub(rl[2], rl[1]), pk_sub(rh[2], rh[1]));
+    vv[3] = cat2(pk_sub(rl[1], rl[3]), pk_sub(rh[1], rh[3]));
+  };
+
+  for (int cc = c_first; cc <= c_last; ++cc) {
+    const int c = cc - c_first;
+    const float* S = lds + (c & 1) * WSTAGE;
+    if (cc < c_last) {
+      load_u(cc + 1, (c & 1) ^ 1);
+      load_raw(cc + 1);
+    }
+    hv4 vh[16][2];
+#pragma unroll
+    for (int hs = 0; hs < 2; ++hs) {
+      f32x4 d[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          d[i][j] = *reinterpret_cast<const f32x4*>(S + apos + 4 * (hs ^ (ty & 1) ^ (i >> 1)) + (i * 10 + j) * WRAW_LD);
+#pragma unroll
+      for (int grp = 0; grp < 4; ++grp) {
+        f32x4 v[4];
+        xform(grp, d, v);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) vh[grp * 4 + q][hs] = __builtin_convertvector(v[q], hv4);
+      }
+    }
+#pragma unroll
+    for (int ab = 0; ab < 16; ++ab) {
+      const f32x4 uraw = *reinterpret_cast<const f32x4*>(S + bbase + ab * USTRIDE);
+      const hv8 a8 = __builtin_shufflevector(vh[ab][0], vh[ab][1], 0, 1, 2, 3, 4, 5, 6, 7);
+      const hv8 b8 = __builtin_bit_cast(hv8, uraw);
+      if constexpr (MM == 1) acc[ab] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, b8, acc[ab], 0, 0, 0);
+      else acc[ab] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a8, b8, acc[ab], 0, 0, 0);
+    }
+    if (cc < c_last) store_raw((c & 1) ^ 1, cc + 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  wino_epilogue<THREADS, NWN>(p, acc, lds, tid, wm, wn, li, lh, n0);
 }
 
 // ---- launch: tile width, split over the chunks, instantiation
@@ -759,7 +978,7 @@ int wino_run(WinoArgs& a, int mode, int kd, float* workspace, size_t workspace_b
   // steps: small grids leave CUs idle and grids just above a multiple of 256 pay a nearly empty last round.  Pick the split
   // count with the smallest modelled time: rounds x block time + the hand-off (partial images written and read back, the
   // serial re-read of a tile's sp slabs of 64 KB by its last block).  The constants can be overridden for measurements.
-  const int nchunks = a.mm ? a.Cin / 16 : kd * (a.Cin / 8);       // the 16-bit kernel's chunk is a pair of 8-channel chunks
+  const int nchunks = a.mm ? kd * (a.Cin / 16) : kd * (a.Cin / 8);  // the 16-bit kernels' chunk is a pair of 8-channel chunks
   int splits = 1;
   const long long grid2 = blocks * (a.Cout / (32 * nwn));
   const int slots = 256 * (nwn == 1 ? 2 : 1);
@@ -788,16 +1007,29 @@ int wino_run(WinoArgs& a, int mode, int kd, float* workspace, size_t workspace_b
   static const bool debug = []() { const char* e = getenv("G6D_WINO_DEBUG"); return e && e[0] == '1'; }();
   if (debug) fprintf(stderr, "wino %d seg, N=%d %dx%dx%d->%d kd=%d mode=%d: grid %lld x %d splits of %d chunks\n", a.nseg, a.N, a.H, a.W, a.Cin,
                      a.Cout, kd, mode, grid2, splits, cps);
-  if (a.mm) {                                   // reduced-precision trunk kernel (MODE 0, 2-D only)
+  if (a.mm) {                                   // 16-bit kernels: the trunk one (MODE 0, 2-D, buffer loads) or the conv-family one
     if (nwn != 2) { g6d_set_error("wino16: Cout % 64 == 0 expected"); return G6D_EINVAL; }
-    const size_t lds16 = 2 * (size_t)(2 * WRAW_FLOATS + 16 * 64 * 8 + 4 * 256) * sizeof(float);
-    auto go = [&](auto V) {
+    const size_t stage16 = (size_t)(2 * WRAW_FLOATS + 16 * 64 * 8 + 4 * 256);
+    const size_t lds16 = (2 * stage16 + (mode == 0 ? 0 : (mode >= 2 ? 8 : 2) * a.Cin)) * sizeof(float);
+    if (lds16 > 160 * 1024) { g6d_set_error("wino16: affine tables do not fit LDS"); return G6D_EINVAL; }
+    auto go_trunk = [&](auto V) {
       constexpr int MM = decltype(V)::value;
       g6d_allow_lds(reinterpret_cast<const void*>(&wino16_conv3x3_kernel<MM, 2>), 160 * 1024);
       hipLaunchKernelGGL((wino16_conv3x3_kernel<MM, 2>), dim3((unsigned)blocks, a.Cout / 64, a.splits), dim3(256), lds16, stream, a);
     };
-    if (a.mm == 1) go(std::integral_constant<int, 1>{}); else go(std::integral_constant<int, 2>{});
-    return g6d_check_launch("wino16_conv3x3");
+    auto go_conv = [&](auto V, auto M, auto K) {
+      constexpr int MM = decltype(V)::value, MODE = decltype(M)::value, KD = decltype(K)::value;
+      g6d_allow_lds(reinterpret_cast<const void*>(&wino16_conv_kernel<MM, MODE, KD>), 160 * 1024);
+      hipLaunchKernelGGL((wino16_conv_kernel<MM, MODE, KD>), dim3((unsigned)blocks, a.Cout / 64, a.splits), dim3(256), lds16, stream, a);
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    auto by_mm = [&](auto M, auto K) { if (a.mm == 1) go_conv(I1{}, M, K); else go_conv(I2{}, M, K); };
+    if (mode == 0 && kd == 1 && !a.stats) { if (a.mm == 1) go_trunk(I1{}); else go_trunk(I2{}); }
+    else if (kd == 3) { if (mode == 0) by_mm(I0{}, I3{}); else if (mode == 1) by_mm(I1{}, I3{}); else if (mode == 2) by_mm(I2{}, I3{});
+                        else { g6d_set_error("wino16: no multiplier prologue for 3x3x3"); return G6D_EINVAL; } }
+    else { if (mode == 0) by_mm(I0{}, I1{}); else if (mode == 1) by_mm(I1{}, I1{}); else if (mode == 2) by_mm(I2{}, I1{}); else by_mm(I3{}, I1{}); }
+    return g6d_check_launch("wino16_conv");
   }
   if (kd == 25) return wino_launch_w<0, 25>(a, blocks, nwn, stream);
   if (kd == 3) return mode == 2 ? wino_launch_w<2, 3>(a, blocks, nwn, stream)
@@ -950,7 +1182,11 @@ extern "C" int g6d_corr2d_wino_multi(const G6dCorrSeg* segs, int nseg, int Cin, 
 // statistics groups = whole images or one group, no forced split.
 bool g6d_wino_eligible(const G6dConv& d) {
   static const bool on = []() { const char* e = getenv("G6D_CONV_WINO"); return !(e && e[0] == '0'); }();
-  if (!on || !d.weight_wino || d.math_mode != 0) return false;
+  static const bool on16 = []() { const char* e = getenv("G6D_CONV_WINO16"); return !(e && e[0] == '0'); }();
+  if (!on) return false;
+  if (d.math_mode != 0) {     // 16-bit kernel: host-rounded 16-bit filters, chunks of 16 channels, 64-channel blocks
+    if (!on16 || !d.weight_wino16 || (d.Cin & 15) || (d.Cout & 63) || !g6d_aligned16(d.weight_wino16)) return false;
+  } else if (!d.weight_wino) return false;
   const bool k2 = d.kd == 1 && d.Di == 1 && d.pd == 0, k3 = d.kd == 3 && d.pd == 1;
   if (!(k2 || k3) || d.kh != 3 || d.kw != 3 || d.ph != 1 || d.pw != 1 || d.sd != 1 || d.sh != 1 || d.sw != 1) return false;
   if ((d.Cin & 7) || (d.Cout & 31) || d.Hi < 6 || d.Wi < 6 || d.out_act > 1 || d.split_k > 1) return false;
@@ -958,22 +1194,26 @@ bool g6d_wino_eligible(const G6dConv& d) {
   if ((d.in_image_mod > 0 || d.mul_group_images > 0) && !k2) return false;
   if (d.stats && d.stat_rows_per_group > 0 && d.stat_rows_per_group % (d.Do * d.Ho * d.Wo)) return false;   // groups = runs of whole images
   if (d.in_scale && d.Cin > 1024) return false;                          // affine tables of the block's four quarters in LDS
-  if (!g6d_aligned16(d.weight_wino) || (d.in_scale && ((d.Cin & 3) != 0))) return false;
+  if ((d.math_mode == 0 && !g6d_aligned16(d.weight_wino)) || (d.in_scale && ((d.Cin & 3) != 0))) return false;
+  if (d.math_mode != 0 && d.mul && d.kd != 1) return false;
   // Profitability (measured per layer, profiles/r02_layer_table.md): a block pays ~4 us of prologue / output transform and the
   // kernel holds a whole SIMD per wave, so layers with a short reduction (K = kd*Cin < 128: 64-channel inputs) or little total work
   // (M * K * Cout < 1.5e8: the 7-image 8x8 / 16x16 feature-net layers, the 8^3 volume layer) stay on the direct kernels.
   // (G6D_WINO_MIN_WORK is read per call so that tests can send small shapes down this path; 0 disables the rule.)
   const char* mw = getenv("G6D_WINO_MIN_WORK");
-  const double min_work = mw ? atof(mw) : 1.5e8;
+  // The 16-bit kernel competes with direct kernels that already run 16-bit MFMAs at twice the fp32 rate while its own transforms
+  // stay fp32 work: measured per layer (profiles/r03_layer_table_fp16.md) it wins from K >= 192 and ~9e8 multiply-adds upwards.
+  const double min_work = mw ? atof(mw) : (d.math_mode ? 9e8 : 1.5e8);
   const double M = (double)d.N * d.Di * d.Hi * d.Wi, K = (double)d.kd * d.Cin;
-  if (min_work > 0 && (K < 128 || M * K * d.Cout < min_work)) return false;
+  if (min_work > 0 && (K < (d.math_mode ? 192 : 128) || M * K * d.Cout < min_work)) return false;
   if ((long long)d.N * d.Di * ((d.Hi + 7) / 8) * ((d.Wi + 7) / 8) >= (1ll << 31)) return false;           // quarter list
   return (long long)(d.in_image_mod > 0 ? d.in_image_mod : d.N) * d.Di * d.Hi * d.Wi * d.ld_in < (1ll << 29);      // 2^31 bytes: the bound of the buffer loads
 }
 
 int g6d_wino_launch(const G6dConv& d, hipStream_t stream) {
   WinoArgs a = {};
-  a.in = d.in; a.U = d.weight_wino; a.bias = d.bias; a.out_full = d.out; a.out_pool = nullptr;
+  a.in = d.in; a.U = d.math_mode ? reinterpret_cast<const float*>(d.weight_wino16) : d.weight_wino; a.mm = d.math_mode;
+  a.bias = d.bias; a.out_full = d.out; a.out_pool = nullptr;
   a.D = d.Di; a.N = d.N * d.Di; a.H = d.Hi; a.W = d.Wi; a.Cin = d.Cin; a.ld_in = d.ld_in; a.Cout = d.Cout; a.ld_full = d.ld_out;
   a.ld_pool = 0; a.relu = d.out_act == 1;
   a.mul = d.mul; a.in_scale = d.in_scale; a.in_shift = d.in_shift; a.in_relu = d.in_relu;

@@ -37,6 +37,7 @@ class G6dConv(C.Structure):
         ("fin_scale", C.c_void_p), ("fin_shift", C.c_void_p), ("fin_counter", C.c_void_p),
         ("fin_count", C.c_double), ("fin_eps", C.c_double), ("fin_groups", C.c_int32),
         ("in_image_mod", C.c_int32), ("mul_group_images", C.c_int32), ("reserved_", C.c_int32),
+        ("weight_wino16", C.c_void_p),
     ]
 
 

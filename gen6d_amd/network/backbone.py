@@ -66,6 +66,14 @@ def winograd_filters_taps(w_taps, kd=1):
     return torch.cat([winograd_filters(w[k].contiguous()) for k in range(kd)], 0).contiguous()
 
 
+def winograd_filters16_taps(w_taps, kd, dtype):
+    """[Cout, kd*9, Cin] -> [kd*Cin/16, 16, Cout, 16] in `dtype`: one winograd_filters16 block per depth tap (G6dConv.weight_wino16)."""
+    co, taps, ci = w_taps.shape
+    assert taps == kd * 9
+    w = w_taps.reshape(co, kd, 3, 3, ci).permute(1, 0, 4, 2, 3)
+    return torch.cat([winograd_filters16(w[k].contiguous(), dtype) for k in range(kd)], 0).contiguous()
+
+
 def winograd_corr_filters(w_taps, k):
     """Correlation filters [Cout, k*k, Cin] (tap = ky*k + kx), k = 3*kb -> U [kb*kb*Cin/8, 16, Cout, 8] for g6d_corr2d_wino_multi:
     the k x k filter cut into kb x kb blocks of 3x3 taps, each transformed like a trunk filter (winograd_filters), block-major

@@ -169,6 +169,15 @@ def conv(x, w, bias, out, ksize=(1, 1, 1), stride=(1, 1, 1), pad=(0, 0, 0), mul=
             raise ValueError(f"conv.mul: expected contiguous {want}")
     if w_wino is not None and (tuple(w_wino.shape) != (kd * (Cin // 8), 16, Cout, 8) or not w_wino.is_contiguous()):
         raise ValueError(f"conv.w_wino: expected contiguous {(kd * (Cin // 8), 16, Cout, 8)}, got {tuple(w_wino.shape)}")
+    u16 = None
+    if MATH_MODE and w_wino is not None and Cin % 16 == 0 and Cout % 64 == 0:
+        # reduced-precision mode: the layer's Winograd filters rounded to the operand type, built once per (layer, type) and kept
+        # on the fp32 filter tensor (a new weight pack drops both)
+        cache = w_wino.__dict__.setdefault("_g6d_u16", {})
+        if MATH_MODE not in cache:
+            from .network.backbone import winograd_filters16_taps
+            cache[MATH_MODE] = winograd_filters16_taps(w, kd, {1: torch.bfloat16, 2: torch.float16}[MATH_MODE])
+        u16 = cache[MATH_MODE]
     ws = workspace(x.device)
     d = _lib.G6dConv(
         in_=x.data_ptr(), mul=mul.data_ptr() if mul is not None else None,
@@ -180,7 +189,8 @@ def conv(x, w, bias, out, ksize=(1, 1, 1), stride=(1, 1, 1), pad=(0, 0, 0), mul=
         kd=kd, kh=kh, kw=kw, sd=stride[0], sh=stride[1], sw=stride[2], pd=pad[0], ph=pad[1], pw=pad[2],
         in_relu=int(in_relu), in_affine_per_n=int(per_n), out_act=int(out_act),
         stat_rows_per_group=int(rows_per_group), split_k=int(split_k), math_mode=int(MATH_MODE),
-        weight_wino=w_wino.data_ptr() if w_wino is not None else None, in_image_mod=int(in_mod), mul_group_images=int(mul_group))
+        weight_wino=w_wino.data_ptr() if w_wino is not None else None, in_image_mod=int(in_mod), mul_group_images=int(mul_group),
+        weight_wino16=u16.data_ptr() if u16 is not None else None)
     fin = None
     if finalize is not None:
         if stats is None:

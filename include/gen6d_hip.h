@@ -113,6 +113,11 @@ typedef struct G6dConv {
   int32_t in_image_mod;
   int32_t mul_group_images;
   int32_t reserved_;
+  const void* weight_wino16;    /* optional, used when math_mode != 0: the Winograd-domain filters ROUNDED to the operand type of
+                                   math_mode (bf16 / fp16), [kd][Cin/16][16][Cout][16] 16-bit values in the layout of
+                                   g6d_wino16_conv3x3_multi's U16 (per depth tap for 3x3x3).  Eligible layers (as weight_wino, and
+                                   Cin % 16 == 0, Cout % 64 == 0) then run on the 16-bit Winograd kernel instead of the direct kernels
+                                   with 16-bit operands.  NULL = never. */
 } G6dConv;
 
 int g6d_conv_igemm(const G6dConv* desc, g6d_stream_t stream);

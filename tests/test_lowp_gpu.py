@@ -160,3 +160,66 @@ def test_wino16_conv3x3_multi(mode, sizes, Cin, Cout, relu, full, pool):
                 e_ref = (yps[i].cpu().double() - refp).abs().max().item() / rng
                 assert e_own <= 3e-4 and e_ref <= TOL[mode], (i, e_own, e_ref)
     record("test_wino16_conv3x3_multi", f"{mode} {sizes} {Cin}->{Cout}", e_ref, TOL[mode], note="relative to range")
+
+
+# conv-family layers on the 16-bit Winograd kernel (G6dConv.weight_wino16): every operand prologue of the fp32 kernel, the depth fold,
+# statistics + finalisation, query-batch addressing (image-group tables, shared input images, per-group multiplier maps)
+WINO16_CONV_CASES = [
+    dict(N=6, D=1, H=16, W=16, Cin=128, Cout=64),                                                # MODE 0, 2-D
+    dict(N=5, D=1, H=13, W=18, Cin=64, Cout=128, aff=1, single=True, relu=True, stats=5),        # MODE 1 + statistics, ragged extents
+    dict(N=12, D=1, H=16, W=16, Cin=128, Cout=64, aff=3, relu=True, stats=3),                    # MODE 2: a table per 3 images
+    dict(N=12, D=1, H=16, W=16, Cin=256, Cout=64, aff=6, mul=6, in_mod=6, stats=6),              # MODE 3: query batch of 2 over 6 shared images
+    dict(N=2, D=8, H=8, W=8, Cin=64, Cout=64, k3=True),                                          # 3x3x3, MODE 0
+    dict(N=2, D=6, H=10, W=12, Cin=128, Cout=64, k3=True, aff=1, relu=True, stats=1),            # 3x3x3, table per volume, statistics
+    dict(N=1, D=8, H=8, W=8, Cin=64, Cout=128, k3=True, aff=1, single=True, relu=True, stats=1),  # 3x3x3, one table
+]
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+@pytest.mark.parametrize("case", WINO16_CONV_CASES)
+def test_conv_wino16_family(mode, case, monkeypatch):
+    import ctypes as C
+    import ref_ops
+    from gen6d_amd import ops
+    from gen6d_amd.network.backbone import winograd_filters_taps
+    monkeypatch.setenv("G6D_WINO_MIN_WORK", "0")
+    c = case
+    g = torch.Generator().manual_seed(11 + c["Cin"] + c["N"])
+    kd = 3 if c.get("k3") else 1
+    N, D, H, W, Cin, Cout = c["N"], c["D"], c["H"], c["W"], c["Cin"], c["Cout"]
+    in_mod, mul_g, per_n = c.get("in_mod", 0), c.get("mul", 0), c.get("aff", 0)
+    x = _rand(g, in_mod or N, D, H, W, Cin)
+    w = _rand(g, Cout, kd * 9, Cin, scale=(1.0 / (kd * 9 * Cin)) ** 0.5 * 3)
+    b = _rand(g, Cout, scale=0.2)
+    mul = _rand(g, N // mul_g, H, W, Cin) if mul_g else None
+    G = (N + per_n - 1) // per_n if per_n else 0
+    one = bool(c.get("single"))                                         # the single-table prologue (MODE 1)
+    sc = (_rand(g, 1 if one else G, Cin) * 0.5 + 1.0) if per_n else None
+    sh = _rand(g, 1 if one else G, Cin, scale=0.3) if per_n else None
+    out = torch.empty((N, D, H, W, Cout), device="cuda")
+    sg = c.get("stats", 0)
+    stats = torch.zeros((N // sg, Cout, 2), dtype=torch.float64, device="cuda") if sg else None
+    kw = dict(ksize=(kd, 3, 3), pad=(kd // 2, 1, 1), in_relu=bool(c.get("relu")), per_n=0 if one else per_n, in_mod=in_mod, mul_group=mul_g,
+              rows_per_group=sg * D * H * W if sg else 0)
+    cu = lambda t: t.cuda() if t is not None else None
+    u = winograd_filters_taps(w, kd).cuda()
+    with ops.math_mode(mode):
+        fin = ops.conv(cu(x), cu(w), cu(b), out, mul=cu(mul), in_scale=cu(sc), in_shift=cu(sh), stats=stats, w_wino=u,
+                       finalize=sg * D * H * W if sg else None, **kw)
+        assert mode and u._g6d_u16                                    # the 16-bit filters were built and handed over
+    ref = torch.empty((N, D, H, W, Cout), dtype=torch.float64)
+    rstats = torch.zeros((N // sg, Cout, 2), dtype=torch.float64) if sg else None
+    dbl = lambda t: t.double() if t is not None else None
+    rfin = ref_ops.conv(dbl(x), dbl(w), dbl(b), ref, mul=dbl(mul), in_scale=dbl(sc), in_shift=dbl(sh), stats=rstats,
+                        finalize=sg * D * H * W if sg else None, **kw)
+    err = (out.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+    record("test_conv_wino16_family", f"{mode} N={N} {D}x{H}x{W}x{Cin}->{Cout} kd={kd} aff={per_n} mul={mul_g} mod={in_mod} stats={sg}", err, TOL[mode],
+           note="relative to range")
+    assert err <= TOL[mode], err
+    if sg:
+        # statistics are sums over the kernel's own outputs: compare with the sums of what it wrote (fp64, tight), and the finalised
+        # affine with the reference's loosely (it carries the operand rounding)
+        o = out.cpu().double().reshape(N // sg, -1, Cout)
+        np.testing.assert_allclose(stats[:, :, 0].cpu().numpy(), o.sum(1).numpy(), rtol=1e-6, atol=1e-4)
+        np.testing.assert_allclose(stats[:, :, 1].cpu().numpy(), (o * o).sum(1).numpy(), rtol=1e-6, atol=1e-4)
+        assert (fin[0].cpu().double() - rfin[0]).abs().max().item() <= 20 * TOL[mode] * rfin[0].abs().max().item()
