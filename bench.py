@@ -256,9 +256,9 @@ def main():
     if rank != 0:
         return
     # HBM traffic of the dominant kernel family cannot be read without rocprofv3: it is taken from the committed PMC
-    # summary of the same command (profiles/r01_pmc_conv_traffic.json, produced with tools/rocpd_pmc.py), else null
+    # summary of the same command (profiles/rNN_pmc_conv_traffic.json, newest round first; tools/pmc_conv_traffic.py), else null
     traffic_json, traffic_src = {}, None
-    for name in ("r02_pmc_conv_traffic.json", "r01_pmc_conv_traffic.json"):
+    for name in ("r03_pmc_conv_traffic.json", "r02_pmc_conv_traffic.json", "r01_pmc_conv_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 traffic_json = json.load(f)
@@ -295,6 +295,11 @@ def main():
                      "launches_per_step": len(pp) / args.steps, "launches_per_query": len(pp) / args.steps / B,
                      "gflop_per_launch": fl / len(pp) / 1e9, "avg_launch_ms": ms / len(pp), "ms_per_step": ms / args.steps,
                      "ms_per_query": ms / args.steps / B, "measured": how}
+        # algorithmic bytes of a launch = every operand once (input, multiplier map, filters, output); traffic / that = re-reads
+        ab = sum(p[4] for p in pp if len(p) > 4) / len(pp)
+        fams[key]["algorithmic_bytes_per_launch"] = ab
+        if tj.get("hbm_bytes_per_launch") and ab > 0:
+            fams[key]["traffic_over_algorithmic"] = tj["hbm_bytes_per_launch"] / ab
         if key == "conv":
             fams[key]["conv_ms_per_step"] = ms / args.steps
         else:

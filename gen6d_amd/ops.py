@@ -210,7 +210,9 @@ def conv(x, w, bias, out, ksize=(1, 1, 1), stride=(1, 1, 1), pad=(0, 0, 0), mul=
         fl = 2.0 * N * Do * Ho * Wo * Cout * kd * kh * kw * Cin
         PROFILE.append((fl / 2.25 if fam == 2 else fl, e0, e1,            # Winograd kernel: FLOPs executed in the transform domain
                         ("wino3x3 " if fam == 2 else "") + f"conv N={N} in={Di}x{Hi}x{Wi}x{Cin} out={Do}x{Ho}x{Wo}x{Cout} k={kd}x{kh}x{kw} s={stride[0]}{stride[1]}{stride[2]}"
-                        f"{' mul' if mul is not None else ''}{' aff' if in_scale is not None else ''}{' stats' if stats is not None else ''}"))
+                        f"{' mul' if mul is not None else ''}{' aff' if in_scale is not None else ''}{' stats' if stats is not None else ''}",
+                        # algorithmic bytes: every operand once (input images, multiplier maps, filters, output)
+                        4.0 * ((in_mod or N) * Di * Hi * Wi * Cin + (mul.numel() if mul is not None else 0) + w.numel() + N * Do * Ho * Wo * Cout)))
     else:
         _lib.check(_lib.load().g6d_conv_igemm(C.byref(d), _stream()), "g6d_conv_igemm")
     if finalize is not None:
@@ -234,7 +236,7 @@ def corr2d_patch(x, w, out, k):
                                            ws.numel() * 4, int(MATH_MODE), _stream()), "g6d_corr2d_patch")
     if PROFILE is not None:
         e1.record()
-        PROFILE.append((flops, e0, e1, f"corr2d_patch in={H}x{W}x{Cin} out={Cout} k={k}x{k}"))
+        PROFILE.append((flops, e0, e1, f"corr2d_patch in={H}x{W}x{Cin} out={Cout} k={k}x{k}", 4.0 * (H * W * (Cin + Cout) + w.numel())))
     return out
 
 
@@ -266,7 +268,8 @@ def corr2d_patch_multi(xs, w, outs, k):
                                                  _stream()), "g6d_corr2d_patch_multi")
     if PROFILE is not None:
         e1.record()
-        PROFILE.append((flops, e0, e1, f"corr2d_patch multi in={'+'.join(sizes)}x{Cin} out={Cout} k={k}x{k}"))
+        PROFILE.append((flops, e0, e1, f"corr2d_patch multi in={'+'.join(sizes)}x{Cin} out={Cout} k={k}x{k}",
+                        4.0 * (sum(x.numel() for x in xs) + sum(o.numel() for o in outs) + w.numel())))
     return outs
 
 
@@ -299,7 +302,8 @@ def corr2d_wino_multi(xs, U, outs, kblocks=5):
     if PROFILE is not None:
         e1.record()
         # FLOPs executed in the Winograd domain = direct form / 2.25 (booked in the Winograd family)
-        PROFILE.append((flops / 2.25, e0, e1, f"wino3x3 corr multi in={'+'.join(sizes)}x{Cin} out={Cout} k={k}x{k} ({kblocks}x{kblocks} blocks of 3x3)"))
+        PROFILE.append((flops / 2.25, e0, e1, f"wino3x3 corr multi in={'+'.join(sizes)}x{Cin} out={Cout} k={k}x{k} ({kblocks}x{kblocks} blocks of 3x3)",
+                        4.0 * (sum(x.numel() for x in xs) + sum(o.numel() for o in outs) + U.numel())))
     return outs
 
 
@@ -454,7 +458,8 @@ def wino_conv3x3(x, U, bias, relu=True, full=True, pool=False):
     if PROFILE is not None:
         e1.record()
         # direct-form FLOPs / 2.25 = multiplications actually executed in the Winograd domain (what the matrix cores do)
-        PROFILE.append((flops / 2.25, e0, e1, f"wino3x3 N={N} in={H}x{W}x{Cin} out={Cout}{' full' if full else ''}{' pool' if pool else ''}"))
+        PROFILE.append((flops / 2.25, e0, e1, f"wino3x3 N={N} in={H}x{W}x{Cin} out={Cout}{' full' if full else ''}{' pool' if pool else ''}",
+                        4.0 * (x.numel() + U.numel() + (y.numel() if full else 0) + (yp.numel() if pool else 0))))
     return y, yp
 
 
@@ -502,7 +507,8 @@ def wino_conv3x3_multi(xs, U, bias, relu=True, full=True, pool=False):
     if PROFILE is not None:
         e1.record()
         sizes = "+".join(f"{x.shape[0]}x{x.shape[1]}x{x.shape[2]}" for x in xs)
-        PROFILE.append((flops / 2.25, e0, e1, f"wino3x3 multi in={sizes}x{Cin} out={Cout}{' full' if full else ''}{' pool' if pool else ''}"))
+        PROFILE.append((flops / 2.25, e0, e1, f"wino3x3 multi in={sizes}x{Cin} out={Cout}{' full' if full else ''}{' pool' if pool else ''}",
+                        4.0 * (sum(x.numel() for x in xs) + U.numel() + (sum(t.numel() for t in ys) if full else 0) + (sum(t.numel() for t in yps) if pool else 0))))
     return ys, yps
 
 
@@ -538,7 +544,8 @@ def wino16_conv3x3_multi(xs, U16, bias, relu=True, full=True, pool=False):
     if PROFILE is not None:
         e1.record()
         sizes = "+".join(f"{x.shape[0]}x{x.shape[1]}x{x.shape[2]}" for x in xs)
-        PROFILE.append((flops / 2.25, e0, e1, f"wino3x3 {'bf16' if mm == 1 else 'fp16'} multi in={sizes}x{Cin} out={Cout}{' full' if full else ''}{' pool' if pool else ''}"))
+        PROFILE.append((flops / 2.25, e0, e1, f"wino3x3 {'bf16' if mm == 1 else 'fp16'} multi in={sizes}x{Cin} out={Cout}{' full' if full else ''}{' pool' if pool else ''}",
+                        4.0 * (sum(x.numel() for x in xs) + U16.numel() / 2 + (sum(t.numel() for t in ys) if full else 0) + (sum(t.numel() for t in yps) if pool else 0))))
     return ys, yps
 
 

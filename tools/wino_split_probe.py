@@ -25,7 +25,13 @@ def main():
             x = torch.randn((n, hh, ww, cin), device=dev)
             U = B.winograd_filters(torch.randn((cout, cin, 3, 3), device=dev) * 0.05)
             b = torch.randn((cout,), device=dev) * 0.1
-            t = timeit(lambda: ops.wino_conv3x3(x, U, b, relu=True, full=not pool, pool=pool), reps)
+            if os.environ.get("LOWP"):            # LOWP=fp16 / bf16: the 16-bit trunk kernel
+                dt = {"fp16": torch.float16, "bf16": torch.bfloat16}[os.environ["LOWP"]]
+                U16 = B.winograd_filters16(torch.randn((cout, cin, 3, 3), device=dev) * 0.05, dt)
+                with ops.math_mode(os.environ["LOWP"]):
+                    t = timeit(lambda: ops.wino16_conv3x3_multi([x], U16, b, relu=True, full=not pool, pool=pool), reps)
+            else:
+                t = timeit(lambda: ops.wino_conv3x3(x, U, b, relu=True, full=not pool, pool=pool), reps)
             tot += t
             print(f"{n}x{hh}x{ww} {cin}->{cout}{' pool' if pool else ''}: {t:.1f}")
     print(f"total {tot:.1f}")
