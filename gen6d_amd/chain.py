@@ -193,7 +193,12 @@ class DeviceChain:
     def predict_many(self, que_imgs, que_Ks, lanes=3, batch=1):
         """Queries [(H,W,3) uint8 numpy or device tensors], intrinsics [3,3] -> list of (pose [3,4] float32 numpy, inter dict).
         `lanes` captured graphs of `batch` queries each are kept in flight; ONE host synchronisation at the end."""
-        imgs = [q if torch.is_tensor(q) else torch.from_numpy(np.array(q, copy=not (q.flags.writeable and q.flags.c_contiguous))) for q in que_imgs]
+        def as_tensor(q):                                # (decoded JPEG frames can be read-only views: torch wants writable memory)
+            if torch.is_tensor(q):
+                return q
+            q = np.asarray(q)
+            return torch.from_numpy(q if (q.flags.writeable and q.flags.c_contiguous) else np.array(q, order="C"))
+        imgs = [as_tensor(q) for q in que_imgs]
         batch = max(1, min(8, int(batch)))
         if (self._lanes is None or len(self._lanes) != lanes or getattr(self, "_batch", 1) != batch or
                 tuple(self._lanes[0][2].shape[1:]) != tuple(imgs[0].shape)):
