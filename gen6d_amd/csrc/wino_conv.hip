@@ -197,7 +197,10 @@ __global__ void __launch_bounds__(128 * NWN, 1) wino_conv3x3_kernel(const WinoAr
   f32x4 rp[NPR], rm[MODE == 3 ? NPR : 1];
   bool rv[NPR];                                               // validity of the piece for the chunk it was loaded for
   auto load_piece = [&](int j, int chunk) {
-    const int kd = KD != 1 ? chunk / nc8 : 0, cc = KD != 1 ? chunk - kd * nc8 : chunk;
+    // reduction order: depth taps outermost for KD = 3; for KD = 25 the 25 block shifts are INNERMOST (chunk-major): the shifted
+    // windows of a block overlap almost completely, so the 25 visits of an 8-channel slice come while its lines are still in L2
+    // (shift-major re-fetched the whole window from the fabric 25 times: 10.5 GB per launch against 0.33 GB of input)
+    const int kd = KD == 25 ? chunk % 25 : (KD != 1 ? chunk / nc8 : 0), cc = KD == 25 ? chunk / 25 : (KD != 1 ? chunk - kd * nc8 : chunk);
     bool v = pval[j];
     int off = poff[j] + cc * 8;
     if constexpr (KD == 3) { v &= kd == 1 || ((dbits >> (2 * j + (kd >> 1))) & 1u) != 0; off += (kd - 1) * slice; }
@@ -226,7 +229,7 @@ __global__ void __launch_bounds__(128 * NWN, 1) wino_conv3x3_kernel(const WinoAr
     for (int j = 0; j < NPR; ++j) load_piece(j, chunk);
   };
   auto store_piece = [&](int j, int st, int chunk) {   // unconditional stores (a branch would serialise them behind one vmcnt(0) each);
-    const int cc = KD != 1 ? chunk % nc8 : chunk;       // the idle pieces of the last round go to a scratch row behind the stages
+    const int cc = KD == 25 ? chunk / 25 : (KD != 1 ? chunk % nc8 : chunk);       // the idle pieces of the last round go to a scratch row behind the stages
     {
       f32x4 v = rp[j];
       if constexpr (MODE == 3) v *= rm[j];

@@ -75,14 +75,16 @@ def winograd_filters16_taps(w_taps, kd, dtype):
 
 
 def winograd_corr_filters(w_taps, k):
-    """Correlation filters [Cout, k*k, Cin] (tap = ky*k + kx), k = 3*kb -> U [kb*kb*Cin/8, 16, Cout, 8] for g6d_corr2d_wino_multi:
-    the k x k filter cut into kb x kb blocks of 3x3 taps, each transformed like a trunk filter (winograd_filters), block-major
-    (block b = kb*bi + bj holds taps [3bi, 3bi+3) x [3bj, 3bj+3))."""
+    """Correlation filters [Cout, k*k, Cin] (tap = ky*k + kx), k = 3*kb -> U [Cin/8 * kb*kb, 16, Cout, 8] for g6d_corr2d_wino_multi:
+    the k x k filter cut into kb x kb blocks of 3x3 taps, each transformed like a trunk filter (winograd_filters), CHUNK-major
+    (row c * kb*kb + b = 8-channel chunk c of block b = kb*bi + bj, which holds taps [3bi, 3bi+3) x [3bj, 3bj+3)): the kernel
+    visits the kb*kb shifts of a chunk back to back."""
     co, taps, ci = w_taps.shape
     kb = k // 3
     assert taps == k * k and k == 3 * kb
     w = w_taps.reshape(co, kb, 3, kb, 3, ci).permute(1, 3, 0, 5, 2, 4)      # [bi, bj, co, ci, 3, 3]
-    return torch.cat([winograd_filters(w[bi, bj].contiguous()) for bi in range(kb) for bj in range(kb)], 0).contiguous()
+    U = torch.stack([winograd_filters(w[bi, bj].contiguous()) for bi in range(kb) for bj in range(kb)], 1)      # [Cin/8, kb*kb, 16, Cout, 8]
+    return U.reshape(-1, *U.shape[2:]).contiguous()
 
 
 class TrunkLayer(tuple):

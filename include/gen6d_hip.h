@@ -148,8 +148,9 @@ int g6d_corr2d_patch_multi(const G6dCorrSeg* segs, int nseg, int Cin, const floa
 /* The 15x15 level of the same correlation (network/detector.py:222-224) on the Winograd kernel of g6d_wino_conv3x3: the filter is
  * cut into kblocks x kblocks (= 5 x 5) blocks of 3x3 taps, out = sum_b conv3x3(in shifted by (3bi-6, 3bj-6), w_b), and the 25 blocks
  * accumulate in the F(2x2,3x3) transform domain: 2.25x fewer multiplications than g6d_corr2d_patch.  Maps as above (all with the
- * same ld_in); U = the sub-filter banks transformed on the host like g6d_wino_conv3x3's U, block-major [25*Cin/8][16][Cout][8]
- * (block b = 5*bi + bj holds w[:, 3bi..3bi+2, 3bj..3bj+2, :]); Cin % 8 == 0, Cout % 32 == 0. */
+ * same ld_in); U = the sub-filter banks transformed on the host like g6d_wino_conv3x3's U, CHUNK-major [Cin/8][25][16][Cout][8]
+ * (row c*25 + b = 8-channel chunk c of block b = 5*bi + bj, which holds w[:, 3bi..3bi+2, 3bj..3bj+2, :]: the 25 shifted visits of a
+ * chunk are consecutive, so the window stays in L2); Cin % 8 == 0, Cout % 32 == 0. */
 int g6d_corr2d_wino_multi(const G6dCorrSeg* segs, int nseg, int Cin, const float* U, int Cout, int kblocks, float* workspace,
                           size_t workspace_bytes, g6d_stream_t stream);
 

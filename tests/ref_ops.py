@@ -82,7 +82,7 @@ def corr2d_wino_multi(xs, U, outs, kblocks=5):
             for bj in range(kb):
                 b = bi * kb + bj
                 sh = xp[:, 3 * bi:3 * bi + H + 2, 3 * bj:3 * bj + W + 2]  # input shifted by (3bi - 6, 3bj - 6) with its halo, zero outside the image
-                y, _ = wino_conv3x3(sh.contiguous(), U[b * nc:(b + 1) * nc], zero_b, relu=False)
+                y, _ = wino_conv3x3(sh.contiguous(), U.view(nc, kb * kb, *U.shape[1:])[:, b].contiguous(), zero_b, relu=False)   # chunk-major rows
                 acc += y[:, 1:H + 1, 1:W + 1]
         o.copy_(acc[:, None])
     return outs
