@@ -102,6 +102,9 @@ def main():
                          "same steps) and reported in the `lowp` object: operands bf16 / fp16, fp32 accumulate; '' = skip.  Default fp16 "
                          "only: bf16's 8-bit mantissa moves the selector logits by more than the top-2 margin of some queries (the "
                          "viewpoint arg-max flips on 1 of the 4 synthetic queries once the trunk runs in bf16) — available as `--lowp bf16,fp16`")
+    ap.add_argument("--lowp-lanes", type=int, default=3,
+                    help="batches in flight during the reduced-precision passes (their kernels are ~2x shorter, so replay gaps weigh "
+                         "more: 342 images/s with 2, 357 with 3; fp32 gains 1 %% from a third lane and keeps the 2 of --lanes)")
     ap.add_argument("--no-cached", action="store_true", help="skip the reference-feature-cache side measurement (`cached` object)")
     ap.add_argument("--chained", action="store_true",
                     help="additionally time the device-resident predict chain (gen6d_amd/chain.py: detection -> crop -> selection "
@@ -363,6 +366,9 @@ def main():
     modes = [m for m in args.lowp.split(",") if m] if (use_graph and world == 1) else []
     # the first re-captured pass after the serialised eager roofline pass measures ~15 % low whatever its type (bf16 first: 169 /
     # fp16 205; fp16 first: fp16 low, bf16 205): one throwaway pass of the first mode precedes the reported ones
+    headline_lanes = lanes
+    if modes:
+        lanes = max(1, args.lowp_lanes)               # (step / images_of read `lanes` when they run)
     for pi, mode in enumerate(modes[:1] + modes):
         with ops.math_mode(mode):
             pipe.capture(lanes=lanes, batch=B)
@@ -376,7 +382,8 @@ def main():
         drain(); torch.cuda.synchronize()
         ldt = time.perf_counter() - t1
         lrows = torch.cat(lrows[:args.steps], 0).cpu()
-        entry = {"dtype": mode, "value": nl * B / ldt, "unit": "images/s", "ms_per_step": ldt / nl * 1e3, "queries": nl * B, "batch": B}
+        entry = {"dtype": mode, "value": nl * B / ldt, "unit": "images/s", "ms_per_step": ldt / nl * 1e3, "queries": nl * B, "batch": B,
+                 "lanes": lanes}
         if (args.sel_refs, args.det_refs) == (64, 32) and os.path.exists(gpath):
             gold = torch.from_numpy(np.load(gpath)["rows"]).float()
             ref = torch.stack([gold[j] for i in range(args.steps) for j in images_of(args.warmup + i)])
@@ -390,6 +397,7 @@ def main():
             lowp[mode] = entry
     if lowp:
         result["lowp"] = lowp
+    lanes = headline_lanes
 
     # ---- reference-feature caching: the refiner's 6 reference crops per step skip the trunk + feature net when
     #      their (view, angle bucket) key repeats; in this workload the canned crops repeat in every step of every query (hit rate 1 after
