@@ -91,6 +91,7 @@ def main():
     shutil.copy(os.path.join(G, "pmc_conv_traffic.json"), os.path.join(P, f"{RND}_pmc_conv_traffic.json"))
     for src, dst in (("bench_final.json", "bench.json"), ("layer_table.md", "layer_table.md"), ("trunk_bench.md", "trunk_bench.md"),
                      ("layer_table_b8.md", "layer_table_batch8.md"), ("layer_table_b1.md", "layer_table_batch1.md"),
+                     ("layer_table_fp16.md", "layer_table_fp16.md"),
                      ("batch_sweep_all.txt", "batch_sweep.txt"), ("prof_b1_serial_stats.md", "kernel_stats_single_query.md"),
                      ("bench_gpus2.json", "bench_gpus2.json"), ("bench_gpus2_shard.json", "bench_gpus2_shard_refs.json"),
                      ("bench_chained.json", "bench_chained.json")):

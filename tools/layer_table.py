@@ -56,12 +56,13 @@ def main():
             stage_us = e0.elapsed_time(e1) / reps * 1e3
             n = len(runs[0])
             tot_us = tot_fl = 0.0
-            print(f"\n## {name}: {n} MFMA-family launches; whole stage {stage_us:.0f} us = {stage_us / B:.0f} us per query\n\n| layer | us | TFLOP/s |\n|---|---|---|")
+            print(f"\n## {name}: {n} MFMA-family launches; whole stage {stage_us:.0f} us = {stage_us / B:.0f} us per query\n\n| layer | us | TFLOP/s | algorithmic GB/s |\n|---|---|---|---|")
             for i in range(n):
                 us = min(run[i][1].elapsed_time(run[i][2]) for run in runs) * 1e3
                 fl = runs[0][i][0]
                 tot_us += us; tot_fl += fl
-                print(f"| {runs[0][i][3]} | {us:.1f} | {fl / us / 1e6:.1f} |")
+                gbs = f" {runs[0][i][4] / us / 1e3:.0f} |" if len(runs[0][i]) > 4 else ""     # algorithmic bytes (every operand once) / time
+                print(f"| {runs[0][i][3]} | {us:.1f} | {fl / us / 1e6:.1f} |{gbs}")
             print(f"| **total** | {tot_us:.0f} ({tot_us / B:.0f} per query) | {tot_fl / tot_us / 1e6:.1f} |")
 
 

@@ -14,3 +14,4 @@ python $R/tools/rocpd_pmc.py /tmp/pu/pmc_results.db MfmaUtil > $R/gpurun_out/pmc
 cd $R
 BATCH=8 python tools/layer_table.py > gpurun_out/layer_table_b8.md 2>&1
 BATCH=1 python tools/layer_table.py > gpurun_out/layer_table_b1.md 2>&1
+BATCH=8 LOWP=fp16 python tools/layer_table.py > gpurun_out/layer_table_fp16.md 2>&1
