@@ -119,8 +119,8 @@ __device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
 // of all images of all segments form one flat list, four consecutive ones per block: no block-level padding on odd quarter
 // counts, and small maps (<= 8x8 pixels = one quarter per image) simply put four images into a block.
 struct QGeo { int n, oy0, ox0; bool valid; int H, W, ld_in, ld_full, ld_pool, in_off, full_off, pool_off; };
-__device__ __forceinline__ QGeo quarter_of(const WinoArgs& p, int q) {
-  const int Q = blockIdx.x * 4 + q;
+__device__ __forceinline__ QGeo quarter_of(const WinoArgs& p, int q, int nq = 4) {
+  const int Q = blockIdx.x * nq + q;
   int sidx = 0;
 #pragma unroll
   for (int k = 1; k < WINO_MAX_SEG; ++k) sidx = (k < p.nseg && Q >= p.seg[k].qstart) ? k : sidx;
@@ -138,13 +138,19 @@ __device__ __forceinline__ QGeo quarter_of(const WinoArgs& p, int q) {
   return g;
 }
 
-template <int MODE, int KD, int NWN>
-__global__ void __launch_bounds__(128 * NWN, 1) wino_conv3x3_kernel(const WinoArgs p) {
+// NWM = 32-tile rows of the block (quarters / 2): 2 = four quarters x 32*NWN channels (the default shape); 1 with NWN = 4 = two quarters x
+// 128 channels — the same four waves, but one staged raw patch feeds twice the output channels: a layer's input is re-read Cout / 128
+// instead of Cout / 64 times (trunk layers with Cout % 128 == 0).
+template <int MODE, int KD, int NWN, int NWM = 2>
+__global__ void __launch_bounds__(64 * NWM * NWN, 1) wino_conv3x3_kernel(const WinoArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int THREADS = 128 * NWN;
-  constexpr int NPR = (800 + THREADS - 1) / THREADS;          // raw-patch pieces per thread and chunk (4 or 7)
+  constexpr int THREADS = 64 * NWM * NWN;
+  constexpr int NQ = 2 * NWM;                                 // quarters per block
+  constexpr int RAWF = NQ * WQ_PIX * WRAW_LD;                 // floats of the raw patch image
+  constexpr int NPR = (200 * NQ + THREADS - 1) / THREADS;     // raw-patch pieces per thread and chunk (2, 4 or 7)
+  constexpr int GL = 16 / NWM;                                // direct-to-LDS filter pieces per wave and chunk
   constexpr int WU_FLOATS = 16 * 32 * NWN * 8;                // [ab][co][8], lane-linear image of the global layout
-  constexpr int WSTAGE = WRAW_FLOATS + WU_FLOATS + 4 * THREADS;   // raw patch, filter image, scratch row for the idle pieces of the last round
+  constexpr int WSTAGE = RAWF + WU_FLOATS + 4 * THREADS;   // raw patch, filter image, scratch row for the idle pieces of the last round
   constexpr int AFF0 = 2 * WSTAGE;                            // affine tables behind the stages
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -166,23 +172,23 @@ __global__ void __launch_bounds__(128 * NWN, 1) wino_conv3x3_kernel(const WinoAr
     const int idx = tid + THREADS * j;
     const int q = idx / 200, r = idx - q * 200, pp = r >> 1, half = r & 1;
     const int py = pp / 10, px = pp - py * 10;
-    const QGeo g = quarter_of(p, q < 4 ? q : 0);
+    const QGeo g = quarter_of(p, q < NQ ? q : 0, NQ);
     const int n = g.n;
     const int iy = g.oy0 + py - 1, ix = g.ox0 + px - 1;
-    pval[j] = (idx < 800) & g.valid & ((unsigned)iy < (unsigned)g.H) & ((unsigned)ix < (unsigned)g.W);
+    pval[j] = (idx < 200 * NQ) & g.valid & ((unsigned)iy < (unsigned)g.H) & ((unsigned)ix < (unsigned)g.W);
     const int n_in = p.img_mod > 0 ? ((n / p.D) % p.img_mod) * p.D + n % p.D : n;      // query batches share the input images
     poff[j] = pval[j] ? g.in_off + ((n_in * g.H + iy) * g.W + ix) * g.ld_in + 4 * half : 0;
-    live[j] = idx < 800;
-    lsto[j] = live[j] ? (q * WQ_PIX + pp) * WRAW_LD + 4 * (half ^ ((py >> 1) & 1)) : WRAW_FLOATS + WU_FLOATS + 4 * tid;
+    live[j] = idx < 200 * NQ;
+    lsto[j] = live[j] ? (q * WQ_PIX + pp) * WRAW_LD + 4 * (half ^ ((py >> 1) & 1)) : RAWF + WU_FLOATS + 4 * tid;
     if constexpr (MODE == 3) moff[j] = pval[j] ? (((p.mul_div > 0 ? n / p.mul_div : 0) * p.H + iy) * p.W + ix) * p.Cin + 4 * half : 0;
-    if constexpr (MODE != 0) aoff[j] = (MODE >= 2 ? (q < 4 ? q : 0) * p.Cin : 0) + 4 * half;
+    if constexpr (MODE != 0) aoff[j] = (MODE >= 2 ? (q < NQ ? q : 0) * p.Cin : 0) + 4 * half;
     if constexpr (KD == 3) { const int dd = n % p.D; dbits |= (unsigned)(dd > 0) << (2 * j) | (unsigned)(dd < p.D - 1) << (2 * j + 1); }
     if constexpr (KD == 25) {
       unsigned m = 0;
 #pragma unroll
       for (int b = 0; b < 5; ++b)
         m |= (unsigned)((unsigned)(iy + 3 * b - 6) < (unsigned)g.H) << b | (unsigned)((unsigned)(ix + 3 * b - 6) < (unsigned)g.W) << (8 + b);
-      smask[j] = ((idx < 800) & g.valid) ? m : 0u;
+      smask[j] = ((idx < 200 * NQ) & g.valid) ? m : 0u;
       rstep[j] = 3 * g.W * g.ld_in;
       poff[j] = g.in_off + ((n * g.H + iy) * g.W + ix) * g.ld_in + 4 * half;      // the UNSHIFTED position (may lie outside: used under smask only)
     }
@@ -235,7 +241,7 @@ __global__ void __launch_bounds__(128 * NWN, 1) wino_conv3x3_kernel(const WinoAr
       if constexpr (MODE == 3) v *= rm[j];
       if constexpr (MODE != 0) {
         const f32x4 sc = *reinterpret_cast<const f32x4*>(lds + AFF0 + aoff[j] + cc * 8);
-        const f32x4 sh = *reinterpret_cast<const f32x4*>(lds + AFF0 + (MODE >= 2 ? 4 : 1) * p.Cin + aoff[j] + cc * 8);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(lds + AFF0 + (MODE >= 2 ? NQ : 1) * p.Cin + aoff[j] + cc * 8);
         v = v * sc + sh;
         if (p.in_relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
       }
@@ -249,10 +255,10 @@ __global__ void __launch_bounds__(128 * NWN, 1) wino_conv3x3_kernel(const WinoAr
     for (int j = 0; j < NPR; ++j) store_piece(j, st, chunk);
   };
   if constexpr (MODE != 0) {                  // InstanceNorm affine tables -> LDS: [G][Cin] scales, then [G][Cin] shifts
-    constexpr int G = MODE >= 2 ? 4 : 1;
+    constexpr int G = MODE >= 2 ? NQ : 1;
     for (int i = tid; i < G * p.Cin; i += THREADS) {
       int g = 0;
-      if constexpr (MODE >= 2) g = p.aff_div > 0 ? (quarter_of(p, i / p.Cin).n / p.D) / p.aff_div : 0;
+      if constexpr (MODE >= 2) g = p.aff_div > 0 ? (quarter_of(p, i / p.Cin, NQ).n / p.D) / p.aff_div : 0;
       const int c = MODE >= 2 ? i % p.Cin : i;
       lds[AFF0 + i] = p.in_scale[g * p.Cin + c];
       lds[AFF0 + G * p.Cin + i] = p.in_shift[g * p.Cin + c];
@@ -270,14 +276,14 @@ __global__ void __launch_bounds__(128 * NWN, 1) wino_conv3x3_kernel(const WinoAr
     const int ab = idx / NWN, h = idx % NWN;
     // wave-uniform source: a 64-bit base per chunk plus a 32-bit piece offset (two scalar adds per piece)
     const char* g = reinterpret_cast<const char*>(ubase) + (size_t)chunk * ((size_t)p.Cout * 512) + (unsigned)((ab * p.Cout + h * 32) * 32);
-    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr0 + 4u * (unsigned)(st * WSTAGE + WRAW_FLOATS + (ab * 32 * NWN + h * 32) * 8));
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr0 + 4u * (unsigned)(st * WSTAGE + RAWF + (ab * 32 * NWN + h * 32) * 8));
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(lane16), "s"(g), "s"(dst) : "memory");
   };
   auto load_u = [&](int chunk, int st) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) glds(chunk, st, wave * 8 + k);
+    for (int k = 0; k < GL; ++k) glds(chunk, st, wave * GL + k);
   };
 
   // ---- fragment bases
@@ -285,7 +291,7 @@ __global__ void __launch_bounds__(128 * NWN, 1) wino_conv3x3_kernel(const WinoAr
   const int apos = ((2 * wm + (li >> 4)) * WQ_PIX + (2 * ty) * 10 + 2 * tx) * WRAW_LD;
   const int abase01 = apos + 4 * (lh ^ (ty & 1));            // patch rows 2ty, 2ty+1   ((py >> 1) & 1 == ty & 1)
   const int abase23 = apos + 4 * (lh ^ (ty & 1) ^ 1);        // patch rows 2ty+2, 2ty+3
-  const int bbase = WRAW_FLOATS + (wn * 32 + li) * 8 + 4 * (lh ^ ((li >> 3) & 1));
+  const int bbase = RAWF + (wn * 32 + li) * 8 + 4 * (lh ^ ((li >> 3) & 1));
   constexpr int USTRIDE = 32 * NWN * 8;                      // floats between (a,b) positions of the filter image
 
   f32x16 acc[16];
@@ -351,8 +357,8 @@ __global__ void __launch_bounds__(128 * NWN, 1) wino_conv3x3_kernel(const WinoAr
       // stretch the dependent pair
       acc[12 + (k & 3)] = __builtin_amdgcn_mfma_f32_32x32x2f32(vD[k & 3][k >> 2], uD[k & 3][k >> 2], acc[12 + (k & 3)], 0, 0, 0);
       if (!WABL(2)) {
-        if (k < 8) glds(cn, (c & 1) ^ 1, wave * 8 + k);
-        else if (k - 8 < NPR) load_piece(k - 8, cn);
+        if (k < GL) glds(cn, (c & 1) ^ 1, wave * GL + k);
+        else if (k - GL < NPR) load_piece(k - GL, cn);
       }
       if (k < 12) {                                // LDS requests in the order of first use: rows 0, 2, fragments 0, row 1, fragments 1, row 3
         const int j0 = 2 * (k & 1);
@@ -374,6 +380,9 @@ __global__ void __launch_bounds__(128 * NWN, 1) wino_conv3x3_kernel(const WinoAr
       for (int m = 0; m < 16; ++m) {
         acc[i * 4 + (m & 3)] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[m & 3][m >> 2], ub[i][m & 3][m >> 2], acc[i * 4 + (m & 3)], 0, 0, 0);
         if (i < 2 && m < 2) { rd_u(i + 2, 2 * m); rd_u(i + 2, 2 * m + 1); }
+        if constexpr (GL == 16) {                    // 16 filter pieces fill the deferred group: the raw pieces follow in the first gaps of group 0
+          if (i == 0 && m >= 2 && m - 2 < NPR && !WABL(2)) load_piece(m - 2, cn);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -439,7 +448,7 @@ __global__ void __launch_bounds__(128 * NWN, 1) wino_conv3x3_kernel(const WinoAr
   const float bv = p.bias ? p.bias[co] : 0.f;
   const bool do_relu = p.relu != 0;
   const bool do_stats = p.stats != nullptr;
-  const QGeo geo[2] = {quarter_of(p, 2 * wm), quarter_of(p, 2 * wm + 1)};      // the wave's two quarters
+  const QGeo geo[2] = {quarter_of(p, 2 * wm, NQ), quarter_of(p, 2 * wm + 1, NQ)};      // the wave's two quarters
   float st1[2] = {0.f, 0.f}, st2[2] = {0.f, 0.f};       // statistics of this lane's column, per quarter of the wave
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -491,8 +500,8 @@ __global__ void __launch_bounds__(128 * NWN, 1) wino_conv3x3_kernel(const WinoAr
     if (tid < 32 * NWN) {
       double a1 = 0.0, a2 = 0.0;
       int cur = -1;
-      for (int q = 0; q < 4; ++q) {
-        const QGeo qg = quarter_of(p, q);
+      for (int q = 0; q < NQ; ++q) {
+        const QGeo qg = quarter_of(p, q, NQ);
         if (!qg.valid) break;
         const int g = p.stats_div > 0 ? (qg.n / p.D) / p.stats_div : 0;
         if (g != cur && cur >= 0) {
@@ -953,12 +962,12 @@ __global__ void __launch_bounds__(256, 1) wino16_conv_kernel(const WinoArgs p) {
 }
 
 // ---- launch: tile width, split over the chunks, instantiation
-template <int MODE, int KD, int NWN>
+template <int MODE, int KD, int NWN, int NWM = 2>
 int wino_launch_t(WinoArgs& a, long long blocks, hipStream_t stream) {
-  constexpr int THREADS = 128 * NWN;
-  const size_t lds_bytes = (2 * (size_t)(WRAW_FLOATS + 16 * 32 * NWN * 8 + 4 * THREADS) + (MODE == 0 ? 0 : (MODE >= 2 ? 8 : 2) * a.Cin)) * sizeof(float);
-  g6d_allow_lds(reinterpret_cast<const void*>(&wino_conv3x3_kernel<MODE, KD, NWN>), 160 * 1024);
-  hipLaunchKernelGGL((wino_conv3x3_kernel<MODE, KD, NWN>), dim3((unsigned)blocks, a.Cout / (32 * NWN), a.splits), dim3(THREADS), lds_bytes,
+  constexpr int THREADS = 64 * NWM * NWN;
+  const size_t lds_bytes = (2 * (size_t)(2 * NWM * WQ_PIX * WRAW_LD + 16 * 32 * NWN * 8 + 4 * THREADS) + (MODE == 0 ? 0 : (MODE >= 2 ? 4 * NWM : 2) * a.Cin)) * sizeof(float);
+  g6d_allow_lds(reinterpret_cast<const void*>(&wino_conv3x3_kernel<MODE, KD, NWN, NWM>), 160 * 1024);
+  hipLaunchKernelGGL((wino_conv3x3_kernel<MODE, KD, NWN, NWM>), dim3((unsigned)blocks, a.Cout / (32 * NWN), a.splits), dim3(THREADS), lds_bytes,
                      stream, a);
   return g6d_check_launch("wino_conv3x3");
 }
@@ -986,14 +995,23 @@ int wino_run(WinoArgs& a, int mode, int kd, float* workspace, size_t workspace_b
     out_elems += (double)g.N * g.H * g.W;
   }
   a.QH = a.seg[0].QH; a.QW = a.seg[0].QW;
-  const long long blocks = (quarters + 3) / 4;
+  // Block shape: four quarters x 64 (32) channels, or — trunk layers with Cout % 128 == 0 — two quarters x 128 channels: the same four
+  // waves and accumulators, half the raw patch and twice the filter tile per chunk, and the layer's input is re-read Cout / 128 times
+  const char* we = getenv("G6D_WINO_WIDE");                // read per call (tests force both shapes): 0 = never, 2 = whenever eligible
+  const bool wide_on = !(we && we[0] == '0'), wide_all = we && we[0] == '2';
+  // (measured per layer, tools/wino_split_probe.py and BATCH=8 tools/layer_table.py with G6D_WINO_WIDE=0/1: -1.5 ... -6 % where the input is
+  // large against the filter bank — the detector's pyramid, the first layers of the crops' trunks; +1 ... 2 % where the doubled filter
+  // stream per block dominates: 16x16 and 8x8 maps of a few crops)
+  const bool wide = wide_on && !a.mm && mode == 0 && kd == 1 && (a.Cout & 127) == 0 && (wide_all || in_extent >= 6ll * 16 * a.Cin * a.Cout);
+  const int nq = wide ? 2 : 4;
+  const long long blocks = (quarters + nq - 1) / nq;
   if (blocks > 0x3fffffffll) { g6d_set_error("wino_conv3x3: grid too large"); return G6D_EINVAL; }
   a.qtotal = (int)quarters;
   if (in_extent * 4 >= (1ll << 31)) { g6d_set_error("wino_conv3x3: input tensor exceeds 2^31 bytes"); return G6D_EINVAL; }
   a.in_bytes = (unsigned)(in_extent * 4);
   // 32-channel (two-wave) blocks only for channel counts that are not multiples of 64: two of them share a CU, so they do not
   // spread a small grid over more CUs — the split over the chunks below does
-  const int nwn = (a.Cout & 63) ? 1 : 2;
+  const int nwn = wide ? 4 : ((a.Cout & 63) ? 1 : 2);
   // Split of the (kd, chunk) list over gridDim.z.  One 64-channel block per CU is resident (512 registers per lane, ~100 KB
   // of LDS) and runs a serial loop of ~2.7 us per chunk, so a launch takes ceil(grid / 256) rounds of (chunks per block)
   // steps: small grids leave CUs idle and grids just above a multiple of 256 pay a nearly empty last round.  Pick the split
@@ -1008,7 +1026,7 @@ int wino_run(WinoArgs& a, int mode, int kd, float* workspace, size_t workspace_b
   static const double m_fix = []() { const char* e = getenv("G6D_WINO_SPLIT_FIX"); return e ? atof(e) : 2.0; }();
   static const double m_per = []() { const char* e = getenv("G6D_WINO_SPLIT_PER"); return e ? atof(e) : 0.6; }();
   const size_t room = workspace && workspace_bytes > G6D_WS_COUNTER_BYTES ? workspace_bytes - G6D_WS_COUNTER_BYTES : 0;
-  const double tile_bytes = (double)grid2 * (128 * nwn) * 64 * sizeof(float);     // one partial image, padded to whole tiles
+  const double tile_bytes = (double)grid2 * (wide ? 256 : 128 * nwn) * 64 * sizeof(float);     // one partial image, padded to whole tiles
   if (room > 0 && grid2 <= G6D_WS_COUNTERS && split_max > 1 && nchunks >= 4) {
     const double out_bytes = out_elems * a.Cout * sizeof(float);
     double best = 1e30;
@@ -1058,6 +1076,7 @@ int wino_run(WinoArgs& a, int mode, int kd, float* workspace, size_t workspace_b
   if (mode == 3) return wino_launch_w<3, 1>(a, blocks, nwn, stream);
   if (mode == 2) return wino_launch_w<2, 1>(a, blocks, nwn, stream);
   if (mode == 1) return wino_launch_w<1, 1>(a, blocks, nwn, stream);
+  if (wide) return wino_launch_t<0, 1, 4, 1>(a, blocks, stream);
   return wino_launch_w<0, 1>(a, blocks, nwn, stream);
 }
 

@@ -541,8 +541,13 @@ WINO_CASES = [
 ]
 
 
+@pytest.mark.parametrize("shape", ["rule", "wide", "square"])      # block shape: by the launcher's rule / 2 quarters x 128 channels / 4 x 64
 @pytest.mark.parametrize("N,H,W,Cin,Cout,relu,full,pool", WINO_CASES)
-def test_wino_conv3x3(ops, N, H, W, Cin, Cout, relu, full, pool):
+def test_wino_conv3x3(ops, N, H, W, Cin, Cout, relu, full, pool, shape, monkeypatch):
+    if shape != "rule":
+        if Cout % 128:
+            pytest.skip("one block shape only")
+        monkeypatch.setenv("G6D_WINO_WIDE", "2" if shape == "wide" else "0")
     """g6d_wino_conv3x3 against F.conv2d (+bias, ReLU, max-pool) in float64: fp32 Winograd F(2x2,3x3) error class."""
     import torch.nn.functional as F
     from gen6d_amd.network.backbone import winograd_filters
@@ -663,8 +668,13 @@ WINO_MULTI_CASES = [
 ]
 
 
+@pytest.mark.parametrize("shape", ["rule", "wide", "square"])
 @pytest.mark.parametrize("sizes,Cin,Cout,relu,full,pool", WINO_MULTI_CASES)
-def test_wino_conv3x3_multi(ops, sizes, Cin, Cout, relu, full, pool):
+def test_wino_conv3x3_multi(ops, sizes, Cin, Cout, relu, full, pool, shape, monkeypatch):
+    if shape != "rule":
+        if Cout % 128:
+            pytest.skip("one block shape only")
+        monkeypatch.setenv("G6D_WINO_WIDE", "2" if shape == "wide" else "0")
     """One launch over several map sizes (flat quarter list across segments) against F.conv2d per segment in float64."""
     import torch.nn.functional as F
     from gen6d_amd.network.backbone import winograd_filters
