@@ -790,6 +790,228 @@ __global__ void __launch_bounds__(128 * NWN, 1) wino16_conv3x3_kernel(const Wino
   wino_epilogue<THREADS, NWN>(p, acc, lds, tid, wm, wn, li, lh, n0);
 }
 
+// Two waves per SIMD for the 16-bit trunk (MODE 0, 2-D, un-split launches): with one 512-register wave per SIMD the chunk of
+// wino16_conv3x3_kernel costs ~8x its matrix-core time because nothing overlaps (ablation table).  Here a block is 512
+// threads = 8 waves with 128 accumulator registers each: the 16 (a,b) positions of a 32-tile x 32-channel output tile are split
+// over two waves (a < 2 / a >= 2), the input transform is done ONCE per tile (the 2 x 2 kernel does it in both channel waves) by
+// 512 work items (tile, 4-channel group, (a,b) half) that leave the rounded V in LDS in fragment order, and the MFMA phase reads
+// V and U fragments with one ds_read_b128 each.  Per chunk: requests of chunk c+2 | transform of chunk c -> V | barrier | 8 MFMAs
+// per wave | raw pieces of chunk c+1 -> LDS | barrier, with the requests two chunks ahead.  LDS: one raw stage (two planes) + 3
+// filter stages + V = 155 KB.
+// The two partial output transforms of a tile (the transform is linear in the (a,b) accumulators) are exchanged through LDS:
+// each wave finishes the 8 accumulator rows (= one quarter) it owns.
+template <int MM>
+__global__ void __launch_bounds__(512, 1) wino16b_conv3x3_kernel(const WinoArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int RAWS = 2 * WRAW_FLOATS;                       // floats of the raw stage (two 8-channel planes)
+  constexpr int US = 16 * 64 * 8;                             // floats of a filter stage ([ab][co][16 x 2 bytes])
+  constexpr int RAW0 = 0, U0 = RAWS, V0 = U0 + 3 * US, SCR = V0 + US;      // ONE raw stage, THREE filter stages, V, scratch row
+  using hv4 = typename std::conditional<MM == 1, b16x4, h16x4>::type;
+  using hv8 = typename std::conditional<MM == 1, bf16x8, f16x8>::type;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n0 = blockIdx.y * 64;
+  const int nc16 = p.Cin >> 4;
+
+  // ---- raw pieces: idx = tid + 512 j < 1600 = 2 planes x 4 quarters x 100 positions x 2 halves
+  unsigned pboff[4]; int lsto[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int idx = tid + 512 * j;
+    const int plane = idx / 800, r0 = idx - plane * 800;
+    const int q = r0 / 200, r = r0 - q * 200, pp = r >> 1, half = r & 1;
+    const int py = pp / 10, px = pp - py * 10;
+    const QGeo g = quarter_of(p, q < 4 ? q : 0);
+    const int iy = g.oy0 + py - 1, ix = g.ox0 + px - 1;
+    const bool v = (idx < 1600) & g.valid & ((unsigned)iy < (unsigned)g.H) & ((unsigned)ix < (unsigned)g.W);
+    pboff[j] = v ? (unsigned)(g.in_off + ((g.n * g.H + iy) * g.W + ix) * g.ld_in + 8 * plane + 4 * half) << 2 : 0x80000000u;
+    lsto[j] = idx < 1600 ? plane * WRAW_FLOATS + (q * WQ_PIX + pp) * WRAW_LD + 4 * (half ^ ((py >> 1) & 1)) : SCR - RAW0 + 4 * (tid & 63);
+  }
+  const auto in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  // Requests run TWO chunks ahead (a chunk's work is shorter than a first-touch load: one chunk of lead left the kernel waiting on
+  // memory, ablation 2): the raw pieces of chunk c+2 wait in the register set of c's parity, the filter tiles in the third stage.
+  f32x4 rp[2][4];
+  auto load_raw = [&](auto S, int chunk) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      rp[decltype(S)::value][j] = __builtin_bit_cast(f32x4, __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, pboff[j], chunk * 64, 0)));
+  };
+  auto store_raw = [&](auto S) {       // (the idle pieces of the last round land in the scratch row)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      *reinterpret_cast<f32x4*>(__builtin_assume_aligned(lds + RAW0 + lsto[j], 16)) = rp[decltype(S)::value][j];
+  };
+  // ---- filter tiles: 32 pieces of 1 KB per chunk, wave w moves pieces 4w .. 4w+3
+  const char* ubase = reinterpret_cast<const char*>(p.U) + (size_t)n0 * 32;
+  const unsigned lane16 = lane * 16;
+  const unsigned lds_addr0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)lds;
+  auto load_u = [&](int chunk, int st) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int idx = wave * 4 + k, ab = idx >> 1, h = idx & 1;
+      const char* g = ubase + (size_t)chunk * ((size_t)p.Cout * 512) + (unsigned)((ab * p.Cout + h * 32) * 32);
+      const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr0 + 4u * (unsigned)(U0 + st * US + (ab * 64 + h * 32) * 8));
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(lane16), "s"(g), "s"(dst) : "memory");
+    }
+  };
+  // ---- transform phase: wave w = (quarter qa, (a,b) half ha); lane = (tile of the quarter, 4-channel group g of the 16)
+  const int qa = wave & 3, ha = wave >> 2;
+  const int tl = lane & 15, ty = tl >> 2, tx = tl & 3, g4 = lane >> 4;
+  const int araw = (g4 >> 1) * WRAW_FLOATS + (qa * WQ_PIX + (2 * ty) * 10 + 2 * tx) * WRAW_LD;
+  const int ahalf = g4 & 1;
+  // V image: [ab][tile 0..63][16 halfs]; this item's 8 bytes of row (ab, qa*16 + tl) at halfs 4*g4
+  // (rows of tiles with bit 3 set carry their two 8-half groups swapped, like the filter rows: the 16-lane groups of the fragment
+  // reads then cover all banks)
+  const int vwr = V0 * 4 + ((8 * ha) * 64 + qa * 16 + tl) * 32 + 8 * (g4 ^ (2 * ((tl >> 3) & 1)));     // bytes from the LDS base, + ab_local * 2048
+  // ---- MFMA phase: wave w = (wa = (a,b) half, wm, wn); lane = (tile / channel li, k half lh)
+  const int wa = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  const int vrd = V0 * 4 + ((8 * wa) * 64 + wm * 32 + li) * 32 + 16 * (lh ^ ((li >> 3) & 1));          // bytes, + ab_local * 2048
+  const int urd = (wn * 32 + li) * 8 + 4 * (lh ^ ((li >> 3) & 1)) + (8 * wa) * 512;     // floats inside a filter stage, + ab_local * 512
+
+  f32x16 acc[8];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+
+  using P0 = std::integral_constant<int, 0>; using P1 = std::integral_constant<int, 1>;
+  load_u(0, 0);
+  load_raw(P0{}, 0);
+  store_raw(P0{});                                  // chunk 0 -> LDS (waits for its pieces)
+  if (nc16 > 1) { load_u(1, 1); load_raw(P1{}, 1); }    // chunk 1: filter stage 1, register set 1
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  char* const ldsb = reinterpret_cast<char*>(lds);
+  // one chunk: requests of c+2 | transform c -> V | barrier | 8 MFMAs | raw pieces of c+1 (set of c+1's parity) -> LDS | barrier
+  auto chunk_step = [&](auto PAR, int c) {
+    using NXT = std::integral_constant<int, decltype(PAR)::value ^ 1>;
+    const float* R = lds + RAW0;
+    const float* Ub = lds + U0 + (c % 3) * US;
+    const bool more = c + 2 < nc16;
+    if (more && !WABL(2)) {                         // the filter pieces first: they must be OLDER than the raw loads the compiler counts
+      load_u(c + 2, (c + 2) % 3);
+      load_raw(PAR, c + 2);                         // set of c's parity: its previous content (chunk c) went to LDS an iteration ago
+    }
+    // transform of the item's 4 channels: rows 0,1,2 (ha = 0: groups a = 0, 1) or 1,2,3 (ha = 1: groups a = 2, 3); the half is
+    // wave-uniform: a scalar branch, no per-lane selects
+    auto transform = [&](auto HA) {
+      constexpr int H = decltype(HA)::value;
+      f32x4 d[3][4];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int row = i + H;
+          d[i][j] = *reinterpret_cast<const f32x4*>(R + araw + 4 * (ahalf ^ ((ty + (row >> 1)) & 1)) + (row * 10 + j) * WRAW_LD);
+        }
+#pragma unroll
+      for (int gl = 0; gl < 2; ++gl) {
+        // H = 0: a=0: d0 - d2, a=1: d1 + d2;   H = 1 (rows 1,2,3 in d[0..2]): a=2: d2 - d1 = d[1] - d[0], a=3: d1 - d3 = d[0] - d[2]
+        f32x2 rl[4], rh[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4& x = H == 0 ? (gl == 0 ? d[0][q] : d[1][q]) : (gl == 0 ? d[1][q] : d[0][q]);
+          const f32x4& y = H == 0 ? d[2][q] : (gl == 0 ? d[0][q] : d[2][q]);
+          if (H == 0 && gl == 1) { rl[q] = pk_add(lo2(x), lo2(y)); rh[q] = pk_add(hi2(x), hi2(y)); }
+          else { rl[q] = pk_sub(lo2(x), lo2(y)); rh[q] = pk_sub(hi2(x), hi2(y)); }
+        }
+        f32x4 vv[4];
+        vv[0] = cat2(pk_sub(rl[0], rl[2]), pk_sub(rh[0], rh[2]));
+        vv[1] = cat2(pk_add(rl[1], rl[2]), pk_add(rh[1], rh[2]));
+        vv[2] = cat2(pk_sub(rl[2], rl[1]), pk_sub(rh[2], rh[1]));
+        vv[3] = cat2(pk_sub(rl[1], rl[3]), pk_sub(rh[1], rh[3]));
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<hv4*>(__builtin_assume_aligned(ldsb + vwr + (gl * 4 + q) * 2048, 8)) = __builtin_convertvector(vv[q], hv4);
+      }
+    };
+    if (!WABL(3) || c == 0) { if (ha == 0) transform(std::integral_constant<int, 0>{}); else transform(std::integral_constant<int, 1>{}); }
+    if (!WABL(1)) __syncthreads();                  // V complete; every read of the raw stage done
+    hv8 a8 = {}, b8 = {};
+#pragma unroll
+    for (int ab = 0; ab < 8; ++ab) {
+      if (!WABL(4) || (c == 0 && ab == 0)) {
+        a8 = *reinterpret_cast<const hv8*>(__builtin_assume_aligned(ldsb + vrd + ab * 2048, 16));
+        b8 = __builtin_bit_cast(hv8, *reinterpret_cast<const f32x4*>(Ub + urd + ab * 512));
+      }
+      if (WINO_ABLATE == 6) { acc[ab][0] += (float)a8[0] * (float)b8[1]; continue; }
+      if constexpr (MM == 1) acc[ab] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, b8, acc[ab], 0, 0, 0);
+      else acc[ab] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a8, b8, acc[ab], 0, 0, 0);
+    }
+    if (c + 1 < nc16 && !WABL(2)) {
+      // chunk c+1 (requested an iteration ago) into the raw stage; everything older than the four raw loads of this iteration has
+      // landed then — its filter tiles too (the compiler's own wait before the stores asks for the same)
+      if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      store_raw(NXT{});
+    }
+    if (!WABL(1)) __syncthreads();
+  };
+  for (int c = 0; c < nc16; c += 2) {
+    chunk_step(P0{}, c);
+    if (c + 1 < nc16) chunk_step(P1{}, c + 1);
+  }
+
+  // ---------------------------------------------------------------- epilogue
+  // partial output transform over the wave's 8 positions: A^T = [1 1 1 0; 0 1 -1 -1] — rows a = 0,1 (wa = 0) or a = 2,3 (wa = 1)
+  f32x4 Y[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float s0[4], s1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (wa == 0) { s0[j] = acc[j][r] + acc[4 + j][r]; s1[j] = acc[4 + j][r]; }
+      else { s0[j] = acc[j][r]; s1[j] = -acc[j][r] - acc[4 + j][r]; }
+    }
+    Y[r] = f32x4{s0[0] + s0[1] + s0[2], s0[1] - s0[2] - s0[3], s1[0] + s1[1] + s1[2], s1[1] - s1[2] - s1[3]};
+  }
+  // the rows this wave does not own go to its slot (8 rows x 64 lanes x 16 bytes; the stages are free behind the loop's last barrier)
+  f32x4* const X = reinterpret_cast<f32x4*>(lds);
+#pragma unroll
+  for (int rr = 0; rr < 8; ++rr) X[(wave * 8 + rr) * 64 + lane] = Y[(wa == 0 ? 8 : 0) + rr];
+  __syncthreads();
+  f32x4 Yo[8];
+#pragma unroll
+  for (int rr = 0; rr < 8; ++rr) Yo[rr] = Y[(wa == 0 ? 0 : 8) + rr] + X[((wave ^ 4) * 8 + rr) * 64 + lane];
+
+  const int co = n0 + wn * 32 + li;
+  const float bv = p.bias ? p.bias[co] : 0.f;
+  const bool do_relu = p.relu != 0;
+  const QGeo g = quarter_of(p, 2 * wm + wa);              // accumulator rows 8 wa .. 8 wa + 7 = the tiles of that quarter
+  if (!g.valid) return;
+  const int Hp = g.H >> 1, Wp = g.W >> 1, n = g.n;
+#pragma unroll
+  for (int rr = 0; rr < 8; ++rr) {
+    const int tyy = lh + 2 * ((rr >> 2) & 1), txx = rr & 3;
+    float y[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        y[a][b] = Yo[rr][2 * a + b] + bv;
+        if (do_relu) y[a][b] = fmaxf(y[a][b], 0.f);
+      }
+    const int oy = g.oy0 + 2 * tyy, ox = g.ox0 + 2 * txx;
+    if (p.out_full) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          if (oy + a < g.H && ox + b < g.W)
+            p.out_full[(size_t)g.full_off + ((size_t)(n * g.H + oy + a) * g.W + ox + b) * g.ld_full + co] = y[a][b];
+    }
+    if (p.out_pool) {
+      const int py = oy >> 1, px = ox >> 1;
+      if (py < Hp && px < Wp)
+        p.out_pool[(size_t)g.pool_off + ((size_t)(n * Hp + py) * Wp + px) * g.ld_pool + co] = fmaxf(fmaxf(y[0][0], y[0][1]), fmaxf(y[1][0], y[1][1]));
+    }
+  }
+}
+
 // The conv family on the 16-bit kernel (G6dConv.weight_wino16, math_mode 1 / 2): the stride-1 3x3 / 3x3x3 layers of the selector, the
 // refiner feature net and the volume net with the operand prologues of the fp32 kernel — MODE 0 none, 1 InstanceNorm affine(+ReLU)
 // with one table, 2 one table per image group (tables of the block's four quarters in LDS), 3 query x reference multiplier + tables
@@ -1064,7 +1286,16 @@ int wino_run(WinoArgs& a, int mode, int kd, float* workspace, size_t workspace_b
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
     using I3 = std::integral_constant<int, 3>;
     auto by_mm = [&](auto M, auto K) { if (a.mm == 1) go_conv(I1{}, M, K); else go_conv(I2{}, M, K); };
-    if (mode == 0 && kd == 1 && !a.stats) { if (a.mm == 1) go_trunk(I1{}); else go_trunk(I2{}); }
+    const char* e2 = getenv("G6D_WINO16_2W");        // (read per call: tests run both kernels) 0 = the one-wave-per-SIMD kernel only
+    const bool two_waves = !(e2 && e2[0] == '0') && mode == 0 && kd == 1 && !a.stats && a.splits == 1;
+    auto go_trunk2 = [&](auto V) {
+      constexpr int MM = decltype(V)::value;
+      const size_t lds2 = (size_t)(2 * WRAW_FLOATS + 4 * 16 * 64 * 8 + 256) * sizeof(float);
+      g6d_allow_lds(reinterpret_cast<const void*>(&wino16b_conv3x3_kernel<MM>), 160 * 1024);
+      hipLaunchKernelGGL((wino16b_conv3x3_kernel<MM>), dim3((unsigned)blocks, a.Cout / 64, 1), dim3(512), lds2, stream, a);
+    };
+    if (two_waves) { if (a.mm == 1) go_trunk2(I1{}); else go_trunk2(I2{}); }
+    else if (mode == 0 && kd == 1 && !a.stats) { if (a.mm == 1) go_trunk(I1{}); else go_trunk(I2{}); }
     else if (kd == 3) { if (mode == 0) by_mm(I0{}, I3{}); else if (mode == 1) by_mm(I1{}, I3{}); else if (mode == 2) by_mm(I2{}, I3{});
                         else { g6d_set_error("wino16: no multiplier prologue for 3x3x3"); return G6D_EINVAL; } }
     else { if (mode == 0) by_mm(I0{}, I1{}); else if (mode == 1) by_mm(I1{}, I1{}); else if (mode == 2) by_mm(I2{}, I1{}); else by_mm(I3{}, I1{}); }

@@ -120,12 +120,16 @@ WINO16_CASES = [
     ([(2, 9, 7), (1, 8, 8), (3, 5, 13)], 128, 64, True, True, False),                        # ragged sizes
     ([(4, 64, 64)], 64, 128, True, False, True),                                             # selector / refiner first Winograd layer
     ([(7, 8, 8)], 512, 512, False, True, False),                                             # small maps: chunk split
+    ([(8, 44, 58), (8, 30, 40), (5, 22, 30), (8, 16, 20)], 256, 256, True, True, True),      # batch-8 pyramid: un-split grid (two-wave kernel), masked quarters
+    ([(24, 32, 32)], 128, 256, True, True, False),                                           # un-split, full output only
 ]
 
 
+@pytest.mark.parametrize("kernel", ["two-waves", "one-wave"])       # G6D_WINO16_2W: un-split launches on wino16b_conv3x3_kernel or not
 @pytest.mark.parametrize("mode", ["bf16", "fp16"])
 @pytest.mark.parametrize("sizes,Cin,Cout,relu,full,pool", WINO16_CASES)
-def test_wino16_conv3x3_multi(mode, sizes, Cin, Cout, relu, full, pool):
+def test_wino16_conv3x3_multi(mode, sizes, Cin, Cout, relu, full, pool, kernel, monkeypatch):
+    monkeypatch.setenv("G6D_WINO16_2W", "1" if kernel == "two-waves" else "0")
     """The trunk's 16-bit Winograd kernel (wino16_conv3x3_kernel: v_mfma_f32_32x32x16_{bf16,f16}, host-rounded filters) against
     (a) the restatement of its own arithmetic (tests/ref_ops.py: fp32 input transform rounded to the operand type, exact products,
     wide accumulation) — tight, and (b) the float64 convolution with the operand-rounding bound of the type."""
