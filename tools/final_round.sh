@@ -1,7 +1,7 @@
 # Round-end measurements on the GPU box (gpurun): full GPU test suite, the bench variants kept under profiles/, then the
 # rocprofv3 round profile (tools/profile_round.sh).  Raw outputs -> gpurun_out/; tools/assemble_profiles.py rNN commits them.
 cd $GRAFT_REPO_ROOT
-export G6D_PARITY_LOG=$PWD/gpurun_out/parity_r02.jsonl; rm -f $G6D_PARITY_LOG
+export G6D_PARITY_LOG=$PWD/gpurun_out/parity_r03.jsonl; rm -f $G6D_PARITY_LOG
 (timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -15) > gpurun_out/final_tests.log; tail -3 gpurun_out/final_tests.log
 unset G6D_PARITY_LOG
 timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err; tail -c 400 gpurun_out/bench_final.json | head -c 300; echo
