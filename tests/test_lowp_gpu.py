@@ -122,6 +122,8 @@ WINO16_CASES = [
     ([(7, 8, 8)], 512, 512, False, True, False),                                             # small maps: chunk split
     ([(8, 44, 58), (8, 30, 40), (5, 22, 30), (8, 16, 20)], 256, 256, True, True, True),      # batch-8 pyramid: un-split grid (two-wave kernel), masked quarters
     ([(24, 32, 32)], 128, 256, True, True, False),                                           # un-split, full output only
+    ([(12, 16, 16)], 32, 64, True, True, True),                                              # two chunks: the request pipeline's shortest case
+    ([(3, 16, 24)], 16, 64, False, True, False),                                             # one chunk
 ]
 
 
