@@ -226,12 +226,175 @@ __global__ void __launch_bounds__(512) corr_patch_kernel(const float* __restrict
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The same correlation with 16-bit matrix-core operands (math_mode 1 / 2) as its own kernel.  corr_patch_kernel<1|2> keeps the fp32
+// structure — one barrier and one weight-tile hand-over per TAP — and that is ~1050 cycles per tap for 64 cycles of 16-bit MFMA.
+// Here a unit (32 channels, ky) stages ALL kw weight tiles at once: the filters come host-rounded and laid out per unit
+// ([unit][kx][32 co][40 halfs]: 32 channels + 8 halfs of padding, 80-byte rows are bank-conflict free for the fragment reads) and
+// go straight to LDS with direct-to-LDS loads (double buffered); the patch is rounded to 16 bits when it is written to LDS
+// ([8 rows][32 + kw - 1 columns][40 halfs], single buffer, the next unit's pieces wait in registers); a wave then runs its
+// 2 kw MFMAs (v_mfma_f32_32x32x16_*) of the unit with one ds_read_b128 per operand and no barrier in between.
+typedef _Float16 c16h4 __attribute__((ext_vector_type(4)));
+typedef __bf16 c16b4 __attribute__((ext_vector_type(4)));
+#define C16_ROW 80                                   // bytes of a (position | tap, co) row: 32 channels x 2 bytes + 16 bytes of padding
+
+template <int MM>
+__global__ void __launch_bounds__(512) corr16_patch_kernel(const float* __restrict__ in_base, const char* __restrict__ w16,
+                                                           float* __restrict__ out_base, const CorrArgs sa, int Cin, int Cout, int kh,
+                                                           int kw, int ph, int pw, int units_per_split, int total_units, int splits,
+                                                           float* __restrict__ ws, int wbuf_bytes) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  using hv4 = typename std::conditional<MM == 1, c16b4, c16h4>::type;
+  using hv8 = typename std::conditional<MM == 1, bf16x8, f16x8>::type;
+  int sidx = 0;
+#pragma unroll
+  for (int k = 1; k < CORR_MAX_SEG; ++k) sidx = (k < sa.nseg && (int)blockIdx.x >= sa.seg[k].tile0) ? k : sidx;
+  const CorrSeg& sg = sa.seg[sidx];
+  const int H = sg.H, W = sg.W, tiles_x = sg.tiles_x, ld_in = sg.ld_in, ld_out = sg.ld_out;
+  const int tile_s = blockIdx.x - sg.tile0, img = tile_s / sg.tiles_img;
+  const float* __restrict__ in = in_base + sg.in_off + (size_t)img * H * W * ld_in;
+  float* __restrict__ out = out_base + sg.out_off + (size_t)img * H * W * ld_out;
+  const int tile = tile_s - img * sg.tiles_img;
+  const int PW = TW + kw - 1;
+  const int npos = TH * PW;
+  char* const ldsb = reinterpret_cast<char*>(lds);
+  const int patch_bytes = (npos * C16_ROW + 1023) & ~1023;
+  const int unit_bytes = kw * 32 * C16_ROW;          // one unit of the filter tensor; wbuf_bytes = that rounded up to whole 1 KB pieces
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int ty0 = (tile / tiles_x) * TH, tx0 = (tile % tiles_x) * TW;
+  const int u_begin = blockIdx.z * units_per_split, u_end = min(total_units, u_begin + units_per_split);
+
+  // patch loader: 16-byte segment `seg` (4 channels) of position p = tid/8 + 64 j
+  const int seg = tid & 7;
+  const int NPL = (npos + 63) / 64;                 // <= 6 for kw <= 15
+  f32x4 rp[6];
+  bool vp[6];
+  auto load_patch = [&](int u) {
+    const int chunk = u / kh, ky = u - chunk * kh;
+    const bool uv = u < u_end;
+    const int c = chunk * 32 + 4 * seg;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      if (j < NPL) {
+        const int p = (tid >> 3) + 64 * j;
+        const int pr = p / PW, pc = p - pr * PW;
+        const int iy = ty0 + pr + ky - ph, ix = tx0 + pc - pw;
+        const bool v = uv & (p < npos) & ((unsigned)iy < (unsigned)H) & ((unsigned)ix < (unsigned)W);
+        vp[j] = v;
+        rp[j] = ldg4(in, v ? (iy * W + ix) * ld_in + c : 0);
+      }
+    }
+  };
+  auto store_patch = [&]() {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      if (j < NPL) {
+        const int p = (tid >> 3) + 64 * j;
+        const f32x4 v = vp[j] ? rp[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p < npos) *reinterpret_cast<hv4*>(__builtin_assume_aligned(ldsb + p * C16_ROW + 8 * seg, 8)) = __builtin_convertvector(v, hv4);
+      }
+    }
+  };
+  // filter tiles of a unit: wbuf_bytes / 1024 pieces of 1 KB, wave w moves pieces w, w + 8, ...
+  const unsigned lds_addr0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)lds;
+  const unsigned lane16 = lane * 16;
+  auto load_w = [&](int u, int buf) {
+    const char* src = w16 + (size_t)u * unit_bytes;
+    const int npieces = wbuf_bytes >> 10;
+    for (int i = wave; i < npieces; i += 8) {
+      const char* g = src + (size_t)i * 1024;
+      const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr0 + (unsigned)(patch_bytes + buf * wbuf_bytes + i * 1024));
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(lane16), "s"(g), "s"(dst) : "memory");
+    }
+  };
+
+  f32x16 acc, acc2;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
+
+  if (u_begin < u_end) {
+    load_w(u_begin, 0);
+    load_patch(u_begin);
+    store_patch();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cur = 0;
+    for (int u = u_begin; u < u_end; ++u) {
+      if (u + 1 < u_end) load_w(u + 1, cur ^ 1);     // (the copies first: older than the loads the compiler counts)
+      load_patch(u + 1);                            // masked beyond u_end
+      const char* A = ldsb + (wave * PW + li) * C16_ROW + 16 * lh;
+      const char* B = ldsb + patch_bytes + cur * wbuf_bytes + li * C16_ROW + 16 * lh;
+      // fragments one tap ahead of their MFMAs (a runtime tap count: the compiler would otherwise wait for every read in front of its use)
+      auto rd = [&](int kx, hv8& a0, hv8& b0, hv8& a1, hv8& b1) {
+        a0 = *reinterpret_cast<const hv8*>(__builtin_assume_aligned(A + kx * C16_ROW, 16));
+        b0 = *reinterpret_cast<const hv8*>(__builtin_assume_aligned(B + kx * 32 * C16_ROW, 16));
+        a1 = *reinterpret_cast<const hv8*>(__builtin_assume_aligned(A + kx * C16_ROW + 32, 16));
+        b1 = *reinterpret_cast<const hv8*>(__builtin_assume_aligned(B + kx * 32 * C16_ROW + 32, 16));
+      };
+      hv8 a0, b0, a1, b1;
+      rd(0, a0, b0, a1, b1);
+      for (int kx = 0; kx < kw; ++kx) {
+        hv8 n0, m0, n1, m1;
+        rd(min(kx + 1, kw - 1), n0, m0, n1, m1);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (MM == 1) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc2, 0, 0, 0);
+        } else {
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc2, 0, 0, 0);
+        }
+        a0 = n0; b0 = m0; a1 = n1; b1 = m1;
+      }
+      __syncthreads();                              // every wave has read its fragments of this unit's patch
+      if (u + 1 < u_end) store_patch();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next unit's filter tiles have landed
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
+
+  if (splits > 1) {
+    constexpr int TILE = TH * TW * 32;
+    float* part = ws + G6D_WS_COUNTERS + (size_t)blockIdx.x * TILE + tid * 4;
+    const size_t zstride = (size_t)gridDim.x * TILE;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      g6d_store_wt(part + blockIdx.z * zstride + q * 2048, f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]});
+    if (!g6d_split_arrive(reinterpret_cast<int*>(ws) + blockIdx.x, splits, reinterpret_cast<int*>(lds))) return;
+    f32x4 sum[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sum[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < splits; ++z) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sum[q] += *reinterpret_cast<const f32x4*>(part + (size_t)z * zstride + q * 2048);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { acc[4 * q] = sum[q][0]; acc[4 * q + 1] = sum[q][1]; acc[4 * q + 2] = sum[q][2]; acc[4 * q + 3] = sum[q][3]; }
+  }
+  const int oy = ty0 + wave;
+  if (oy < H && li < Cout) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ox = tx0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (ox < W) out[((size_t)oy * W + ox) * ld_out + li] = acc[r];
+    }
+  }
+}
+
 }  // namespace
 
 namespace {
 
 int corr_run(const float* in_base, float* out_base, CorrArgs& sa, int Cin, const float* wgt, int Cout, int kh, int kw, float* workspace,
-             size_t workspace_bytes, int math_mode, hipStream_t stream) {
+             size_t workspace_bytes, int math_mode, hipStream_t stream, const void* w16 = nullptr) {
   int tiles = 0;
   for (int k = 0; k < sa.nseg; ++k) {
     CorrSeg& g = sa.seg[k];
@@ -251,7 +414,8 @@ int corr_run(const float* in_base, float* out_base, CorrArgs& sa, int Cin, const
     if (max_s > 64) max_s = 64;
     if ((size_t)max_s > room / per) max_s = (int)(room / per);
     if (max_s < 1 || tiles > G6D_WS_COUNTERS) max_s = 1;
-    static const int slots = []() { const char* e = getenv("G6D_CORR_SLOTS"); return e ? atoi(e) : 512; }();   // two 58 KB blocks per CU
+    static const int slots2 = []() { const char* e = getenv("G6D_CORR_SLOTS"); return e ? atoi(e) : 512; }();   // two 58 KB blocks per CU
+    const int slots = w16 ? 256 : slots2;                  // (the 16-bit kernel's block holds 100+ KB of LDS: one per CU)
     double best = -1.0;
     for (int sp = 1; sp <= max_s; ++sp) {
       const int ups_ = (total_units + sp - 1) / sp;
@@ -263,6 +427,18 @@ int corr_run(const float* in_base, float* out_base, CorrArgs& sa, int Cin, const
   }
   const int ups = (total_units + splits - 1) / splits;
   splits = (total_units + ups - 1) / ups;
+  if (w16) {
+    const int wbuf = (kw * 32 * C16_ROW + 1023) & ~1023;
+    const size_t lds16 = (size_t)((TH * (TW + kw - 1) * C16_ROW + 1023) & ~1023) + 2 * (size_t)wbuf;
+    auto go16 = [&](auto V) {
+      constexpr int MM = decltype(V)::value;
+      g6d_allow_lds(reinterpret_cast<const void*>(&corr16_patch_kernel<MM>), 160 * 1024);
+      hipLaunchKernelGGL(corr16_patch_kernel<MM>, dim3(tiles, 1, splits), dim3(512), lds16, stream, in_base, reinterpret_cast<const char*>(w16),
+                         out_base, sa, Cin, Cout, kh, kw, kh / 2, kw / 2, ups, total_units, splits, workspace, wbuf);
+    };
+    if (math_mode == 1) go16(std::integral_constant<int, 1>{}); else go16(std::integral_constant<int, 2>{});
+    return g6d_check_launch("corr2d_patch16");
+  }
   const size_t lds_bytes = (size_t)(TH * (TW + kw - 1) * LDS_K + 2 * 32 * LDS_K) * sizeof(float);
   auto go = [&](auto V) {
     constexpr int MM = decltype(V)::value;
@@ -324,4 +500,35 @@ extern "C" int g6d_corr2d_patch_multi(const G6dCorrSeg* segs, int nseg, int Cin,
     sa.seg[k] = CorrSeg{0, g.H, g.W, 0, (int)io, (int)oo, g.ld_in, g.ld_out, g.N, 0};
   }
   return corr_run(in0, out0, sa, Cin, wgt, Cout, kh, kw, workspace, workspace_bytes, math_mode, reinterpret_cast<hipStream_t>(stream_));
+}
+
+// g6d_corr2d_patch_multi with 16-bit matrix-core operands on its own kernel (corr16_patch_kernel): w16 = the filters rounded to the
+// operand type of math_mode (1 = bf16, 2 = fp16) on the host, per unit: [(Cin/32) * kh units][kw][32 co][40 x 16 bit] (32 channels of
+// chunk u / kh at tap row u % kh, 8 x 16 bit of zero padding per row; rows co >= Cout zero), followed by >= 1 KB of padding.
+extern "C" int g6d_corr2d_patch16_multi(const G6dCorrSeg* segs, int nseg, int Cin, const void* w16, int Cout, int kh, int kw,
+                                        float* workspace, size_t workspace_bytes, int math_mode, g6d_stream_t stream_) {
+  if (!segs || nseg < 1 || nseg > CORR_MAX_SEG || !w16 || Cin <= 0 || (Cin & 31) || Cout <= 0 || Cout > 32 || !(kh & 1) || !(kw & 1) ||
+      kw > 15 || !g6d_aligned16(w16) || (math_mode != 1 && math_mode != 2)) {
+    g6d_set_error("corr2d_patch16_multi: bad args (1..4 maps, Cin % 32 == 0, Cout <= 32, odd kernel <= 15, math_mode 1 or 2)"); return G6D_EINVAL;
+  }
+  const float* in0 = segs[0].in; float* out0 = segs[0].out;
+  for (int k = 0; k < nseg; ++k) {
+    const G6dCorrSeg& g = segs[k];
+    if (!g.in || !g.out || g.H <= 0 || g.W <= 0 || g.N <= 0 || (g.ld_in & 3) || g.ld_in < Cin || g.ld_out < Cout || !g6d_aligned16(g.in)) {
+      g6d_set_error("corr2d_patch16_multi: bad map"); return G6D_EINVAL;
+    }
+    if (g.in < in0) in0 = g.in;
+    if (g.out < out0) out0 = g.out;
+  }
+  CorrArgs sa = {};
+  sa.nseg = nseg;
+  for (int k = 0; k < nseg; ++k) {
+    const G6dCorrSeg& g = segs[k];
+    const long long io = g.in - in0, oo = g.out - out0;
+    if (io + (long long)g.N * g.H * g.W * g.ld_in >= (1ll << 30) || oo + (long long)g.N * g.H * g.W * g.ld_out >= (1ll << 31)) {
+      g6d_set_error("corr2d_patch16_multi: maps must lie within 2^30 floats of each other (allocate them from one buffer)"); return G6D_EINVAL;
+    }
+    sa.seg[k] = CorrSeg{0, g.H, g.W, 0, (int)io, (int)oo, g.ld_in, g.ld_out, g.N, 0};
+  }
+  return corr_run(in0, out0, sa, Cin, nullptr, Cout, kh, kw, workspace, workspace_bytes, math_mode, reinterpret_cast<hipStream_t>(stream_), w16);
 }

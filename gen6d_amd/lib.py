@@ -51,6 +51,7 @@ SIGNATURES = {
     "g6d_corr2d_patch": [_P, _I, _I, _I, _I, _P, _I, _I, _I, _P, _I, _P, C.c_size_t, _I, _P],
     "g6d_corr2d_patch_multi": [_P, _I, _I, _P, _I, _I, _I, _P, C.c_size_t, _I, _P],
     "g6d_corr2d_wino_multi": [_P, _I, _I, _P, _I, _I, _P, C.c_size_t, _P],
+    "g6d_corr2d_patch16_multi": [_P, _I, _I, _P, _I, _I, _I, _P, C.c_size_t, _I, _P],
     "g6d_stats_finalize": [_P, _I, _D, _D, _P, _P, _P],
     "g6d_affine_act_pool": [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P],
     "g6d_upsample_bilinear": [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P],

@@ -240,6 +240,22 @@ def corr2d_patch(x, w, out, k):
     return out
 
 
+# G6D_CORR16=0: in the reduced-precision mode the correlation stays on corr_patch_kernel with 16-bit operands (one hand-over per tap); A/B aid
+CORR16 = _os.environ.get("G6D_CORR16", "1") != "0"
+
+
+def corr_filters16(w, k, dtype):
+    """Correlation filters [Cout, k*k, Cin] (tap = ky*k + kx, Cin % 32 == 0, Cout <= 32) -> the unit-major 16-bit layout of
+    g6d_corr2d_patch16_multi: [(Cin/32) * k units][k taps kx][32 co][40] (32 channels + 8 zeros per row; rows co >= Cout zero),
+    flattened, followed by 1 KB of zeros."""
+    Cout, taps, Cin = w.shape
+    assert taps == k * k and Cin % 32 == 0 and Cout <= 32
+    v = w.reshape(Cout, k, k, Cin // 32, 32).permute(3, 1, 2, 0, 4)                     # [chunk, ky, kx, co, 32]
+    out = torch.zeros((Cin // 32, k, k, 32, 40), dtype=dtype, device=w.device)
+    out[:, :, :, :Cout, :32] = v.to(dtype)
+    return torch.cat([out.reshape(-1), torch.zeros(512, dtype=dtype, device=w.device)]).contiguous()
+
+
 def corr2d_patch_multi(xs, w, outs, k):
     """corr2d_patch for several map sizes in ONE launch (the scales of the detector's pyramid against the same reference filters):
     xs[i] [N,1,H_i,W_i,Cin] and outs[i] [N,1,H_i,W_i,Cout] dense tensors (N = queries of the batch at that scale), each list cut
@@ -261,14 +277,26 @@ def corr2d_patch_multi(xs, w, outs, k):
     if tuple(w.shape) != (Cout, k * k, Cin) or not w.is_contiguous():
         raise ValueError("corr2d_patch_multi: filter shape mismatch")
     ws = workspace(w.device)
+    # reduced-precision mode: the 16-bit kernel with all kw weight tiles of a unit staged at once (g6d_corr2d_patch16_multi); its
+    # host-rounded, unit-major filters are built once per (filter tensor, type) and kept on the fp32 tensor
+    w16 = None
+    if MATH_MODE and CORR16 and Cin % 32 == 0 and k <= 15:
+        cache = w.__dict__.setdefault("_g6d_c16", {})
+        if MATH_MODE not in cache:
+            cache[MATH_MODE] = corr_filters16(w, k, {1: torch.bfloat16, 2: torch.float16}[MATH_MODE])
+        w16 = cache[MATH_MODE]
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.check(_lib.load().g6d_corr2d_patch_multi(segs, len(xs), Cin, _ptr(w), Cout, k, k, _ptr(ws), ws.numel() * 4, int(MATH_MODE),
-                                                 _stream()), "g6d_corr2d_patch_multi")
+    if w16 is not None:
+        _lib.check(_lib.load().g6d_corr2d_patch16_multi(segs, len(xs), Cin, _ptr(w16), Cout, k, k, _ptr(ws), ws.numel() * 4, int(MATH_MODE),
+                                                       _stream()), "g6d_corr2d_patch16_multi")
+    else:
+        _lib.check(_lib.load().g6d_corr2d_patch_multi(segs, len(xs), Cin, _ptr(w), Cout, k, k, _ptr(ws), ws.numel() * 4, int(MATH_MODE),
+                                                     _stream()), "g6d_corr2d_patch_multi")
     if PROFILE is not None:
         e1.record()
-        PROFILE.append((flops, e0, e1, f"corr2d_patch multi in={'+'.join(sizes)}x{Cin} out={Cout} k={k}x{k}",
+        PROFILE.append((flops, e0, e1, f"corr2d_patch{'16' if w16 is not None else ''} multi in={'+'.join(sizes)}x{Cin} out={Cout} k={k}x{k}",
                         4.0 * (sum(x.numel() for x in xs) + sum(o.numel() for o in outs) + w.numel())))
     return outs
 

@@ -144,6 +144,15 @@ typedef struct G6dCorrSeg {
 } G6dCorrSeg;
 int g6d_corr2d_patch_multi(const G6dCorrSeg* segs, int nseg, int Cin, const float* wgt, int Cout, int kh, int kw,
                            float* workspace, size_t workspace_bytes, int math_mode, g6d_stream_t stream);
+/* The same correlation with 16-bit matrix-core operands on its own kernel (math_mode 1 = bf16, 2 = fp16; fp32 maps in and out, fp32
+ * accumulation): the reference filters are rounded and laid out per unit on the host, once per object — w16 =
+ * [(Cin/32) * kh units][kw][32 co][40 x 16 bit]: unit u holds the 32 channels of chunk u / kh at filter row u % kh, every (tap, co)
+ * row is 32 channels + 8 values of zero padding (rows co >= Cout zero), and >= 1 KB of padding follows the last unit.  All kw weight
+ * tiles of a unit are staged at once, so a wave runs its 2 kw MFMAs without a barrier (g6d_corr2d_patch_multi with math_mode != 0
+ * keeps one hand-over per tap).  Cin % 32 == 0, Cout <= 32, odd kh, odd kw <= 15.  Replaces network/detector.py:222-224 in the
+ * reduced-precision mode. */
+int g6d_corr2d_patch16_multi(const G6dCorrSeg* segs, int nseg, int Cin, const void* w16, int Cout, int kh, int kw,
+                             float* workspace, size_t workspace_bytes, int math_mode, g6d_stream_t stream);
 
 /* The 15x15 level of the same correlation (network/detector.py:222-224) on the Winograd kernel of g6d_wino_conv3x3: the filter is
  * cut into kblocks x kblocks (= 5 x 5) blocks of 3x3 taps, out = sum_b conv3x3(in shifted by (3bi-6, 3bj-6), w_b), and the 25 blocks

@@ -81,6 +81,52 @@ def test_corr2d_patch_lowp(mode):
     assert err <= TOL[mode], err
 
 
+CORR16_CASES = [
+    # segment sizes (N, H, W), Cin, Cout, k
+    ([(1, 30, 40)], 512, 32, 15),                                      # one map, split over the units
+    ([(2, 22, 29), (2, 15, 20), (1, 11, 15), (3, 8, 10)], 64, 32, 15),  # pyramid with batches, ragged tiles, short reduction (2 chunks)
+    ([(8, 44, 58), (8, 30, 40)], 128, 20, 7),                          # batch of 8, fewer than 32 references, 7x7 level
+    ([(1, 9, 33)], 32, 32, 3),                                         # one chunk, 3x3, a second column tile of one column
+]
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+@pytest.mark.parametrize("sizes,Cin,Cout,k", CORR16_CASES)
+def test_corr2d_patch16_multi(mode, sizes, Cin, Cout, k):
+    """The 16-bit correlation kernel (corr16_patch_kernel via ops.corr2d_patch_multi in the reduced-precision mode: host-rounded
+    unit-major filters, all kw weight tiles of a unit staged at once) against (a) the restatement of its arithmetic — inputs and
+    filters rounded to the operand type, exact products, wide accumulation: tight — and (b) the float64 correlation of the
+    unrounded operands with the rounding bound of the type."""
+    from gen6d_amd import ops
+    dt = {"bf16": torch.bfloat16, "fp16": torch.float16}[mode]
+    g = torch.Generator().manual_seed(900 + Cin + k)
+    w = _rand(g, Cout, k * k, Cin, scale=(1.0 / (k * k * Cin)) ** 0.5 * 3)
+    xs_cpu = [F.relu(_rand(g, n, 1, h, ww, Cin)) for n, h, ww in sizes]
+    xs = ops.alloc_like_segments([tuple(x.shape) for x in xs_cpu], torch.device("cuda"))
+    outs = ops.alloc_like_segments([(n, 1, h, ww, Cout) for n, h, ww in sizes], torch.device("cuda"))
+    for d_, x in zip(xs, xs_cpu):
+        d_.copy_(x)
+    wd = w.cuda()
+    w4 = w.double().reshape(Cout, k, k, Cin).permute(0, 3, 1, 2)
+    w4r = w.to(dt).double().reshape(Cout, k, k, Cin).permute(0, 3, 1, 2)
+    for rep in range(2):                                   # twice: split counters re-armed
+        for o in outs:
+            o.fill_(float("nan"))
+        with ops.math_mode(mode):
+            assert ops.CORR16
+            ops.corr2d_patch_multi(xs, wd, outs, k)
+            assert wd._g6d_c16[ops.MATH_MODE].dtype == dt     # the 16-bit filters were built and handed over
+        for x, o in zip(xs_cpu, outs):
+            xin = x[:, 0].permute(0, 3, 1, 2)
+            ref = F.conv2d(xin.double(), w4, padding=k // 2).permute(0, 2, 3, 1)
+            own = F.conv2d(xin.to(dt).double(), w4r, padding=k // 2).permute(0, 2, 3, 1)
+            got = o.cpu().double()[:, 0]
+            rng = ref.abs().max().item()
+            e_own, e_ref = (got - own).abs().max().item() / rng, (got - ref).abs().max().item() / rng
+            assert e_own <= 2e-5 and e_ref <= TOL[mode], (e_own, e_ref)
+    record("test_corr2d_patch16_multi", f"{mode} {sizes} x{Cin} -> {Cout}, {k}x{k}", e_ref, TOL[mode], note="relative to range")
+
+
 @pytest.mark.parametrize("mode", ["bf16", "fp16"])
 def test_selector_headline_lowp(golden, mode):
     """64 references x 5 rotations with the cfg key: same arg-max viewpoint as the reference, logit error recorded."""
