@@ -31,6 +31,9 @@
 // wino_conv.hip: eligible 3x3 / 3x3x3 stride-1 layers with pre-transformed filters (G6dConv.weight_wino) on the Winograd kernel
 bool g6d_wino_eligible(const G6dConv& d);
 int g6d_wino_launch(const G6dConv& d, hipStream_t stream);
+// wino43_conv.hip: the F(4x4,3x3) kernel for layers that carry G6dConv.weight_wino43
+bool g6d_wino43_eligible(const G6dConv& d);
+int g6d_wino43_launch(const G6dConv& d, hipStream_t stream);
 // conv_patch.hip: 3x3 / 3x3x3 stride-1 layers with Cout <= 64: spatial output tile, input patch reused by all taps
 bool g6d_conv_patch_eligible(const G6dConv& d);
 int g6d_conv_patch_launch(const G6dConv& d, int M, hipStream_t stream);
@@ -481,6 +484,7 @@ int launch_cfg(const G6dConv& d, int M, int T, int nChunks, int splits, hipStrea
 // (no launch; bench.py uses it to book the executed FLOPs of a launch in the right roofline family).
 extern "C" int g6d_conv_plan(const G6dConv* desc) {
   if (!desc) return G6D_EINVAL;
+  if (g6d_wino43_eligible(*desc)) return 3;
   if (g6d_wino_eligible(*desc)) return 2;
   static const bool use_patch = []() { const char* e = getenv("G6D_CONV_PATCH"); return !(e && e[0] == '0'); }();
   return (use_patch && g6d_conv_patch_eligible(*desc)) ? 1 : 0;
@@ -519,6 +523,7 @@ extern "C" int g6d_conv_igemm(const G6dConv* desc, g6d_stream_t stream_) {
   const long long Mll = (long long)d.N * d.Do * d.Ho * d.Wo;
   if (Mll > (1ll << 30)) { g6d_set_error("conv: M too large"); return G6D_EINVAL; }
   const int M = (int)Mll;
+  if (g6d_wino43_eligible(d)) return g6d_wino43_launch(d, stream);
   if (g6d_wino_eligible(d)) return g6d_wino_launch(d, stream);
   static const bool use_patch = []() { const char* e = getenv("G6D_CONV_PATCH"); return !(e && e[0] == '0'); }();
   if (use_patch && g6d_conv_patch_eligible(d)) return g6d_conv_patch_launch(d, M, stream);

@@ -1,0 +1,762 @@
+// 3x3 stride-1 pad-1 convolution as Winograd F(4x4,3x3) on the fp32 matrix cores of gfx950: 36 multiplications per 16 outputs —
+// 4x fewer than the direct form, 1.78x fewer than the F(2x2,3x3) kernel of wino_conv.hip.  Used where the parity budget has
+// room for the larger transform constants: the detector's image-pyramid trunk (reference
+// network/pretrain_models.py:9-31, network/detector.py:188-197), its 15x15 reference-as-filter correlation as 5x5 blocks of 3x3
+// (network/detector.py:222-224) and the refiner's 32^3 volume layers (network/refiner.py:88-143).
+//
+//   Y(4x4) = A^T [ sum_ci U_ci (.) V_ci ] A,   U = G g G^T (host, fp64, once per checkpoint),   V = B^T d B (6x6 input tile)
+//
+// Interpolation points (0, +-3/4, +-3/2, inf) instead of the textbook (0, +-1, +-2, inf): same operation count (every step is an
+// FMA with a constant either way), 3.6x smaller fp32 error (measured: 1.3e-6 of the output range at Cin = 512 against 4.6e-6;
+// F(2x2,3x3): 2.5e-7).  With a = 3/4, b = 3/2 the 1-D transforms are
+//   B^T d : r0 = a^2b^2 d0 - (a^2+b^2) d2 + d4          A^T m : y0 = m0 + (m1+m2) + (m3+m4)
+//           r1,r2 = (d4 - b^2 d2) +- a (d3 - b^2 d1)            y1 = a (m1-m2) + b (m3-m4)
+//           r3,r4 = (d4 - a^2 d2) +- b (d3 - a^2 d1)            y2 = a^2 (m1+m2) + b^2 (m3+m4)
+//           r5 = a^2b^2 d1 - (a^2+b^2) d3 + d5                  y3 = a^3 (m1-m2) + b^3 (m3-m4) + m5
+// and G = diag(1/N_i) [1 p_i p_i^2] (row inf = [0 0 1]), N_i = prod_{k != i} (p_i - p_k)  (backbone.winograd43_filters).
+//
+// Mapping to v_mfma_f32_16x16x4_f32 (M = tiles, N = co, K = ci), designed around two facts measured on this chip:
+// vector-ALU instructions never overlap with fp32 MFMAs, and 36 accumulator tiles of 32 tiles x 32 channels (576 registers) do not
+// fit one wave.
+//   block   = 256 threads = 4 waves = 8 "quarters" (8x8 output pixels = 2x2 Winograd tiles, the same flat quarter list as
+//             wino_conv.hip) x 16*NT output channels (NT = 4: 64 channels; NT = 2: 32, the correlation's 32 references).
+//   wave    = (pair pr, half hh): pair pr owns 16 tiles (4 quarters); the two waves of a pair split the 36 transform positions
+//             by ROW: wave hh holds rows a = 3hh..3hh+2, all 6 columns b, for all 16*NT channels: 18 x NT accumulators of 4
+//             registers (288 at NT = 4).  A 16-row A operand against a 64-column B operand halves the input-transform work per
+//             MFMA compared with 32 x 32 tiles: a lane transforms ONE tile (2 channels) for 18 x NT x 2 MFMAs.
+//             The row split costs nothing in the transform: r0..r2 need 6 operations, r3..r5 need 6 (72 packed FMAs per wave
+//             and 8-channel chunk against 144 MFMAs of 32 cycles).
+//   K loop  = chunks of 8 input channels, two phases each.  The filter tile of a chunk (36 positions x 64 channels x 8 = 72 KB)
+//             does not fit LDS twice, so it is staged in halves: X = columns b 0..2, Y = columns b 3..5 (36 KB each, direct to
+//             LDS); phase X runs the 9 positions (3 rows x 3 columns) of slot 0 while slot 1 receives Y, phase Y runs slot 1
+//             while slot 0 receives X of the next chunk: one barrier per phase.  The RAW 10x10 patch of every quarter is
+//             staged once per chunk (single buffer: all raw reads of a chunk happen in phase X, the next chunk's pieces are
+//             written in phase Y) and transformed in registers at the start of phase X.
+//   K trick = lane group kg = lane >> 4 reads channels 2kg, 2kg+1 with ONE ds_read_b64 per operand; MFMA s (0, 1) consumes channel
+//             2kg + s of both operands (the same permutation of K on both sides).
+//   epilogue= output transform of the wave's three rows (A^T is applied per row, then the three rows are combined into a partial
+//             4x4 output), the two waves of a pair exchange half of their partial outputs through LDS (wave hh finishes output
+//             rows 2hh, 2hh+1), then bias / ReLU / stores / 2x2 max-pool / statistics per lane.  Chunk split with the in-kernel
+//             hand-off of g6d_common.h as in the other kernels.
+#include "g6d_common.h"
+#include <stdlib.h>
+#include <stdio.h>
+#include <algorithm>
+#include <type_traits>
+
+#ifndef W43_ABLATE
+#define W43_ABLATE 0     // profiling builds only (results wrong by construction): 1 no barriers, 2 no next-chunk traffic, 3 no transform,
+                         // 4 no fragment reads, 5 all of them, 7 no epilogue
+#endif
+#define W43ABL(n) (W43_ABLATE == (n) || W43_ABLATE == 5)
+
+namespace {
+
+#define W43_QPIX 101                         // position stride between quarters (10 x 10 used); odd: conflict-free b64 reads
+#define W43_NQ 8                             // quarters per block
+#define W43_RAWF (28 * 64 * 4)               // floats of the raw patch region: 8 quarters x 101 positions x 8 channels, rounded up to 28 KB
+#define W43_MAX_SEG 4
+
+constexpr float WA = 0.75f, WB = 1.5f;
+constexpr float WA2 = WA * WA, WB2 = WB * WB, WA3 = WA * WA * WA, WB3 = WB * WB * WB;
+constexpr float WC0 = WA2 * WB2, WC2 = WA2 + WB2;
+
+struct W43Seg { int qstart, N, H, W, QH, QW, in_off, full_off, pool_off, ld_in, ld_full, ld_pool; };
+
+struct W43Args {
+  const float* in; const float* U; const float* bias; float* out_full; float* out_pool;
+  int Cin, Cout, relu;
+  int nseg, qtotal; W43Seg seg[W43_MAX_SEG];
+  unsigned in_bytes;                             // extent of the input tensor(s) from `in` (< 2^31): bound of the buffer loads
+  int splits, chunks_per_split; float* ws;
+  int D;                                         // depth slices per image (1 for 2-D layers); KD = 3 pads in depth
+  int H0, W0, ld0;                               // geometry of segment 0 (KD = 3 depth step)
+  const float* in_scale; const float* in_shift; int in_relu;
+  int aff_div;                                   // MODE 2: image i uses affine table i / aff_div
+  double* stats; int stats_div;                  // [groups][Cout][2]; group of image i = i / stats_div (0: one group)
+  G6dFin fin;
+};
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 fma2(f2 a, float k, f2 c) { return __builtin_elementwise_fma(a, f2{k, k}, c); }
+
+// ds_read_b64 that the compiler's load/store optimizer does not fuse into ds_read2(_st64)_b64: those run at half the LDS rate and with
+// 16-lane service groups over 32 banks, for which the images below are 2- and 4-way conflicted (volatile keeps the counters tracked)
+typedef __attribute__((address_space(3))) float lds_float;
+__device__ __forceinline__ f2 lds_rd64(const lds_float* p) { return *reinterpret_cast<const volatile __attribute__((address_space(3))) f2*>(p); }
+
+// Accumulators: 18 x 4 tiles of 4 registers = 288 > the 256 AGPRs hipcc gives the builtin's accumulators; the 8 tiles that do not
+// fit would be copied VGPR <-> AGPR around every MFMA (v_accvgpr_write / read: 128 vector-ALU instructions per chunk).  Those tiles
+// (row 2, columns 4 and 5 at NT = 4) therefore use the VGPR form of the instruction, hand-issued: an accumulator is reused 4 MFMAs
+// (128 cycles) later at the earliest, beyond every software wait state of the instruction; the epilogue waits 32 cycles first.
+template <bool VG>
+__device__ __forceinline__ void mfma16(float a, float b, f32x4& c) {
+  if constexpr (VG) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+  else c = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+struct QGeo { int n, oy0, ox0; bool valid; int H, W, ld_in, ld_full, ld_pool, in_off, full_off, pool_off; };
+__device__ __forceinline__ QGeo quarter_of(const W43Args& p, int q) {
+  const int Q = blockIdx.x * W43_NQ + q;
+  int sidx = 0;
+#pragma unroll
+  for (int k = 1; k < W43_MAX_SEG; ++k) sidx = (k < p.nseg && Q >= p.seg[k].qstart) ? k : sidx;
+  const W43Seg& sg = p.seg[sidx];
+  QGeo g;
+  g.valid = Q < p.qtotal;
+  const int Ql = g.valid ? Q - sg.qstart : 0;
+  const int per = sg.QH * sg.QW;
+  g.n = Ql / per;
+  const int r = Ql - g.n * per;
+  const int qy = r / sg.QW, qx = r - qy * sg.QW;
+  g.oy0 = 8 * qy; g.ox0 = 8 * qx;
+  g.H = sg.H; g.W = sg.W; g.ld_in = sg.ld_in; g.ld_full = sg.ld_full; g.ld_pool = sg.ld_pool;
+  g.in_off = sg.in_off; g.full_off = sg.full_off; g.pool_off = sg.pool_off;
+  return g;
+}
+
+__device__ __forceinline__ void bt_full(const f2 (&d)[6], f2 (&r)[6]) {
+  const f2 Ea = fma2(d[2], -WB2, d[4]), Oa = fma2(d[1], -WB2, d[3]);
+  const f2 Eb = fma2(d[2], -WA2, d[4]), Ob = fma2(d[1], -WA2, d[3]);
+  r[0] = fma2(d[0], WC0, fma2(d[2], -WC2, d[4]));
+  r[1] = fma2(Oa, WA, Ea);
+  r[2] = fma2(Oa, -WA, Ea);
+  r[3] = fma2(Ob, WB, Eb);
+  r[4] = fma2(Ob, -WB, Eb);
+  r[5] = fma2(d[1], WC0, fma2(d[3], -WC2, d[5]));
+}
+// 1-D output transform of one row of six transform-domain values
+__device__ __forceinline__ void at_row(const float (&m)[6], float (&y)[4]) {
+  const float s1 = m[1] + m[2], d1 = m[1] - m[2], s2 = m[3] + m[4], d2 = m[3] - m[4];
+  y[0] = m[0] + s1 + s2;
+  y[1] = fmaf(WB, d2, WA * d1);
+  y[2] = fmaf(WB2, s2, WA2 * s1);
+  y[3] = fmaf(WB3, d2, fmaf(WA3, d1, m[5]));
+}
+
+// MODE  operand prologue applied when the raw patch is written to LDS: 0 none, 1 InstanceNorm affine (+ReLU) with one table,
+//       2 one table per image group (image / aff_div; LDS holds the tables of the block's eight quarters); zero padding stays zero
+// KD    1: 2-D layer; 3: 3x3x3 layer, depth taps folded into the reduction (chunk = (kd, 8 channels) reads slice d + kd - 1);
+//       25: 15x15 "same" correlation as 5x5 blocks of 3x3 (chunk = (8 channels, block), block shifts innermost)
+// NT    output channels of a block in 16s (4 or 2)
+template <int MODE, int KD, int NT>
+__global__ void __launch_bounds__(256, 1) wino43_kernel(const W43Args p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int THREADS = 256, NQ = W43_NQ;
+  constexpr int RAWF = W43_RAWF;                            // 28 wave-instructions of 64 16-byte slots (the image itself ends at slot 1616)
+  constexpr int HALF = 18 * 16 * NT * 8;                    // floats of one filter half-slot: [18 positions][16 NT channels][8]
+  constexpr int AFF0 = RAWF + 2 * HALF;                     // affine tables behind the stages
+  constexpr int NPR = 7;                                    // 16-byte raw slots per thread and chunk
+  constexpr int PCS = 9 * NT;                               // 1 KB direct-to-LDS pieces per half-slot (32 channels x 32 B each)
+  constexpr int NPC = (PCS + 3) / 4;                        // ... per wave (NT = 2: 4.5 -> 5, the surplus pieces repeat piece idx % PCS)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int pr = wave >> 1, hh = wave & 1;
+  const int lt = lane & 15, kg = lane >> 4;
+  const int n0 = blockIdx.y * (16 * NT);
+  const int nc8 = p.Cin >> 3;
+  const int c_first = blockIdx.z * p.chunks_per_split;
+  const int c_last = min(KD * nc8, c_first + p.chunks_per_split) - 1;
+
+  // ---- raw patch loader.  LDS image: position (q, py, px) at ((q*101 + py*10 + px) * 8) floats, its two 4-channel halves swapped
+  // when (py >> 2) is odd (every ds_read_b64 of the fragment loop is then bank-conflict free: exhaustive check over both 32-lane
+  // service groups).  The image is filled in 16-byte slots s = (w*7 + j)*64 + lane — lane-linear per wave instruction, so that
+  // MODE 0 can move the pieces global -> LDS directly (buffer_load ... lds: the LDS address is M0 + 16 lane, the GLOBAL address is
+  // per lane: each lane fetches the piece that belongs into its slot; pieces outside the image, the padding position 100 of a
+  // quarter and the slots behind the image ask for an offset beyond the tensor and the hardware writes zeros).
+  int poff[NPR], aoff[MODE != 0 ? NPR : 1];
+  bool pval[NPR];
+  unsigned dbits = 0;                                          // KD = 3: bit 2j / 2j+1 = piece j has a slice below / above
+  unsigned smask[KD == 25 ? NPR : 1];                          // KD = 25: bits 0-4 / 8-12 = row / column of the piece inside the image under block shift b
+  int rstep[KD == 25 ? NPR : 1];
+#pragma unroll
+  for (int j = 0; j < NPR; ++j) {
+    const int sl = (wave * NPR + j) * 64 + lane;
+    const int pl = sl >> 1, q = pl / W43_QPIX, pp = pl - q * W43_QPIX;
+    const int py = pp / 10, px = pp - py * 10;
+    const int half = (sl & 1) ^ ((py >> 2) & 1);
+    const bool live = (q < NQ) & (pp < 100);
+    const QGeo g = quarter_of(p, live ? q : 0);
+    const int n = g.n;
+    const int iy = g.oy0 + py - 1, ix = g.ox0 + px - 1;
+    pval[j] = live & g.valid & ((unsigned)iy < (unsigned)g.H) & ((unsigned)ix < (unsigned)g.W);
+    poff[j] = pval[j] ? g.in_off + ((n * g.H + iy) * g.W + ix) * g.ld_in + 4 * half : 0;
+    if constexpr (MODE != 0) aoff[j] = (MODE >= 2 ? (live ? q : 0) * p.Cin : 0) + 4 * half;
+    if constexpr (KD == 3) { const int dd = n % p.D; dbits |= (unsigned)(dd > 0) << (2 * j) | (unsigned)(dd < p.D - 1) << (2 * j + 1); }
+    if constexpr (KD == 25) {
+      unsigned m = 0;
+#pragma unroll
+      for (int b = 0; b < 5; ++b)
+        m |= (unsigned)((unsigned)(iy + 3 * b - 6) < (unsigned)g.H) << b | (unsigned)((unsigned)(ix + 3 * b - 6) < (unsigned)g.W) << (8 + b);
+      smask[j] = (live & g.valid) ? m : 0u;
+      rstep[j] = 3 * g.W * g.ld_in;
+      poff[j] = g.in_off + ((n * g.H + iy) * g.W + ix) * g.ld_in + 4 * half;      // the UNSHIFTED position (used under smask only)
+    }
+  }
+  unsigned pboff[KD == 1 ? NPR : 1];                          // byte offsets of the pieces for the buffer loads (beyond the tensor: zero)
+  if constexpr (KD == 1) {
+#pragma unroll
+    for (int j = 0; j < NPR; ++j) pboff[j] = pval[j] ? (unsigned)poff[j] << 2 : 0x80000000u;
+  }
+  const int slice = p.H0 * p.W0 * p.ld0;                      // KD = 3: one depth step
+  const auto in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
+  const unsigned lds_addr0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)lds;
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  f32x4 rp[MODE != 0 ? NPR : 1];
+  bool rv[MODE != 0 ? NPR : 1];
+  // piece j of chunk `chunk`: MODE 0 straight to LDS, otherwise into rp[j] (the affine prologue runs in registers: store_raw)
+  auto load_piece = [&](int j, int chunk) {
+    const int kd = KD == 25 ? chunk % 25 : (KD != 1 ? chunk / nc8 : 0), cc = KD == 25 ? chunk / 25 : (KD != 1 ? chunk - kd * nc8 : chunk);
+    unsigned voff; int soff = 0;
+    if constexpr (KD == 1) { voff = pboff[j]; soff = cc * 32; }
+    else {
+      bool v = pval[j];
+      int off = poff[j] + cc * 8;
+      if constexpr (KD == 3) { v &= kd == 1 || ((dbits >> (2 * j + (kd >> 1))) & 1u) != 0; off += (kd - 1) * slice; }
+      if constexpr (KD == 25) {
+        const int bi = kd / 5, bj = kd - 5 * bi;
+        v = ((smask[j] >> bi) & (smask[j] >> (8 + bj)) & 1u) != 0;
+        off += (bi - 2) * rstep[j] + (bj - 2) * 3 * p.ld0;
+      }
+      if constexpr (MODE != 0) rv[j] = v;
+      voff = v ? (unsigned)off << 2 : 0x80000000u;
+    }
+    if constexpr (MODE == 0) {
+      const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr0 + 1024u * (unsigned)(wave * NPR + j));
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(voff), "s"(in_rsrc), "s"(dst), "s"(soff) : "memory");
+    } else {
+      if constexpr (KD == 1) rv[j] = pval[j];
+      rp[j] = __builtin_bit_cast(f32x4, __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, voff, soff, 0)));
+    }
+  };
+  auto load_raw = [&](int chunk) {
+    if (W43ABL(2)) return;
+#pragma unroll
+    for (int j = 0; j < NPR; ++j) load_piece(j, chunk);
+  };
+  auto store_raw = [&](int chunk) {                            // MODE != 0 only: affine (+ReLU), exact zeros outside the image, -> LDS
+    if constexpr (MODE != 0) {
+      if (W43ABL(2)) return;
+      const int cc = KD != 1 ? chunk % nc8 : chunk;
+#pragma unroll
+      for (int j = 0; j < NPR; ++j) {
+        f32x4 v = rp[j];
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(lds + AFF0 + aoff[j] + cc * 8);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(lds + AFF0 + (MODE >= 2 ? NQ : 1) * p.Cin + aoff[j] + cc * 8);
+        v = v * sc + sh;
+        if (p.in_relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        if (!rv[j]) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(__builtin_assume_aligned(lds + ((wave * NPR + j) * 64 + lane) * 4, 16)) = v;
+      }
+    }
+  };
+  if constexpr (MODE != 0) {                  // InstanceNorm affine tables -> LDS: [G][Cin] scales, then [G][Cin] shifts
+    constexpr int G = MODE >= 2 ? NQ : 1;
+    for (int i = tid; i < G * p.Cin; i += THREADS) {
+      int g = 0;
+      if constexpr (MODE >= 2) g = p.aff_div > 0 ? (quarter_of(p, i / p.Cin).n / p.D) / p.aff_div : 0;
+      const int c = MODE >= 2 ? i % p.Cin : i;
+      lds[AFF0 + i] = p.in_scale[g * p.Cin + c];
+      lds[AFF0 + G * p.Cin + i] = p.in_shift[g * p.Cin + c];
+    }
+    __syncthreads();
+  }
+  // ---- filter half-slots: U43 is [chunk][half][18 positions][Cout][8]; a block's half is 18 runs of 16 NT x 32 bytes, moved
+  // global -> LDS directly in 1 KB pieces (inline asm: with the builtin hipcc books the copy on the LDS counter as well)
+  const unsigned lane16 = lane * 16;
+  const char* ubase = reinterpret_cast<const char*>(p.U + (size_t)n0 * 8);
+  const size_t chunk_bytes = (size_t)36 * p.Cout * 32;
+  auto glds = [&](int chunk, int half, int k) {
+    if (W43ABL(2)) return;
+    int idx = wave * NPC + k;
+    if (PCS % 4 != 0) idx = idx % PCS;
+    const int pos = idx / (NT / 2), sub = idx % (NT / 2);
+    const char* g = ubase + (size_t)chunk * chunk_bytes + (unsigned)(((half * 18 + pos) * p.Cout + sub * 32) * 32);
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr0 + 4u * (unsigned)(RAWF + half * HALF + (pos * 16 * NT + sub * 32) * 8));
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(lane16), "s"(g), "s"(dst) : "memory");
+  };
+  auto load_u = [&](int chunk, int half) {
+#pragma unroll
+    for (int k = 0; k < NPC; ++k) glds(chunk, half, k);
+  };
+
+  // ---- fragment bases.  A: tile lt of the pair = quarter 4 pr + (lt >> 2), tile (ty, tx) of its 2x2; raw rows 4 ty + i
+  const int ty = (lt >> 1) & 1, tx = lt & 1;
+  const int apos = ((4 * pr + (lt >> 2)) * W43_QPIX + (4 * ty) * 10 + 4 * tx) * 8;
+  const int abase_lo = apos + 2 * (kg ^ (2 * ty));            // rows i = 0..3: ((4 ty + i) >> 2) & 1 == ty
+  const int abase_hi = apos + 2 * (kg ^ (2 * (ty ^ 1)));      // rows i = 4, 5
+  int arow[5];                                                // float offsets of raw rows hh .. hh+4 of the lane's tile
+#pragma unroll
+  for (int k = 0; k < 5; ++k) arow[k] = (hh + k < 4 ? abase_lo : abase_hi) + (hh + k) * 80;
+  // B: channel 16 nt + lt of the block, slot kg of its 8-float row (halves swapped for co & 8 on the host)
+  const int bbase = RAWF + ((9 * hh) * 16 * NT + lt) * 8 + 2 * (kg ^ (2 * ((lt >> 3) & 1)));
+
+  f32x4 acc[3][6][NT];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 6; ++b)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[a][b][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const lds_float* L = (const lds_float*)lds;
+  load_u(c_first, 0);
+  load_raw(c_first);
+  store_raw(c_first);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  f2 V[3][6];
+  // One phase: the 9 positions (3 rows x columns B0..B0+2) of filter slot `half`, 2 NT MFMAs each (s = 0: channels 2kg, s = 1: 2kg + 1;
+  // consecutive MFMAs go to different accumulators).  One wave per SIMD: only the wave's own instruction order hides latency, so
+  // everything else is pinned into the MFMA gaps — the NT fragment reads of position pp + 1 behind the first NT MFMAs of position pp,
+  // one memory request `req(k)` (direct-to-LDS pieces of the next half / chunk) behind each of the other NT.
+  f2 bf[2][NT];
+  auto phase_begin = [&](int half) {              // fragments of the phase's first position
+    const lds_float* S = L + bbase + half * HALF;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) bf[0][n] = W43ABL(4) ? f2{1.f, 1.f} : lds_rd64(S + (16 * n) * 8);
+    if (W43ABL(4)) {
+#pragma unroll
+      for (int n = 0; n < NT; ++n) bf[1][n] = f2{1.f, 1.f};
+    }
+  };
+  auto phase = [&](auto B0c, int half, auto&& req) {
+    constexpr int B0 = decltype(B0c)::value;
+    const lds_float* S = L + bbase + half * HALF;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int pp = 0; pp < 9; ++pp) {
+      const int ai = pp / 3, b = B0 + pp % 3;
+#pragma unroll
+      for (int m = 0; m < 2 * NT; ++m) {
+        const int sidx = m / NT, n = m % NT;
+        if (NT == 4 && ai == 2 && b >= 4) mfma16<true>(V[ai][b][sidx], bf[pp & 1][n][sidx], acc[ai][b][n]);
+        else mfma16<false>(V[ai][b][sidx], bf[pp & 1][n][sidx], acc[ai][b][n]);
+        if (m < NT) { if (pp + 1 < 9 && !W43ABL(4)) bf[(pp + 1) & 1][n] = lds_rd64(S + ((pp + 1) * 16 * NT + 16 * n) * 8); }
+        else req(pp * NT + (m - NT));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I3 = std::integral_constant<int, 3>;
+
+  for (int cc = c_first; cc <= c_last; ++cc) {
+    const int cn = min(cc + 1, c_last);           // the last chunk re-requests itself: no branches
+    // ---- phase X: raw tile -> registers, input transform, 9 positions of slot 0 while slot 1 receives Y of this chunk.
+    // The wave's rows a = 3hh..3hh+2 of B^T d need raw rows hh..hh+4 only (r0..r2: d0..d4, r3..r5: d1..d5)
+    {
+      f2 e[5][6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) e[k][j] = W43ABL(4) ? f2{1.f, 1.f} : lds_rd64(L + arow[k] + j * 8);
+      phase_begin(0);                              // ... and the first filter fragments: they arrive behind the transform
+      if (W43ABL(3)) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int b = 0; b < 6; ++b) V[a][b] = e[a][b];
+      } else {
+        f2 T[3][6];
+        if (hh == 0) {
+#pragma unroll
+          for (int j = 0; j < 6; ++j) {            // columns: rows 0..2 of B^T d
+            const f2 E = fma2(e[2][j], -WB2, e[4][j]), O = fma2(e[1][j], -WB2, e[3][j]);
+            T[0][j] = fma2(e[0][j], WC0, fma2(e[2][j], -WC2, e[4][j]));
+            T[1][j] = fma2(O, WA, E);
+            T[2][j] = fma2(O, -WA, E);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 6; ++j) {            // rows 3..5 (e[k] = d[k + 1])
+            const f2 E = fma2(e[1][j], -WA2, e[3][j]), O = fma2(e[0][j], -WA2, e[2][j]);
+            T[0][j] = fma2(O, WB, E);
+            T[1][j] = fma2(O, -WB, E);
+            T[2][j] = fma2(e[0][j], WC0, fma2(e[2][j], -WC2, e[4][j]));
+          }
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) bt_full(T[a], V[a]);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // requests of phase X: the NPC filter pieces of Y (direct to LDS: invisible to the compiler's load counting, so they are issued
+    // BEFORE the loads it waits for), then (MODE != 0) the raw pieces of chunk c+1 into registers
+    phase(I0{}, 0, [&](int k) {
+      if (k < NPC) glds(cc, 1, k);
+      else if (MODE != 0 && k - NPC < NPR && !W43ABL(2)) load_piece(k - NPC, cn);
+    });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // slot 1 has landed
+    if (!W43ABL(1)) __syncthreads();
+    // ---- phase Y: every wave has read the raw image of chunk c, which now receives chunk c+1 (MODE 0: straight from memory;
+    // otherwise the pieces loaded during phase X, through the prologue), slot 0 <- X of chunk c+1, 9 positions of slot 1
+    phase_begin(1);
+    if constexpr (MODE != 0) store_raw(cn);
+    __builtin_amdgcn_sched_barrier(0);
+    phase(I3{}, 1, [&](int k) {
+      if (k < NPC) glds(cn, 0, k);
+      else if (MODE == 0 && k - NPC < NPR && !W43ABL(2)) load_piece(k - NPC, cn);
+    });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!W43ABL(1)) __syncthreads();
+  }
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");     // the hand-issued MFMAs of the last positions have left the pipe
+
+  if (W43_ABLATE == 7) {
+    float t = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 6; ++b)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) t += acc[a][b][n][0] + acc[a][b][n][1] + acc[a][b][n][2] + acc[a][b][n][3];
+    if (t == 12345.f && p.out_full) p.out_full[tid] = t;
+    return;
+  }
+  // ---------------------------------------------------------------- epilogue
+  // element e = (nt, r): accumulator register r of channel tile nt = Winograd tile r of quarter 4 pr + kg, channel n0 + 16 nt + lt.
+  // Partial outputs of the wave's three transform rows, P[x][y] = sum_a A^T[x][3hh+a] (row a transformed along b).
+  // Wave hh keeps output rows 2hh, 2hh+1 and hands rows 2(1-hh), 2(1-hh)+1 to its partner, NT/2 channel tiles per round (64 floats per
+  // lane and round, lane-linear 16-byte rows: 16 KB per wave; the K loop's LDS is free: every wave has passed its last barrier).
+  float Y[NT][4][2][4];                              // [nt][r][output row 2hh + xl][output column]
+  float* xbuf = lds;
+#pragma unroll
+  for (int rd = 0; rd < NT / 2; ++rd) {
+    float keep[2][4][2][4], send[2][4][2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float R[3][4];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          const float m[6] = {acc[a][0][2 * rd + u][r], acc[a][1][2 * rd + u][r], acc[a][2][2 * rd + u][r],
+                              acc[a][3][2 * rd + u][r], acc[a][4][2 * rd + u][r], acc[a][5][2 * rd + u][r]};
+          at_row(m, R[a]);
+        }
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+          if (hh == 0) {                             // points 0, +a, -a
+            const float s = R[1][y] + R[2][y], dd = R[1][y] - R[2][y];
+            keep[u][r][0][y] = R[0][y] + s; keep[u][r][1][y] = WA * dd;
+            send[u][r][0][y] = WA2 * s; send[u][r][1][y] = WA3 * dd;
+          } else {                                   // points +b, -b, inf
+            const float s = R[0][y] + R[1][y], dd = R[0][y] - R[1][y];
+            send[u][r][0][y] = s; send[u][r][1][y] = WB * dd;
+            keep[u][r][0][y] = WB2 * s; keep[u][r][1][y] = fmaf(WB3, dd, R[2][y]);
+          }
+        }
+      }
+    if (rd > 0) __syncthreads();                     // the previous round's rows have been read
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int xl = 0; xl < 2; ++xl)
+          *reinterpret_cast<f32x4*>(xbuf + wave * 4096 + (((u * 4 + r) * 2 + xl) * 64 + lane) * 4) =
+              f32x4{send[u][r][xl][0], send[u][r][xl][1], send[u][r][xl][2], send[u][r][xl][3]};
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int xl = 0; xl < 2; ++xl) {
+          const f32x4 o = *reinterpret_cast<const f32x4*>(xbuf + (wave ^ 1) * 4096 + (((u * 4 + r) * 2 + xl) * 64 + lane) * 4);
+#pragma unroll
+          for (int y = 0; y < 4; ++y) Y[2 * rd + u][r][xl][y] = keep[u][r][xl][y] + o[y];
+        }
+  }
+  if (p.splits > 1) {
+    // partial OUTPUT tiles (the output transform is linear) -> workspace as [split][tile][k][thread] 16-byte pieces; the block of a tile
+    // that arrives last adds them in split order and carries on with bias / ReLU / pool / statistics
+    constexpr int TILE = THREADS * NT * 32;
+    const int ntiles = gridDim.x * gridDim.y, tile = blockIdx.y * gridDim.x + blockIdx.x;
+    float* part = p.ws + G6D_WS_COUNTERS + (size_t)tile * TILE + tid * 4;
+    const size_t zstride = (size_t)ntiles * TILE;
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int xl = 0; xl < 2; ++xl)
+          g6d_store_wt(part + blockIdx.z * zstride + ((n * 4 + r) * 2 + xl) * (THREADS * 4),
+                       f32x4{Y[n][r][xl][0], Y[n][r][xl][1], Y[n][r][xl][2], Y[n][r][xl][3]});
+    if (!g6d_split_arrive(reinterpret_cast<int*>(p.ws) + tile, p.splits, reinterpret_cast<int*>(lds))) return;
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int xl = 0; xl < 2; ++xl)
+#pragma unroll
+          for (int y = 0; y < 4; ++y) Y[n][r][xl][y] = 0.f;
+    for (int z = 0; z < p.splits; ++z) {
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int xl = 0; xl < 2; ++xl) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(part + (size_t)z * zstride + ((n * 4 + r) * 2 + xl) * (THREADS * 4));
+#pragma unroll
+            for (int y = 0; y < 4; ++y) Y[n][r][xl][y] += v[y];
+          }
+    }
+  }
+  const QGeo g = quarter_of(p, 4 * pr + kg);          // the lane's quarter: accumulator register r = tile r of it
+  const bool do_relu = p.relu != 0, do_stats = p.stats != nullptr;
+  const int Hp = g.H >> 1, Wp = g.W >> 1;
+  float st1[NT], st2[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    st1[n] = 0.f; st2[n] = 0.f;
+    const int co = n0 + 16 * n + lt;
+    const float bv = p.bias ? p.bias[co] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int oy = g.oy0 + 4 * (r >> 1) + 2 * hh, ox = g.ox0 + 4 * (r & 1);
+      float y[2][4];
+#pragma unroll
+      for (int xl = 0; xl < 2; ++xl)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          y[xl][c] = Y[n][r][xl][c] + bv;
+          if (do_relu) y[xl][c] = fmaxf(y[xl][c], 0.f);
+        }
+      if (p.out_full && g.valid) {
+#pragma unroll
+        for (int xl = 0; xl < 2; ++xl)
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            if (oy + xl < g.H && ox + c < g.W) {
+              p.out_full[(size_t)g.full_off + ((size_t)(g.n * g.H + oy + xl) * g.W + ox + c) * g.ld_full + co] = y[xl][c];
+              if (do_stats) { st1[n] += y[xl][c]; st2[n] += y[xl][c] * y[xl][c]; }
+            }
+      }
+      if (p.out_pool && g.valid) {
+        const int py = oy >> 1;
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+          const int px = (ox >> 1) + c2;
+          if (py < Hp && px < Wp)
+            p.out_pool[(size_t)g.pool_off + ((size_t)(g.n * Hp + py) * Wp + px) * g.ld_pool + co] =
+                fmaxf(fmaxf(y[0][2 * c2], y[0][2 * c2 + 1]), fmaxf(y[1][2 * c2], y[1][2 * c2 + 1]));
+        }
+      }
+    }
+  }
+  if (do_stats) {
+    // [quarter][half][channel][2] float partials in LDS, then one fp64 atomic per channel and run of quarters with the same group
+    float* sred = lds;
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      sred[(((4 * pr + kg) * 2 + hh) * 16 * NT + 16 * n + lt) * 2] = st1[n];
+      sred[(((4 * pr + kg) * 2 + hh) * 16 * NT + 16 * n + lt) * 2 + 1] = st2[n];
+    }
+    __syncthreads();
+    if (tid < 16 * NT) {
+      double a1 = 0.0, a2 = 0.0;
+      int cur = -1;
+      for (int q = 0; q < NQ; ++q) {
+        const QGeo qg = quarter_of(p, q);
+        if (!qg.valid) break;
+        const int gi = p.stats_div > 0 ? (qg.n / p.D) / p.stats_div : 0;
+        if (gi != cur && cur >= 0) {
+          double* st = p.stats + ((size_t)cur * p.Cout + n0 + tid) * 2;
+          atomicAdd(st, a1); atomicAdd(st + 1, a2); a1 = a2 = 0.0;
+        }
+        cur = gi;
+        a1 += (double)sred[((q * 2 + 0) * 16 * NT + tid) * 2] + (double)sred[((q * 2 + 1) * 16 * NT + tid) * 2];
+        a2 += (double)sred[((q * 2 + 0) * 16 * NT + tid) * 2 + 1] + (double)sred[((q * 2 + 1) * 16 * NT + tid) * 2 + 1];
+      }
+      if (cur >= 0) {
+        double* st = p.stats + ((size_t)cur * p.Cout + n0 + tid) * 2;
+        atomicAdd(st, a1); atomicAdd(st + 1, a2);
+      }
+    }
+    if (p.fin.scale) {
+      __syncthreads();
+      g6d_finalize_stats(p.fin, gridDim.x * gridDim.y, reinterpret_cast<int*>(lds));
+    }
+  }
+}
+
+// ---- launch: split over the chunks, instantiation
+template <int MODE, int KD, int NT>
+int w43_launch_t(W43Args& a, long long blocks, hipStream_t stream) {
+  const size_t lds_bytes = ((size_t)W43_RAWF + 2 * (18 * 16 * NT * 8) + 4 * 256 + (MODE == 0 ? 0 : (MODE >= 2 ? 2 * W43_NQ : 2) * a.Cin)) * sizeof(float);
+  const size_t need = std::max(lds_bytes, (size_t)4 * 4096 * sizeof(float));      // the epilogue exchange: 16 KB per wave
+  g6d_allow_lds(reinterpret_cast<const void*>(&wino43_kernel<MODE, KD, NT>), 160 * 1024);
+  hipLaunchKernelGGL((wino43_kernel<MODE, KD, NT>), dim3((unsigned)blocks, a.Cout / (16 * NT), a.splits), dim3(256), need, stream, a);
+  return g6d_check_launch("wino43_conv3x3");
+}
+
+int w43_run(W43Args& a, int mode, int kd, float* workspace, size_t workspace_bytes, hipStream_t stream) {
+  long long quarters = 0, in_extent = 0;
+  double out_elems = 0.0;
+  for (int k = 0; k < a.nseg; ++k) {
+    W43Seg& g = a.seg[k];
+    in_extent = std::max(in_extent, (long long)g.in_off + (long long)g.N * g.H * g.W * g.ld_in);
+    g.QH = (g.H + 7) / 8; g.QW = (g.W + 7) / 8;
+    g.qstart = (int)quarters;
+    quarters += (long long)g.N * g.QH * g.QW;
+    out_elems += (double)g.N * g.H * g.W;
+  }
+  a.H0 = a.seg[0].H; a.W0 = a.seg[0].W; a.ld0 = a.seg[0].ld_in;
+  const long long blocks = (quarters + W43_NQ - 1) / W43_NQ;
+  if (blocks > 0x3fffffffll) { g6d_set_error("wino43: grid too large"); return G6D_EINVAL; }
+  a.qtotal = (int)quarters;
+  if (in_extent * 4 >= (1ll << 31)) { g6d_set_error("wino43: input tensor exceeds 2^31 bytes"); return G6D_EINVAL; }
+  a.in_bytes = (unsigned)(in_extent * 4);
+  const int nt = (a.Cout & 63) ? 2 : 4;
+  if (mode != 0 && (size_t)(mode >= 2 ? 2 * W43_NQ : 2) * a.Cin * 4 + ((size_t)W43_RAWF + 2 * 18 * 16 * nt * 8 + 1024) * 4 > 160 * 1024) {
+    g6d_set_error("wino43: affine tables do not fit LDS"); return G6D_EINVAL;
+  }
+  // Split of the (kd, chunk) list over gridDim.z: one block per CU is resident and runs a serial loop of ~2.6 us per chunk (NT = 4;
+  // ~1.5 at NT = 2); pick the split count with the smallest modelled time, as wino_conv.hip does (constants overridable)
+  const int nchunks = kd * (a.Cin / 8);
+  int splits = 1;
+  const long long grid2 = blocks * (a.Cout / (16 * nt));
+  static const int split_max = []() { const char* e = getenv("G6D_W43_SPLIT_MAX"); return e ? atoi(e) : 32; }();
+  static const double m_gain = []() { const char* e = getenv("G6D_W43_SPLIT_GAIN"); return e ? atof(e) : 0.85; }();
+  static const double m_chunk4 = []() { const char* e = getenv("G6D_W43_CHUNK_US"); return e ? atof(e) : 2.8; }();
+  const size_t room = workspace && workspace_bytes > G6D_WS_COUNTER_BYTES ? workspace_bytes - G6D_WS_COUNTER_BYTES : 0;
+  const double tile_bytes = (double)grid2 * 256 * nt * 32 * sizeof(float);
+  if (room > 0 && grid2 <= G6D_WS_COUNTERS && split_max > 1 && nchunks >= 4) {
+    const double out_bytes = out_elems * a.Cout * sizeof(float);
+    double best = 1e30;
+    for (int sp = 1; sp <= split_max && sp <= nchunks / 2; ++sp) {
+      if ((double)sp * tile_bytes > (double)room) break;
+      const int cps_ = (nchunks + sp - 1) / sp, real = (nchunks + cps_ - 1) / cps_;
+      if (real != sp) continue;
+      const double rounds = (double)((grid2 * sp + 255) / 256);
+      double t = rounds * (cps_ * (nt == 4 ? m_chunk4 : 0.55 * m_chunk4) + 6.0);
+      if (sp > 1) t += 2.0 + 0.6 * sp + (2 * sp + 1) * out_bytes / 2.5e6;
+      if (t < best * m_gain) { best = t; splits = sp; }
+    }
+  }
+  const int cps = (nchunks + splits - 1) / splits;
+  splits = (nchunks + cps - 1) / cps;
+  a.splits = splits; a.chunks_per_split = cps; a.ws = workspace;
+  static const bool debug = []() { const char* e = getenv("G6D_WINO_DEBUG"); return e && e[0] == '1'; }();
+  if (debug) fprintf(stderr, "wino43 %d seg, %dx%dx%d->%d kd=%d mode=%d: grid %lld x %d splits of %d chunks\n", a.nseg, a.seg[0].H, a.seg[0].W, a.Cin,
+                     a.Cout, kd, mode, grid2, splits, cps);
+  if (kd == 25) return nt == 4 ? w43_launch_t<0, 25, 4>(a, blocks, stream) : w43_launch_t<0, 25, 2>(a, blocks, stream);
+  if (nt != 4) { g6d_set_error("wino43: Cout % 64 == 0 expected"); return G6D_EINVAL; }
+  if (kd == 3) return mode == 2 ? w43_launch_t<2, 3, 4>(a, blocks, stream) : mode == 1 ? w43_launch_t<1, 3, 4>(a, blocks, stream) : w43_launch_t<0, 3, 4>(a, blocks, stream);
+  if (mode == 2) return w43_launch_t<2, 1, 4>(a, blocks, stream);
+  if (mode == 1) return w43_launch_t<1, 1, 4>(a, blocks, stream);
+  return w43_launch_t<0, 1, 4>(a, blocks, stream);
+}
+
+}  // namespace
+
+// One trunk layer over up to 4 map sizes in ONE launch, as g6d_wino_conv3x3_multi, on the F(4x4,3x3) kernel.  U43 = the filters
+// transformed on the host (backbone.winograd43_filters): [Cin/8][2][18][Cout][8] — chunk c, column half (b < 3 / b >= 3), position
+// a*3 + b%3, output channel, the chunk's 8 input channels with the two 4-channel halves swapped for co & 8.
+// Replaces features[4..27] of vgg11_bn on the detector's image pyramid (network/pretrain_models.py:17-25, network/detector.py:236-241).
+extern "C" int g6d_wino43_conv3x3_multi(const G6dWinoSeg* segs, int nseg, int Cin, const float* U43, const float* bias, int Cout, int relu,
+                                        float* workspace, size_t workspace_bytes, g6d_stream_t stream) {
+  if (!segs || nseg < 1 || nseg > W43_MAX_SEG || !U43 || Cin <= 0 || (Cin & 7) || Cout <= 0 || (Cout & 63) || !g6d_aligned16(U43)) {
+    g6d_set_error("wino43_conv3x3_multi: bad args (1..4 segments, Cin % 8 == 0, Cout % 64 == 0)"); return G6D_EINVAL;
+  }
+  W43Args a = {};
+  const bool want_full = segs[0].out_full != nullptr, want_pool = segs[0].out_pool != nullptr;
+  if (!want_full && !want_pool) { g6d_set_error("wino43_conv3x3_multi: no output"); return G6D_EINVAL; }
+  const float* in0 = segs[0].in; float* f0 = segs[0].out_full; float* p0 = segs[0].out_pool;
+  for (int k = 0; k < nseg; ++k) {
+    const G6dWinoSeg& g = segs[k];
+    if (!g.in || (g.out_full != nullptr) != want_full || (g.out_pool != nullptr) != want_pool || g.N <= 0 || g.H <= 0 || g.W <= 0 ||
+        (g.ld_in & 3) || g.ld_in < Cin || (want_full && g.ld_full < Cout) || (want_pool && (g.ld_pool < Cout || g.H < 2 || g.W < 2)) ||
+        !g6d_aligned16(g.in)) {
+      g6d_set_error("wino43_conv3x3_multi: bad segment (all segments give the same kinds of output)"); return G6D_EINVAL;
+    }
+    if (g.in < in0) in0 = g.in;
+    if (want_full && g.out_full < f0) f0 = g.out_full;
+    if (want_pool && g.out_pool < p0) p0 = g.out_pool;
+  }
+  a.in = in0; a.U = U43; a.bias = bias; a.out_full = f0; a.out_pool = p0;
+  a.Cin = Cin; a.Cout = Cout; a.relu = relu; a.D = 1; a.nseg = nseg;
+  for (int k = 0; k < nseg; ++k) {
+    const G6dWinoSeg& g = segs[k];
+    const long long io = g.in - in0, fo = want_full ? g.out_full - f0 : 0, po = want_pool ? g.out_pool - p0 : 0;
+    if (io + (long long)g.N * g.H * g.W * g.ld_in >= (1ll << 29) || fo + (long long)g.N * g.H * g.W * g.ld_full >= (1ll << 31) ||
+        po + (long long)g.N * g.H * g.W * g.ld_pool >= (1ll << 31)) {
+      g6d_set_error("wino43_conv3x3_multi: segments must lie within 2^29 floats of each other (allocate them from one buffer)"); return G6D_EINVAL;
+    }
+    a.seg[k] = W43Seg{0, g.N, g.H, g.W, 0, 0, (int)io, (int)fo, (int)po, g.ld_in, g.ld_full, g.ld_pool};
+  }
+  return w43_run(a, 0, 1, workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream));
+}
+
+// The detector's 15x15 reference-as-filter correlation (network/detector.py:222-224) as 5x5 blocks of 3x3 sub-filters accumulated in
+// the F(4x4,3x3) transform domain: 225 taps cost 25 * 36 / 16 = 56.25 multiplications per output.  Maps as g6d_corr2d_wino_multi;
+// U43 = the 25 sub-filter banks transformed like g6d_wino43_conv3x3_multi's, CHUNK-major: [Cin/8 * 25][2][18][Cout][8], row
+// c * 25 + b = 8-channel chunk c of block b = 5 bi + bj holding w[:, 3bi..3bi+2, 3bj..3bj+2, :]; Cout % 32 == 0.
+extern "C" int g6d_corr2d_wino43_multi(const G6dCorrSeg* segs, int nseg, int Cin, const float* U43, int Cout, int kblocks, float* workspace,
+                                       size_t workspace_bytes, g6d_stream_t stream) {
+  if (!segs || nseg < 1 || nseg > W43_MAX_SEG || !U43 || kblocks != 5 || Cin <= 0 || (Cin & 7) || Cout <= 0 || (Cout & 31) || !g6d_aligned16(U43)) {
+    g6d_set_error("corr2d_wino43_multi: bad args (1..4 map sizes, 15x15 = 5 blocks, Cin % 8 == 0, Cout % 32 == 0)"); return G6D_EINVAL;
+  }
+  W43Args a = {};
+  const float* in0 = segs[0].in; float* f0 = segs[0].out;
+  for (int k = 0; k < nseg; ++k) {
+    const G6dCorrSeg& g = segs[k];
+    if (!g.in || !g.out || g.N <= 0 || g.H <= 0 || g.W <= 0 || (g.ld_in & 3) || g.ld_in < Cin || g.ld_in != segs[0].ld_in || g.ld_out < Cout ||
+        !g6d_aligned16(g.in)) {
+      g6d_set_error("corr2d_wino43_multi: bad map (all maps share ld_in)"); return G6D_EINVAL;
+    }
+    if (g.in < in0) in0 = g.in;
+    if (g.out < f0) f0 = g.out;
+  }
+  a.in = in0; a.U = U43; a.bias = nullptr; a.out_full = f0; a.out_pool = nullptr;
+  a.Cin = Cin; a.Cout = Cout; a.relu = 0; a.D = 1; a.nseg = nseg;
+  for (int k = 0; k < nseg; ++k) {
+    const G6dCorrSeg& g = segs[k];
+    const long long io = g.in - in0, fo = g.out - f0;
+    if (io + (long long)g.N * g.H * g.W * g.ld_in >= (1ll << 29) || fo + (long long)g.N * g.H * g.W * g.ld_out >= (1ll << 31)) {
+      g6d_set_error("corr2d_wino43_multi: maps must lie within 2^29 floats of each other (allocate them from one buffer)"); return G6D_EINVAL;
+    }
+    a.seg[k] = W43Seg{0, g.N, g.H, g.W, 0, 0, (int)io, (int)fo, 0, g.ld_in, g.ld_out, 0};
+  }
+  return w43_run(a, 0, kblocks * kblocks, workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream));
+}
+
+// ---- the conv family on the F(4x4,3x3) kernel (called by g6d_conv_igemm when G6dConv.weight_wino43 is set): kernel (1,3,3) on 2-D maps
+// or (3,3,3), stride 1, "same" padding, Cin % 8 == 0, Cout % 64 == 0, fp32, no multiplier prologue, no LeakyReLU
+bool g6d_wino43_eligible(const G6dConv& d) {
+  static const bool on = []() { const char* e = getenv("G6D_CONV_WINO43"); return !(e && e[0] == '0'); }();
+  if (!on || !d.weight_wino43 || d.math_mode != 0 || d.mul || d.in_image_mod > 0 || d.mul_group_images > 0) return false;
+  const bool k2 = d.kd == 1 && d.Di == 1 && d.pd == 0, k3 = d.kd == 3 && d.pd == 1;
+  if (!(k2 || k3) || d.kh != 3 || d.kw != 3 || d.ph != 1 || d.pw != 1 || d.sd != 1 || d.sh != 1 || d.sw != 1) return false;
+  if ((d.Cin & 7) || (d.Cout & 63) || d.Hi < 8 || d.Wi < 8 || d.out_act > 1 || d.split_k > 1) return false;
+  if (d.stats && d.stat_rows_per_group > 0 && d.stat_rows_per_group % (d.Do * d.Ho * d.Wo)) return false;
+  if (d.in_scale && (d.Cin > 512 || (d.Cin & 3))) return false;
+  if (!g6d_aligned16(d.weight_wino43)) return false;
+  if ((long long)d.N * d.Di * ((d.Hi + 7) / 8) * ((d.Wi + 7) / 8) >= (1ll << 31)) return false;
+  return (long long)d.N * d.Di * d.Hi * d.Wi * d.ld_in < (1ll << 29);
+}
+
+int g6d_wino43_launch(const G6dConv& d, hipStream_t stream) {
+  W43Args a = {};
+  a.in = d.in; a.U = d.weight_wino43; a.bias = d.bias; a.out_full = d.out; a.out_pool = nullptr;
+  a.D = d.Di; a.Cin = d.Cin; a.Cout = d.Cout; a.relu = d.out_act == 1;
+  a.nseg = 1;
+  a.seg[0] = W43Seg{0, d.N * d.Di, d.Hi, d.Wi, 0, 0, 0, 0, 0, d.ld_in, d.ld_out, 0};
+  a.in_scale = d.in_scale; a.in_shift = d.in_shift; a.in_relu = d.in_relu;
+  a.stats = d.stats; a.stats_div = d.stat_rows_per_group > 0 ? d.stat_rows_per_group / (d.Do * d.Ho * d.Wo) : 0;
+  a.aff_div = d.in_affine_per_n;
+  if (d.fin_scale)
+    a.fin = G6dFin{d.fin_scale, d.fin_shift, reinterpret_cast<int*>(d.fin_counter), d.stats, 1.0 / d.fin_count, d.fin_eps, d.fin_groups * d.Cout};
+  const int mode = !d.in_scale ? 0 : (d.in_affine_per_n ? 2 : 1);
+  return w43_run(a, mode, d.kd, d.workspace, d.workspace_bytes, stream);
+}

@@ -37,7 +37,7 @@ class G6dConv(C.Structure):
         ("fin_scale", C.c_void_p), ("fin_shift", C.c_void_p), ("fin_counter", C.c_void_p),
         ("fin_count", C.c_double), ("fin_eps", C.c_double), ("fin_groups", C.c_int32),
         ("in_image_mod", C.c_int32), ("mul_group_images", C.c_int32), ("reserved_", C.c_int32),
-        ("weight_wino16", C.c_void_p),
+        ("weight_wino16", C.c_void_p), ("weight_wino43", C.c_void_p),
     ]
 
 
@@ -62,6 +62,8 @@ SIGNATURES = {
     "g6d_wino_conv3x3": [_P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _P, _I, _P, C.c_size_t, _P],
     "g6d_wino_conv3x3_multi": [_P, _I, _I, _P, _P, _I, _I, _P, C.c_size_t, _P],
     "g6d_wino16_conv3x3_multi": [_P, _I, _I, _P, _P, _I, _I, _I, _P, C.c_size_t, _P],
+    "g6d_wino43_conv3x3_multi": [_P, _I, _I, _P, _P, _I, _I, _P, C.c_size_t, _P],
+    "g6d_corr2d_wino43_multi": [_P, _I, _I, _P, _I, _I, _P, C.c_size_t, _P],
     "g6d_l2norm_rows": [_P, _I, _I, _I, _P],
     "g6d_nchw_to_nhwc": [_P, _I, _I, _I, _I, _I, _P, _I, _P],
     "g6d_selector_ref_sums": [_P, _I, _I, _I, _P, _P, _P],

@@ -87,6 +87,74 @@ def winograd_corr_filters(w_taps, k):
     return U.reshape(-1, *U.shape[2:]).contiguous()
 
 
+# ---- Winograd F(4x4,3x3) with the interpolation points (0, +-3/4, +-3/2, inf) of gen6d_amd/csrc/wino43_conv.hip
+W43_A, W43_B = 0.75, 1.5
+
+
+def winograd43_matrices(dtype=torch.float64, device=None):
+    """(B^T [6,6], G [6,3], A^T [4,6]) of F(4,3) at the points (0, a, -a, b, -b, inf), a = 3/4, b = 3/2, normalised so that B^T has the
+    monic rows the kernel evaluates (csrc/wino43_conv.hip header) and G carries the 1 / prod_{k != i} (p_i - p_k) factors."""
+    a, b = W43_A, W43_B
+    a2, b2 = a * a, b * b
+    BT = torch.tensor([[a2 * b2, 0, -(a2 + b2), 0, 1, 0],
+                       [0, -a * b2, -b2, a, 1, 0],
+                       [0, a * b2, -b2, -a, 1, 0],
+                       [0, -b * a2, -a2, b, 1, 0],
+                       [0, b * a2, -a2, -b, 1, 0],
+                       [0, a2 * b2, 0, -(a2 + b2), 0, 1]], dtype=dtype, device=device)
+    pts = [0.0, a, -a, b, -b]
+    rows = []
+    for i, pi in enumerate(pts):
+        n = 1.0
+        for k, pk in enumerate(pts):
+            if k != i:
+                n *= pi - pk
+        rows.append([1.0 / n, pi / n, pi * pi / n])
+    rows.append([0.0, 0.0, 1.0])
+    G = torch.tensor(rows, dtype=dtype, device=device)
+    AT = torch.tensor([[1, 1, 1, 1, 1, 0],
+                       [0, a, -a, b, -b, 0],
+                       [0, a2, a2, b2, b2, 0],
+                       [0, a2 * a, -a2 * a, b2 * b, -b2 * b, 1]], dtype=dtype, device=device)
+    return BT, G, AT
+
+
+def winograd43_filters(w):
+    """[Cout,Cin,3,3] -> U43 [Cin/8, 2, 18, Cout, 8] for g6d_wino43_conv3x3_multi: U43[c][b // 3][3 a + b % 3][co][k ^ (4 if co & 8 else 0)]
+    = (G g G^T)[a][b] of filter (co, 8c + k) — a chunk's filter tile in the two column halves the kernel stages one after the other,
+    rows with co & 8 carrying their two 4-channel halves swapped (bank-conflict-free fragment reads).  Computed in fp64."""
+    co, ci = w.shape[:2]
+    if ci % 8 or co % 32:
+        raise ValueError("winograd43_filters: Cin % 8 == 0 and Cout % 32 == 0 expected")
+    _, G, _ = winograd43_matrices(device=w.device)
+    U = torch.einsum("ai,ocij,bj->ocab", G, w.double(), G).to(w.dtype)               # [co,ci,6,6]
+    U = U.reshape(co, ci // 8, 8, 6, 2, 3).permute(1, 4, 3, 5, 0, 2)                 # [chunk][half][a][b % 3][co][8]
+    U = U.reshape(ci // 8, 2, 18, co, 8).contiguous()
+    swap = (torch.arange(co, device=w.device) & 8) != 0
+    U[:, :, :, swap] = torch.cat([U[:, :, :, swap, 4:], U[:, :, :, swap, :4]], -1)
+    return U
+
+
+def winograd43_filters_taps(w_taps, kd=1):
+    """[Cout, kd*9, Cin] (ParamBank.conv_w) -> [kd*Cin/8, 2, 18, Cout, 8]: one winograd43_filters block per depth tap, depth taps outermost
+    (G6dConv.weight_wino43)."""
+    co, taps, ci = w_taps.shape
+    assert taps == kd * 9
+    w = w_taps.reshape(co, kd, 3, 3, ci).permute(1, 0, 4, 2, 3)
+    return torch.cat([winograd43_filters(w[k].contiguous()) for k in range(kd)], 0).contiguous()
+
+
+def winograd43_corr_filters(w_taps, k):
+    """Correlation filters [Cout, k*k, Cin], k = 3*kb -> U43 [Cin/8 * kb*kb, 2, 18, Cout, 8] for g6d_corr2d_wino43_multi: CHUNK-major
+    like winograd_corr_filters (row c * kb*kb + b = 8-channel chunk c of block b = kb*bi + bj)."""
+    co, taps, ci = w_taps.shape
+    kb = k // 3
+    assert taps == k * k and k == 3 * kb
+    w = w_taps.reshape(co, kb, 3, kb, 3, ci).permute(1, 3, 0, 5, 2, 4)      # [bi, bj, co, ci, 3, 3]
+    U = torch.stack([winograd43_filters(w[bi, bj].contiguous()) for bi in range(kb) for bj in range(kb)], 1)      # [Cin/8, kb*kb, 2, 18, Cout, 8]
+    return U.reshape(-1, *U.shape[2:]).contiguous()
+
+
 class TrunkLayer(tuple):
     """(U, bias) of a Winograd trunk layer as the fp32 kernel takes them; `.u16(dtype)` = the 16-bit filters of the reduced-precision
     kernel, built from the folded fp32 weights on first use (ops.MATH_MODE 1 / 2)."""

@@ -140,7 +140,7 @@ FUSED_FINALIZE = _os.environ.get("G6D_FUSED_FINALIZE", "1") != "0"
 
 def conv(x, w, bias, out, ksize=(1, 1, 1), stride=(1, 1, 1), pad=(0, 0, 0), mul=None, in_scale=None, in_shift=None,
          in_relu=False, per_n=False, out_act=0, stats=None, rows_per_group=0, split_k=0, w_wino=None, finalize=None, eps=1e-5,
-         in_mod=0, mul_group=0):
+         in_mod=0, mul_group=0, w_wino43=None):
     """Implicit-GEMM convolution (g6d_conv_igemm). x [N,Di,Hi,Wi,Cin], w [Cout,taps,Cin], out [N,Do,Ho,Wo,Cout] views.
     stats [G,Cout,2] fp64 (zeroed): per-(group, channel) sum / sum of squares of the output are accumulated into it.
     finalize=count: additionally turn the completed statistics into the affine of the following InstanceNorm (count values
@@ -169,6 +169,8 @@ def conv(x, w, bias, out, ksize=(1, 1, 1), stride=(1, 1, 1), pad=(0, 0, 0), mul=
             raise ValueError(f"conv.mul: expected contiguous {want}")
     if w_wino is not None and (tuple(w_wino.shape) != (kd * (Cin // 8), 16, Cout, 8) or not w_wino.is_contiguous()):
         raise ValueError(f"conv.w_wino: expected contiguous {(kd * (Cin // 8), 16, Cout, 8)}, got {tuple(w_wino.shape)}")
+    if w_wino43 is not None and (tuple(w_wino43.shape) != (kd * (Cin // 8), 2, 18, Cout, 8) or not w_wino43.is_contiguous()):
+        raise ValueError(f"conv.w_wino43: expected contiguous {(kd * (Cin // 8), 2, 18, Cout, 8)}, got {tuple(w_wino43.shape)}")
     u16 = None
     if MATH_MODE and w_wino is not None and Cin % 16 == 0 and Cout % 64 == 0:
         # reduced-precision mode: the layer's Winograd filters rounded to the operand type, built once per (layer, type) and kept
@@ -190,7 +192,8 @@ def conv(x, w, bias, out, ksize=(1, 1, 1), stride=(1, 1, 1), pad=(0, 0, 0), mul=
         in_relu=int(in_relu), in_affine_per_n=int(per_n), out_act=int(out_act),
         stat_rows_per_group=int(rows_per_group), split_k=int(split_k), math_mode=int(MATH_MODE),
         weight_wino=w_wino.data_ptr() if w_wino is not None else None, in_image_mod=int(in_mod), mul_group_images=int(mul_group),
-        weight_wino16=u16.data_ptr() if u16 is not None else None)
+        weight_wino16=u16.data_ptr() if u16 is not None else None,
+        weight_wino43=w_wino43.data_ptr() if (w_wino43 is not None and not MATH_MODE) else None)
     fin = None
     if finalize is not None:
         if stats is None:
@@ -208,11 +211,11 @@ def conv(x, w, bias, out, ksize=(1, 1, 1), stride=(1, 1, 1), pad=(0, 0, 0), mul=
         e1.record()
         fam = _lib.load().g6d_conv_plan(C.byref(d))
         fl = 2.0 * N * Do * Ho * Wo * Cout * kd * kh * kw * Cin
-        PROFILE.append((fl / 2.25 if fam == 2 else fl, e0, e1,            # Winograd kernel: FLOPs executed in the transform domain
-                        ("wino3x3 " if fam == 2 else "") + f"conv N={N} in={Di}x{Hi}x{Wi}x{Cin} out={Do}x{Ho}x{Wo}x{Cout} k={kd}x{kh}x{kw} s={stride[0]}{stride[1]}{stride[2]}"
+        PROFILE.append((fl / 4 if fam == 3 else (fl / 2.25 if fam == 2 else fl), e0, e1,      # Winograd kernels: FLOPs executed in the transform domain
+                        ("wino3x3 F43 " if fam == 3 else "wino3x3 " if fam == 2 else "") + f"conv N={N} in={Di}x{Hi}x{Wi}x{Cin} out={Do}x{Ho}x{Wo}x{Cout} k={kd}x{kh}x{kw} s={stride[0]}{stride[1]}{stride[2]}"
                         f"{' mul' if mul is not None else ''}{' aff' if in_scale is not None else ''}{' stats' if stats is not None else ''}",
                         # algorithmic bytes: every operand once (input images, multiplier maps, filters, output)
-                        4.0 * ((in_mod or N) * Di * Hi * Wi * Cin + (mul.numel() if mul is not None else 0) + w.numel() + N * Do * Ho * Wo * Cout)))
+                        4.0 * ((in_mod or N) * Di * Hi * Wi * Cin + (mul.numel() if mul is not None else 0) + w.numel() + N * Do * Ho * Wo * Cout), fl))
     else:
         _lib.check(_lib.load().g6d_conv_igemm(C.byref(d), _stream()), "g6d_conv_igemm")
     if finalize is not None:
@@ -538,6 +541,78 @@ def wino_conv3x3_multi(xs, U, bias, relu=True, full=True, pool=False):
         PROFILE.append((flops / 2.25, e0, e1, f"wino3x3 multi in={sizes}x{Cin} out={Cout}{' full' if full else ''}{' pool' if pool else ''}",
                         4.0 * (sum(x.numel() for x in xs) + U.numel() + (sum(t.numel() for t in ys) if full else 0) + (sum(t.numel() for t in yps) if pool else 0))))
     return ys, yps
+
+
+def wino43_conv3x3_multi(xs, U43, bias, relu=True, full=True, pool=False):
+    """wino_conv3x3_multi on the Winograd F(4x4,3x3) kernel (g6d_wino43_conv3x3_multi): 4x fewer multiplications than the direct form
+    (1.78x fewer than F(2x2,3x3)) at ~5x the fp32 error — for the layers whose parity budget has the room (the detector's pyramid).
+    U43 [Cin/8,2,18,Cout,8] (backbone.winograd43_filters), Cout % 64 == 0."""
+    _need_gpu(U43, bias, *xs)
+    if not 1 <= len(xs) <= 4:
+        raise ValueError("wino43_conv3x3_multi: 1..4 segments")
+    Cin, Cout = xs[0].shape[3], U43.shape[3]
+    if tuple(U43.shape) != (Cin // 8, 2, 18, Cout, 8) or not U43.is_contiguous() or bias.numel() != Cout:
+        raise ValueError(f"wino43_conv3x3_multi: U43 must be contiguous {(Cin // 8, 2, 18, Cout, 8)}")
+    for x in xs:
+        if x.dim() != 4 or x.dtype != torch.float32 or not x.is_contiguous() or x.shape[3] != Cin:
+            raise ValueError("wino43_conv3x3_multi: segments must be contiguous float32 [N,H,W,Cin]")
+    dev = xs[0].device
+    ys = alloc_like_segments([(x.shape[0], x.shape[1], x.shape[2], Cout) for x in xs], dev) if full else None
+    yps = alloc_like_segments([(x.shape[0], x.shape[1] // 2, x.shape[2] // 2, Cout) for x in xs], dev) if pool else None
+    segs = (_lib.G6dWinoSeg * len(xs))()
+    flops = 0.0
+    for i, x in enumerate(xs):
+        N, H, W, _ = x.shape
+        segs[i] = _lib.G6dWinoSeg(in_=x.data_ptr(), out_full=ys[i].data_ptr() if full else None,
+                                  out_pool=yps[i].data_ptr() if pool else None, N=N, H=H, W=W, ld_in=Cin, ld_full=Cout, ld_pool=Cout)
+        flops += 2.0 * N * H * W * Cout * 9 * Cin
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    ws = workspace(dev)
+    _lib.check(_lib.load().g6d_wino43_conv3x3_multi(segs, len(xs), Cin, _ptr(U43), _ptr(bias), Cout, int(relu), _ptr(ws), ws.numel() * 4,
+                                                   _stream()), "g6d_wino43_conv3x3_multi")
+    if PROFILE is not None:
+        e1.record()
+        sizes = "+".join(f"{x.shape[0]}x{x.shape[1]}x{x.shape[2]}" for x in xs)
+        # direct-form FLOPs / 4 = multiplications executed in the F(4x4,3x3) domain (36 per 16 outputs instead of 144)
+        PROFILE.append((flops / 4, e0, e1, f"wino3x3 F43 multi in={sizes}x{Cin} out={Cout}{' full' if full else ''}{' pool' if pool else ''}",
+                        4.0 * (sum(x.numel() for x in xs) + U43.numel() + (sum(t.numel() for t in ys) if full else 0) + (sum(t.numel() for t in yps) if pool else 0)),
+                        flops))
+    return ys, yps
+
+
+def corr2d_wino43_multi(xs, U43, outs, kblocks=5):
+    """corr2d_wino_multi on the F(4x4,3x3) kernel (g6d_corr2d_wino43_multi): U43 [kblocks^2 * Cin/8, 2, 18, Cout, 8]
+    (backbone.winograd43_corr_filters), Cout % 32 == 0."""
+    _need_gpu(U43, *xs, *outs)
+    if not 1 <= len(xs) <= 4 or len(outs) != len(xs):
+        raise ValueError("corr2d_wino43_multi: 1..4 map sizes")
+    Cin, Cout = xs[0].shape[4], U43.shape[3]
+    if tuple(U43.shape) != (kblocks * kblocks * (Cin // 8), 2, 18, Cout, 8) or not U43.is_contiguous():
+        raise ValueError(f"corr2d_wino43_multi: U43 must be contiguous {(kblocks * kblocks * (Cin // 8), 2, 18, Cout, 8)}")
+    segs = (_lib.G6dCorrSeg * len(xs))()
+    flops, sizes = 0.0, []
+    k = 3 * kblocks
+    for i, (x, o) in enumerate(zip(xs, outs)):
+        N, D, H, W, Cx, ld_in = _cl5(x, "corr2d_wino43.x")
+        No, _, Ho, Wo, Co, ld_out = _cl5(o, "corr2d_wino43.out")
+        if D != 1 or No != N or (Ho, Wo) != (H, W) or Cx != Cin or Co != Cout or not (x.is_contiguous() and o.is_contiguous()):
+            raise ValueError("corr2d_wino43_multi: shape mismatch (maps must be dense)")
+        segs[i] = _lib.G6dCorrSeg(in_=x.data_ptr(), out=o.data_ptr(), H=H, W=W, ld_in=ld_in, ld_out=ld_out, N=N)
+        flops += 2.0 * N * H * W * Cout * k * k * Cin
+        sizes.append(f"{N}x{H}x{W}" if N > 1 else f"{H}x{W}")
+    ws = workspace(U43.device)
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.check(_lib.load().g6d_corr2d_wino43_multi(segs, len(xs), Cin, _ptr(U43), Cout, int(kblocks), _ptr(ws), ws.numel() * 4, _stream()),
+               "g6d_corr2d_wino43_multi")
+    if PROFILE is not None:
+        e1.record()
+        PROFILE.append((flops / 4, e0, e1, f"wino3x3 F43 corr multi in={'+'.join(sizes)}x{Cin} out={Cout} k={k}x{k} ({kblocks}x{kblocks} blocks of 3x3)",
+                        4.0 * (sum(x.numel() for x in xs) + sum(o.numel() for o in outs) + U43.numel()), flops))
+    return outs
 
 
 def wino16_conv3x3_multi(xs, U16, bias, relu=True, full=True, pool=False):

@@ -118,10 +118,17 @@ typedef struct G6dConv {
                                    g6d_wino16_conv3x3_multi's U16 (per depth tap for 3x3x3).  Eligible layers (as weight_wino, and
                                    Cin % 16 == 0, Cout % 64 == 0) then run on the 16-bit Winograd kernel instead of the direct kernels
                                    with 16-bit operands.  NULL = never. */
+  const float* weight_wino43;   /* optional (ABI v8): the same filters transformed for Winograd F(4x4,3x3) in the layout of
+                                   g6d_wino43_conv3x3_multi's U43, [kd][Cin/8][2][18][Cout][8] (per depth tap for 3x3x3).  When set
+                                   and the layer is eligible (fp32, stride 1, "same" padding, maps >= 8x8, Cin % 8 == 0, Cout % 64 ==
+                                   0, no multiplier) the launch runs on the F(4x4,3x3) kernel: 4x fewer multiplications than the direct
+                                   form at ~5x the fp32 error of F(2x2,3x3) — set it only on layers whose parity budget has the room
+                                   (the refiner's 32^3 volume layers); takes precedence over weight_wino.  NULL = never. */
 } G6dConv;
 
 int g6d_conv_igemm(const G6dConv* desc, g6d_stream_t stream);
-/* Kernel family g6d_conv_igemm will run `desc` on (no launch): 0 generic implicit GEMM, 1 LDS-patch kernel, 2 Winograd kernel */
+/* Kernel family g6d_conv_igemm will run `desc` on (no launch): 0 generic implicit GEMM, 1 LDS-patch kernel, 2 Winograd F(2x2,3x3) kernel,
+   3 Winograd F(4x4,3x3) kernel */
 int g6d_conv_plan(const G6dConv* desc);
 /* sizeof(G6dConv) as compiled into the library: bindings check their struct layout against it */
 int g6d_sizeof_conv_desc(void);
@@ -162,6 +169,12 @@ int g6d_corr2d_patch16_multi(const G6dCorrSeg* segs, int nseg, int Cin, const vo
  * chunk are consecutive, so the window stays in L2); Cin % 8 == 0, Cout % 32 == 0. */
 int g6d_corr2d_wino_multi(const G6dCorrSeg* segs, int nseg, int Cin, const float* U, int Cout, int kblocks, float* workspace,
                           size_t workspace_bytes, g6d_stream_t stream);
+
+/* The same 15x15 correlation with the 25 blocks accumulated in the F(4x4,3x3) transform domain (ABI v8; kernel and filter layout of
+ * g6d_wino43_conv3x3_multi): 225 taps cost 25 * 36 / 16 = 56.25 multiplications per output (F(2x2,3x3): 100).  U43 CHUNK-major
+ * [Cin/8 * 25][2][18][Cout][8], row c*25 + b = chunk c of block b; Cin % 8 == 0, Cout % 32 == 0. */
+int g6d_corr2d_wino43_multi(const G6dCorrSeg* segs, int nseg, int Cin, const float* U43, int Cout, int kblocks, float* workspace,
+                            size_t workspace_bytes, g6d_stream_t stream);
 
 /* InstanceNorm finalisation: stats[g][c] = (sum, sumsq) over `count` elements ->
  * scale = 1/sqrt(var+eps), shift = -mean*scale (biased variance; torch InstanceNorm{1,2,3}d, eps 1e-5,
@@ -233,6 +246,18 @@ int g6d_wino_conv3x3_multi(const G6dWinoSeg* segs, int nseg, int Cin, const floa
  * two 16-byte halves swapped, as in g6d_wino_conv3x3's U); Cin % 16 == 0, Cout % 64 == 0. */
 int g6d_wino16_conv3x3_multi(const G6dWinoSeg* segs, int nseg, int Cin, const void* U16, const float* bias, int Cout, int relu,
                              int math_mode, float* workspace, size_t workspace_bytes, g6d_stream_t stream);
+
+/* g6d_wino_conv3x3_multi on the Winograd F(4x4,3x3) kernel (ABI v8, fp32 on v_mfma_f32_16x16x4_f32): 36 multiplications per 16
+ * outputs — 4x fewer than the direct form, 1.78x fewer than F(2x2,3x3) — with the interpolation points (0, +-3/4, +-3/2, inf), whose
+ * fp32 error is ~1.3e-6 of the output range at Cin = 512 (F(2x2,3x3): 2.5e-7; the textbook points 0, +-1, +-2: 4.6e-6).  Meant for the
+ * layers whose parity budget has that room: the detector's image pyramid (network/pretrain_models.py:17-25, network/detector.py:188-197,
+ * 236-241; headline detector parity 1.5e-6 of range against a 1e-4 bar).
+ * U43 = the filters transformed on the host in fp64, [Cin/8][2][18][Cout][8]: chunk c of 8 input channels, column half (b < 3 / b >= 3
+ * of the 6x6 transform positions), position 3a + b % 3, output channel, the chunk's 8 channels (rows with co & 8 carry their two
+ * 4-channel halves swapped) — the two halves are the units the kernel stages in LDS.  Cin % 8 == 0, Cout % 64 == 0; segments, bias,
+ * relu, outputs and workspace as g6d_wino_conv3x3_multi. */
+int g6d_wino43_conv3x3_multi(const G6dWinoSeg* segs, int nseg, int Cin, const float* U43, const float* bias, int Cout, int relu,
+                             float* workspace, size_t workspace_bytes, g6d_stream_t stream);
 
 /* In-place L2 normalisation over C of channels-last rows x[rows][ld] (F.normalize eps 1e-12, network/selector.py:118,
  * network/refiner.py:69-71,165).  16-byte accesses when x is 16-byte aligned and ld % 4 == 0 (then C % 4 == 0 is required),

@@ -25,7 +25,7 @@ def _act(v, act):
 
 
 def conv(x, w, bias, out, ksize=(1, 1, 1), stride=(1, 1, 1), pad=(0, 0, 0), mul=None, in_scale=None, in_shift=None,
-         in_relu=False, per_n=False, out_act=0, stats=None, rows_per_group=0, split_k=0, w_wino=None, finalize=None, eps=1e-5,
+         in_relu=False, per_n=False, out_act=0, stats=None, rows_per_group=0, split_k=0, w_wino=None, finalize=None, eps=1e-5, w_wino43=None,
          in_mod=0, mul_group=0):
     N = out.shape[0] if in_mod else x.shape[0]
     _, Di, Hi, Wi, Cin = x.shape
@@ -186,6 +186,55 @@ def wino_conv3x3(x, U, bias, relu=True, full=True, pool=False):
         y = F.relu(y)
     yp = F.max_pool2d(y.permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1).contiguous() if pool else None
     return (y.contiguous() if full else None), yp
+
+
+def _wino43(x, U43, bias, relu, full, pool):
+    """The F(4x4,3x3) ALGORITHM of csrc/wino43_conv.hip on the transformed filters the kernel receives (layout of
+    backbone.winograd43_filters), in the dtype of x."""
+    from gen6d_amd.network.backbone import winograd43_matrices
+    N, H, W, Cin = x.shape
+    Cout = U43.shape[3]
+    dt = x.dtype
+    BT, _, AT = winograd43_matrices(dtype=dt)
+    Ht, Wt = (H + 3) // 4, (W + 3) // 4
+    xp = F.pad(x, (0, 0, 1, 4 * Wt + 1 - W, 1, 4 * Ht + 1 - H))
+    d = xp.unfold(1, 6, 4).unfold(2, 6, 4)                                             # [N,Ht,Wt,C,6,6]
+    V = torch.einsum("ai,ntucij,bj->ntuabc", BT, d, BT)
+    U = U43.clone()
+    swap = (torch.arange(Cout) & 8) != 0                                               # undo the LDS-bank swizzle of the halves
+    U[:, :, :, swap] = torch.cat([U[:, :, :, swap, 4:], U[:, :, :, swap, :4]], -1)
+    U6 = U.reshape(Cin // 8, 2, 6, 3, Cout, 8).permute(2, 1, 3, 4, 0, 5).reshape(6, 6, Cout, Cin).to(dt)    # [a][b = 3 half + b%3][co][ci]
+    M = torch.einsum("ntuabc,aboc->ntuabo", V, U6)
+    Y = torch.einsum("pa,ntuabo,qb->ntupqo", AT, M, AT)                               # [N,Ht,Wt,4,4,Cout]
+    y = Y.permute(0, 1, 3, 2, 4, 5).reshape(N, 4 * Ht, 4 * Wt, Cout)[:, :H, :W] + (bias.to(dt) if bias is not None else 0)
+    if relu:
+        y = F.relu(y)
+    yp = F.max_pool2d(y.permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1).contiguous() if pool else None
+    return (y.contiguous() if full else None), yp
+
+
+def wino43_conv3x3_multi(xs, U43, bias, relu=True, full=True, pool=False):
+    res = [_wino43(x, U43, bias, relu, full, pool) for x in xs]
+    return ([r[0] for r in res] if full else None), ([r[1] for r in res] if pool else None)
+
+
+def corr2d_wino43_multi(xs, U43, outs, kblocks=5):
+    """As corr2d_wino_multi with the F(4x4,3x3) blocks of backbone.winograd43_corr_filters."""
+    kb = kblocks
+    for x, o in zip(xs, outs):
+        N, _, H, W, Cin = x.shape
+        nc = Cin // 8
+        acc = torch.zeros((N, H, W, U43.shape[3]), dtype=x.dtype)
+        pad = 3 * (kb - 1) // 2 + 1
+        xp = F.pad(x[:, 0], (0, 0, pad, pad, pad, pad))
+        for bi in range(kb):
+            for bj in range(kb):
+                b = bi * kb + bj
+                sh = xp[:, 3 * bi:3 * bi + H + 2, 3 * bj:3 * bj + W + 2]
+                y, _ = _wino43(sh.contiguous(), U43.view(nc, kb * kb, *U43.shape[1:])[:, b].contiguous(), None, False, True, False)
+                acc += y[:, 1:H + 1, 1:W + 1]
+        o.copy_(acc[:, None])
+    return outs
 
 
 def wino16_conv3x3_multi(xs, U16, bias, relu=True, full=True, pool=False):

@@ -1,0 +1,5 @@
+cd $GRAFT_REPO_ROOT
+(timeout 900 python -m pytest tests/test_wino43_gpu.py -q -x 2>&1 | tail -40) > gpurun_out/w43_tests.log 2>&1
+tail -30 gpurun_out/w43_tests.log
+(timeout 600 python tools/w43_bench.py 5 2>&1 | grep -v amdgpu.ids) > gpurun_out/w43_bench.md 2>&1
+cat gpurun_out/w43_bench.md
