@@ -32,7 +32,9 @@ def test_struct_layout_matches_header():
     # 10 pointer-sized fields, 26 int32 (incl. math_mode), then the weight_wino pointer (include/gen6d_hip.h: struct G6dConv)
     import ctypes as C
     # ... 3 fin pointers, 2 doubles, fin_groups + the round-3 batching fields in_image_mod, mul_group_images + reserved_
-    assert C.sizeof(lib.G6dConv) == 10 * 8 + 26 * 4 + 8 + 3 * 8 + 2 * 8 + 4 * 4 + 8 == lib.load().g6d_sizeof_conv_desc()
+    # ... weight_wino16, and (ABI v8) weight_wino43
+    assert C.sizeof(lib.G6dConv) == 10 * 8 + 26 * 4 + 8 + 3 * 8 + 2 * 8 + 4 * 4 + 8 + 8 == lib.load().g6d_sizeof_conv_desc()
+    assert lib.G6dConv.weight_wino43.offset == C.sizeof(lib.G6dConv) - 8
     assert lib.G6dConv.in_image_mod.offset == 80 + 26 * 4 + 8 + 24 + 16 + 4 and C.sizeof(lib.G6dCorrSeg) == 40
     assert lib.G6dConv.fin_scale.offset == 80 + 26 * 4 + 8 and lib.G6dConv.fin_count.offset == 80 + 26 * 4 + 8 + 24
     assert lib.G6dConv.N.offset == 80 and lib.G6dConv.split_k.offset == 80 + 24 * 4
