@@ -46,7 +46,8 @@
 
 #ifndef W43_ABLATE
 #define W43_ABLATE 0     // profiling builds only (results wrong by construction): 1 no barriers, 2 no next-chunk traffic, 3 no transform,
-                         // 4 no fragment reads, 5 all of them, 7 no epilogue
+                         // 4 no fragment reads, 5 all of them, 7 no epilogue, 8 requests issued with EXEC = 0 (their scalar code stays), 10 filter pieces always from
+                         // the first chunk (L1 / L2 hits)
 #endif
 #define W43ABL(n) (W43_ABLATE == (n) || W43_ABLATE == 5)
 
@@ -84,6 +85,7 @@ __device__ __forceinline__ f2 fma2(f2 a, float k, f2 c) { return __builtin_eleme
 // 16-lane service groups over 32 banks, for which the images below are 2- and 4-way conflicted (volatile keeps the counters tracked)
 typedef __attribute__((address_space(3))) float lds_float;
 __device__ __forceinline__ f2 lds_rd64(const lds_float* p) { return *reinterpret_cast<const volatile __attribute__((address_space(3))) f2*>(p); }
+__device__ __forceinline__ f32x4 lds_rd128(const lds_float* p) { return *reinterpret_cast<const volatile __attribute__((address_space(3))) f32x4*>(p); }
 
 // Accumulators: 18 x 4 tiles of 4 registers = 288 > the 256 AGPRs hipcc gives the builtin's accumulators; the 8 tiles that do not
 // fit would be copied VGPR <-> AGPR around every MFMA (v_accvgpr_write / read: 128 vector-ALU instructions per chunk).  Those tiles
@@ -145,7 +147,8 @@ __global__ void __launch_bounds__(256, 1) wino43_kernel(const W43Args p) {
   constexpr int THREADS = 256, NQ = W43_NQ;
   constexpr int RAWF = W43_RAWF;                            // 28 wave-instructions of 64 16-byte slots (the image itself ends at slot 1616)
   constexpr int HALF = 18 * 16 * NT * 8;                    // floats of one filter half-slot: [18 positions][16 NT channels][8]
-  constexpr int AFF0 = RAWF + 2 * HALF;                     // affine tables behind the stages
+  constexpr int FLT0 = 2 * RAWF;                            // two raw stages, then two filter slots, then the affine tables
+  constexpr int AFF0 = FLT0 + 2 * HALF;
   constexpr int NPR = 7;                                    // 16-byte raw slots per thread and chunk
   constexpr int PCS = 9 * NT;                               // 1 KB direct-to-LDS pieces per half-slot (32 channels x 32 B each)
   constexpr int NPC = (PCS + 3) / 4;                        // ... per wave (NT = 2: 4.5 -> 5, the surplus pieces repeat piece idx % PCS)
@@ -205,7 +208,7 @@ __global__ void __launch_bounds__(256, 1) wino43_kernel(const W43Args p) {
   f32x4 rp[MODE != 0 ? NPR : 1];
   bool rv[MODE != 0 ? NPR : 1];
   // piece j of chunk `chunk`: MODE 0 straight to LDS, otherwise into rp[j] (the affine prologue runs in registers: store_raw)
-  auto load_piece = [&](int j, int chunk) {
+  auto load_piece = [&](int j, int chunk, int stage, unsigned long long em) {
     const int kd = KD == 25 ? chunk % 25 : (KD != 1 ? chunk / nc8 : 0), cc = KD == 25 ? chunk / 25 : (KD != 1 ? chunk - kd * nc8 : chunk);
     unsigned voff; int soff = 0;
     if constexpr (KD == 1) { voff = pboff[j]; soff = cc * 32; }
@@ -222,21 +225,23 @@ __global__ void __launch_bounds__(256, 1) wino43_kernel(const W43Args p) {
       voff = v ? (unsigned)off << 2 : 0x80000000u;
     }
     if constexpr (MODE == 0) {
-      const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr0 + 1024u * (unsigned)(wave * NPR + j));
+      const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr0 + 4u * (unsigned)(stage * RAWF) + 1024u * (unsigned)(wave * NPR + j));
       unsigned keep;
-      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
-                   : "=&s"(keep) : "v"(voff), "s"(in_rsrc), "s"(dst), "s"(soff) : "memory");
+      unsigned long long ex;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b64 %1, exec\n\ts_mov_b32 m0, %4\n\ts_mov_b64 exec, %6\n\tbuffer_load_dwordx4 %2, %3, %5 offen lds\n\t"
+                   "s_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep), "=&s"(ex) : "v"(voff), "s"(in_rsrc), "s"(dst), "s"(soff), "s"(em) : "memory");
     } else {
       if constexpr (KD == 1) rv[j] = pval[j];
       rp[j] = __builtin_bit_cast(f32x4, __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, voff, soff, 0)));
     }
   };
-  auto load_raw = [&](int chunk) {
+  auto load_raw = [&](int chunk, int stage) {
     if (W43ABL(2)) return;
 #pragma unroll
-    for (int j = 0; j < NPR; ++j) load_piece(j, chunk);
+    for (int j = 0; j < NPR; ++j) load_piece(j, chunk, stage, ~0ull);
   };
-  auto store_raw = [&](int chunk) {                            // MODE != 0 only: affine (+ReLU), exact zeros outside the image, -> LDS
+  auto store_raw = [&](int chunk, int stage) {                 // MODE != 0 only: affine (+ReLU), exact zeros outside the image, -> LDS
     if constexpr (MODE != 0) {
       if (W43ABL(2)) return;
       const int cc = KD != 1 ? chunk % nc8 : chunk;
@@ -248,7 +253,7 @@ __global__ void __launch_bounds__(256, 1) wino43_kernel(const W43Args p) {
         v = v * sc + sh;
         if (p.in_relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
         if (!rv[j]) v = f32x4{0.f, 0.f, 0.f, 0.f};
-        *reinterpret_cast<f32x4*>(__builtin_assume_aligned(lds + ((wave * NPR + j) * 64 + lane) * 4, 16)) = v;
+        *reinterpret_cast<f32x4*>(__builtin_assume_aligned(lds + stage * RAWF + ((wave * NPR + j) * 64 + lane) * 4, 16)) = v;
       }
     }
   };
@@ -263,25 +268,37 @@ __global__ void __launch_bounds__(256, 1) wino43_kernel(const W43Args p) {
     }
     __syncthreads();
   }
-  // ---- filter half-slots: U43 is [chunk][half][18 positions][Cout][8]; a block's half is 18 runs of 16 NT x 32 bytes, moved
-  // global -> LDS directly in 1 KB pieces (inline asm: with the builtin hipcc books the copy on the LDS counter as well)
+  // ---- filter half-tiles: U43 is [chunk][half][co block][18 positions][NT/2][kg][lt][4] — a block's half is ONE contiguous run of
+  // 18 NT KB in exactly the order of its LDS image, moved global -> LDS directly in 1 KB pieces (inline asm: with the builtin hipcc
+  // books the copy on the LDS counter as well).  A lane's 16 bytes at [position][np][kg][lt] are its B operands for the channel tiles
+  // 2np and 2np+1 (two channels each): ONE ds_read_b128 per two tiles, conflict-free in all four 16-lane service groups, and at the
+  // full LDS rate from one wave per SIMD (8-byte reads reach a fifth of it there: MI355X_MICROARCH.md, LDS).
+  // Two slots: phase X computes from slot 0 while slot 1 receives Y of the chunk, phase Y from slot 1 while slot 0 receives X of the
+  // next chunk.  (A ring of three slots with two phases of lead was measured and changed nothing: what the requests cost is not their
+  // latency but their issue — the four waves of a block run the same code in step, and a 1 KB piece occupies the CU's one address
+  // path for 16 cycles: issued in the same gap, the fourth wave waits 48.  The requests are therefore STAGGERED: wave w uses the
+  // gaps of parity w & 1, and the raw image is double-buffered so that its pieces spread over both phases.)
   const unsigned lane16 = lane * 16;
-  const char* ubase = reinterpret_cast<const char*>(p.U + (size_t)n0 * 8);
-  const size_t chunk_bytes = (size_t)36 * p.Cout * 32;
-  auto glds = [&](int chunk, int half, int k) {
+  const char* ubase = reinterpret_cast<const char*>(p.U) + (size_t)blockIdx.y * (HALF * 4);
+  const size_t half_bytes = (size_t)gridDim.y * (HALF * 4);
+  // The requests in the chunk loop are exec-masked (`em`): both wave parities run the same instruction stream, and a request whose
+  // gap belongs to the other parity executes with EXEC = 0 — the hardware drops it — instead of being branched around.
+  const unsigned long long em_all = ~0ull;
+  auto glds = [&](int chunk, int half, int slot, int k, unsigned long long em) {
     if (W43ABL(2)) return;
     int idx = wave * NPC + k;
     if (PCS % 4 != 0) idx = idx % PCS;
-    const int pos = idx / (NT / 2), sub = idx % (NT / 2);
-    const char* g = ubase + (size_t)chunk * chunk_bytes + (unsigned)(((half * 18 + pos) * p.Cout + sub * 32) * 32);
-    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr0 + 4u * (unsigned)(RAWF + half * HALF + (pos * 16 * NT + sub * 32) * 8));
+    const char* g = ubase + (size_t)(2 * chunk + half) * half_bytes + (unsigned)(idx * 1024);
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr0 + 4u * (unsigned)(FLT0 + slot * HALF) + 1024u * (unsigned)idx);
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(lane16), "s"(g), "s"(dst) : "memory");
+    unsigned long long ex;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b64 %1, exec\n\ts_mov_b32 m0, %4\n\ts_mov_b64 exec, %5\n\tglobal_load_lds_dwordx4 %2, %3\n\t"
+                 "s_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep), "=&s"(ex) : "v"(lane16), "s"(g), "s"(dst), "s"(em) : "memory");
   };
-  auto load_u = [&](int chunk, int half) {
+  auto load_u = [&](int chunk, int half, int slot) {
 #pragma unroll
-    for (int k = 0; k < NPC; ++k) glds(chunk, half, k);
+    for (int k = 0; k < NPC; ++k) glds(chunk, half, slot, k, em_all);
   };
 
   // ---- fragment bases.  A: tile lt of the pair = quarter 4 pr + (lt >> 2), tile (ty, tx) of its 2x2; raw rows 4 ty + i
@@ -292,8 +309,8 @@ __global__ void __launch_bounds__(256, 1) wino43_kernel(const W43Args p) {
   int arow[5];                                                // float offsets of raw rows hh .. hh+4 of the lane's tile
 #pragma unroll
   for (int k = 0; k < 5; ++k) arow[k] = (hh + k < 4 ? abase_lo : abase_hi) + (hh + k) * 80;
-  // B: channel 16 nt + lt of the block, slot kg of its 8-float row (halves swapped for co & 8 on the host)
-  const int bbase = RAWF + ((9 * hh) * 16 * NT + lt) * 8 + 2 * (kg ^ (2 * ((lt >> 3) & 1)));
+  // B: 16 bytes at [position 9 hh + pp][np][kg][lt] of the slot = lane-linear within the 1 KB row of (position, np)
+  const int bbase = FLT0 + (9 * hh) * (NT / 2) * 256 + lane * 4;
 
   f32x4 acc[3][6][NT];
 #pragma unroll
@@ -304,30 +321,31 @@ __global__ void __launch_bounds__(256, 1) wino43_kernel(const W43Args p) {
       for (int n = 0; n < NT; ++n) acc[a][b][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const lds_float* L = (const lds_float*)lds;
-  load_u(c_first, 0);
-  load_raw(c_first);
-  store_raw(c_first);
+  load_u(c_first, 0, 0);
+  load_raw(c_first, 0);
+  store_raw(c_first, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   f2 V[3][6];
-  // One phase: the 9 positions (3 rows x columns B0..B0+2) of filter slot `half`, 2 NT MFMAs each (s = 0: channels 2kg, s = 1: 2kg + 1;
+  // One phase: the 9 positions (3 rows x columns B0..B0+2) of filter slot `slot`, 2 NT MFMAs each (s = 0: channels 2kg, s = 1: 2kg + 1;
   // consecutive MFMAs go to different accumulators).  One wave per SIMD: only the wave's own instruction order hides latency, so
-  // everything else is pinned into the MFMA gaps — the NT fragment reads of position pp + 1 behind the first NT MFMAs of position pp,
-  // one memory request `req(k)` (direct-to-LDS pieces of the next half / chunk) behind each of the other NT.
-  f2 bf[2][NT];
-  auto phase_begin = [&](int half) {              // fragments of the phase's first position
-    const lds_float* S = L + bbase + half * HALF;
+  // everything else is pinned into the MFMA gaps — the NT/2 fragment reads of position pp + 1 behind the first MFMAs of position pp,
+  // memory request j of the phase (`req(j)`: direct-to-LDS pieces) behind MFMA 2j + (w & 1) of the phase's second halves.
+  f32x4 bq[2][NT / 2];
+  auto phase_begin = [&](int slot) {              // fragments of the phase's first position
+    const lds_float* S = L + bbase + slot * HALF;
 #pragma unroll
-    for (int n = 0; n < NT; ++n) bf[0][n] = W43ABL(4) ? f2{1.f, 1.f} : lds_rd64(S + (16 * n) * 8);
+    for (int n = 0; n < NT / 2; ++n) bq[0][n] = W43ABL(4) ? f32x4{1.f, 1.f, 1.f, 1.f} : lds_rd128(S + n * 256);
     if (W43ABL(4)) {
 #pragma unroll
-      for (int n = 0; n < NT; ++n) bf[1][n] = f2{1.f, 1.f};
+      for (int n = 0; n < NT / 2; ++n) bq[1][n] = f32x4{1.f, 1.f, 1.f, 1.f};
     }
   };
-  auto phase = [&](auto B0c, int half, auto&& req) {
+  const unsigned long long emask[2] = {(wave & 1) == 0 && W43_ABLATE != 8 ? ~0ull : 0ull, (wave & 1) == 1 && W43_ABLATE != 8 ? ~0ull : 0ull};
+  auto phase = [&](auto B0c, int slot, auto&& req) {
     constexpr int B0 = decltype(B0c)::value;
-    const lds_float* S = L + bbase + half * HALF;
+    const lds_float* S = L + bbase + slot * HALF;
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int pp = 0; pp < 9; ++pp) {
@@ -335,19 +353,25 @@ __global__ void __launch_bounds__(256, 1) wino43_kernel(const W43Args p) {
 #pragma unroll
       for (int m = 0; m < 2 * NT; ++m) {
         const int sidx = m / NT, n = m % NT;
-        if (NT == 4 && ai == 2 && b >= 4) mfma16<true>(V[ai][b][sidx], bf[pp & 1][n][sidx], acc[ai][b][n]);
-        else mfma16<false>(V[ai][b][sidx], bf[pp & 1][n][sidx], acc[ai][b][n]);
-        if (m < NT) { if (pp + 1 < 9 && !W43ABL(4)) bf[(pp + 1) & 1][n] = lds_rd64(S + ((pp + 1) * 16 * NT + 16 * n) * 8); }
-        else req(pp * NT + (m - NT));
+        const float bv = bq[pp & 1][n >> 1][2 * (n & 1) + sidx];
+        if (NT == 4 && ai == 2 && b >= 4) mfma16<true>(V[ai][b][sidx], bv, acc[ai][b][n]);
+        else mfma16<false>(V[ai][b][sidx], bv, acc[ai][b][n]);
+        if (m < NT / 2) { if (pp + 1 < 9 && !W43ABL(4)) bq[(pp + 1) & 1][m] = lds_rd128(S + ((pp + 1) * (NT / 2) + m) * 256); }
+        else if (m >= NT) {
+          const int k = pp * NT + (m - NT);          // gap slot of the phase; request k >> 1 goes to the waves of parity k & 1
+          req(k >> 1, k & 1);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
   };
   using I0 = std::integral_constant<int, 0>;
   using I3 = std::integral_constant<int, 3>;
+  constexpr int NRX = NPR / 2, NRY = NPR - NRX;   // raw pieces requested in phase X / phase Y (MODE 0)
 
   for (int cc = c_first; cc <= c_last; ++cc) {
     const int cn = min(cc + 1, c_last);           // the last chunk re-requests itself: no branches
+    const int st = (cc - c_first) & 1;            // raw stage of this chunk
     // ---- phase X: raw tile -> registers, input transform, 9 positions of slot 0 while slot 1 receives Y of this chunk.
     // The wave's rows a = 3hh..3hh+2 of B^T d need raw rows hh..hh+4 only (r0..r2: d0..d4, r3..r5: d1..d5)
     {
@@ -355,7 +379,7 @@ __global__ void __launch_bounds__(256, 1) wino43_kernel(const W43Args p) {
 #pragma unroll
       for (int j = 0; j < 6; ++j)
 #pragma unroll
-        for (int k = 0; k < 5; ++k) e[k][j] = W43ABL(4) ? f2{1.f, 1.f} : lds_rd64(L + arow[k] + j * 8);
+        for (int k = 0; k < 5; ++k) e[k][j] = W43ABL(4) ? f2{1.f, 1.f} : lds_rd64(L + st * RAWF + arow[k] + j * 8);
       phase_begin(0);                              // ... and the first filter fragments: they arrive behind the transform
       if (W43ABL(3)) {
 #pragma unroll
@@ -386,22 +410,24 @@ __global__ void __launch_bounds__(256, 1) wino43_kernel(const W43Args p) {
       }
     }
     __builtin_amdgcn_sched_barrier(0);
-    // requests of phase X: the NPC filter pieces of Y (direct to LDS: invisible to the compiler's load counting, so they are issued
-    // BEFORE the loads it waits for), then (MODE != 0) the raw pieces of chunk c+1 into registers
-    phase(I0{}, 0, [&](int k) {
-      if (k < NPC) glds(cc, 1, k);
-      else if (MODE != 0 && k - NPC < NPR && !W43ABL(2)) load_piece(k - NPC, cn);
+    // requests of phase X: the NPC pieces of Y of this chunk (direct to LDS: invisible to the compiler's load counting, so they are
+    // issued BEFORE the loads it waits for), then raw pieces of chunk c+1 for the other raw stage (MODE 0: the first NRX, straight to
+    // LDS — they may stay in flight over the barrier; MODE != 0: all of them, into registers)
+    phase(I0{}, 0, [&](int k, int par) {
+      if (k < NPC) glds(W43_ABLATE == 10 ? c_first : cc, 1, 1, k, emask[par]);
+      else if (MODE == 0 && k - NPC < NRX && !W43ABL(2)) load_piece(k - NPC, cn, st ^ 1, emask[par]);
+      else if (MODE != 0 && k - NPC < NPR && par == 0 && !W43ABL(2)) load_piece(k - NPC, cn, st ^ 1, ~0ull);     // register loads: not staggered
     });
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // slot 1 has landed
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MODE != 0 ? NPR : NRX) : "memory");     // slot 1 has landed
     if (!W43ABL(1)) __syncthreads();
-    // ---- phase Y: every wave has read the raw image of chunk c, which now receives chunk c+1 (MODE 0: straight from memory;
-    // otherwise the pieces loaded during phase X, through the prologue), slot 0 <- X of chunk c+1, 9 positions of slot 1
+    // ---- phase Y: 9 positions of slot 1 while slot 0 receives X of chunk c+1 and the other raw stage the rest of its image
+    // (MODE != 0: the pieces loaded during phase X, through the prologue)
     phase_begin(1);
-    if constexpr (MODE != 0) store_raw(cn);
+    if constexpr (MODE != 0) store_raw(cn, st ^ 1);
     __builtin_amdgcn_sched_barrier(0);
-    phase(I3{}, 1, [&](int k) {
-      if (k < NPC) glds(cn, 0, k);
-      else if (MODE == 0 && k - NPC < NPR && !W43ABL(2)) load_piece(k - NPC, cn);
+    phase(I3{}, 1, [&](int k, int par) {
+      if (k < NPC) glds(W43_ABLATE == 10 ? c_first : cn, 0, 0, k, emask[par]);
+      else if (MODE == 0 && k - NPC < NRY && !W43ABL(2)) load_piece(NRX + k - NPC, cn, st ^ 1, emask[par]);
     });
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (!W43ABL(1)) __syncthreads();
@@ -593,7 +619,7 @@ __global__ void __launch_bounds__(256, 1) wino43_kernel(const W43Args p) {
 // ---- launch: split over the chunks, instantiation
 template <int MODE, int KD, int NT>
 int w43_launch_t(W43Args& a, long long blocks, hipStream_t stream) {
-  const size_t lds_bytes = ((size_t)W43_RAWF + 2 * (18 * 16 * NT * 8) + 4 * 256 + (MODE == 0 ? 0 : (MODE >= 2 ? 2 * W43_NQ : 2) * a.Cin)) * sizeof(float);
+  const size_t lds_bytes = ((size_t)2 * W43_RAWF + 2 * (18 * 16 * NT * 8) + (MODE == 0 ? 0 : (MODE >= 2 ? 2 * W43_NQ : 2) * a.Cin)) * sizeof(float);
   const size_t need = std::max(lds_bytes, (size_t)4 * 4096 * sizeof(float));      // the epilogue exchange: 16 KB per wave
   g6d_allow_lds(reinterpret_cast<const void*>(&wino43_kernel<MODE, KD, NT>), 160 * 1024);
   hipLaunchKernelGGL((wino43_kernel<MODE, KD, NT>), dim3((unsigned)blocks, a.Cout / (16 * NT), a.splits), dim3(256), need, stream, a);
@@ -618,7 +644,7 @@ int w43_run(W43Args& a, int mode, int kd, float* workspace, size_t workspace_byt
   if (in_extent * 4 >= (1ll << 31)) { g6d_set_error("wino43: input tensor exceeds 2^31 bytes"); return G6D_EINVAL; }
   a.in_bytes = (unsigned)(in_extent * 4);
   const int nt = (a.Cout & 63) ? 2 : 4;
-  if (mode != 0 && (size_t)(mode >= 2 ? 2 * W43_NQ : 2) * a.Cin * 4 + ((size_t)W43_RAWF + 2 * 18 * 16 * nt * 8 + 1024) * 4 > 160 * 1024) {
+  if (mode != 0 && (size_t)(mode >= 2 ? 2 * W43_NQ : 2) * a.Cin * 4 + ((size_t)2 * W43_RAWF + 2 * 18 * 16 * nt * 8) * 4 > 160 * 1024) {
     g6d_set_error("wino43: affine tables do not fit LDS"); return G6D_EINVAL;
   }
   // Split of the (kd, chunk) list over gridDim.z: one block per CU is resident and runs a serial loop of ~2.6 us per chunk (NT = 4;
@@ -661,8 +687,7 @@ int w43_run(W43Args& a, int mode, int kd, float* workspace, size_t workspace_byt
 }  // namespace
 
 // One trunk layer over up to 4 map sizes in ONE launch, as g6d_wino_conv3x3_multi, on the F(4x4,3x3) kernel.  U43 = the filters
-// transformed on the host (backbone.winograd43_filters): [Cin/8][2][18][Cout][8] — chunk c, column half (b < 3 / b >= 3), position
-// a*3 + b%3, output channel, the chunk's 8 input channels with the two 4-channel halves swapped for co & 8.
+// transformed on the host (backbone.winograd43_filters): [Cin/8][2][Cout/64][18][2][4][16][4] (include/gen6d_hip.h).
 // Replaces features[4..27] of vgg11_bn on the detector's image pyramid (network/pretrain_models.py:17-25, network/detector.py:236-241).
 extern "C" int g6d_wino43_conv3x3_multi(const G6dWinoSeg* segs, int nseg, int Cin, const float* U43, const float* bias, int Cout, int relu,
                                         float* workspace, size_t workspace_bytes, g6d_stream_t stream) {
@@ -700,7 +725,7 @@ extern "C" int g6d_wino43_conv3x3_multi(const G6dWinoSeg* segs, int nseg, int Ci
 
 // The detector's 15x15 reference-as-filter correlation (network/detector.py:222-224) as 5x5 blocks of 3x3 sub-filters accumulated in
 // the F(4x4,3x3) transform domain: 225 taps cost 25 * 36 / 16 = 56.25 multiplications per output.  Maps as g6d_corr2d_wino_multi;
-// U43 = the 25 sub-filter banks transformed like g6d_wino43_conv3x3_multi's, CHUNK-major: [Cin/8 * 25][2][18][Cout][8], row
+// U43 = the 25 sub-filter banks transformed like g6d_wino43_conv3x3_multi's, CHUNK-major: [Cin/8 * 25][2][Cout/CB][18][CB/32][4][16][4], row
 // c * 25 + b = 8-channel chunk c of block b = 5 bi + bj holding w[:, 3bi..3bi+2, 3bj..3bj+2, :]; Cout % 32 == 0.
 extern "C" int g6d_corr2d_wino43_multi(const G6dCorrSeg* segs, int nseg, int Cin, const float* U43, int Cout, int kblocks, float* workspace,
                                        size_t workspace_bytes, g6d_stream_t stream) {
@@ -740,7 +765,7 @@ bool g6d_wino43_eligible(const G6dConv& d) {
   if (!(k2 || k3) || d.kh != 3 || d.kw != 3 || d.ph != 1 || d.pw != 1 || d.sd != 1 || d.sh != 1 || d.sw != 1) return false;
   if ((d.Cin & 7) || (d.Cout & 63) || d.Hi < 8 || d.Wi < 8 || d.out_act > 1 || d.split_k > 1) return false;
   if (d.stats && d.stat_rows_per_group > 0 && d.stat_rows_per_group % (d.Do * d.Ho * d.Wo)) return false;
-  if (d.in_scale && (d.Cin > 512 || (d.Cin & 3))) return false;
+  if (d.in_scale && (d.Cin > 256 || (d.Cin & 3))) return false;      // affine tables of the block's eight quarters beside three filter slots
   if (!g6d_aligned16(d.weight_wino43)) return false;
   if ((long long)d.N * d.Di * ((d.Hi + 7) / 8) * ((d.Wi + 7) / 8) >= (1ll << 31)) return false;
   return (long long)d.N * d.Di * d.Hi * d.Wi * d.ld_in < (1ll << 29);

@@ -120,23 +120,24 @@ def winograd43_matrices(dtype=torch.float64, device=None):
 
 
 def winograd43_filters(w):
-    """[Cout,Cin,3,3] -> U43 [Cin/8, 2, 18, Cout, 8] for g6d_wino43_conv3x3_multi: U43[c][b // 3][3 a + b % 3][co][k ^ (4 if co & 8 else 0)]
-    = (G g G^T)[a][b] of filter (co, 8c + k) — a chunk's filter tile in the two column halves the kernel stages one after the other,
-    rows with co & 8 carrying their two 4-channel halves swapped (bank-conflict-free fragment reads).  Computed in fp64."""
+    """[Cout,Cin,3,3] -> U43 [Cin/8, 2, Cout/CB, 18, CB/32, 4, 16, 4] (CB = 64, or 32 when Cout % 64) for g6d_wino43_conv3x3_multi:
+    U43[c][b // 3][blk][3 a + b % 3][np][kg][lt][2 par + s] = (G g G^T)[a][b] of filter (co = CB blk + 32 np + 16 par + lt,
+    ci = 8 c + 2 kg + s) — per 8-channel chunk the two column halves the kernel stages one after the other, each half of a CB-channel
+    block ONE contiguous run in the order of its LDS image (a lane reads the 16 bytes at [position][np][kg][lt]: its B operands for
+    the channel tiles 2 np and 2 np + 1).  Computed in fp64."""
     co, ci = w.shape[:2]
     if ci % 8 or co % 32:
         raise ValueError("winograd43_filters: Cin % 8 == 0 and Cout % 32 == 0 expected")
+    cb = 32 if co % 64 else 64
     _, G, _ = winograd43_matrices(device=w.device)
     U = torch.einsum("ai,ocij,bj->ocab", G, w.double(), G).to(w.dtype)               # [co,ci,6,6]
-    U = U.reshape(co, ci // 8, 8, 6, 2, 3).permute(1, 4, 3, 5, 0, 2)                 # [chunk][half][a][b % 3][co][8]
-    U = U.reshape(ci // 8, 2, 18, co, 8).contiguous()
-    swap = (torch.arange(co, device=w.device) & 8) != 0
-    U[:, :, :, swap] = torch.cat([U[:, :, :, swap, 4:], U[:, :, :, swap, :4]], -1)
-    return U
+    U = U.reshape(co // cb, cb // 32, 2, 16, ci // 8, 4, 2, 6, 2, 3)                 # blk, np, par, lt, c, kg, s, a, half, b3
+    U = U.permute(4, 8, 0, 7, 9, 1, 5, 3, 2, 6)                                      # c, half, blk, a, b3, np, kg, lt, par, s
+    return U.reshape(ci // 8, 2, co // cb, 18, cb // 32, 4, 16, 4).contiguous()
 
 
 def winograd43_filters_taps(w_taps, kd=1):
-    """[Cout, kd*9, Cin] (ParamBank.conv_w) -> [kd*Cin/8, 2, 18, Cout, 8]: one winograd43_filters block per depth tap, depth taps outermost
+    """[Cout, kd*9, Cin] (ParamBank.conv_w) -> [kd*Cin/8, 2, Cout/CB, 18, CB/32, 4, 16, 4]: one winograd43_filters block per depth tap, depth taps outermost
     (G6dConv.weight_wino43)."""
     co, taps, ci = w_taps.shape
     assert taps == kd * 9
@@ -145,13 +146,13 @@ def winograd43_filters_taps(w_taps, kd=1):
 
 
 def winograd43_corr_filters(w_taps, k):
-    """Correlation filters [Cout, k*k, Cin], k = 3*kb -> U43 [Cin/8 * kb*kb, 2, 18, Cout, 8] for g6d_corr2d_wino43_multi: CHUNK-major
+    """Correlation filters [Cout, k*k, Cin], k = 3*kb -> U43 [Cin/8 * kb*kb, 2, Cout/CB, 18, CB/32, 4, 16, 4] for g6d_corr2d_wino43_multi: CHUNK-major
     like winograd_corr_filters (row c * kb*kb + b = 8-channel chunk c of block b = kb*bi + bj)."""
     co, taps, ci = w_taps.shape
     kb = k // 3
     assert taps == k * k and k == 3 * kb
     w = w_taps.reshape(co, kb, 3, kb, 3, ci).permute(1, 3, 0, 5, 2, 4)      # [bi, bj, co, ci, 3, 3]
-    U = torch.stack([winograd43_filters(w[bi, bj].contiguous()) for bi in range(kb) for bj in range(kb)], 1)      # [Cin/8, kb*kb, 2, 18, Cout, 8]
+    U = torch.stack([winograd43_filters(w[bi, bj].contiguous()) for bi in range(kb) for bj in range(kb)], 1)      # [Cin/8, kb*kb, 2, Cout/CB, 18, CB/32, 4, 16, 4]
     return U.reshape(-1, *U.shape[2:]).contiguous()
 
 

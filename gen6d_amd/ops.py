@@ -169,8 +169,8 @@ def conv(x, w, bias, out, ksize=(1, 1, 1), stride=(1, 1, 1), pad=(0, 0, 0), mul=
             raise ValueError(f"conv.mul: expected contiguous {want}")
     if w_wino is not None and (tuple(w_wino.shape) != (kd * (Cin // 8), 16, Cout, 8) or not w_wino.is_contiguous()):
         raise ValueError(f"conv.w_wino: expected contiguous {(kd * (Cin // 8), 16, Cout, 8)}, got {tuple(w_wino.shape)}")
-    if w_wino43 is not None and (tuple(w_wino43.shape) != (kd * (Cin // 8), 2, 18, Cout, 8) or not w_wino43.is_contiguous()):
-        raise ValueError(f"conv.w_wino43: expected contiguous {(kd * (Cin // 8), 2, 18, Cout, 8)}, got {tuple(w_wino43.shape)}")
+    if w_wino43 is not None and (tuple(w_wino43.shape) != w43_shape(kd * (Cin // 8), Cout) or not w_wino43.is_contiguous()):
+        raise ValueError(f"conv.w_wino43: expected contiguous {w43_shape(kd * (Cin // 8), Cout)}, got {tuple(w_wino43.shape)}")
     u16 = None
     if MATH_MODE and w_wino is not None and Cin % 16 == 0 and Cout % 64 == 0:
         # reduced-precision mode: the layer's Winograd filters rounded to the operand type, built once per (layer, type) and kept
@@ -543,16 +543,22 @@ def wino_conv3x3_multi(xs, U, bias, relu=True, full=True, pool=False):
     return ys, yps
 
 
+def w43_shape(chunks, Cout):
+    """Shape of the F(4x4,3x3) filter tensor (backbone.winograd43_filters) for `chunks` 8-channel chunks and Cout output channels."""
+    cb = 32 if Cout % 64 else 64
+    return (chunks, 2, Cout // cb, 18, cb // 32, 4, 16, 4)
+
+
 def wino43_conv3x3_multi(xs, U43, bias, relu=True, full=True, pool=False):
     """wino_conv3x3_multi on the Winograd F(4x4,3x3) kernel (g6d_wino43_conv3x3_multi): 4x fewer multiplications than the direct form
     (1.78x fewer than F(2x2,3x3)) at ~5x the fp32 error — for the layers whose parity budget has the room (the detector's pyramid).
-    U43 [Cin/8,2,18,Cout,8] (backbone.winograd43_filters), Cout % 64 == 0."""
+    U43 = backbone.winograd43_filters(w) (shape w43_shape(Cin/8, Cout)), Cout % 64 == 0."""
     _need_gpu(U43, bias, *xs)
     if not 1 <= len(xs) <= 4:
         raise ValueError("wino43_conv3x3_multi: 1..4 segments")
-    Cin, Cout = xs[0].shape[3], U43.shape[3]
-    if tuple(U43.shape) != (Cin // 8, 2, 18, Cout, 8) or not U43.is_contiguous() or bias.numel() != Cout:
-        raise ValueError(f"wino43_conv3x3_multi: U43 must be contiguous {(Cin // 8, 2, 18, Cout, 8)}")
+    Cin, Cout = xs[0].shape[3], bias.numel()
+    if tuple(U43.shape) != w43_shape(Cin // 8, Cout) or not U43.is_contiguous():
+        raise ValueError(f"wino43_conv3x3_multi: U43 must be contiguous {w43_shape(Cin // 8, Cout)}")
     for x in xs:
         if x.dim() != 4 or x.dtype != torch.float32 or not x.is_contiguous() or x.shape[3] != Cin:
             raise ValueError("wino43_conv3x3_multi: segments must be contiguous float32 [N,H,W,Cin]")
@@ -583,14 +589,14 @@ def wino43_conv3x3_multi(xs, U43, bias, relu=True, full=True, pool=False):
 
 
 def corr2d_wino43_multi(xs, U43, outs, kblocks=5):
-    """corr2d_wino_multi on the F(4x4,3x3) kernel (g6d_corr2d_wino43_multi): U43 [kblocks^2 * Cin/8, 2, 18, Cout, 8]
-    (backbone.winograd43_corr_filters), Cout % 32 == 0."""
+    """corr2d_wino_multi on the F(4x4,3x3) kernel (g6d_corr2d_wino43_multi): U43 = backbone.winograd43_corr_filters(w, 15)
+    (shape w43_shape(kblocks^2 * Cin/8, Cout)), Cout % 32 == 0."""
     _need_gpu(U43, *xs, *outs)
     if not 1 <= len(xs) <= 4 or len(outs) != len(xs):
         raise ValueError("corr2d_wino43_multi: 1..4 map sizes")
-    Cin, Cout = xs[0].shape[4], U43.shape[3]
-    if tuple(U43.shape) != (kblocks * kblocks * (Cin // 8), 2, 18, Cout, 8) or not U43.is_contiguous():
-        raise ValueError(f"corr2d_wino43_multi: U43 must be contiguous {(kblocks * kblocks * (Cin // 8), 2, 18, Cout, 8)}")
+    Cin, Cout = xs[0].shape[4], outs[0].shape[4]
+    if tuple(U43.shape) != w43_shape(kblocks * kblocks * (Cin // 8), Cout) or not U43.is_contiguous():
+        raise ValueError(f"corr2d_wino43_multi: U43 must be contiguous {w43_shape(kblocks * kblocks * (Cin // 8), Cout)}")
     segs = (_lib.G6dCorrSeg * len(xs))()
     flops, sizes = 0.0, []
     k = 3 * kblocks

@@ -119,7 +119,7 @@ typedef struct G6dConv {
                                    Cin % 16 == 0, Cout % 64 == 0) then run on the 16-bit Winograd kernel instead of the direct kernels
                                    with 16-bit operands.  NULL = never. */
   const float* weight_wino43;   /* optional (ABI v8): the same filters transformed for Winograd F(4x4,3x3) in the layout of
-                                   g6d_wino43_conv3x3_multi's U43, [kd][Cin/8][2][18][Cout][8] (per depth tap for 3x3x3).  When set
+                                   g6d_wino43_conv3x3_multi's U43, [kd * Cin/8][2][Cout/64][18][2][4][16][4] (per depth tap for 3x3x3).  When set
                                    and the layer is eligible (fp32, stride 1, "same" padding, maps >= 8x8, Cin % 8 == 0, Cout % 64 ==
                                    0, no multiplier) the launch runs on the F(4x4,3x3) kernel: 4x fewer multiplications than the direct
                                    form at ~5x the fp32 error of F(2x2,3x3) — set it only on layers whose parity budget has the room
@@ -172,7 +172,7 @@ int g6d_corr2d_wino_multi(const G6dCorrSeg* segs, int nseg, int Cin, const float
 
 /* The same 15x15 correlation with the 25 blocks accumulated in the F(4x4,3x3) transform domain (ABI v8; kernel and filter layout of
  * g6d_wino43_conv3x3_multi): 225 taps cost 25 * 36 / 16 = 56.25 multiplications per output (F(2x2,3x3): 100).  U43 CHUNK-major
- * [Cin/8 * 25][2][18][Cout][8], row c*25 + b = chunk c of block b; Cin % 8 == 0, Cout % 32 == 0. */
+ * [Cin/8 * 25][2][Cout/CB][18][CB/32][4][16][4], row c*25 + b = chunk c of block b; Cin % 8 == 0, Cout % 32 == 0. */
 int g6d_corr2d_wino43_multi(const G6dCorrSeg* segs, int nseg, int Cin, const float* U43, int Cout, int kblocks, float* workspace,
                             size_t workspace_bytes, g6d_stream_t stream);
 
@@ -252,10 +252,12 @@ int g6d_wino16_conv3x3_multi(const G6dWinoSeg* segs, int nseg, int Cin, const vo
  * fp32 error is ~1.3e-6 of the output range at Cin = 512 (F(2x2,3x3): 2.5e-7; the textbook points 0, +-1, +-2: 4.6e-6).  Meant for the
  * layers whose parity budget has that room: the detector's image pyramid (network/pretrain_models.py:17-25, network/detector.py:188-197,
  * 236-241; headline detector parity 1.5e-6 of range against a 1e-4 bar).
- * U43 = the filters transformed on the host in fp64, [Cin/8][2][18][Cout][8]: chunk c of 8 input channels, column half (b < 3 / b >= 3
- * of the 6x6 transform positions), position 3a + b % 3, output channel, the chunk's 8 channels (rows with co & 8 carry their two
- * 4-channel halves swapped) — the two halves are the units the kernel stages in LDS.  Cin % 8 == 0, Cout % 64 == 0; segments, bias,
- * relu, outputs and workspace as g6d_wino_conv3x3_multi. */
+ * U43 = the filters transformed on the host in fp64, [Cin/8][2][Cout/CB][18][CB/32][4][16][4] (CB = 64; 32 when Cout % 64):
+ * U43[c][b / 3][blk][3a + b % 3][np][kg][lt][2 par + s] = (G g G^T)[a][b] of filter (co = CB blk + 32 np + 16 par + lt, ci = 8c + 2kg + s),
+ * (a, b) = position in the 6x6 transform domain.  Per chunk of 8 input channels the two column halves (b < 3, b >= 3) are the units
+ * the kernel stages in LDS: each half of a CB-channel block is one contiguous run (18 CB/32 KB) in the order of its LDS image, of which
+ * lane (kg, lt) reads the 16 bytes [position][np][kg][lt] — its B operands for two 16-channel tiles.  Cin % 8 == 0, Cout % 64 == 0;
+ * segments, bias, relu, outputs and workspace as g6d_wino_conv3x3_multi. */
 int g6d_wino43_conv3x3_multi(const G6dWinoSeg* segs, int nseg, int Cin, const float* U43, const float* bias, int Cout, int relu,
                              float* workspace, size_t workspace_bytes, g6d_stream_t stream);
 

@@ -193,17 +193,16 @@ def _wino43(x, U43, bias, relu, full, pool):
     backbone.winograd43_filters), in the dtype of x."""
     from gen6d_amd.network.backbone import winograd43_matrices
     N, H, W, Cin = x.shape
-    Cout = U43.shape[3]
+    Cout = U43.shape[2] * U43.shape[4] * 32
     dt = x.dtype
     BT, _, AT = winograd43_matrices(dtype=dt)
     Ht, Wt = (H + 3) // 4, (W + 3) // 4
     xp = F.pad(x, (0, 0, 1, 4 * Wt + 1 - W, 1, 4 * Ht + 1 - H))
     d = xp.unfold(1, 6, 4).unfold(2, 6, 4)                                             # [N,Ht,Wt,C,6,6]
     V = torch.einsum("ai,ntucij,bj->ntuabc", BT, d, BT)
-    U = U43.clone()
-    swap = (torch.arange(Cout) & 8) != 0                                               # undo the LDS-bank swizzle of the halves
-    U[:, :, :, swap] = torch.cat([U[:, :, :, swap, 4:], U[:, :, :, swap, :4]], -1)
-    U6 = U.reshape(Cin // 8, 2, 6, 3, Cout, 8).permute(2, 1, 3, 4, 0, 5).reshape(6, 6, Cout, Cin).to(dt)    # [a][b = 3 half + b%3][co][ci]
+    nblk, npp = U43.shape[2], U43.shape[4]
+    U6 = U43.reshape(Cin // 8, 2, nblk, 6, 3, npp, 4, 16, 2, 2)                        # c, half, blk, a, b3, np, kg, lt, par, s
+    U6 = U6.permute(3, 1, 4, 2, 5, 8, 7, 0, 6, 9).reshape(6, 6, Cout, Cin).to(dt)      # [a][b = 3 half + b3][co = blk, np, par, lt][ci = c, kg, s]
     M = torch.einsum("ntuabc,aboc->ntuabo", V, U6)
     Y = torch.einsum("pa,ntuabo,qb->ntupqo", AT, M, AT)                               # [N,Ht,Wt,4,4,Cout]
     y = Y.permute(0, 1, 3, 2, 4, 5).reshape(N, 4 * Ht, 4 * Wt, Cout)[:, :H, :W] + (bias.to(dt) if bias is not None else 0)
@@ -224,7 +223,7 @@ def corr2d_wino43_multi(xs, U43, outs, kblocks=5):
     for x, o in zip(xs, outs):
         N, _, H, W, Cin = x.shape
         nc = Cin // 8
-        acc = torch.zeros((N, H, W, U43.shape[3]), dtype=x.dtype)
+        acc = torch.zeros((N, H, W, U43.shape[2] * U43.shape[4] * 32), dtype=x.dtype)
         pad = 3 * (kb - 1) // 2 + 1
         xp = F.pad(x[:, 0], (0, 0, pad, pad, pad, pad))
         for bi in range(kb):
