@@ -203,15 +203,15 @@ __global__ void __launch_bounds__(256, 1) wino43_kernel(const W43Args p) {
   }
   const int slice = p.H0 * p.W0 * p.ld0;                      // KD = 3: one depth step
   const auto in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
-  const unsigned lds_addr0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)lds;
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-  f32x4 rp[MODE != 0 ? NPR : 1];
+  f32x4 rp[NPR];
   bool rv[MODE != 0 ? NPR : 1];
-  // piece j of chunk `chunk`: MODE 0 straight to LDS, otherwise into rp[j] (the affine prologue runs in registers: store_raw)
-  auto load_piece = [&](int j, int chunk, int stage, unsigned long long em) {
+  // piece j of chunk `chunk` -> rp[j] (the LDS image is written by store_piece, where the MODE != 0 prologue runs)
+  auto load_piece = [&](int j, int chunk) {
+    if (W43ABL(2)) return;
     const int kd = KD == 25 ? chunk % 25 : (KD != 1 ? chunk / nc8 : 0), cc = KD == 25 ? chunk / 25 : (KD != 1 ? chunk - kd * nc8 : chunk);
     unsigned voff; int soff = 0;
-    if constexpr (KD == 1) { voff = pboff[j]; soff = cc * 32; }
+    if constexpr (KD == 1) { voff = pboff[j]; soff = cc * 32; if constexpr (MODE != 0) rv[j] = pval[j]; }
     else {
       bool v = pval[j];
       int off = poff[j] + cc * 8;
@@ -224,38 +224,21 @@ __global__ void __launch_bounds__(256, 1) wino43_kernel(const W43Args p) {
       if constexpr (MODE != 0) rv[j] = v;
       voff = v ? (unsigned)off << 2 : 0x80000000u;
     }
-    if constexpr (MODE == 0) {
-      const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr0 + 4u * (unsigned)(stage * RAWF) + 1024u * (unsigned)(wave * NPR + j));
-      unsigned keep;
-      unsigned long long ex;
-      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b64 %1, exec\n\ts_mov_b32 m0, %4\n\ts_mov_b64 exec, %6\n\tbuffer_load_dwordx4 %2, %3, %5 offen lds\n\t"
-                   "s_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
-                   : "=&s"(keep), "=&s"(ex) : "v"(voff), "s"(in_rsrc), "s"(dst), "s"(soff), "s"(em) : "memory");
-    } else {
-      if constexpr (KD == 1) rv[j] = pval[j];
-      rp[j] = __builtin_bit_cast(f32x4, __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, voff, soff, 0)));
-    }
+    // bounds-checked buffer load: pieces outside the image ask for an offset beyond the tensor and get zeros from the hardware
+    rp[j] = __builtin_bit_cast(f32x4, __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, voff, soff, 0)));
   };
-  auto load_raw = [&](int chunk, int stage) {
+  auto store_piece = [&](int j, int chunk, int stage) {        // affine (+ReLU) with exact zeros outside the image for MODE != 0, -> LDS
     if (W43ABL(2)) return;
-#pragma unroll
-    for (int j = 0; j < NPR; ++j) load_piece(j, chunk, stage, ~0ull);
-  };
-  auto store_raw = [&](int chunk, int stage) {                 // MODE != 0 only: affine (+ReLU), exact zeros outside the image, -> LDS
+    f32x4 v = rp[j];
     if constexpr (MODE != 0) {
-      if (W43ABL(2)) return;
       const int cc = KD != 1 ? chunk % nc8 : chunk;
-#pragma unroll
-      for (int j = 0; j < NPR; ++j) {
-        f32x4 v = rp[j];
-        const f32x4 sc = *reinterpret_cast<const f32x4*>(lds + AFF0 + aoff[j] + cc * 8);
-        const f32x4 sh = *reinterpret_cast<const f32x4*>(lds + AFF0 + (MODE >= 2 ? NQ : 1) * p.Cin + aoff[j] + cc * 8);
-        v = v * sc + sh;
-        if (p.in_relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-        if (!rv[j]) v = f32x4{0.f, 0.f, 0.f, 0.f};
-        *reinterpret_cast<f32x4*>(__builtin_assume_aligned(lds + stage * RAWF + ((wave * NPR + j) * 64 + lane) * 4, 16)) = v;
-      }
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(lds + AFF0 + aoff[j] + cc * 8);
+      const f32x4 sh = *reinterpret_cast<const f32x4*>(lds + AFF0 + (MODE >= 2 ? NQ : 1) * p.Cin + aoff[j] + cc * 8);
+      v = v * sc + sh;
+      if (p.in_relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+      if (!rv[j]) v = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    *reinterpret_cast<f32x4*>(__builtin_assume_aligned(lds + stage * RAWF + ((wave * NPR + j) * 64 + lane) * 4, 16)) = v;
   };
   if constexpr (MODE != 0) {                  // InstanceNorm affine tables -> LDS: [G][Cin] scales, then [G][Cin] shifts
     constexpr int G = MODE >= 2 ? NQ : 1;
@@ -269,36 +252,27 @@ __global__ void __launch_bounds__(256, 1) wino43_kernel(const W43Args p) {
     __syncthreads();
   }
   // ---- filter half-tiles: U43 is [chunk][half][co block][18 positions][NT/2][kg][lt][4] — a block's half is ONE contiguous run of
-  // 18 NT KB in exactly the order of its LDS image, moved global -> LDS directly in 1 KB pieces (inline asm: with the builtin hipcc
-  // books the copy on the LDS counter as well).  A lane's 16 bytes at [position][np][kg][lt] are its B operands for the channel tiles
-  // 2np and 2np+1 (two channels each): ONE ds_read_b128 per two tiles, conflict-free in all four 16-lane service groups, and at the
-  // full LDS rate from one wave per SIMD (8-byte reads reach a fifth of it there: MI355X_MICROARCH.md, LDS).
+  // 18 NT KB in exactly the order of its LDS image.  A lane's 16 bytes at [position][np][kg][lt] are its B operands for the channel
+  // tiles 2np and 2np+1 (two channels each): ONE ds_read_b128 per two tiles, conflict-free in all four 16-lane service groups, and at
+  // the full LDS rate from one wave per SIMD (8-byte reads reach a fifth of it there: MI355X_MICROARCH.md, LDS).
   // Two slots: phase X computes from slot 0 while slot 1 receives Y of the chunk, phase Y from slot 1 while slot 0 receives X of the
-  // next chunk.  (A ring of three slots with two phases of lead was measured and changed nothing: what the requests cost is not their
-  // latency but their issue — the four waves of a block run the same code in step, and a 1 KB piece occupies the CU's one address
-  // path for 16 cycles: issued in the same gap, the fourth wave waits 48.  The requests are therefore STAGGERED: wave w uses the
-  // gaps of parity w & 1, and the raw image is double-buffered so that its pieces spread over both phases.)
-  const unsigned lane16 = lane * 16;
-  const char* ubase = reinterpret_cast<const char*>(p.U) + (size_t)blockIdx.y * (HALF * 4);
-  const size_t half_bytes = (size_t)gridDim.y * (HALF * 4);
-  // The requests in the chunk loop are exec-masked (`em`): both wave parities run the same instruction stream, and a request whose
-  // gap belongs to the other parity executes with EXEC = 0 — the hardware drops it — instead of being branched around.
-  const unsigned long long em_all = ~0ull;
-  auto glds = [&](int chunk, int half, int slot, int k, unsigned long long em) {
+  // next chunk.  The pieces (1 KB per wave instruction) travel global -> registers -> LDS: measured on this kernel
+  // (profiles/r04_w43_ablate_*.md), a direct-to-LDS piece costs its wave ~60 cycles of issue beside the MFMAs — 25 pieces per wave and
+  // chunk were 20 % of the kernel, plus 10 % for their scalar address / M0 code — against ~6 + 13 for a load and a ds_write_b128; the
+  // registers are those of the input transform, idle between two transforms.  (Also measured and dropped: fragments straight from
+  // L2 into registers without LDS, 17 % slower; a three-slot ring with two phases of lead; requests staggered over the waves.)
+  const auto u_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.U) + (size_t)blockIdx.y * HALF, 0, 0x7ffffff0, 0x00020000);
+  const unsigned lane16 = lane * 16;                       // lane offset; the piece's offset (< 2^31: launch check) is the instruction's scalar offset
+  const unsigned half_bytes = gridDim.y * (HALF * 4);
+  f32x4 fp[NPC];
+  auto fidx = [&](int k) { int idx = wave * NPC + k; if (PCS % 4 != 0) idx = idx % PCS; return idx; };
+  auto load_f = [&](int chunk, int half, int k) {
     if (W43ABL(2)) return;
-    int idx = wave * NPC + k;
-    if (PCS % 4 != 0) idx = idx % PCS;
-    const char* g = ubase + (size_t)(2 * chunk + half) * half_bytes + (unsigned)(idx * 1024);
-    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr0 + 4u * (unsigned)(FLT0 + slot * HALF) + 1024u * (unsigned)idx);
-    unsigned keep;
-    unsigned long long ex;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b64 %1, exec\n\ts_mov_b32 m0, %4\n\ts_mov_b64 exec, %5\n\tglobal_load_lds_dwordx4 %2, %3\n\t"
-                 "s_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep), "=&s"(ex) : "v"(lane16), "s"(g), "s"(dst), "s"(em) : "memory");
+    fp[k] = __builtin_bit_cast(f32x4, __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, lane16, (2 * chunk + half) * half_bytes + fidx(k) * 1024, 0)));
   };
-  auto load_u = [&](int chunk, int half, int slot) {
-#pragma unroll
-    for (int k = 0; k < NPC; ++k) glds(chunk, half, slot, k, em_all);
+  auto store_f = [&](int slot, int k) {
+    if (W43ABL(2)) return;
+    *reinterpret_cast<f32x4*>(__builtin_assume_aligned(lds + FLT0 + slot * HALF + fidx(k) * 256 + lane * 4, 16)) = fp[k];
   };
 
   // ---- fragment bases.  A: tile lt of the pair = quarter 4 pr + (lt >> 2), tile (ty, tx) of its 2x2; raw rows 4 ty + i
@@ -321,10 +295,14 @@ __global__ void __launch_bounds__(256, 1) wino43_kernel(const W43Args p) {
       for (int n = 0; n < NT; ++n) acc[a][b][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const lds_float* L = (const lds_float*)lds;
-  load_u(c_first, 0, 0);
-  load_raw(c_first, 0);
-  store_raw(c_first, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int k = 0; k < NPC; ++k) load_f(c_first, 0, k);
+#pragma unroll
+  for (int j = 0; j < NPR; ++j) load_piece(j, c_first);
+#pragma unroll
+  for (int k = 0; k < NPC; ++k) store_f(0, k);
+#pragma unroll
+  for (int j = 0; j < NPR; ++j) store_piece(j, c_first, 0);
   __syncthreads();
 
   f2 V[3][6];
@@ -342,7 +320,6 @@ __global__ void __launch_bounds__(256, 1) wino43_kernel(const W43Args p) {
       for (int n = 0; n < NT / 2; ++n) bq[1][n] = f32x4{1.f, 1.f, 1.f, 1.f};
     }
   };
-  const unsigned long long emask[2] = {(wave & 1) == 0 && W43_ABLATE != 8 ? ~0ull : 0ull, (wave & 1) == 1 && W43_ABLATE != 8 ? ~0ull : 0ull};
   auto phase = [&](auto B0c, int slot, auto&& req) {
     constexpr int B0 = decltype(B0c)::value;
     const lds_float* S = L + bbase + slot * HALF;
@@ -358,8 +335,8 @@ __global__ void __launch_bounds__(256, 1) wino43_kernel(const W43Args p) {
         else mfma16<false>(V[ai][b][sidx], bv, acc[ai][b][n]);
         if (m < NT / 2) { if (pp + 1 < 9 && !W43ABL(4)) bq[(pp + 1) & 1][m] = lds_rd128(S + ((pp + 1) * (NT / 2) + m) * 256); }
         else if (m >= NT) {
-          const int k = pp * NT + (m - NT);          // gap slot of the phase; request k >> 1 goes to the waves of parity k & 1
-          req(k >> 1, k & 1);
+          const int k = pp * NT + (m - NT);          // request slot of the phase (9 NT of them)
+          req(k);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -367,7 +344,6 @@ __global__ void __launch_bounds__(256, 1) wino43_kernel(const W43Args p) {
   };
   using I0 = std::integral_constant<int, 0>;
   using I3 = std::integral_constant<int, 3>;
-  constexpr int NRX = NPR / 2, NRY = NPR - NRX;   // raw pieces requested in phase X / phase Y (MODE 0)
 
   for (int cc = c_first; cc <= c_last; ++cc) {
     const int cn = min(cc + 1, c_last);           // the last chunk re-requests itself: no branches
@@ -410,26 +386,24 @@ __global__ void __launch_bounds__(256, 1) wino43_kernel(const W43Args p) {
       }
     }
     __builtin_amdgcn_sched_barrier(0);
-    // requests of phase X: the NPC pieces of Y of this chunk (direct to LDS: invisible to the compiler's load counting, so they are
-    // issued BEFORE the loads it waits for), then raw pieces of chunk c+1 for the other raw stage (MODE 0: the first NRX, straight to
-    // LDS — they may stay in flight over the barrier; MODE != 0: all of them, into registers)
-    phase(I0{}, 0, [&](int k, int par) {
-      if (k < NPC) glds(W43_ABLATE == 10 ? c_first : cc, 1, 1, k, emask[par]);
-      else if (MODE == 0 && k - NPC < NRX && !W43ABL(2)) load_piece(k - NPC, cn, st ^ 1, emask[par]);
-      else if (MODE != 0 && k - NPC < NPR && par == 0 && !W43ABL(2)) load_piece(k - NPC, cn, st ^ 1, ~0ull);     // register loads: not staggered
+    // requests of phase X: the NPC pieces of Y of this chunk and the raw pieces of chunk c+1 are loaded behind the first positions;
+    // the filter pieces go to slot 1 behind the last positions (the raw pieces wait for phase Y: the other raw stage is free, but
+    // the LDS stores are spread over both phases)
+    constexpr int NS = 9 * NT;                       // request slots of a phase
+    phase(I0{}, 0, [&](int k) {
+      if (k < NPC) load_f(cc, 1, k);
+      else if (k - NPC < NPR) load_piece(k - NPC, cn);
+      else if (k >= NS - NPC) store_f(1, k - (NS - NPC));
     });
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MODE != 0 ? NPR : NRX) : "memory");     // slot 1 has landed
     if (!W43ABL(1)) __syncthreads();
-    // ---- phase Y: 9 positions of slot 1 while slot 0 receives X of chunk c+1 and the other raw stage the rest of its image
-    // (MODE != 0: the pieces loaded during phase X, through the prologue)
+    // ---- phase Y: 9 positions of slot 1 while slot 0 receives X of chunk c+1 and the other raw stage its image
     phase_begin(1);
-    if constexpr (MODE != 0) store_raw(cn, st ^ 1);
     __builtin_amdgcn_sched_barrier(0);
-    phase(I3{}, 1, [&](int k, int par) {
-      if (k < NPC) glds(W43_ABLATE == 10 ? c_first : cn, 0, 0, k, emask[par]);
-      else if (MODE == 0 && k - NPC < NRY && !W43ABL(2)) load_piece(NRX + k - NPC, cn, st ^ 1, emask[par]);
+    phase(I3{}, 1, [&](int k) {
+      if (k < NPC) load_f(cn, 0, k);
+      else if (k - NPC < NPR) store_piece(k - NPC, cn, st ^ 1);
+      else if (k >= NS - NPC) store_f(0, k - (NS - NPC));
     });
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (!W43ABL(1)) __syncthreads();
   }
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");     // the hand-issued MFMAs of the last positions have left the pipe
@@ -643,6 +617,7 @@ int w43_run(W43Args& a, int mode, int kd, float* workspace, size_t workspace_byt
   a.qtotal = (int)quarters;
   if (in_extent * 4 >= (1ll << 31)) { g6d_set_error("wino43: input tensor exceeds 2^31 bytes"); return G6D_EINVAL; }
   a.in_bytes = (unsigned)(in_extent * 4);
+  if ((long long)kd * (a.Cin / 8) * 36 * a.Cout * 32 >= (1ll << 31)) { g6d_set_error("wino43: filter bank exceeds 2^31 bytes"); return G6D_EINVAL; }
   const int nt = (a.Cout & 63) ? 2 : 4;
   if (mode != 0 && (size_t)(mode >= 2 ? 2 * W43_NQ : 2) * a.Cin * 4 + ((size_t)2 * W43_RAWF + 2 * 18 * 16 * nt * 8) * 4 > 160 * 1024) {
     g6d_set_error("wino43: affine tables do not fit LDS"); return G6D_EINVAL;

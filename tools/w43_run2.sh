@@ -3,4 +3,4 @@ cd $GRAFT_REPO_ROOT
 tail -5 gpurun_out/w43_tests.log
 (timeout 600 python tools/w43_bench.py 5 2>&1 | grep -v amdgpu.ids) > gpurun_out/w43_bench.md 2>&1
 cat gpurun_out/w43_bench.md
-ABL="2 4" bash tools/w43_ablate_run.sh > gpurun_out/w43_ablate.log 2>&1; cat gpurun_out/w43_ablate.log
+ABL="1 2 4 7" bash tools/w43_ablate_run.sh > gpurun_out/w43_ablate.log 2>&1; cat gpurun_out/w43_ablate.log
