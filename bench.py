@@ -106,8 +106,9 @@ def main():
                     help="batches in flight during the reduced-precision passes (their kernels are ~2x shorter, so replay gaps weigh "
                          "more: 342 images/s with 2, 357 with 3; fp32 gains 1 %% from a third lane and keeps the 2 of --lanes)")
     ap.add_argument("--no-cached", action="store_true", help="skip the reference-feature-cache side measurement (`cached` object)")
+    ap.add_argument("--no-chained", action="store_true", help="skip the `chained` measurement")
     ap.add_argument("--chained", action="store_true",
-                    help="additionally time the device-resident predict chain (gen6d_amd/chain.py: detection -> crop -> selection "
+                    help="(default since round 4; kept for old command lines) additionally time the device-resident predict chain (gen6d_amd/chain.py: detection -> crop -> selection "
                          "-> pose -> 3 x refine with every inter-stage warp and the pose algebra on the GPU, one captured graph "
                          "per lane) on a procedural 480x640 database with REAL data flow between the stages; reported as `chained`")
     ap.add_argument("--chain-batch", type=int, default=8, help="queries per captured graph of the --chained measurement")
@@ -158,7 +159,7 @@ def main():
     qseed = 0 if shard_refs else rank           # same queries on every rank when the references are sharded
     fulls = synth.imgs_to_tensor(synth.synth_images(4, 480, 640, seed=100 + qseed)).to(dev)
     crops = synth.imgs_to_tensor(synth.synth_images(4, 128, 128, seed=200 + qseed)).to(dev)
-    B = 1 if shard_refs else max(1, min(8, args.batch))
+    B = max(1, min(8, args.batch))                # sharded references: the batch also shares every collective (round 4)
 
     use_graph = not args.no_graph and not shard_refs and not args.serial     # collectives are issued eagerly
     no_fork = args.serial or (use_graph and not args.fork)
@@ -261,7 +262,7 @@ def main():
     # HBM traffic of the dominant kernel family cannot be read without rocprofv3: it is taken from the committed PMC
     # summary of the same command (profiles/rNN_pmc_conv_traffic.json, newest round first; tools/pmc_conv_traffic.py), else null
     traffic_json, traffic_src = {}, None
-    for name in ("r03_pmc_conv_traffic.json", "r02_pmc_conv_traffic.json", "r01_pmc_conv_traffic.json"):
+    for name in ("r04_pmc_conv_traffic.json", "r03_pmc_conv_traffic.json", "r02_pmc_conv_traffic.json", "r01_pmc_conv_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 traffic_json = json.load(f)
@@ -284,8 +285,9 @@ def main():
                              "g6d_conv_igemm family: conv_igemm / conv_patch / corr_patch kernels (fp32 v_mfma_f32_32x32x2_f32); split "
                              "launches add their partial tiles inside the kernel"),
                             ("winograd", lambda p: p[3].startswith("wino3x3"),
-                             "wino_conv3x3_kernel (Winograd F(2x2,3x3) on fp32 v_mfma_f32_32x32x2_f32): own VGG trunk (g6d_wino_conv3x3) + "
-                             "the stride-1 3x3 / 3x3x3 layers g6d_conv_igemm routes to it; the detector's pyramid runs each layer as one launch")):
+                             "Winograd kernels on the fp32 matrix cores: wino_conv3x3_kernel (F(2x2,3x3), v_mfma_f32_32x32x2_f32) and wino43_kernel "
+                             "(F(4x4,3x3), v_mfma_f32_16x16x4_f32): own VGG trunks + the stride-1 3x3 / 3x3x3 layers g6d_conv_igemm routes to "
+                             "them + the detector's 15x15 correlation; the detector's pyramid runs each layer as one launch")):
         pp = [p for p in prof if sel(p)]
         if not pp:
             continue
@@ -306,8 +308,20 @@ def main():
         if key == "conv":
             fams[key]["conv_ms_per_step"] = ms / args.steps
         else:
-            fams[key].update(flops_counted="EXECUTED in the Winograd domain = direct-form / 2.25",
-                             achieved_direct_form_equivalent=2.25 * ach, gflop_direct_form_per_step=2.25 * fl / args.steps / 1e9)
+            # per-launch factor: the F(2x2,3x3) kernel executes direct-form / 2.25 multiplications, the F(4x4,3x3) kernel direct-form / 4
+            direct = sum((p[5] if len(p) > 5 else 2.25 * p[0]) for p in pp)
+            by = {}
+            for tag, sel43 in (("F(2x2,3x3) wino_conv3x3_kernel, direct / 2.25", False), ("F(4x4,3x3) wino43_kernel, direct / 4", True)):
+                qq = [p for p in pp if p[3].startswith("wino3x3 F43") == sel43]
+                if qq:
+                    f_, m_ = sum(p[0] for p in qq), sum(p[1].elapsed_time(p[2]) for p in qq)
+                    by[tag] = {"launches_per_step": len(qq) / args.steps, "ms_per_step": m_ / args.steps, "gflop_executed_per_step": f_ / args.steps / 1e9,
+                               "achieved": f_ / (m_ * 1e-3) / 1e12, "frac": f_ / (m_ * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS}
+            fams[key].update(flops_counted="EXECUTED in the Winograd domain, per launch: direct-form / 2.25 on the F(2x2,3x3) kernel (selector and "
+                                           "refiner InstanceNorm stacks, reference-side trunks), direct-form / 4 on the F(4x4,3x3) kernel (detector "
+                                           "pyramid trunk, 15x15 correlation, refiner volume layers)",
+                             by_transform=by, achieved_direct_form_equivalent=direct / (ms * 1e-3) / 1e12,
+                             gflop_direct_form_per_step=direct / args.steps / 1e9)
     dominant = max(fams, key=lambda k: fams[k]["ms_per_step"]) if fams else None
     result = {
         "metric": "query images/sec (detect+select+3x refine), 64 ref views",
@@ -348,9 +362,10 @@ def main():
             k = kinds.setdefault(kind, {"count": 0, "bytes": 0, "us": 0.0})
             k["count"] += 1; k["bytes"] += nb; k["us"] += sec * 1e6
         result["collectives_per_query"] = {
-            "total": len(coll_log), "total_us": sum(c[2] for c in coll_log) * 1e6,
+            "total": len(coll_log) / B, "per_batch": len(coll_log), "batch": B, "total_us_per_batch": sum(c[2] for c in coll_log) * 1e6,
             "by_kind": {k: {"count": v["count"], "mean_bytes": v["bytes"] / v["count"], "mean_us": v["us"] / v["count"]} for k, v in kinds.items()},
-            "how": "one extra query with a stream synchronisation around every data-path collective (rank 0's view); "
+            "how": "one extra batch with a stream synchronisation around every data-path collective (rank 0's view; selector 9 + "
+                   "detector 1 per batch of queries); "
                    + ("RCCL: enqueued on device tensors, no host staging" if parallel.backend_name() == "nccl" else
                       "gloo: every collective is staged through host memory (ranks share one GPU on this lease; RCCL refuses that)")}
     result["build_s"] = {"value": build_s, "what": "TensorPipeline.build: detector reference filters + selector reference cache "
@@ -440,15 +455,22 @@ def main():
             "refiner_step_ms_single_query": {"uncached": t_step(False), "cached": t_step(True)},
             "rows_vs_uncached_max_rel": float(((crows - got_rows[:crows.shape[0]]).abs() / got_rows[:crows.shape[0]].abs().clamp(min=1.0)).max())}
 
-    if args.chained and world == 1:
+    if not args.no_chained and world == 1 and rank == 0:
         # the estimator-level path: the crop fed to the selector comes from the detection, the refiner inputs from the pose of
         # the previous stage (bench headline: canned crops / poses)
         from gen6d_amd.estimator import Gen6DEstimator
         from gen6d_amd.synth_db import SyntheticDatabase
         tb = time.perf_counter()
         db = SyntheticDatabase(n_views=88, size=(480, 640), focal=560.0)
+        # the refiner of this leg has its pose heads damped towards the identity update (synth.damp_refiner_head), as a trained
+        # refiner's are: with the seeded random heads a single grey level of a crop moves the pose by 1e-2 and step-to-step
+        # comparisons say nothing.  Same layers, same launches, same cost.
+        from gen6d_amd.network import name2network
+        ref_d = name2network["refiner"]({"name": "refiner_synth_damped"})
+        ref_d.load_state_dict(synth.damp_refiner_head(pipe.state_dicts["refiner"]))
+        ref_d.to(dev).eval()
         est = Gen6DEstimator({"ref_view_num": args.sel_refs, "det_ref_view_num": args.det_refs, "refine_iter": 3},
-                             modules={"detector": pipe.detector, "selector": pipe.selector, "refiner": pipe.refiner})
+                             modules={"detector": pipe.detector, "selector": pipe.selector, "refiner": ref_d})
         est.build(db, "all")
         torch.cuda.synchronize()
         cbuild = time.perf_counter() - tb
@@ -477,8 +499,11 @@ def main():
                              "vs_host_driven_predict": {
                                  "same_viewpoint": bool(inter_d["sel_ref_idx"] == inter_h["sel_ref_idx"]),
                                  "pose_from_detection_and_selection_maxabs": float(np.abs(inter_d["refine_poses"][0] - inter_h["refine_poses"][0]).max()),
-                                 "after_1_refine_step_maxabs": float(np.abs(inter_d["refine_poses"][1] - inter_h["refine_poses"][1]).max()),
-                                 "note": "later steps diverge: the randomly initialised refiner amplifies single grey levels of the crops"}}
+                                 "after_refine_step_maxabs": [float(np.abs(inter_d["refine_poses"][i] - inter_h["refine_poses"][i]).max())
+                                                              for i in range(1, len(inter_h["refine_poses"]))],
+                                 "final_pose_maxabs": float(np.abs(inter_d["refine_poses"][-1] - inter_h["refine_poses"][-1]).max()),
+                                 "graph_replay_vs_eager_chain_maxabs": float(np.abs(res[0][0] - inter_d["refine_poses"][-1]).max()),
+                                 "bar": 1e-4, "note": "pose heads damped towards the identity (synth.damp_refiner_head), all 3 dependent refine steps"}}
 
     def row_diff(got, ref):
         """Row layout: position(2, px), scale, ref_idx, angle, quaternion(4), offset(2), log2-scale."""

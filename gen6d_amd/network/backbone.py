@@ -162,8 +162,14 @@ class TrunkLayer(tuple):
 
     def __new__(cls, U, b, w):
         t = super().__new__(cls, (U, b))
-        t._w, t._u16 = w, {}
+        t._w, t._u16, t._u43 = w, {}, None
         return t
+
+    def u43(self):
+        """The layer's filters for the F(4x4,3x3) kernel (winograd43_filters), built on first use."""
+        if self._u43 is None:
+            self._u43 = winograd43_filters(self._w)
+        return self._u43
 
     def u16(self, dtype):
         if dtype not in self._u16:
@@ -176,12 +182,15 @@ _LOWP_DTYPE = {1: torch.bfloat16, 2: torch.float16}
 _LOWP_TRUNK = os.environ.get("G6D_LOWP_TRUNK", "1") != "0"
 
 
-def _wino_layer(xs, layer, relu=True, full=True, pool=False):
-    """One trunk layer over the segments xs on the kernel of the current math mode: fp32 Winograd, or (ops.MATH_MODE 1 / 2, Cin % 16
-    == 0) the 16-bit one."""
+def _wino_layer(xs, layer, relu=True, full=True, pool=False, f43=False):
+    """One trunk layer over the segments xs on the kernel of the current math mode: fp32 Winograd — F(2x2,3x3), or with f43 the
+    F(4x4,3x3) kernel (1.78x fewer multiplications at ~5x the rounding error: the detector's pyramid, whose parity budget has the
+    room) — or (ops.MATH_MODE 1 / 2, Cin % 16 == 0) the 16-bit one."""
     mm = ops.MATH_MODE
     if mm and _LOWP_TRUNK and hasattr(layer, "u16") and xs[0].shape[3] % 16 == 0:
         return ops.wino16_conv3x3_multi(xs, layer.u16(_LOWP_DTYPE[mm]), layer[1], relu=relu, full=full, pool=pool)
+    if f43 and not mm and layer[1].numel() % 64 == 0:
+        return ops.wino43_conv3x3_multi(xs, layer.u43(), layer[1], relu=relu, full=full, pool=pool)
     return ops.wino_conv3x3_multi(xs, layer[0], layer[1], relu=relu, full=full, pool=pool)
 
 
@@ -214,22 +223,22 @@ def vgg_taps_cl(packed, x, taps, norm=None):
     return {k: v for k, v in out.items() if v is not None and (k in taps or k == "c7_pre")}
 
 
-def vgg_taps_cl_multi(packed, xs, taps, norm=None):
+def vgg_taps_cl_multi(packed, xs, taps, norm=None, f43=False):
     """vgg_taps_cl for several image sizes at once (the scales of the detector's pyramid): every Winograd layer is ONE launch
     over all sizes (ops.wino_conv3x3_multi).  xs: list of [1,3,h_i,w_i] images (normalised, or in [0,1] with norm) -> list of
-    tap dicts."""
+    tap dicts.  f43: the seven Winograd layers on the F(4x4,3x3) kernel (fp32 mode only)."""
     w0, b0 = packed[0]
     dev = xs[0].device
     cur = ops.alloc_like_segments([(x.shape[0], x.shape[2] // 2, x.shape[3] // 2, w0.shape[0]) for x in xs], dev)
     for x, o in zip(xs, cur):
         ops.vgg_conv1_pool_nhwc(x.contiguous(), w0, b0, out=o, norm=norm)               # conv0 + ReLU + pool, per size
-    _, cur = _wino_layer(cur, packed[1], relu=True, full=False, pool=True)
-    cur, _ = _wino_layer(cur, packed[2], relu=True)
-    c3, cur = _wino_layer(cur, packed[3], relu=True, full="c3" in taps, pool=True)
-    cur, _ = _wino_layer(cur, packed[4], relu=True)
-    c5, cur = _wino_layer(cur, packed[5], relu=True, full="c5" in taps, pool=True)
-    cur, _ = _wino_layer(cur, packed[6], relu=True)
-    c7, p7 = _wino_layer(cur, packed[7], relu=False, full=True, pool="p7" in taps)
+    _, cur = _wino_layer(cur, packed[1], relu=True, full=False, pool=True, f43=f43)
+    cur, _ = _wino_layer(cur, packed[2], relu=True, f43=f43)
+    c3, cur = _wino_layer(cur, packed[3], relu=True, full="c3" in taps, pool=True, f43=f43)
+    cur, _ = _wino_layer(cur, packed[4], relu=True, f43=f43)
+    c5, cur = _wino_layer(cur, packed[5], relu=True, full="c5" in taps, pool=True, f43=f43)
+    cur, _ = _wino_layer(cur, packed[6], relu=True, f43=f43)
+    c7, p7 = _wino_layer(cur, packed[7], relu=False, full=True, pool="p7" in taps, f43=f43)
     outs = []
     for i in range(len(xs)):
         d = {"c3": c3, "c5": c5, "c7_pre": c7, "p7": p7}
@@ -237,12 +246,12 @@ def vgg_taps_cl_multi(packed, xs, taps, norm=None):
     return outs
 
 
-def trunk_features_multi(packed, imgs_list, keys):
+def trunk_features_multi(packed, imgs_list, keys, f43=False):
     """trunk_features (no L2 normalisation) for a list of [1,3,h_i,w_i] images of different sizes -> list of lists of
     [1,1,h_l,w_l,C] maps.  One launch per layer for all sizes on the own trunk; the library trunk runs them one by one."""
     if not _OWN_TRUNK or len(imgs_list) > 4:
         return [trunk_features(packed, im, keys, False) for im in imgs_list]
-    taps = vgg_taps_cl_multi(packed, imgs_list, set(keys), norm=_IMG_NORM)
+    taps = vgg_taps_cl_multi(packed, imgs_list, set(keys), norm=_IMG_NORM, f43=f43)
     return [[t[k].unsqueeze(1) for k in keys] for t in taps]
 
 

@@ -18,7 +18,7 @@ import torch.nn.functional as F
 from .. import ops, parallel, specs
 import os
 
-from .backbone import pack_trunk, trunk_features, trunk_features_multi, winograd_corr_filters
+from .backbone import pack_trunk, trunk_features, trunk_features_multi, winograd_corr_filters, winograd43_corr_filters
 from .params import ParamBank, fold_vgg
 
 # G6D_TRUNK_MULTI=0: one trunk pass per pyramid scale (A/B aid); default: one launch per layer over all scales
@@ -29,6 +29,10 @@ _CORR3_MULTI = os.environ.get("G6D_CORR3_MULTI", "1") != "0"
 # G6D_CORR_WINO=0: the 15x15 correlation level on the direct corr_patch kernel (round 2); default: on the Winograd kernel
 # (5x5 blocks of 3x3 sub-filters accumulated in the transform domain: 2.25x fewer multiplications) when rfn % 32 == 0 and fp32
 _CORR_WINO = os.environ.get("G6D_CORR_WINO", "1") != "0"
+# Winograd F(4x4,3x3) (csrc/wino43_conv.hip) for the query pyramid's trunk and the 15x15 correlation level: 1.78x fewer fp32
+# multiplications than F(2x2,3x3) at ~5x its rounding error — the detector holds ~4e-6 of the score range against the 1e-4 bar
+# (tests/test_parity_timed_gpu.py).  False: the F(2x2,3x3) kernels of round 3 (tools/ A/B runs and tests flip this attribute).
+F43 = True
 MAX_BATCH = 8        # queries that share one set of launches (g6d_selector_levels / g6d_linear_gemv take <= 8)
 
 
@@ -47,7 +51,8 @@ class Detector(ParamBank):
             raise NotImplementedError("score_conv expects 3 levels x 4 detection scales (12 channels)")
         self.pool_ratio = 8
         self.ref_center_feats = None     # three [rfn, k*k, 512] correlation filters
-        self.ref_wino15 = None           # the 15x15 level's filters in the Winograd domain (winograd_corr_filters)
+        self.ref_wino15 = None           # the 15x15 level's filters in the Winograd domain (winograd_corr_filters), F(2x2,3x3)
+        self.ref_wino15_43 = None        # ... for the F(4x4,3x3) kernel (winograd43_corr_filters); one of the two is built
         self.ref_shape = None
         self.rank, self.world, self.group = 0, 1, None
 
@@ -91,8 +96,9 @@ class Detector(ParamBank):
         self.ref_shape = [120, 120]
         # Winograd-domain filters of the 15x15 level (the reference views used as filters: transformed once per object)
         rfn = self.ref_center_feats[0].shape[0]
-        self.ref_wino15 = (winograd_corr_filters(self.ref_center_feats[0], 15)
-                           if (_CORR_WINO and self.ref_ksize[0] == 15 and rfn % 32 == 0) else None)
+        ok15 = _CORR_WINO and self.ref_ksize[0] == 15 and rfn % 32 == 0
+        self.ref_wino15 = winograd_corr_filters(self.ref_center_feats[0], 15) if (ok15 and not F43) else None
+        self.ref_wino15_43 = winograd43_corr_filters(self.ref_center_feats[0], 15) if (ok15 and F43) else None
 
     # ------------------------------------------------------------------ detection
     def _scores_one_scale(self, que_img, scale_idx, stacked, hs, ws):
@@ -116,7 +122,10 @@ class Detector(ParamBank):
                 for d_, x in zip(seg, xs):
                     d_.copy_(x)
                 xs = seg
-            if k == 15 and self.ref_wino15 is not None and ops.MATH_MODE == 0 and len(xs) <= 4:
+            if k == 15 and self.ref_wino15_43 is not None and ops.MATH_MODE == 0 and len(xs) <= 4:
+                outs = ops.alloc_like_segments([(qn, 1, x.shape[2], x.shape[3], rfn) for x in xs], dev)
+                ops.corr2d_wino43_multi([x.contiguous() for x in xs], self.ref_wino15_43, outs, 5)
+            elif k == 15 and self.ref_wino15 is not None and ops.MATH_MODE == 0 and len(xs) <= 4:
                 outs = ops.alloc_like_segments([(qn, 1, x.shape[2], x.shape[3], rfn) for x in xs], dev)
                 ops.corr2d_wino_multi([x.contiguous() for x in xs], self.ref_wino15, outs, 5)
             elif rfn <= 32 and len(xs) <= 4 and (k >= 7 or _CORR3_MULTI):
@@ -173,7 +182,7 @@ class Detector(ParamBank):
         if _TRUNK_MULTI and len(order) <= 4:
             # every trunk layer is ONE launch over the whole pyramid (the small scales fill the blocks the large ones leave
             # over); the correlations of the scales then run side by side
-            feats = trunk_features_multi(pk["vgg"], [resized(sc) for _, sc in order], ("c5", "c7_pre", "p7"))
+            feats = trunk_features_multi(pk["vgg"], [resized(sc) for _, sc in order], ("c5", "c7_pre", "p7"), f43=F43)
             self._scores_from_pyramid(feats, [si for si, _ in order], stacked, hs, ws)
         else:
             ops.fork_join([(lambda si=si, sc=sc: self._scores_one_scale(resized(sc), si, stacked, hs, ws)) for si, sc in order], dev)

@@ -9,11 +9,12 @@ from .. import specs
 
 class ConvW(tuple):
     """(weight [Cout,taps,Cin], bias) as the conv kernels take them, plus `.u`: the same filters transformed for the Winograd
-    kernel (None when the layer never qualifies).  Unpacks like the plain pair."""
+    kernel (None when the layer never qualifies), and `.u43`: the same for the F(4x4,3x3) kernel (G6dConv.weight_wino43; only for the
+    layers that ask for it).  Unpacks like the plain pair."""
 
-    def __new__(cls, w, b, u=None):
+    def __new__(cls, w, b, u=None, u43=None):
         t = super().__new__(cls, (w, b))
-        t.u = u
+        t.u, t.u43 = u, u43
         return t
 
 
@@ -58,24 +59,23 @@ class ParamBank(nn.Module):
     def device_(self):
         return next(self.parameters()).device
 
-    def conv_w(self, prefix, cin_pad=None, wino_kd=0):
+    def conv_w(self, prefix, cin_pad=None, wino_kd=0, f43=False):
         """[Cout,Cin,*k] -> ConvW([Cout,taps,Cin] contiguous (Cin zero-padded to cin_pad), bias).  wino_kd = 1 / 3: the layer is
-        a stride-1 (1,3,3) / (3,3,3) convolution — also keep its Winograd-domain filters (`.u`, see G6dConv.weight_wino)."""
+        a stride-1 (1,3,3) / (3,3,3) convolution — also keep its Winograd-domain filters (`.u`, see G6dConv.weight_wino); f43: and those of
+        the F(4x4,3x3) kernel (`.u43`, Cout % 64 == 0)."""
         w = self.p(prefix + ".weight")
         co, ci = w.shape[:2]
         w = w.reshape(co, ci, -1).permute(0, 2, 1)
         if cin_pad is not None and cin_pad != ci:
             w = torch.nn.functional.pad(w, (0, cin_pad - ci))
         w = w.contiguous()
-        u = None
+        u = u43 = None
         if wino_kd and ci % 8 == 0 and co % 32 == 0 and w.shape[1] == 9 * wino_kd:
-            from .backbone import winograd_filters_taps
-            u = _wino_pad(winograd_filters_taps(w, wino_kd), co)
-        return ConvW(w, self.p(prefix + ".bias").contiguous(), u)
-
-
-def _wino_pad(u, co):
-    return u
+            from .backbone import winograd_filters_taps, winograd43_filters_taps
+            u = winograd_filters_taps(w, wino_kd)
+            if f43 and co % 64 == 0:
+                u43 = winograd43_filters_taps(w, wino_kd)
+        return ConvW(w, self.p(prefix + ".bias").contiguous(), u, u43)
 
 
 def fold_vgg(bank, prefix):

@@ -17,6 +17,10 @@ from .backbone import pack_trunk, trunk_features
 from .operator import pose_apply_th
 from .params import ParamBank, fold_vgg
 
+# Winograd F(4x4,3x3) filters for the stride-1 3x3x3 layers of the volume net (csrc/wino43_conv.hip); VOLUME_F43_LAYERS: which of
+# conv0 (32^3), conv2 (16^3), conv4 (8^3) take it beside the two embed pairs (32^3)
+VOLUME_F43 = True
+VOLUME_F43_LAYERS = ("conv0", "conv2", "conv4")
 MAX_BATCH = 8          # queries that share one set of launches (g6d_linear_gemv takes <= 8 right-hand sides)
 _K3, _P3 = (3, 3, 3), (1, 1, 1)
 _K2, _P2 = (1, 3, 3), (0, 1, 1)
@@ -106,10 +110,13 @@ class VolumeRefiner(ParamBank):
             pk = {"vgg": pack_trunk(fold_vgg(self, "feature_net.backbone.features"))}
             for name in ("conv0", "conv1", "conv2", "conv_out"):
                 pk[name] = [self.conv_w(f"feature_net.{name}.{i}", wino_kd=1) for i in (0, 3)]
+            # the 32^3 volume layers (mean_embed, var_embed, conv0) also carry F(4x4,3x3) filters (VOLUME_F43): 1.4-1.5x faster there
+            # at 1.3-3.4e-6 of the layer's range (profiles/r04_w43_bench_v5.md)
             for name in ("mean_embed", "var_embed", "conv5"):         # conv5 works on 8^3 -> 4^3 maps: never on the Winograd kernel
-                pk["v_" + name] = [self.conv_w(f"volume_net.{name}.{i}", wino_kd=0 if name == "conv5" else 3) for i in (0, 3)]
+                pk["v_" + name] = [self.conv_w(f"volume_net.{name}.{i}", wino_kd=0 if name == "conv5" else 3, f43=VOLUME_F43) for i in (0, 3)]
             for name in ("conv0", "conv1", "conv2", "conv3", "conv4"):
-                pk["v_" + name] = self.conv_w(f"volume_net.{name}.0", wino_kd=3 if name in ("conv0", "conv2", "conv4") else 0)
+                pk["v_" + name] = self.conv_w(f"volume_net.{name}.0", wino_kd=3 if name in ("conv0", "conv2", "conv4") else 0,
+                                              f43=VOLUME_F43 and name in VOLUME_F43_LAYERS)
             # fc.0.0 consumes x.flatten(1) of [512,4,4,4] (index c*64+v); our code is [v][c] -> permute once
             w = self.p("regressor.fc.0.0.weight")
             pk["fc0"] = (w.reshape(512, 512, 64).permute(0, 2, 1).reshape(512, 32768).contiguous(),
@@ -181,7 +188,8 @@ class VolumeRefiner(ParamBank):
             return ops.conv(x, wb[0], wb[1], out, ksize=_K3, stride=(stride,) * 3, pad=_P3, in_scale=sc, in_shift=sh,
                             in_relu=aff is not None, per_n=pn if aff is not None else 0, stats=st,
                             rows_per_group=pn * (count or 0) if stats_c else 0,
-                            w_wino=getattr(wb, "u", None) if stride == 1 else None, finalize=count if stats_c else None)
+                            w_wino=getattr(wb, "u", None) if stride == 1 else None,
+                            w_wino43=getattr(wb, "u43", None) if stride == 1 else None, finalize=count if stats_c else None)
 
         def buf(s, c):
             return torch.empty((qn, s, s, s, c), dtype=torch.float32, device=dev)

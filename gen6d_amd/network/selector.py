@@ -14,10 +14,12 @@ Query-time data flow (reference compute_view_point_feats, selector.py:177-215), 
 
 Reference-sharded mode (`set_shard(rank, world)`): every rank keeps the cache of a contiguous slice of
 the references (all rotations of a reference stay together).  The logits of one reference depend on all references
-through the InstanceNorms, so the exchange is: one all-reduce of R1/R2 at build time; at query time one all-reduce of
-the 2*C fp64 (sum, sumsq) per InstanceNorm layer (<= 8 KB each), one all-gather of the vps scalars, one all-gather of the per-reference feature rows [rfn/G, 512] before the
-replicated attention tail, and one all-gather of the per-reference angles (RCCL over xGMI via torch.distributed;
-messages are KB-sized, i.e. latency-bound).  Results equal the unsharded ones up to fp reassociation of the sums.
+through the InstanceNorms, so the exchange is: one all-reduce of R1/R2 at build time; per BATCH of <= 8 queries (they share every
+collective: the tables are [qn, C, 2]) five all-reduces of the fp64 (sum, sumsq) InstanceNorm tables of the correlation stacks (the
+three levels advance in lock-step, a round's tables travel together: <= 8 * 3 * 8 KB), one for corr_feats_conv's InstanceNorm, one
+all-gather of the vps scalars, one of the per-reference feature rows [qn, rfn/G, 512] before the replicated attention tail, and one
+of the per-reference angles: 9 collectives per batch (RCCL over xGMI via torch.distributed, issued on device tensors on the current
+stream; messages are KB-sized, i.e. latency-bound).  Results equal the unsharded ones up to fp reassociation of the sums.
 """
 import numpy as np
 import torch
@@ -72,6 +74,15 @@ class ViewpointSelector(ParamBank):
         if self.world == 1:
             return rows
         return parallel.all_gather_ragged_rows(rows, n_total, self.world, self.group)
+
+    def _allgather_batch(self, t, qn, n_local, n_total):
+        """[qn * n_local, F] (query-major rows of the local references) -> [qn * n_total, F] over all references: ONE all-gather
+        for the whole batch (a rank's message = its references' rows of all qn queries)."""
+        if self.world == 1:
+            return t
+        F_ = t.shape[1]
+        rows = t.view(qn, n_local, F_).permute(1, 0, 2).reshape(n_local, qn * F_).contiguous()
+        return self._allgather_rows(rows, n_total).view(n_total, qn, F_).permute(1, 0, 2).reshape(qn * n_total, F_)
 
     # ------------------------------------------------------------------ weights
     def _pack(self):
@@ -148,7 +159,9 @@ class ViewpointSelector(ParamBank):
 
     # ------------------------------------------------------------------ query
     def _level(self, l, q, cat, scale, shift, qn=1):
-        """One pyramid level for a batch of qn queries: q [qn,1,h,w,512] query features, (scale, shift) [qn,512] the InstanceNorm
+        """GENERATOR (it runs to completion without yielding when the references are not sharded; in the sharded mode it yields the
+        fp64 statistics tensor of every InstanceNorm whose sums still have to be added over the ranks — the caller all-reduces it
+        in place, together with those of the other levels, and resumes).  One pyramid level for a batch of qn queries: q [qn,1,h,w,512] query features, (scale, shift) [qn,512] the InstanceNorm
         affine of each query x reference product; writes channels [256l,256l+256) of cat [qn*D,1,4,4,768].  The qn*D hypothesis
         images of the batch go through every launch together: image n = query n // D, hypothesis n % D; the first conv reads the
         reference cache through `in_mod` (shared, not replicated) with the query's own feature map as multiplier, and every
@@ -180,7 +193,7 @@ class ViewpointSelector(ParamBank):
             if fin is not None:
                 scale, shift = res
             else:
-                self._allreduce([stats])
+                yield stats                                                  # [qn, co, 2] fp64: summed over the ranks by the caller
                 scale, shift = ops.stats_finalize(stats, Dg * h * w)
             if has_pool:
                 pooled = torch.empty((qn * D, 1, h // 2, w // 2, co), dtype=torch.float32, device=dev)
@@ -199,8 +212,6 @@ class ViewpointSelector(ParamBank):
         rfn_all, rfn = self.rfn, self.r_end - self.r_begin                  # global / local reference counts
         D, Dg = rfn * an, rfn_all * an
         dev = que_imgs.device
-        if self.world > 1 and qn > 1:
-            raise ValueError("reference-sharded selector: one query per call (collectives are issued per query)")
         grp = D if qn > 1 else 0
         ops.stats_arena_begin(dev)
         qf = self.get_feats(que_imgs)
@@ -208,12 +219,22 @@ class ViewpointSelector(ParamBank):
         # score maps -> viewpoint scores and the product's InstanceNorm statistics of all three levels: one streaming launch
         caches = [c.view(c.shape[0], c.shape[2] * c.shape[3], 512) for c in self.ref_feats_cache]
         vps, psc, psh, _ = ops.selector_levels([qf[l].view(qn, -1, 512) for l in range(3)], caches, self.ref_sums, Dg)  # [qn,3,D], [qn,3,512]
-        levels = [(lambda l=l: self._level(l, qf[l], cat, psc[:, l].contiguous(), psh[:, l].contiguous(), qn)) for l in range(3)]
-        # collectives must be issued in the same order on every rank: no stream fork in sharded mode
+        levels = [self._level(l, qf[l], cat, psc[:, l].contiguous(), psh[:, l].contiguous(), qn) for l in range(3)]
         if self.world == 1:
-            ops.fork_join(levels, dev)
+            ops.fork_join([(lambda g=g: sum(1 for _ in g)) for g in levels], dev)       # nothing is yielded: the levels run side by side
         else:
-            for f in levels: f()
+            # sharded: the three levels advance in lock-step on ONE stream (collectives must be issued in the same order on every
+            # rank); the InstanceNorm sums that the levels reach in the same round share one all-reduce: 5 rounds (5 / 3 / 1
+            # InstanceNorms per level) instead of 9 collectives, each carrying the [qn, C, 2] tables of the whole query batch
+            while levels:
+                pending, alive = [], []
+                for g in levels:
+                    st = next(g, None)
+                    if st is not None:
+                        pending.append(st); alive.append(g)
+                if pending:
+                    self._allreduce(pending)
+                levels = alive
 
         # corr_feats_conv: 1x1x1 768->512, IN3d, ReLU, (AvgPool commuted) 512->512   selector.py:71-77,197-200
         y = torch.empty((qn * D, 1, 4, 4, 512), dtype=torch.float32, device=dev)
@@ -221,7 +242,7 @@ class ViewpointSelector(ParamBank):
         if self.world == 1:
             sc, sh = ops.conv(cat, pk["fuse0"][0], pk["fuse0"][1], y, stats=st, finalize=Dg * 16, rows_per_group=grp * 16)
         else:
-            ops.conv(cat, pk["fuse0"][0], pk["fuse0"][1], y, stats=st)
+            ops.conv(cat, pk["fuse0"][0], pk["fuse0"][1], y, stats=st, rows_per_group=grp * 16)
             self._allreduce([st])
             sc, sh = ops.stats_finalize(st, Dg * 16)
         pooled = torch.empty((qn * D, 1, 1, 1, 512), dtype=torch.float32, device=dev)
@@ -231,10 +252,12 @@ class ViewpointSelector(ParamBank):
         if self.world == 1:
             ops.vps_norm(vps, feats, 512)                                               # selector.py:201-202
         else:                                                                           # norm over ALL hypotheses
-            vall = self._allgather_rows(vps[0].T.contiguous().view(rfn, an * 3), rfn_all).view(Dg, 3).T.contiguous()
-            fall = torch.zeros((Dg, FEAT_LD), dtype=torch.float32, device=dev)
+            # one all-gather for the batch: row r = the (an, qn, 3) scalars of local reference r, in global reference order
+            rows = vps.reshape(qn, 3, rfn, an).permute(2, 3, 0, 1).reshape(rfn, an * qn * 3).contiguous()
+            vall = self._allgather_rows(rows, rfn_all).view(rfn_all, an, qn, 3).permute(2, 3, 0, 1).reshape(qn, 3, Dg).contiguous()
+            fall = torch.zeros((qn * Dg, FEAT_LD), dtype=torch.float32, device=dev)
             ops.vps_norm(vall, fall, 512)
-            feats[:, 512:515] = fall[self.r_begin * an:self.r_end * an, 512:515]
+            feats.view(qn, D, FEAT_LD)[:, :, 512:515] = fall.view(qn, Dg, FEAT_LD)[:, self.r_begin * an:self.r_end * an, 512:515]
 
         # score_process + max over rotations + viewpoint embedding                     selector.py:204-205
         t0 = torch.empty((1, 1, 1, qn * D, 512), dtype=torch.float32, device=dev)
@@ -246,7 +269,7 @@ class ViewpointSelector(ParamBank):
         feats_l, rfn_l = feats, rfn
         rfn = rfn_all                                                                   # the tail runs on ALL refs
         xm = torch.empty((qn * rfn, 1024), dtype=torch.float32, device=dev)             # [x | msg]
-        xm[:, :512] = self._allgather_rows(xl, rfn_all)
+        xm[:, :512] = self._allgather_batch(xl, qn, rfn_l, rfn_all)
 
         def tok(t, n_tok=None):      # [qn*n, C] (row-strided) -> conv view [qn,1,1,n,C]: one image per query
             n_tok = rfn if n_tok is None else n_tok
@@ -284,7 +307,7 @@ class ViewpointSelector(ParamBank):
         ops.conv(tok(a0, rfn_l), pk["ang2"][0], pk["ang2"][1], tok(a1, rfn_l), out_act=1)
         angles = torch.empty((qn * rfn_l, 1), dtype=torch.float32, device=dev)
         ops.conv(tok(a1, rfn_l), pk["ang4"][0], pk["ang4"][1], tok(angles, rfn_l))
-        return logits.view(qn, rfn), self._allgather_rows(angles, rfn_all).view(qn, rfn_all)
+        return logits.view(qn, rfn), self._allgather_batch(angles, qn, rfn_l, rfn_all).view(qn, rfn_all)
 
     def compute_view_point_feats(self, *a, **k):
         """cfg key 'math_mode' ('bf16' / 'fp16'; default fp32) selects the matrix-core operand precision of this network's conv /
@@ -294,7 +317,7 @@ class ViewpointSelector(ParamBank):
 
     def _compute_view_point_feats_fp(self, que_imgs):
         """que_imgs [qn,3,h,w] in [0,1] -> logits [qn,rfn], angles [qn,rfn] (reference selector.py:177-215)."""
-        step = 1 if self.world > 1 else MAX_BATCH                               # the queries of a chunk share every launch
+        step = MAX_BATCH                               # the queries of a chunk share every launch (and, sharded, every collective)
         outs = [self._query_batch(que_imgs[i:i + step].contiguous()) for i in range(0, que_imgs.shape[0], step)]
         return torch.cat([o[0] for o in outs], 0), torch.cat([o[1] for o in outs], 0)
 

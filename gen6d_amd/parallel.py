@@ -129,6 +129,12 @@ def _all_gather_ragged_rows(rows, n_total, world, group=None):
     out_device = rows.device
     rows = rows.to(_coll_device(rows.device))
     cap = (n_total + world - 1) // world
+    if n_total % world == 0 and rows.is_cuda:
+        # even shards under RCCL: one all_gather_into_tensor straight into the result (fixed shapes, device tensors, issued on the
+        # current stream: capturable in a hipGraph together with the kernels around it)
+        out = torch.empty((n_total, rows.shape[1]), dtype=rows.dtype, device=rows.device)
+        dist.all_gather_into_tensor(out, rows.contiguous(), group=group)
+        return out
     pad = torch.zeros((cap, rows.shape[1]), dtype=rows.dtype, device=rows.device)
     pad[:rows.shape[0]] = rows
     bufs = [torch.empty_like(pad) for _ in range(world)]

@@ -44,7 +44,8 @@ class TensorPipeline:
     def query(self, que_full, que_crop, cached_refs=False):
         """que_full [qn,3,H,W] (detector input), que_crop [qn,3,128,128] (selector/refiner input), device tensors; the qn
         queries of the call share every launch (qn <= 8 per chunk inside the networks).
-        Returns [qn,12] rows: position(2), scale, ref_idx, angle, quaternion(4), offset(2), log2-scale."""
+        Returns [qn, 5 + 7 * refine_iter] rows: position(2), scale, ref_idx, angle, then quaternion(4), offset(2), log2-scale of EVERY
+        refinement step in order (26 columns at 3 steps: a wrong first or second step shows in the row)."""
         r = self.ref_dev
         qn = que_crop.shape[0]
         with torch.no_grad():
@@ -56,6 +57,7 @@ class TensorPipeline:
             logits, angles = self.selector.compute_view_point_feats(que_crop)
             idx = torch.argmax(logits, 1)
             ang = angles.gather(1, idx[:, None])
+            steps = []
             for it in range(self.refine_iter):
                 if qn == 1:
                     rot, off, scl = self.refiner._step(que_crop, r["Ks_in"][0], self.iter_poses[it][0], r["ref_imgs"][0],
@@ -70,7 +72,8 @@ class TensorPipeline:
                                                ref_feats=self.ref_feats[None].expand(n, *self.ref_feats.shape) if cached_refs else None)
                         rots.append(o[0]); offs.append(o[1]); scls.append(o[2])
                     rot, off, scl = (torch.cat(t, 0) for t in (rots, offs, scls))
-        return torch.cat([det["positions"], det["scales"][:, None], idx[:, None].float(), ang, rot, off, scl], 1)
+                steps += [rot, off, scl]
+        return torch.cat([det["positions"], det["scales"][:, None], idx[:, None].float(), ang] + steps, 1)
 
     # ------------------------------------------------------------------ hipGraph
     def capture(self, full_shape=(1, 3, 480, 640), crop_shape=(1, 3, 128, 128), warmup=2, lanes=1, batch=None, cached_refs=False):

@@ -16,7 +16,7 @@ def build_state(state_dicts, det_refs, sel_case):
 
 
 def query(state_dicts, state, ref_case, iter_poses, que_full, que_crop, stage_s=None):
-    """One query: returns the same [1,12] row as TensorPipeline.query plus the selector logits.
+    """One query: returns the same [1, 5 + 7 * steps] row as TensorPipeline.query (every refinement step's outputs) plus the selector logits.
     `stage_s`: optional dict that receives the wall seconds of the detector / selector / refiner stages."""
     import time
     with torch.no_grad():
@@ -27,11 +27,13 @@ def query(state_dicts, state, ref_case, iter_poses, que_full, que_crop, stage_s=
         logits, angles = O.selector_forward(state_dicts["selector"], que_crop, state["sel_cache"], state["sel_embed"])
         idx, ang = O.selector_select(logits, angles)
         t2 = time.perf_counter()
+        steps = []
         for p in iter_poses:
             o = O.refiner_forward(state_dicts["refiner"], que_crop, ref_case["Ks_in"], p, ref_case["ref_imgs"],
                                   ref_case["ref_Ks"], ref_case["ref_poses"])
+            steps += [o["rotation"], o["offset"], o["scale"]]
         t3 = time.perf_counter()
     if stage_s is not None:
         stage_s.update(detector=t1 - t0, selector=t2 - t1, refiner=t3 - t2)
-    row = torch.cat([pos, scl[:, None], idx[:, None].float(), ang[:, None], o["rotation"], o["offset"], o["scale"]], 1)
+    row = torch.cat([pos, scl[:, None], idx[:, None].float(), ang[:, None]] + steps, 1)
     return row, logits

@@ -8,7 +8,7 @@ timed-but-unchecked:
     sel_64x36.npz     64 refs x 36 rotations   (BASELINE configs[1])
     operator.npz      network/operator.py:4-24 normalize_coords / pose_apply_th / generate_coords
     ref_grids.npz     VolumeRefiner.forward(...)["grids"] (inference=False branch)               refiner.py:262-268
-    pipeline_rows.npz the [1,12] result rows of bench.py's four synthetic queries (detector + selector + 3 refiner
+    pipeline_rows.npz the [1,26] result rows (5 + 7 per refinement step) of bench.py's four synthetic queries (detector + selector + 3 refiner
                       steps on gen6d_amd.pipeline.TensorPipeline's synthetic state), so that bench.py can state parity
                       against the reference itself on a box that has no /root/reference
 
@@ -110,11 +110,13 @@ def pipeline_rows(n2n, synth):
             logits, angles = sel.compute_view_point_feats(crops[j:j + 1])
             idx = torch.argmax(logits, 1)
             ang = angles[torch.arange(1), idx]
+            steps = []
             for p in iter_poses:
                 o = ref({"que_imgs_info": {"imgs": crops[j:j + 1], "Ks_in": rc["Ks_in"], "poses_in": p},
                          "ref_imgs_info": {"imgs": rc["ref_imgs"], "Ks": rc["ref_Ks"], "poses": rc["ref_poses"]},
                          "inference": True})
-            rows.append(torch.cat([pos, scl[:, None], idx[:, None].float(), ang[:, None], o["rotation"], o["offset"], o["scale"]], 1))
+                steps += [o["rotation"], o["offset"], o["scale"]]          # every step's outputs (round 4: was the last step only)
+            rows.append(torch.cat([pos, scl[:, None], idx[:, None].float(), ang[:, None]] + steps, 1))
             logits_all.append(logits)
             print("query", j, rows[-1].numpy().round(4))
     save("pipeline_rows", rows=torch.cat(rows, 0).numpy(), logits=torch.cat(logits_all, 0).numpy(),

@@ -123,7 +123,7 @@ def test_detector_winograd_correlation_host_path(golden):
     case = synth.detector_case(int(g["rfn"]), int(g["hq"]), int(g["wq"]))
     with torch.no_grad():
         out = net({"ref_imgs_info": {"imgs": case["ref_imgs"]}, "que_imgs_info": {"imgs": case["que_imgs"]}})
-    assert net.ref_wino15 is not None and tuple(net.ref_wino15.shape) == (25 * 64, 16, 32, 8)
+    assert net.ref_wino15 is None and tuple(net.ref_wino15_43.shape) == (25 * 64, 2, 1, 18, 1, 4, 16, 4)      # F(4x4,3x3) route (detector.F43)
     for k in ("scores", "select_pr_offset", "select_pr_scale"):
         np.testing.assert_allclose(out[k].numpy(), g[k], rtol=1e-3, atol=1e-3 * np.abs(g[k]).max())
     assert np.array_equal(out["que_select_id"].numpy(), g["que_select_id"])

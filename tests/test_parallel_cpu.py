@@ -128,3 +128,73 @@ def test_reference_sharded_detector_matches_golden(tmp_path):
                          env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert out.stdout.count("sharded detector ok") == 3
+
+
+BATCH_SHARD_WORKER = textwrap.dedent("""
+    import sys, numpy as np, torch
+    sys.path.insert(0, %r); sys.path.insert(0, %r)
+    import ref_ops
+    from gen6d_amd import ops, parallel, synth
+    from gen6d_amd.network import name2network
+    for name in dir(ops):                       # CPU emulation of the HIP ops (host-logic test)
+        if not name.startswith("_") and callable(getattr(ops, name)) and hasattr(ref_ops, name):
+            setattr(ops, name, getattr(ref_ops, name))
+    rank, world, local = parallel.init_from_env(backend="gloo")
+    g = dict(np.load(%r))
+    rfn, an = int(g["rfn"]), int(g["an"])
+    net = name2network["selector"]({"name": "t", "selector_angle_num": an}).eval()
+    net.load_state_dict(synth.synth_state_dict("selector", an=an))
+    net.set_shard(rank, world)
+    case = synth.selector_case(rfn, an)
+    # a BATCH of three queries through one set of launches and one set of collectives: the golden query first and last, another
+    # image in between (its row must differ: the per-query statistics tables must not mix)
+    other = synth.imgs_to_tensor(synth.synth_images(1, 128, 128, 977))
+    ques = torch.cat([case["que_imgs"], other, case["que_imgs"]], 0)
+    parallel.COLLECTIVE_LOG = []
+    with torch.no_grad():
+        net.extract_ref_feats(case["ref_imgs"], case["ref_poses"], case["object_center"], case["object_vert"])
+        n_build = len(parallel.COLLECTIVE_LOG)
+        logits, angles = net.compute_view_point_feats(ques)
+    n_query = len(parallel.COLLECTIVE_LOG) - n_build
+    parallel.COLLECTIVE_LOG = None
+    b, e = parallel.shard_range(rfn, rank, world)
+    assert net.ref_feats_cache[0].shape[0] == (e - b) * an          # only the local slice of the cache is resident
+    assert logits.shape == (3, rfn) and angles.shape == (3, rfn)
+    for row in (0, 2):
+        np.testing.assert_allclose(logits[row:row + 1].numpy(), g["logits"], atol=2e-3)
+        np.testing.assert_allclose(angles[row:row + 1].numpy(), g["angles"], atol=2e-3)
+        assert int(logits[row].argmax()) == int(g["logits"].argmax(1)[0])
+    assert float((logits[1] - logits[0]).abs().max()) > 1e-2
+    assert n_build == 1 and n_query == 9, (n_build, n_query)        # 9 collectives for the whole batch: 3 per query here, 9/8 at 8 queries
+    print("rank", rank, "batched sharded selector ok", n_query)
+""")
+
+
+@pytest.mark.parametrize("tag,world,port", [("sel_128x5", 8, 29651), ("sel_small", 3, 29653)])
+def test_reference_sharded_selector_batch_of_queries(tmp_path, tag, world, port):
+    """BASELINE configs[3]'s shape — 128 references x 5 rotations sharded 8-way (16 per rank) — and a ragged 3-rank split of 8
+    references, each with a batch of three queries per call: every collective is shared by the batch (9 per batch), the rows of
+    the golden query reproduce the reference's logits (tests/golden/sel_128x5.npz / sel_small.npz)."""
+    script = tmp_path / "batch_shard_worker.py"
+    script.write_text(BATCH_SHARD_WORKER % (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden", tag + ".npz")))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                         env=env, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert out.stdout.count("batched sharded selector ok") == world
+
+
+@pytest.mark.parametrize("tag,world,port", [("det_mid", 4, 29661), ("det_mid", 5, 29663)])
+def test_reference_sharded_detector_32_refs(tmp_path, tag, world, port):
+    """32 references over 4 ranks (8 each) and, ragged, over 5 (7+7+6+6+6) against the reference's golden detection (det_mid: 160x192
+    query): the local 15x15 levels fall back from the Winograd route (needs 32 local references) to the direct kernels, the
+    all-reduce(MAX) of the score features restores the global max over references."""
+    script = tmp_path / "det_worker.py"
+    script.write_text(DET_WORKER % (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden", tag + ".npz")))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert out.stdout.count("sharded detector ok") == world
