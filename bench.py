@@ -69,6 +69,93 @@ def stage_times(pipe, full, crop, reps=5):
     return out
 
 
+def ref_sweep(dev, B, lanes, steps, warmup):
+    """north_star's reference-view sweep on the current code: the full pipeline (detector 480x640 vs 32 refs + selector + 3 refiner
+    steps) at 32 / 128 selector reference views x 5 rotations, timed like the headline (hipGraph replay, `lanes` batches of B in
+    flight), plus BASELINE configs[1] — the selector alone at 64 views x 36 rotations (reference network/selector.py:13-15,97-104 is
+    parametric in the rotation count; configs/gen6d_pretrain.yaml:10 uses 5).  Each entry: images/s, the Winograd family's executed
+    TFLOP/s and fraction of the fp32 MFMA peak from a serialised eager pass, and the selector logits against the reference's own
+    (tests/golden/sel_128x5.npz, sel_64x36.npz) where such a fixture exists."""
+    from gen6d_amd import ops, synth
+    from gen6d_amd.pipeline import TensorPipeline
+    fulls = synth.imgs_to_tensor(synth.synth_images(4, 480, 640, seed=100)).to(dev)
+    crops = synth.imgs_to_tensor(synth.synth_images(4, 128, 128, seed=200)).to(dev)
+    out = {}
+
+    def logits_parity(pipe, tag):
+        gp = os.path.join(ROOT, "tests", "golden", tag + ".npz")
+        if not os.path.exists(gp):
+            return None
+        g = np.load(gp)
+        with torch.no_grad():
+            lg = pipe.selector.compute_view_point_feats(pipe.sel_case["que_imgs"].to(dev))[0].cpu().numpy()
+        return {"source": f"tests/golden/{tag}.npz (the reference's own module)", "logits_max_abs_diff": float(np.abs(lg - g["logits"]).max()),
+                "argmax_equal": bool((lg.argmax(1) == g["logits"].argmax(1)).all()), "bar": 1e-4}
+
+    def wino_frac(fn):
+        ops.SERIAL = True
+        with torch.no_grad():
+            fn(); torch.cuda.synchronize()
+            ops.PROFILE, ops.PROFILE_HBM = [], {}
+            fn(); torch.cuda.synchronize()
+        prof, ops.PROFILE, ops.PROFILE_HBM = ops.PROFILE, None, None
+        r = {}
+        for key, sel in (("winograd", lambda p: p[3].startswith("wino3x3")), ("all_mfma", lambda p: True)):
+            pp = [p for p in prof if sel(p)]
+            fl, ms = sum(p[0] for p in pp), sum(p[1].elapsed_time(p[2]) for p in pp)
+            r[key] = {"achieved_TFLOPs_executed": fl / (ms * 1e-3) / 1e12, "frac_of_fp32_mfma_peak": fl / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                      "ms_per_batch": ms}
+        return r
+
+    for sel_refs in (32, 128):
+        pipe = TensorPipeline(dev, sel_rfn=sel_refs, det_rfn=32); pipe.build()
+        ops.SERIAL = True
+        pipe.capture(lanes=lanes, batch=B)
+        busy = [None] * lanes
+        def run(n):
+            for i in range(n):
+                idx = torch.tensor([(i * B + b + i // lanes) % 4 for b in range(B)], device=dev)
+                lane = i % lanes
+                if busy[lane] is not None: busy[lane].synchronize()
+                _, stream = pipe.query_graph(fulls[idx], crops[idx], lane)
+                ev = torch.cuda.Event(); ev.record(stream); busy[lane] = ev
+            torch.cuda.synchronize()
+        run(warmup)
+        t0 = time.perf_counter(); run(steps); dt = time.perf_counter() - t0
+        idx = torch.arange(B, device=dev) % 4
+        out[f"{sel_refs}x5"] = {"workload": f"full pipeline, selector {sel_refs} refs x 5 rotations, detector 32 refs, 3 refine steps",
+                                "value": steps * B / dt, "unit": "images/s", "ms_per_step": dt / steps * 1e3, "batch": B, "lanes": lanes,
+                                "roofline": wino_frac(lambda: pipe.query(fulls[idx], crops[idx])),
+                                "parity_vs_reference": logits_parity(pipe, f"sel_{sel_refs}x5")}
+        del pipe; torch.cuda.empty_cache()
+    # BASELINE configs[1]: selector only, 64 views x 36 rotations (D = 2304 hypotheses per query)
+    pipe = TensorPipeline(dev, sel_rfn=64, det_rfn=32, an=36); pipe.build()
+    ops.SERIAL = True
+    idx = torch.arange(B, device=dev) % 4
+    g_in = crops[idx].clone()
+    stream = torch.cuda.Stream(device=dev)
+    stream.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(stream), torch.no_grad():
+        for _ in range(2): pipe.selector.compute_view_point_feats(g_in)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=stream), torch.no_grad():
+        g_out = pipe.selector.compute_view_point_feats(g_in)
+    for _ in range(2): graph.replay()
+    torch.cuda.synchronize()
+    n = max(4, steps // 2)
+    t0 = time.perf_counter()
+    for _ in range(n): graph.replay()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out["64x36_selector_only"] = {"workload": "BASELINE configs[1]: selector only, 64 refs x 36 rotations, 128x128 queries", "value": n * B / dt,
+                                  "unit": "queries/s", "ms_per_step": dt / n * 1e3, "batch": B, "lanes": 1,
+                                  "roofline": wino_frac(lambda: pipe.selector.compute_view_point_feats(g_in)),
+                                  "parity_vs_reference": logits_parity(pipe, "sel_64x36")}
+    del pipe, graph, g_out; torch.cuda.empty_cache()
+    return out
+
+
 def self_launch(args):
     """`python bench.py --gpus N` with N > 1 and no launcher environment: re-exec under torch.distributed.run
     (one process per GPU, rendezvous on 127.0.0.1) and exit with its return code.  On a box with fewer than N GPUs
@@ -97,16 +184,19 @@ def main():
     ap.add_argument("--sel-refs", type=int, default=64)
     ap.add_argument("--det-refs", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--lowp", default="fp16",
+    ap.add_argument("--lowp", default="fp16,bf16mix",
                     help="comma list of reduced-precision matrix-core modes measured AFTER the fp32 headline (same launch mode, "
                          "same steps) and reported in the `lowp` object: operands bf16 / fp16, fp32 accumulate; '' = skip.  Default fp16 "
                          "only: bf16's 8-bit mantissa moves the selector logits by more than the top-2 margin of some queries (the "
-                         "viewpoint arg-max flips on 1 of the 4 synthetic queries once the trunk runs in bf16) — available as `--lowp bf16,fp16`")
+                         "viewpoint arg-max flips on 1 of the 4 synthetic queries once the trunk runs in bf16) — available as `--lowp bf16,fp16`; "
+                         "bf16mix = bf16 in the detector and the refiner, fp16 in the selector")
     ap.add_argument("--lowp-lanes", type=int, default=3,
                     help="batches in flight during the reduced-precision passes (their kernels are ~2x shorter, so replay gaps weigh "
                          "more: 342 images/s with 2, 357 with 3; fp32 gains 1 %% from a third lane and keeps the 2 of --lanes)")
     ap.add_argument("--no-cached", action="store_true", help="skip the reference-feature-cache side measurement (`cached` object)")
     ap.add_argument("--no-chained", action="store_true", help="skip the `chained` measurement")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the reference-view sweep (`sweep` object: 32 / 128 refs x 5 full pipeline, "
+                                                            "64 x 36 selector only)")
     ap.add_argument("--chained", action="store_true",
                     help="(default since round 4; kept for old command lines) additionally time the device-resident predict chain (gen6d_amd/chain.py: detection -> crop -> selection "
                          "-> pose -> 3 x refine with every inter-stage warp and the pose algebra on the GPU, one captured graph "
@@ -117,7 +207,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="time the eager launch path instead of hipGraph replay")
     ap.add_argument("--batch", type=int, default=8,
                     help="queries per step: they go through every launch together (M dimension of the conv / correlation grids, one "
-                         "pass over the selector's reference cache, one FC weight stream), 1..8")
+                         "pass over the selector's reference cache, one FC weight stream), 1..32 (the detector cuts at 16)")
     ap.add_argument("--lanes", type=int, default=2,
                     help="independent hipGraph copies (one batch each) kept in flight on separate streams")
     ap.add_argument("--serial", action="store_true",
@@ -159,7 +249,7 @@ def main():
     qseed = 0 if shard_refs else rank           # same queries on every rank when the references are sharded
     fulls = synth.imgs_to_tensor(synth.synth_images(4, 480, 640, seed=100 + qseed)).to(dev)
     crops = synth.imgs_to_tensor(synth.synth_images(4, 128, 128, seed=200 + qseed)).to(dev)
-    B = max(1, min(8, args.batch))                # sharded references: the batch also shares every collective (round 4)
+    B = max(1, min(32, args.batch))               # sharded references: the batch also shares every collective (round 4)
 
     use_graph = not args.no_graph and not shard_refs and not args.serial     # collectives are issued eagerly
     no_fork = args.serial or (use_graph and not args.fork)
@@ -390,7 +480,13 @@ def main():
     headline_lanes = lanes
     if modes:
         lanes = max(1, args.lowp_lanes)               # (step / images_of read `lanes` when they run)
-    for pi, mode in enumerate(modes[:1] + modes):
+    LOWP_PEAK_TFLOPS = 2500.0                          # dense 16-bit MFMA peak (MI355X_MICROARCH.md; AMD's 5 PFLOP/s figure is 2:1 sparse)
+    gold_npz = np.load(gpath) if ((args.sel_refs, args.det_refs) == (64, 32) and os.path.exists(gpath)) else None
+    for pi, mode_name in enumerate(modes[:1] + modes):
+        # "bf16mix": bf16 operands in the detector and the refiner, fp16 in the selector — the stage whose 13 stacked InstanceNorms
+        # amplify bf16's 8-bit mantissa past the top-2 logit margin of some queries (network cfg key `math_mode` overrides the context)
+        mode = "bf16" if mode_name == "bf16mix" else mode_name
+        pipe.selector.cfg["math_mode"] = "fp16" if mode_name == "bf16mix" else None
         with ops.math_mode(mode):
             pipe.capture(lanes=lanes, batch=B)
         lane_busy[:] = [None] * lanes
@@ -403,10 +499,44 @@ def main():
         drain(); torch.cuda.synchronize()
         ldt = time.perf_counter() - t1
         lrows = torch.cat(lrows[:args.steps], 0).cpu()
-        entry = {"dtype": mode, "value": nl * B / ldt, "unit": "images/s", "ms_per_step": ldt / nl * 1e3, "queries": nl * B, "batch": B,
+        entry = {"dtype": mode_name, "value": nl * B / ldt, "unit": "images/s", "ms_per_step": ldt / nl * 1e3, "queries": nl * B, "batch": B,
                  "lanes": lanes}
-        if (args.sel_refs, args.det_refs) == (64, 32) and os.path.exists(gpath):
-            gold = torch.from_numpy(np.load(gpath)["rows"]).float()
+        if mode_name == "bf16mix":
+            entry["scheme"] = "detector bf16, selector fp16, refiner bf16 (fp32 accumulation, InstanceNorm statistics, selector tail and regressor everywhere)"
+        if pi > 0:
+            # roofline of the mode: serialised eager pass of the same steps with HIP events around every MFMA-family launch
+            ops.SERIAL = True
+            with ops.math_mode(mode):
+                step(0, eager=True); torch.cuda.synchronize()
+                ops.PROFILE, ops.PROFILE_HBM = [], {}
+                for i in range(args.steps):
+                    step(args.warmup + i, eager=True)
+                torch.cuda.synchronize()
+                lp, ops.PROFILE, ops.PROFILE_HBM = ops.PROFILE, None, None
+                if gold_npz is not None:              # selector logits of the 4 synthetic queries in this mode vs the reference's
+                    lg = pipe.selector.compute_view_point_feats(crops)[0].cpu()
+            ops.SERIAL = no_fork
+            fl = sum(p[0] for p in lp); ms = sum(p[1].elapsed_time(p[2]) for p in lp)
+            wino = [p for p in lp if p[3].startswith("wino3x3")]
+            entry["roofline"] = {"bound": "mfma", "achieved": fl / (ms * 1e-3) / 1e12, "peak": LOWP_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": fl / (ms * 1e-3) / 1e12 / LOWP_PEAK_TFLOPS, "traffic": None,
+                                 "kernel": "all MFMA-family launches of a step (16-bit Winograd trunk / conv family, corr16_patch, conv_igemm / conv_patch "
+                                           "with 16-bit operands)", "flops_counted": "EXECUTED (Winograd launches: direct-form / 2.25)",
+                                 "mfma_ms_per_step": ms / args.steps, "gflop_executed_per_step": fl / args.steps / 1e9,
+                                 "winograd_share_of_ms": sum(p[1].elapsed_time(p[2]) for p in wino) / ms if ms > 0 else None,
+                                 "lds_bytes_per_chunk": {"wino16b_conv3x3_kernel": 316 * 1024, "note": "raw patch 98 + V 64 + filter fragments 64 read, "
+                                                         "V 32 + raw 26 + filters 32 written per 16-channel chunk (DESIGN.md 4.7); the LDS write rate is the bound"},
+                                 "measured": "HIP events around every launch, serialised eager re-run of the same steps"}
+            if gold_npz is not None:
+                gl = torch.from_numpy(gold_npz["logits"]).float()
+                top2 = gl.topk(2, 1)[0]
+                margin = float((top2[:, 0] - top2[:, 1]).min())
+                err = float((lg - gl).abs().max())
+                entry["selector_logits"] = {"max_abs_err": err, "min_top2_margin_of_the_4_queries": margin, "err_over_margin": err / margin,
+                                            "bar": 0.25, "ok": bool(err <= 0.25 * margin),
+                                            "argmax_equal": bool((lg.argmax(1) == gl.argmax(1)).all())}
+        if gold_npz is not None:
+            gold = torch.from_numpy(gold_npz["rows"]).float()
             ref = torch.stack([gold[j] for i in range(args.steps) for j in images_of(args.warmup + i)])
             r32 = torch.stack([row32[j] for i in range(args.steps) for j in images_of(args.warmup + i)])
             d = (lrows - ref).abs()
@@ -416,7 +546,8 @@ def main():
                 "max_rel_diff_row": float((d / ref.abs().clamp(min=1.0)).max()),
                 "vs_fp32_path_max_rel": float(((lrows - r32).abs() / r32.abs().clamp(min=1.0)).max())}
         if pi > 0:
-            lowp[mode] = entry
+            lowp[mode_name] = entry
+    pipe.selector.cfg["math_mode"] = None
     if lowp:
         result["lowp"] = lowp
     lanes = headline_lanes
@@ -482,7 +613,7 @@ def main():
         qk = [Ks[i % 8] for i in range(n_c + lanes)]
         chain = est.device_chain()
         clanes = min(lanes, 3)
-        cb = min(B, args.chain_batch)  # queries per captured chain graph (they share every launch)
+        cb = min(B, args.chain_batch, 8)  # queries per captured chain graph (they share every launch)
         n_c = max(n_c, 6 * cb * clanes)
         qi = [imgs[i % 8] for i in range(n_c)]
         qk = [Ks[i % 8] for i in range(n_c)]
@@ -504,6 +635,14 @@ def main():
                                  "final_pose_maxabs": float(np.abs(inter_d["refine_poses"][-1] - inter_h["refine_poses"][-1]).max()),
                                  "graph_replay_vs_eager_chain_maxabs": float(np.abs(res[0][0] - inter_d["refine_poses"][-1]).max()),
                                  "bar": 1e-4, "note": "pose heads damped towards the identity (synth.damp_refiner_head), all 3 dependent refine steps"}}
+
+    if not args.no_sweep and world == 1 and use_graph and (args.sel_refs, args.det_refs) == (64, 32):
+        sw = ref_sweep(dev, B, headline_lanes, max(6, args.steps // 2), max(2, args.warmup // 2))
+        sw["64x5"] = {"workload": "the headline of this line", "value": result["value"], "unit": "images/s",
+                      "roofline": {"winograd": {"achieved_TFLOPs_executed": fams.get("winograd", {}).get("achieved"),
+                                                "frac_of_fp32_mfma_peak": fams.get("winograd", {}).get("frac")}}}
+        result["sweep"] = sw
+        ops.SERIAL = no_fork
 
     def row_diff(got, ref):
         """Row layout: position(2, px), scale, ref_idx, angle, quaternion(4), offset(2), log2-scale."""

@@ -31,7 +31,7 @@ void g6d_allow_lds(const void* func, int bytes) {
   if (done.insert({func, dev}).second) (void)hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
-extern "C" int g6d_abi_version(void) { return 8; }
+extern "C" int g6d_abi_version(void) { return 9; }
 extern "C" const char* g6d_last_error(void) { return g_err; }
 extern "C" int g6d_sizeof_conv_desc(void) { return (int)sizeof(G6dConv); }
 

@@ -347,6 +347,75 @@ __global__ void __launch_bounds__(GEMV_THREADS) linear_gemv_kernel(const float* 
   }
 }
 
+// Batched weight-streaming GEMV for 2 <= B <= 8 right-hand sides and long rows (the refiner's first FC layer with a batch of queries:
+// K = 32768, O = 512, 67 MB of weights for B x 33 MFLOP).  linear_gemv_kernel gives every block ONE output row and lets it read all B
+// rows of x: 512 blocks x 1 MB of x through L2 for 67 MB of HBM traffic — measured 49 us at B = 8 (0.17 of 8 TB/s) against ~11 us
+// for the weight stream.  Here a block owns R = 8 output rows x one K slice of 1024 KV floats: a thread holds its KV 16-byte pieces of
+// all R rows in registers (R KV loads in flight per thread, 128 KB per block), reads each x piece ONCE for the R rows (x through
+// L2: O / R x B x K x 4 bytes = the size of the weight stream at B = 8) and runs R x B x 4 FMAs per x piece.  The K slices of a row group
+// meet through the workspace like the split launches of the conv kernels (g6d_split_arrive): partial sums written through, the block
+// that arrives last adds them IN SLICE ORDER (deterministic) and applies bias / activation.
+#define GEMVB_THREADS 256
+#define GEMVB_R 8
+template <int KV>
+__global__ void __launch_bounds__(GEMVB_THREADS, 2) linear_gemv_batch_kernel(const float* __restrict__ x, int B, int K, const float* __restrict__ W,
+                                                                              const float* __restrict__ bias, int act, float* __restrict__ out,
+                                                                              int O, float* __restrict__ ws) {
+  constexpr int R = GEMVB_R, KL = GEMVB_THREADS * 4 * KV;
+  __shared__ float red[GEMVB_THREADS / 64][R * 8];
+  __shared__ int flag;
+  const int og = blockIdx.x, ks = blockIdx.y, KS = gridDim.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kbase = ks * KL + tid * 4;
+  f32x4 wv[R][KV];
+#pragma unroll
+  for (int v = 0; v < KV; ++v)
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      wv[r][v] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(W + (size_t)(og * R + r) * K + kbase + v * (GEMVB_THREADS * 4)));
+  float acc[R][8];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[r][b] = 0.f;
+#pragma unroll
+  for (int v = 0; v < KV; ++v)
+#pragma unroll
+    for (int b = 0; b < 8; ++b)
+      if (b < B) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)b * K + kbase + v * (GEMVB_THREADS * 4));
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+          acc[r][b] += wv[r][v][0] * xv[0] + wv[r][v][1] * xv[1] + wv[r][v][2] * xv[2] + wv[r][v][3] * xv[3];
+      }
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const float sm = wave_sum(acc[r][b]);
+      if (lane == 0) red[wave][r * 8 + b] = sm;
+    }
+  __syncthreads();
+  float part = 0.f;
+  if (tid < R * 8) {
+#pragma unroll
+    for (int w = 0; w < GEMVB_THREADS / 64; ++w) part += red[w][tid];
+  }
+  if (KS > 1) {
+    float* slab = ws + G6D_WS_COUNTERS + (size_t)og * KS * (R * 8);
+    if (tid < R * 8) asm volatile("global_store_dword %0, %1, off sc1" ::"v"(slab + ks * (R * 8) + tid), "v"(part) : "memory");
+    if (!g6d_split_arrive(reinterpret_cast<int*>(ws) + og, KS, &flag)) return;
+    if (tid < R * 8) {
+      part = 0.f;
+      for (int z = 0; z < KS; ++z) part += slab[z * (R * 8) + tid];
+    }
+  }
+  if (tid < R * 8) {
+    const int r = tid >> 3, b = tid & 7, o = og * R + r;
+    if (b < B) out[(size_t)b * O + o] = apply_act(part + (bias ? bias[o] : 0.f), act);
+  }
+}
+
 inline int grid_for(long long total, int block) {
   long long g = (total + block - 1) / block;
   return (int)(g > 65535 * 16 ? 65535 * 16 : (g < 1 ? 1 : g));
@@ -474,6 +543,33 @@ extern "C" int g6d_affine_act_add(const float* in, int ld_in, const float* scale
   hipLaunchKernelGGL(affine_act_add_kernel, dim3((n * C + 255) / 256), dim3(256), 0, STREAM(stream), in, ld_in, scale,
                      shift, relu, residual, ld_res, n, C, out, ld_out, rows_per_group);
   return g6d_check_launch("affine_act_add");
+}
+
+extern "C" int g6d_linear_gemv_batch(const float* x, int B, int K, const float* W, const float* bias, int O, int act, float* out,
+                                     float* workspace, size_t workspace_bytes, g6d_stream_t stream) {
+  if (!x || !W || !out || B <= 0 || K <= 0 || (K & 3) || O <= 0 || !g6d_aligned16(x) || !g6d_aligned16(W)) {
+    g6d_set_error("linear_gemv_batch: bad args"); return G6D_EINVAL;
+  }
+  constexpr int KL = GEMVB_THREADS * 4 * 4;                 // KV = 4: K slices of 4096 floats
+  const bool rows_ok = O % GEMVB_R == 0 && K % KL == 0 && O / GEMVB_R <= G6D_WS_COUNTERS;
+  const int KS = rows_ok ? K / KL : 0;
+  const size_t need = G6D_WS_COUNTER_BYTES + (size_t)(O / GEMVB_R) * (KS > 0 ? KS : 1) * GEMVB_R * 8 * sizeof(float);
+  // groups of <= 8 right-hand sides; a group of one, short rows or a missing workspace take the row-per-block kernel.  Later groups
+  // re-read W, which (67 MB) then comes out of the 256 MB Infinity Cache rather than HBM.
+  for (int b0 = 0; b0 < B; b0 += 8) {
+    const int nb = B - b0 < 8 ? B - b0 : 8;
+    const float* xg = x + (size_t)b0 * K;
+    float* og = out + (size_t)b0 * O;
+    if (nb >= 2 && rows_ok && KS >= 2 && workspace && workspace_bytes >= need && g6d_aligned16(workspace)) {
+      hipLaunchKernelGGL(linear_gemv_batch_kernel<4>, dim3(O / GEMVB_R, KS), dim3(GEMVB_THREADS), 0, STREAM(stream), xg, nb, K, W, bias, act, og, O,
+                         workspace);
+    } else if (K >= GEMV_THREADS * 4 * 16) {
+      hipLaunchKernelGGL(linear_gemv_kernel<16>, dim3(O), dim3(GEMV_THREADS), 0, STREAM(stream), xg, nb, K, W, bias, act, og, O);
+    } else {
+      hipLaunchKernelGGL(linear_gemv_kernel<4>, dim3(O), dim3(GEMV_THREADS), 0, STREAM(stream), xg, nb, K, W, bias, act, og, O);
+    }
+  }
+  return g6d_check_launch("linear_gemv_batch");
 }
 
 extern "C" int g6d_linear_gemv(const float* x, int B, int K, const float* W, const float* bias, int O, int act,

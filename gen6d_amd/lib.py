@@ -81,6 +81,7 @@ SIGNATURES = {
     "g6d_layernorm": [_P, _I, _I, _I, _P, _P, _F, _P, _I, _P],
     "g6d_affine_act_add": [_P, _I, _P, _P, _I, _P, _I, _I, _I, _P, _I, _I, _P],
     "g6d_linear_gemv": [_P, _I, _I, _P, _P, _I, _I, _P, _P],
+    "g6d_linear_gemv_batch": [_P, _I, _I, _P, _P, _I, _I, _P, _P, C.c_size_t, _P],
     "g6d_chain_crop_from_detection": [_P, _F, _P, _I, _P],
     "g6d_chain_pose_from_selection": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P],
     "g6d_chain_refine_prepare": [_P, _P, _P, _F, _F, _P, _P, _I, _I, _P, _P, _F, _P, _I, _P],

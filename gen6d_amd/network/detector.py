@@ -33,7 +33,8 @@ _CORR_WINO = os.environ.get("G6D_CORR_WINO", "1") != "0"
 # multiplications than F(2x2,3x3) at ~5x its rounding error — the detector holds ~4e-6 of the score range against the 1e-4 bar
 # (tests/test_parity_timed_gpu.py).  False: the F(2x2,3x3) kernels of round 3 (tools/ A/B runs and tests flip this attribute).
 F43 = True
-MAX_BATCH = 8        # queries that share one set of launches (g6d_selector_levels / g6d_linear_gemv take <= 8)
+MAX_BATCH = 16       # queries that share one set of launches: the pyramid's first layers address all scales of the batch with 32-bit
+                     # offsets from one base (< 2^29 floats: 16 images of 480x640 at 64 channels; 32 would not fit)
 
 
 class Detector(ParamBank):

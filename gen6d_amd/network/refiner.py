@@ -20,8 +20,8 @@ from .params import ParamBank, fold_vgg
 # Winograd F(4x4,3x3) filters for the stride-1 3x3x3 layers of the volume net (csrc/wino43_conv.hip); VOLUME_F43_LAYERS: which of
 # conv0 (32^3), conv2 (16^3), conv4 (8^3) take it beside the two embed pairs (32^3)
 VOLUME_F43 = True
-VOLUME_F43_LAYERS = ("conv0", "conv2", "conv4")
-MAX_BATCH = 8          # queries that share one set of launches (g6d_linear_gemv takes <= 8 right-hand sides)
+VOLUME_F43_LAYERS = ("conv0",)          # measured per batch of 8: conv2 (16^3) 147 vs 151 us, conv4 (8^3) 144 vs 94 us on F(2x2,3x3): only 32^3 pays
+MAX_BATCH = 32         # queries that share one set of launches (g6d_linear_gemv_batch: 8 right-hand sides per weight pass)
 _K3, _P3 = (3, 3, 3), (1, 1, 1)
 _K2, _P2 = (1, 3, 3), (0, 1, 1)
 
@@ -218,7 +218,7 @@ class VolumeRefiner(ParamBank):
 
     def run_regressor(self, code):
         """code [v,512] (one query) or [qn,v,512] -> rotation [qn,4] (unit quaternion), offset [qn,2], scale [qn,1]; the 67 MB FC
-        weight stream is read once for the whole batch (g6d_linear_gemv, B <= 8)."""
+        weight stream is read once per 8 queries (g6d_linear_gemv_batch)."""
         pk = self._pack()
         qn = code.shape[0] if code.dim() == 3 else 1
         x = ops.linear_gemv(code.reshape(qn, -1), pk["fc0"][0], pk["fc0"][1], act=2)

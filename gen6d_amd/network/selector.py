@@ -36,7 +36,8 @@ _CORR = (
     ((1, 1, 1, 0), (4, 0, 0, 0)),
 )
 _K133, _P011 = (1, 3, 3), (0, 1, 1)
-MAX_BATCH = 8          # queries that share one set of launches (g6d_selector_levels takes <= 8)
+MAX_BATCH = 32         # queries that share one set of launches (BASELINE configs[4]: 32 concurrent queries; g6d_selector_levels runs them
+                       # in groups of 8 query rows per pass over the reference cache)
 FEAT_LD = 516          # 512 corr channels + 3 vps channels + 1 zero pad (16-byte rows)
 
 
@@ -204,7 +205,7 @@ class ViewpointSelector(ParamBank):
                 x, relu = out, bool(has_relu)
 
     def _query_batch(self, que_imgs):
-        """que_imgs [qn,3,128,128], qn <= MAX_BATCH -> logits [qn,rfn], angles [qn,rfn]; one set of launches for the whole batch
+        """que_imgs [qn,3,128,128], qn <= MAX_BATCH (32) -> logits [qn,rfn], angles [qn,rfn]; one set of launches for the whole batch
         (the reference cache is streamed once per batch, the qn*D hypothesis images fill the conv grids)."""
         pk = self._pack()
         an = self.an

@@ -340,7 +340,7 @@ def corr2d_wino_multi(xs, U, outs, kblocks=5):
 
 _ARENA = {}          # (device, stream) -> [buffer, bump offset]
 _CUR_ARENA = None    # arena of the query being enqueued (host-side state; set by stats_arena_begin)
-ARENA_DOUBLES = 1 << 19      # 4 MB: a batch of 8 queries needs ~140 K accumulators in the refiner step (56 images x 1024 channels x 2)
+ARENA_DOUBLES = 1 << 21      # 16 MB: a batch of 8 queries needs ~140 K accumulators in the refiner step (56 images x 1024 channels x 2), 32 queries 560 K
 
 
 def stats_arena_begin(device):
@@ -732,6 +732,10 @@ def selector_levels(ques, refs, sums, Dg, eps=1e-5, want_maps=False):
     if single:
         ques = [q.unsqueeze(0) for q in ques]
     qn = ques[0].shape[0]
+    if qn > 8:                                           # the kernel keeps <= 8 query rows in registers: groups of 8 (one cache pass each)
+        parts = [selector_levels([q[i:i + 8] for q in ques], refs, sums, Dg, eps, want_maps) for i in range(0, qn, 8)]
+        return (torch.cat([p_[0] for p_ in parts], 0), torch.cat([p_[1] for p_ in parts], 0), torch.cat([p_[2] for p_ in parts], 0),
+                [torch.cat([p_[3][l] for p_ in parts], 0) for l in range(L)] if want_maps else None)
     D, _, Cc = refs[0].shape
     dev = ques[0].device
     for q, r in zip(ques, refs):
@@ -885,15 +889,16 @@ def affine_act_add(x, out, scale=None, shift=None, relu=False, residual=None, ro
 
 
 def linear_gemv(x, W, bias, act=0):
-    """x [B,K] contiguous, W [O,K] contiguous -> [B,O]."""
+    """x [B,K] contiguous, W [O,K] contiguous -> [B,O] (g6d_linear_gemv_batch: any B, groups of 8 per weight pass)."""
     _need_gpu(x, W)
     B, K = x.shape
     O = W.shape[0]
     out = torch.empty((B, O), dtype=torch.float32, device=x.device)
     x = x.contiguous()
+    ws = workspace(x.device)
     _timed_hbm("linear_gemv" if O * K >= (1 << 22) else "linear_gemv_small", 4.0 * (O * K + B * K + B * O),
-               lambda: _lib.check(_lib.load().g6d_linear_gemv(_ptr(x), B, K, _ptr(W), _ptr(bias), O, int(act), _ptr(out),
-                                                              _stream()), "g6d_linear_gemv"))
+               lambda: _lib.check(_lib.load().g6d_linear_gemv_batch(_ptr(x), B, K, _ptr(W), _ptr(bias), O, int(act), _ptr(out), _ptr(ws),
+                                                                    ws.numel() * 4, _stream()), "g6d_linear_gemv_batch"))
     return out
 
 

@@ -6,6 +6,7 @@ import torch
 
 from . import synth
 from .network import name2network
+from .network import refiner as refiner_mod
 
 
 class TensorPipeline:
@@ -43,7 +44,7 @@ class TensorPipeline:
 
     def query(self, que_full, que_crop, cached_refs=False):
         """que_full [qn,3,H,W] (detector input), que_crop [qn,3,128,128] (selector/refiner input), device tensors; the qn
-        queries of the call share every launch (qn <= 8 per chunk inside the networks).
+        queries of the call share every launch (chunks of <= 16 / 32 / 32 queries inside the detector / selector / refiner).
         Returns [qn, 5 + 7 * refine_iter] rows: position(2), scale, ref_idx, angle, then quaternion(4), offset(2), log2-scale of EVERY
         refinement step in order (26 columns at 3 steps: a wrong first or second step shows in the row)."""
         r = self.ref_dev
@@ -64,8 +65,9 @@ class TensorPipeline:
                                                        r["ref_Ks"][0], r["ref_poses"][0], ref_feats=self.ref_feats if cached_refs else None)
                 else:                                  # every query of the batch with its own (here: the same canned) views / poses
                     rots, offs, scls = [], [], []
-                    for q0 in range(0, qn, 8):
-                        n = min(8, qn - q0)
+                    rb = refiner_mod.MAX_BATCH
+                    for q0 in range(0, qn, rb):
+                        n = min(rb, qn - q0)
                         ex = lambda t: t.expand(n, *t.shape[1:])
                         o = self.refiner._step(que_crop[q0:q0 + n], ex(r["Ks_in"]).contiguous(), ex(self.iter_poses[it]).contiguous(),
                                                ex(r["ref_imgs"]), ex(r["ref_Ks"]).contiguous(), ex(r["ref_poses"]).contiguous(),

@@ -80,7 +80,7 @@ def test_tensor_pipeline_matches_oracle_pipeline():
     row = pipe.query(full, crop)
     st = PO.build_state(pipe.state_dicts, pipe.det_refs, pipe.sel_case)
     ref, logits = PO.query(pipe.state_dicts, st, pipe.ref_case, [p for p in pipe.iter_poses], full, crop)
-    assert row.shape == (1, 12)
+    assert row.shape == (1, 5 + 7 * 2)                 # every refine step in the row
     assert int(row[0, 3]) == int(ref[0, 3])
     np.testing.assert_allclose(row.numpy(), ref.numpy(), rtol=2e-3, atol=2e-2)
 
@@ -95,7 +95,7 @@ def test_batched_queries_equal_single_queries():
     fulls = synth.imgs_to_tensor(synth.synth_images(3, 64, 96, seed=100))
     crops = synth.imgs_to_tensor(synth.synth_images(3, 128, 128, seed=200))
     rows = pipe.query(fulls, crops)
-    assert rows.shape == (3, 12)
+    assert rows.shape == (3, 5 + 7 * 1)
     for j in range(3):
         one = pipe.query(fulls[j:j + 1], crops[j:j + 1])
         assert int(rows[j, 3]) == int(one[0, 3])
@@ -129,9 +129,13 @@ def test_detector_winograd_correlation_host_path(golden):
     assert np.array_equal(out["que_select_id"].numpy(), g["que_select_id"])
 
 
-def test_more_queries_than_one_launch_batch():
-    """qn = 9 > MAX_BATCH (8): the networks cut the call into chunks of <= 8 queries that share a set of launches each; the [qn, ...]
-    results are those of the single-query calls (selector and refiner forward; CPU emulation of the ops)."""
+def test_more_queries_than_one_launch_batch(monkeypatch):
+    """qn = 9 > MAX_BATCH (set to 8 here; 32 in the product): the networks cut the call into chunks of <= MAX_BATCH queries that share
+    a set of launches each; the [qn, ...] results are those of the single-query calls (selector and refiner forward; CPU emulation
+    of the ops)."""
+    from gen6d_amd.network import refiner as refiner_mod, selector as selector_mod
+    monkeypatch.setattr(selector_mod, "MAX_BATCH", 8)
+    monkeypatch.setattr(refiner_mod, "MAX_BATCH", 2)
     an, rfn = 5, 4
     sel = name2network["selector"]({"name": "t", "selector_angle_num": an}).eval()
     sel.load_state_dict(synth.synth_state_dict("selector", an=an))

@@ -474,12 +474,19 @@ def test_selector_tail_ops(ops):
     _check(ob2, rob2, 1e-6, "affine_act_add batch")
 
 
-@pytest.mark.parametrize("B,K,O,act", [(1, 32768, 512, 2), (1, 512, 7, 0), (3, 1024, 40, 1)])
+@pytest.mark.parametrize("B,K,O,act", [(1, 32768, 512, 2), (1, 512, 7, 0), (3, 1024, 40, 1),
+                                       # g6d_linear_gemv_batch's 8-rows x K-slice kernel (B >= 2, K % 4096 == 0, O % 8 == 0): the refiner's
+                                       # first FC layer with 2 / 8 queries, a ragged group (11 = 8 + 3), configs[4]'s 32, and shapes that
+                                       # fall back to the row-per-block kernel (O % 8 != 0; one K slice)
+                                       (2, 32768, 512, 2), (8, 32768, 512, 2), (11, 8192, 64, 1), (32, 32768, 512, 0), (5, 8192, 20, 0),
+                                       (4, 4096, 16, 2)])
 def test_linear_gemv(ops, B, K, O, act):
     g = torch.Generator().manual_seed(12)
     x, W, b = _rand(g, B, K), _rand(g, O, K, scale=K ** -0.5), _rand(g, O, scale=0.1)
     out = ops.linear_gemv(x.cuda(), W.cuda(), b.cuda(), act)
     _check(out, ref_ops.linear_gemv(_d(x), _d(W), _d(b), act), 1e-5)
+    out2 = ops.linear_gemv(x.cuda(), W.cuda(), b.cuda(), act)      # slices are added in slice order: bit-equal from run to run, counters re-armed
+    assert torch.equal(out, out2)
 
 
 @pytest.mark.parametrize("out_float", [False, True])
