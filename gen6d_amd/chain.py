@@ -10,6 +10,8 @@ Reference state resident on the GPU (built once per object by `DeviceChain(estim
   * for the refiner: the farthest-point subset (<= 128 views) of the reference images as one uint8 stack [n,H,W,3] plus
     their normalised poses and intrinsics — the reference re-reads these from disk on every refinement step.
 """
+import itertools
+
 import numpy as np
 import torch
 
@@ -25,8 +27,13 @@ class DeviceChain:
     MARGIN = 0.05
     REFINE_SIZE = 128
 
+    _TOKENS = itertools.count(1)
+
     def __init__(self, est, even_num=128):
         self.est = est
+        # reference-feature cache keys carry the real view id and a token that is unique per chain (CPython may reuse a freed chain's
+        # id(), and the same sub-index can mean another view after a rebuild on the same database: ADVICE r03)
+        self.cache_token = next(DeviceChain._TOKENS)
         self.dev = est.device
         self.size = int(est.cfg["ref_resolution"])                      # selector crop (estimator.py:184)
         self.refine_size = int(est.cfg.get("refine_size", self.REFINE_SIZE))
@@ -91,7 +98,7 @@ class DeviceChain:
                 geo_K, geo_P = geo[33:33 + 9 * R].view(R, 3, 3), geo[33 + 9 * R:33 + 21 * R].view(R, 3, 4)
                 if use_feat_cache and astep > 0:
                     kb = torch.stack([idx, prep[2]], 0).cpu().numpy()            # the step's only host round trip: 2 x R ints
-                    keys = [(id(self), int(kb[0, k]), int(kb[1, k]), rs) for k in range(R)]
+                    keys = [(self.cache_token, str(self.sub_ids[int(kb[0, k])]), int(kb[1, k]), rs) for k in range(R)]
 
                     def make(miss):
                         m = torch.tensor(miss, dtype=torch.long, device=self.dev)

@@ -31,6 +31,48 @@ void g6d_allow_lds(const void* func, int bytes) {
   if (done.insert({func, dev}).second) (void)hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
+// ---- launch-policy knobs (g6d_common.h): name, product default
+namespace {
+struct KnobDef { const char* name; double def; };
+const KnobDef kKnobs[G6D_KNOB_COUNT] = {
+    {"conv_patch", 1},        // conv family: eligible layers on conv_patch_kernel (0: conv_igemm only)
+    {"tile_policy", 1},       // conv_igemm: 64x64 / 128x64 tile choice by block count (0: fixed 128-row tiles)
+    {"split_target", 512},    // conv_igemm: blocks a split launch aims for
+    {"patch_pipe", 1},        // conv_patch: pipelined variant (0: the round-2 loop)
+    {"corr_slots", 512},      // corr_patch: resident blocks assumed by the split model (two 58 KB blocks per CU)
+    {"sel_rowq", -1},         // selector_levels: query rows in registers: -1 batches only, 0 never, 1 always
+    {"conv1_mfma", 1},        // first trunk layer on the matrix cores (0: vector-pipe kernel)
+    {"w43_split_max", 32}, {"w43_split_gain", 0.85}, {"w43_chunk_us", 2.8},      // F(4x4,3x3) split model
+    {"wino_debug", 0},        // 1: print the chosen split of every Winograd launch to stderr
+    {"conv_wino43", 1},       // conv family: layers that carry weight_wino43 on the F(4x4,3x3) kernel
+    {"wino_wide", 1},         // F(2x2,3x3) trunk: 128-channel blocks where the model says so (0 never, 2 whenever eligible)
+    {"wino_split_max", 32}, {"wino_split_gain", 0.85}, {"wino_split_fix", 2.0}, {"wino_split_per", 0.6},    // F(2x2,3x3) split model
+    {"wino16_2w", 1},         // 16-bit trunk: un-split launches on the two-waves-per-SIMD kernel (0: one-wave kernel only)
+    {"conv_wino", 1},         // conv family: eligible layers on the F(2x2,3x3) kernel
+    {"conv_wino16", 1},       // ... and on its 16-bit variant in the reduced-precision mode
+    {"wino_min_work", -1},    // Winograd profitability rule: -1 = built-in thresholds, 0 = off, > 0 = minimum M*K*Cout
+};
+double g_knob[G6D_KNOB_COUNT];
+bool g_knob_init = false;
+void knob_init() {
+  if (!g_knob_init) { for (int i = 0; i < G6D_KNOB_COUNT; ++i) g_knob[i] = kKnobs[i].def; g_knob_init = true; }
+}
+}  // namespace
+double g6d_knob(int id) { knob_init(); return g_knob[id]; }
+extern "C" int g6d_set_knob(const char* name, double value) {
+  knob_init();
+  for (int i = 0; name && i < G6D_KNOB_COUNT; ++i)
+    if (!strcmp(name, kKnobs[i].name)) { g_knob[i] = value; return G6D_OK; }
+  g6d_set_error("set_knob: unknown knob"); return G6D_EINVAL;
+}
+extern "C" double g6d_get_knob(const char* name) {
+  knob_init();
+  for (int i = 0; name && i < G6D_KNOB_COUNT; ++i)
+    if (!strcmp(name, kKnobs[i].name)) return g_knob[i];
+  return -1e300;
+}
+extern "C" void g6d_reset_knobs(void) { g_knob_init = false; knob_init(); }
+
 extern "C" int g6d_abi_version(void) { return 9; }
 extern "C" const char* g6d_last_error(void) { return g_err; }
 extern "C" int g6d_sizeof_conv_desc(void) { return (int)sizeof(G6dConv); }

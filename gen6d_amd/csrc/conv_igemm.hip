@@ -486,7 +486,7 @@ extern "C" int g6d_conv_plan(const G6dConv* desc) {
   if (!desc) return G6D_EINVAL;
   if (g6d_wino43_eligible(*desc)) return 3;
   if (g6d_wino_eligible(*desc)) return 2;
-  static const bool use_patch = []() { const char* e = getenv("G6D_CONV_PATCH"); return !(e && e[0] == '0'); }();
+  const bool use_patch = g6d_knob(G6D_KNOB_CONV_PATCH) != 0;
   return (use_patch && g6d_conv_patch_eligible(*desc)) ? 1 : 0;
 }
 
@@ -525,7 +525,7 @@ extern "C" int g6d_conv_igemm(const G6dConv* desc, g6d_stream_t stream_) {
   const int M = (int)Mll;
   if (g6d_wino43_eligible(d)) return g6d_wino43_launch(d, stream);
   if (g6d_wino_eligible(d)) return g6d_wino_launch(d, stream);
-  static const bool use_patch = []() { const char* e = getenv("G6D_CONV_PATCH"); return !(e && e[0] == '0'); }();
+  const bool use_patch = g6d_knob(G6D_KNOB_CONV_PATCH) != 0;
   if (use_patch && g6d_conv_patch_eligible(d)) return g6d_conv_patch_launch(d, M, stream);
   const int T = d.kd * d.kh * d.kw;
   const int nChunks = (d.Cin + BK - 1) / BK;
@@ -539,7 +539,7 @@ extern "C" int g6d_conv_igemm(const G6dConv* desc, g6d_stream_t stream_) {
   //  * if 64x64 tiles give >= 256 blocks on their own, take them and skip split-K and its reduce launch altogether;
   //  * mid-size M (>= 2048 rows): 64x64 tiles need 4x fewer splits, i.e. 4x less partial-sum traffic;
   //  * small M (<= 1024 rows) with wide N: 128x64 tiles halve the split count at the same block count.
-  static const bool tile_policy = []() { const char* e = getenv("G6D_TILE_POLICY"); return !(e && e[0] == '0'); }();
+  const bool tile_policy = g6d_knob(G6D_KNOB_TILE_POLICY) != 0;
   bool no_split = false;
   if (tile_policy && d.Cout > 32 && bm == 128 && d.split_k <= 0) {
     const long long blocks128 = (long long)((M + 127) / 128) * ((d.Cout + bn - 1) / bn);
@@ -555,7 +555,7 @@ extern "C" int g6d_conv_igemm(const G6dConv* desc, g6d_stream_t stream_) {
   int splits = d.split_k;
   if (splits <= 0) {
     splits = 1;
-    static const int split_target = []() { const char* e = getenv("G6D_SPLIT_TARGET"); return e ? atoi(e) : 512; }();
+    const int split_target = (int)g6d_knob(G6D_KNOB_SPLIT_TARGET);
     if (blocks < (split_target < 256 ? split_target : 256) && total >= 8 && !no_split) {
       splits = (int)((split_target + blocks - 1) / blocks);
       if (splits > total / 4) splits = total / 4;

@@ -357,7 +357,7 @@ int launch_patch(const G6dConv& d, int M, hipStream_t stream) {
   const int cps = (total_chunks + splits - 1) / splits;
   splits = (total_chunks + cps - 1) / cps;
   const size_t lds_bytes = (size_t)(NPOS * LDS_K + 2 * BN * LDS_K) * sizeof(float);
-  static const bool pipe = []() { const char* e = getenv("G6D_PATCH_PIPE"); return !(e && e[0] == '0'); }();
+  const bool pipe = g6d_knob(G6D_KNOB_PATCH_PIPE) != 0;
   const int var = d.math_mode == 1 ? 2 : d.math_mode == 2 ? 3 : (pipe ? 0 : 1);
   auto go = [&](auto V) {
     constexpr int VAR = decltype(V)::value;

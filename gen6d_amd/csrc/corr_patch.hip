@@ -414,7 +414,7 @@ int corr_run(const float* in_base, float* out_base, CorrArgs& sa, int Cin, const
     if (max_s > 64) max_s = 64;
     if ((size_t)max_s > room / per) max_s = (int)(room / per);
     if (max_s < 1 || tiles > G6D_WS_COUNTERS) max_s = 1;
-    static const int slots2 = []() { const char* e = getenv("G6D_CORR_SLOTS"); return e ? atoi(e) : 512; }();   // two 58 KB blocks per CU
+    const int slots2 = (int)g6d_knob(G6D_KNOB_CORR_SLOTS);   // two 58 KB blocks per CU
     const int slots = w16 ? 256 : slots2;                  // (the 16-bit kernel's block holds 100+ KB of LDS: one per CU)
     double best = -1.0;
     for (int sp = 1; sp <= max_s; ++sp) {

@@ -53,6 +53,17 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// Launch-policy knobs (common.hip): every dispatch decision that used to hide behind an environment variable is a named knob with the
+// product default; tools/ and tests set them through the C ABI (g6d_set_knob / g6d_reset_knobs, include/gen6d_hip.h) to force a kernel
+// variant or to sweep a model constant.  The library itself reads no environment variable.
+enum G6dKnob {
+  G6D_KNOB_CONV_PATCH, G6D_KNOB_TILE_POLICY, G6D_KNOB_SPLIT_TARGET, G6D_KNOB_PATCH_PIPE, G6D_KNOB_CORR_SLOTS, G6D_KNOB_SEL_ROWQ,
+  G6D_KNOB_CONV1_MFMA, G6D_KNOB_W43_SPLIT_MAX, G6D_KNOB_W43_SPLIT_GAIN, G6D_KNOB_W43_CHUNK_US, G6D_KNOB_WINO_DEBUG, G6D_KNOB_CONV_WINO43,
+  G6D_KNOB_WINO_WIDE, G6D_KNOB_WINO_SPLIT_MAX, G6D_KNOB_WINO_SPLIT_GAIN, G6D_KNOB_WINO_SPLIT_FIX, G6D_KNOB_WINO_SPLIT_PER, G6D_KNOB_WINO16_2W,
+  G6D_KNOB_CONV_WINO, G6D_KNOB_CONV_WINO16, G6D_KNOB_WINO_MIN_WORK, G6D_KNOB_COUNT
+};
+double g6d_knob(int id);
+
 // Split launches (a tile's reduction spread over gridDim.z blocks) finish inside the kernel: every block writes its partial
 // tile to the workspace, takes a ticket from the tile's counter, and the block that arrives last adds all partials (in
 // split order, so the sum does not depend on which block that was) and runs the layer's epilogue.  No second kernel, and the

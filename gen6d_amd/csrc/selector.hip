@@ -289,8 +289,8 @@ extern "C" int g6d_selector_levels(int nlev, int qn, const float* const* que, co
     a.lv[l] = SelLevel{que[l], refs[l], r1[l], r2[l], score_maps[l], HW[l], parts, blk, 0};
     blk += D * parts;
   }
-  // query rows in registers (ROWQ) for batches with C == 512 (G6D_SEL_ROWQ=0: never, =1: also for a single query; A/B aid)
-  static const int rowq_env = []() { const char* e = getenv("G6D_SEL_ROWQ"); return e ? atoi(e) : -1; }();
+  // query rows in registers (ROWQ) for batches with C == 512 (knob sel_rowq = 0: never, 1: also for a single query)
+  const int rowq_env = (int)g6d_knob(G6D_KNOB_SEL_ROWQ);
   const bool rowq = C == 512 && (rowq_env < 0 ? qn > 1 : rowq_env == 1 || (rowq_env != 0 && qn > 1));
   if (rowq) {
     // hypotheses per unit: all units are equal-sized, so the launch takes ceil(blocks / resident blocks) rounds of `dc` rows — pick the

@@ -213,8 +213,8 @@ int conv1_launch(const float* in, int N, int H, int W, const float* w_oihw, cons
     for (int c = 0; c < C1_CIN; ++c) { nm.mean[c] = mean[c]; nm.std[c] = stdv[c]; }
     nm.on = 1;
   }
-  // channels-last results take the matrix-core kernel (G6D_CONV1_MFMA=0: the vector-pipe kernel, A/B aid)
-  static const bool use_mfma = []() { const char* e = getenv("G6D_CONV1_MFMA"); return !(e && e[0] == '0'); }();
+  // channels-last results take the matrix-core kernel (knob conv1_mfma = 0: the vector-pipe kernel)
+  const bool use_mfma = g6d_knob(G6D_KNOB_CONV1_MFMA) != 0;
   if (nhwc && use_mfma) {
     hipLaunchKernelGGL(vgg_conv1_pool_mfma_kernel, dim3((Wo + M1_PTX - 1) / M1_PTX, (Ho + M1_PTY - 1) / M1_PTY, N), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), in, w_oihw, bias, H, W, Ho, Wo, out, nm);

@@ -627,9 +627,9 @@ int w43_run(W43Args& a, int mode, int kd, float* workspace, size_t workspace_byt
   const int nchunks = kd * (a.Cin / 8);
   int splits = 1;
   const long long grid2 = blocks * (a.Cout / (16 * nt));
-  static const int split_max = []() { const char* e = getenv("G6D_W43_SPLIT_MAX"); return e ? atoi(e) : 32; }();
-  static const double m_gain = []() { const char* e = getenv("G6D_W43_SPLIT_GAIN"); return e ? atof(e) : 0.85; }();
-  static const double m_chunk4 = []() { const char* e = getenv("G6D_W43_CHUNK_US"); return e ? atof(e) : 2.8; }();
+  const int split_max = (int)g6d_knob(G6D_KNOB_W43_SPLIT_MAX);
+  const double m_gain = g6d_knob(G6D_KNOB_W43_SPLIT_GAIN);
+  const double m_chunk4 = g6d_knob(G6D_KNOB_W43_CHUNK_US);
   const size_t room = workspace && workspace_bytes > G6D_WS_COUNTER_BYTES ? workspace_bytes - G6D_WS_COUNTER_BYTES : 0;
   const double tile_bytes = (double)grid2 * 256 * nt * 32 * sizeof(float);
   if (room > 0 && grid2 <= G6D_WS_COUNTERS && split_max > 1 && nchunks >= 4) {
@@ -648,7 +648,7 @@ int w43_run(W43Args& a, int mode, int kd, float* workspace, size_t workspace_byt
   const int cps = (nchunks + splits - 1) / splits;
   splits = (nchunks + cps - 1) / cps;
   a.splits = splits; a.chunks_per_split = cps; a.ws = workspace;
-  static const bool debug = []() { const char* e = getenv("G6D_WINO_DEBUG"); return e && e[0] == '1'; }();
+  const bool debug = g6d_knob(G6D_KNOB_WINO_DEBUG) == 1;
   if (debug) fprintf(stderr, "wino43 %d seg, %dx%dx%d->%d kd=%d mode=%d: grid %lld x %d splits of %d chunks\n", a.nseg, a.seg[0].H, a.seg[0].W, a.Cin,
                      a.Cout, kd, mode, grid2, splits, cps);
   if (kd == 25) return nt == 4 ? w43_launch_t<0, 25, 4>(a, blocks, stream) : w43_launch_t<0, 25, 2>(a, blocks, stream);
@@ -734,7 +734,7 @@ extern "C" int g6d_corr2d_wino43_multi(const G6dCorrSeg* segs, int nseg, int Cin
 // ---- the conv family on the F(4x4,3x3) kernel (called by g6d_conv_igemm when G6dConv.weight_wino43 is set): kernel (1,3,3) on 2-D maps
 // or (3,3,3), stride 1, "same" padding, Cin % 8 == 0, Cout % 64 == 0, fp32, no multiplier prologue, no LeakyReLU
 bool g6d_wino43_eligible(const G6dConv& d) {
-  static const bool on = []() { const char* e = getenv("G6D_CONV_WINO43"); return !(e && e[0] == '0'); }();
+  const bool on = g6d_knob(G6D_KNOB_CONV_WINO43) != 0;
   if (!on || !d.weight_wino43 || d.math_mode != 0 || d.mul || d.in_image_mod > 0 || d.mul_group_images > 0) return false;
   const bool k2 = d.kd == 1 && d.Di == 1 && d.pd == 0, k3 = d.kd == 3 && d.pd == 1;
   if (!(k2 || k3) || d.kh != 3 || d.kw != 3 || d.ph != 1 || d.pw != 1 || d.sd != 1 || d.sh != 1 || d.sw != 1) return false;

@@ -1219,8 +1219,8 @@ int wino_run(WinoArgs& a, int mode, int kd, float* workspace, size_t workspace_b
   a.QH = a.seg[0].QH; a.QW = a.seg[0].QW;
   // Block shape: four quarters x 64 (32) channels, or — trunk layers with Cout % 128 == 0 — two quarters x 128 channels: the same four
   // waves and accumulators, half the raw patch and twice the filter tile per chunk, and the layer's input is re-read Cout / 128 times
-  const char* we = getenv("G6D_WINO_WIDE");                // read per call (tests force both shapes): 0 = never, 2 = whenever eligible
-  const bool wide_on = !(we && we[0] == '0'), wide_all = we && we[0] == '2';
+  const int we = (int)g6d_knob(G6D_KNOB_WINO_WIDE);         // (tests force both shapes): 0 = never, 2 = whenever eligible
+  const bool wide_on = we != 0, wide_all = we == 2;
   // (measured per layer, tools/wino_split_probe.py and BATCH=8 tools/layer_table.py with G6D_WINO_WIDE=0/1: -1.5 ... -6 % where the input is
   // large against the filter bank — the detector's pyramid, the first layers of the crops' trunks; +1 ... 2 % where the doubled filter
   // stream per block dominates: 16x16 and 8x8 maps of a few crops)
@@ -1243,10 +1243,10 @@ int wino_run(WinoArgs& a, int mode, int kd, float* workspace, size_t workspace_b
   int splits = 1;
   const long long grid2 = blocks * (a.Cout / (32 * nwn));
   const int slots = 256 * (nwn == 1 ? 2 : 1);
-  static const int split_max = []() { const char* e = getenv("G6D_WINO_SPLIT_MAX"); return e ? atoi(e) : 32; }();
-  static const double m_gain = []() { const char* e = getenv("G6D_WINO_SPLIT_GAIN"); return e ? atof(e) : 0.85; }();
-  static const double m_fix = []() { const char* e = getenv("G6D_WINO_SPLIT_FIX"); return e ? atof(e) : 2.0; }();
-  static const double m_per = []() { const char* e = getenv("G6D_WINO_SPLIT_PER"); return e ? atof(e) : 0.6; }();
+  const int split_max = (int)g6d_knob(G6D_KNOB_WINO_SPLIT_MAX);
+  const double m_gain = g6d_knob(G6D_KNOB_WINO_SPLIT_GAIN);
+  const double m_fix = g6d_knob(G6D_KNOB_WINO_SPLIT_FIX);
+  const double m_per = g6d_knob(G6D_KNOB_WINO_SPLIT_PER);
   const size_t room = workspace && workspace_bytes > G6D_WS_COUNTER_BYTES ? workspace_bytes - G6D_WS_COUNTER_BYTES : 0;
   const double tile_bytes = (double)grid2 * (wide ? 256 : 128 * nwn) * 64 * sizeof(float);     // one partial image, padded to whole tiles
   if (room > 0 && grid2 <= G6D_WS_COUNTERS && split_max > 1 && nchunks >= 4) {
@@ -1265,7 +1265,7 @@ int wino_run(WinoArgs& a, int mode, int kd, float* workspace, size_t workspace_b
   const int cps = (nchunks + splits - 1) / splits;
   splits = (nchunks + cps - 1) / cps;
   a.splits = splits; a.chunks_per_split = cps; a.ws = workspace;
-  static const bool debug = []() { const char* e = getenv("G6D_WINO_DEBUG"); return e && e[0] == '1'; }();
+  const bool debug = g6d_knob(G6D_KNOB_WINO_DEBUG) == 1;
   if (debug) fprintf(stderr, "wino %d seg, N=%d %dx%dx%d->%d kd=%d mode=%d: grid %lld x %d splits of %d chunks\n", a.nseg, a.N, a.H, a.W, a.Cin,
                      a.Cout, kd, mode, grid2, splits, cps);
   if (a.mm) {                                   // 16-bit kernels: the trunk one (MODE 0, 2-D, buffer loads) or the conv-family one
@@ -1286,8 +1286,8 @@ int wino_run(WinoArgs& a, int mode, int kd, float* workspace, size_t workspace_b
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
     using I3 = std::integral_constant<int, 3>;
     auto by_mm = [&](auto M, auto K) { if (a.mm == 1) go_conv(I1{}, M, K); else go_conv(I2{}, M, K); };
-    const char* e2 = getenv("G6D_WINO16_2W");        // (read per call: tests run both kernels) 0 = the one-wave-per-SIMD kernel only
-    const bool two_waves = !(e2 && e2[0] == '0') && mode == 0 && kd == 1 && !a.stats && a.splits == 1;
+    // knob wino16_2w (tests run both kernels): 0 = the one-wave-per-SIMD kernel only
+    const bool two_waves = g6d_knob(G6D_KNOB_WINO16_2W) != 0 && mode == 0 && kd == 1 && !a.stats && a.splits == 1;
     auto go_trunk2 = [&](auto V) {
       constexpr int MM = decltype(V)::value;
       const size_t lds2 = (size_t)(2 * WRAW_FLOATS + 4 * 16 * 64 * 8 + 256) * sizeof(float);
@@ -1416,7 +1416,8 @@ extern "C" int g6d_wino16_conv3x3_multi(const G6dWinoSeg* segs, int nseg, int Ci
 // The detector's 15x15 reference-as-filter correlation (network/detector.py:222-224) on the Winograd kernel: 5x5 blocks of 3x3
 // sub-filters accumulated in the transform domain (KD = 25 above) — 2.25x fewer multiplications than the direct form of
 // g6d_corr2d_patch.  Maps as in g6d_corr2d_patch_multi (up to 4 sizes, N maps each); U = the 25 sub-filter banks transformed like
-// g6d_wino_conv3x3's, block-major: [25 * Cin/8][16][Cout][8], block b = 5 bi + bj holding w[:, 3bi..3bi+2, 3bj..3bj+2, :].
+// g6d_wino_conv3x3's, CHUNK-major: [Cin/8 * 25][16][Cout][8], row c * 25 + b = 8-channel chunk c of block b = 5 bi + bj, which holds
+// w[:, 3bi..3bi+2, 3bj..3bj+2, 8c..8c+7] (include/gen6d_hip.h, backbone.winograd_corr_filters; the kernel walks kd = chunk % 25 innermost).
 extern "C" int g6d_corr2d_wino_multi(const G6dCorrSeg* segs, int nseg, int Cin, const float* U, int Cout, int kblocks, float* workspace,
                                      size_t workspace_bytes, g6d_stream_t stream) {
   if (!segs || nseg < 1 || nseg > WINO_MAX_SEG || !U || kblocks != 5 || Cin <= 0 || (Cin & 7) || Cout <= 0 || (Cout & 31) || !g6d_aligned16(U)) {
@@ -1452,8 +1453,7 @@ extern "C" int g6d_corr2d_wino_multi(const G6dCorrSeg* segs, int nseg, int Cin, 
 // 6x6 (4x4 maps would fill a quarter of an 8x8 output quarter: the direct kernels are better there), fp32 math, no LeakyReLU,
 // statistics groups = whole images or one group, no forced split.
 bool g6d_wino_eligible(const G6dConv& d) {
-  static const bool on = []() { const char* e = getenv("G6D_CONV_WINO"); return !(e && e[0] == '0'); }();
-  static const bool on16 = []() { const char* e = getenv("G6D_CONV_WINO16"); return !(e && e[0] == '0'); }();
+  const bool on = g6d_knob(G6D_KNOB_CONV_WINO) != 0, on16 = g6d_knob(G6D_KNOB_CONV_WINO16) != 0;
   if (!on) return false;
   if (d.math_mode != 0) {     // 16-bit kernel: host-rounded 16-bit filters, chunks of 16 channels, 64-channel blocks
     if (!on16 || !d.weight_wino16 || (d.Cin & 15) || (d.Cout & 63) || !g6d_aligned16(d.weight_wino16)) return false;
@@ -1470,11 +1470,11 @@ bool g6d_wino_eligible(const G6dConv& d) {
   // Profitability (measured per layer, profiles/r02_layer_table.md): a block pays ~4 us of prologue / output transform and the
   // kernel holds a whole SIMD per wave, so layers with a short reduction (K = kd*Cin < 128: 64-channel inputs) or little total work
   // (M * K * Cout < 1.5e8: the 7-image 8x8 / 16x16 feature-net layers, the 8^3 volume layer) stay on the direct kernels.
-  // (G6D_WINO_MIN_WORK is read per call so that tests can send small shapes down this path; 0 disables the rule.)
-  const char* mw = getenv("G6D_WINO_MIN_WORK");
+  // (knob wino_min_work: tests send small shapes down this path with 0, which disables the rule; -1 = the built-in thresholds.)
+  const double mw = g6d_knob(G6D_KNOB_WINO_MIN_WORK);
   // The 16-bit kernel competes with direct kernels that already run 16-bit MFMAs at twice the fp32 rate while its own transforms
   // stay fp32 work: measured per layer (profiles/r03_layer_table_fp16.md) it wins from K >= 192 and ~9e8 multiply-adds upwards.
-  const double min_work = mw ? atof(mw) : (d.math_mode ? 9e8 : 1.5e8);
+  const double min_work = mw >= 0 ? mw : (d.math_mode ? 9e8 : 1.5e8);
   const double M = (double)d.N * d.Di * d.Hi * d.Wi, K = (double)d.kd * d.Cin;
   if (min_work > 0 && (K < (d.math_mode ? 192 : 128) || M * K * d.Cout < min_work)) return false;
   if ((long long)d.N * d.Di * ((d.Hi + 7) / 8) * ((d.Wi + 7) / 8) >= (1ll << 31)) return false;           // quarter list

@@ -147,15 +147,18 @@ def run_queries(estimator, que_database, que_ids, lanes=3, prefetch=6, decode_th
         return t, torch.from_numpy(np.ascontiguousarray(que_database.get_K(i), dtype=np.float32))
 
     poses, inters = [None] * len(que_ids), [None] * len(que_ids)
+    if len(que_ids) == 0:
+        return np.zeros((0, 3, 4), np.float32), 0.0, []
     with ThreadPoolExecutor(decode_threads) as pool:
-        futs = [pool.submit(fetch, i) for i in que_ids[:prefetch]]
-        # graph capture (once per image size / lane configuration) is set-up, not streaming time: done before the clock starts
-        shape0 = tuple(futs[0].result()[0].shape)
+        # graph capture (once per image size / lane configuration) is set-up, not streaming time: done on the first image's shape
+        # BEFORE the clock starts and before any other decode is submitted, so that the reported rate includes every decode
+        shape0 = tuple(fetch(que_ids[0])[0].shape)
         if (chain._lanes is None or len(chain._lanes) != lanes or getattr(chain, "_batch", 1) != batch or
                 tuple(chain._lanes[0][2].shape[1:]) != shape0):
             chain.capture(shape0, lanes, batch=batch)
         torch.cuda.synchronize(dev) if dev.type == "cuda" else None
         t0 = time.perf_counter()
+        futs = [pool.submit(fetch, i) for i in que_ids[:prefetch]]
         busy = [None] * lanes                                               # (event, rows, first query index, count)
 
         def finish(slot):
@@ -180,6 +183,8 @@ def run_queries(estimator, que_database, que_ids, lanes=3, prefetch=6, decode_th
                     futs.append(pool.submit(fetch, que_ids[qi + prefetch]))
                 imgs.append(img); Ks.append(K)
             shape = tuple(imgs[0].shape)
+            if any(tuple(im.shape) != shape for im in imgs):
+                raise ValueError("run_queries: the images of one launch batch must share one size (use batch=1 for mixed-size query sets)")
             if (chain._lanes is None or len(chain._lanes) != lanes or getattr(chain, "_batch", 1) != batch or
                     tuple(chain._lanes[0][2].shape[1:]) != shape):
                 chain.capture(shape, lanes, batch=batch)

@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("G6D_LIB_PATH") or os.path.join(_HERE, "libgen6d_hip.so")   # env override: profiling builds
+LIB_PATH = os.path.join(_HERE, "libgen6d_hip.so")      # (tools/ load profiling builds by assigning lib.LIB_PATH before the first call)
 
 G6D_ERRORS = {-1: "G6D_EINVAL", -2: "G6D_ENOSPC", -3: "G6D_ELAUNCH"}
 
@@ -111,8 +111,24 @@ def load():
     if lib.g6d_sizeof_conv_desc() != C.sizeof(G6dConv):
         raise RuntimeError("libgen6d_hip.so: G6dConv layout differs from the ctypes binding (stale build?)")
     lib.g6d_last_error.restype = C.c_char_p
+    lib.g6d_set_knob.argtypes, lib.g6d_set_knob.restype = [C.c_char_p, C.c_double], C.c_int
+    lib.g6d_get_knob.argtypes, lib.g6d_get_knob.restype = [C.c_char_p], C.c_double
+    lib.g6d_reset_knobs.argtypes, lib.g6d_reset_knobs.restype = [], None
     _lib = lib
     return lib
+
+
+def set_knob(name, value):
+    """Launch-policy knob of the library (include/gen6d_hip.h): tools/ and tests force kernel variants / sweep model constants with it."""
+    check(load().g6d_set_knob(name.encode(), float(value)), f"g6d_set_knob({name})")
+
+
+def get_knob(name):
+    return load().g6d_get_knob(name.encode())
+
+
+def reset_knobs():
+    load().g6d_reset_knobs()
 
 
 def check(rc, what):

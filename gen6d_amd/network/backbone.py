@@ -2,26 +2,13 @@
 including its quirk that the 1/16 output is the BatchNorm output of conv 25 WITHOUT the final ReLU
 (reference network/pretrain_models.py:17-25,66-72,109-111).
 
-Two implementations of the same function:
-  * `vgg_taps_cl` (default): the own trunk — g6d_vgg_conv1_pool_nhwc for the 3->64 layer and g6d_wino_conv3x3 (Winograd
-    F(2x2,3x3) on fp32 MFMA, bias + ReLU + 2x2 max-pool fused) for the other seven, channels-last end to end, so the
-    features reach the correlation / similarity / volume kernels without any layout pass;
-  * `vgg_taps` (G6D_OWN_TRUNK=0): PyTorch-ROCm / MIOpen convolutions on NCHW, which BASELINE.json's north_star allows
-    for the backbones; kept for A/B measurements."""
-import os
-
+`vgg_taps_cl` / `vgg_taps_cl_multi`: g6d_vgg_conv1_pool_nhwc for the 3->64 layer and the Winograd kernels (F(2x2,3x3), or F(4x4,3x3)
+for the detector's pyramid, on fp32 MFMA; bias + ReLU + 2x2 max-pool fused) for the other seven, channels-last end to end, so the
+features reach the correlation / similarity / volume kernels without any layout pass.  (The PyTorch-ROCm / MIOpen trunk that rounds
+1-2 kept beside it for A/B measurements lives in tools/library_trunk.py.)"""
 import torch
-import torch.nn.functional as F
 
 from .. import ops, specs
-
-# The 3 -> 64 layer in front of the first pool runs on the fused HIP kernel g6d_vgg_conv1_pool (G6D_OWN_CONV1=0: MIOpen).
-_OWN_CONV1 = os.environ.get("G6D_OWN_CONV1", "1") != "0"
-
-if os.environ.get("G6D_MIOPEN_FIND", "0") == "1":
-    torch.backends.cudnn.benchmark = True        # MIOpen Find (measured solver choice) instead of the immediate-mode heuristic
-
-_OWN_TRUNK = os.environ.get("G6D_OWN_TRUNK", "1") != "0"
 
 _POOL_BEFORE = (1, 2, 4, 6)          # positions (in the list of 8 convs) preceded by a 2x2 max-pool
 
@@ -178,8 +165,7 @@ class TrunkLayer(tuple):
 
 
 _LOWP_DTYPE = {1: torch.bfloat16, 2: torch.float16}
-# G6D_LOWP_TRUNK=0: in the reduced-precision mode the trunk stays on the fp32 Winograd kernel (rounds 1-2); default: 16-bit kernel
-_LOWP_TRUNK = os.environ.get("G6D_LOWP_TRUNK", "1") != "0"
+LOWP_TRUNK = True        # reduced-precision mode: trunk on the 16-bit Winograd kernel (False, set by tools / tests: stays on the fp32 kernel)
 
 
 def _wino_layer(xs, layer, relu=True, full=True, pool=False, f43=False):
@@ -187,7 +173,7 @@ def _wino_layer(xs, layer, relu=True, full=True, pool=False, f43=False):
     F(4x4,3x3) kernel (1.78x fewer multiplications at ~5x the rounding error: the detector's pyramid, whose parity budget has the
     room) — or (ops.MATH_MODE 1 / 2, Cin % 16 == 0) the 16-bit one."""
     mm = ops.MATH_MODE
-    if mm and _LOWP_TRUNK and hasattr(layer, "u16") and xs[0].shape[3] % 16 == 0:
+    if mm and LOWP_TRUNK and hasattr(layer, "u16") and xs[0].shape[3] % 16 == 0:
         return ops.wino16_conv3x3_multi(xs, layer.u16(_LOWP_DTYPE[mm]), layer[1], relu=relu, full=full, pool=pool)
     if f43 and not mm and layer[1].numel() % 64 == 0:
         return ops.wino43_conv3x3_multi(xs, layer.u43(), layer[1], relu=relu, full=full, pool=pool)
@@ -195,9 +181,7 @@ def _wino_layer(xs, layer, relu=True, full=True, pool=False, f43=False):
 
 
 def pack_trunk(folded):
-    """fold_vgg(...) output -> what the active trunk implementation consumes."""
-    if not _OWN_TRUNK:
-        return folded
+    """fold_vgg(...) output -> what the trunk consumes: the first layer's (w, b) and a TrunkLayer per Winograd layer."""
     return [folded[0]] + [TrunkLayer(winograd_filters(w), b, w) for w, b in folded[1:]]
 
 
@@ -208,7 +192,7 @@ def vgg_taps_cl(packed, x, taps, norm=None):
     """Own trunk, channels-last: x [n,3,h,w] normalised image (or an image in [0,1] with norm = (mean, std): the first layer
     normalises while it stages its input) -> {'c3': [n,h/4,w/4,256] post-ReLU, 'c5': [n,h/8,w/8,512] post-ReLU,
     'c7_pre': [n,h/16,w/16,512] pre-ReLU, 'p7': max-pool of c7_pre} (only the requested taps + c7_pre)."""
-    if ops.MATH_MODE and _LOWP_TRUNK:
+    if ops.MATH_MODE and LOWP_TRUNK:
         return vgg_taps_cl_multi(packed, [x], taps, norm=norm)[0]               # reduced precision: the multi-segment 16-bit kernel
     w0, b0 = packed[0]
     x = ops.vgg_conv1_pool_nhwc(x.contiguous(), w0, b0, norm=norm)              # (normalise +) conv0 + ReLU + pool
@@ -248,8 +232,8 @@ def vgg_taps_cl_multi(packed, xs, taps, norm=None, f43=False):
 
 def trunk_features_multi(packed, imgs_list, keys, f43=False):
     """trunk_features (no L2 normalisation) for a list of [1,3,h_i,w_i] images of different sizes -> list of lists of
-    [1,1,h_l,w_l,C] maps.  One launch per layer for all sizes on the own trunk; the library trunk runs them one by one."""
-    if not _OWN_TRUNK or len(imgs_list) > 4:
+    [1,1,h_l,w_l,C] maps.  One launch per layer for all sizes (up to 4 per launch)."""
+    if len(imgs_list) > 4:
         return [trunk_features(packed, im, keys, False) for im in imgs_list]
     taps = vgg_taps_cl_multi(packed, imgs_list, set(keys), norm=_IMG_NORM, f43=f43)
     return [[t[k].unsqueeze(1) for k in keys] for t in taps]
@@ -258,58 +242,11 @@ def trunk_features_multi(packed, imgs_list, keys, f43=False):
 def trunk_features(packed, imgs, keys, l2norm):
     """Normalised images [n,3,h,w] in [0,1] -> channels-last 5-D feature maps [n,1,h_l,w_l,C] for `keys`, optionally
     L2-normalised over C (F.normalize, reference selector.py:118 / refiner.py:69-71)."""
-    if _OWN_TRUNK:
-        t = vgg_taps_cl(packed, imgs, set(keys), norm=_IMG_NORM)
-        outs = []
-        for k in keys:
-            f = t[k]
-            if l2norm:
-                ops.l2norm_rows(f)                  # in place: a tap is never the input of a later layer
-            outs.append(f.unsqueeze(1))
-        return outs
-    t = vgg_taps(packed, img_norm(imgs), set(keys))
+    t = vgg_taps_cl(packed, imgs, set(keys), norm=_IMG_NORM)
     outs = []
     for k in keys:
-        f = t[k].contiguous()
-        n, c, h, w = f.shape
-        outs.append(ops.nchw_to_nhwc(f, torch.empty((n, 1, h, w, c), dtype=torch.float32, device=f.device), l2norm))
+        f = t[k]
+        if l2norm:
+            ops.l2norm_rows(f)                  # in place: a tap is never the input of a later layer
+        outs.append(f.unsqueeze(1))
     return outs
-
-
-_NORM = {}
-
-
-def img_norm(x):
-    """torchvision.transforms.Normalize(ImageNet) on [n,3,h,w] in [0,1]. Constants are cached per device so that the
-    call is capturable in a hipGraph (no host-to-device copy on the query path)."""
-    key = (str(x.device), x.dtype)
-    if key not in _NORM:
-        _NORM[key] = (torch.tensor(specs.IMAGENET_MEAN, dtype=x.dtype, device=x.device).view(1, 3, 1, 1),
-                      torch.tensor(specs.IMAGENET_STD, dtype=x.dtype, device=x.device).view(1, 3, 1, 1))
-    m, s = _NORM[key]
-    return (x - m) / s
-
-
-def vgg_taps(folded, x, taps):
-    """Run the folded trunk; `taps` is a set of names among
-       'c3' (256ch @1/4, post-ReLU), 'c5' (512 @1/8, post-ReLU), 'c7_pre' (512 @1/16, pre-ReLU), 'p7' (max-pool of c7_pre)."""
-    out = {}
-    for i, (w, b) in enumerate(folded):
-        if i == 0 and _OWN_CONV1 and x.shape[1] == 3 and w.shape[0] == 64 and x.shape[2] >= 2 and x.shape[3] >= 2:
-            x = ops.vgg_conv1_pool(x.contiguous(), w, b)                      # conv + bias + ReLU + pool in one kernel
-            continue
-        y = F.conv2d(x, w, None, padding=1)                                  # MIOpen; bias/ReLU/pool fused below
-        if i == 7:
-            out["c7_pre"] = ops.bias_relu_pool_nchw(y, b, False, False)       # BN output WITHOUT the last ReLU
-            if "p7" in taps:
-                out["p7"] = ops.bias_relu_pool_nchw(y, b, False, True)
-            break
-        pool_next = (i + 1) in _POOL_BEFORE
-        tap = {3: "c3", 5: "c5"}.get(i)
-        if tap in taps and pool_next:                                         # tapped feature is the un-pooled one
-            out[tap] = ops.bias_relu_pool_nchw(y, b, True, False)
-            x = ops.bias_relu_pool_nchw(y, b, True, True)
-        else:
-            x = ops.bias_relu_pool_nchw(y, b, True, pool_next)
-            if tap in taps: out[tap] = x
-    return {k: v for k, v in out.items() if k in taps or k == "c7_pre"}

@@ -1,11 +1,11 @@
 """Detector — drop-in for the reference's network/detector.py:Detector (same constructor, state_dict keys, methods and
-output dicts), driving hand-written HIP kernels for everything after the VGG trunk.
+output dicts), driving hand-written HIP kernels end to end.
 
-Per detection scale (reference detect_impl, detector.py:232-266):
-    trunk (PyTorch-ROCm)            -> x0 @1/8, x1 @1/16, x2 @1/32
-    g6d_conv_igemm x3               query features correlated with the reference feature maps used as filters
-                                    (F.conv2d(que_x, ref_x, padding=7/3/1), detector.py:222-224): implicit GEMM with
-                                    M = positions, N = rfn, K = 512*k*k on fp32 MFMA, split along K to fill the chip
+For the 4 detection scales of a batch of queries at once (reference detect_impl, detector.py:232-266):
+    own Winograd trunk              F(4x4,3x3) on fp32 MFMA, one launch per layer over the whole pyramid -> x0 @1/8, x1 @1/16, x2 @1/32
+    correlation x3                  query features correlated with the reference feature maps used as filters
+                                    (F.conv2d(que_x, ref_x, padding=7/3/1), detector.py:222-224): the 15x15 level as 5x5 blocks of 3x3
+                                    in the F(4x4,3x3) domain (g6d_corr2d_wino43_multi), 7x7 / 3x3 on g6d_corr2d_patch_multi
     g6d_detector_assemble           nearest up-sampling, (x-mu)/sigma, clip, bilinear resize to (h/8,w/8), stack
 then g6d_detector_score_mlp_max     score_conv MLP + max over references, never materialising [64,rfn,hs,ws]
      g6d_conv_igemm x7              the three 3x3 heads (first layers merged into one 64->192 conv)
@@ -16,19 +16,13 @@ import torch
 import torch.nn.functional as F
 
 from .. import ops, parallel, specs
-import os
-
 from .backbone import pack_trunk, trunk_features, trunk_features_multi, winograd_corr_filters, winograd43_corr_filters
 from .params import ParamBank, fold_vgg
 
-# G6D_TRUNK_MULTI=0: one trunk pass per pyramid scale (A/B aid); default: one launch per layer over all scales
-_TRUNK_MULTI = os.environ.get("G6D_TRUNK_MULTI", "1") != "0"
-# G6D_CORR3_MULTI=0: the 3x3 correlation level as one generic-conv launch per scale (round 2); default: one corr_patch launch over all
-# scales, like the 15x15 and 7x7 levels
-_CORR3_MULTI = os.environ.get("G6D_CORR3_MULTI", "1") != "0"
-# G6D_CORR_WINO=0: the 15x15 correlation level on the direct corr_patch kernel (round 2); default: on the Winograd kernel
-# (5x5 blocks of 3x3 sub-filters accumulated in the transform domain: 2.25x fewer multiplications) when rfn % 32 == 0 and fp32
-_CORR_WINO = os.environ.get("G6D_CORR_WINO", "1") != "0"
+# Launch-structure switches; the product runs with all of them True, tools / tests flip the attribute for A/B runs:
+TRUNK_MULTI = True       # one launch per trunk layer over all pyramid scales (False: one trunk pass per scale)
+CORR3_MULTI = True       # the 3x3 correlation level as one corr_patch launch over all scales (False: one generic conv launch per scale)
+CORR_WINO = True         # the 15x15 correlation level in the Winograd domain, 5x5 blocks of 3x3, when rfn % 32 == 0 and fp32 (False: corr_patch)
 # Winograd F(4x4,3x3) (csrc/wino43_conv.hip) for the query pyramid's trunk and the 15x15 correlation level: 1.78x fewer fp32
 # multiplications than F(2x2,3x3) at ~5x its rounding error — the detector holds ~4e-6 of the score range against the 1e-4 bar
 # (tests/test_parity_timed_gpu.py).  False: the F(2x2,3x3) kernels of round 3 (tools/ A/B runs and tests flip this attribute).
@@ -97,7 +91,7 @@ class Detector(ParamBank):
         self.ref_shape = [120, 120]
         # Winograd-domain filters of the 15x15 level (the reference views used as filters: transformed once per object)
         rfn = self.ref_center_feats[0].shape[0]
-        ok15 = _CORR_WINO and self.ref_ksize[0] == 15 and rfn % 32 == 0
+        ok15 = CORR_WINO and self.ref_ksize[0] == 15 and rfn % 32 == 0
         self.ref_wino15 = winograd_corr_filters(self.ref_center_feats[0], 15) if (ok15 and not F43) else None
         self.ref_wino15_43 = winograd43_corr_filters(self.ref_center_feats[0], 15) if (ok15 and F43) else None
 
@@ -115,10 +109,11 @@ class Detector(ParamBank):
         maps = [[None] * 3 for _ in feats]
         for l, (wref, k) in enumerate(zip(self.ref_center_feats, self.ref_ksize)):
             xs = [f[l] for f in feats]
-            # one launch over all scales addresses the maps with 32-bit offsets from a common base: maps that do not come out of one
-            # buffer (the library trunk of G6D_OWN_TRUNK=0 allocates every scale on its own) are gathered into one first
-            ptrs = [x.data_ptr() for x in xs]
-            if max(ptrs) - min(ptrs) >= (1 << 31) or not all(x.is_contiguous() for x in xs):
+            # one launch over all scales addresses the maps with 32-bit offsets from a common base (offset + extent < 2^29 floats on the
+            # Winograd routes): maps that do not come out of one buffer (a trunk that allocates every scale on its own) are gathered first
+            lo = min(x.data_ptr() for x in xs)
+            hi = max(x.data_ptr() + x.numel() * 4 for x in xs)
+            if hi - lo >= (1 << 31) or not all(x.is_contiguous() for x in xs):
                 seg = ops.alloc_like_segments([tuple(x.shape) for x in xs], dev)
                 for d_, x in zip(seg, xs):
                     d_.copy_(x)
@@ -129,7 +124,7 @@ class Detector(ParamBank):
             elif k == 15 and self.ref_wino15 is not None and ops.MATH_MODE == 0 and len(xs) <= 4:
                 outs = ops.alloc_like_segments([(qn, 1, x.shape[2], x.shape[3], rfn) for x in xs], dev)
                 ops.corr2d_wino_multi([x.contiguous() for x in xs], self.ref_wino15, outs, 5)
-            elif rfn <= 32 and len(xs) <= 4 and (k >= 7 or _CORR3_MULTI):
+            elif rfn <= 32 and len(xs) <= 4 and (k >= 7 or CORR3_MULTI):
                 outs = ops.alloc_like_segments([(qn, 1, x.shape[2], x.shape[3], rfn) for x in xs], dev)
                 ops.corr2d_patch_multi(xs, wref, outs, k)
             else:
@@ -180,7 +175,7 @@ class Detector(ParamBank):
 
         # the scales are independent until `stacked` is complete: largest first on the main stream
         order = sorted(enumerate(self.cfg["detection_scales"]), key=lambda t: -t[1])
-        if _TRUNK_MULTI and len(order) <= 4:
+        if TRUNK_MULTI and len(order) <= 4:
             # every trunk layer is ONE launch over the whole pyramid (the small scales fill the blocks the large ones leave
             # over); the correlations of the scales then run side by side
             feats = trunk_features_multi(pk["vgg"], [resized(sc) for _, sc in order], ("c5", "c7_pre", "p7"), f43=F43)

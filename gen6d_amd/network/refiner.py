@@ -1,12 +1,13 @@
 """VolumeRefiner — drop-in for the reference's network/refiner.py (same constructor, state_dict keys, forward dict).
 
 One refinement step (reference forward, refiner.py:249-269):
-    trunk (PyTorch-ROCm) on the 6 reference crops + the query crop, g6d_nchw_to_nhwc(l2norm)
+    own channels-last Winograd trunk (backbone.py) on the 6 reference crops + the query crop, g6d_l2norm_rows on its taps
     RefineFeatureNet 2-D convs on g6d_conv_igemm; every InstanceNorm2d is a per-image (sum, sumsq) epilogue of the
         producing conv and an affine(+ReLU) in the loader of the consuming conv / up-sampler      refiner.py:24-51,64-78
     g6d_refiner_volume: projection + bilinear sampling + mean/std over references, fused            refiner.py:183-247
-    RefineVolumeEncodingNet 3x3x3 convs on g6d_conv_igemm (implicit 3-D GEMM, split-K for the 8^3/4^3 layers)
-    g6d_linear_gemv: the 32768->512 FC is a 67 MB weight stream                                     refiner.py:153-166
+    RefineVolumeEncodingNet 3x3x3 convs on g6d_conv_igemm (32^3 layers: Winograd F(4x4,3x3), depth taps folded into the reduction;
+        16^3: F(2x2,3x3); 8^3/4^3 and stride-2 layers: implicit 3-D GEMM with split-K)
+    g6d_linear_gemv_batch: the 32768->512 FC is a 67 MB weight stream, read once per 8 queries                                    refiner.py:153-166
 """
 import numpy as np
 import torch
@@ -95,10 +96,14 @@ class VolumeRefiner(ParamBank):
     def cached_ref_feats(self, keys, make_imgs):
         """Features [len(keys),fh,fw,C] of the reference crops with cache keys `keys`; make_imgs(missing_positions) must return the
         crops [m,3,h,w] in [0,1] of the positions that are not cached (they go through the feature net in one batch)."""
-        got = [self.feat_cache.get(k) for k in keys]
-        miss = [i for i, f in enumerate(got) if f is None]
+        # features depend on the matrix-core operand precision they were computed in: the mode is part of the key, and misses run in
+        # the network's own mode like _step does (ADVICE r03)
+        with ops.math_mode(self.cfg.get("math_mode"), inherit_if_none=True):
+            keys = [(k, ops.MATH_MODE) for k in keys]
+            got = [self.feat_cache.get(k) for k in keys]
+            miss = [i for i, f in enumerate(got) if f is None]
+            feats = self.run_feature_net(make_imgs(miss)) if miss else None
         if miss:
-            feats = self.run_feature_net(make_imgs(miss))
             for j, i in enumerate(miss):
                 got[i] = feats[j].clone()
                 self.feat_cache.put(keys[i], got[i])

@@ -1,7 +1,7 @@
 """ViewpointSelector — drop-in for the reference's network/selector.py (same constructor, state_dict keys, methods).
 
 Query-time data flow (reference compute_view_point_feats, selector.py:177-215), D = rfn*an hypotheses, d = r*an + a:
-    trunk (PyTorch-ROCm) + g6d_nchw_to_nhwc(l2norm)       query features, 3 levels, channels-last
+    own Winograd trunk + g6d_l2norm_rows                  query features, 3 levels, channels-last
   per level l:
     g6d_selector_scan          score maps sum_c q*r and the "vps" scalars  (one coalesced pass over the ref cache)
     g6d_selector_prod_affine   InstanceNorm3d(512) statistics of the never-materialised product q*r from R1/R2

@@ -10,7 +10,6 @@ per-op PyTorch references of tests/ref_ops.py to validate host orchestration wit
 has no fallback — `lib.load()` raises if libgen6d_hip.so is absent.
 """
 import ctypes as C
-import os as _os
 
 import torch
 
@@ -133,9 +132,9 @@ def _cl5(t, name):
     return N, D, H, W, Cc, ld
 
 
-# G6D_FUSED_FINALIZE=0: InstanceNorm finalisation as a separate g6d_stats_finalize launch after the producing conv (A/B aid);
-# default: the conv's last block does it (G6dConv.fin_*)
-FUSED_FINALIZE = _os.environ.get("G6D_FUSED_FINALIZE", "1") != "0"
+# InstanceNorm finalisation by the last block of the producing conv (G6dConv.fin_*).  False (set by tools / tests for A/B runs): a
+# separate g6d_stats_finalize launch after the conv
+FUSED_FINALIZE = True
 
 
 def conv(x, w, bias, out, ksize=(1, 1, 1), stride=(1, 1, 1), pad=(0, 0, 0), mul=None, in_scale=None, in_shift=None,
@@ -243,8 +242,9 @@ def corr2d_patch(x, w, out, k):
     return out
 
 
-# G6D_CORR16=0: in the reduced-precision mode the correlation stays on corr_patch_kernel with 16-bit operands (one hand-over per tap); A/B aid
-CORR16 = _os.environ.get("G6D_CORR16", "1") != "0"
+# reduced-precision mode: correlation on corr16_patch_kernel (False, set by tools / tests: corr_patch_kernel with 16-bit operands, one
+# hand-over per tap)
+CORR16 = True
 
 
 def corr_filters16(w, k, dtype):
@@ -340,6 +340,7 @@ def corr2d_wino_multi(xs, U, outs, kblocks=5):
 
 _ARENA = {}          # (device, stream) -> [buffer, bump offset]
 _CUR_ARENA = None    # arena of the query being enqueued (host-side state; set by stats_arena_begin)
+USE_ARENA = True     # False (tools / tests): one zero-fill per InstanceNorm statistics buffer instead of one arena per query
 ARENA_DOUBLES = 1 << 21      # 16 MB: a batch of 8 queries needs ~140 K accumulators in the refiner step (56 images x 1024 channels x 2), 32 queries 560 K
 
 
@@ -358,7 +359,7 @@ def stats_arena_begin(device):
 
 
 def new_stats(groups, channels, device):
-    a = None if _os.environ.get("G6D_NO_ARENA") else _CUR_ARENA
+    a = _CUR_ARENA if USE_ARENA else None
     n = groups * channels * 2
     if a is None or a[0].device != torch.device(device) or a[1] + n > ARENA_DOUBLES:
         return torch.zeros((groups, channels, 2), dtype=torch.float64, device=device)
@@ -369,7 +370,7 @@ def new_stats(groups, channels, device):
 
 def new_counter(device):
     """One zeroed int32 (an arrival counter of a launch that finalises its statistics): a slot of the query's arena."""
-    a = None if _os.environ.get("G6D_NO_ARENA") else _CUR_ARENA
+    a = _CUR_ARENA if USE_ARENA else None
     if a is None or a[0].device != torch.device(device) or a[1] + 1 > ARENA_DOUBLES:
         return torch.zeros((2,), dtype=torch.int32, device=device)
     t = a[0][a[1]:a[1] + 1].view(torch.int32)

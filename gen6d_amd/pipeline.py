@@ -94,7 +94,7 @@ class TensorPipeline:
             stream = torch.cuda.Stream(device=d)
             stream.wait_stream(torch.cuda.current_stream(d))
             with torch.cuda.stream(stream):
-                for _ in range(warmup):                  # MIOpen find, workspaces and allocator warm-up off-graph
+                for _ in range(warmup):                  # workspaces, statistics arenas and allocator warm-up off-graph
                     self.query(g_full, g_crop, cached_refs)
             torch.cuda.synchronize(d)
             graph = torch.cuda.CUDAGraph()

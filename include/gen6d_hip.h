@@ -36,6 +36,16 @@ int g6d_abi_version(void);
 /* last HIP error string of this thread ("" if none) */
 const char* g6d_last_error(void);
 
+/* Launch-policy knobs.  The library reads NO environment variable: every dispatch decision that tools/ and tests want to force (a kernel
+ * variant for an A/B run, a constant of a split model for a sweep) is a named knob with the product default — conv_patch, tile_policy,
+ * split_target, patch_pipe, corr_slots, sel_rowq, conv1_mfma, w43_split_max / _gain / w43_chunk_us, wino_debug, conv_wino43, wino_wide,
+ * wino_split_max / _gain / _fix / _per, wino16_2w, conv_wino, conv_wino16, wino_min_work (gen6d_amd/csrc/common.hip lists meanings and
+ * defaults).  Process-wide, not thread-safe against concurrent launches: set them before launching.  g6d_set_knob returns G6D_EINVAL for
+ * an unknown name; g6d_get_knob returns -1e300 for one. */
+int g6d_set_knob(const char* name, double value);
+double g6d_get_knob(const char* name);
+void g6d_reset_knobs(void);
+
 /* Profiling aid: launches the empty kernel `g6d_marker_kernel` so a kernel trace can be cut to a region of interest. */
 int g6d_marker(int id, g6d_stream_t stream);
 
@@ -193,8 +203,9 @@ int g6d_affine_act_pool(const float* in, int ld_in, const float* scale, const fl
 int g6d_upsample_bilinear(const float* in, int ld_in, const float* scale, const float* shift, int affine_per_n,
                           int N, int H, int W, int C, int factor, float* out, int ld_out, g6d_stream_t stream);
 
-/* VGG trunk glue on NCHW (the trunk's convolutions themselves run on MIOpen, reference pretrain_models.py:86-104 with
- * BatchNorm folded): out = maxpool2x2?( relu?( in + bias[c] ) ) in one pass. */
+/* VGG trunk glue for an NCHW caller (a trunk whose convolutions run elsewhere, e.g. tools/library_trunk.py's MIOpen A/B trunk; reference
+ * pretrain_models.py:86-104 with BatchNorm folded): out = maxpool2x2?( relu?( in + bias[c] ) ) in one pass.  The product trunk
+ * (g6d_vgg_conv1_pool_nhwc + g6d_wino_conv3x3* / g6d_wino43_conv3x3_multi) fuses this into its epilogues and does not call it. */
 int g6d_bias_relu_pool_nchw(const float* in, const float* bias, int N, int C, int H, int W, int relu, int pool, float* out,
                             g6d_stream_t stream);
 
@@ -222,7 +233,7 @@ int g6d_vgg_conv1_pool_nhwc_norm(const float* in, int N, int H, int W, const flo
  *   y = conv3x3_pad1(in) + bias[co];  relu != 0: y = max(y, 0)
  *   out_full (optional) [N][H][W][ld_full] = y;  out_pool (optional) [N][H/2][W/2][ld_pool] = maxpool2x2(y) (floor)
  *   workspace (optional): small maps split the channel chunks over more blocks (see "Workspace")
- * Replaces the MIOpen convolutions of the trunk and the bias/ReLU/pool and layout passes around them. */
+ * One trunk layer = one launch: convolution, bias, ReLU, 2x2 max-pool and the channels-last layout in the kernel's epilogue. */
 int g6d_wino_conv3x3(const float* in, int N, int H, int W, int Cin, int ld_in, const float* U, const float* bias, int Cout,
                      int relu, float* out_full, int ld_full, float* out_pool, int ld_pool, float* workspace,
                      size_t workspace_bytes, g6d_stream_t stream);

@@ -39,10 +39,44 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+def _apply_session_switches():
+    """A/B variants of the product path for whole test runs (tests/test_networks_gpu.py::test_alternative_paths_keep_parity starts
+    pytest with G6D_TEST_SWITCHES set): comma list of `knob:<name>=<value>` (library launch-policy knobs, include/gen6d_hip.h),
+    `attr:<module>.<NAME>=<0|1>` (launch-structure attributes of the package) and `library_trunk` (tools/library_trunk.py: the MIOpen
+    trunk).  The switches live HERE, in the test infrastructure: neither the package nor the library reads the environment."""
+    spec = os.environ.get("G6D_TEST_SWITCHES", "")
+    for item in filter(None, (t.strip() for t in spec.split(","))):
+        if item == "library_trunk":
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import library_trunk
+            library_trunk.install()
+        elif item.startswith("knob:"):
+            from gen6d_amd import lib
+            name, val = item[5:].split("=")
+            lib.set_knob(name, float(val))
+        elif item.startswith("attr:"):
+            import importlib
+            path, val = item[5:].split("=")
+            mod, attr = path.rsplit(".", 1)
+            setattr(importlib.import_module(mod), attr, bool(int(val)))
+        else:
+            raise ValueError(f"G6D_TEST_SWITCHES: cannot parse {item!r}")
+
+
 def pytest_sessionstart(session):
-    """Achieved parity errors of the GPU tests are appended to gpurun_out/parity_r03.jsonl (tools/parity_table.py turns
-    them into profiles/r03_parity.md)."""
-    os.environ.setdefault("G6D_PARITY_LOG", os.path.join(ROOT, "gpurun_out", "parity_r03.jsonl"))
+    """Achieved parity errors of the GPU tests are appended to gpurun_out/parity_r04.jsonl (tools/parity_table.py turns
+    them into profiles/r04_parity.md)."""
+    os.environ.setdefault("G6D_PARITY_LOG", os.path.join(ROOT, "gpurun_out", "parity_r04.jsonl"))
+    _apply_session_switches()
+
+
+@pytest.fixture
+def knob():
+    """knob(name, value): set a launch-policy knob of the library for the duration of one test (product defaults are restored)."""
+    from gen6d_amd import lib
+    yield lib.set_knob
+    lib.reset_knobs()
+    _apply_session_switches()
 
 
 

@@ -25,7 +25,26 @@ def test_header_symbols_exported():
         assert hasattr(l, n), f"{n} declared in gen6d_hip.h but not exported by libgen6d_hip.so"
     assert l.g6d_abi_version() == 9
     # every typed binding corresponds to a declared symbol and vice versa
-    assert set(lib.SIGNATURES) | {"g6d_abi_version", "g6d_last_error", "g6d_sizeof_conv_desc"} == set(names)
+    assert set(lib.SIGNATURES) | {"g6d_abi_version", "g6d_last_error", "g6d_sizeof_conv_desc", "g6d_set_knob", "g6d_get_knob",
+                                  "g6d_reset_knobs"} == set(names)
+
+
+def test_knobs_have_product_defaults_and_no_environment_reads():
+    """The library's launch policy is set through g6d_set_knob only: defaults as documented, unknown names rejected, reset restores, and
+    neither the library sources nor the package read A/B switches from the environment."""
+    import glob
+    assert lib.get_knob("conv_wino") == 1 and lib.get_knob("wino_min_work") == -1 and lib.get_knob("split_target") == 512
+    lib.set_knob("conv_wino", 0)
+    assert lib.get_knob("conv_wino") == 0
+    lib.reset_knobs()
+    assert lib.get_knob("conv_wino") == 1
+    with pytest.raises(RuntimeError):
+        lib.set_knob("no_such_knob", 1)
+    for f in glob.glob(os.path.join(ROOT, "gen6d_amd", "csrc", "*")):
+        assert "getenv" not in open(f, errors="ignore").read(), f
+    for f in glob.glob(os.path.join(ROOT, "gen6d_amd", "**", "*.py"), recursive=True):
+        src = open(f).read()
+        assert "G6D_" not in src.replace("G6D_ERRORS", "").replace("G6D_E", "").replace("G6D_OK", "") or f.endswith("parallel.py"), f
 
 
 def test_struct_layout_matches_header():

@@ -123,10 +123,10 @@ WINO_CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", WINO_CONV_CASES, ids=lambda c: f"{c['N']}x{c['D']}x{c['H']}_{c['Cin']}x{c['Cout']}k{c['k'][0]}")
-def test_conv_on_winograd_kernel(ops, case, monkeypatch):
-    """G6D_WINO_MIN_WORK=0 lifts the library's profitability rule (read per call) so that the small test shapes take the Winograd
-    path; the stage-level parity tests run with the production rule."""
-    monkeypatch.setenv("G6D_WINO_MIN_WORK", "0")
+def test_conv_on_winograd_kernel(ops, case, knob):
+    """Knob wino_min_work = 0 lifts the library's profitability rule so that the small test shapes take the Winograd path; the
+    stage-level parity tests run with the production rule."""
+    knob("wino_min_work", 0)
     ops.PROFILE = []
     try:
         _run_conv_case(ops, case, True)
@@ -550,11 +550,11 @@ WINO_CASES = [
 
 @pytest.mark.parametrize("shape", ["rule", "wide", "square"])      # block shape: by the launcher's rule / 2 quarters x 128 channels / 4 x 64
 @pytest.mark.parametrize("N,H,W,Cin,Cout,relu,full,pool", WINO_CASES)
-def test_wino_conv3x3(ops, N, H, W, Cin, Cout, relu, full, pool, shape, monkeypatch):
+def test_wino_conv3x3(ops, N, H, W, Cin, Cout, relu, full, pool, shape, knob):
     if shape != "rule":
         if Cout % 128:
             pytest.skip("one block shape only")
-        monkeypatch.setenv("G6D_WINO_WIDE", "2" if shape == "wide" else "0")
+        knob("wino_wide", 2 if shape == "wide" else 0)
     """g6d_wino_conv3x3 against F.conv2d (+bias, ReLU, max-pool) in float64: fp32 Winograd F(2x2,3x3) error class."""
     import torch.nn.functional as F
     from gen6d_amd.network.backbone import winograd_filters
@@ -677,11 +677,11 @@ WINO_MULTI_CASES = [
 
 @pytest.mark.parametrize("shape", ["rule", "wide", "square"])
 @pytest.mark.parametrize("sizes,Cin,Cout,relu,full,pool", WINO_MULTI_CASES)
-def test_wino_conv3x3_multi(ops, sizes, Cin, Cout, relu, full, pool, shape, monkeypatch):
+def test_wino_conv3x3_multi(ops, sizes, Cin, Cout, relu, full, pool, shape, knob):
     if shape != "rule":
         if Cout % 128:
             pytest.skip("one block shape only")
-        monkeypatch.setenv("G6D_WINO_WIDE", "2" if shape == "wide" else "0")
+        knob("wino_wide", 2 if shape == "wide" else 0)
     """One launch over several map sizes (flat quarter list across segments) against F.conv2d per segment in float64."""
     import torch.nn.functional as F
     from gen6d_amd.network.backbone import winograd_filters
@@ -764,7 +764,11 @@ def test_l2norm_rows(ops):
 
 
 def test_own_trunk_matches_library_trunk(ops):
-    """The two trunk implementations (own channels-last Winograd vs MIOpen NCHW) produce the same taps."""
+    """The product trunk (own channels-last Winograd kernels) against the MIOpen NCHW trunk of tools/library_trunk.py: same taps."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import library_trunk as LT
     from gen6d_amd import synth
     from gen6d_amd.network import backbone as B
     from gen6d_amd.network.params import fold_vgg
@@ -775,8 +779,8 @@ def test_own_trunk_matches_library_trunk(ops):
     folded = fold_vgg(net, "backbone.features")
     img = synth.imgs_to_tensor(synth.synth_images(2, 96, 160, 9)).cuda()
     with torch.no_grad():
-        x = B.img_norm(img)
-        lib_t = B.vgg_taps(folded, x, {"c3", "c5", "c7_pre", "p7"})
+        x = LT.img_norm(img)
+        lib_t = LT.vgg_taps(folded, x, {"c3", "c5", "c7_pre", "p7"})
         own_t = B.vgg_taps_cl([folded[0]] + [(B.winograd_filters(w), b) for w, b in folded[1:]], x, {"c3", "c5", "c7_pre", "p7"})
     for k in ("c3", "c5", "c7_pre", "p7"):
         _check(own_t[k].permute(0, 3, 1, 2), lib_t[k].double().cpu(), 5e-5, k)

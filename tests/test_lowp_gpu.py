@@ -173,11 +173,11 @@ WINO16_CASES = [
 ]
 
 
-@pytest.mark.parametrize("kernel", ["two-waves", "one-wave"])       # G6D_WINO16_2W: un-split launches on wino16b_conv3x3_kernel or not
+@pytest.mark.parametrize("kernel", ["two-waves", "one-wave"])       # knob wino16_2w: un-split launches on wino16b_conv3x3_kernel or not
 @pytest.mark.parametrize("mode", ["bf16", "fp16"])
 @pytest.mark.parametrize("sizes,Cin,Cout,relu,full,pool", WINO16_CASES)
-def test_wino16_conv3x3_multi(mode, sizes, Cin, Cout, relu, full, pool, kernel, monkeypatch):
-    monkeypatch.setenv("G6D_WINO16_2W", "1" if kernel == "two-waves" else "0")
+def test_wino16_conv3x3_multi(mode, sizes, Cin, Cout, relu, full, pool, kernel, knob):
+    knob("wino16_2w", 1 if kernel == "two-waves" else 0)
     """The trunk's 16-bit Winograd kernel (wino16_conv3x3_kernel: v_mfma_f32_32x32x16_{bf16,f16}, host-rounded filters) against
     (a) the restatement of its own arithmetic (tests/ref_ops.py: fp32 input transform rounded to the operand type, exact products,
     wide accumulation) — tight, and (b) the float64 convolution with the operand-rounding bound of the type."""
@@ -229,12 +229,12 @@ WINO16_CONV_CASES = [
 
 @pytest.mark.parametrize("mode", ["bf16", "fp16"])
 @pytest.mark.parametrize("case", WINO16_CONV_CASES)
-def test_conv_wino16_family(mode, case, monkeypatch):
+def test_conv_wino16_family(mode, case, knob):
     import ctypes as C
     import ref_ops
     from gen6d_amd import ops
     from gen6d_amd.network.backbone import winograd_filters_taps
-    monkeypatch.setenv("G6D_WINO_MIN_WORK", "0")
+    knob("wino_min_work", 0)
     c = case
     g = torch.Generator().manual_seed(11 + c["Cin"] + c["N"])
     kd = 3 if c.get("k3") else 1

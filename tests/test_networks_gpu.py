@@ -257,16 +257,17 @@ def test_detector_reference_permutation_invariance_full_size():
     assert o0["scores"].shape == (1, 1, 60, 80)
 
 
-@pytest.mark.parametrize("env", [{"G6D_TRUNK_MULTI": "0", "G6D_FUSED_FINALIZE": "0"}, {"G6D_OWN_TRUNK": "0"},
-                                 {"G6D_CONV_WINO": "0", "G6D_CONV_PATCH": "0"}],
-                         ids=["per-scale-trunk+separate-finalize", "library-trunk", "generic-conv-only"])
-def test_alternative_paths_keep_parity(env):
-    """The A/B switches (read once per process) select other kernels / launch structures for the same function: the golden
-    detector / selector / refiner tests must pass on them too."""
+@pytest.mark.parametrize("switches", ["attr:gen6d_amd.network.detector.TRUNK_MULTI=0,attr:gen6d_amd.ops.FUSED_FINALIZE=0", "library_trunk",
+                                      "knob:conv_wino=0,knob:conv_wino43=0,knob:conv_patch=0",
+                                      "attr:gen6d_amd.network.detector.F43=0,attr:gen6d_amd.network.refiner.VOLUME_F43=0"],
+                         ids=["per-scale-trunk+separate-finalize", "library-trunk", "generic-conv-only", "F(2x2,3x3)-everywhere"])
+def test_alternative_paths_keep_parity(switches):
+    """Other kernels / launch structures for the same function (selected through tests/conftest.py's G6D_TEST_SWITCHES: library knobs,
+    package attributes, the MIOpen trunk of tools/): the golden detector / selector / refiner tests must pass on them too."""
     import os
     import subprocess
     import sys
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k",
                           "test_detector and det_small or test_selector_golden and sel_small or test_refiner"],
-                         env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+                         env=dict(os.environ, G6D_TEST_SWITCHES=switches), capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]

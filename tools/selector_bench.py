@@ -9,6 +9,8 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import toolenv  # noqa: E402,F401  (G6D_LIB_PATH / KNOBS)
 from gen6d_amd import synth  # noqa: E402
 from gen6d_amd.network import name2network  # noqa: E402
 

@@ -9,6 +9,9 @@ import torch
 import torch.nn.functional as F
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import toolenv  # noqa: E402,F401  (G6D_LIB_PATH / KNOBS)
+import library_trunk as LT  # noqa: E402
 from gen6d_amd import ops, synth  # noqa: E402
 from gen6d_amd.network import backbone as B  # noqa: E402
 
@@ -64,7 +67,7 @@ def main():
         def own():
             B.vgg_taps_cl(packed, img, {"c5", "c7_pre", "p7"})
         def lib():
-            t = B.vgg_taps(folded, img, {"c5", "c7_pre", "p7"})
+            t = LT.vgg_taps(folded, img, {"c5", "c7_pre", "p7"})
             for k in ("c5", "c7_pre", "p7"):
                 f = t[k].contiguous()
                 ops.nchw_to_nhwc(f, torch.empty((f.shape[0], 1, f.shape[2], f.shape[3], f.shape[1]), device=dev), False)

@@ -1,12 +1,14 @@
 #!/usr/bin/env python
-"""Own-trunk layer times at the detector / crop map sizes (one line per layer); run under different G6D_WINO_SPLIT_* settings to
-compare split choices.  G6D_WINO_DEBUG=1 prints the chosen split of every launch to stderr."""
+"""Own-trunk layer times at the detector / crop map sizes (one line per layer); run with KNOBS="wino_split_max=..,wino_split_gain=.." (tools/toolenv.py) to
+compare split choices.  KNOBS=wino_debug=1 prints the chosen split of every launch to stderr."""
 import os
 import sys
 
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import toolenv  # noqa: E402,F401  (G6D_LIB_PATH / KNOBS)
 from gen6d_amd import ops  # noqa: E402
 from gen6d_amd.network import backbone as B  # noqa: E402
 from trunk_bench import LAYERS, timeit  # noqa: E402
