@@ -349,12 +349,14 @@ __global__ void __launch_bounds__(GEMV_THREADS) linear_gemv_kernel(const float* 
 
 // Batched weight-streaming GEMV for 2 <= B <= 8 right-hand sides and long rows (the refiner's first FC layer with a batch of queries:
 // K = 32768, O = 512, 67 MB of weights for B x 33 MFLOP).  linear_gemv_kernel gives every block ONE output row and lets it read all B
-// rows of x: 512 blocks x 1 MB of x through L2 for 67 MB of HBM traffic — measured 49 us at B = 8 (0.17 of 8 TB/s) against ~11 us
-// for the weight stream.  Here a block owns R = 8 output rows x one K slice of 1024 KV floats: a thread holds its KV 16-byte pieces of
-// all R rows in registers (R KV loads in flight per thread, 128 KB per block), reads each x piece ONCE for the R rows (x through
-// L2: O / R x B x K x 4 bytes = the size of the weight stream at B = 8) and runs R x B x 4 FMAs per x piece.  The K slices of a row group
-// meet through the workspace like the split launches of the conv kernels (g6d_split_arrive): partial sums written through, the block
-// that arrives last adds them IN SLICE ORDER (deterministic) and applies bias / activation.
+// rows of x: 512 blocks x 1 MB of x through L2 for 67 MB of HBM traffic — measured 49 us at B = 8 (0.17 of 8 TB/s) against 14.8 us
+// at B = 1.  Here a block owns R = 8 output rows x one K slice of 1024 KV floats: a thread requests its KV 16-byte pieces of all B rows
+// of x (L2) and then of all R weight rows (HBM, streamed past the caches) BEFORE it uses any of them — every load of the block is in
+// flight at once (a first version that fetched the x pieces inside the FMA loop paid one exposed L2 round trip per piece: 41 us) —
+// and runs R x B x 4 FMAs per x piece.  x through L2: O / R x B x K x 4 bytes = the size of the weight stream at B = 8.  The
+// R x 8 partial sums of a wave are reduced with the transposing butterfly (63 shuffles instead of 64 x 6), the K slices of a row
+// group meet through the workspace like the split launches of the conv kernels (g6d_split_arrive): partial sums written through, the
+// block that arrives last adds them IN SLICE ORDER (deterministic) and applies bias / activation.
 #define GEMVB_THREADS 256
 #define GEMVB_R 8
 template <int KV>
@@ -367,34 +369,45 @@ __global__ void __launch_bounds__(GEMVB_THREADS, 2) linear_gemv_batch_kernel(con
   const int og = blockIdx.x, ks = blockIdx.y, KS = gridDim.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kbase = ks * KL + tid * 4;
+  f32x4 xr[8][KV];
+#pragma unroll
+  for (int b = 0; b < 8; ++b)
+#pragma unroll
+    for (int v = 0; v < KV; ++v)
+      xr[b][v] = b < B ? *reinterpret_cast<const f32x4*>(x + (size_t)b * K + kbase + v * (GEMVB_THREADS * 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
   f32x4 wv[R][KV];
 #pragma unroll
   for (int v = 0; v < KV; ++v)
 #pragma unroll
     for (int r = 0; r < R; ++r)
       wv[r][v] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(W + (size_t)(og * R + r) * K + kbase + v * (GEMVB_THREADS * 4)));
-  float acc[R][8];
-#pragma unroll
-  for (int r = 0; r < R; ++r)
-#pragma unroll
-    for (int b = 0; b < 8; ++b) acc[r][b] = 0.f;
-#pragma unroll
-  for (int v = 0; v < KV; ++v)
-#pragma unroll
-    for (int b = 0; b < 8; ++b)
-      if (b < B) {
-        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)b * K + kbase + v * (GEMVB_THREADS * 4));
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-          acc[r][b] += wv[r][v][0] * xv[0] + wv[r][v][1] * xv[1] + wv[r][v][2] * xv[2] + wv[r][v][3] * xv[3];
-      }
+  float acc[R * 8];                       // value index i = r * 8 + b
 #pragma unroll
   for (int r = 0; r < R; ++r)
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
-      const float sm = wave_sum(acc[r][b]);
-      if (lane == 0) red[wave][r * 8 + b] = sm;
+      float a = 0.f;
+#pragma unroll
+      for (int v = 0; v < KV; ++v)
+        a += wv[r][v][0] * xr[b][v][0] + wv[r][v][1] * xr[b][v][1] + wv[r][v][2] * xr[b][v][2] + wv[r][v][3] * xr[b][v][3];
+      acc[r * 8 + b] = a;
     }
+  // transposing butterfly: after the step with lane bit `bit` every lane holds half as many values, each summed over that bit; at the
+  // end lane L holds the wave's sum of value index bitrev6(L)
+  int bit = 32;
+#pragma unroll
+  for (int nv = R * 8; nv > 1; nv >>= 1, bit >>= 1) {
+    const bool hi = (lane & bit) != 0;
+#pragma unroll
+    for (int i = 0; i < nv / 2; ++i) {
+      const float keep = hi ? acc[2 * i + 1] : acc[2 * i], send = hi ? acc[2 * i] : acc[2 * i + 1];
+      acc[i] = keep + __shfl_xor(send, bit, 64);
+    }
+  }
+  int idx = 0;
+#pragma unroll
+  for (int sft = 0; sft < 6; ++sft) idx |= ((lane >> (5 - sft)) & 1) << sft;
+  red[wave][idx] = acc[0];
   __syncthreads();
   float part = 0.f;
   if (tid < R * 8) {
@@ -550,7 +563,7 @@ extern "C" int g6d_linear_gemv_batch(const float* x, int B, int K, const float* 
   if (!x || !W || !out || B <= 0 || K <= 0 || (K & 3) || O <= 0 || !g6d_aligned16(x) || !g6d_aligned16(W)) {
     g6d_set_error("linear_gemv_batch: bad args"); return G6D_EINVAL;
   }
-  constexpr int KL = GEMVB_THREADS * 4 * 4;                 // KV = 4: K slices of 4096 floats
+  constexpr int KL = GEMVB_THREADS * 4 * 2;                 // KV = 2: K slices of 2048 floats
   const bool rows_ok = O % GEMVB_R == 0 && K % KL == 0 && O / GEMVB_R <= G6D_WS_COUNTERS;
   const int KS = rows_ok ? K / KL : 0;
   const size_t need = G6D_WS_COUNTER_BYTES + (size_t)(O / GEMVB_R) * (KS > 0 ? KS : 1) * GEMVB_R * 8 * sizeof(float);
@@ -561,7 +574,7 @@ extern "C" int g6d_linear_gemv_batch(const float* x, int B, int K, const float* 
     const float* xg = x + (size_t)b0 * K;
     float* og = out + (size_t)b0 * O;
     if (nb >= 2 && rows_ok && KS >= 2 && workspace && workspace_bytes >= need && g6d_aligned16(workspace)) {
-      hipLaunchKernelGGL(linear_gemv_batch_kernel<4>, dim3(O / GEMVB_R, KS), dim3(GEMVB_THREADS), 0, STREAM(stream), xg, nb, K, W, bias, act, og, O,
+      hipLaunchKernelGGL(linear_gemv_batch_kernel<2>, dim3(O / GEMVB_R, KS), dim3(GEMVB_THREADS), 0, STREAM(stream), xg, nb, K, W, bias, act, og, O,
                          workspace);
     } else if (K >= GEMV_THREADS * 4 * 16) {
       hipLaunchKernelGGL(linear_gemv_kernel<16>, dim3(O), dim3(GEMV_THREADS), 0, STREAM(stream), xg, nb, K, W, bias, act, og, O);

@@ -101,6 +101,9 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing: build it with `python __graft_entry__.py` "
                            "(make -C gen6d_amd/csrc). There is no fallback path.")
+    # PyTorch-ROCm ships its own HIP runtime: it has to be in the process BEFORE this library is loaded, so that both resolve to the
+    # same libamdhip64 (loaded the other way round the launches here see "no ROCm-capable device")
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)

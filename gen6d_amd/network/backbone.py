@@ -188,12 +188,13 @@ def pack_trunk(folded):
 _IMG_NORM = (tuple(specs.IMAGENET_MEAN), tuple(specs.IMAGENET_STD))
 
 
-def vgg_taps_cl(packed, x, taps, norm=None):
+def vgg_taps_cl(packed, x, taps, norm=None, f43=False):
     """Own trunk, channels-last: x [n,3,h,w] normalised image (or an image in [0,1] with norm = (mean, std): the first layer
     normalises while it stages its input) -> {'c3': [n,h/4,w/4,256] post-ReLU, 'c5': [n,h/8,w/8,512] post-ReLU,
     'c7_pre': [n,h/16,w/16,512] pre-ReLU, 'p7': max-pool of c7_pre} (only the requested taps + c7_pre)."""
-    if ops.MATH_MODE and LOWP_TRUNK:
-        return vgg_taps_cl_multi(packed, [x], taps, norm=norm)[0]               # reduced precision: the multi-segment 16-bit kernel
+    if (ops.MATH_MODE and LOWP_TRUNK) or f43:
+        # reduced precision: the multi-segment 16-bit kernel; f43: the F(4x4,3x3) kernel (one segment)
+        return vgg_taps_cl_multi(packed, [x], taps, norm=norm, f43=f43)[0]
     w0, b0 = packed[0]
     x = ops.vgg_conv1_pool_nhwc(x.contiguous(), w0, b0, norm=norm)              # (normalise +) conv0 + ReLU + pool
     _, x = ops.wino_conv3x3(x, *packed[1], relu=True, full=False, pool=True)    # conv1 + ReLU + pool
@@ -239,10 +240,10 @@ def trunk_features_multi(packed, imgs_list, keys, f43=False):
     return [[t[k].unsqueeze(1) for k in keys] for t in taps]
 
 
-def trunk_features(packed, imgs, keys, l2norm):
+def trunk_features(packed, imgs, keys, l2norm, f43=False):
     """Normalised images [n,3,h,w] in [0,1] -> channels-last 5-D feature maps [n,1,h_l,w_l,C] for `keys`, optionally
     L2-normalised over C (F.normalize, reference selector.py:118 / refiner.py:69-71)."""
-    t = vgg_taps_cl(packed, imgs, set(keys), norm=_IMG_NORM)
+    t = vgg_taps_cl(packed, imgs, set(keys), norm=_IMG_NORM, f43=f43)
     outs = []
     for k in keys:
         f = t[k]

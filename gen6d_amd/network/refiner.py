@@ -20,6 +20,7 @@ from .params import ParamBank, fold_vgg
 
 # Winograd F(4x4,3x3) filters for the stride-1 3x3x3 layers of the volume net (csrc/wino43_conv.hip); VOLUME_F43_LAYERS: which of
 # conv0 (32^3), conv2 (16^3), conv4 (8^3) take it beside the two embed pairs (32^3)
+TRUNK_F43 = True        # the crops' VGG trunk on the F(4x4,3x3) kernel (1.31-1.35x over F(2x2,3x3) at 56 crops, profiles/r04_w43_bench_v5.md)
 VOLUME_F43 = True
 VOLUME_F43_LAYERS = ("conv0",)          # measured per batch of 8: conv2 (16^3) 147 vs 151 us, conv4 (8^3) 144 vs 94 us on F(2x2,3x3): only 32^3 pays
 MAX_BATCH = 32         # queries that share one set of launches (g6d_linear_gemv_batch: 8 right-hand sides per weight pass)
@@ -139,7 +140,7 @@ class VolumeRefiner(ParamBank):
         pk = self._pack()
         n, _, h, w = imgs.shape
         dev = imgs.device
-        f3, f5, f7 = trunk_features(pk["vgg"], imgs, ("c3", "c5", "c7_pre"), True)      # channels-last, L2-normalised
+        f3, f5, f7 = trunk_features(pk["vgg"], imgs, ("c3", "c5", "c7_pre"), True, f43=TRUNK_F43 and n >= 4)      # channels-last, L2-normalised
 
         def pair(name, x):
             """conv, IN, ReLU, conv, (IN returned as affine) — per-image statistics."""

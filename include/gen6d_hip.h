@@ -430,9 +430,9 @@ int g6d_linear_gemv(const float* x, int B, int K, const float* W, const float* b
                     g6d_stream_t stream);
 
 /* (ABI v9) The same layer for ANY number of right-hand sides (network/refiner.py:249-269 takes [qn, ...] queries): groups of up to 8 rows of
- * x per weight pass; groups of >= 2 with O % 8 == 0 and K % 4096 == 0 run 8 output rows x one 4096-float K slice per block (x read once
+ * x per weight pass; groups of >= 2 with O % 8 == 0 and K % 2048 == 0 run 8 output rows x one 2048-float K slice per block (x read once
  * per 8 rows, partial sums joined in slice order through `workspace`: G6D_WORKSPACE_COUNTER_BYTES of counters, zero at rest, then
- * O * K / 4096 * 8 floats), anything else the row-per-block kernel of g6d_linear_gemv. */
+ * O * K / 2048 * 8 floats), anything else the row-per-block kernel of g6d_linear_gemv. */
 int g6d_linear_gemv_batch(const float* x, int B, int K, const float* W, const float* bias, int O, int act, float* out, float* workspace,
                           size_t workspace_bytes, g6d_stream_t stream);
 

@@ -27,30 +27,39 @@ def _net(kind, sd, **cfg):
     return net.cuda()
 
 
-@pytest.mark.parametrize("shrink,min_clipped", [(40.0, 0.5), (4.0, 0.02)])
-def test_detector_scores_saturate_the_clip(monkeypatch, shrink, min_clipped):
-    """sigma / shrink: at 40 more than half of the 12 x rfn x hs x ws normalised scores sit at exactly +-10 (both signs), at 4 a few
-    per cent do and many values lie close to the bound.  Scores / offsets / scales stay within 1e-4 of the range of the oracle's
-    and the detection cell is the same."""
+@pytest.mark.parametrize("spread,min_each", [(80.0, 0.25), (20.0, 0.01)])
+def test_detector_scores_saturate_the_clip(monkeypatch, spread, min_each):
+    """With the seeded random trunk the raw correlation scores sit far above the trained level statistics: every detector test already
+    runs with ~99 % of the normalised scores clipped at +10 and none at -10.  Here the statistics are re-centred on the raw scores'
+    per-level median with sigma = (q90 - q10) / spread: at spread 80 more than a quarter of the values sit at EACH bound (35 % / 30 %), at 20 fewer (15 % / 2 %)
+    and most values lie in the linear range close to it.  Scores / offsets / scales stay within 1e-4 of the range of the
+    oracle's and the detection cell is the same (reference network/detector.py:226-230)."""
     from parity_log import record
-    stats = [[mu, sg / shrink] for mu, sg in O.SCORE_STATS]
-    monkeypatch.setattr(O, "SCORE_STATS", stats)
     sd = synth.synth_state_dict("detector")
     case = synth.detector_case(32, 160, 192)
+    sd64 = O.to_double(sd)
+    with torch.no_grad():
+        rf32, rf64 = O.detector_ref_feats(sd, case["ref_imgs"]), O.detector_ref_feats(sd64, case["ref_imgs"].double())
+        monkeypatch.setattr(O, "SCORE_STATS", [[0.0, 1e20]] * 3)                # raw scores (nothing clips at this sigma)
+        raw = O.detector_detect(sd, case["que_imgs"], rf32, return_intermediates=True)["stacked"] * 1e20      # [1, 4 scales x 3 levels, rfn, hs, ws]
+    stats = []
+    for l in range(3):
+        q = torch.quantile(raw[:, l::3].flatten()[::7], torch.tensor([0.1, 0.5, 0.9]))
+        stats.append([float(q[1]), float(q[2] - q[0]) / spread])
+    monkeypatch.setattr(O, "SCORE_STATS", stats)
     net = _net("detector", sd, vgg_score_stats=stats)
     with torch.no_grad():
         out = net({"ref_imgs_info": {"imgs": case["ref_imgs"].cuda()}, "que_imgs_info": {"imgs": case["que_imgs"].cuda()}})
-        sd64 = O.to_double(sd)
-        o32 = O.detector_detect(sd, case["que_imgs"], O.detector_ref_feats(sd, case["ref_imgs"]), return_intermediates=True)
-        o64 = O.detector_detect(sd64, case["que_imgs"].double(), O.detector_ref_feats(sd64, case["ref_imgs"].double()))
+        o32 = O.detector_detect(sd, case["que_imgs"], rf32, return_intermediates=True)
+        o64 = O.detector_detect(sd64, case["que_imgs"].double(), rf64)
     st = o32["stacked"]
     hi, lo = float((st == 10).float().mean()), float((st == -10).float().mean())
-    assert hi + lo >= min_clipped and hi > 0 and lo > 0, (hi, lo)
+    assert hi >= min_each and lo >= min_each, (hi, lo)
     for k in ("scores", "select_pr_offset", "select_pr_scale"):
         rng = max(float(o64[k].abs().max()), 1.0)
         e_new = float((out[k].cpu().double() - o64[k]).abs().max()) / rng
         e_ref = float((o32[k].double() - o64[k]).abs().max()) / rng
-        record(f"test_detector_scores_saturate_the_clip[/{shrink:g}]", f"{k} ({100 * (hi + lo):.0f} % of the scores clipped)", e_new,
+        record(f"test_detector_scores_saturate_the_clip[spread {spread:g}]", f"{k} ({100 * hi:.0f} % at +10, {100 * lo:.0f} % at -10)", e_new,
                max(1e-4, 1.5 * e_ref), e_ref, "relative to range")
         assert e_new <= max(1e-4, 1.5 * e_ref), (k, e_new, e_ref)
     assert torch.equal(out["que_select_id"].cpu(), o64["que_select_id"])

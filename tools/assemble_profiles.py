@@ -10,7 +10,7 @@ G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
 RND = sys.argv[1] if len(sys.argv) > 1 else "r01"
 FAMILY = ("conv_igemm_kernel", "conv_patch_kernel", "corr_patch_kernel")      # split launches finish inside these kernels
-WFAMILY = ("wino_conv3x3_kernel",)
+WFAMILY = ("wino_conv3x3_kernel", "wino43_kernel")
 
 
 def rd(f):
@@ -54,6 +54,7 @@ def main():
     r, w = fams["conv"], fams.get("winograd", {})
     gflop_step = r["gflop_per_launch"] * r["launches_per_step"]
     wg = w.get("gflop_direct_form_per_step", 0.0)
+    wexec = w.get("gflop_per_launch", 0.0) * w.get("launches_per_step", 0.0)
     open(os.path.join(P, f"{RND}_bench_kernel_stats_serial.md"), "w").write(
         f"# rocprofv3 --kernel-trace --stats of `python bench.py --steps {steps} --warmup 2 --no-cpu-baseline --no-cached --lowp '' --serial` (1x MI355X)\n\n"
         f"Same workload, one BATCH of {ser.get('batch', 1)} queries at a time, no graph replay (`--serial`), which is how bench.py's roofline pass\n"
@@ -63,11 +64,13 @@ def main():
         f"  {ms:.2f} ms = {ms / steps:.2f} ms per step ({main / steps:.0f} launches per step, {gflop_step:.1f} GFLOP per step -> "
         f"{gflop_step / (ms / steps):.1f} TFLOP/s by kernel durations; bench.py's HIP-event figure in the same profiled run: "
         f"{r['conv_ms_per_step']:.2f} ms per step, {r['achieved']:.1f} TFLOP/s — the event brackets include launch gaps and the profiler's per-dispatch overhead).\n"
-        "* Winograd family (wino_conv3x3_kernel<MODE,KD,NWN>: the own VGG trunk and the conv layers routed to it):\n"
+        "* Winograd family (wino_conv3x3_kernel<MODE,KD,NWN> = F(2x2,3x3) and wino43_kernel<MODE,KD,NT> = F(4x4,3x3): the own VGG trunks, the conv\n"
+        "  layers routed to them and the detector's 15x15 correlation):\n"
         f"  {wms:.2f} ms = {wms / steps:.2f} ms per step ({wmain / steps:.0f} launches per step, {wg:.1f} GFLOP per step in DIRECT form = "
-        f"{wg / 2.25:.1f} GFLOP executed in the Winograd domain -> {wg / 2.25 / max(wms / steps, 1e-9):.1f} TFLOP/s executed, "
+        f"{wexec:.1f} GFLOP executed in the Winograd domain (direct / 2.25 on F(2x2,3x3) launches, direct / 4 on F(4x4,3x3) launches) -> "
+        f"{wexec / max(wms / steps, 1e-9):.1f} TFLOP/s executed, "
         f"{wg / max(wms / steps, 1e-9):.1f} TFLOP/s direct-form equivalent; bench.py: {w.get('ms_per_step', 0):.2f} ms per step, "
-        f"{w.get('achieved', 0):.1f} TFLOP/s executed).\n\n" + sstats)
+        f"{w.get('achieved', 0):.1f} TFLOP/s executed; by transform: {json.dumps({k: {kk: round(vv, 2) for kk, vv in v.items()} for k, v in w.get('by_transform', {}).items()})}).\n\n" + sstats)
     traffic = json.load(open(os.path.join(G, "pmc_conv_traffic.json")))
     open(os.path.join(P, f"{RND}_pmc_hbm.md"), "w").write(
         "# HBM traffic counters (rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes, no other trace domains)\n\n"

@@ -2,7 +2,7 @@
 # Usage (GPU box, repo root): bash tools/batch_sweep.sh "1x4 2x2 4x1 4x2 8x1 8x2" > gpurun_out/batch_sweep.txt
 for c in ${1:-"1x4 2x2 4x1 4x2 8x1 8x2"}; do
   B=${c%x*}; L=${c#*x}
-  timeout 300 python bench.py --batch $B --lanes $L --steps ${STEPS:-12} --warmup 3 --no-cpu-baseline --no-cached --lowp "" 2> /tmp/sweep_err.log | python -c "
+  timeout 300 python bench.py --batch $B --lanes $L --steps ${STEPS:-12} --warmup 3 --no-cpu-baseline --no-cached --no-chained --no-sweep --lowp "" 2> /tmp/sweep_err.log | python -c "
 import sys, json
 for line in sys.stdin:
     line = line.strip()

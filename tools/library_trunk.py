@@ -48,7 +48,7 @@ def vgg_taps(folded, x, taps):
     return {k: v for k, v in out.items() if k in taps or k == "c7_pre"}
 
 
-def trunk_features(folded, imgs, keys, l2norm):
+def trunk_features(folded, imgs, keys, l2norm, f43=False):
     t = vgg_taps(folded, img_norm(imgs), set(keys))
     outs = []
     for k in keys:

@@ -11,7 +11,7 @@ import sys
 
 MAIN = ("conv_igemm_kernel", "conv_patch_kernel", "corr_patch_kernel")
 FAMILY = MAIN                      # split launches finish inside the kernels: no reduce kernels any more
-WMAIN = ("wino_conv3x3_kernel",)
+WMAIN = ("wino_conv3x3_kernel", "wino43_kernel")
 WFAMILY = WMAIN
 
 
@@ -44,7 +44,7 @@ def main():
     }
     wf, wl = family_sum(fetch_db, "FETCH_SIZE", WFAMILY, WMAIN)
     ww, _ = family_sum(write_db, "WRITE_SIZE", WFAMILY, WMAIN)
-    res["winograd_family"] = {"kernels": "wino_conv3x3_kernel (own trunk and the conv layers routed to it)",
+    res["winograd_family"] = {"kernels": "wino_conv3x3_kernel + wino43_kernel (own trunks, the conv layers routed to them, the 15x15 correlation)",
                               "fetch_kb_total": wf, "write_kb_total": ww, "launches": wl,
                               "hbm_bytes_per_launch": (2 * wf + ww) * 1024 / max(wl, 1)}
     with open(out, "w") as f:
