@@ -20,6 +20,10 @@ from .params import ParamBank, fold_vgg
 
 # Winograd F(4x4,3x3) filters for the stride-1 3x3x3 layers of the volume net (csrc/wino43_conv.hip); VOLUME_F43_LAYERS: which of
 # conv0 (32^3), conv2 (16^3), conv4 (8^3) take it beside the two embed pairs (32^3)
+# Both pay from ~4 queries per launch on: one query's 7 crops / single volume leave most CUs without a block and the kernel's longer
+# per-block prologue / epilogue shows (measured per step at batch 1: crops' trunk 475 vs 320 us, volume layers 541 vs 418 us on
+# F(2x2,3x3); at batch 8: 1.06 vs 1.43 ms and 1.96 vs 3.06 ms the other way round)
+F43_MIN_QUERIES = 4
 TRUNK_F43 = True        # the crops' VGG trunk on the F(4x4,3x3) kernel (1.31-1.35x over F(2x2,3x3) at 56 crops, profiles/r04_w43_bench_v5.md)
 VOLUME_F43 = True
 VOLUME_F43_LAYERS = ("conv0",)          # measured per batch of 8: conv2 (16^3) 147 vs 151 us, conv4 (8^3) 144 vs 94 us on F(2x2,3x3): only 32^3 pays
@@ -140,7 +144,7 @@ class VolumeRefiner(ParamBank):
         pk = self._pack()
         n, _, h, w = imgs.shape
         dev = imgs.device
-        f3, f5, f7 = trunk_features(pk["vgg"], imgs, ("c3", "c5", "c7_pre"), True, f43=TRUNK_F43 and n >= 4)      # channels-last, L2-normalised
+        f3, f5, f7 = trunk_features(pk["vgg"], imgs, ("c3", "c5", "c7_pre"), True, f43=TRUNK_F43 and n >= F43_MIN_QUERIES * 7)      # channels-last, L2-normalised
 
         def pair(name, x):
             """conv, IN, ReLU, conv, (IN returned as affine) — per-image statistics."""
@@ -195,7 +199,8 @@ class VolumeRefiner(ParamBank):
                             in_relu=aff is not None, per_n=pn if aff is not None else 0, stats=st,
                             rows_per_group=pn * (count or 0) if stats_c else 0,
                             w_wino=getattr(wb, "u", None) if stride == 1 else None,
-                            w_wino43=getattr(wb, "u43", None) if stride == 1 else None, finalize=count if stats_c else None)
+                            w_wino43=getattr(wb, "u43", None) if (stride == 1 and qn >= F43_MIN_QUERIES) else None,
+                            finalize=count if stats_c else None)
 
         def buf(s, c):
             return torch.empty((qn, s, s, s, c), dtype=torch.float32, device=dev)

@@ -42,7 +42,9 @@ FEAT_LD = 516          # 512 corr channels + 3 vps channels + 1 zero pad (16-byt
 
 
 class ViewpointSelector(ParamBank):
-    default_cfg = {"selector_angle_num": 5}
+    # lowp_keep_fp32: parts that stay on fp32 matrix-core operands when the reduced-precision mode is on (cfg `math_mode` or an enclosing
+    # ops.math_mode): "trunk" = the query's VGG trunk, "product" = the first conv of every level (query x reference product); () = none
+    default_cfg = {"selector_angle_num": 5, "lowp_keep_fp32": ()}
 
     def __init__(self, cfg):
         self.cfg = {**self.default_cfg, **cfg}
@@ -119,7 +121,8 @@ class ViewpointSelector(ParamBank):
     # ------------------------------------------------------------------ features
     def get_feats(self, imgs):
         """imgs [n,3,h,w] in [0,1] -> 3 channels-last, L2-normalised maps [n,1,h_l,w_l,512] (selector.py:113-119)."""
-        return trunk_features(self._pack()["vgg"], imgs, ("c5", "c7_pre", "p7"), True)
+        with ops.math_mode("fp32" if "trunk" in self.cfg.get("lowp_keep_fp32", ()) else None, inherit_if_none=True):
+            return trunk_features(self._pack()["vgg"], imgs, ("c5", "c7_pre", "p7"), True)
 
     def extract_ref_feats(self, ref_imgs, ref_poses, object_center, object_vert, is_train=False):
         """ref_imgs [an,rfn,3,h,w]; builds the reference cache, its R1/R2 sums and the viewpoint embedding
@@ -185,9 +188,10 @@ class ViewpointSelector(ParamBank):
             stats = ops.new_stats(qn, co, dev) if has_in else None
             # InstanceNorm finalisation inside the producing launch, unless the statistics still have to be summed over ranks
             fin = Dg * h * w if (has_in and not last and self.world == 1) else None
-            res = ops.conv(x, wgt, bias, out, ksize=_K133, pad=_P011, mul=mul, in_scale=scale, in_shift=shift, in_relu=relu, stats=stats,
-                           w_wino=wu, finalize=fin, per_n=grp if scale is not None else 0, rows_per_group=grp * h * w,
-                           in_mod=grp if first else 0, mul_group=grp if mul is not None else 0)
+            with ops.math_mode("fp32" if (first and "product" in self.cfg.get("lowp_keep_fp32", ())) else None, inherit_if_none=True):
+                res = ops.conv(x, wgt, bias, out, ksize=_K133, pad=_P011, mul=mul, in_scale=scale, in_shift=shift, in_relu=relu, stats=stats,
+                               w_wino=wu, finalize=fin, per_n=grp if scale is not None else 0, rows_per_group=grp * h * w,
+                               in_mod=grp if first else 0, mul_group=grp if mul is not None else 0)
             mul, first = None, False
             if last:
                 break
