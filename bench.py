@@ -474,193 +474,211 @@ def main():
     # ---- reduced-precision speed modes (BASELINE configs[2] "bf16", configs[4] "fp16 MFMA convs"): separately graded, never
     #      the headline.  Same pipeline, same launch mode, matrix-core operands rounded to bf16 / fp16 in the conv / correlation
     #      kernels (fp32 accumulation, fp32 InstanceNorm statistics, fp32 trunk).
-    lowp = {}
-    modes = [m for m in args.lowp.split(",") if m] if (use_graph and world == 1) else []
-    # the first re-captured pass after the serialised eager roofline pass measures ~15 % low whatever its type (bf16 first: 169 /
-    # fp16 205; fp16 first: fp16 low, bf16 205): one throwaway pass of the first mode precedes the reported ones
-    headline_lanes = lanes
-    if modes:
-        lanes = max(1, args.lowp_lanes)               # (step / images_of read `lanes` when they run)
-    LOWP_PEAK_TFLOPS = 2500.0                          # dense 16-bit MFMA peak (MI355X_MICROARCH.md; AMD's 5 PFLOP/s figure is 2:1 sparse)
-    gold_npz = np.load(gpath) if ((args.sel_refs, args.det_refs) == (64, 32) and os.path.exists(gpath)) else None
-    for pi, mode_name in enumerate(modes[:1] + modes):
-        # "bf16mix": bf16 operands in the detector and the refiner, fp16 in the selector — the stage whose 13 stacked InstanceNorms
-        # amplify bf16's 8-bit mantissa past the top-2 logit margin of some queries (network cfg key `math_mode` overrides the context)
-        # "fp16sel32": fp16 operands in the detector and the refiner, the selector on fp32 operands — the scheme that keeps the logit
-        # error below a quarter of the smallest top-2 margin (tools/lowp_selector_schemes.py: an fp32 query trunk / product conv alone
-        # only reach 0.30 / 0.29 of the margin; the 13 stacked InstanceNorms carry the rounding of every fp16 layer to the logits)
-        mode = {"bf16mix": "bf16", "fp16sel32": "fp16"}.get(mode_name, mode_name)
-        pipe.selector.cfg["math_mode"] = {"bf16mix": "fp16", "fp16sel32": "fp32"}.get(mode_name)
-        with ops.math_mode(mode):
-            pipe.capture(lanes=lanes, batch=B)
-        lane_busy[:] = [None] * lanes
-        for i in range(args.warmup):
-            step(i)
-        drain(); torch.cuda.synchronize()
-        nl = 3 * args.steps                            # side measurement: three times the headline's queries for a steadier number
-        t1 = time.perf_counter()
-        lrows = [step(args.warmup + i) for i in range(nl)]
-        drain(); torch.cuda.synchronize()
-        ldt = time.perf_counter() - t1
-        lrows = torch.cat(lrows[:args.steps], 0).cpu()
-        entry = {"dtype": mode_name, "value": nl * B / ldt, "unit": "images/s", "ms_per_step": ldt / nl * 1e3, "queries": nl * B, "batch": B,
-                 "lanes": lanes}
-        if mode_name == "bf16mix":
-            entry["scheme"] = "detector bf16, selector fp16, refiner bf16 (fp32 accumulation, InstanceNorm statistics, selector tail and regressor everywhere)"
-        if mode_name == "fp16sel32":
-            entry["scheme"] = "detector fp16, selector fp32, refiner fp16: the mixed scheme whose selector logits stay within a quarter of the top-2 margin"
-        if pi > 0:
-            # roofline of the mode: serialised eager pass of the same steps with HIP events around every MFMA-family launch
-            ops.SERIAL = True
+    lowp, headline_lanes = {}, lanes
+    try:
+        modes = [m for m in args.lowp.split(",") if m] if (use_graph and world == 1) else []
+        # the first re-captured pass after the serialised eager roofline pass measures ~15 % low whatever its type (bf16 first: 169 /
+        # fp16 205; fp16 first: fp16 low, bf16 205): one throwaway pass of the first mode precedes the reported ones
+        if modes:
+            lanes = max(1, args.lowp_lanes)               # (step / images_of read `lanes` when they run)
+        LOWP_PEAK_TFLOPS = 2500.0                          # dense 16-bit MFMA peak (MI355X_MICROARCH.md; AMD's 5 PFLOP/s figure is 2:1 sparse)
+        gold_npz = np.load(gpath) if ((args.sel_refs, args.det_refs) == (64, 32) and os.path.exists(gpath)) else None
+        for pi, mode_name in enumerate(modes[:1] + modes):
+            # "bf16mix": bf16 operands in the detector and the refiner, fp16 in the selector — the stage whose 13 stacked InstanceNorms
+            # amplify bf16's 8-bit mantissa past the top-2 logit margin of some queries (network cfg key `math_mode` overrides the context)
+            # "fp16sel32": fp16 operands in the detector and the refiner, the selector on fp32 operands — the scheme that keeps the logit
+            # error below a quarter of the smallest top-2 margin (tools/lowp_selector_schemes.py: an fp32 query trunk / product conv alone
+            # only reach 0.30 / 0.29 of the margin; the 13 stacked InstanceNorms carry the rounding of every fp16 layer to the logits)
+            mode = {"bf16mix": "bf16", "fp16sel32": "fp16"}.get(mode_name, mode_name)
+            pipe.selector.cfg["math_mode"] = {"bf16mix": "fp16", "fp16sel32": "fp32"}.get(mode_name)
             with ops.math_mode(mode):
-                step(0, eager=True); torch.cuda.synchronize()
-                ops.PROFILE, ops.PROFILE_HBM = [], {}
-                for i in range(args.steps):
-                    step(args.warmup + i, eager=True)
-                torch.cuda.synchronize()
-                lp, ops.PROFILE, ops.PROFILE_HBM = ops.PROFILE, None, None
-                if gold_npz is not None:              # selector logits of the 4 synthetic queries in this mode vs the reference's
-                    lg = pipe.selector.compute_view_point_feats(crops)[0].cpu()
-            ops.SERIAL = no_fork
-            fl = sum(p[0] for p in lp); ms = sum(p[1].elapsed_time(p[2]) for p in lp)
-            wino = [p for p in lp if p[3].startswith("wino3x3")]
-            entry["roofline"] = {"bound": "mfma", "achieved": fl / (ms * 1e-3) / 1e12, "peak": LOWP_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                 "frac": fl / (ms * 1e-3) / 1e12 / LOWP_PEAK_TFLOPS, "traffic": None,
-                                 "kernel": "all MFMA-family launches of a step (16-bit Winograd trunk / conv family, corr16_patch, conv_igemm / conv_patch "
-                                           "with 16-bit operands)", "flops_counted": "EXECUTED (Winograd launches: direct-form / 2.25)",
-                                 "mfma_ms_per_step": ms / args.steps, "gflop_executed_per_step": fl / args.steps / 1e9,
-                                 "winograd_share_of_ms": sum(p[1].elapsed_time(p[2]) for p in wino) / ms if ms > 0 else None,
-                                 "lds_bytes_per_chunk": {"wino16b_conv3x3_kernel": 316 * 1024, "note": "raw patch 98 + V 64 + filter fragments 64 read, "
-                                                         "V 32 + raw 26 + filters 32 written per 16-channel chunk (DESIGN.md 4.7); the LDS write rate is the bound"},
-                                 "measured": "HIP events around every launch, serialised eager re-run of the same steps"}
+                pipe.capture(lanes=lanes, batch=B)
+            lane_busy[:] = [None] * lanes
+            for i in range(args.warmup):
+                step(i)
+            drain(); torch.cuda.synchronize()
+            nl = 3 * args.steps                            # side measurement: three times the headline's queries for a steadier number
+            t1 = time.perf_counter()
+            lrows = [step(args.warmup + i) for i in range(nl)]
+            drain(); torch.cuda.synchronize()
+            ldt = time.perf_counter() - t1
+            lrows = torch.cat(lrows[:args.steps], 0).cpu()
+            entry = {"dtype": mode_name, "value": nl * B / ldt, "unit": "images/s", "ms_per_step": ldt / nl * 1e3, "queries": nl * B, "batch": B,
+                     "lanes": lanes}
+            if mode_name == "bf16mix":
+                entry["scheme"] = "detector bf16, selector fp16, refiner bf16 (fp32 accumulation, InstanceNorm statistics, selector tail and regressor everywhere)"
+            if mode_name == "fp16sel32":
+                entry["scheme"] = "detector fp16, selector fp32, refiner fp16: the mixed scheme whose selector logits stay within a quarter of the top-2 margin"
+            if pi > 0:
+                # roofline of the mode: serialised eager pass of the same steps with HIP events around every MFMA-family launch
+                ops.SERIAL = True
+                with ops.math_mode(mode):
+                    step(0, eager=True); torch.cuda.synchronize()
+                    ops.PROFILE, ops.PROFILE_HBM = [], {}
+                    for i in range(args.steps):
+                        step(args.warmup + i, eager=True)
+                    torch.cuda.synchronize()
+                    lp, ops.PROFILE, ops.PROFILE_HBM = ops.PROFILE, None, None
+                    if gold_npz is not None:              # selector logits of the 4 synthetic queries in this mode vs the reference's
+                        lg = pipe.selector.compute_view_point_feats(crops)[0].cpu()
+                ops.SERIAL = no_fork
+                fl = sum(p[0] for p in lp); ms = sum(p[1].elapsed_time(p[2]) for p in lp)
+                wino = [p for p in lp if p[3].startswith("wino3x3")]
+                entry["roofline"] = {"bound": "mfma", "achieved": fl / (ms * 1e-3) / 1e12, "peak": LOWP_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                     "frac": fl / (ms * 1e-3) / 1e12 / LOWP_PEAK_TFLOPS, "traffic": None,
+                                     "kernel": "all MFMA-family launches of a step (16-bit Winograd trunk / conv family, corr16_patch, conv_igemm / conv_patch "
+                                               "with 16-bit operands)", "flops_counted": "EXECUTED (Winograd launches: direct-form / 2.25)",
+                                     "mfma_ms_per_step": ms / args.steps, "gflop_executed_per_step": fl / args.steps / 1e9,
+                                     "winograd_share_of_ms": sum(p[1].elapsed_time(p[2]) for p in wino) / ms if ms > 0 else None,
+                                     "lds_bytes_per_chunk": {"wino16b_conv3x3_kernel": 316 * 1024, "note": "raw patch 98 + V 64 + filter fragments 64 read, "
+                                                             "V 32 + raw 26 + filters 32 written per 16-channel chunk (DESIGN.md 4.7); the LDS write rate is the bound"},
+                                     "measured": "HIP events around every launch, serialised eager re-run of the same steps"}
+                if gold_npz is not None:
+                    gl = torch.from_numpy(gold_npz["logits"]).float()
+                    top2 = gl.topk(2, 1)[0]
+                    margin = float((top2[:, 0] - top2[:, 1]).min())
+                    err = float((lg - gl).abs().max())
+                    entry["selector_logits"] = {"max_abs_err": err, "min_top2_margin_of_the_4_queries": margin, "err_over_margin": err / margin,
+                                                "bar": 0.25, "ok": bool(err <= 0.25 * margin),
+                                                "argmax_equal": bool((lg.argmax(1) == gl.argmax(1)).all())}
             if gold_npz is not None:
-                gl = torch.from_numpy(gold_npz["logits"]).float()
-                top2 = gl.topk(2, 1)[0]
-                margin = float((top2[:, 0] - top2[:, 1]).min())
-                err = float((lg - gl).abs().max())
-                entry["selector_logits"] = {"max_abs_err": err, "min_top2_margin_of_the_4_queries": margin, "err_over_margin": err / margin,
-                                            "bar": 0.25, "ok": bool(err <= 0.25 * margin),
-                                            "argmax_equal": bool((lg.argmax(1) == gl.argmax(1)).all())}
-        if gold_npz is not None:
-            gold = torch.from_numpy(gold_npz["rows"]).float()
-            ref = torch.stack([gold[j] for i in range(args.steps) for j in images_of(args.warmup + i)])
-            r32 = torch.stack([row32[j] for i in range(args.steps) for j in images_of(args.warmup + i)])
-            d = (lrows - ref).abs()
-            entry["parity_vs_reference"] = {
-                "ref_idx_equal": bool((lrows[:, 3].long() == ref[:, 3].long()).all()),
-                "detection_cell_px": float(d[:, 0:2].max()), "max_abs_diff_row": float(d.max()),
-                "max_rel_diff_row": float((d / ref.abs().clamp(min=1.0)).max()),
-                "vs_fp32_path_max_rel": float(((lrows - r32).abs() / r32.abs().clamp(min=1.0)).max())}
-        if pi > 0:
-            lowp[mode_name] = entry
-    pipe.selector.cfg["math_mode"] = None
-    if lowp:
-        result["lowp"] = lowp
-    lanes = headline_lanes
+                gold = torch.from_numpy(gold_npz["rows"]).float()
+                ref = torch.stack([gold[j] for i in range(args.steps) for j in images_of(args.warmup + i)])
+                r32 = torch.stack([row32[j] for i in range(args.steps) for j in images_of(args.warmup + i)])
+                d = (lrows - ref).abs()
+                entry["parity_vs_reference"] = {
+                    "ref_idx_equal": bool((lrows[:, 3].long() == ref[:, 3].long()).all()),
+                    "detection_cell_px": float(d[:, 0:2].max()), "max_abs_diff_row": float(d.max()),
+                    "max_rel_diff_row": float((d / ref.abs().clamp(min=1.0)).max()),
+                    "vs_fp32_path_max_rel": float(((lrows - r32).abs() / r32.abs().clamp(min=1.0)).max())}
+            if pi > 0:
+                lowp[mode_name] = entry
+        pipe.selector.cfg["math_mode"] = None
+        if lowp:
+            result["lowp"] = lowp
+        lanes = headline_lanes
+    except Exception as e:                 # a side measurement must not take the headline line with it
+        result.setdefault("side_leg_errors", {})["lowp"] = f"{type(e).__name__}: {e}"[:600]
+    finally:
+        pipe.selector.cfg["math_mode"] = None
+        lanes = headline_lanes
+        if lowp:
+            result["lowp"] = lowp
 
     # ---- reference-feature caching: the refiner's 6 reference crops per step skip the trunk + feature net when
     #      their (view, angle bucket) key repeats; in this workload the canned crops repeat in every step of every query (hit rate 1 after
     #      the first step), so this is the upper bound of what the cache buys.  Side number: the headline stays uncached.
-    if use_graph and world == 1 and not args.no_cached:
-        pipe.capture(lanes=lanes, batch=B, cached_refs=True)
-        lane_busy[:] = [None] * lanes
-        for i in range(args.warmup):
-            step(i)
-        drain(); torch.cuda.synchronize()
-        nl = 2 * args.steps
-        t1 = time.perf_counter()
-        crows = [step(args.warmup + i) for i in range(nl)]
-        drain(); torch.cuda.synchronize()
-        cdt = time.perf_counter() - t1
-        crows = torch.cat(crows[:args.steps], 0).cpu()
-        r_ = pipe.ref_dev
-        def t_step(cached):
-            qc = crops[0:1]
-            fn = lambda: pipe.refiner._step(qc, r_["Ks_in"][0], pipe.iter_poses[0][0], r_["ref_imgs"][0], r_["ref_Ks"][0], r_["ref_poses"][0],
-                                            ref_feats=pipe.ref_feats if cached else None)
-            with torch.no_grad():
-                fn(); fn()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                torch.cuda.synchronize(); e0.record()
-                for _ in range(5): fn()
-                e1.record(); torch.cuda.synchronize()
-            return e0.elapsed_time(e1) / 5
-        result["cached"] = {
-            "value": nl * B / cdt, "unit": "images/s", "ms_per_step": cdt / nl * 1e3, "queries": nl * B, "hit_rate": 1.0,
-            "what": "same launch mode with the refiner's reference-crop features cached per (view, in-plane angle bucket): only the query "
-                    "crop passes the trunk + feature net in each of the 3 steps; upper bound (every key repeats in this workload)",
-            "refiner_step_ms_single_query": {"uncached": t_step(False), "cached": t_step(True)},
-            "rows_vs_uncached_max_rel": float(((crows - got_rows[:crows.shape[0]]).abs() / got_rows[:crows.shape[0]].abs().clamp(min=1.0)).max())}
+    try:
+        if use_graph and world == 1 and not args.no_cached:
+            pipe.capture(lanes=lanes, batch=B, cached_refs=True)
+            lane_busy[:] = [None] * lanes
+            for i in range(args.warmup):
+                step(i)
+            drain(); torch.cuda.synchronize()
+            nl = 2 * args.steps
+            t1 = time.perf_counter()
+            crows = [step(args.warmup + i) for i in range(nl)]
+            drain(); torch.cuda.synchronize()
+            cdt = time.perf_counter() - t1
+            crows = torch.cat(crows[:args.steps], 0).cpu()
+            r_ = pipe.ref_dev
+            def t_step(cached):
+                qc = crops[0:1]
+                fn = lambda: pipe.refiner._step(qc, r_["Ks_in"][0], pipe.iter_poses[0][0], r_["ref_imgs"][0], r_["ref_Ks"][0], r_["ref_poses"][0],
+                                                ref_feats=pipe.ref_feats if cached else None)
+                with torch.no_grad():
+                    fn(); fn()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    torch.cuda.synchronize(); e0.record()
+                    for _ in range(5): fn()
+                    e1.record(); torch.cuda.synchronize()
+                return e0.elapsed_time(e1) / 5
+            result["cached"] = {
+                "value": nl * B / cdt, "unit": "images/s", "ms_per_step": cdt / nl * 1e3, "queries": nl * B, "hit_rate": 1.0,
+                "what": "same launch mode with the refiner's reference-crop features cached per (view, in-plane angle bucket): only the query "
+                        "crop passes the trunk + feature net in each of the 3 steps; upper bound (every key repeats in this workload)",
+                "refiner_step_ms_single_query": {"uncached": t_step(False), "cached": t_step(True)},
+                "rows_vs_uncached_max_rel": float(((crows - got_rows[:crows.shape[0]]).abs() / got_rows[:crows.shape[0]].abs().clamp(min=1.0)).max())}
+    except Exception as e:                 # a side measurement must not take the headline line with it
+        result.setdefault("side_leg_errors", {})["cached"] = f"{type(e).__name__}: {e}"[:600]
 
-    if not args.no_chained and world == 1 and rank == 0:
-        # the estimator-level path: the crop fed to the selector comes from the detection, the refiner inputs from the pose of
-        # the previous stage (bench headline: canned crops / poses)
-        from gen6d_amd.estimator import Gen6DEstimator
-        from gen6d_amd.synth_db import SyntheticDatabase
-        tb = time.perf_counter()
-        db = SyntheticDatabase(n_views=88, size=(480, 640), focal=560.0)
-        # the refiner of this leg has its pose heads damped towards the identity update (synth.damp_refiner_head), as a trained
-        # refiner's are: with the seeded random heads a single grey level of a crop moves the pose by 1e-2 and step-to-step
-        # comparisons say nothing.  Same layers, same launches, same cost.
-        from gen6d_amd.network import name2network
-        ref_d = name2network["refiner"]({"name": "refiner_synth_damped"})
-        ref_d.load_state_dict(synth.damp_refiner_head(pipe.state_dicts["refiner"]))
-        ref_d.to(dev).eval()
-        est = Gen6DEstimator({"ref_view_num": args.sel_refs, "det_ref_view_num": args.det_refs, "refine_iter": 3},
-                             modules={"detector": pipe.detector, "selector": pipe.selector, "refiner": ref_d})
-        est.build(db, "all")
-        torch.cuda.synchronize()
-        cbuild = time.perf_counter() - tb
-        _, qids = db.get_split("all")
-        imgs = [torch.from_numpy(db.get_image(i)).to(dev) for i in qids[:8]]
-        Ks = [db.get_K(i) for i in qids[:8]]
-        n_c = max(3 * args.steps, 24)
-        qi = [imgs[i % 8] for i in range(n_c + lanes)]
-        qk = [Ks[i % 8] for i in range(n_c + lanes)]
-        chain = est.device_chain()
-        clanes = min(lanes, 3)
-        cb = min(B, args.chain_batch, 8)  # queries per captured chain graph (they share every launch)
-        n_c = max(n_c, 6 * cb * clanes)
-        qi = [imgs[i % 8] for i in range(n_c)]
-        qk = [Ks[i % 8] for i in range(n_c)]
-        chain.predict_many(qi[:cb * clanes], qk[:cb * clanes], clanes, batch=cb)              # capture + warm-up
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        res = chain.predict_many(qi[:n_c], qk[:n_c], clanes, batch=cb)
-        cdt = time.perf_counter() - t1
-        _, inter_h = est.predict(imgs[0], Ks[0])                      # the host-driven path (numpy pose algebra, 5+ syncs per query)
-        _, inter_d = est.predict_device(imgs[0], Ks[0])               # the same query through the eager device chain
-        # every refine step of the device chain on the HOST path's input pose of that step (the chain's tracking entry: pose_init,
-        # one step): per-step agreement without the free-running accumulation — the crops are uint8 (rint of the bilinear warp, as
-        # cv2 returns them), so a 1e-6 pose difference flips single grey levels of the next crops and the randomly initialised
-        # feature net answers a flipped grey level with 1e-4 ... 1e-3 on the pose even behind damped heads
-        forced = []
-        K0 = torch.from_numpy(np.ascontiguousarray(Ks[0], dtype=np.float32)).to(dev)
-        for k_ in range(len(inter_h["refine_poses"]) - 1):
-            o_ = chain.query(imgs[0], K0, pose_init=torch.from_numpy(np.ascontiguousarray(inter_h["refine_poses"][k_], dtype=np.float32)), refine_iter=1)
-            forced.append(float(np.abs(o_["pose"].cpu().numpy() - inter_h["refine_poses"][k_ + 1]).max()))
-        result["chained"] = {"value": n_c / cdt, "unit": "images/s", "ms_per_query": cdt / n_c * 1e3, "queries": n_c, "lanes": clanes, "batch": cb,
-                             "database": "procedural sphere, 66 reference views 480x640, 64/32 selected; build incl. rendering "
-                                         f"{cbuild:.1f} s", "finite": bool(all(np.isfinite(p).all() for p, _ in res)),
-                             "vs_host_driven_predict": {
-                                 "same_viewpoint": bool(inter_d["sel_ref_idx"] == inter_h["sel_ref_idx"]),
-                                 "pose_from_detection_and_selection_maxabs": float(np.abs(inter_d["refine_poses"][0] - inter_h["refine_poses"][0]).max()),
-                                 "after_refine_step_maxabs": [float(np.abs(inter_d["refine_poses"][i] - inter_h["refine_poses"][i]).max())
-                                                              for i in range(1, len(inter_h["refine_poses"]))],
-                                 "final_pose_maxabs": float(np.abs(inter_d["refine_poses"][-1] - inter_h["refine_poses"][-1]).max()),
-                                 "each_step_on_the_host_paths_input_pose_maxabs": forced, "each_step_ok": bool(max(forced) <= 1e-4),
-                                 "graph_replay_vs_eager_chain_maxabs": float(np.abs(res[0][0] - inter_d["refine_poses"][-1]).max()),
-                                 "bar": 1e-4, "note": "pose heads damped towards the identity (synth.damp_refiner_head); `each_step_...` holds the bar (every step on "
-                                 "identical inputs); the free-running `after_refine_step_maxabs` grows from step 2 on because uint8 crops turn a 1e-6 pose "
-                                 "difference into flipped grey levels, which the random feature net amplifies (the graph-replayed batch differs from the "
-                                 "eager single query by the same mechanism: other split choices, 1e-6, flipped pixels)"}}
+    try:
+        if not args.no_chained and world == 1 and rank == 0:
+            # the estimator-level path: the crop fed to the selector comes from the detection, the refiner inputs from the pose of
+            # the previous stage (bench headline: canned crops / poses)
+            from gen6d_amd.estimator import Gen6DEstimator
+            from gen6d_amd.synth_db import SyntheticDatabase
+            tb = time.perf_counter()
+            db = SyntheticDatabase(n_views=88, size=(480, 640), focal=560.0)
+            # the refiner of this leg has its pose heads damped towards the identity update (synth.damp_refiner_head), as a trained
+            # refiner's are: with the seeded random heads a single grey level of a crop moves the pose by 1e-2 and step-to-step
+            # comparisons say nothing.  Same layers, same launches, same cost.
+            from gen6d_amd.network import name2network
+            ref_d = name2network["refiner"]({"name": "refiner_synth_damped"})
+            ref_d.load_state_dict(synth.damp_refiner_head(pipe.state_dicts["refiner"]))
+            ref_d.to(dev).eval()
+            est = Gen6DEstimator({"ref_view_num": args.sel_refs, "det_ref_view_num": args.det_refs, "refine_iter": 3},
+                                 modules={"detector": pipe.detector, "selector": pipe.selector, "refiner": ref_d})
+            est.build(db, "all")
+            torch.cuda.synchronize()
+            cbuild = time.perf_counter() - tb
+            _, qids = db.get_split("all")
+            imgs = [torch.from_numpy(db.get_image(i)).to(dev) for i in qids[:8]]
+            Ks = [db.get_K(i) for i in qids[:8]]
+            n_c = max(3 * args.steps, 24)
+            qi = [imgs[i % 8] for i in range(n_c + lanes)]
+            qk = [Ks[i % 8] for i in range(n_c + lanes)]
+            chain = est.device_chain()
+            clanes = min(lanes, 3)
+            cb = min(B, args.chain_batch, 8)  # queries per captured chain graph (they share every launch)
+            n_c = max(n_c, 6 * cb * clanes)
+            qi = [imgs[i % 8] for i in range(n_c)]
+            qk = [Ks[i % 8] for i in range(n_c)]
+            chain.predict_many(qi[:cb * clanes], qk[:cb * clanes], clanes, batch=cb)              # capture + warm-up
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            res = chain.predict_many(qi[:n_c], qk[:n_c], clanes, batch=cb)
+            cdt = time.perf_counter() - t1
+            _, inter_h = est.predict(imgs[0], Ks[0])                      # the host-driven path (numpy pose algebra, 5+ syncs per query)
+            _, inter_d = est.predict_device(imgs[0], Ks[0])               # the same query through the eager device chain
+            # every refine step of the device chain on the HOST path's input pose of that step (the chain's tracking entry: pose_init,
+            # one step): per-step agreement without the free-running accumulation — the crops are uint8 (rint of the bilinear warp, as
+            # cv2 returns them), so a 1e-6 pose difference flips single grey levels of the next crops and the randomly initialised
+            # feature net answers a flipped grey level with 1e-4 ... 1e-3 on the pose even behind damped heads
+            forced = []
+            K0 = torch.from_numpy(np.ascontiguousarray(Ks[0], dtype=np.float32)).to(dev)
+            for k_ in range(len(inter_h["refine_poses"]) - 1):
+                o_ = chain.query(imgs[0], K0, pose_init=torch.from_numpy(np.ascontiguousarray(inter_h["refine_poses"][k_], dtype=np.float32)), refine_iter=1)
+                forced.append(float(np.abs(o_["pose"].cpu().numpy() - inter_h["refine_poses"][k_ + 1]).max()))
+            result["chained"] = {"value": n_c / cdt, "unit": "images/s", "ms_per_query": cdt / n_c * 1e3, "queries": n_c, "lanes": clanes, "batch": cb,
+                                 "database": "procedural sphere, 66 reference views 480x640, 64/32 selected; build incl. rendering "
+                                             f"{cbuild:.1f} s", "finite": bool(all(np.isfinite(p).all() for p, _ in res)),
+                                 "vs_host_driven_predict": {
+                                     "same_viewpoint": bool(inter_d["sel_ref_idx"] == inter_h["sel_ref_idx"]),
+                                     "pose_from_detection_and_selection_maxabs": float(np.abs(inter_d["refine_poses"][0] - inter_h["refine_poses"][0]).max()),
+                                     "after_refine_step_maxabs": [float(np.abs(inter_d["refine_poses"][i] - inter_h["refine_poses"][i]).max())
+                                                                  for i in range(1, len(inter_h["refine_poses"]))],
+                                     "final_pose_maxabs": float(np.abs(inter_d["refine_poses"][-1] - inter_h["refine_poses"][-1]).max()),
+                                     "each_step_on_the_host_paths_input_pose_maxabs": forced, "each_step_ok": bool(max(forced) <= 1e-4),
+                                     "graph_replay_vs_eager_chain_maxabs": float(np.abs(res[0][0] - inter_d["refine_poses"][-1]).max()),
+                                     "bar": 1e-4, "note": "pose heads damped towards the identity (synth.damp_refiner_head); `each_step_...` holds the bar (every step on "
+                                     "identical inputs); the free-running `after_refine_step_maxabs` grows from step 2 on because uint8 crops turn a 1e-6 pose "
+                                     "difference into flipped grey levels, which the random feature net amplifies (the graph-replayed batch differs from the "
+                                     "eager single query by the same mechanism: other split choices, 1e-6, flipped pixels)"}}
+    except Exception as e:                 # a side measurement must not take the headline line with it
+        result.setdefault("side_leg_errors", {})["chained"] = f"{type(e).__name__}: {e}"[:600]
 
-    if not args.no_sweep and world == 1 and use_graph and (args.sel_refs, args.det_refs) == (64, 32):
-        sw = ref_sweep(dev, B, headline_lanes, max(6, args.steps // 2), max(2, args.warmup // 2))
-        sw["64x5"] = {"workload": "the headline of this line", "value": result["value"], "unit": "images/s",
-                      "roofline": {"winograd": {"achieved_TFLOPs_executed": fams.get("winograd", {}).get("achieved"),
-                                                "frac_of_fp32_mfma_peak": fams.get("winograd", {}).get("frac")}}}
-        result["sweep"] = sw
+    try:
+        if not args.no_sweep and world == 1 and use_graph and (args.sel_refs, args.det_refs) == (64, 32):
+            sw = ref_sweep(dev, B, headline_lanes, max(6, args.steps // 2), max(2, args.warmup // 2))
+            sw["64x5"] = {"workload": "the headline of this line", "value": result["value"], "unit": "images/s",
+                          "roofline": {"winograd": {"achieved_TFLOPs_executed": fams.get("winograd", {}).get("achieved"),
+                                                    "frac_of_fp32_mfma_peak": fams.get("winograd", {}).get("frac")}}}
+            result["sweep"] = sw
+            ops.SERIAL = no_fork
+    except Exception as e:                 # a side measurement must not take the headline line with it
+        result.setdefault("side_leg_errors", {})["sweep"] = f"{type(e).__name__}: {e}"[:600]
+    finally:
         ops.SERIAL = no_fork
 
     def row_diff(got, ref):
@@ -688,57 +706,60 @@ def main():
         worst["source"] = "tests/golden/pipeline_rows.npz (outputs of the reference's own PyTorch-CPU modules)"
         result["parity_vs_reference"] = worst
 
-    if world == 1 and not args.no_cpu_baseline:
-        # BASELINE.md §3 protocol: threads = physical cores, 1 warm-up + min of >= 3 runs, torch.std share split out
-        from oracle import gen6d_oracle as GO
-        from oracle import pipeline_oracle as PO
-        try:
-            import psutil
-            cores = psutil.cpu_count(logical=False) or torch.get_num_threads()
-        except ImportError:
-            cores = torch.get_num_threads()
-        st = PO.build_state(pipe.state_dicts, pipe.det_refs, pipe.sel_case)
-        iter_poses = [p.cpu() for p in pipe.iter_poses]
-        j0 = images_of(args.warmup)[0]                # the image of the first timed row
-        qf, qc = fulls[j0:j0 + 1].cpu(), crops[j0:j0 + 1].cpu()
+    try:
+        if world == 1 and not args.no_cpu_baseline:
+            # BASELINE.md §3 protocol: threads = physical cores, 1 warm-up + min of >= 3 runs, torch.std share split out
+            from oracle import gen6d_oracle as GO
+            from oracle import pipeline_oracle as PO
+            try:
+                import psutil
+                cores = psutil.cpu_count(logical=False) or torch.get_num_threads()
+            except ImportError:
+                cores = torch.get_num_threads()
+            st = PO.build_state(pipe.state_dicts, pipe.det_refs, pipe.sel_case)
+            iter_poses = [p.cpu() for p in pipe.iter_poses]
+            j0 = images_of(args.warmup)[0]                # the image of the first timed row
+            qf, qc = fulls[j0:j0 + 1].cpu(), crops[j0:j0 + 1].cpu()
 
-        def one_run():
-            GO.TIMERS = {}
-            stage_s = {}
-            t1 = time.perf_counter()
-            r_, _ = PO.query(pipe.state_dicts, st, pipe.ref_case, iter_poses, qf, qc, stage_s)
-            return time.perf_counter() - t1, stage_s, GO.TIMERS.get("refiner_std", 0.0), r_
+            def one_run():
+                GO.TIMERS = {}
+                stage_s = {}
+                t1 = time.perf_counter()
+                r_, _ = PO.query(pipe.state_dicts, st, pipe.ref_case, iter_poses, qf, qc, stage_s)
+                return time.perf_counter() - t1, stage_s, GO.TIMERS.get("refiner_std", 0.0), r_
 
-        # The oracle is a PORT of the reference's PyTorch-CPU path (the reference itself is not on this box).  torch's CPU kernels
-        # do not scale to every core of a large host (round 2: 128 threads were SLOWER than 8), so the baseline is the best thread
-        # count of a short sweep: one run per candidate after a common warm-up, then min of `--cpu-reps` runs at the winner.
-        cands = [args.cpu_threads] if args.cpu_threads > 0 else sorted({t for t in (8, 16, 32, 64, cores) if t <= cores})
-        torch.set_num_threads(cands[-1])
-        one_run()                                     # warm-up (allocator, oneDNN primitive caches)
-        sweep = {}
-        for t in cands:
-            torch.set_num_threads(t)
-            sweep[t] = one_run()[0]
-        best_t = min(sweep, key=sweep.get)
-        torch.set_num_threads(best_t)
-        runs, stage_runs, std_runs = [], [], []
-        row = None
-        for rep in range(max(1, args.cpu_reps - 1)):
-            dt_rep, stage_s, std_s, row = one_run()
-            runs.append(dt_rep); stage_runs.append(stage_s); std_runs.append(std_s)
-        GO.TIMERS = None
-        best = min(range(len(runs)), key=lambda i: runs[i])
-        cpu_dt = min(runs[best], sweep[best_t])
-        result["cpu_baseline"] = {
-            "value": 1.0 / cpu_dt, "unit": "images/s", "cores": best_t, "kind": "port",
-            "sample": f"1 query of the same workload (image {j0}) through oracle/ (torch CPU fp32, a port of the reference's PyTorch-CPU "
-                      f"path: the reference itself is not on this box), reference state prebuilt; 1 warm-up, one run per thread count "
-                      f"{cands}, then min of {len(runs) + 1} runs at the best count ({best_t} of {cores} physical cores)",
-            "seconds": cpu_dt, "thread_sweep_s": {str(k): v for k, v in sweep.items()}, "physical_cores": cores, "runs": len(runs) + 1,
-            "stages_s": stage_runs[best], "torch_std_s": std_runs[best],
-            "value_without_torch_std": 1.0 / max(cpu_dt - std_runs[best], 1e-9),
-            "note": "reported baseline, not the target: the GPU/CPU ratio says nothing about kernel quality (see roofline)"}
-        result["parity_vs_cpu"] = row_diff(got_rows[0], row[0])
+            # The oracle is a PORT of the reference's PyTorch-CPU path (the reference itself is not on this box).  torch's CPU kernels
+            # do not scale to every core of a large host (round 2: 128 threads were SLOWER than 8), so the baseline is the best thread
+            # count of a short sweep: one run per candidate after a common warm-up, then min of `--cpu-reps` runs at the winner.
+            cands = [args.cpu_threads] if args.cpu_threads > 0 else sorted({t for t in (8, 16, 32, 64, cores) if t <= cores})
+            torch.set_num_threads(cands[-1])
+            one_run()                                     # warm-up (allocator, oneDNN primitive caches)
+            sweep = {}
+            for t in cands:
+                torch.set_num_threads(t)
+                sweep[t] = one_run()[0]
+            best_t = min(sweep, key=sweep.get)
+            torch.set_num_threads(best_t)
+            runs, stage_runs, std_runs = [], [], []
+            row = None
+            for rep in range(max(1, args.cpu_reps - 1)):
+                dt_rep, stage_s, std_s, row = one_run()
+                runs.append(dt_rep); stage_runs.append(stage_s); std_runs.append(std_s)
+            GO.TIMERS = None
+            best = min(range(len(runs)), key=lambda i: runs[i])
+            cpu_dt = min(runs[best], sweep[best_t])
+            result["cpu_baseline"] = {
+                "value": 1.0 / cpu_dt, "unit": "images/s", "cores": best_t, "kind": "port",
+                "sample": f"1 query of the same workload (image {j0}) through oracle/ (torch CPU fp32, a port of the reference's PyTorch-CPU "
+                          f"path: the reference itself is not on this box), reference state prebuilt; 1 warm-up, one run per thread count "
+                          f"{cands}, then min of {len(runs) + 1} runs at the best count ({best_t} of {cores} physical cores)",
+                "seconds": cpu_dt, "thread_sweep_s": {str(k): v for k, v in sweep.items()}, "physical_cores": cores, "runs": len(runs) + 1,
+                "stages_s": stage_runs[best], "torch_std_s": std_runs[best],
+                "value_without_torch_std": 1.0 / max(cpu_dt - std_runs[best], 1e-9),
+                "note": "reported baseline, not the target: the GPU/CPU ratio says nothing about kernel quality (see roofline)"}
+            result["parity_vs_cpu"] = row_diff(got_rows[0], row[0])
+    except Exception as e:                 # a side measurement must not take the headline line with it
+        result.setdefault("side_leg_errors", {})["cpu_baseline"] = f"{type(e).__name__}: {e}"[:600]
     print(json.dumps(result))
 
 

@@ -322,7 +322,13 @@ class ViewpointSelector(ParamBank):
 
     def _compute_view_point_feats_fp(self, que_imgs):
         """que_imgs [qn,3,h,w] in [0,1] -> logits [qn,rfn], angles [qn,rfn] (reference selector.py:177-215)."""
-        step = MAX_BATCH                               # the queries of a chunk share every launch (and, sharded, every collective)
+        # the queries of a chunk share every launch (and, sharded, every collective); a chunk's largest tensor — the first conv's output
+        # [qn * D, h0, w0, 64] — has to stay below the 2^31-byte reach of the kernels' buffer loads (64 x 36 rotations: 14 -> 8 queries)
+        c0 = self.ref_feats_cache[0]
+        per_query = c0.shape[0] * c0.shape[2] * c0.shape[3] * 64 * 4
+        step = max(1, min(MAX_BATCH, ((1 << 31) - 1) // per_query))
+        if step >= 8:
+            step -= step % 8                           # whole groups of 8 for g6d_selector_levels
         outs = [self._query_batch(que_imgs[i:i + step].contiguous()) for i in range(0, que_imgs.shape[0], step)]
         return torch.cat([o[0] for o in outs], 0), torch.cat([o[1] for o in outs], 0)
 
