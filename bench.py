@@ -689,7 +689,9 @@ def main():
 
     # parity of EVERY timed row (graph replay, `lanes` queries in flight) against the reference's own modules: the rows of
     # the four synthetic queries were produced from /root/reference by tests/golden/make_golden_r02.py (pipeline_rows.npz)
-    default_cfg = (args.sel_refs, args.det_refs) == (64, 32) and not shard_refs
+    # (reference-sharded runs draw the same four queries on every rank: their rows are held to the same golden rows — the sharded sums
+    # differ from the unsharded ones by fp reassociation only)
+    default_cfg = (args.sel_refs, args.det_refs) == (64, 32)
     if default_cfg and os.path.exists(gpath):
         gold = torch.from_numpy(np.load(gpath)["rows"]).float()
         worst = {"ref_idx_equal": True, "max_abs_diff_row": 0.0, "max_rel_diff_row": 0.0}

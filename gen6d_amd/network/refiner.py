@@ -25,6 +25,10 @@ from .params import ParamBank, fold_vgg
 # F(2x2,3x3); at batch 8: 1.06 vs 1.43 ms and 1.96 vs 3.06 ms the other way round)
 F43_MIN_QUERIES = 4
 TRUNK_F43 = True        # the crops' VGG trunk on the F(4x4,3x3) kernel (1.31-1.35x over F(2x2,3x3) at 56 crops, profiles/r04_w43_bench_v5.md)
+# feature-net layers (name, index in the Sequential) that carry F(4x4,3x3) filters — measured per layer at 56 crops against F(2x2,3x3)
+# (profiles/r04_layer_table_featnet_f43.md): 512->256 @16x16 159 vs 173 us, 192->128 @32x32 119 vs 148, 128->128 @32x32 107 vs 129 kept;
+# 256->64 @32x32 131 vs 94, 256->64 @16x16 88 vs 60, 512->256 @8x8 108 vs 80 stay on F(2x2,3x3)
+FEATNET_F43_LAYERS = {("conv1", 0), ("conv_out", 0), ("conv_out", 3)}
 VOLUME_F43 = True
 VOLUME_F43_LAYERS = ("conv0",)          # measured per batch of 8: conv2 (16^3) 147 vs 151 us, conv4 (8^3) 144 vs 94 us on F(2x2,3x3): only 32^3 pays
 MAX_BATCH = 32         # queries that share one set of launches (g6d_linear_gemv_batch: 8 right-hand sides per weight pass)
@@ -119,7 +123,7 @@ class VolumeRefiner(ParamBank):
         if self._packed is None:
             pk = {"vgg": pack_trunk(fold_vgg(self, "feature_net.backbone.features"))}
             for name in ("conv0", "conv1", "conv2", "conv_out"):
-                pk[name] = [self.conv_w(f"feature_net.{name}.{i}", wino_kd=1) for i in (0, 3)]
+                pk[name] = [self.conv_w(f"feature_net.{name}.{i}", wino_kd=1, f43=(name, i) in FEATNET_F43_LAYERS) for i in (0, 3)]
             # the 32^3 volume layers (mean_embed, var_embed, conv0) also carry F(4x4,3x3) filters (VOLUME_F43): 1.4-1.5x faster there
             # at 1.3-3.4e-6 of the layer's range (profiles/r04_w43_bench_v5.md)
             for name in ("mean_embed", "var_embed", "conv5"):         # conv5 works on 8^3 -> 4^3 maps: never on the Winograd kernel
@@ -150,14 +154,16 @@ class VolumeRefiner(ParamBank):
             """conv, IN, ReLU, conv, (IN returned as affine) — per-image statistics."""
             (w0, b0), (w1, b1) = pk[name]
             u0, u1 = pk[name][0].u, pk[name][1].u
+            big = n >= F43_MIN_QUERIES * 7                           # F(4x4,3x3) filters only from 4 queries per launch on
+            v0, v1 = (pk[name][0].u43, pk[name][1].u43) if big else (None, None)
             _, _, hh, ww, _ = x.shape
             y0 = torch.empty((n, 1, hh, ww, w0.shape[0]), dtype=torch.float32, device=dev)
             s0 = ops.new_stats(n, w0.shape[0], dev)
-            sc0, sh0 = ops.conv(x, w0, b0, y0, ksize=_K2, pad=_P2, stats=s0, rows_per_group=hh * ww, w_wino=u0, finalize=hh * ww)
+            sc0, sh0 = ops.conv(x, w0, b0, y0, ksize=_K2, pad=_P2, stats=s0, rows_per_group=hh * ww, w_wino=u0, w_wino43=v0, finalize=hh * ww)
             y1 = torch.empty((n, 1, hh, ww, w1.shape[0]), dtype=torch.float32, device=dev)
             s1 = ops.new_stats(n, w1.shape[0], dev)
             sc1, sh1 = ops.conv(y0, w1, b1, y1, ksize=_K2, pad=_P2, in_scale=sc0, in_shift=sh0, in_relu=True, per_n=True,
-                                stats=s1, rows_per_group=hh * ww, w_wino=u1, finalize=hh * ww)
+                                stats=s1, rows_per_group=hh * ww, w_wino=u1, w_wino43=v1, finalize=hh * ww)
             return y1, sc1, sh1
 
         hq, wq = h // 4, w // 4
