@@ -139,12 +139,15 @@ __device__ __forceinline__ void at_row(const float (&m)[6], float (&y)[4]) {
 // MODE  operand prologue applied when the raw patch is written to LDS: 0 none, 1 InstanceNorm affine (+ReLU) with one table,
 //       2 one table per image group (image / aff_div; LDS holds the tables of the block's eight quarters); zero padding stays zero
 // KD    1: 2-D layer; 3: 3x3x3 layer, depth taps folded into the reduction (chunk = (kd, 8 channels) reads slice d + kd - 1);
-//       25: 15x15 "same" correlation as 5x5 blocks of 3x3 (chunk = (8 channels, block), block shifts innermost)
+//       25: 15x15 "same" correlation as 5x5 blocks of 3x3 (chunk = (8 channels, block), block shifts innermost); 9: 9x9 as 3x3 blocks
+//       (the detector's 7x7 level, zero-extended by one tap on every side)
 // NT    output channels of a block in 16s (4 or 2)
 template <int MODE, int KD, int NT>
 __global__ void __launch_bounds__(256, 1) wino43_kernel(const W43Args p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int THREADS = 256, NQ = W43_NQ;
+  constexpr int KB = KD == 25 ? 5 : (KD == 9 ? 3 : 0);     // correlation: the 3 KB x 3 KB "same" filter cut into KB x KB blocks of 3x3 (KD = KB^2)
+  constexpr bool CORR = KB > 0;
   constexpr int RAWF = W43_RAWF;                            // 28 wave-instructions of 64 16-byte slots (the image itself ends at slot 1616)
   constexpr int HALF = 18 * 16 * NT * 8;                    // floats of one filter half-slot: [18 positions][16 NT channels][8]
   constexpr int FLT0 = 2 * RAWF;                            // two raw stages, then two filter slots, then the affine tables
@@ -170,8 +173,8 @@ __global__ void __launch_bounds__(256, 1) wino43_kernel(const W43Args p) {
   int poff[NPR], aoff[MODE != 0 ? NPR : 1];
   bool pval[NPR];
   unsigned dbits = 0;                                          // KD = 3: bit 2j / 2j+1 = piece j has a slice below / above
-  unsigned smask[KD == 25 ? NPR : 1];                          // KD = 25: bits 0-4 / 8-12 = row / column of the piece inside the image under block shift b
-  int rstep[KD == 25 ? NPR : 1];
+  unsigned smask[CORR ? NPR : 1];                              // correlation: bits 0-4 / 8-12 = row / column of the piece inside the image under block shift b
+  int rstep[CORR ? NPR : 1];
 #pragma unroll
   for (int j = 0; j < NPR; ++j) {
     const int sl = (wave * NPR + j) * 64 + lane;
@@ -186,11 +189,11 @@ __global__ void __launch_bounds__(256, 1) wino43_kernel(const W43Args p) {
     poff[j] = pval[j] ? g.in_off + ((n * g.H + iy) * g.W + ix) * g.ld_in + 4 * half : 0;
     if constexpr (MODE != 0) aoff[j] = (MODE >= 2 ? (live ? q : 0) * p.Cin : 0) + 4 * half;
     if constexpr (KD == 3) { const int dd = n % p.D; dbits |= (unsigned)(dd > 0) << (2 * j) | (unsigned)(dd < p.D - 1) << (2 * j + 1); }
-    if constexpr (KD == 25) {
+    if constexpr (CORR) {
       unsigned m = 0;
 #pragma unroll
-      for (int b = 0; b < 5; ++b)
-        m |= (unsigned)((unsigned)(iy + 3 * b - 6) < (unsigned)g.H) << b | (unsigned)((unsigned)(ix + 3 * b - 6) < (unsigned)g.W) << (8 + b);
+      for (int b = 0; b < KB; ++b)
+        m |= (unsigned)((unsigned)(iy + 3 * b - 3 * (KB / 2)) < (unsigned)g.H) << b | (unsigned)((unsigned)(ix + 3 * b - 3 * (KB / 2)) < (unsigned)g.W) << (8 + b);
       smask[j] = (live & g.valid) ? m : 0u;
       rstep[j] = 3 * g.W * g.ld_in;
       poff[j] = g.in_off + ((n * g.H + iy) * g.W + ix) * g.ld_in + 4 * half;      // the UNSHIFTED position (used under smask only)
@@ -209,17 +212,17 @@ __global__ void __launch_bounds__(256, 1) wino43_kernel(const W43Args p) {
   // piece j of chunk `chunk` -> rp[j] (the LDS image is written by store_piece, where the MODE != 0 prologue runs)
   auto load_piece = [&](int j, int chunk) {
     if (W43ABL(2)) return;
-    const int kd = KD == 25 ? chunk % 25 : (KD != 1 ? chunk / nc8 : 0), cc = KD == 25 ? chunk / 25 : (KD != 1 ? chunk - kd * nc8 : chunk);
+    const int kd = CORR ? chunk % KD : (KD != 1 ? chunk / nc8 : 0), cc = CORR ? chunk / KD : (KD != 1 ? chunk - kd * nc8 : chunk);
     unsigned voff; int soff = 0;
     if constexpr (KD == 1) { voff = pboff[j]; soff = cc * 32; if constexpr (MODE != 0) rv[j] = pval[j]; }
     else {
       bool v = pval[j];
       int off = poff[j] + cc * 8;
       if constexpr (KD == 3) { v &= kd == 1 || ((dbits >> (2 * j + (kd >> 1))) & 1u) != 0; off += (kd - 1) * slice; }
-      if constexpr (KD == 25) {
-        const int bi = kd / 5, bj = kd - 5 * bi;
+      if constexpr (CORR) {
+        const int bi = kd / KB, bj = kd - KB * bi;
         v = ((smask[j] >> bi) & (smask[j] >> (8 + bj)) & 1u) != 0;
-        off += (bi - 2) * rstep[j] + (bj - 2) * 3 * p.ld0;
+        off += (bi - KB / 2) * rstep[j] + (bj - KB / 2) * 3 * p.ld0;
       }
       if constexpr (MODE != 0) rv[j] = v;
       voff = v ? (unsigned)off << 2 : 0x80000000u;
@@ -652,6 +655,7 @@ int w43_run(W43Args& a, int mode, int kd, float* workspace, size_t workspace_byt
   if (debug) fprintf(stderr, "wino43 %d seg, %dx%dx%d->%d kd=%d mode=%d: grid %lld x %d splits of %d chunks\n", a.nseg, a.seg[0].H, a.seg[0].W, a.Cin,
                      a.Cout, kd, mode, grid2, splits, cps);
   if (kd == 25) return nt == 4 ? w43_launch_t<0, 25, 4>(a, blocks, stream) : w43_launch_t<0, 25, 2>(a, blocks, stream);
+  if (kd == 9) return nt == 4 ? w43_launch_t<0, 9, 4>(a, blocks, stream) : w43_launch_t<0, 9, 2>(a, blocks, stream);
   if (nt != 4) { g6d_set_error("wino43: Cout % 64 == 0 expected"); return G6D_EINVAL; }
   if (kd == 3) return mode == 2 ? w43_launch_t<2, 3, 4>(a, blocks, stream) : mode == 1 ? w43_launch_t<1, 3, 4>(a, blocks, stream) : w43_launch_t<0, 3, 4>(a, blocks, stream);
   if (mode == 2) return w43_launch_t<2, 1, 4>(a, blocks, stream);
@@ -699,13 +703,14 @@ extern "C" int g6d_wino43_conv3x3_multi(const G6dWinoSeg* segs, int nseg, int Ci
 }
 
 // The detector's 15x15 reference-as-filter correlation (network/detector.py:222-224) as 5x5 blocks of 3x3 sub-filters accumulated in
-// the F(4x4,3x3) transform domain: 225 taps cost 25 * 36 / 16 = 56.25 multiplications per output.  Maps as g6d_corr2d_wino_multi;
+// the F(4x4,3x3) transform domain: 225 taps cost 25 * 36 / 16 = 56.25 multiplications per output.  kblocks = 3: a 9x9 "same" correlation
+// as 3x3 blocks — the 7x7 level with its filters zero-extended by one tap on every side: 9 * 36 / 16 = 20.25 multiplications instead of 49.  Maps as g6d_corr2d_wino_multi;
 // U43 = the 25 sub-filter banks transformed like g6d_wino43_conv3x3_multi's, CHUNK-major: [Cin/8 * 25][2][Cout/CB][18][CB/32][4][16][4], row
 // c * 25 + b = 8-channel chunk c of block b = 5 bi + bj holding w[:, 3bi..3bi+2, 3bj..3bj+2, :]; Cout % 32 == 0.
 extern "C" int g6d_corr2d_wino43_multi(const G6dCorrSeg* segs, int nseg, int Cin, const float* U43, int Cout, int kblocks, float* workspace,
                                        size_t workspace_bytes, g6d_stream_t stream) {
-  if (!segs || nseg < 1 || nseg > W43_MAX_SEG || !U43 || kblocks != 5 || Cin <= 0 || (Cin & 7) || Cout <= 0 || (Cout & 31) || !g6d_aligned16(U43)) {
-    g6d_set_error("corr2d_wino43_multi: bad args (1..4 map sizes, 15x15 = 5 blocks, Cin % 8 == 0, Cout % 32 == 0)"); return G6D_EINVAL;
+  if (!segs || nseg < 1 || nseg > W43_MAX_SEG || !U43 || (kblocks != 5 && kblocks != 3) || Cin <= 0 || (Cin & 7) || Cout <= 0 || (Cout & 31) || !g6d_aligned16(U43)) {
+    g6d_set_error("corr2d_wino43_multi: bad args (1..4 map sizes, 15x15 = 5 blocks or 9x9 = 3 blocks, Cin % 8 == 0, Cout % 32 == 0)"); return G6D_EINVAL;
   }
   W43Args a = {};
   const float* in0 = segs[0].in; float* f0 = segs[0].out;

@@ -143,6 +143,19 @@ def winograd43_corr_filters(w_taps, k):
     return U.reshape(-1, *U.shape[2:]).contiguous()
 
 
+def winograd43_corr_filters_padded(w_taps, k):
+    """Correlation filters [Cout, k*k, Cin] with k NOT a multiple of 3 (the detector's 7x7 level): zero-extended symmetrically to the
+    next multiple of 3 (9x9: one tap on every side — the "same" correlation is unchanged) and cut into blocks like
+    winograd43_corr_filters.  Returns (U43, kblocks)."""
+    co, taps, ci = w_taps.shape
+    kb = (k + 2) // 3
+    e = 3 * kb - k
+    if taps != k * k or e % 2:
+        raise ValueError("winograd43_corr_filters_padded: odd k expected")
+    w = torch.nn.functional.pad(w_taps.reshape(co, k, k, ci), (0, 0, e // 2, e // 2, e // 2, e // 2))
+    return winograd43_corr_filters(w.reshape(co, 9 * kb * kb, ci).contiguous(), 3 * kb), kb
+
+
 class TrunkLayer(tuple):
     """(U, bias) of a Winograd trunk layer as the fp32 kernel takes them; `.u16(dtype)` = the 16-bit filters of the reduced-precision
     kernel, built from the folded fp32 weights on first use (ops.MATH_MODE 1 / 2)."""

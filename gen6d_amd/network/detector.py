@@ -16,7 +16,8 @@ import torch
 import torch.nn.functional as F
 
 from .. import ops, parallel, specs
-from .backbone import pack_trunk, trunk_features, trunk_features_multi, winograd_corr_filters, winograd43_corr_filters
+from .backbone import (pack_trunk, trunk_features, trunk_features_multi, winograd_corr_filters, winograd43_corr_filters,
+                       winograd43_corr_filters_padded)
 from .params import ParamBank, fold_vgg
 
 # Launch-structure switches; the product runs with all of them True, tools / tests flip the attribute for A/B runs:
@@ -27,6 +28,8 @@ CORR_WINO = True         # the 15x15 correlation level in the Winograd domain, 5
 # multiplications than F(2x2,3x3) at ~5x its rounding error — the detector holds ~4e-6 of the score range against the 1e-4 bar
 # (tests/test_parity_timed_gpu.py).  False: the F(2x2,3x3) kernels of round 3 (tools/ A/B runs and tests flip this attribute).
 F43 = True
+CORR7_F43 = True         # the 7x7 level as 3x3 blocks of 3x3 on zero-extended 9x9 filters in the F(4x4,3x3) domain (20.25 instead of 49
+                         # multiplications per output) when rfn % 32 == 0 and fp32; False: corr_patch
 MAX_BATCH = 16       # queries that share one set of launches: the pyramid's first layers address all scales of the batch with 32-bit
                      # offsets from one base (< 2^29 floats: 16 images of 480x640 at 64 channels; 32 would not fit)
 
@@ -48,6 +51,7 @@ class Detector(ParamBank):
         self.ref_center_feats = None     # three [rfn, k*k, 512] correlation filters
         self.ref_wino15 = None           # the 15x15 level's filters in the Winograd domain (winograd_corr_filters), F(2x2,3x3)
         self.ref_wino15_43 = None        # ... for the F(4x4,3x3) kernel (winograd43_corr_filters); one of the two is built
+        self.ref_wino7_43 = None         # the 7x7 level's filters, zero-extended to 9x9, for the F(4x4,3x3) kernel
         self.ref_shape = None
         self.rank, self.world, self.group = 0, 1, None
 
@@ -94,6 +98,8 @@ class Detector(ParamBank):
         ok15 = CORR_WINO and self.ref_ksize[0] == 15 and rfn % 32 == 0
         self.ref_wino15 = winograd_corr_filters(self.ref_center_feats[0], 15) if (ok15 and not F43) else None
         self.ref_wino15_43 = winograd43_corr_filters(self.ref_center_feats[0], 15) if (ok15 and F43) else None
+        ok7 = CORR_WINO and F43 and CORR7_F43 and self.ref_ksize[1] == 7 and rfn % 32 == 0
+        self.ref_wino7_43 = winograd43_corr_filters_padded(self.ref_center_feats[1], 7)[0] if ok7 else None
 
     # ------------------------------------------------------------------ detection
     def _scores_one_scale(self, que_img, scale_idx, stacked, hs, ws):
@@ -121,6 +127,9 @@ class Detector(ParamBank):
             if k == 15 and self.ref_wino15_43 is not None and ops.MATH_MODE == 0 and len(xs) <= 4:
                 outs = ops.alloc_like_segments([(qn, 1, x.shape[2], x.shape[3], rfn) for x in xs], dev)
                 ops.corr2d_wino43_multi([x.contiguous() for x in xs], self.ref_wino15_43, outs, 5)
+            elif k == 7 and self.ref_wino7_43 is not None and ops.MATH_MODE == 0 and len(xs) <= 4:
+                outs = ops.alloc_like_segments([(qn, 1, x.shape[2], x.shape[3], rfn) for x in xs], dev)
+                ops.corr2d_wino43_multi([x.contiguous() for x in xs], self.ref_wino7_43, outs, 3, k_true=7)
             elif k == 15 and self.ref_wino15 is not None and ops.MATH_MODE == 0 and len(xs) <= 4:
                 outs = ops.alloc_like_segments([(qn, 1, x.shape[2], x.shape[3], rfn) for x in xs], dev)
                 ops.corr2d_wino_multi([x.contiguous() for x in xs], self.ref_wino15, outs, 5)

@@ -589,9 +589,10 @@ def wino43_conv3x3_multi(xs, U43, bias, relu=True, full=True, pool=False):
     return ys, yps
 
 
-def corr2d_wino43_multi(xs, U43, outs, kblocks=5):
+def corr2d_wino43_multi(xs, U43, outs, kblocks=5, k_true=None):
     """corr2d_wino_multi on the F(4x4,3x3) kernel (g6d_corr2d_wino43_multi): U43 = backbone.winograd43_corr_filters(w, 15)
-    (shape w43_shape(kblocks^2 * Cin/8, Cout)), Cout % 32 == 0."""
+    (shape w43_shape(kblocks^2 * Cin/8, Cout)), Cout % 32 == 0.  kblocks = 3 with k_true = 7: the 7x7 level on zero-extended 9x9
+    filters (backbone.winograd43_corr_filters_padded; k_true only enters the profile's direct-form FLOP count)."""
     _need_gpu(U43, *xs, *outs)
     if not 1 <= len(xs) <= 4 or len(outs) != len(xs):
         raise ValueError("corr2d_wino43_multi: 1..4 map sizes")
@@ -609,6 +610,7 @@ def corr2d_wino43_multi(xs, U43, outs, kblocks=5):
         segs[i] = _lib.G6dCorrSeg(in_=x.data_ptr(), out=o.data_ptr(), H=H, W=W, ld_in=ld_in, ld_out=ld_out, N=N)
         flops += 2.0 * N * H * W * Cout * k * k * Cin
         sizes.append(f"{N}x{H}x{W}" if N > 1 else f"{H}x{W}")
+    kt = k_true or k
     ws = workspace(U43.device)
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -617,8 +619,8 @@ def corr2d_wino43_multi(xs, U43, outs, kblocks=5):
                "g6d_corr2d_wino43_multi")
     if PROFILE is not None:
         e1.record()
-        PROFILE.append((flops / 4, e0, e1, f"wino3x3 F43 corr multi in={'+'.join(sizes)}x{Cin} out={Cout} k={k}x{k} ({kblocks}x{kblocks} blocks of 3x3)",
-                        4.0 * (sum(x.numel() for x in xs) + sum(o.numel() for o in outs) + U43.numel()), flops))
+        PROFILE.append((flops / 4, e0, e1, f"wino3x3 F43 corr multi in={'+'.join(sizes)}x{Cin} out={Cout} k={kt}x{kt} ({kblocks}x{kblocks} blocks of 3x3)",
+                        4.0 * (sum(x.numel() for x in xs) + sum(o.numel() for o in outs) + U43.numel()), flops * kt * kt / (k * k)))
     return outs
 
 

@@ -217,7 +217,7 @@ def wino43_conv3x3_multi(xs, U43, bias, relu=True, full=True, pool=False):
     return ([r[0] for r in res] if full else None), ([r[1] for r in res] if pool else None)
 
 
-def corr2d_wino43_multi(xs, U43, outs, kblocks=5):
+def corr2d_wino43_multi(xs, U43, outs, kblocks=5, k_true=None):
     """As corr2d_wino_multi with the F(4x4,3x3) blocks of backbone.winograd43_corr_filters."""
     kb = kblocks
     for x, o in zip(xs, outs):

@@ -126,6 +126,34 @@ def test_corr2d_wino43_multi(ops, N, sizes, Cin, Cout):
             assert e <= 2e-5, f"rep {rep}: {e:.3e}; {_where(o[:, 0], ref[:, 0])}"
 
 
+@pytest.mark.parametrize("N,sizes,Cin,Cout", [(1, [(16, 16)], 8, 32), (3, [(22, 30), (9, 13)], 64, 32),
+                                              (2, [(44, 58), (30, 40), (22, 30), (16, 20)], 512, 32)])
+def test_corr2d_wino43_multi_7x7_on_9x9_blocks(ops, N, sizes, Cin, Cout):
+    """The 7x7 "same" correlation as 3x3 blocks of 3x3 on zero-extended 9x9 filters (kblocks = 3) against the fp64 direct 7x7 correlation."""
+    from gen6d_amd.network.backbone import winograd43_corr_filters_padded
+    g = torch.Generator().manual_seed(700 + Cin)
+    k = 7
+    w = _rand(g, Cout, k * k, Cin, scale=(1.0 / (k * k * Cin)) ** 0.5)
+    U, kb = winograd43_corr_filters_padded(w, k)
+    assert kb == 3
+    U = U.cuda()
+    xs_cpu = [_rand(g, N, 1, h, ww, Cin) for h, ww in sizes]
+    dev = torch.device("cuda")
+    xs = ops.alloc_like_segments([tuple(x.shape) for x in xs_cpu], dev)
+    for d_, x in zip(xs, xs_cpu):
+        d_.copy_(x)
+    outs = ops.alloc_like_segments([(N, 1, h, ww, Cout) for h, ww in sizes], dev)
+    for rep in range(2):
+        for o in outs:
+            o.fill_(-3.0)
+        ops.corr2d_wino43_multi(xs, U, outs, 3, k_true=7)
+        for o, xc in zip(outs, xs_cpu):
+            ref = torch.empty(tuple(o.shape), dtype=torch.float64)
+            ref_ops.corr2d_patch(_d(xc), _d(w), ref, k)
+            e = _err(o, ref)
+            assert e <= 2e-5, f"rep {rep}: {e:.3e}; {_where(o[:, 0], ref[:, 0])}"
+
+
 W43_CONV_CASES = [
     dict(N=1, D=16, H=16, W=16, Cin=128, Cout=64, stats=True),                                  # 3-D: depth taps folded into K
     dict(N=1, D=8, H=8, W=8, Cin=64, Cout=64, aff=True, relu=True, stats=True),
