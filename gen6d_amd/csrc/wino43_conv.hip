@@ -50,6 +50,15 @@
                          // the first chunk (L1 / L2 hits)
 #endif
 #define W43ABL(n) (W43_ABLATE == (n) || W43_ABLATE == 5)
+// -DW43_TIMING (profiling builds only, tools/w43_timing.sh): every wave stamps the shader clock at the phase boundaries of its chunk loop and
+// adds the intervals to g_w43_timing[wave][slot] (slots: 0 prologue, 1 raw reads + input transform, 2 phase X, 3 barrier after X,
+// 4 phase Y, 5 barrier after Y, 6 epilogue, 7 chunks counted); g6d_w43_timing_read copies and clears the table.
+#ifdef W43_TIMING
+__device__ unsigned long long g_w43_timing[4][8];
+#define W43_T(slot) do { const long long t_ = clock64(); tacc[slot] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define W43_T(slot) do { } while (0)
+#endif
 
 namespace {
 
@@ -145,6 +154,9 @@ __device__ __forceinline__ void at_row(const float (&m)[6], float (&y)[4]) {
 template <int MODE, int KD, int NT>
 __global__ void __launch_bounds__(256, 1) wino43_kernel(const W43Args p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+#ifdef W43_TIMING
+  const long long t_start = clock64();
+#endif
   constexpr int THREADS = 256, NQ = W43_NQ;
   constexpr int KB = KD == 25 ? 5 : (KD == 9 ? 3 : 0);     // correlation: the 3 KB x 3 KB "same" filter cut into KB x KB blocks of 3x3 (KD = KB^2)
   constexpr bool CORR = KB > 0;
@@ -348,6 +360,10 @@ __global__ void __launch_bounds__(256, 1) wino43_kernel(const W43Args p) {
   using I0 = std::integral_constant<int, 0>;
   using I3 = std::integral_constant<int, 3>;
 
+#ifdef W43_TIMING
+  long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = t_start;
+#endif
+  W43_T(0);
   for (int cc = c_first; cc <= c_last; ++cc) {
     const int cn = min(cc + 1, c_last);           // the last chunk re-requests itself: no branches
     const int st = (cc - c_first) & 1;            // raw stage of this chunk
@@ -388,6 +404,7 @@ __global__ void __launch_bounds__(256, 1) wino43_kernel(const W43Args p) {
         for (int a = 0; a < 3; ++a) bt_full(T[a], V[a]);
       }
     }
+    W43_T(1);
     __builtin_amdgcn_sched_barrier(0);
     // requests of phase X: the NPC pieces of Y of this chunk and the raw pieces of chunk c+1 are loaded behind the first positions;
     // the filter pieces go to slot 1 behind the last positions (the raw pieces wait for phase Y: the other raw stage is free, but
@@ -398,7 +415,9 @@ __global__ void __launch_bounds__(256, 1) wino43_kernel(const W43Args p) {
       else if (k - NPC < NPR) load_piece(k - NPC, cn);
       else if (k >= NS - NPC) store_f(1, k - (NS - NPC));
     });
+    W43_T(2);
     if (!W43ABL(1)) __syncthreads();
+    W43_T(3);
     // ---- phase Y: 9 positions of slot 1 while slot 0 receives X of chunk c+1 and the other raw stage its image
     phase_begin(1);
     __builtin_amdgcn_sched_barrier(0);
@@ -407,7 +426,12 @@ __global__ void __launch_bounds__(256, 1) wino43_kernel(const W43Args p) {
       else if (k - NPC < NPR) store_piece(k - NPC, cn, st ^ 1);
       else if (k >= NS - NPC) store_f(0, k - (NS - NPC));
     });
+    W43_T(4);
     if (!W43ABL(1)) __syncthreads();
+    W43_T(5);
+#ifdef W43_TIMING
+    tacc[7] += 1;
+#endif
   }
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");     // the hand-issued MFMAs of the last positions have left the pipe
 
@@ -591,6 +615,13 @@ __global__ void __launch_bounds__(256, 1) wino43_kernel(const W43Args p) {
       g6d_finalize_stats(p.fin, gridDim.x * gridDim.y, reinterpret_cast<int*>(lds));
     }
   }
+#ifdef W43_TIMING
+  W43_T(6);
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) atomicAdd(&g_w43_timing[wave][i], (unsigned long long)tacc[i]);
+  }
+#endif
 }
 
 // ---- launch: split over the chunks, instantiation
@@ -664,6 +695,15 @@ int w43_run(W43Args& a, int mode, int kd, float* workspace, size_t workspace_byt
 }
 
 }  // namespace
+
+#ifdef W43_TIMING
+extern "C" int g6d_w43_timing_read(unsigned long long* out) {      // [4 waves][8 slots]; clears the table
+  unsigned long long zero[32] = {};
+  if (hipDeviceSynchronize() != hipSuccess) return G6D_ELAUNCH;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_w43_timing), sizeof(zero)) != hipSuccess) return G6D_ELAUNCH;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_w43_timing), zero, sizeof(zero)) == hipSuccess ? G6D_OK : G6D_ELAUNCH;
+}
+#endif
 
 // One trunk layer over up to 4 map sizes in ONE launch, as g6d_wino_conv3x3_multi, on the F(4x4,3x3) kernel.  U43 = the filters
 // transformed on the host (backbone.winograd43_filters): [Cin/8][2][Cout/64][18][2][4][16][4] (include/gen6d_hip.h).

@@ -182,7 +182,9 @@ int g6d_corr2d_wino_multi(const G6dCorrSeg* segs, int nseg, int Cin, const float
 
 /* The same 15x15 correlation with the 25 blocks accumulated in the F(4x4,3x3) transform domain (ABI v8; kernel and filter layout of
  * g6d_wino43_conv3x3_multi): 225 taps cost 25 * 36 / 16 = 56.25 multiplications per output (F(2x2,3x3): 100).  U43 CHUNK-major
- * [Cin/8 * 25][2][Cout/CB][18][CB/32][4][16][4], row c*25 + b = chunk c of block b; Cin % 8 == 0, Cout % 32 == 0. */
+ * [Cin/8 * 25][2][Cout/CB][18][CB/32][4][16][4], row c*25 + b = chunk c of block b; Cin % 8 == 0, Cout % 32 == 0.
+ * kblocks = 3 (ABI v9): a 9x9 "same" correlation as 3x3 blocks (rows c*9 + b, shifts 3bi-3, 3bj-3) — the 7x7 level of the detector
+ * (F.conv2d(que_x1, ref_x1, padding=3)) with its filters zero-extended by one tap on every side: 20.25 multiplications instead of 49. */
 int g6d_corr2d_wino43_multi(const G6dCorrSeg* segs, int nseg, int Cin, const float* U43, int Cout, int kblocks, float* workspace,
                             size_t workspace_bytes, g6d_stream_t stream);
 
