@@ -169,6 +169,24 @@ __global__ void __launch_bounds__(256, 1) wino43_kernel(const W43Args p) {
   constexpr int NPC = (PCS + 3) / 4;                        // ... per wave (NT = 2: 4.5 -> 5, the surplus pieces repeat piece idx % PCS)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // geometry of the block's eight quarters, computed ONCE (segment search + two runtime divisions each) by eight lanes and kept in LDS:
+  // every thread needs it for its seven raw pieces and again in the epilogue — done per thread, the ~30 divisions were 3 us of a
+  // block's 6 us prologue (profiles/r04_w43_phase_timing.md)
+  __shared__ __attribute__((aligned(128))) int qtab[W43_NQ * 16];
+  if (tid < W43_NQ) {
+    const QGeo g = quarter_of(p, tid);
+    int* t = qtab + tid * 16;
+    t[0] = g.valid; t[1] = g.n; t[2] = g.oy0; t[3] = g.ox0; t[4] = g.H; t[5] = g.W; t[6] = g.ld_in; t[7] = g.ld_full;
+    t[8] = g.ld_pool; t[9] = g.in_off; t[10] = g.full_off; t[11] = g.pool_off;
+  }
+  __syncthreads();
+  auto qgeo = [&](int q) {
+    const int* t = qtab + q * 16;
+    QGeo g;
+    g.valid = t[0] != 0; g.n = t[1]; g.oy0 = t[2]; g.ox0 = t[3]; g.H = t[4]; g.W = t[5]; g.ld_in = t[6]; g.ld_full = t[7];
+    g.ld_pool = t[8]; g.in_off = t[9]; g.full_off = t[10]; g.pool_off = t[11];
+    return g;
+  };
   const int pr = wave >> 1, hh = wave & 1;
   const int lt = lane & 15, kg = lane >> 4;
   const int n0 = blockIdx.y * (16 * NT);
@@ -194,7 +212,7 @@ __global__ void __launch_bounds__(256, 1) wino43_kernel(const W43Args p) {
     const int py = pp / 10, px = pp - py * 10;
     const int half = (sl & 1) ^ ((py >> 2) & 1);
     const bool live = (q < NQ) & (pp < 100);
-    const QGeo g = quarter_of(p, live ? q : 0);
+    const QGeo g = qgeo(live ? q : 0);
     const int n = g.n;
     const int iy = g.oy0 + py - 1, ix = g.ox0 + px - 1;
     pval[j] = live & g.valid & ((unsigned)iy < (unsigned)g.H) & ((unsigned)ix < (unsigned)g.W);
@@ -259,7 +277,7 @@ __global__ void __launch_bounds__(256, 1) wino43_kernel(const W43Args p) {
     constexpr int G = MODE >= 2 ? NQ : 1;
     for (int i = tid; i < G * p.Cin; i += THREADS) {
       int g = 0;
-      if constexpr (MODE >= 2) g = p.aff_div > 0 ? (quarter_of(p, i / p.Cin).n / p.D) / p.aff_div : 0;
+      if constexpr (MODE >= 2) g = p.aff_div > 0 ? (qgeo(i / p.Cin).n / p.D) / p.aff_div : 0;
       const int c = MODE >= 2 ? i % p.Cin : i;
       lds[AFF0 + i] = p.in_scale[g * p.Cin + c];
       lds[AFF0 + G * p.Cin + i] = p.in_shift[g * p.Cin + c];
@@ -310,6 +328,9 @@ __global__ void __launch_bounds__(256, 1) wino43_kernel(const W43Args p) {
       for (int n = 0; n < NT; ++n) acc[a][b][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const lds_float* L = (const lds_float*)lds;
+#ifdef W43_TIMING
+  const long long t_geo = clock64() - t_start;      // launch to first request: piece geometry (quarter_of: runtime divisions), tables
+#endif
 #pragma unroll
   for (int k = 0; k < NPC; ++k) load_f(c_first, 0, k);
 #pragma unroll
@@ -364,6 +385,9 @@ __global__ void __launch_bounds__(256, 1) wino43_kernel(const W43Args p) {
   long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = t_start;
 #endif
   W43_T(0);
+#ifdef W43_TIMING_GEO
+  tacc[0] = t_geo;                                  // (-DW43_TIMING_GEO: slot 0 = the part of the prologue in front of the first request)
+#endif
   for (int cc = c_first; cc <= c_last; ++cc) {
     const int cn = min(cc + 1, c_last);           // the last chunk re-requests itself: no branches
     const int st = (cc - c_first) & 1;            // raw stage of this chunk
@@ -538,45 +562,51 @@ __global__ void __launch_bounds__(256, 1) wino43_kernel(const W43Args p) {
           }
     }
   }
-  const QGeo g = quarter_of(p, 4 * pr + kg);          // the lane's quarter: accumulator register r = tile r of it
+  const QGeo g = qgeo(4 * pr + kg);                   // the lane's quarter: accumulator register r = tile r of it
   const bool do_relu = p.relu != 0, do_stats = p.stats != nullptr;
   const int Hp = g.H >> 1, Wp = g.W >> 1;
-  float st1[NT], st2[NT];
+  // Stores.  The address of an output element is hoisted out of the element loops: one 64-bit base per tile row of the lane's quarter
+  // (r, output row), then 32-bit column / channel-tile offsets — computed per element (the compiler does not hoist it through the
+  // unrolled loops) the address arithmetic was ~1300 of the epilogue's instructions, 370 of them quarter-rate integer multiplies.
+  float st1[NT], st2[NT], bv[NT];
 #pragma unroll
-  for (int n = 0; n < NT; ++n) {
-    st1[n] = 0.f; st2[n] = 0.f;
-    const int co = n0 + 16 * n + lt;
-    const float bv = p.bias ? p.bias[co] : 0.f;
+  for (int n = 0; n < NT; ++n) { st1[n] = 0.f; st2[n] = 0.f; bv[n] = p.bias ? p.bias[n0 + 16 * n + lt] : 0.f; }
+  const int ldf = g.ld_full, ldp = g.ld_pool;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int oy = g.oy0 + 4 * (r >> 1) + 2 * hh, ox = g.ox0 + 4 * (r & 1);
+  for (int r = 0; r < 4; ++r) {
+    const int oy = g.oy0 + 4 * (r >> 1) + 2 * hh, ox = g.ox0 + 4 * (r & 1);
+    const int ncol = g.W - ox;                                          // columns c < ncol of the tile row are inside the map
+    const bool row0 = g.valid && oy < g.H, row1 = g.valid && oy + 1 < g.H;
+    float* f0 = p.out_full + (size_t)g.full_off + ((size_t)(g.n * g.H + oy) * g.W + ox) * (size_t)ldf + (n0 + lt);
+    float* f1 = f0 + (size_t)g.W * (size_t)ldf;
+    const int py = oy >> 1, px0 = ox >> 1;
+    float* q0 = p.out_pool + (size_t)g.pool_off + ((size_t)(g.n * Hp + py) * Wp + px0) * (size_t)ldp + (n0 + lt);
+    const bool prow = g.valid && py < Hp;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
       float y[2][4];
 #pragma unroll
       for (int xl = 0; xl < 2; ++xl)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          y[xl][c] = Y[n][r][xl][c] + bv;
+          y[xl][c] = Y[n][r][xl][c] + bv[n];
           if (do_relu) y[xl][c] = fmaxf(y[xl][c], 0.f);
         }
-      if (p.out_full && g.valid) {
+      if (p.out_full) {
 #pragma unroll
         for (int xl = 0; xl < 2; ++xl)
 #pragma unroll
           for (int c = 0; c < 4; ++c)
-            if (oy + xl < g.H && ox + c < g.W) {
-              p.out_full[(size_t)g.full_off + ((size_t)(g.n * g.H + oy + xl) * g.W + ox + c) * g.ld_full + co] = y[xl][c];
+            if ((xl ? row1 : row0) && c < ncol) {
+              (xl ? f1 : f0)[c * ldf + 16 * n] = y[xl][c];
               if (do_stats) { st1[n] += y[xl][c]; st2[n] += y[xl][c] * y[xl][c]; }
             }
       }
-      if (p.out_pool && g.valid) {
-        const int py = oy >> 1;
+      if (p.out_pool && prow) {
 #pragma unroll
-        for (int c2 = 0; c2 < 2; ++c2) {
-          const int px = (ox >> 1) + c2;
-          if (py < Hp && px < Wp)
-            p.out_pool[(size_t)g.pool_off + ((size_t)(g.n * Hp + py) * Wp + px) * g.ld_pool + co] =
-                fmaxf(fmaxf(y[0][2 * c2], y[0][2 * c2 + 1]), fmaxf(y[1][2 * c2], y[1][2 * c2 + 1]));
-        }
+        for (int c2 = 0; c2 < 2; ++c2)
+          if (px0 + c2 < Wp)
+            q0[c2 * ldp + 16 * n] = fmaxf(fmaxf(y[0][2 * c2], y[0][2 * c2 + 1]), fmaxf(y[1][2 * c2], y[1][2 * c2 + 1]));
       }
     }
   }
@@ -594,7 +624,7 @@ __global__ void __launch_bounds__(256, 1) wino43_kernel(const W43Args p) {
       double a1 = 0.0, a2 = 0.0;
       int cur = -1;
       for (int q = 0; q < NQ; ++q) {
-        const QGeo qg = quarter_of(p, q);
+        const QGeo qg = qgeo(q);
         if (!qg.valid) break;
         const int gi = p.stats_div > 0 ? (qg.n / p.D) / p.stats_div : 0;
         if (gi != cur && cur >= 0) {
@@ -629,7 +659,7 @@ template <int MODE, int KD, int NT>
 int w43_launch_t(W43Args& a, long long blocks, hipStream_t stream) {
   const size_t lds_bytes = ((size_t)2 * W43_RAWF + 2 * (18 * 16 * NT * 8) + (MODE == 0 ? 0 : (MODE >= 2 ? 2 * W43_NQ : 2) * a.Cin)) * sizeof(float);
   const size_t need = std::max(lds_bytes, (size_t)4 * 4096 * sizeof(float));      // the epilogue exchange: 16 KB per wave
-  g6d_allow_lds(reinterpret_cast<const void*>(&wino43_kernel<MODE, KD, NT>), 160 * 1024);
+  g6d_allow_lds(reinterpret_cast<const void*>(&wino43_kernel<MODE, KD, NT>), 160 * 1024 - 512);      // (512 B of static LDS: the quarter table)
   hipLaunchKernelGGL((wino43_kernel<MODE, KD, NT>), dim3((unsigned)blocks, a.Cout / (16 * NT), a.splits), dim3(256), need, stream, a);
   return g6d_check_launch("wino43_conv3x3");
 }
@@ -653,7 +683,7 @@ int w43_run(W43Args& a, int mode, int kd, float* workspace, size_t workspace_byt
   a.in_bytes = (unsigned)(in_extent * 4);
   if ((long long)kd * (a.Cin / 8) * 36 * a.Cout * 32 >= (1ll << 31)) { g6d_set_error("wino43: filter bank exceeds 2^31 bytes"); return G6D_EINVAL; }
   const int nt = (a.Cout & 63) ? 2 : 4;
-  if (mode != 0 && (size_t)(mode >= 2 ? 2 * W43_NQ : 2) * a.Cin * 4 + ((size_t)2 * W43_RAWF + 2 * 18 * 16 * nt * 8) * 4 > 160 * 1024) {
+  if (mode != 0 && (size_t)(mode >= 2 ? 2 * W43_NQ : 2) * a.Cin * 4 + ((size_t)2 * W43_RAWF + 2 * 18 * 16 * nt * 8) * 4 > 160 * 1024 - 512) {
     g6d_set_error("wino43: affine tables do not fit LDS"); return G6D_EINVAL;
   }
   // Split of the (kd, chunk) list over gridDim.z: one block per CU is resident and runs a serial loop of ~2.6 us per chunk (NT = 4;
