@@ -164,3 +164,22 @@ def test_more_queries_than_one_launch_batch(monkeypatch):
                    "ref_imgs_info": {k: v[1:2] for k, v in data["ref_imgs_info"].items()}, "inference": True})
     for k in ("rotation", "offset", "scale"):
         np.testing.assert_allclose(out[k][1].numpy(), one[k][0].numpy(), atol=2e-4)
+
+
+def test_padded_correlation_filters_for_the_7x7_level():
+    """backbone.winograd43_corr_filters_padded: the 7x7 correlation filters zero-extended to 9x9 and cut into 3x3 blocks of 3x3 reproduce
+    the direct 7x7 "same" correlation when accumulated block-wise in the F(4x4,3x3) domain (the algorithm of g6d_corr2d_wino43_multi with
+    kblocks = 3, emulated in float64 on the filters the kernel receives)."""
+    from gen6d_amd.network.backbone import winograd43_corr_filters_padded
+    g = torch.Generator().manual_seed(5)
+    w = (torch.rand((32, 49, 16), generator=g) * 2 - 1).double()
+    x = (torch.rand((2, 1, 11, 13, 16), generator=g) * 2 - 1).double()
+    U, kb = winograd43_corr_filters_padded(w, 7)
+    assert kb == 3 and tuple(U.shape) == (2 * 9, 2, 1, 18, 1, 4, 16, 4)
+    out = torch.empty((2, 1, 11, 13, 32), dtype=torch.float64)
+    ref_ops.corr2d_wino43_multi([x], U, [out], kb, k_true=7)
+    ref = torch.empty_like(out)
+    ref_ops.corr2d_patch(x, w, ref, 7)
+    assert float((out - ref).abs().max()) < 1e-12
+    with pytest.raises(ValueError):
+        winograd43_corr_filters_padded(torch.zeros((32, 64, 16), dtype=torch.float64), 8)        # 8 -> 9 cannot be centred
