@@ -40,7 +40,7 @@ def test_knobs_have_product_defaults_and_no_environment_reads():
     assert lib.get_knob("conv_wino") == 1
     with pytest.raises(RuntimeError):
         lib.set_knob("no_such_knob", 1)
-    for f in glob.glob(os.path.join(ROOT, "gen6d_amd", "csrc", "*")):
+    for f in glob.glob(os.path.join(ROOT, "gen6d_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "gen6d_amd", "csrc", "*.h")):
         assert "getenv" not in open(f, errors="ignore").read(), f
     for f in glob.glob(os.path.join(ROOT, "gen6d_amd", "**", "*.py"), recursive=True):
         src = open(f).read()
