@@ -21,3 +21,4 @@ for f in ("bench_final", "bench_gpus2", "bench_gpus2_shard"):
         print(f, "failed", e)
 PY
 bash tools/profile_round.sh > gpurun_out/profile_round.log 2>&1; tail -4 gpurun_out/profile_round.log | cut -c1-200
+bash tools/single_query_profile.sh | tail -2
