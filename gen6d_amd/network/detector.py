@@ -5,7 +5,8 @@ For the 4 detection scales of a batch of queries at once (reference detect_impl,
     own Winograd trunk              F(4x4,3x3) on fp32 MFMA, one launch per layer over the whole pyramid -> x0 @1/8, x1 @1/16, x2 @1/32
     correlation x3                  query features correlated with the reference feature maps used as filters
                                     (F.conv2d(que_x, ref_x, padding=7/3/1), detector.py:222-224): the 15x15 level as 5x5 blocks of 3x3
-                                    in the F(4x4,3x3) domain (g6d_corr2d_wino43_multi), 7x7 / 3x3 on g6d_corr2d_patch_multi
+                                    and the 7x7 level as 3x3 blocks (filters zero-extended to 9x9) in the F(4x4,3x3) domain
+                                    (g6d_corr2d_wino43_multi), the 3x3 level on g6d_corr2d_patch_multi
     g6d_detector_assemble           nearest up-sampling, (x-mu)/sigma, clip, bilinear resize to (h/8,w/8), stack
 then g6d_detector_score_mlp_max     score_conv MLP + max over references, never materialising [64,rfn,hs,ws]
      g6d_conv_igemm x7              the three 3x3 heads (first layers merged into one 64->192 conv)

@@ -14,9 +14,9 @@ Query-time data flow (reference compute_view_point_feats, selector.py:177-215), 
 
 Reference-sharded mode (`set_shard(rank, world)`): every rank keeps the cache of a contiguous slice of
 the references (all rotations of a reference stay together).  The logits of one reference depend on all references
-through the InstanceNorms, so the exchange is: one all-reduce of R1/R2 at build time; per BATCH of <= 8 queries (they share every
+through the InstanceNorms, so the exchange is: one all-reduce of R1/R2 at build time; per BATCH of <= 32 queries (they share every
 collective: the tables are [qn, C, 2]) five all-reduces of the fp64 (sum, sumsq) InstanceNorm tables of the correlation stacks (the
-three levels advance in lock-step, a round's tables travel together: <= 8 * 3 * 8 KB), one for corr_feats_conv's InstanceNorm, one
+three levels advance in lock-step, a round's tables travel together: <= qn * 3 * 8 KB), one for corr_feats_conv's InstanceNorm, one
 all-gather of the vps scalars, one of the per-reference feature rows [qn, rfn/G, 512] before the replicated attention tail, and one
 of the per-reference angles: 9 collectives per batch (RCCL over xGMI via torch.distributed, issued on device tensors on the current
 stream; messages are KB-sized, i.e. latency-bound).  Results equal the unsharded ones up to fp reassociation of the sums.
