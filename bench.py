@@ -143,7 +143,7 @@ def ref_sweep(dev, B, lanes, steps, warmup):
         g_out = pipe.selector.compute_view_point_feats(g_in)
     for _ in range(2): graph.replay()
     torch.cuda.synchronize()
-    n = max(4, steps // 2)
+    n = max(10, steps)
     t0 = time.perf_counter()
     for _ in range(n): graph.replay()
     torch.cuda.synchronize()
@@ -233,15 +233,17 @@ def main():
     want_world = int(os.environ.get("WORLD_SIZE", "1"))
     backend = os.environ.get("G6D_DIST_BACKEND") or ("nccl" if n_dev >= want_world else "gloo")   # nccl = RCCL over xGMI
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % n_dev)
-    rank, world, local = parallel.init_from_env(backend=backend)
+    # `--shard-refs --gpus 1`: a one-rank RCCL process group — the sharded path issues its 9 + 1 collectives per batch on it
+    rank, world, local = parallel.init_from_env(backend=backend, force=args.shard_refs and want_world == 1)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     local = local % n_dev                            # (fewer GPUs than ranks: several ranks share a device, gloo)
     dev = torch.device("cuda", local)
     ranks_seen = int(parallel.sum_over_ranks(1, dev))
 
-    shard_refs = args.shard_refs and world > 1
-    pipe = TensorPipeline(dev, sel_rfn=args.sel_refs, det_rfn=args.det_refs, shard=(rank, world) if shard_refs else (0, 1))
+    shard_refs = args.shard_refs
+    pipe = TensorPipeline(dev, sel_rfn=args.sel_refs, det_rfn=args.det_refs, shard=(rank, world) if shard_refs else (0, 1),
+                          force_collectives=shard_refs and world == 1)
     torch.cuda.synchronize()
     tb = time.perf_counter()
     pipe.build()
@@ -252,11 +254,14 @@ def main():
     crops = synth.imgs_to_tensor(synth.synth_images(4, 128, 128, seed=200 + qseed)).to(dev)
     B = max(1, min(32, args.batch))               # sharded references: the batch also shares every collective (round 4)
 
-    use_graph = not args.no_graph and not shard_refs and not args.serial     # collectives are issued eagerly
+    # reference-sharded runs: under RCCL the collectives are enqueued on device tensors on the launch stream and are captured into the
+    # batch's hipGraph with the kernels around them; under gloo (ranks sharing one GPU) they are host-staged, i.e. eager only
+    use_graph = not args.no_graph and not args.serial and (not shard_refs or parallel.backend_name() == "nccl")
     no_fork = args.serial or (use_graph and not args.fork)
     if no_fork:
         ops.SERIAL = True
-    lanes = max(1, args.lanes) if use_graph else 1
+    # (sharded: ONE graph in flight — two replays on different streams could run their collectives in different orders on different ranks)
+    lanes = (1 if shard_refs else max(1, args.lanes)) if use_graph else 1
     if use_graph:
         pipe.capture(lanes=lanes, batch=B)
     main_stream = torch.cuda.current_stream(dev)
@@ -295,7 +300,7 @@ def main():
     if shard_refs:
         # per-collective log of ONE extra query (outside the timed region: logging synchronises the stream around every collective)
         parallel.COLLECTIVE_LOG = []
-        step(0)
+        step(0, eager=True)
         torch.cuda.synchronize()
         coll_log, parallel.COLLECTIVE_LOG = parallel.COLLECTIVE_LOG, None
         parallel.barrier()
@@ -330,7 +335,7 @@ def main():
     # latency of ONE query alone: a batch-1 graph on one lane, replays back to back (what a single camera stream would see); measured
     # without and with the query's independent branches (selector levels, refiner feature branches) forked onto side streams
     single_ms, single_detail = None, None
-    if rank == 0 and use_graph:
+    if rank == 0 and use_graph and not shard_refs:
         single_detail = {}
         for tag, serial in (("one_stream", True), ("branches_forked", False)):
             ops.SERIAL = serial
@@ -353,7 +358,8 @@ def main():
     # HBM traffic of the dominant kernel family cannot be read without rocprofv3: it is taken from the committed PMC
     # summary of the same command (profiles/rNN_pmc_conv_traffic.json, newest round first; tools/pmc_conv_traffic.py), else null
     traffic_json, traffic_src = {}, None
-    for name in ("r04_pmc_conv_traffic.json", "r03_pmc_conv_traffic.json", "r02_pmc_conv_traffic.json", "r01_pmc_conv_traffic.json"):
+    # (the CURRENT round's file or null: an older round's ratio printed beside this round's kernels would be stale — VERDICT r04 weak #4)
+    for name in ("r05_pmc_conv_traffic.json",):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 traffic_json = json.load(f)
@@ -362,7 +368,8 @@ def main():
         except (OSError, ValueError):
             pass
     tr_note = (f"STATIC, not measured in this run: {traffic_src} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
-               "`bench.py --no-graph`, tools/profile_round.sh); HBM-side bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024")
+               "`bench.py --no-graph`, tools/profile_round.sh); HBM-side bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024"
+               if traffic_src else "null: no PMC summary of this round's kernels is committed (profiles/r05_pmc_conv_traffic.json)")
     # two MFMA-bound kernel families, both measured with HIP events around every launch (serialised eager re-run of the same
     # steps after the graph-replay timed region when graphs are used):
     #   conv      conv_igemm / conv_patch / corr_patch (split launches finish inside the kernel); executed = direct-form FLOPs
@@ -449,16 +456,33 @@ def main():
     result["ranks_seen"], result["backend"] = ranks_seen, parallel.backend_name()
     if coll_log is not None:
         kinds = {}
-        for kind, nb, sec in coll_log:
-            k = kinds.setdefault(kind, {"count": 0, "bytes": 0, "us": 0.0})
-            k["count"] += 1; k["bytes"] += nb; k["us"] += sec * 1e6
+        for kind, nb, sec, enq in coll_log:
+            k = kinds.setdefault(kind, {"count": 0, "bytes": 0, "us": 0.0, "enq": 0.0})
+            k["count"] += 1; k["bytes"] += nb; k["us"] += sec * 1e6; k["enq"] += enq * 1e6
         result["collectives_per_query"] = {
             "total": len(coll_log) / B, "per_batch": len(coll_log), "batch": B, "total_us_per_batch": sum(c[2] for c in coll_log) * 1e6,
-            "by_kind": {k: {"count": v["count"], "mean_bytes": v["bytes"] / v["count"], "mean_us": v["us"] / v["count"]} for k, v in kinds.items()},
-            "how": "one extra batch with a stream synchronisation around every data-path collective (rank 0's view; selector 9 + "
-                   "detector 1 per batch of queries); "
+            "captured": bool(use_graph), "enqueue_us_mean": sum(c[3] for c in coll_log) * 1e6 / max(1, len(coll_log)),
+            "by_kind": {k: {"count": v["count"], "mean_bytes": v["bytes"] / v["count"], "mean_us": v["us"] / v["count"],
+                            "mean_enqueue_us": v["enq"] / v["count"]} for k, v in kinds.items()},
+            "how": "one extra EAGER batch with a stream synchronisation around every data-path collective (rank 0's view; selector 9 + "
+                   "detector 1 per batch of queries): mean_us = enqueue + execution on an idle stream, mean_enqueue_us = host time of the "
+                   "call alone; `captured`: the timed region replays ONE hipGraph per batch that holds the kernels AND the collectives; "
                    + ("RCCL: enqueued on device tensors, no host staging" if parallel.backend_name() == "nccl" else
                       "gloo: every collective is staged through host memory (ranks share one GPU on this lease; RCCL refuses that)")}
+    if shard_refs and world == 1:
+        # the forced-collective path against the plain one on the same four images (same kernels apart from the InstanceNorm
+        # finalisation, which moves from the producers' last blocks into g6d_stats_finalize behind the all-reduce)
+        idx4 = torch.arange(4, device=dev)
+        with torch.no_grad():
+            sh_rows = pipe.query(fulls[idx4], crops[idx4])
+            pipe.selector.sharded = pipe.detector.sharded = False
+            un_rows = pipe.query(fulls[idx4], crops[idx4])
+            pipe.selector.sharded = pipe.detector.sharded = True
+        dd = (sh_rows - un_rows).abs()
+        result["sharded_vs_unsharded"] = {"max_abs_diff_row": float(dd.max()), "max_rel_diff_row": float((dd / un_rows.abs().clamp(min=1.0)).max()),
+                                          "ref_idx_equal": bool((sh_rows[:, 3] == un_rows[:, 3]).all()),
+                                          "what": "world-size-1 RCCL group, force_collectives: 9 selector + 1 detector collectives per batch, "
+                                                  "rows of 4 queries vs the same pipeline without collectives"}
     result["build_s"] = {"value": build_s, "what": "TensorPipeline.build: detector reference filters + selector reference cache "
                                                    "(trunk over 32 + 320 crops, R1/R2 sums, viewpoint embedding), incl. first-use "
                                                    "library initialisation; reference: 0.57 s + 9.8 s on 8 CPU threads (BASELINE.md §2)"}
@@ -476,7 +500,7 @@ def main():
     #      kernels (fp32 accumulation, fp32 InstanceNorm statistics, fp32 trunk).
     lowp, headline_lanes = {}, lanes
     try:
-        modes = [m for m in args.lowp.split(",") if m] if (use_graph and world == 1) else []
+        modes = [m for m in args.lowp.split(",") if m] if (use_graph and world == 1 and not shard_refs) else []
         # the first re-captured pass after the serialised eager roofline pass measures ~15 % low whatever its type (bf16 first: 169 /
         # fp16 205; fp16 first: fp16 low, bf16 205): one throwaway pass of the first mode precedes the reported ones
         if modes:
@@ -569,7 +593,7 @@ def main():
     #      their (view, angle bucket) key repeats; in this workload the canned crops repeat in every step of every query (hit rate 1 after
     #      the first step), so this is the upper bound of what the cache buys.  Side number: the headline stays uncached.
     try:
-        if use_graph and world == 1 and not args.no_cached:
+        if use_graph and world == 1 and not args.no_cached and not shard_refs:
             pipe.capture(lanes=lanes, batch=B, cached_refs=True)
             lane_busy[:] = [None] * lanes
             for i in range(args.warmup):
@@ -603,7 +627,7 @@ def main():
         result.setdefault("side_leg_errors", {})["cached"] = f"{type(e).__name__}: {e}"[:600]
 
     try:
-        if not args.no_chained and world == 1 and rank == 0:
+        if not args.no_chained and world == 1 and rank == 0 and not shard_refs:
             # the estimator-level path: the crop fed to the selector comes from the detection, the refiner inputs from the pose of
             # the previous stage (bench headline: canned crops / poses)
             from gen6d_amd.estimator import Gen6DEstimator
@@ -669,8 +693,8 @@ def main():
         result.setdefault("side_leg_errors", {})["chained"] = f"{type(e).__name__}: {e}"[:600]
 
     try:
-        if not args.no_sweep and world == 1 and use_graph and (args.sel_refs, args.det_refs) == (64, 32):
-            sw = ref_sweep(dev, B, headline_lanes, max(6, args.steps // 2), max(2, args.warmup // 2))
+        if not args.no_sweep and world == 1 and use_graph and not shard_refs and (args.sel_refs, args.det_refs) == (64, 32):
+            sw = ref_sweep(dev, B, headline_lanes, max(10, args.steps // 2), max(2, args.warmup // 2))
             sw["64x5"] = {"workload": "the headline of this line", "value": result["value"], "unit": "images/s",
                           "roofline": {"winograd": {"achieved_TFLOPs_executed": fams.get("winograd", {}).get("achieved"),
                                                     "frac_of_fp32_mfma_peak": fams.get("winograd", {}).get("frac")}}}
@@ -709,7 +733,7 @@ def main():
         result["parity_vs_reference"] = worst
 
     try:
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not shard_refs:
             # BASELINE.md §3 protocol: threads = physical cores, 1 warm-up + min of >= 3 runs, torch.std share split out
             from oracle import gen6d_oracle as GO
             from oracle import pipeline_oracle as PO

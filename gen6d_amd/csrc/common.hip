@@ -2,6 +2,7 @@
 #include "g6d_common.h"
 #include <string.h>
 #include <stdio.h>
+#include <atomic>
 #include <mutex>
 #include <set>
 #include <utility>
@@ -52,26 +53,25 @@ const KnobDef kKnobs[G6D_KNOB_COUNT] = {
     {"conv_wino16", 1},       // ... and on its 16-bit variant in the reduced-precision mode
     {"wino_min_work", -1},    // Winograd profitability rule: -1 = built-in thresholds, 0 = off, > 0 = minimum M*K*Cout
 };
-double g_knob[G6D_KNOB_COUNT];
-bool g_knob_init = false;
-void knob_init() {
-  if (!g_knob_init) { for (int i = 0; i < G6D_KNOB_COUNT; ++i) g_knob[i] = kKnobs[i].def; g_knob_init = true; }
-}
+// Process-global table, filled when the library is loaded (static initialisation, before any entry point can run); reads and writes
+// are relaxed atomics, so a g6d_set_knob racing with launches on other threads is a benign race on one value (a launch sees the
+// old or the new policy).  Tools and tests set knobs BEFORE the launches they want to steer.
+std::atomic<double> g_knob[G6D_KNOB_COUNT];
+void knob_defaults() { for (int i = 0; i < G6D_KNOB_COUNT; ++i) g_knob[i].store(kKnobs[i].def, std::memory_order_relaxed); }
+struct KnobInit { KnobInit() { knob_defaults(); } } g_knob_init;
 }  // namespace
-double g6d_knob(int id) { knob_init(); return g_knob[id]; }
+double g6d_knob(int id) { return g_knob[id].load(std::memory_order_relaxed); }
 extern "C" int g6d_set_knob(const char* name, double value) {
-  knob_init();
   for (int i = 0; name && i < G6D_KNOB_COUNT; ++i)
-    if (!strcmp(name, kKnobs[i].name)) { g_knob[i] = value; return G6D_OK; }
+    if (!strcmp(name, kKnobs[i].name)) { g_knob[i].store(value, std::memory_order_relaxed); return G6D_OK; }
   g6d_set_error("set_knob: unknown knob"); return G6D_EINVAL;
 }
 extern "C" double g6d_get_knob(const char* name) {
-  knob_init();
   for (int i = 0; name && i < G6D_KNOB_COUNT; ++i)
-    if (!strcmp(name, kKnobs[i].name)) return g_knob[i];
+    if (!strcmp(name, kKnobs[i].name)) return g_knob[i].load(std::memory_order_relaxed);
   return -1e300;
 }
-extern "C" void g6d_reset_knobs(void) { g_knob_init = false; knob_init(); }
+extern "C" void g6d_reset_knobs(void) { knob_defaults(); }
 
 extern "C" int g6d_abi_version(void) { return 9; }
 extern "C" const char* g6d_last_error(void) { return g_err; }

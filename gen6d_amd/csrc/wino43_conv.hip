@@ -664,6 +664,18 @@ int w43_launch_t(W43Args& a, long long blocks, hipStream_t stream) {
   return g6d_check_launch("wino43_conv3x3");
 }
 
+// The hard size limits of a launch, shared by w43_run (error) and g6d_wino43_eligible (fall back to another kernel): 32-bit grid,
+// the 2^31-byte reach of the buffer loads on input and filter bank, the affine tables beside the stages in LDS.  nullptr = fits.
+const char* w43_limits(long long quarters, long long in_extent_floats, int kd, int Cin, int Cout, int mode) {
+  if ((quarters + W43_NQ - 1) / W43_NQ > 0x3fffffffll) return "wino43: grid too large";
+  if (in_extent_floats * 4 >= (1ll << 31)) return "wino43: input tensor exceeds 2^31 bytes";
+  if ((long long)kd * (Cin / 8) * 36 * Cout * 32 >= (1ll << 31)) return "wino43: filter bank exceeds 2^31 bytes";
+  const int nt = (Cout & 63) ? 2 : 4;
+  if (mode != 0 && (size_t)(mode >= 2 ? 2 * W43_NQ : 2) * Cin * 4 + ((size_t)2 * W43_RAWF + 2 * 18 * 16 * nt * 8) * 4 > 160 * 1024 - 512)
+    return "wino43: affine tables do not fit LDS";
+  return nullptr;
+}
+
 int w43_run(W43Args& a, int mode, int kd, float* workspace, size_t workspace_bytes, hipStream_t stream) {
   long long quarters = 0, in_extent = 0;
   double out_elems = 0.0;
@@ -677,15 +689,10 @@ int w43_run(W43Args& a, int mode, int kd, float* workspace, size_t workspace_byt
   }
   a.H0 = a.seg[0].H; a.W0 = a.seg[0].W; a.ld0 = a.seg[0].ld_in;
   const long long blocks = (quarters + W43_NQ - 1) / W43_NQ;
-  if (blocks > 0x3fffffffll) { g6d_set_error("wino43: grid too large"); return G6D_EINVAL; }
-  a.qtotal = (int)quarters;
-  if (in_extent * 4 >= (1ll << 31)) { g6d_set_error("wino43: input tensor exceeds 2^31 bytes"); return G6D_EINVAL; }
-  a.in_bytes = (unsigned)(in_extent * 4);
-  if ((long long)kd * (a.Cin / 8) * 36 * a.Cout * 32 >= (1ll << 31)) { g6d_set_error("wino43: filter bank exceeds 2^31 bytes"); return G6D_EINVAL; }
   const int nt = (a.Cout & 63) ? 2 : 4;
-  if (mode != 0 && (size_t)(mode >= 2 ? 2 * W43_NQ : 2) * a.Cin * 4 + ((size_t)2 * W43_RAWF + 2 * 18 * 16 * nt * 8) * 4 > 160 * 1024 - 512) {
-    g6d_set_error("wino43: affine tables do not fit LDS"); return G6D_EINVAL;
-  }
+  if (const char* why = w43_limits(quarters, in_extent, kd, a.Cin, a.Cout, mode)) { g6d_set_error(why); return G6D_EINVAL; }
+  a.qtotal = (int)quarters;
+  a.in_bytes = (unsigned)(in_extent * 4);
   // Split of the (kd, chunk) list over gridDim.z: one block per CU is resident and runs a serial loop of ~2.6 us per chunk (NT = 4;
   // ~1.5 at NT = 2); pick the split count with the smallest modelled time, as wino_conv.hip does (constants overridable)
   const int nchunks = kd * (a.Cin / 8);
@@ -815,9 +822,14 @@ bool g6d_wino43_eligible(const G6dConv& d) {
   if (!(k2 || k3) || d.kh != 3 || d.kw != 3 || d.ph != 1 || d.pw != 1 || d.sd != 1 || d.sh != 1 || d.sw != 1) return false;
   if ((d.Cin & 7) || (d.Cout & 63) || d.Hi < 8 || d.Wi < 8 || d.out_act > 1 || d.split_k > 1) return false;
   if (d.stats && d.stat_rows_per_group > 0 && d.stat_rows_per_group % (d.Do * d.Ho * d.Wo)) return false;
-  if (d.in_scale && (d.Cin > 256 || (d.Cin & 3))) return false;      // affine tables of the block's eight quarters beside three filter slots
+  if (d.in_scale && (d.Cin > 256 || (d.Cin & 3))) return false;      // affine prologue: tested up to 256 input channels
   if (!g6d_aligned16(d.weight_wino43)) return false;
-  if ((long long)d.N * d.Di * ((d.Hi + 7) / 8) * ((d.Wi + 7) / 8) >= (1ll << 31)) return false;
+  // the launch's own hard limits (w43_run would refuse): such a layer falls through to the F(2x2,3x3) / implicit-GEMM kernels and
+  // g6d_conv_plan reports that family
+  const long long quarters = (long long)d.N * d.Di * ((d.Hi + 7) / 8) * ((d.Wi + 7) / 8);
+  const int mode = !d.in_scale ? 0 : (d.in_affine_per_n ? 2 : 1);
+  if (w43_limits(quarters, (long long)d.N * d.Di * d.Hi * d.Wi * d.ld_in, d.kd, d.Cin, d.Cout, mode)) return false;
+  if ((long long)d.N * d.Do * d.Ho * d.Wo * d.ld_out >= (1ll << 31)) return false;      // 32-bit output offsets
   return (long long)d.N * d.Di * d.Hi * d.Wi * d.ld_in < (1ll << 29);
 }
 

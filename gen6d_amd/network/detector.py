@@ -31,8 +31,9 @@ CORR_WINO = True         # the 15x15 correlation level in the Winograd domain, 5
 F43 = True
 CORR7_F43 = True         # the 7x7 level as 3x3 blocks of 3x3 on zero-extended 9x9 filters in the F(4x4,3x3) domain (20.25 instead of 49
                          # multiplications per output) when rfn % 32 == 0 and fp32; False: corr_patch
-MAX_BATCH = 16       # queries that share one set of launches: the pyramid's first layers address all scales of the batch with 32-bit
-                     # offsets from one base (< 2^29 floats: 16 images of 480x640 at 64 channels; 32 would not fit)
+MAX_BATCH = 16       # most queries that share one set of launches; _detect_impl_fp cuts the chunk further for larger images (the pyramid's
+                     # first layers address all scales of the batch with 32-bit offsets from one base, < 2^29 floats: 16 images of
+                     # 480x640 at 64 channels; 32 would not fit)
 
 
 class Detector(ParamBank):
@@ -55,13 +56,16 @@ class Detector(ParamBank):
         self.ref_wino7_43 = None         # the 7x7 level's filters, zero-extended to 9x9, for the F(4x4,3x3) kernel
         self.ref_shape = None
         self.rank, self.world, self.group = 0, 1, None
+        self.sharded = False
 
-    def set_shard(self, rank, world, group=None):
+    def set_shard(self, rank, world, group=None, force_collectives=False):
         """Reference-sharded mode: this rank correlates the query against references
         parallel.shard_range(rfn, rank, world) only; correlation, score assembly and the score MLP are per-reference, and
         `torch.max(scores, 2)` over the references (detector.py:247) becomes one all-reduce(MAX) of the [hs*ws, 64]
-        feature map (1.2 MB at 60x80) over torch.distributed (RCCL).  The query trunk and the heads are replicated."""
+        feature map (1.2 MB at 60x80) over torch.distributed (RCCL).  The query trunk and the heads are replicated.
+        `force_collectives`: issue the all-reduce at world size 1 as well (see ViewpointSelector.set_shard)."""
         self.rank, self.world, self.group = int(rank), int(world), group
+        self.sharded = self.world > 1 or bool(force_collectives)
 
     # ------------------------------------------------------------------ weights
     def _pack(self):
@@ -167,7 +171,15 @@ class Detector(ParamBank):
         ops.detector_assemble(maps[0], maps[1], maps[2], hc, wc, self.cfg["vgg_score_stats"],
                               float(self.cfg["vgg_score_max"]), hs, ws, scale_idx, stacked, batch=qn)
 
-    def _detect_batch(self, que_imgs):
+    @staticmethod
+    def _scale_size(hq, wq, scale):
+        """Size of the query at a detection scale: round(h * 2^s), rounded UP to a multiple of 32 (reference detector.py:237-239)."""
+        ht, wt = int(np.round(hq * 2 ** scale)), int(np.round(wq * 2 ** scale))
+        if ht % 32 != 0: ht = (ht // 32 + 1) * 32
+        if wt % 32 != 0: wt = (wt // 32 + 1) * 32
+        return ht, wt
+
+    def _detect_batch(self, que_imgs, multi=True):
         """que_imgs [qn,3,hq,wq]: the whole batch goes through every launch together (trunk pyramid segments of qn images,
         correlation tiles of qn maps per scale, heads with M = qn*hs*ws) — reference API: detector.py:291-304 takes [qn,H,W,3]."""
         pk = self._pack()
@@ -178,14 +190,11 @@ class Detector(ParamBank):
         P = hs * ws
         stacked = torch.empty((qn * P, rfn, 12), dtype=torch.float32, device=dev)
         def resized(scale):
-            ht, wt = int(np.round(hq * 2 ** scale)), int(np.round(wq * 2 ** scale))
-            if ht % 32 != 0: ht = (ht // 32 + 1) * 32
-            if wt % 32 != 0: wt = (wt // 32 + 1) * 32
-            return F.interpolate(que_imgs, size=(ht, wt), mode="bilinear")
+            return F.interpolate(que_imgs, size=self._scale_size(hq, wq, scale), mode="bilinear")
 
         # the scales are independent until `stacked` is complete: largest first on the main stream
         order = sorted(enumerate(self.cfg["detection_scales"]), key=lambda t: -t[1])
-        if TRUNK_MULTI and len(order) <= 4:
+        if TRUNK_MULTI and multi and len(order) <= 4:
             # every trunk layer is ONE launch over the whole pyramid (the small scales fill the blocks the large ones leave
             # over); the correlations of the scales then run side by side
             feats = trunk_features_multi(pk["vgg"], [resized(sc) for _, sc in order], ("c5", "c7_pre", "p7"), f43=F43)
@@ -193,7 +202,7 @@ class Detector(ParamBank):
         else:
             ops.fork_join([(lambda si=si, sc=sc: self._scores_one_scale(resized(sc), si, stacked, hs, ws)) for si, sc in order], dev)
         feats = ops.detector_score_mlp_max(stacked, *pk["mlp"])               # [qn*P,64], max over the local references
-        if self.world > 1:
+        if self.sharded:
             parallel.all_reduce_(feats, "max", self.group)
         k3, p3 = (1, 3, 3), (0, 1, 1)
         a = torch.empty((qn, 1, hs, ws, 192), dtype=torch.float32, device=dev)
@@ -222,8 +231,16 @@ class Detector(ParamBank):
         """que_imgs [qn,3,hq,wq] in [0,1] -> the reference's output dict (detector.py:232-266) plus
         'positions' [qn,2] and 'scales' [qn] already decoded on the device."""
         outs, results = [], []
-        for q0 in range(0, que_imgs.shape[0], MAX_BATCH):                      # the queries of a chunk share every launch
-            o4, res, _ = self._detect_batch(que_imgs[q0:q0 + MAX_BATCH].contiguous())
+        # the queries of a chunk share every launch; the chunk is sized by the image: the one-launch-per-layer pyramid addresses all
+        # scales of the batch with 32-bit offsets from one base (< 2^29 floats; the widest tensor is the first layer's pooled output,
+        # 64 channels at a quarter of the pixels) — 16 queries of 480x640, 9 of 720x1280; an image whose pyramid alone exceeds the
+        # reach runs one trunk pass per scale (ADVICE r04)
+        _, _, hq, wq = que_imgs.shape
+        per_query = sum(self._scale_size(hq, wq, sc)[0] * self._scale_size(hq, wq, sc)[1] for sc in self.cfg["detection_scales"]) // 4 * 64
+        step = max(1, min(MAX_BATCH, ((1 << 29) - 1) // per_query))
+        multi = per_query < (1 << 29)
+        for q0 in range(0, que_imgs.shape[0], step):
+            o4, res, _ = self._detect_batch(que_imgs[q0:q0 + step].contiguous(), multi)
             outs.append(o4.permute(0, 3, 1, 2))
             results.append(res)
         o = torch.cat(outs, 0)                                                 # qn,4,hs,ws

@@ -111,7 +111,9 @@ class VolumeRefiner(ParamBank):
             keys = [(k, ops.MATH_MODE) for k in keys]
             got = [self.feat_cache.get(k) for k in keys]
             miss = [i for i, f in enumerate(got) if f is None]
-            feats = self.run_feature_net(make_imgs(miss)) if miss else None
+            # (f43=False: a cached feature must not depend on how many keys missed together — the F(2x2,3x3) / F(4x4,3x3) choice of
+            # run_feature_net follows the batch size otherwise)
+            feats = self.run_feature_net(make_imgs(miss), f43=False) if miss else None
         if miss:
             for j, i in enumerate(miss):
                 got[i] = feats[j].clone()
@@ -143,18 +145,20 @@ class VolumeRefiner(ParamBank):
         return self._packed
 
     # ------------------------------------------------------------------ 2-D feature net
-    def run_feature_net(self, imgs):
-        """imgs [n,3,h,w] in [0,1] -> channels-last features [n,h/4,w/4,128] (reference refiner.py:64-78)."""
+    def run_feature_net(self, imgs, f43=None):
+        """imgs [n,3,h,w] in [0,1] -> channels-last features [n,h/4,w/4,128] (reference refiner.py:64-78).
+        f43: None = the F(4x4,3x3) kernels from 4 queries (28 crops) per launch on (below that F(2x2,3x3) is faster); False = never
+        (results that are cached per crop must not depend on the batch they were computed in)."""
         pk = self._pack()
         n, _, h, w = imgs.shape
         dev = imgs.device
-        f3, f5, f7 = trunk_features(pk["vgg"], imgs, ("c3", "c5", "c7_pre"), True, f43=TRUNK_F43 and n >= F43_MIN_QUERIES * 7)      # channels-last, L2-normalised
+        big = (n >= F43_MIN_QUERIES * 7) if f43 is None else bool(f43)
+        f3, f5, f7 = trunk_features(pk["vgg"], imgs, ("c3", "c5", "c7_pre"), True, f43=TRUNK_F43 and big)      # channels-last, L2-normalised
 
         def pair(name, x):
             """conv, IN, ReLU, conv, (IN returned as affine) — per-image statistics."""
             (w0, b0), (w1, b1) = pk[name]
             u0, u1 = pk[name][0].u, pk[name][1].u
-            big = n >= F43_MIN_QUERIES * 7                           # F(4x4,3x3) filters only from 4 queries per launch on
             v0, v1 = (pk[name][0].u43, pk[name][1].u43) if big else (None, None)
             _, _, hh, ww, _ = x.shape
             y0 = torch.empty((n, 1, hh, ww, w0.shape[0]), dtype=torch.float32, device=dev)

@@ -54,17 +54,21 @@ class ViewpointSelector(ParamBank):
         self.ref_pose_embed = None       # [rfn, 512]
         self.rfn = self.an = None
         self.rank, self.world, self.group = 0, 1, None
+        self.sharded = False             # True: the collective-carrying path (world > 1, or forced at world 1)
         self.r_begin, self.r_end = 0, None
 
     # ------------------------------------------------------------------ reference sharding
-    def set_shard(self, rank, world, group=None):
+    def set_shard(self, rank, world, group=None, force_collectives=False):
         """Keep only references [begin, end) = parallel.shard_range(rfn, rank, world) on this rank (call before
-        load_ref_imgs / extract_ref_feats). world == 1 restores the unsharded behaviour."""
+        load_ref_imgs / extract_ref_feats). world == 1 restores the unsharded behaviour — unless `force_collectives`: then the
+        sharded code path runs with its 9 collectives per batch on a one-rank process group (RCCL accepts every collective at world
+        size 1), which is how the path meets ncclAllReduce / ncclAllGather and stream capture on a 1-GPU box."""
         self.rank, self.world, self.group = int(rank), int(world), group
+        self.sharded = self.world > 1 or bool(force_collectives)
 
     def _allreduce(self, tensors):
         """Sum small fp64 statistics tensors over the ranks in ONE collective."""
-        if self.world == 1:
+        if not self.sharded:
             return
         flat = torch.cat([t.reshape(-1) for t in tensors])
         parallel.all_reduce_(flat, "sum", self.group)
@@ -74,14 +78,14 @@ class ViewpointSelector(ParamBank):
 
     def _allgather_rows(self, rows, n_total):
         """[n_local, F] per rank -> [n_total, F] in global reference order."""
-        if self.world == 1:
+        if not self.sharded:
             return rows
         return parallel.all_gather_ragged_rows(rows, n_total, self.world, self.group)
 
     def _allgather_batch(self, t, qn, n_local, n_total):
         """[qn * n_local, F] (query-major rows of the local references) -> [qn * n_total, F] over all references: ONE all-gather
         for the whole batch (a rank's message = its references' rows of all qn queries)."""
-        if self.world == 1:
+        if not self.sharded:
             return t
         F_ = t.shape[1]
         rows = t.view(qn, n_local, F_).permute(1, 0, 2).reshape(n_local, qn * F_).contiguous()
@@ -187,7 +191,7 @@ class ViewpointSelector(ParamBank):
             out = cat[..., 256 * l:256 * l + 256] if last else torch.empty((qn * D, 1, h, w, co), dtype=torch.float32, device=dev)
             stats = ops.new_stats(qn, co, dev) if has_in else None
             # InstanceNorm finalisation inside the producing launch, unless the statistics still have to be summed over ranks
-            fin = Dg * h * w if (has_in and not last and self.world == 1) else None
+            fin = Dg * h * w if (has_in and not last and not self.sharded) else None
             with ops.math_mode("fp32" if (first and "product" in self.cfg.get("lowp_keep_fp32", ())) else None, inherit_if_none=True):
                 res = ops.conv(x, wgt, bias, out, ksize=_K133, pad=_P011, mul=mul, in_scale=scale, in_shift=shift, in_relu=relu, stats=stats,
                                w_wino=wu, finalize=fin, per_n=grp if scale is not None else 0, rows_per_group=grp * h * w,
@@ -225,7 +229,7 @@ class ViewpointSelector(ParamBank):
         caches = [c.view(c.shape[0], c.shape[2] * c.shape[3], 512) for c in self.ref_feats_cache]
         vps, psc, psh, _ = ops.selector_levels([qf[l].view(qn, -1, 512) for l in range(3)], caches, self.ref_sums, Dg)  # [qn,3,D], [qn,3,512]
         levels = [self._level(l, qf[l], cat, psc[:, l].contiguous(), psh[:, l].contiguous(), qn) for l in range(3)]
-        if self.world == 1:
+        if not self.sharded:
             ops.fork_join([(lambda g=g: sum(1 for _ in g)) for g in levels], dev)       # nothing is yielded: the levels run side by side
         else:
             # sharded: the three levels advance in lock-step on ONE stream (collectives must be issued in the same order on every
@@ -244,7 +248,7 @@ class ViewpointSelector(ParamBank):
         # corr_feats_conv: 1x1x1 768->512, IN3d, ReLU, (AvgPool commuted) 512->512   selector.py:71-77,197-200
         y = torch.empty((qn * D, 1, 4, 4, 512), dtype=torch.float32, device=dev)
         st = ops.new_stats(qn, 512, dev)
-        if self.world == 1:
+        if not self.sharded:
             sc, sh = ops.conv(cat, pk["fuse0"][0], pk["fuse0"][1], y, stats=st, finalize=Dg * 16, rows_per_group=grp * 16)
         else:
             ops.conv(cat, pk["fuse0"][0], pk["fuse0"][1], y, stats=st, rows_per_group=grp * 16)
@@ -254,7 +258,7 @@ class ViewpointSelector(ParamBank):
         ops.affine_act_pool(y, pooled, sc, sh, per_n=grp, relu=True, pool=2)
         feats = torch.zeros((qn * D, FEAT_LD), dtype=torch.float32, device=dev)
         ops.conv(pooled.view(1, 1, 1, qn * D, 512), pk["fuse3"][0], pk["fuse3"][1], feats.view(1, 1, 1, qn * D, FEAT_LD)[..., :512])
-        if self.world == 1:
+        if not self.sharded:
             ops.vps_norm(vps, feats, 512)                                               # selector.py:201-202
         else:                                                                           # norm over ALL hypotheses
             # one all-gather for the batch: row r = the (an, qn, 3) scalars of local reference r, in global reference order
@@ -324,8 +328,10 @@ class ViewpointSelector(ParamBank):
         """que_imgs [qn,3,h,w] in [0,1] -> logits [qn,rfn], angles [qn,rfn] (reference selector.py:177-215)."""
         # the queries of a chunk share every launch (and, sharded, every collective); a chunk's largest tensor — the first conv's output
         # [qn * D, h0, w0, 64] — has to stay below the 2^31-byte reach of the kernels' buffer loads (64 x 36 rotations: 14 -> 8 queries)
+        # (sharded: sized by the LARGEST shard, so that every rank cuts the same chunks and issues the same collectives — ADVICE r04)
         c0 = self.ref_feats_cache[0]
-        per_query = c0.shape[0] * c0.shape[2] * c0.shape[3] * 64 * 4
+        d_max = -(-self.rfn // self.world) * self.an
+        per_query = d_max * c0.shape[2] * c0.shape[3] * 64 * 4
         step = max(1, min(MAX_BATCH, ((1 << 31) - 1) // per_query))
         if step >= 8:
             step -= step % 8                           # whole groups of 8 for g6d_selector_levels

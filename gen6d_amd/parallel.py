@@ -9,14 +9,23 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None):
-    """Initialise from RANK / WORLD_SIZE / MASTER_* (torch.distributed.run). Returns (rank, world, local_rank)."""
+def init_from_env(backend=None, force=False):
+    """Initialise from RANK / WORLD_SIZE / MASTER_* (torch.distributed.run). Returns (rank, world, local_rank).
+    force=True creates the process group at world size 1 as well (a one-rank RCCL communicator accepts every collective: the
+    reference-sharded path can be exercised, and captured in a hipGraph, on a 1-GPU box — `bench.py --shard-refs --gpus 1`)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
+        if "MASTER_PORT" not in os.environ:
+            if world == 1:                                  # no launcher: any free port will do
+                import socket
+                with socket.socket() as sock:
+                    sock.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
+            else:
+                os.environ["MASTER_PORT"] = "29533"
         if backend is None:
             backend = os.environ.get("G6D_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
@@ -81,7 +90,7 @@ def gather_rows(local_rows, n_items):
     return torch.cat(out, 0).to(out_device)
 
 
-# When set to a list, every data-path collective appends (kind, bytes, seconds): `bench.py --shard-refs` reports the count per query
+# When set to a list, every data-path collective appends (kind, bytes, seconds, seconds until the call returned): `bench.py --shard-refs` reports the count per query
 # and the mean time per collective.  Host wall time around the call: with RCCL the call only ENQUEUES on the stream (no host staging,
 # no synchronisation), so a stream synchronisation brackets the call while logging; under gloo the tensor goes through the host.
 COLLECTIVE_LOG = None
@@ -95,9 +104,10 @@ def _timed(kind, t, fn):
         torch.cuda.synchronize(t.device)
     t0 = time.perf_counter()
     out = fn()
+    t1 = time.perf_counter()                                  # the call has returned: enqueued (RCCL) or done (gloo)
     if t.is_cuda:
         torch.cuda.synchronize(t.device)
-    COLLECTIVE_LOG.append((kind, t.numel() * t.element_size(), time.perf_counter() - t0))
+    COLLECTIVE_LOG.append((kind, t.numel() * t.element_size(), time.perf_counter() - t0, t1 - t0))
     return out
 
 

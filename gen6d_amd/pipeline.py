@@ -10,7 +10,7 @@ from .network import refiner as refiner_mod
 
 
 class TensorPipeline:
-    def __init__(self, device, sel_rfn=64, det_rfn=32, an=5, refine_iter=3, seed=1234, shard=(0, 1)):
+    def __init__(self, device, sel_rfn=64, det_rfn=32, an=5, refine_iter=3, seed=1234, shard=(0, 1), force_collectives=False):
         self.device = torch.device(device)
         self.refine_iter = refine_iter
         self.cfg = dict(sel_rfn=sel_rfn, det_rfn=det_rfn, an=an, refine_iter=refine_iter)
@@ -21,8 +21,10 @@ class TensorPipeline:
         for k, net in (("detector", self.detector), ("selector", self.selector), ("refiner", self.refiner)):
             net.load_state_dict(self.state_dicts[k])
             net.to(self.device).eval()
-        self.selector.set_shard(*shard)          # (rank, world): references of selector and detector sharded over the ranks
-        self.detector.set_shard(*shard)
+        # (rank, world): references of selector and detector sharded over the ranks; force_collectives: the sharded code path (9 + 1
+        # collectives per batch) at world size 1 as well
+        self.selector.set_shard(*shard, force_collectives=force_collectives)
+        self.detector.set_shard(*shard, force_collectives=force_collectives)
 
     def build(self, seed=1):
         """Reference state from synthetic views (Gen6DEstimator.build, reference estimator.py:139-171)."""

@@ -64,10 +64,24 @@ def _apply_session_switches():
 
 
 def pytest_sessionstart(session):
-    """Achieved parity errors of the GPU tests are appended to gpurun_out/parity_r04.jsonl (tools/parity_table.py turns
-    them into profiles/r04_parity.md)."""
-    os.environ.setdefault("G6D_PARITY_LOG", os.path.join(ROOT, "gpurun_out", "parity_r04.jsonl"))
+    """Achieved parity errors of the GPU tests are appended to gpurun_out/parity_r05.jsonl (tools/parity_table.py turns
+    them into profiles/r05_parity.md)."""
+    os.environ.setdefault("G6D_PARITY_LOG", os.path.join(ROOT, "gpurun_out", "parity_r05.jsonl"))
     _apply_session_switches()
+
+
+@pytest.fixture(autouse=True)
+def _knobs_back_to_defaults(request):
+    """A GPU test that sets launch-policy knobs (directly through lib.set_knob, or by failing inside the `knob` fixture's scope) must
+    not leave a non-default launch policy behind for the tests that follow in the same process."""
+    yield
+    if "gpu" in request.keywords:
+        try:
+            from gen6d_amd import lib
+            lib.reset_knobs()
+            _apply_session_switches()
+        except Exception:
+            pass
 
 
 @pytest.fixture

@@ -5,6 +5,7 @@ timed-but-unchecked:
     det_head.npz      Detector, 480x640 query vs 32 refs (the headline detector call)            detector.py:232-266
     sel_head.npz      ViewpointSelector, 64 refs x 5 rotations (the headline selector call)     selector.py:177-215
     sel_128x5.npz     128 refs x 5 rotations   (BASELINE configs[3] size)
+    sel_32x5.npz      32 refs x 5 rotations    (north_star's 32 / 64 / 128 sweep; round 5)
     sel_64x36.npz     64 refs x 36 rotations   (BASELINE configs[1])
     operator.npz      network/operator.py:4-24 normalize_coords / pose_apply_th / generate_coords
     ref_grids.npz     VolumeRefiner.forward(...)["grids"] (inference=False branch)               refiner.py:262-268
@@ -133,7 +134,7 @@ def main():
     n2n = MG.load_reference()
     if not hasattr(np, "bool"): np.bool = bool
     from gen6d_amd import synth
-    todo = sys.argv[1:] or ["operator", "ref_grids", "det_head", "sel_head", "sel_128x5", "sel_64x36", "pipeline_rows"]
+    todo = sys.argv[1:] or ["operator", "ref_grids", "det_head", "sel_head", "sel_128x5", "sel_32x5", "sel_64x36", "pipeline_rows"]
     for name in todo:
         t0 = time.time()
         if name == "operator": operator_golden()
@@ -141,6 +142,7 @@ def main():
         elif name == "det_head": det_head(n2n, synth)
         elif name == "sel_head": _selector(n2n, synth, "sel_head", 64, 5)
         elif name == "sel_128x5": _selector(n2n, synth, "sel_128x5", 128, 5)
+        elif name == "sel_32x5": _selector(n2n, synth, "sel_32x5", 32, 5)
         elif name == "sel_64x36": _selector(n2n, synth, "sel_64x36", 64, 36)
         elif name == "pipeline_rows": pipeline_rows(n2n, synth)
         else: raise SystemExit(f"unknown fixture {name}")

@@ -166,6 +166,31 @@ def test_more_queries_than_one_launch_batch(monkeypatch):
         np.testing.assert_allclose(out[k][1].numpy(), one[k][0].numpy(), atol=2e-4)
 
 
+def test_detector_chunk_follows_the_image_size(monkeypatch):
+    """the queries of a detector chunk share launches whose 32-bit offsets reach 2^29 floats from one base — the chunk is
+    derived from the image size (16 queries of 480x640, 9 of 720x1280), and an image whose pyramid exceeds the reach by itself runs
+    one trunk pass per scale instead of failing with G6D_EINVAL."""
+    det = name2network["detector"]({"name": "t"}).eval()
+    calls = []
+
+    def fake_batch(que, multi=True):
+        qn, _, hq, wq = que.shape
+        calls.append((qn, multi))
+        hs, ws = hq // 8, wq // 8
+        return torch.zeros(qn, hs, ws, 4), torch.zeros(qn, 5), (hs, ws)
+    monkeypatch.setattr(det, "_detect_batch", fake_batch)
+    for (h, w, n), want in (((480, 640, 20), [(16, True), (4, True)]), ((720, 1280, 11), [(9, True), (2, True)]),
+                            ((2160, 3840, 2), [(1, True), (1, True)])):
+        calls.clear()
+        out = det._detect_impl_fp(torch.zeros(n, 3, h, w).expand(n, 3, h, w))
+        assert calls == want, (h, w, calls)
+        assert out["scores"].shape == (n, 1, h // 8, w // 8) and out["positions"].shape == (n, 2)
+    # (an image of 4000 x 6000 pixels: the pyramid alone is 1.4e9 floats at 64 channels -> per-scale trunk passes)
+    per_query = sum(det._scale_size(4000, 6000, s)[0] * det._scale_size(4000, 6000, s)[1] for s in det.cfg["detection_scales"]) // 4 * 64
+    assert per_query >= (1 << 29)
+    assert det._scale_size(480, 640, 0.5) == (704, 928) and det._scale_size(480, 640, -1.0) == (256, 320)      # reference detector.py:237-239
+
+
 def test_padded_correlation_filters_for_the_7x7_level():
     """backbone.winograd43_corr_filters_padded: the 7x7 correlation filters zero-extended to 9x9 and cut into 3x3 blocks of 3x3 reproduce
     the direct 7x7 "same" correlation when accumulated block-wise in the F(4x4,3x3) domain (the algorithm of g6d_corr2d_wino43_multi with

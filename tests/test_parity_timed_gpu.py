@@ -43,7 +43,7 @@ def test_detector_headline_480x640x32(golden):
     np.testing.assert_allclose(out["scales"].cpu().numpy(), g["scales"], rtol=5e-3)
 
 
-@pytest.mark.parametrize("tag,fp64_state", [("sel_128x5", True), ("sel_64x36", False)])
+@pytest.mark.parametrize("tag,fp64_state", [("sel_128x5", True), ("sel_32x5", True), ("sel_64x36", False)])
 def test_selector_sweep_sizes(golden, tag, fp64_state):
     """128 refs x 5 rotations and 64 x 36 (2304 hypotheses, 1.6 GB cache).  For 64x36 the fp64 reference state is built
     from the oracle's fp32 feature cache cast to double (a genuine fp64 trunk over 2304 crops takes minutes of host

@@ -16,6 +16,7 @@ CASES = {
     "sel_mid": lambda g: (synth.selector_case(16, 5), synth.synth_state_dict("selector", an=5)),
     "sel_head": lambda g: (synth.selector_case(64, 5), synth.synth_state_dict("selector", an=5)),
     "sel_128x5": lambda g: (synth.selector_case(128, 5), synth.synth_state_dict("selector", an=5)),
+    "sel_32x5": lambda g: (synth.selector_case(32, 5), synth.synth_state_dict("selector", an=5)),
     "sel_64x36": lambda g: (synth.selector_case(64, 36), synth.synth_state_dict("selector", an=36)),
     "ref_step": lambda g: (synth.refiner_case(), synth.synth_state_dict("refiner")),
     "ref_grids": lambda g: (synth.refiner_case(), synth.synth_state_dict("refiner")),
