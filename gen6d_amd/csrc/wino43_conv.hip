@@ -85,6 +85,7 @@ struct W43Args {
   int aff_div;                                   // MODE 2: image i uses affine table i / aff_div
   double* stats; int stats_div;                  // [groups][Cout][2]; group of image i = i / stats_div (0: one group)
   G6dFin fin;
+  int gx, gy, map_mode;                          // pixel-tile blocks, channel-slice blocks; block id -> (bx, by) mapping (w43_block_of)
 };
 
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -106,9 +107,25 @@ __device__ __forceinline__ void mfma16(float a, float b, f32x4& c) {
   else c = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// Block id -> (pixel-tile block bx, channel-slice block by).  map_mode 0: the launch grid itself (x = pixel tiles fastest, y = slices): the
+// 256 resident blocks work on ONE channel slice, and every slice re-reads the layer's input from HBM (pyramid inputs are 0.6-1.2 GB at
+// batches of 8-16: far beyond the 256 MB Infinity Cache).  map_mode 1 (1-D grid): hardware hands consecutive workgroup ids to the 8 XCDs
+// in turn, so within a group of 8 pixel tiles the id runs (tile-in-group fastest, then slice): XCD k gets tile 8g + k with ALL its gy
+// slices back to back — they run side by side on that XCD's CUs and share the tile's raw patches through its L2 (input read from HBM
+// once instead of gy times; the filter slices of a layer are then streamed by every XCD from the Infinity Cache).  map_mode 2: slices
+// fastest, plain (the slices of a tile land on neighbouring XCDs: shared through the Infinity Cache only).
+__device__ __forceinline__ void w43_block_of(const W43Args& p, int& bx, int& by) {
+  if (p.map_mode == 0) { bx = blockIdx.x; by = blockIdx.y; return; }
+  const int L = blockIdx.x;
+  if (p.map_mode == 2) { bx = L / p.gy; by = L - bx * p.gy; return; }
+  const int per = 8 * p.gy, g = L / per, Lp = L - g * per;
+  const int m = min(8, p.gx - 8 * g);
+  by = Lp / m; bx = 8 * g + (Lp - by * m);
+}
+
 struct QGeo { int n, oy0, ox0; bool valid; int H, W, ld_in, ld_full, ld_pool, in_off, full_off, pool_off; };
-__device__ __forceinline__ QGeo quarter_of(const W43Args& p, int q) {
-  const int Q = blockIdx.x * W43_NQ + q;
+__device__ __forceinline__ QGeo quarter_of(const W43Args& p, int bx, int q) {
+  const int Q = bx * W43_NQ + q;
   int sidx = 0;
 #pragma unroll
   for (int k = 1; k < W43_MAX_SEG; ++k) sidx = (k < p.nseg && Q >= p.seg[k].qstart) ? k : sidx;
@@ -173,8 +190,10 @@ __global__ void __launch_bounds__(256, 1) wino43_kernel(const W43Args p) {
   // every thread needs it for its seven raw pieces and again in the epilogue — done per thread, the ~30 divisions were 3 us of a
   // block's 6 us prologue (profiles/r04_w43_phase_timing.md)
   __shared__ __attribute__((aligned(128))) int qtab[W43_NQ * 16];
+  int bx, by;
+  w43_block_of(p, bx, by);
   if (tid < W43_NQ) {
-    const QGeo g = quarter_of(p, tid);
+    const QGeo g = quarter_of(p, bx, tid);
     int* t = qtab + tid * 16;
     t[0] = g.valid; t[1] = g.n; t[2] = g.oy0; t[3] = g.ox0; t[4] = g.H; t[5] = g.W; t[6] = g.ld_in; t[7] = g.ld_full;
     t[8] = g.ld_pool; t[9] = g.in_off; t[10] = g.full_off; t[11] = g.pool_off;
@@ -189,7 +208,7 @@ __global__ void __launch_bounds__(256, 1) wino43_kernel(const W43Args p) {
   };
   const int pr = wave >> 1, hh = wave & 1;
   const int lt = lane & 15, kg = lane >> 4;
-  const int n0 = blockIdx.y * (16 * NT);
+  const int n0 = by * (16 * NT);
   const int nc8 = p.Cin >> 3;
   const int c_first = blockIdx.z * p.chunks_per_split;
   const int c_last = min(KD * nc8, c_first + p.chunks_per_split) - 1;
@@ -294,9 +313,9 @@ __global__ void __launch_bounds__(256, 1) wino43_kernel(const W43Args p) {
   // chunk were 20 % of the kernel, plus 10 % for their scalar address / M0 code — against ~6 + 13 for a load and a ds_write_b128; the
   // registers are those of the input transform, idle between two transforms.  (Also measured and dropped: fragments straight from
   // L2 into registers without LDS, 17 % slower; a three-slot ring with two phases of lead; requests staggered over the waves.)
-  const auto u_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.U) + (size_t)blockIdx.y * HALF, 0, 0x7ffffff0, 0x00020000);
+  const auto u_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.U) + (size_t)by * HALF, 0, 0x7ffffff0, 0x00020000);
   const unsigned lane16 = lane * 16;                       // lane offset; the piece's offset (< 2^31: launch check) is the instruction's scalar offset
-  const unsigned half_bytes = gridDim.y * (HALF * 4);
+  const unsigned half_bytes = p.gy * (HALF * 4);
   f32x4 fp[NPC];
   auto fidx = [&](int k) { int idx = wave * NPC + k; if (PCS % 4 != 0) idx = idx % PCS; return idx; };
   auto load_f = [&](int chunk, int half, int k) {
@@ -529,7 +548,7 @@ __global__ void __launch_bounds__(256, 1) wino43_kernel(const W43Args p) {
     // partial OUTPUT tiles (the output transform is linear) -> workspace as [split][tile][k][thread] 16-byte pieces; the block of a tile
     // that arrives last adds them in split order and carries on with bias / ReLU / pool / statistics
     constexpr int TILE = THREADS * NT * 32;
-    const int ntiles = gridDim.x * gridDim.y, tile = blockIdx.y * gridDim.x + blockIdx.x;
+    const int ntiles = p.gx * p.gy, tile = by * p.gx + bx;
     float* part = p.ws + G6D_WS_COUNTERS + (size_t)tile * TILE + tid * 4;
     const size_t zstride = (size_t)ntiles * TILE;
 #pragma unroll
@@ -642,7 +661,7 @@ __global__ void __launch_bounds__(256, 1) wino43_kernel(const W43Args p) {
     }
     if (p.fin.scale) {
       __syncthreads();
-      g6d_finalize_stats(p.fin, gridDim.x * gridDim.y, reinterpret_cast<int*>(lds));
+      g6d_finalize_stats(p.fin, p.gx * p.gy, reinterpret_cast<int*>(lds));
     }
   }
 #ifdef W43_TIMING
@@ -660,7 +679,11 @@ int w43_launch_t(W43Args& a, long long blocks, hipStream_t stream) {
   const size_t lds_bytes = ((size_t)2 * W43_RAWF + 2 * (18 * 16 * NT * 8) + (MODE == 0 ? 0 : (MODE >= 2 ? 2 * W43_NQ : 2) * a.Cin)) * sizeof(float);
   const size_t need = std::max(lds_bytes, (size_t)4 * 4096 * sizeof(float));      // the epilogue exchange: 16 KB per wave
   g6d_allow_lds(reinterpret_cast<const void*>(&wino43_kernel<MODE, KD, NT>), 160 * 1024 - 512);      // (512 B of static LDS: the quarter table)
-  hipLaunchKernelGGL((wino43_kernel<MODE, KD, NT>), dim3((unsigned)blocks, a.Cout / (16 * NT), a.splits), dim3(256), need, stream, a);
+  a.gx = (int)blocks; a.gy = a.Cout / (16 * NT);
+  a.map_mode = (int)g6d_knob(G6D_KNOB_W43_MAP);
+  if (a.gy == 1 || (long long)a.gx * a.gy >= (1ll << 31)) a.map_mode = 0;
+  const dim3 grid = a.map_mode == 0 ? dim3((unsigned)blocks, a.gy, a.splits) : dim3((unsigned)(blocks * a.gy), 1, a.splits);
+  hipLaunchKernelGGL((wino43_kernel<MODE, KD, NT>), grid, dim3(256), need, stream, a);
   return g6d_check_launch("wino43_conv3x3");
 }
 

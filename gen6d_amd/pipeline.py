@@ -100,7 +100,9 @@ class TensorPipeline:
                     self.query(g_full, g_crop, cached_refs)
             torch.cuda.synchronize(d)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=stream):
+            # thread_local: a process group's watchdog thread polls its work events while this thread captures; under the default
+            # (global) capture mode such a query from another thread fails and takes the process down
+            with torch.cuda.graph(graph, stream=stream, capture_error_mode="thread_local"):
                 g_out = self.query(g_full, g_crop, cached_refs)
             self._lanes.append((graph, stream, g_full, g_crop, g_out))
         torch.cuda.synchronize(d)

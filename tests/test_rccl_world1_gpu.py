@@ -81,7 +81,7 @@ def test_sharded_path_on_rccl_world1_eager_and_captured(tmp_path):
     assert "rccl world-1 ok" in out.stdout
     try:
         from parity_log import record
-        tail = out.stdout.strip().splitlines()[-1]
+        tail = [l for l in out.stdout.splitlines() if "rccl world-1 ok" in l][-1]      # (RCCL prints its version banner at exit)
         record("test_sharded_path_on_rccl_world1_eager_and_captured", "captured graph rows vs golden rows (rel)", float(tail.split()[-1]), 1e-4)
     except Exception:
         pass

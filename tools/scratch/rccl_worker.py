@@ -1,0 +1,47 @@
+
+import os, sys, numpy as np, torch
+sys.path.insert(0, '/root/repo')
+from gen6d_amd import ops, parallel, synth
+from gen6d_amd.pipeline import TensorPipeline
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+rank, world, _ = parallel.init_from_env(backend="nccl", force=True)
+assert (rank, world) == (0, 1) and parallel.backend_name() == "nccl"
+ops.SERIAL = True
+parallel.COLLECTIVE_LOG = []
+pipe = TensorPipeline(dev, shard=(0, 1), force_collectives=True)
+pipe.build()
+n_build = len(parallel.COLLECTIVE_LOG)
+fulls = synth.imgs_to_tensor(synth.synth_images(4, 480, 640, seed=100)).to(dev)
+crops = synth.imgs_to_tensor(synth.synth_images(4, 128, 128, seed=200)).to(dev)
+B = 2
+rows_sh = pipe.query(fulls[0:B], crops[0:B])
+torch.cuda.synchronize()
+log, parallel.COLLECTIVE_LOG = parallel.COLLECTIVE_LOG, None
+n_query = len(log) - n_build
+kinds = sorted(k for k, *_ in log[n_build:])
+assert n_build == 1 and n_query == 10, (n_build, n_query, kinds)       # R1/R2 at build; 9 selector + 1 detector per batch
+assert kinds.count("all_reduce_max") == 1 and kinds.count("all_reduce_sum") == 6 and kinds.count("all_gather_rows") == 3, kinds
+# the same pipeline without collectives
+pipe.selector.sharded = pipe.detector.sharded = False
+rows_un = torch.cat([pipe.query(fulls[i:i + B], crops[i:i + B]) for i in (0, 2)], 0)
+pipe.selector.sharded = pipe.detector.sharded = True
+torch.cuda.synchronize()
+rel = lambda a, b: float(((a - b).abs() / b.abs().clamp(min=1.0)).max())
+e_eager = rel(rows_sh, rows_un[0:B])
+assert e_eager <= 1e-4 and bool((rows_sh[:, 3] == rows_un[0:B, 3]).all()), e_eager
+# kernels + collectives of a batch in ONE hipGraph; replayed on the captured images and on two others
+pipe.capture(lanes=1, batch=B)
+got = []
+for i in (0, 2, 0):
+    out, stream = pipe.query_graph(fulls[i:i + B], crops[i:i + B], 0)
+    stream.synchronize()
+    got.append(out.clone())
+e_graph = max(rel(got[0], rows_un[0:B]), rel(got[1], rows_un[2:4]), rel(got[2], rows_un[0:B]))
+assert e_graph <= 1e-4, e_graph
+assert float((got[0] - got[1]).abs().max()) > 1e-3                      # the replay really processed the other images
+gold = torch.from_numpy(np.load(os.path.join('/root/repo', "tests", "golden", "pipeline_rows.npz"))["rows"]).float().to(dev)
+e_gold = max(rel(got[0], gold[0:B]), rel(got[1], gold[2:4]))
+assert e_gold <= 1e-4 and bool((got[1][:, 3] == gold[2:4, 3]).all()), e_gold
+torch.distributed.destroy_process_group()
+print("rccl world-1 ok: collectives per batch", n_query, "eager vs plain %.2e graph vs plain %.2e graph vs golden %.2e" % (e_eager, e_graph, e_gold))
