@@ -153,6 +153,15 @@ __device__ __forceinline__ void bt_full(const f2 (&d)[6], f2 (&r)[6]) {
   r[4] = fma2(Ob, -WB, Eb);
   r[5] = fma2(d[1], WC0, fma2(d[3], -WC2, d[5]));
 }
+__device__ __forceinline__ f2 mul2(f2 a, float k) { return a * f2{k, k}; }
+// 1-D output transform of one row of six transform-domain values, two channel tiles at a time (packed)
+__device__ __forceinline__ void at_row2(const f2 (&m)[6], f2 (&y)[4]) {
+  const f2 s1 = fma2(m[2], 1.f, m[1]), d1 = fma2(m[2], -1.f, m[1]), s2 = fma2(m[4], 1.f, m[3]), d2 = fma2(m[4], -1.f, m[3]);
+  y[0] = fma2(s2, 1.f, fma2(s1, 1.f, m[0]));
+  y[1] = fma2(d2, WB, mul2(d1, WA));
+  y[2] = fma2(s2, WB2, mul2(s1, WA2));
+  y[3] = fma2(d2, WB3, fma2(d1, WA3, m[5]));
+}
 // 1-D output transform of one row of six transform-domain values
 __device__ __forceinline__ void at_row(const float (&m)[6], float (&y)[4]) {
   const float s1 = m[1] + m[2], d1 = m[1] - m[2], s2 = m[3] + m[4], d2 = m[3] - m[4];
@@ -186,12 +195,53 @@ __global__ void __launch_bounds__(256, 1) wino43_kernel(const W43Args p) {
   constexpr int NPC = (PCS + 3) / 4;                        // ... per wave (NT = 2: 4.5 -> 5, the surplus pieces repeat piece idx % PCS)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int bx, by;
+  w43_block_of(p, bx, by);
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const int pr = wave >> 1, hh = wave & 1;
+  const int lt = lane & 15, kg = lane >> 4;
+  const int n0 = by * (16 * NT);
+  const int nc8 = p.Cin >> 3;
+  const int c_first = blockIdx.z * p.chunks_per_split;
+  const int c_last = min(KD * nc8, c_first + p.chunks_per_split) - 1;
+
+  // ---- filter half-tiles: U43 is [chunk][half][co block][18 positions][NT/2][kg][lt][4] — a block's half is ONE contiguous run of
+  // 18 NT KB in exactly the order of its LDS image.  A lane's 16 bytes at [position][np][kg][lt] are its B operands for the channel
+  // tiles 2np and 2np+1 (two channels each): ONE ds_read_b128 per two tiles, conflict-free in all four 16-lane service groups, and at
+  // the full LDS rate from one wave per SIMD (8-byte reads reach a fifth of it there: MI355X_MICROARCH.md, LDS).
+  // Two slots: phase X computes from slot 0 while slot 1 receives Y of the chunk, phase Y from slot 1 while slot 0 receives X of the
+  // next chunk.  The pieces (1 KB per wave instruction) travel global -> registers -> LDS: measured on this kernel
+  // (profiles/r04_w43_ablate_*.md), a direct-to-LDS piece costs its wave ~60 cycles of issue beside the MFMAs — 25 pieces per wave and
+  // chunk were 20 % of the kernel, plus 10 % for their scalar address / M0 code — against ~6 + 13 for a load and a ds_write_b128; the
+  // registers are those of the input transform, idle between two transforms.  (Also measured and dropped: fragments straight from
+  // L2 into registers without LDS, 17 % slower; a three-slot ring with two phases of lead; requests staggered over the waves.)
+  const auto u_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.U) + (size_t)by * HALF, 0, 0x7ffffff0, 0x00020000);
+  const unsigned lane16 = lane * 16;                       // lane offset; the piece's offset (< 2^31: launch check) is the instruction's scalar offset
+  const unsigned half_bytes = p.gy * (HALF * 4);
+  f32x4 fp[NPC];
+  auto fidx = [&](int k) { int idx = wave * NPC + k; if (PCS % 4 != 0) idx = idx % PCS; return idx; };
+  auto load_f = [&](int chunk, int half, int k) {
+    if (W43_ABLATE == 12) { asm volatile("" : "+v"(fp[k])); return; }
+    if (W43ABL(2)) return;
+    fp[k] = __builtin_bit_cast(f32x4, __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, lane16, (2 * chunk + half) * half_bytes + fidx(k) * 1024, 0)));
+  };
+  auto store_f = [&](int slot, int k) {
+    if (W43_ABLATE == 11) { asm volatile("" :: "v"(fp[k])); return; }
+    if (W43ABL(2)) return;
+    *reinterpret_cast<f32x4*>(__builtin_assume_aligned(lds + FLT0 + slot * HALF + fidx(k) * 256 + lane * 4, 16)) = fp[k];
+  };
+
+  // the first chunk's filter half is requested BEFORE the piece geometry (segment search, quarter table, ~60 LDS reads and the
+  // affine tables): its ~2 us of latency under load run beside that work instead of behind it (profiles/r04_w43_phase_timing.md:
+  // a block spent 12-15 k cycles in front of its first chunk)
+#pragma unroll
+  for (int k = 0; k < NPC; ++k) load_f(c_first, 0, k);
+  __builtin_amdgcn_sched_barrier(0);
+
   // geometry of the block's eight quarters, computed ONCE (segment search + two runtime divisions each) by eight lanes and kept in LDS:
   // every thread needs it for its seven raw pieces and again in the epilogue — done per thread, the ~30 divisions were 3 us of a
   // block's 6 us prologue (profiles/r04_w43_phase_timing.md)
   __shared__ __attribute__((aligned(128))) int qtab[W43_NQ * 16];
-  int bx, by;
-  w43_block_of(p, bx, by);
   if (tid < W43_NQ) {
     const QGeo g = quarter_of(p, bx, tid);
     int* t = qtab + tid * 16;
@@ -206,12 +256,6 @@ __global__ void __launch_bounds__(256, 1) wino43_kernel(const W43Args p) {
     g.ld_pool = t[8]; g.in_off = t[9]; g.full_off = t[10]; g.pool_off = t[11];
     return g;
   };
-  const int pr = wave >> 1, hh = wave & 1;
-  const int lt = lane & 15, kg = lane >> 4;
-  const int n0 = by * (16 * NT);
-  const int nc8 = p.Cin >> 3;
-  const int c_first = blockIdx.z * p.chunks_per_split;
-  const int c_last = min(KD * nc8, c_first + p.chunks_per_split) - 1;
 
   // ---- raw patch loader.  LDS image: position (q, py, px) at ((q*101 + py*10 + px) * 8) floats, its two 4-channel halves swapped
   // when (py >> 2) is odd (every ds_read_b64 of the fragment loop is then bank-conflict free: exhaustive check over both 32-lane
@@ -255,11 +299,11 @@ __global__ void __launch_bounds__(256, 1) wino43_kernel(const W43Args p) {
   }
   const int slice = p.H0 * p.W0 * p.ld0;                      // KD = 3: one depth step
   const auto in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
-  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   f32x4 rp[NPR];
   bool rv[MODE != 0 ? NPR : 1];
   // piece j of chunk `chunk` -> rp[j] (the LDS image is written by store_piece, where the MODE != 0 prologue runs)
   auto load_piece = [&](int j, int chunk) {
+    if (W43_ABLATE == 12) { asm volatile("" : "+v"(rp[j])); return; }      // (an opaque definition: the stores stay)
     if (W43ABL(2)) return;
     const int kd = CORR ? chunk % KD : (KD != 1 ? chunk / nc8 : 0), cc = CORR ? chunk / KD : (KD != 1 ? chunk - kd * nc8 : chunk);
     unsigned voff; int soff = 0;
@@ -280,6 +324,7 @@ __global__ void __launch_bounds__(256, 1) wino43_kernel(const W43Args p) {
     rp[j] = __builtin_bit_cast(f32x4, __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, voff, soff, 0)));
   };
   auto store_piece = [&](int j, int chunk, int stage) {        // affine (+ReLU) with exact zeros outside the image for MODE != 0, -> LDS
+    if (W43_ABLATE == 11) { asm volatile("" :: "v"(rp[j])); return; }         // (an opaque use: the loads stay)
     if (W43ABL(2)) return;
     f32x4 v = rp[j];
     if constexpr (MODE != 0) {
@@ -303,30 +348,6 @@ __global__ void __launch_bounds__(256, 1) wino43_kernel(const W43Args p) {
     }
     __syncthreads();
   }
-  // ---- filter half-tiles: U43 is [chunk][half][co block][18 positions][NT/2][kg][lt][4] — a block's half is ONE contiguous run of
-  // 18 NT KB in exactly the order of its LDS image.  A lane's 16 bytes at [position][np][kg][lt] are its B operands for the channel
-  // tiles 2np and 2np+1 (two channels each): ONE ds_read_b128 per two tiles, conflict-free in all four 16-lane service groups, and at
-  // the full LDS rate from one wave per SIMD (8-byte reads reach a fifth of it there: MI355X_MICROARCH.md, LDS).
-  // Two slots: phase X computes from slot 0 while slot 1 receives Y of the chunk, phase Y from slot 1 while slot 0 receives X of the
-  // next chunk.  The pieces (1 KB per wave instruction) travel global -> registers -> LDS: measured on this kernel
-  // (profiles/r04_w43_ablate_*.md), a direct-to-LDS piece costs its wave ~60 cycles of issue beside the MFMAs — 25 pieces per wave and
-  // chunk were 20 % of the kernel, plus 10 % for their scalar address / M0 code — against ~6 + 13 for a load and a ds_write_b128; the
-  // registers are those of the input transform, idle between two transforms.  (Also measured and dropped: fragments straight from
-  // L2 into registers without LDS, 17 % slower; a three-slot ring with two phases of lead; requests staggered over the waves.)
-  const auto u_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.U) + (size_t)by * HALF, 0, 0x7ffffff0, 0x00020000);
-  const unsigned lane16 = lane * 16;                       // lane offset; the piece's offset (< 2^31: launch check) is the instruction's scalar offset
-  const unsigned half_bytes = p.gy * (HALF * 4);
-  f32x4 fp[NPC];
-  auto fidx = [&](int k) { int idx = wave * NPC + k; if (PCS % 4 != 0) idx = idx % PCS; return idx; };
-  auto load_f = [&](int chunk, int half, int k) {
-    if (W43ABL(2)) return;
-    fp[k] = __builtin_bit_cast(f32x4, __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, lane16, (2 * chunk + half) * half_bytes + fidx(k) * 1024, 0)));
-  };
-  auto store_f = [&](int slot, int k) {
-    if (W43ABL(2)) return;
-    *reinterpret_cast<f32x4*>(__builtin_assume_aligned(lds + FLT0 + slot * HALF + fidx(k) * 256 + lane * 4, 16)) = fp[k];
-  };
-
   // ---- fragment bases.  A: tile lt of the pair = quarter 4 pr + (lt >> 2), tile (ty, tx) of its 2x2; raw rows 4 ty + i
   const int ty = (lt >> 1) & 1, tx = lt & 1;
   const int apos = ((4 * pr + (lt >> 2)) * W43_QPIX + (4 * ty) * 10 + 4 * tx) * 8;
@@ -339,21 +360,22 @@ __global__ void __launch_bounds__(256, 1) wino43_kernel(const W43Args p) {
   const int bbase = FLT0 + (9 * hh) * (NT / 2) * 256 + lane * 4;
 
   f32x4 acc[3][6][NT];
-#pragma unroll
-  for (int a = 0; a < 3; ++a)
-#pragma unroll
-    for (int b = 0; b < 6; ++b)
-#pragma unroll
-      for (int n = 0; n < NT; ++n) acc[a][b][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const lds_float* L = (const lds_float*)lds;
 #ifdef W43_TIMING
   const long long t_geo = clock64() - t_start;      // launch to first request: piece geometry (quarter_of: runtime divisions), tables
 #endif
 #pragma unroll
-  for (int k = 0; k < NPC; ++k) load_f(c_first, 0, k);
-#pragma unroll
   for (int j = 0; j < NPR; ++j) load_piece(j, c_first);
+  __builtin_amdgcn_sched_barrier(0);
+  // accumulator initialisation (288 vector-ALU instructions) in the shadow of the first chunk's requests
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 6; ++b)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[a][b][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int k = 0; k < NPC; ++k) store_f(0, k);
 #pragma unroll
@@ -494,54 +516,56 @@ __global__ void __launch_bounds__(256, 1) wino43_kernel(const W43Args p) {
   // Partial outputs of the wave's three transform rows, P[x][y] = sum_a A^T[x][3hh+a] (row a transformed along b).
   // Wave hh keeps output rows 2hh, 2hh+1 and hands rows 2(1-hh), 2(1-hh)+1 to its partner, NT/2 channel tiles per round (64 floats per
   // lane and round, lane-linear 16-byte rows: 16 KB per wave; the K loop's LDS is free: every wave has passed its last barrier).
-  float Y[NT][4][2][4];                              // [nt][r][output row 2hh + xl][output column]
+  // All of it on PAIRS of channel tiles (n = 2 rd, 2 rd + 1 in the two halves of a 64-bit register pair): v_pk_fma_f32 does two lanes'
+  // worth of the transform per issue slot, and vector-ALU time is what the epilogue is made of (~2100 scalar instructions before).
+  f2 Y[NT / 2][4][2][4];                             // [rd][r][output row 2hh + xl][output column], .x = tile 2 rd, .y = tile 2 rd + 1
   float* xbuf = lds;
+  constexpr float ONE = 1.f;
 #pragma unroll
   for (int rd = 0; rd < NT / 2; ++rd) {
-    float keep[2][4][2][4], send[2][4][2][4];
+    f2 keep[4][2][4], send[4][2][4];
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int r = 0; r < 4; ++r) {
+      f2 R[3][4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float R[3][4];
+      for (int a = 0; a < 3; ++a) {
+        f2 m[6];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-          const float m[6] = {acc[a][0][2 * rd + u][r], acc[a][1][2 * rd + u][r], acc[a][2][2 * rd + u][r],
-                              acc[a][3][2 * rd + u][r], acc[a][4][2 * rd + u][r], acc[a][5][2 * rd + u][r]};
-          at_row(m, R[a]);
-        }
+        for (int b = 0; b < 6; ++b) m[b] = f2{acc[a][b][2 * rd][r], acc[a][b][2 * rd + 1][r]};
+        at_row2(m, R[a]);
+      }
 #pragma unroll
-        for (int y = 0; y < 4; ++y) {
-          if (hh == 0) {                             // points 0, +a, -a
-            const float s = R[1][y] + R[2][y], dd = R[1][y] - R[2][y];
-            keep[u][r][0][y] = R[0][y] + s; keep[u][r][1][y] = WA * dd;
-            send[u][r][0][y] = WA2 * s; send[u][r][1][y] = WA3 * dd;
-          } else {                                   // points +b, -b, inf
-            const float s = R[0][y] + R[1][y], dd = R[0][y] - R[1][y];
-            send[u][r][0][y] = s; send[u][r][1][y] = WB * dd;
-            keep[u][r][0][y] = WB2 * s; keep[u][r][1][y] = fmaf(WB3, dd, R[2][y]);
-          }
+      for (int y = 0; y < 4; ++y) {
+        if (hh == 0) {                               // points 0, +a, -a
+          const f2 s = fma2(R[2][y], ONE, R[1][y]), dd = fma2(R[2][y], -ONE, R[1][y]);
+          keep[r][0][y] = fma2(s, ONE, R[0][y]); keep[r][1][y] = mul2(dd, WA);
+          send[r][0][y] = mul2(s, WA2); send[r][1][y] = mul2(dd, WA3);
+        } else {                                     // points +b, -b, inf
+          const f2 s = fma2(R[1][y], ONE, R[0][y]), dd = fma2(R[1][y], -ONE, R[0][y]);
+          send[r][0][y] = s; send[r][1][y] = mul2(dd, WB);
+          keep[r][0][y] = mul2(s, WB2); keep[r][1][y] = fma2(dd, WB3, R[2][y]);
         }
       }
+    }
     if (rd > 0) __syncthreads();                     // the previous round's rows have been read
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
+      for (int xl = 0; xl < 2; ++xl)
 #pragma unroll
-        for (int xl = 0; xl < 2; ++xl)
-          *reinterpret_cast<f32x4*>(xbuf + wave * 4096 + (((u * 4 + r) * 2 + xl) * 64 + lane) * 4) =
-              f32x4{send[u][r][xl][0], send[u][r][xl][1], send[u][r][xl][2], send[u][r][xl][3]};
+        for (int yp = 0; yp < 2; ++yp)
+          *reinterpret_cast<f32x4*>(xbuf + wave * 4096 + (((r * 2 + xl) * 2 + yp) * 64 + lane) * 4) =
+              f32x4{send[r][xl][2 * yp].x, send[r][xl][2 * yp].y, send[r][xl][2 * yp + 1].x, send[r][xl][2 * yp + 1].y};
     __syncthreads();
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
+      for (int xl = 0; xl < 2; ++xl)
 #pragma unroll
-        for (int xl = 0; xl < 2; ++xl) {
-          const f32x4 o = *reinterpret_cast<const f32x4*>(xbuf + (wave ^ 1) * 4096 + (((u * 4 + r) * 2 + xl) * 64 + lane) * 4);
-#pragma unroll
-          for (int y = 0; y < 4; ++y) Y[2 * rd + u][r][xl][y] = keep[u][r][xl][y] + o[y];
+        for (int yp = 0; yp < 2; ++yp) {
+          const f32x4 o = *reinterpret_cast<const f32x4*>(xbuf + (wave ^ 1) * 4096 + (((r * 2 + xl) * 2 + yp) * 64 + lane) * 4);
+          Y[rd][r][xl][2 * yp] = fma2(f2{o[0], o[1]}, ONE, keep[r][xl][2 * yp]);
+          Y[rd][r][xl][2 * yp + 1] = fma2(f2{o[2], o[3]}, ONE, keep[r][xl][2 * yp + 1]);
         }
   }
   if (p.splits > 1) {
@@ -552,33 +576,37 @@ __global__ void __launch_bounds__(256, 1) wino43_kernel(const W43Args p) {
     float* part = p.ws + G6D_WS_COUNTERS + (size_t)tile * TILE + tid * 4;
     const size_t zstride = (size_t)ntiles * TILE;
 #pragma unroll
-    for (int n = 0; n < NT; ++n)
+    for (int rd = 0; rd < NT / 2; ++rd)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int xl = 0; xl < 2; ++xl)
-          g6d_store_wt(part + blockIdx.z * zstride + ((n * 4 + r) * 2 + xl) * (THREADS * 4),
-                       f32x4{Y[n][r][xl][0], Y[n][r][xl][1], Y[n][r][xl][2], Y[n][r][xl][3]});
+#pragma unroll
+          for (int yp = 0; yp < 2; ++yp)
+            g6d_store_wt(part + blockIdx.z * zstride + (((rd * 4 + r) * 2 + xl) * 2 + yp) * (THREADS * 4),
+                         f32x4{Y[rd][r][xl][2 * yp].x, Y[rd][r][xl][2 * yp].y, Y[rd][r][xl][2 * yp + 1].x, Y[rd][r][xl][2 * yp + 1].y});
     if (!g6d_split_arrive(reinterpret_cast<int*>(p.ws) + tile, p.splits, reinterpret_cast<int*>(lds))) return;
 #pragma unroll
-    for (int n = 0; n < NT; ++n)
+    for (int rd = 0; rd < NT / 2; ++rd)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int xl = 0; xl < 2; ++xl)
 #pragma unroll
-          for (int y = 0; y < 4; ++y) Y[n][r][xl][y] = 0.f;
+          for (int y = 0; y < 4; ++y) Y[rd][r][xl][y] = f2{0.f, 0.f};
     for (int z = 0; z < p.splits; ++z) {
 #pragma unroll
-      for (int n = 0; n < NT; ++n)
+      for (int rd = 0; rd < NT / 2; ++rd)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-          for (int xl = 0; xl < 2; ++xl) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(part + (size_t)z * zstride + ((n * 4 + r) * 2 + xl) * (THREADS * 4));
+          for (int xl = 0; xl < 2; ++xl)
 #pragma unroll
-            for (int y = 0; y < 4; ++y) Y[n][r][xl][y] += v[y];
-          }
+            for (int yp = 0; yp < 2; ++yp) {
+              const f32x4 v = *reinterpret_cast<const f32x4*>(part + (size_t)z * zstride + (((rd * 4 + r) * 2 + xl) * 2 + yp) * (THREADS * 4));
+              Y[rd][r][xl][2 * yp] = fma2(f2{v[0], v[1]}, ONE, Y[rd][r][xl][2 * yp]);
+              Y[rd][r][xl][2 * yp + 1] = fma2(f2{v[2], v[3]}, ONE, Y[rd][r][xl][2 * yp + 1]);
+            }
     }
   }
   const QGeo g = qgeo(4 * pr + kg);                   // the lane's quarter: accumulator register r = tile r of it
@@ -587,9 +615,13 @@ __global__ void __launch_bounds__(256, 1) wino43_kernel(const W43Args p) {
   // Stores.  The address of an output element is hoisted out of the element loops: one 64-bit base per tile row of the lane's quarter
   // (r, output row), then 32-bit column / channel-tile offsets — computed per element (the compiler does not hoist it through the
   // unrolled loops) the address arithmetic was ~1300 of the epilogue's instructions, 370 of them quarter-rate integer multiplies.
-  float st1[NT], st2[NT], bv[NT];
+  float st1[NT], st2[NT];
+  f2 bv[NT / 2];
 #pragma unroll
-  for (int n = 0; n < NT; ++n) { st1[n] = 0.f; st2[n] = 0.f; bv[n] = p.bias ? p.bias[n0 + 16 * n + lt] : 0.f; }
+  for (int n = 0; n < NT; ++n) { st1[n] = 0.f; st2[n] = 0.f; }
+#pragma unroll
+  for (int rd = 0; rd < NT / 2; ++rd)
+    bv[rd] = p.bias ? f2{p.bias[n0 + 32 * rd + lt], p.bias[n0 + 32 * rd + 16 + lt]} : f2{0.f, 0.f};
   const int ldf = g.ld_full, ldp = g.ld_pool;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -602,30 +634,39 @@ __global__ void __launch_bounds__(256, 1) wino43_kernel(const W43Args p) {
     float* q0 = p.out_pool + (size_t)g.pool_off + ((size_t)(g.n * Hp + py) * Wp + px0) * (size_t)ldp + (n0 + lt);
     const bool prow = g.valid && py < Hp;
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      float y[2][4];
+    for (int rd = 0; rd < NT / 2; ++rd) {
+      f2 yv[2][4];
 #pragma unroll
       for (int xl = 0; xl < 2; ++xl)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          y[xl][c] = Y[n][r][xl][c] + bv[n];
-          if (do_relu) y[xl][c] = fmaxf(y[xl][c], 0.f);
+          yv[xl][c] = fma2(Y[rd][r][xl][c], ONE, bv[rd]);
+          if (do_relu) yv[xl][c] = f2{fmaxf(yv[xl][c].x, 0.f), fmaxf(yv[xl][c].y, 0.f)};
         }
-      if (p.out_full) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int n = 2 * rd + u;
+        float y[2][4];
 #pragma unroll
         for (int xl = 0; xl < 2; ++xl)
 #pragma unroll
-          for (int c = 0; c < 4; ++c)
-            if ((xl ? row1 : row0) && c < ncol) {
-              (xl ? f1 : f0)[c * ldf + 16 * n] = y[xl][c];
-              if (do_stats) { st1[n] += y[xl][c]; st2[n] += y[xl][c] * y[xl][c]; }
-            }
-      }
-      if (p.out_pool && prow) {
+          for (int c = 0; c < 4; ++c) y[xl][c] = u ? yv[xl][c].y : yv[xl][c].x;
+        if (p.out_full) {
 #pragma unroll
-        for (int c2 = 0; c2 < 2; ++c2)
-          if (px0 + c2 < Wp)
-            q0[c2 * ldp + 16 * n] = fmaxf(fmaxf(y[0][2 * c2], y[0][2 * c2 + 1]), fmaxf(y[1][2 * c2], y[1][2 * c2 + 1]));
+          for (int xl = 0; xl < 2; ++xl)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+              if ((xl ? row1 : row0) && c < ncol) {
+                (xl ? f1 : f0)[c * ldf + 16 * n] = y[xl][c];
+                if (do_stats) { st1[n] += y[xl][c]; st2[n] += y[xl][c] * y[xl][c]; }
+              }
+        }
+        if (p.out_pool && prow) {
+#pragma unroll
+          for (int c2 = 0; c2 < 2; ++c2)
+            if (px0 + c2 < Wp)
+              q0[c2 * ldp + 16 * n] = fmaxf(fmaxf(y[0][2 * c2], y[0][2 * c2 + 1]), fmaxf(y[1][2 * c2], y[1][2 * c2 + 1]));
+        }
       }
     }
   }

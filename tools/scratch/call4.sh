@@ -1,0 +1,5 @@
+cd $GRAFT_REPO_ROOT/tools
+for a in 0 2 11 12; do
+  if [ $a = 0 ]; then unset G6D_LIB_PATH; else export G6D_LIB_PATH=$PWD/../gen6d_amd/csrc/_abl/libgen6d_x$a.so; fi
+  echo "== ablate $a"; REPS=4 python w43_probe.py 2>&1 | grep -v amdgpu
+done | tee ../gpurun_out/c4_ablate.log
