@@ -54,6 +54,8 @@ const KnobDef kKnobs[G6D_KNOB_COUNT] = {
     {"wino_min_work", -1},    // Winograd profitability rule: -1 = built-in thresholds, 0 = off, > 0 = minimum M*K*Cout
     {"w43_map", 1},           // F(4x4,3x3): block id -> (pixel tile, channel slice): 1 a tile's slices on one XCD (measured +0.7 % on the
                               // bench line, profiles/r05_w43_experiments.md), 0 grid order, 2 slices fastest
+    {"conv_pm", 1},           // conv_igemm: position-major tiles for small 2-D maps with many images (padding taps skipped): 1 layers with an
+                              // InstanceNorm prologue (where it measured faster), 2 every eligible layer, 0 row order
 };
 // Process-global table, filled when the library is loaded (static initialisation, before any entry point can run); reads and writes
 // are relaxed atomics, so a g6d_set_knob racing with launches on other threads is a benign race on one value (a launch sees the

@@ -53,7 +53,8 @@ template <int BM, int BN, int WGM, int WGN, int MODE, int MM>
 __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const G6dConv p, const int M, const int T,
                                                          const int nChunks, const int itersPerSplit,
                                                          const int totalIters, const int splits, const unsigned in_bytes,
-                                                         const unsigned w_bytes, const unsigned mul_bytes) {
+                                                         const unsigned w_bytes, const unsigned mul_bytes, const int pm_hw,
+                                                         const int pm_tiles) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int WM = BM / WGM, WN = BN / WGN;
   constexpr int MT = WM / 32, NT = WN / 32;
@@ -67,9 +68,29 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const G6dConv p, con
   const int li = lane & 31, lh = lane >> 5;
   const int lrow = tid >> 3, lseg = tid & 7;
 
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  // Row order of the GEMM.  Default: row = output position in memory order, tile = BM consecutive positions.  POSITION-MAJOR
+  // (pm_hw = Ho*Wo > 0: small 2-D maps, stride 1, many images — the selector's 4x4 / 8x8 stacks over 2560 hypothesis images): a tile is
+  // ONE output position (oy, ox) of BM consecutive images, so the taps that fall into the zero padding are the same for every row
+  // of the tile and the K loop simply skips them — a 3x3 "same" conv on a 4x4 map has 100 live (position, tap) pairs of 144 (1.44x
+  // fewer K steps), on an 8x8 map 484 of 576.  Block id -> (image tile, position): hardware hands consecutive ids to the 8 XCDs in
+  // turn, so within a group of 8 image tiles the id runs (tile-in-group fastest, then position): XCD k gets ALL positions of image
+  // tile 8g + k back to back, and the up-to-9 position tiles that read the same input rows meet in that XCD's L2.
+  int pm_pos = 0, pm_tile = blockIdx.x;
+  if (pm_hw > 0) {
+    const int per = 8 * pm_hw, g = blockIdx.x / per, r = blockIdx.x - g * per;
+    const int m8 = min(8, pm_tiles - 8 * g);
+    pm_pos = r / m8; pm_tile = 8 * g + (r - pm_pos * m8);
+  }
+  const int m0 = pm_tile * BM, n0 = blockIdx.y * BN;            // (position-major: first IMAGE of the tile)
+  auto row_m = [&](int r) { return pm_hw > 0 ? (m0 + r) * pm_hw + pm_pos : m0 + r; };      // tile row -> output position index m
+  int ky0 = 0, ky1 = p.kh - 1, kx0 = 0, kx1 = p.kw - 1;        // live taps of the tile (position-major: the padding taps are cut)
+  if (pm_hw > 0) {
+    const int oy = pm_pos / p.Wo, ox = pm_pos - oy * p.Wo;
+    ky0 = max(0, p.ph - oy); ky1 = min(p.kh - 1, p.Hi - 1 + p.ph - oy);
+    kx0 = max(0, p.pw - ox); kx1 = min(p.kw - 1, p.Wi - 1 + p.pw - ox);
+  }
   const int it_begin = blockIdx.z * itersPerSplit;
-  const int it_end = min(totalIters, it_begin + itersPerSplit);
+  const int it_end = pm_hw > 0 ? p.kd * (ky1 - ky0 + 1) * (kx1 - kx0 + 1) * nChunks : min(totalIters, it_begin + itersPerSplit);
 
   const int Cin = p.Cin, khw = p.kh * p.kw;
   const float* __restrict__ gsc = p.in_scale;
@@ -89,7 +110,7 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const G6dConv p, con
   int nbase[PER_N ? RA : 1];
 #pragma unroll
   for (int j = 0; j < RA; ++j) {
-    const int m = m0 + lrow + 32 * j;
+    const int m = row_m(lrow + 32 * j);
     amz[j] = amy[j] = amx[j] = 0u; avoff[j] = 0u;
     if constexpr (MUL) mvoff[j] = 0u;
     if constexpr (PER_N) nbase[j] = 0;
@@ -140,15 +161,15 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const G6dConv p, con
   // K steps read the same channel chunk at positions shifted by one tap: the shifted window is still in L1/L2, whereas a
   // chunk-fastest order brings it back only after nChunks tiles per resident block (~4 MB per XCD: L2 thrash -> MALL).
   int lt = it_begin;                       // index of the tile being loaded
-  int cc = it_begin / T;
-  int tap = it_begin - cc * T;
-  int kz = tap / khw, ky = (tap - kz * khw) / p.kw, kx = tap - kz * khw - ky * p.kw;
+  int cc = pm_hw > 0 ? 0 : it_begin / T;
+  const int tap0 = it_begin - cc * T;
+  int kz = pm_hw > 0 ? 0 : tap0 / khw, ky = pm_hw > 0 ? ky0 : (tap0 - kz * khw) / p.kw, kx = pm_hw > 0 ? kx0 : tap0 - kz * khw - ky * p.kw;
   auto advance = [&]() {
     lt += 1;
-    tap += 1; kx += 1; const bool w1 = kx == p.kw; kx = w1 ? 0 : kx;
-    ky += w1; const bool w2 = ky == p.kh; ky = w2 ? 0 : ky;
+    kx += 1; const bool w1 = kx > kx1; kx = w1 ? kx0 : kx;
+    ky += w1; const bool w2 = ky > ky1; ky = w2 ? ky0 : ky;
     kz += w2; const bool w3 = kz == p.kd; kz = w3 ? 0 : kz;
-    tap = w3 ? 0 : tap; cc += w3;
+    cc += w3;
   };
 
   // All loads are unconditional so that they pipeline (a branch around a load makes hipcc wait for each one separately).
@@ -167,7 +188,7 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const G6dConv p, con
     cm = live ? (cc == nChunks - 1 ? thr_last : 0xffffffffu) : 0u;
     toff = live ? (((kz * p.Hi + ky) * p.Wi + kx) * p.ld_in + cc * BK) << 2 : 0;
     moff = live ? ((ky * p.Wi + kx) * Cin + cc * BK) << 2 : 0;
-    woff = live ? (tap * Cin + cc * BK) << 2 : 0;
+    woff = live ? (((kz * p.kh + ky) * p.kw + kx) * Cin + cc * BK) << 2 : 0;
     if constexpr (AFF && !PER_N) { rsc[s][0] = ldg(gsc, cv ? cch : 0); rsh[s][0] = ldg(gsh, cv ? cch : 0); }
   };
   auto load_a = [&](auto S, int j) {
@@ -387,8 +408,8 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const G6dConv p, con
 
   const bool do_stats = p.stats != nullptr;
   const int rpg = p.stat_rows_per_group;
-  const int mlast = min(m0 + BM, M) - 1;
-  const int g0 = rpg > 0 ? m0 / rpg : 0;
+  const int mlast = pm_hw > 0 ? min(row_m(BM - 1), M - pm_hw + pm_pos) : min(m0 + BM, M) - 1;      // last valid row of the tile
+  const int g0 = rpg > 0 ? row_m(0) / rpg : 0;
   const bool one_group = rpg <= 0 || (mlast / rpg) == g0;
   float* sred = lds;   // [BN][2], reused after the K loop (all waves passed the final barrier)
   if (do_stats && one_group) {
@@ -405,7 +426,7 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const G6dConv p, con
     for (int i = 0; i < MT; ++i) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int row = row_m(wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh);
         float v = apply_act(acc[i][j][r] + bv, p.out_act);
         if (row < M && cval) {
           p.out[(size_t)row * p.ld_out + col] = v;
@@ -442,12 +463,26 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const G6dConv p, con
   }
 }
 
+// Position-major row order (see the kernel): 2-D stride-1 "same" layers on maps of at most 8x8 with at least 4 tiles of images, un-split.
+// Knob conv_pm: 1 = where it measured faster — the layers with an InstanceNorm prologue (64-channel N tiles; the selector's 4x4 stacks:
+// 480 -> 465 us and 970 -> 945 us per batch of 8).  A position tile reads every input row ONCE (the row-order tile re-reads its 16 KB
+// of rows for each of the 9 taps out of L1), so the K loop gets 1.44x shorter while its operand stream moves from L1 to L2: the plain
+// 128x128-tile layer (4x4x128 -> 256) lost 8 % and keeps the row order; 2 = every eligible layer (tests).
+bool igemm_position_major(const G6dConv& d, int bm, int splits) {
+  const int pm = (int)g6d_knob(G6D_KNOB_CONV_PM);
+  return pm != 0 && (pm == 2 || d.in_scale != nullptr) && splits == 1 && d.Di == 1 && d.Do == 1 && d.kd == 1 && d.sh == 1 && d.sw == 1 && d.Ho == d.Hi &&
+         d.Wo == d.Wi && d.Ho * d.Wo <= 64 && d.Ho * d.Wo > 1 && (d.kh > 1 || d.kw > 1) && d.kh == 2 * d.ph + 1 && d.kw == 2 * d.pw + 1 &&
+         d.N >= 4 * bm;
+}
+
 template <int BM, int BN, int WGM, int WGN, int MODE, int MM>
 int launch_mm(const G6dConv& d, int M, int T, int nChunks, int splits, hipStream_t stream) {
   const int total = T * nChunks;
   const int ips = (total + splits - 1) / splits;
   splits = (total + ips - 1) / ips;
-  dim3 grid((M + BM - 1) / BM, (d.Cout + BN - 1) / BN, splits);
+  const bool pm = igemm_position_major(d, BM, splits);
+  const int pm_hw = pm ? d.Ho * d.Wo : 0, pm_tiles = pm ? (d.N + BM - 1) / BM : 0;
+  dim3 grid(pm ? pm_hw * pm_tiles : (M + BM - 1) / BM, (d.Cout + BN - 1) / BN, splits);
   const size_t lds_bytes = 2 * (size_t)(BM + BN) * LDS_K * sizeof(float);
   g6d_allow_lds(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WGM, WGN, MODE, MM>), (int)lds_bytes);
   // extents of the buffer-load descriptors (the activation and multiplier descriptors start `pad` elements in front of the tensor)
@@ -458,7 +493,7 @@ int launch_mm(const G6dConv& d, int M, int T, int nChunks, int splits, hipStream
   const unsigned w_bytes = (unsigned)((long long)d.Cout * T * d.Cin * 4);
   const unsigned mul_bytes = (unsigned)((n_mul * d.Hi * d.Wi * d.Cin + pad_m) * 4);
   hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, MODE, MM>), grid, dim3(256), lds_bytes, stream, d, M, T, nChunks,
-                     ips, total, splits, in_bytes, w_bytes, mul_bytes);
+                     ips, total, splits, in_bytes, w_bytes, mul_bytes, pm_hw, pm_tiles);
   return g6d_check_launch("conv_igemm");
 }
 

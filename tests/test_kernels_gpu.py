@@ -94,6 +94,29 @@ def test_conv_igemm(ops, case):
     _run_conv_case(ops, case, False)
 
 
+# Position-major tiles of conv_igemm (round 5): small 2-D maps with >= 4 tiles of images — a tile is one output position of 128 (64)
+# consecutive images and the K loop skips the taps that fall into the zero padding.  Ragged image counts (partial last tile, partial
+# last group of 8 tiles), every operand prologue, statistics groups that straddle tiles, and the forced fall-backs.
+PM_CASES = [
+    dict(N=600, D=1, H=4, W=4, Cin=128, Cout=256, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), aff=True, relu=True, per_n=200, stats=True, rpg=200 * 16),
+    dict(N=1040, D=1, H=4, W=4, Cin=512, Cout=256, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), mul=True, aff=True, per_n=260, in_mod=260, mul_group=260,
+         stats=True, rpg=260 * 16),                                                                    # 9 tiles: a full group of 8 + a tail of 1
+    dict(N=1285, D=1, H=4, W=4, Cin=256, Cout=256, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), aff=True, relu=True, per_n=257),   # odd N, no statistics
+    dict(N=520, D=1, H=8, W=8, Cin=64, Cout=128, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), stats=True, rpg=130 * 64),
+    dict(N=515, D=1, H=5, W=3, Cin=20, Cout=40, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), act=2),                               # odd map, Cin tail chunk
+    dict(N=512, D=1, H=2, W=6, Cin=64, Cout=96, k=(1, 1, 5), s=(1, 1, 1), p=(0, 0, 2), aff=True, relu=True, stats=True),     # 1x5 taps, one table
+    dict(N=512, D=1, H=4, W=4, Cin=128, Cout=32, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), ld_out=48),                          # 128x32 tiles, channel slice
+]
+
+
+@pytest.mark.parametrize("pm", [2, 0], ids=["position-major", "row-order"])
+@pytest.mark.parametrize("case", PM_CASES, ids=lambda c: f"{c['N']}x{c['H']}x{c['W']}_{c['Cin']}x{c['Cout']}")
+def test_conv_igemm_position_major(ops, case, pm, knob):
+    knob("conv_patch", 0)            # (8x8 maps with Cout <= 64-channel tiles would take the LDS-patch kernel)
+    knob("conv_pm", pm)
+    _run_conv_case(ops, case, False)
+
+
 # Layers that g6d_conv_igemm routes to the Winograd kernel when G6dConv.weight_wino is given (every prologue / epilogue variant the
 # selector, the refiner feature net and the volume net use), plus shapes that must fall back to the direct kernels.
 WINO_CONV_CASES = [
