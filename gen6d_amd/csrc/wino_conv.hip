@@ -82,6 +82,7 @@ struct WinoArgs {
   int QH, QW;
   int nseg, qtotal; WinoSeg seg[WINO_MAX_SEG];
   unsigned in_bytes;                              // extent of the input tensor(s) from `in` (< 2^31): bound of the buffer loads
+  unsigned mul_bytes;                             // ... of the multiplier maps from `mul` (MODE 3)
   int splits, chunks_per_split; float* ws;       // splits > 1: tile counters + partial outputs (no bias / ReLU / pool)
   // conv-family extras (zero / null for the trunk)
   int D;                                         // depth slices per image (1 for 2-D layers); KD = 3 pads in depth
@@ -151,7 +152,8 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 1) wino_conv3x3_kernel(const W
   constexpr int GL = 16 / NWM;                                // direct-to-LDS filter pieces per wave and chunk
   constexpr int WU_FLOATS = 16 * 32 * NWN * 8;                // [ab][co][8], lane-linear image of the global layout
   constexpr int WSTAGE = RAWF + WU_FLOATS + 4 * THREADS;   // raw patch, filter image, scratch row for the idle pieces of the last round
-  constexpr int AFF0 = 2 * WSTAGE;                            // affine tables behind the stages
+  constexpr int AFF0 = 2 * WSTAGE;                            // affine tables behind the stages: [G][Cin] scales, [G][Cin] shifts, [Cin] zeros
+  constexpr int AFFG = MODE >= 2 ? NQ : 1;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / NWN, wn = wave % NWN;
@@ -193,13 +195,32 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 1) wino_conv3x3_kernel(const W
       poff[j] = g.in_off + ((n * g.H + iy) * g.W + ix) * g.ld_in + 4 * half;      // the UNSHIFTED position (may lie outside: used under smask only)
     }
   }
-  unsigned pboff[MODE == 0 && KD == 1 ? NPR : 1];            // byte offsets of the pieces for the buffer loads (beyond the tensor: zero)
-  if constexpr (MODE == 0 && KD == 1) {
+  // Operand prologues without a select and (2-D layers) without per-chunk address arithmetic: every piece comes through a
+  // bounds-checked buffer load — a piece outside the image (zero padding, masked quarter) asks for an offset beyond the tensor and the
+  // hardware returns zeros — and the InstanceNorm SHIFT of such a piece is read from a row of zeros behind the tables, so that
+  // raw * scale + shift (and ReLU of it) is exactly zero there, as the reference's padding behind the norm is.  2-D layers: the lane
+  // offset of a piece and the LDS offset of its shift are constants of the piece, the chunk's channel offset is the instruction's
+  // scalar / immediate offset.  (Round 4: per piece and chunk a `v ? off : 0` select and 64-bit address per load, 4 multiplies, 4 FMAs
+  // and 4 selects beside the MFMAs — the MODE 3 / MODE 2 instantiations ran at 44-56 % MfmaUtil against 66 % for MODE 0.)
+  unsigned pboff[KD == 1 ? NPR : 1];                          // byte offsets of the pieces for the buffer loads (beyond the tensor: zero)
+  unsigned mboff[MODE == 3 ? NPR : 1];                        // ... into the multiplier maps
+  int shoff[MODE != 0 ? NPR : 1];                             // LDS offset of the piece's shift values: its table, or the zero row
+  if constexpr (KD == 1) {
 #pragma unroll
     for (int j = 0; j < NPR; ++j) pboff[j] = pval[j] ? (unsigned)poff[j] << 2 : 0x80000000u;
   }
+  if constexpr (MODE == 3) {
+#pragma unroll
+    for (int j = 0; j < NPR; ++j) mboff[j] = pval[j] ? (unsigned)moff[j] << 2 : 0x80000000u;
+  }
+  if constexpr (MODE != 0) {
+#pragma unroll
+    for (int j = 0; j < NPR; ++j) shoff[j] = pval[j] ? AFF0 + AFFG * p.Cin + aoff[j] : AFF0 + 2 * AFFG * p.Cin + (aoff[j] & 4);
+  }
   const int slice = p.H * p.W * p.ld_in;                     // KD = 3: one depth step
   const auto in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
+  const auto mul_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(MODE == 3 ? p.mul : p.in), 0, MODE == 3 ? p.mul_bytes : p.in_bytes, 0x00020000);
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   f32x4 rp[NPR], rm[MODE == 3 ? NPR : 1];
   bool rv[NPR];                                               // validity of the piece for the chunk it was loaded for
   auto load_piece = [&](int j, int chunk) {
@@ -216,19 +237,17 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 1) wino_conv3x3_kernel(const W
       off += (bi - 2) * rstep[j] + (bj - 2) * 3 * p.ld_in;
     }
     rv[j] = v;
-    if constexpr (MODE == 0) {
+    {
       // bounds-checked buffer load: pieces outside the image (zero padding, masked quarters) ask for an offset beyond the
       // tensor and get zeros from the hardware — no select when the piece goes to LDS; for 2-D layers the lane offset is a
       // constant of the piece and the chunk's channel offset is the instruction's scalar offset: no vector-ALU work at all
-      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
       u32x4 raw;
       if constexpr (KD == 1) raw = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, pboff[j], cc * 32, 0));
       else raw = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, v ? (unsigned)off << 2 : 0x80000000u, 0, 0));
       rp[j] = __builtin_bit_cast(f32x4, raw);
-    } else {
-      rp[j] = ldg4(p.in, v ? off : 0);
     }
-    if constexpr (MODE == 3) rm[j] = ldg4(p.mul, v ? moff[j] + cc * 8 : 0);
+    if constexpr (MODE == 3)      // (2-D layers only: g6d_wino_eligible)
+      rm[j] = __builtin_bit_cast(f32x4, __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(mul_rsrc, mboff[j], cc * 32, 0)));
   };
   auto load_raw = [&](int chunk) {
 #pragma unroll
@@ -238,16 +257,21 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 1) wino_conv3x3_kernel(const W
     const int cc = KD == 25 ? chunk / 25 : (KD != 1 ? chunk % nc8 : chunk);       // the idle pieces of the last round go to a scratch row behind the stages
     {
       f32x4 v = rp[j];
-      if constexpr (MODE == 3) v *= rm[j];
       if constexpr (MODE != 0) {
-        const f32x4 sc = *reinterpret_cast<const f32x4*>(lds + AFF0 + aoff[j] + cc * 8);
-        const f32x4 sh = *reinterpret_cast<const f32x4*>(lds + AFF0 + (MODE >= 2 ? NQ : 1) * p.Cin + aoff[j] + cc * 8);
-        v = v * sc + sh;
+        // packed: two v_pk_fma_f32 (+ two v_pk_mul_f32 for the multiplier) per piece; the shift comes from the zero row for a piece
+        // outside the image (3-D layers: decided per chunk by the depth tap — one select on the LDS offset instead of four on the data)
+        const int so = KD == 1 ? shoff[j] : (rv[j] ? shoff[j] : AFF0 + 2 * AFFG * p.Cin + (aoff[j] & 4));
+        f32x4 sc = *reinterpret_cast<const f32x4*>(lds + AFF0 + aoff[j] + cc * 8);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(lds + so + cc * 8);
+        f32x2w s0 = {sc[0], sc[1]}, s1 = {sc[2], sc[3]};
+        if constexpr (MODE == 3) { s0 = s0 * f32x2w{rm[j][0], rm[j][1]}; s1 = s1 * f32x2w{rm[j][2], rm[j][3]}; }
+        const f32x2w r0 = __builtin_elementwise_fma(f32x2w{v[0], v[1]}, s0, f32x2w{sh[0], sh[1]});
+        const f32x2w r1 = __builtin_elementwise_fma(f32x2w{v[2], v[3]}, s1, f32x2w{sh[2], sh[3]});
+        v = f32x4{r0.x, r0.y, r1.x, r1.y};
         if (p.in_relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
       }
       f32x4* dst = reinterpret_cast<f32x4*>(__builtin_assume_aligned(lds + st * WSTAGE + lsto[j], 16));
-      if constexpr (MODE == 0) *dst = v;
-      else *dst = rv[j] ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      *dst = v;
     }
   };
   auto store_raw = [&](int st, int chunk) {
@@ -263,6 +287,7 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 1) wino_conv3x3_kernel(const W
       lds[AFF0 + i] = p.in_scale[g * p.Cin + c];
       lds[AFF0 + G * p.Cin + i] = p.in_shift[g * p.Cin + c];
     }
+    for (int i = tid; i < p.Cin; i += THREADS) lds[AFF0 + 2 * G * p.Cin + i] = 0.f;      // the shifts of the pieces outside the image
     __syncthreads();
   }
   // ---- filter tiles: wave w moves (ab, half) pairs idx = 8w .. 8w+7, 1 KB (32 co x 32 B) per instruction
@@ -1187,7 +1212,7 @@ __global__ void __launch_bounds__(256, 1) wino16_conv_kernel(const WinoArgs p) {
 template <int MODE, int KD, int NWN, int NWM = 2>
 int wino_launch_t(WinoArgs& a, long long blocks, hipStream_t stream) {
   constexpr int THREADS = 64 * NWM * NWN;
-  const size_t lds_bytes = (2 * (size_t)(2 * NWM * WQ_PIX * WRAW_LD + 16 * 32 * NWN * 8 + 4 * THREADS) + (MODE == 0 ? 0 : (MODE >= 2 ? 4 * NWM : 2) * a.Cin)) * sizeof(float);
+  const size_t lds_bytes = (2 * (size_t)(2 * NWM * WQ_PIX * WRAW_LD + 16 * 32 * NWN * 8 + 4 * THREADS) + (MODE == 0 ? 0 : (MODE >= 2 ? 4 * NWM : 2) * a.Cin + a.Cin)) * sizeof(float);
   g6d_allow_lds(reinterpret_cast<const void*>(&wino_conv3x3_kernel<MODE, KD, NWN, NWM>), 160 * 1024);
   hipLaunchKernelGGL((wino_conv3x3_kernel<MODE, KD, NWN, NWM>), dim3((unsigned)blocks, a.Cout / (32 * NWN), a.splits), dim3(THREADS), lds_bytes,
                      stream, a);
@@ -1488,6 +1513,7 @@ int g6d_wino_launch(const G6dConv& d, hipStream_t stream) {
   a.D = d.Di; a.N = d.N * d.Di; a.H = d.Hi; a.W = d.Wi; a.Cin = d.Cin; a.ld_in = d.ld_in; a.Cout = d.Cout; a.ld_full = d.ld_out;
   a.ld_pool = 0; a.relu = d.out_act == 1;
   a.mul = d.mul; a.in_scale = d.in_scale; a.in_shift = d.in_shift; a.in_relu = d.in_relu;
+  a.mul_bytes = d.mul ? (unsigned)((long long)(d.mul_group_images > 0 ? (d.N + d.mul_group_images - 1) / d.mul_group_images : 1) * d.Hi * d.Wi * d.Cin * 4) : 0u;      // (< 2^31: g6d_conv_igemm)
   a.stats = d.stats; a.stats_div = d.stat_rows_per_group > 0 ? d.stat_rows_per_group / (d.Do * d.Ho * d.Wo) : 0;
   a.aff_div = d.in_affine_per_n; a.img_mod = d.in_image_mod; a.mul_div = d.mul_group_images > 0 ? d.mul_group_images * d.Di : 0;
   if (d.fin_scale)
