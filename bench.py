@@ -184,13 +184,15 @@ def main():
     ap.add_argument("--sel-refs", type=int, default=64)
     ap.add_argument("--det-refs", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--lowp", default="fp16,fp16sel32,bf16mix",
+    ap.add_argument("--lowp", default="fp16,bf16mix,fp16all",
                     help="comma list of reduced-precision matrix-core modes measured AFTER the fp32 headline (same launch mode, "
                          "same steps) and reported in the `lowp` object: operands bf16 / fp16, fp32 accumulate; '' = skip.  Default fp16 "
                          "only: bf16's 8-bit mantissa moves the selector logits by more than the top-2 margin of some queries (the "
                          "viewpoint arg-max flips on 1 of the 4 synthetic queries once the trunk runs in bf16) — available as `--lowp bf16,fp16`; "
-                         "bf16mix = bf16 in the detector and the refiner, fp16 in the selector; fp16sel32 = fp16 in the detector and the refiner, fp32 "
-                         "in the selector")
+                         "fp16 = the product's reduced-precision scheme (all three networks on fp16 operands; the selector's query trunk and "
+                         "attention / predictor tail — a few small launches — stay on fp32 operands: ViewpointSelector.default_cfg['lowp_keep_fp32']); "
+                         "bf16mix = bf16 in the detector and the refiner, that selector; fp16all = nothing kept on fp32 (fails the margin bar: "
+                         "reported to show what the keep-list buys); fp16sel32 = the whole selector on fp32 operands")
     ap.add_argument("--lowp-lanes", type=int, default=3,
                     help="batches in flight during the reduced-precision passes (their kernels are ~2x shorter, so replay gaps weigh "
                          "more: 342 images/s with 2, 357 with 3; fp32 gains 1 %% from a third lane and keeps the 2 of --lanes)")
@@ -513,8 +515,10 @@ def main():
             # "fp16sel32": fp16 operands in the detector and the refiner, the selector on fp32 operands — the scheme that keeps the logit
             # error below a quarter of the smallest top-2 margin (tools/lowp_selector_schemes.py: an fp32 query trunk / product conv alone
             # only reach 0.30 / 0.29 of the margin; the 13 stacked InstanceNorms carry the rounding of every fp16 layer to the logits)
-            mode = {"bf16mix": "bf16", "fp16sel32": "fp16"}.get(mode_name, mode_name)
+            mode = {"bf16mix": "bf16", "fp16sel32": "fp16", "fp16all": "fp16"}.get(mode_name, mode_name)
             pipe.selector.cfg["math_mode"] = {"bf16mix": "fp16", "fp16sel32": "fp32"}.get(mode_name)
+            keep_default = pipe.selector.default_cfg["lowp_keep_fp32"]
+            pipe.selector.cfg["lowp_keep_fp32"] = () if mode_name == "fp16all" else keep_default
             with ops.math_mode(mode):
                 pipe.capture(lanes=lanes, batch=B)
             lane_busy[:] = [None] * lanes
@@ -529,10 +533,13 @@ def main():
             lrows = torch.cat(lrows[:args.steps], 0).cpu()
             entry = {"dtype": mode_name, "value": nl * B / ldt, "unit": "images/s", "ms_per_step": ldt / nl * 1e3, "queries": nl * B, "batch": B,
                      "lanes": lanes}
-            if mode_name == "bf16mix":
-                entry["scheme"] = "detector bf16, selector fp16, refiner bf16 (fp32 accumulation, InstanceNorm statistics, selector tail and regressor everywhere)"
-            if mode_name == "fp16sel32":
-                entry["scheme"] = "detector fp16, selector fp32, refiner fp16: the mixed scheme whose selector logits stay within a quarter of the top-2 margin"
+            kept = ", ".join(pipe.selector.cfg["lowp_keep_fp32"]) or "nothing"
+            entry["scheme"] = {
+                "fp16": f"detector, selector, refiner on fp16 operands; selector parts on fp32 operands: {kept} (profiles/r05_lowp_selector_sensitivity.md)",
+                "bf16mix": f"detector and refiner bf16, selector fp16 with {kept} on fp32 operands (bf16 breaks the margin bar in every InstanceNorm-stack layer)",
+                "fp16all": "every matrix-core launch on fp16 operands, nothing kept on fp32: the selector's trunk and tail carry the logit error past the bar",
+                "fp16sel32": "detector fp16, selector fp32, refiner fp16"}.get(mode_name, mode_name)
+            entry["default_scheme"] = mode_name == "fp16"
             if pi > 0:
                 # roofline of the mode: serialised eager pass of the same steps with HIP events around every MFMA-family launch
                 ops.SERIAL = True
@@ -578,6 +585,7 @@ def main():
             if pi > 0:
                 lowp[mode_name] = entry
         pipe.selector.cfg["math_mode"] = None
+        pipe.selector.cfg["lowp_keep_fp32"] = pipe.selector.default_cfg["lowp_keep_fp32"]
         if lowp:
             result["lowp"] = lowp
         lanes = headline_lanes
@@ -585,6 +593,7 @@ def main():
         result.setdefault("side_leg_errors", {})["lowp"] = f"{type(e).__name__}: {e}"[:600]
     finally:
         pipe.selector.cfg["math_mode"] = None
+        pipe.selector.cfg["lowp_keep_fp32"] = pipe.selector.default_cfg["lowp_keep_fp32"]
         lanes = headline_lanes
         if lowp:
             result["lowp"] = lowp

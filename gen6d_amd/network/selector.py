@@ -43,8 +43,15 @@ FEAT_LD = 516          # 512 corr channels + 3 vps channels + 1 zero pad (16-byt
 
 class ViewpointSelector(ParamBank):
     # lowp_keep_fp32: parts that stay on fp32 matrix-core operands when the reduced-precision mode is on (cfg `math_mode` or an enclosing
-    # ops.math_mode): "trunk" = the query's VGG trunk, "product" = the first conv of every level (query x reference product); () = none
-    default_cfg = {"selector_angle_num": 5, "lowp_keep_fp32": ()}
+    # ops.math_mode): "trunk" = the query's VGG trunk, "product" = the first conv of every level (query x reference product), "stack" =
+    # the later convs of the three InstanceNorm stacks, "corr<l>.<i>" = conv i of level l alone, "fuse" = corr_feats_conv, "tail" =
+    # score_process / attention / predictors; () = none.  lowp_only (tools/lowp_selector_sensitivity.py): when set, ONLY the named parts
+    # run on 16-bit operands.
+    # Default ("trunk", "tail"): measured part by part (profiles/r05_lowp_selector_sensitivity.md), the fp16 logit error is made by the
+    # query trunk (1.0e-2 alone) and the attention / predictor tail (0.7e-2) — both a few small launches — not by the InstanceNorm stacks
+    # that hold the multiply-adds (1-3e-3 each): with these two on fp32 operands the reduced-precision selector keeps its logits within
+    # 0.17 of the smallest top-2 margin (bar 1/4) at the all-fp16 speed (4.88 vs 4.79 ms per batch of 8).
+    default_cfg = {"selector_angle_num": 5, "lowp_keep_fp32": ("trunk", "tail"), "lowp_only": None}
 
     def __init__(self, cfg):
         self.cfg = {**self.default_cfg, **cfg}
@@ -122,10 +129,18 @@ class ViewpointSelector(ParamBank):
             self._packed = pk
         return self._packed
 
+    def _mm(self, *names):
+        """math-mode context of one part of the network: fp32 if any of its names is in cfg['lowp_keep_fp32'] (or, with cfg['lowp_only'],
+        if none of them is listed there), else whatever the enclosing mode is."""
+        only = self.cfg.get("lowp_only")
+        keep = self.cfg.get("lowp_keep_fp32") or ()
+        fp32 = (not any(n in only for n in names)) if only is not None else any(n in keep for n in names)
+        return ops.math_mode("fp32" if fp32 else None, inherit_if_none=True)
+
     # ------------------------------------------------------------------ features
     def get_feats(self, imgs):
         """imgs [n,3,h,w] in [0,1] -> 3 channels-last, L2-normalised maps [n,1,h_l,w_l,512] (selector.py:113-119)."""
-        with ops.math_mode("fp32" if "trunk" in self.cfg.get("lowp_keep_fp32", ()) else None, inherit_if_none=True):
+        with self._mm("trunk"):
             return trunk_features(self._pack()["vgg"], imgs, ("c5", "c7_pre", "p7"), True)
 
     def extract_ref_feats(self, ref_imgs, ref_poses, object_center, object_vert, is_train=False):
@@ -192,7 +207,7 @@ class ViewpointSelector(ParamBank):
             stats = ops.new_stats(qn, co, dev) if has_in else None
             # InstanceNorm finalisation inside the producing launch, unless the statistics still have to be summed over ranks
             fin = Dg * h * w if (has_in and not last and not self.sharded) else None
-            with ops.math_mode("fp32" if (first and "product" in self.cfg.get("lowp_keep_fp32", ())) else None, inherit_if_none=True):
+            with self._mm("product" if first else "stack", f"corr{l}.{li}"):
                 res = ops.conv(x, wgt, bias, out, ksize=_K133, pad=_P011, mul=mul, in_scale=scale, in_shift=shift, in_relu=relu, stats=stats,
                                w_wino=wu, finalize=fin, per_n=grp if scale is not None else 0, rows_per_group=grp * h * w,
                                in_mod=grp if first else 0, mul_group=grp if mul is not None else 0)
@@ -245,19 +260,20 @@ class ViewpointSelector(ParamBank):
                     self._allreduce(pending)
                 levels = alive
 
-        # corr_feats_conv: 1x1x1 768->512, IN3d, ReLU, (AvgPool commuted) 512->512   selector.py:71-77,197-200
-        y = torch.empty((qn * D, 1, 4, 4, 512), dtype=torch.float32, device=dev)
-        st = ops.new_stats(qn, 512, dev)
-        if not self.sharded:
-            sc, sh = ops.conv(cat, pk["fuse0"][0], pk["fuse0"][1], y, stats=st, finalize=Dg * 16, rows_per_group=grp * 16)
-        else:
-            ops.conv(cat, pk["fuse0"][0], pk["fuse0"][1], y, stats=st, rows_per_group=grp * 16)
-            self._allreduce([st])
-            sc, sh = ops.stats_finalize(st, Dg * 16)
-        pooled = torch.empty((qn * D, 1, 1, 1, 512), dtype=torch.float32, device=dev)
-        ops.affine_act_pool(y, pooled, sc, sh, per_n=grp, relu=True, pool=2)
-        feats = torch.zeros((qn * D, FEAT_LD), dtype=torch.float32, device=dev)
-        ops.conv(pooled.view(1, 1, 1, qn * D, 512), pk["fuse3"][0], pk["fuse3"][1], feats.view(1, 1, 1, qn * D, FEAT_LD)[..., :512])
+        with self._mm("fuse"):
+            # corr_feats_conv: 1x1x1 768->512, IN3d, ReLU, (AvgPool commuted) 512->512   selector.py:71-77,197-200
+            y = torch.empty((qn * D, 1, 4, 4, 512), dtype=torch.float32, device=dev)
+            st = ops.new_stats(qn, 512, dev)
+            if not self.sharded:
+                sc, sh = ops.conv(cat, pk["fuse0"][0], pk["fuse0"][1], y, stats=st, finalize=Dg * 16, rows_per_group=grp * 16)
+            else:
+                ops.conv(cat, pk["fuse0"][0], pk["fuse0"][1], y, stats=st, rows_per_group=grp * 16)
+                self._allreduce([st])
+                sc, sh = ops.stats_finalize(st, Dg * 16)
+            pooled = torch.empty((qn * D, 1, 1, 1, 512), dtype=torch.float32, device=dev)
+            ops.affine_act_pool(y, pooled, sc, sh, per_n=grp, relu=True, pool=2)
+            feats = torch.zeros((qn * D, FEAT_LD), dtype=torch.float32, device=dev)
+            ops.conv(pooled.view(1, 1, 1, qn * D, 512), pk["fuse3"][0], pk["fuse3"][1], feats.view(1, 1, 1, qn * D, FEAT_LD)[..., :512])
         if not self.sharded:
             ops.vps_norm(vps, feats, 512)                                               # selector.py:201-202
         else:                                                                           # norm over ALL hypotheses
@@ -268,54 +284,55 @@ class ViewpointSelector(ParamBank):
             ops.vps_norm(vall, fall, 512)
             feats.view(qn, D, FEAT_LD)[:, :, 512:515] = fall.view(qn, Dg, FEAT_LD)[:, self.r_begin * an:self.r_end * an, 512:515]
 
-        # score_process + max over rotations + viewpoint embedding                     selector.py:204-205
-        t0 = torch.empty((1, 1, 1, qn * D, 512), dtype=torch.float32, device=dev)
-        ops.conv(feats.view(1, 1, 1, qn * D, FEAT_LD), pk["sp0"][0], pk["sp0"][1], t0, out_act=1)
-        t1 = torch.empty_like(t0)
-        ops.conv(t0, pk["sp2"][0], pk["sp2"][1], t1)
-        xl = torch.empty((qn * rfn, 512), dtype=torch.float32, device=dev)
-        ops.max_an_add(t1.view(qn * D, 512), rfn, an, self.ref_pose_embed[self.r_begin:self.r_end].contiguous(), xl, batch=qn)
-        feats_l, rfn_l = feats, rfn
-        rfn = rfn_all                                                                   # the tail runs on ALL refs
-        xm = torch.empty((qn * rfn, 1024), dtype=torch.float32, device=dev)             # [x | msg]
-        xm[:, :512] = self._allgather_batch(xl, qn, rfn_l, rfn_all)
+        with self._mm("tail"):
+            # score_process + max over rotations + viewpoint embedding                     selector.py:204-205
+            t0 = torch.empty((1, 1, 1, qn * D, 512), dtype=torch.float32, device=dev)
+            ops.conv(feats.view(1, 1, 1, qn * D, FEAT_LD), pk["sp0"][0], pk["sp0"][1], t0, out_act=1)
+            t1 = torch.empty_like(t0)
+            ops.conv(t0, pk["sp2"][0], pk["sp2"][1], t1)
+            xl = torch.empty((qn * rfn, 512), dtype=torch.float32, device=dev)
+            ops.max_an_add(t1.view(qn * D, 512), rfn, an, self.ref_pose_embed[self.r_begin:self.r_end].contiguous(), xl, batch=qn)
+            feats_l, rfn_l = feats, rfn
+            rfn = rfn_all                                                                   # the tail runs on ALL refs
+            xm = torch.empty((qn * rfn, 1024), dtype=torch.float32, device=dev)             # [x | msg]
+            xm[:, :512] = self._allgather_batch(xl, qn, rfn_l, rfn_all)
 
-        def tok(t, n_tok=None):      # [qn*n, C] (row-strided) -> conv view [qn,1,1,n,C]: one image per query
-            n_tok = rfn if n_tok is None else n_tok
-            return t.as_strided((qn, 1, 1, n_tok, t.shape[1]), (n_tok * t.stride(0), 0, 0, t.stride(0), 1), t.storage_offset())
+            def tok(t, n_tok=None):      # [qn*n, C] (row-strided) -> conv view [qn,1,1,n,C]: one image per query
+                n_tok = rfn if n_tok is None else n_tok
+                return t.as_strided((qn, 1, 1, n_tok, t.shape[1]), (n_tok * t.stride(0), 0, 0, t.stride(0), 1), t.storage_offset())
 
-        pn = 1 if qn > 1 else 0                      # InstanceNorm1d tables per query (image of the tok view)
-        for i in range(2):                                                              # selector.py:207-209
-            a = pk["att"][i]
-            qkv = torch.empty((qn * rfn, 1536), dtype=torch.float32, device=dev)
-            ops.conv(tok(xm[:, :512]), a["qkv"][0], a["qkv"][1], tok(qkv))
-            att = torch.empty((qn * rfn, 512), dtype=torch.float32, device=dev)
-            ops.attention(qkv[:, 0:512], qkv[:, 512:1024], qkv[:, 1024:1536], 8, att, batch=qn)
-            mrg = torch.empty((qn * rfn, 512), dtype=torch.float32, device=dev)
-            ops.conv(tok(att), a["merge"][0], a["merge"][1], tok(mrg))
-            ops.layernorm(mrg, a["ln"][0], a["ln"][1], xm[:, 512:])
-            y0 = torch.empty((qn * rfn, 512), dtype=torch.float32, device=dev)
-            s0 = ops.new_stats(qn, 512, dev)
-            sc0, sh0 = ops.conv(tok(xm), a["mlp0"][0], a["mlp0"][1], tok(y0), stats=s0, finalize=rfn, rows_per_group=pn * rfn)
-            y1 = torch.empty((qn * rfn, 512), dtype=torch.float32, device=dev)
-            s1 = ops.new_stats(qn, 512, dev)
-            sc1, sh1 = ops.conv(tok(y0), a["mlp3"][0], a["mlp3"][1], tok(y1), in_scale=sc0, in_shift=sh0, in_relu=True, per_n=pn, stats=s1,
-                                finalize=rfn, rows_per_group=pn * rfn)
-            xn = torch.empty((qn * rfn, 1024), dtype=torch.float32, device=dev)
-            ops.affine_act_add(y1, xn[:, :512], sc1, sh1, relu=True, residual=xm[:, :512], rows_per_group=pn * rfn)
-            xm = xn
-        p0 = torch.empty((qn * rfn, 512), dtype=torch.float32, device=dev)
-        ops.conv(tok(xm[:, :512]), pk["pred0"][0], pk["pred0"][1], tok(p0), out_act=1)
-        logits = torch.empty((qn * rfn, 1), dtype=torch.float32, device=dev)
-        ops.conv(tok(p0), pk["pred2"][0], pk["pred2"][1], tok(logits))
+            pn = 1 if qn > 1 else 0                      # InstanceNorm1d tables per query (image of the tok view)
+            for i in range(2):                                                              # selector.py:207-209
+                a = pk["att"][i]
+                qkv = torch.empty((qn * rfn, 1536), dtype=torch.float32, device=dev)
+                ops.conv(tok(xm[:, :512]), a["qkv"][0], a["qkv"][1], tok(qkv))
+                att = torch.empty((qn * rfn, 512), dtype=torch.float32, device=dev)
+                ops.attention(qkv[:, 0:512], qkv[:, 512:1024], qkv[:, 1024:1536], 8, att, batch=qn)
+                mrg = torch.empty((qn * rfn, 512), dtype=torch.float32, device=dev)
+                ops.conv(tok(att), a["merge"][0], a["merge"][1], tok(mrg))
+                ops.layernorm(mrg, a["ln"][0], a["ln"][1], xm[:, 512:])
+                y0 = torch.empty((qn * rfn, 512), dtype=torch.float32, device=dev)
+                s0 = ops.new_stats(qn, 512, dev)
+                sc0, sh0 = ops.conv(tok(xm), a["mlp0"][0], a["mlp0"][1], tok(y0), stats=s0, finalize=rfn, rows_per_group=pn * rfn)
+                y1 = torch.empty((qn * rfn, 512), dtype=torch.float32, device=dev)
+                s1 = ops.new_stats(qn, 512, dev)
+                sc1, sh1 = ops.conv(tok(y0), a["mlp3"][0], a["mlp3"][1], tok(y1), in_scale=sc0, in_shift=sh0, in_relu=True, per_n=pn, stats=s1,
+                                    finalize=rfn, rows_per_group=pn * rfn)
+                xn = torch.empty((qn * rfn, 1024), dtype=torch.float32, device=dev)
+                ops.affine_act_add(y1, xn[:, :512], sc1, sh1, relu=True, residual=xm[:, :512], rows_per_group=pn * rfn)
+                xm = xn
+            p0 = torch.empty((qn * rfn, 512), dtype=torch.float32, device=dev)
+            ops.conv(tok(xm[:, :512]), pk["pred0"][0], pk["pred0"][1], tok(p0), out_act=1)
+            logits = torch.empty((qn * rfn, 1), dtype=torch.float32, device=dev)
+            ops.conv(tok(p0), pk["pred2"][0], pk["pred2"][1], tok(logits))
 
-        # angle head on the per-reference rows [an*516]                                 selector.py:212-214
-        a0 = torch.empty((qn * rfn_l, 512), dtype=torch.float32, device=dev)
-        ops.conv(tok(feats_l.view(qn * rfn_l, an * FEAT_LD), rfn_l), pk["ang0"][0], pk["ang0"][1], tok(a0, rfn_l), out_act=1)
-        a1 = torch.empty_like(a0)
-        ops.conv(tok(a0, rfn_l), pk["ang2"][0], pk["ang2"][1], tok(a1, rfn_l), out_act=1)
-        angles = torch.empty((qn * rfn_l, 1), dtype=torch.float32, device=dev)
-        ops.conv(tok(a1, rfn_l), pk["ang4"][0], pk["ang4"][1], tok(angles, rfn_l))
+            # angle head on the per-reference rows [an*516]                                 selector.py:212-214
+            a0 = torch.empty((qn * rfn_l, 512), dtype=torch.float32, device=dev)
+            ops.conv(tok(feats_l.view(qn * rfn_l, an * FEAT_LD), rfn_l), pk["ang0"][0], pk["ang0"][1], tok(a0, rfn_l), out_act=1)
+            a1 = torch.empty_like(a0)
+            ops.conv(tok(a0, rfn_l), pk["ang2"][0], pk["ang2"][1], tok(a1, rfn_l), out_act=1)
+            angles = torch.empty((qn * rfn_l, 1), dtype=torch.float32, device=dev)
+            ops.conv(tok(a1, rfn_l), pk["ang4"][0], pk["ang4"][1], tok(angles, rfn_l))
         return logits.view(qn, rfn), self._allgather_batch(angles, qn, rfn_l, rfn_all).view(qn, rfn_all)
 
     def compute_view_point_feats(self, *a, **k):

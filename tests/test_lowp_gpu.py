@@ -127,23 +127,36 @@ def test_corr2d_patch16_multi(mode, sizes, Cin, Cout, k):
     record("test_corr2d_patch16_multi", f"{mode} {sizes} x{Cin} -> {Cout}, {k}x{k}", e_ref, TOL[mode], note="relative to range")
 
 
-@pytest.mark.parametrize("mode", ["bf16", "fp16"])
-def test_selector_headline_lowp(golden, mode):
-    """64 references x 5 rotations with the cfg key: same arg-max viewpoint as the reference, logit error recorded."""
-    g = golden("sel_head")
+@pytest.mark.parametrize("mode,keep,lo,hi", [("fp16", None, 0.0, 0.25), ("fp16", (), 0.25, 1.0), ("bf16", None, 0.25, 4.0), ("bf16", (), 0.25, 8.0)],
+                         ids=["fp16-default-scheme", "fp16-nothing-kept", "bf16-default-keep-list", "bf16-nothing-kept"])
+def test_selector_headline_lowp(golden, mode, keep, lo, hi):
+    """64 references x 5 rotations in the reduced-precision modes against the reference's own logits — the four synthetic queries of
+    bench.py (tests/golden/pipeline_rows.npz), whose smallest top-2 margin is 0.038.  The bounds are TIED TO THE MARGIN as on the bench
+    line (lo / hi in units of it).  The product's scheme — fp16 with the cfg default keep-list (query trunk and
+    attention / predictor tail on fp32 operands, the InstanceNorm stacks on fp16); "bf16mix" on the bench line is this selector inside a
+    bf16 pipeline — must keep every logit within a QUARTER of the margin: the arg-max is then equal by construction.  The other three
+    document why: fp16 with nothing kept and bf16 (with or without the keep-list: every InstanceNorm-stack layer alone moves the logits by
+    0.2-0.8 of the margin in bf16) stay within their type's rounding class but EXCEED the quarter bar
+    (profiles/r05_lowp_selector_sensitivity.md); should one of them start to hold it, the default / DESIGN.md want updating."""
+    g = golden("pipeline_rows")
+    gl = g["logits"]
+    top2 = np.sort(gl, 1)[:, -2:]
+    margin = float((top2[:, 1] - top2[:, 0]).min())
     case = synth.selector_case(64, 5)
-    net = _net("selector", math_mode=mode)
+    cfg = {"math_mode": mode}
+    if keep is not None:
+        cfg["lowp_keep_fp32"] = keep
+    net = _net("selector", **cfg)
+    crops = synth.imgs_to_tensor(synth.synth_images(4, 128, 128, seed=200)).cuda()
     with torch.no_grad():
-        out = net({"ref_imgs": case["ref_imgs"].cuda(), "ref_imgs_info": {"poses": case["ref_poses"].cuda()},
-                   "object_center": case["object_center"].cuda(), "object_vert": case["object_vert"].cuda(),
-                   "que_imgs_info": {"imgs": case["que_imgs"].cuda()}, "eval": True})
-    got = out["ref_vp_logits"].cpu().numpy()
-    err = np.abs(got - g["logits"]).max()
-    spread = float(np.sort(g["logits"][0])[-1] - np.sort(g["logits"][0])[-2])
-    record("test_selector_headline_lowp", f"{mode} 64x5 logits vs reference golden (top-2 margin {spread:.3f})", err,
-           {"bf16": 0.5, "fp16": 0.1}[mode])
-    assert np.array_equal(got.argmax(1), g["logits"].argmax(1)), (err, spread)
-    assert err <= {"bf16": 0.5, "fp16": 0.1}[mode]
+        net.extract_ref_feats(case["ref_imgs"].cuda(), case["ref_poses"].cuda(), case["object_center"].cuda(), case["object_vert"].cuda())
+        got = net.compute_view_point_feats(crops)[0].cpu().numpy()
+    err = float(np.abs(got - gl).max())
+    record("test_selector_headline_lowp", f"{mode} keep={'default' if keep is None else keep} 64x5 logits of 4 queries vs reference golden "
+           f"(smallest top-2 margin {margin:.4f})", err, hi * margin)
+    assert lo * margin <= err <= hi * margin, (err / margin, lo, hi)
+    if hi <= 0.25:
+        assert np.array_equal(got.argmax(1), gl.argmax(1)), (err, margin)
 
 
 @pytest.mark.parametrize("mode", ["bf16", "fp16"])
