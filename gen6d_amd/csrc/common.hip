@@ -77,7 +77,7 @@ extern "C" double g6d_get_knob(const char* name) {
 }
 extern "C" void g6d_reset_knobs(void) { knob_defaults(); }
 
-extern "C" int g6d_abi_version(void) { return 9; }
+extern "C" int g6d_abi_version(void) { return 10; }
 extern "C" const char* g6d_last_error(void) { return g_err; }
 extern "C" int g6d_sizeof_conv_desc(void) { return (int)sizeof(G6dConv); }
 
@@ -88,4 +88,13 @@ __global__ void g6d_marker_kernel(int id) { (void)id; }
 extern "C" int g6d_marker(int id, g6d_stream_t stream) {
   hipLaunchKernelGGL(g6d_marker_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), id);
   return g6d_check_launch("g6d_marker");
+}
+
+// Stream-ordered zero fill of device memory (the per-query InstanceNorm statistics arena): a memset node in a captured graph
+// instead of a fill kernel.
+extern "C" int g6d_zero_bytes(void* ptr, size_t bytes, g6d_stream_t stream) {
+  if (!ptr && bytes) { g6d_set_error("zero_bytes: null pointer"); return G6D_EINVAL; }
+  if (bytes == 0) return G6D_OK;
+  if (hipMemsetAsync(ptr, 0, bytes, reinterpret_cast<hipStream_t>(stream)) != hipSuccess) { g6d_set_error("zero_bytes: hipMemsetAsync failed"); return G6D_ELAUNCH; }
+  return G6D_OK;
 }

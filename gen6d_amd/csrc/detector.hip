@@ -114,6 +114,35 @@ __global__ void __launch_bounds__(256) decode_kernel(const float* __restrict__ s
   }
 }
 
+
+// ---- the detector's image pyramid (network/detector.py:236-241: F.interpolate(que_imgs, size=(ht, wt), mode='bilinear'), align_corners
+// False) for all detection scales in ONE launch: planes = N*3 image planes [H][W] -> up to 4 destinations [planes][h_k][w_k].  Source
+// index as ATen's upsample_bilinear2d: scale = in / out (float), src = scale * (dst + 0.5) - 0.5 clamped at 0, the far neighbour
+// clamped to the last row / column.  A scale of the source's own size is not a destination: the caller passes the image itself on.
+struct PyrArgs { const float* src; int planes, H, W, n; int h[4], w[4]; long long first[5]; float* dst[4]; };
+
+__global__ void resize_pyramid_kernel(const PyrArgs a) {
+  const long long total = a.first[a.n];
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int k = 0;
+#pragma unroll
+    for (int j = 1; j < 4; ++j) k = (j < a.n && i >= a.first[j]) ? j : k;
+    const long long l = i - a.first[k];
+    const int h = a.h[k], w = a.w[k];
+    const int x = (int)(l % w); const long long t = l / w;
+    const int y = (int)(t % h), pl = (int)(t / h);
+    const float ry = (float)a.H / (float)h, rx = (float)a.W / (float)w;
+    float sy = ry * (y + 0.5f) - 0.5f; if (sy < 0.f) sy = 0.f;
+    float sx = rx * (x + 0.5f) - 0.5f; if (sx < 0.f) sx = 0.f;
+    const int y0 = min((int)sy, a.H - 1), x0 = min((int)sx, a.W - 1);
+    const int y1 = y0 + (y0 < a.H - 1), x1 = x0 + (x0 < a.W - 1);
+    const float ly = sy - y0, lx = sx - x0, hy = 1.f - ly, hx = 1.f - lx;
+    const float* b = a.src + (size_t)pl * a.H * a.W;
+    const float v = hy * (hx * b[(size_t)y0 * a.W + x0] + lx * b[(size_t)y0 * a.W + x1]) +
+                    ly * (hx * b[(size_t)y1 * a.W + x0] + lx * b[(size_t)y1 * a.W + x1]);
+    a.dst[k][l] = v;
+  }
+}
 }  // namespace
 
 #define STREAM(s) reinterpret_cast<hipStream_t>(s)
@@ -150,4 +179,23 @@ extern "C" int g6d_detector_decode(const float* scores, int ld_s, const float* o
   hipLaunchKernelGGL(decode_kernel, dim3(batch), dim3(256), 0, STREAM(stream), scores, ld_s, offset, ld_o, scale, ld_c, hs, ws,
                      (float)pool_ratio, result);
   return g6d_check_launch("detector_decode");
+}
+
+extern "C" int g6d_resize_bilinear_pyramid(const float* src, int planes, int H, int W, int nscale, const int* hs, const int* ws,
+                                           float* const* dsts, g6d_stream_t stream) {
+  if (!src || !hs || !ws || !dsts || planes <= 0 || H <= 0 || W <= 0 || nscale < 1 || nscale > 4) {
+    g6d_set_error("resize_bilinear_pyramid: bad args (1..4 destination sizes)"); return G6D_EINVAL;
+  }
+  PyrArgs a = {};
+  a.src = src; a.planes = planes; a.H = H; a.W = W; a.n = nscale;
+  long long tot = 0;
+  for (int k = 0; k < nscale; ++k) {
+    if (hs[k] <= 0 || ws[k] <= 0 || !dsts[k]) { g6d_set_error("resize_bilinear_pyramid: bad destination"); return G6D_EINVAL; }
+    a.h[k] = hs[k]; a.w[k] = ws[k]; a.dst[k] = dsts[k]; a.first[k] = tot;
+    tot += (long long)planes * hs[k] * ws[k];
+  }
+  for (int k = nscale; k < 5; ++k) a.first[k] = tot;
+  const long long blocks = (tot + 255) / 256;
+  hipLaunchKernelGGL(resize_pyramid_kernel, dim3((unsigned)(blocks < 65536 * 8 ? blocks : 65536 * 8)), dim3(256), 0, STREAM(stream), a);
+  return g6d_check_launch("resize_bilinear_pyramid");
 }

@@ -75,6 +75,8 @@ SIGNATURES = {
     "g6d_detector_assemble": [_P, _P, _P, _I, _I, _I, C.POINTER(C.c_float), _F, _I, _I, _I, _I, _P, _I, _P],
     "g6d_detector_score_mlp_max": [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "g6d_detector_decode": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _I, _P],
+    "g6d_resize_bilinear_pyramid": [_P, _I, _I, _I, _I, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_void_p), _P],
+    "g6d_zero_bytes": [_P, C.c_size_t, _P],
     "g6d_vps_norm": [_P, _I, _P, _I, _I, _I, _P],
     "g6d_max_an_add": [_P, _I, _I, _I, _I, _P, _P, _I, _I, _P],
     "g6d_attention": [_P, _P, _P, _I, _I, _I, _I, _P, _I, _I, _P],

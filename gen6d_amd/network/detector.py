@@ -197,7 +197,9 @@ class Detector(ParamBank):
         if TRUNK_MULTI and multi and len(order) <= 4:
             # every trunk layer is ONE launch over the whole pyramid (the small scales fill the blocks the large ones leave
             # over); the correlations of the scales then run side by side
-            feats = trunk_features_multi(pk["vgg"], [resized(sc) for _, sc in order], ("c5", "c7_pre", "p7"), f43=F43)
+            # the image pyramid in ONE launch (g6d_resize_bilinear_pyramid; the scale of the query's own size is the query itself)
+            pyr = ops.resize_bilinear_pyramid(que_imgs, [self._scale_size(hq, wq, sc) for _, sc in order])
+            feats = trunk_features_multi(pk["vgg"], pyr, ("c5", "c7_pre", "p7"), f43=F43)
             self._scores_from_pyramid(feats, [si for si, _ in order], stacked, hs, ws)
         else:
             ops.fork_join([(lambda si=si, sc=sc: self._scores_one_scale(resized(sc), si, stacked, hs, ws)) for si, sc in order], dev)
@@ -243,8 +245,8 @@ class Detector(ParamBank):
             o4, res, _ = self._detect_batch(que_imgs[q0:q0 + step].contiguous(), multi)
             outs.append(o4.permute(0, 3, 1, 2))
             results.append(res)
-        o = torch.cat(outs, 0)                                                 # qn,4,hs,ws
-        r = torch.cat(results, 0)
+        o = ops.cat1(outs, 0)                                                  # qn,4,hs,ws
+        r = ops.cat1(results, 0)
         return {"scores": o[:, 0:1], "select_pr_scale": o[:, 1:2], "select_pr_offset": o[:, 2:4],
                 "que_select_id": r[:, 3:5].round().long(), "pool_ratio": self.pool_ratio,
                 "positions": r[:, 0:2], "scales": r[:, 2]}

@@ -320,8 +320,8 @@ class VolumeRefiner(ParamBank):
             outs = [self._step(que["imgs"][q0:q0 + MAX_BATCH], que["Ks_in"][q0:q0 + MAX_BATCH], que["poses_in"][q0:q0 + MAX_BATCH],
                                ref["imgs"][q0:q0 + MAX_BATCH], ref["Ks"][q0:q0 + MAX_BATCH], ref["poses"][q0:q0 + MAX_BATCH])
                     for q0 in range(0, qn_all, MAX_BATCH)]
-        out = {"rotation": torch.cat([o[0] for o in outs], 0), "offset": torch.cat([o[1] for o in outs], 0),
-               "scale": torch.cat([o[2] for o in outs], 0)}
+        out = {"rotation": ops.cat1([o[0] for o in outs], 0), "offset": ops.cat1([o[1] for o in outs], 0),
+               "scale": ops.cat1([o[2] for o in outs], 0)}
         if not is_inference:
             sn = self.cfg["refiner_sample_num"]
             g = torch.linspace(-1, 1, sn, dtype=torch.float32, device=que["imgs"].device)

@@ -353,7 +353,7 @@ class ViewpointSelector(ParamBank):
         if step >= 8:
             step -= step % 8                           # whole groups of 8 for g6d_selector_levels
         outs = [self._query_batch(que_imgs[i:i + step].contiguous()) for i in range(0, que_imgs.shape[0], step)]
-        return torch.cat([o[0] for o in outs], 0), torch.cat([o[1] for o in outs], 0)
+        return ops.cat1([o[0] for o in outs], 0), ops.cat1([o[1] for o in outs], 0)
 
     def forward(self, data):
         self.extract_ref_feats(data["ref_imgs"], data["ref_imgs_info"]["poses"], data["object_center"],

@@ -351,9 +351,14 @@ def stats_arena_begin(device):
     global _CUR_ARENA
     key = (str(device), torch.cuda.current_stream(device).cuda_stream)
     if key not in _ARENA:
-        _ARENA[key] = [torch.zeros(ARENA_DOUBLES, dtype=torch.float64, device=device), 0]
+        _ARENA[key] = [torch.zeros(ARENA_DOUBLES, dtype=torch.float64, device=device), 0, 0]
     a = _ARENA[key]
-    a[0].zero_()
+    # only what has ever been handed out of this arena needs clearing (a[2] = its all-time high-water mark: everything behind it is
+    # still zero from the allocation); hipMemsetAsync through the C ABI — a memset node in a captured graph, not a fill kernel over
+    # 16 MB.  (A captured memset keeps the size it had at capture time: the lanes' streams, and with them their arenas, are private to
+    # their graphs, whose replays hand out the same slices every time.)
+    if a[2]:
+        _lib.check(_lib.load().g6d_zero_bytes(_ptr(a[0]), a[2] * 8, _stream()), "g6d_zero_bytes")
     a[1] = 0
     _CUR_ARENA = a
 
@@ -365,6 +370,7 @@ def new_stats(groups, channels, device):
         return torch.zeros((groups, channels, 2), dtype=torch.float64, device=device)
     t = a[0][a[1]:a[1] + n].view(groups, channels, 2)
     a[1] += n
+    a[2] = max(a[2], a[1])
     return t
 
 
@@ -375,6 +381,7 @@ def new_counter(device):
         return torch.zeros((2,), dtype=torch.int32, device=device)
     t = a[0][a[1]:a[1] + 1].view(torch.int32)
     a[1] += 1
+    a[2] = max(a[2], a[1])
     return t
 
 
@@ -725,7 +732,7 @@ def selector_scan(que, refs):
     return smap, vps
 
 
-def selector_levels(ques, refs, sums, Dg, eps=1e-5, want_maps=False):
+def selector_levels(ques, refs, sums, Dg, eps=1e-5, want_maps=False, _out=None):
     """All pyramid levels of a batch of queries in one launch: ques[l] [qn,HW_l,C] (or [HW_l,C] for one query), refs[l] [D,HW_l,C],
     sums[l] = (r1, r2) of selector_ref_sums -> vps [qn,L,D], scale [qn,L,C], shift [qn,L,C] (the InstanceNorm affine of the product
     over Dg*HW_l values; a single 2-D query gives [L,D] / [L,C]) and, if want_maps, the score maps [qn,D,HW_l]."""
@@ -735,19 +742,29 @@ def selector_levels(ques, refs, sums, Dg, eps=1e-5, want_maps=False):
     if single:
         ques = [q.unsqueeze(0) for q in ques]
     qn = ques[0].shape[0]
-    if qn > 8:                                           # the kernel keeps <= 8 query rows in registers: groups of 8 (one cache pass each)
-        parts = [selector_levels([q[i:i + 8] for q in ques], refs, sums, Dg, eps, want_maps) for i in range(0, qn, 8)]
-        return (torch.cat([p_[0] for p_ in parts], 0), torch.cat([p_[1] for p_ in parts], 0), torch.cat([p_[2] for p_ in parts], 0),
-                [torch.cat([p_[3][l] for p_ in parts], 0) for l in range(L)] if want_maps else None)
     D, _, Cc = refs[0].shape
     dev = ques[0].device
+    if qn > 8:                                           # the kernel keeps <= 8 query rows in registers: groups of 8 (one cache pass each),
+        vps = torch.empty((qn, L, D), dtype=torch.float32, device=dev)                 # every group writes its rows of the results
+        scale = torch.empty((qn, L, Cc), dtype=torch.float32, device=dev)
+        shift = torch.empty_like(scale)
+        maps = [torch.empty((qn, D, r.shape[1]), dtype=torch.float32, device=dev) for r in refs] if want_maps else None
+        for i in range(0, qn, 8):
+            selector_levels([q[i:i + 8] for q in ques], refs, sums, Dg, eps, want_maps,
+                            _out=(vps[i:i + 8], scale[i:i + 8], shift[i:i + 8], [m[i:i + 8] for m in maps] if want_maps else None))
+        return vps, scale, shift, maps
     for q, r in zip(ques, refs):
         if not (q.is_contiguous() and r.is_contiguous()) or r.shape[0] != D or r.shape[2] != Cc or tuple(q.shape) != (qn,) + tuple(r.shape[1:]):
             raise ValueError("selector_levels: operands must be contiguous [qn,HW,C] / [D,HW,C]")
-    vps = torch.empty((qn, L, D), dtype=torch.float32, device=dev)
-    scale = torch.empty((qn, L, Cc), dtype=torch.float32, device=dev)
-    shift = torch.empty_like(scale)
-    maps = [torch.empty((qn, D, r.shape[1]), dtype=torch.float32, device=dev) for r in refs]
+    if _out is not None:
+        vps, scale, shift, maps = _out
+    else:
+        vps = torch.empty((qn, L, D), dtype=torch.float32, device=dev)
+        scale = torch.empty((qn, L, Cc), dtype=torch.float32, device=dev)
+        shift = torch.empty_like(scale)
+        maps = None
+    if maps is None:
+        maps = [torch.empty((qn, D, r.shape[1]), dtype=torch.float32, device=dev) for r in refs]
     arr = lambda ts: (C.c_void_p * L)(*[t.data_ptr() if t is not None else None for t in ts])
     hw = (C.c_int * L)(*[r.shape[1] for r in refs])
     # algorithmic bytes: the reference cache once per BATCH, query rows, score maps written and re-read, r1/r2 (fp64) per query
@@ -800,6 +817,39 @@ def refiner_volume_kp(feats, ref_Ks, ref_poses, K_in, pose_in, lin, h_in, w_in, 
                                                                     _ptr(lin), V - 1, fh, fw, Cc, int(h_in), int(w_in), sn, _ptr(mean_in),
                                                                     _ptr(std), B, _stream()), "g6d_refiner_volume_kp"))
     return mean_in, std
+
+
+def cat1(ts, dim=0):
+    """torch.cat that hands a single tensor through (no copy launch for calls that fit one chunk)."""
+    return ts[0] if len(ts) == 1 else torch.cat(ts, dim)
+
+
+def resize_bilinear_pyramid(imgs, sizes):
+    """F.interpolate(imgs, size=s, mode='bilinear') (align_corners False) for every size of `sizes` in ONE launch
+    (g6d_resize_bilinear_pyramid; reference network/detector.py:236-241): imgs [N,3,H,W] contiguous -> list of [N,3,h,w], cut from one
+    buffer; a size equal to the image's own returns the image itself."""
+    _need_gpu(imgs)
+    if imgs.dim() != 4 or imgs.dtype != torch.float32 or not imgs.is_contiguous():
+        raise ValueError("resize_bilinear_pyramid: imgs must be contiguous float32 [N,C,H,W]")
+    N, Cc, H, W = imgs.shape
+    todo = [i for i, (h, w) in enumerate(sizes) if (h, w) != (H, W)]
+    if len(todo) > 4:
+        raise ValueError("resize_bilinear_pyramid: at most 4 destination sizes")
+    outs = [imgs] * len(sizes)
+    if not todo:
+        return outs
+    buf = torch.empty(sum(N * Cc * sizes[i][0] * sizes[i][1] for i in todo), dtype=torch.float32, device=imgs.device)
+    o = 0
+    dst = []
+    for i in todo:
+        h, w = sizes[i]
+        dst.append(buf[o:o + N * Cc * h * w].view(N, Cc, h, w)); o += N * Cc * h * w
+        outs[i] = dst[-1]
+    hs = (C.c_int * len(todo))(*[sizes[i][0] for i in todo])
+    ws_ = (C.c_int * len(todo))(*[sizes[i][1] for i in todo])
+    ptrs = (C.c_void_p * len(todo))(*[d.data_ptr() for d in dst])
+    _lib.check(_lib.load().g6d_resize_bilinear_pyramid(_ptr(imgs), N * Cc, H, W, len(todo), hs, ws_, ptrs, _stream()), "g6d_resize_bilinear_pyramid")
+    return outs
 
 
 def detector_assemble(s0, s1, s2, hc, wc, mu_sigma, clip, hs, ws, scale_idx, stacked, batch=1):

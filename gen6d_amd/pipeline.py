@@ -4,7 +4,7 @@ Used by bench.py, __graft_entry__.smoke() and the GPU tests; mirrors `Gen6DEstim
 (det 32 refs, sel 64 refs x 5 rotations, 6 refiner views, refine_iter 3)."""
 import torch
 
-from . import synth
+from . import ops, synth
 from .network import name2network
 from .network import refiner as refiner_mod
 
@@ -38,11 +38,21 @@ class TensorPipeline:
             self.selector.extract_ref_feats(self.sel_case["ref_imgs"].to(d), self.sel_case["ref_poses"].to(d),
                                             self.sel_case["object_center"].to(d), self.sel_case["object_vert"].to(d))
         self.ref_feats = None                        # features of the canned reference crops (query(..., cached_refs=True))
+        self._canned_cache = {}
         self.ref_case = synth.refiner_case()
         self.ref_dev = {k: v.to(d) for k, v in self.ref_case.items()}
         # a slightly different input pose per refinement iteration (no cross-iteration caching possible)
         self.iter_poses = [torch.from_numpy(synth.perturb_pose(self.ref_case["poses_in"][0].numpy(), 2.0 * i, 0.01 * i))[None].to(d)
                            for i in range(self.refine_iter)]
+
+    def _canned(self, n, it):
+        """(Ks_in, pose_in of iteration `it`, ref_Ks, ref_poses) of the canned refinement case replicated for n queries (dense)."""
+        key = (n, it)
+        if key not in self._canned_cache:
+            r = self.ref_dev
+            ex = lambda t: t.expand(n, *t.shape[1:]).contiguous()
+            self._canned_cache[key] = (ex(r["Ks_in"]), ex(self.iter_poses[it]), ex(r["ref_Ks"]), ex(r["ref_poses"]))
+        return self._canned_cache[key]
 
     def query(self, que_full, que_crop, cached_refs=False):
         """que_full [qn,3,H,W] (detector input), que_crop [qn,3,128,128] (selector/refiner input), device tensors; the qn
@@ -71,11 +81,11 @@ class TensorPipeline:
                     for q0 in range(0, qn, rb):
                         n = min(rb, qn - q0)
                         ex = lambda t: t.expand(n, *t.shape[1:])
-                        o = self.refiner._step(que_crop[q0:q0 + n], ex(r["Ks_in"]).contiguous(), ex(self.iter_poses[it]).contiguous(),
-                                               ex(r["ref_imgs"]), ex(r["ref_Ks"]).contiguous(), ex(r["ref_poses"]).contiguous(),
+                        cam = self._canned(n, it)              # the canned cameras / poses of n queries: dense copies made once per n
+                        o = self.refiner._step(que_crop[q0:q0 + n], cam[0], cam[1], ex(r["ref_imgs"]), cam[2], cam[3],
                                                ref_feats=self.ref_feats[None].expand(n, *self.ref_feats.shape) if cached_refs else None)
                         rots.append(o[0]); offs.append(o[1]); scls.append(o[2])
-                    rot, off, scl = (torch.cat(t, 0) for t in (rots, offs, scls))
+                    rot, off, scl = (ops.cat1(t, 0) for t in (rots, offs, scls))
                 steps += [rot, off, scl]
         return torch.cat([det["positions"], det["scales"][:, None], idx[:, None].float(), ang] + steps, 1)
 

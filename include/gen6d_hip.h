@@ -352,6 +352,13 @@ int g6d_detector_score_mlp_max(const float* stacked, int P, int rfn, int nch, co
  * batch >= 1 queries: the maps of query b start b*hs*ws rows after those of query 0, result [batch][5]. */
 int g6d_detector_decode(const float* scores, int ld_s, const float* offset, int ld_o, const float* scale, int ld_c,
                         int hs, int ws, int pool_ratio, float* result, int batch, g6d_stream_t stream);
+/* (ABI v10) The detector's image pyramid in one launch: F.interpolate(que_imgs, size=(h_k, w_k), mode='bilinear') (align_corners False;
+ * network/detector.py:236-241) of src [planes = N*3][H][W] for up to 4 destination sizes -> dsts[k] [planes][hs[k]][ws[k]] (dense).
+ * Source index as ATen: scale = in / out, src = scale * (dst + 0.5) - 0.5 clamped at 0. */
+int g6d_resize_bilinear_pyramid(const float* src, int planes, int H, int W, int nscale, const int* hs, const int* ws,
+                                float* const* dsts, g6d_stream_t stream);
+/* (ABI v10) Stream-ordered zero fill of `bytes` bytes of device memory (hipMemsetAsync: a memset node in a captured graph). */
+int g6d_zero_bytes(void* ptr, size_t bytes, g6d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Selector tail helpers (network/selector.py:201-214, network/attention.py:4-17,50-68).

@@ -333,6 +333,11 @@ def refiner_volume(feats, projs, rot_in, lin, h_in, w_in, mean_in, std):
     return mean_in, std
 
 
+def resize_bilinear_pyramid(imgs, sizes):
+    """F.interpolate(..., mode='bilinear') per size (reference network/detector.py:236-241)."""
+    return [imgs if tuple(sz) == tuple(imgs.shape[2:]) else F.interpolate(imgs, size=tuple(sz), mode="bilinear") for sz in sizes]
+
+
 def detector_assemble(s0, s1, s2, hc, wc, mu_sigma, clip, hs, ws, scale_idx, stacked, batch=1):
     if batch > 1:
         for b in range(batch):

@@ -807,3 +807,29 @@ def test_own_trunk_matches_library_trunk(ops):
         own_t = B.vgg_taps_cl([folded[0]] + [(B.winograd_filters(w), b) for w, b in folded[1:]], x, {"c3", "c5", "c7_pre", "p7"})
     for k in ("c3", "c5", "c7_pre", "p7"):
         _check(own_t[k].permute(0, 3, 1, 2), lib_t[k].double().cpu(), 5e-5, k)
+
+
+@pytest.mark.parametrize("N,H,W", [(2, 480, 640), (1, 128, 128), (3, 45, 77)])
+def test_resize_bilinear_pyramid(ops, N, H, W):
+    """The detector's image pyramid in one launch (reference network/detector.py:236-241: F.interpolate(..., mode='bilinear') per
+    detection scale, align_corners False) against torch's own interpolation in fp64 on the CPU; the scale of the image's own size is the
+    image itself (no copy)."""
+    from gen6d_amd.network.detector import Detector
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand((N, 3, H, W), generator=g)
+    sizes = [Detector._scale_size(H, W, s) for s in (0.5, 0.0, -0.5, -1.0)]
+    if (H, W) == (45, 77):
+        sizes[1] = (H, W)                         # (odd sizes: the identity scale is not rounded up to a multiple of 32 here)
+    xg = x.cuda()
+    outs = ops.resize_bilinear_pyramid(xg, sizes)
+    torch.cuda.synchronize()
+    for o, sz in zip(outs, sizes):
+        assert tuple(o.shape) == (N, 3) + tuple(sz)
+        if tuple(sz) == (H, W):
+            assert o.data_ptr() == xg.data_ptr()
+            continue
+        # the source coordinate is formed in fp32, as ATen's own device kernel forms it (ulp 3e-5 at coordinate 480: the weights of a
+        # random image's neighbours move by that much against an fp64 evaluation): fp64 at 1e-4, ATen's device kernel at 2e-6
+        ref = torch.nn.functional.interpolate(x.double(), size=tuple(sz), mode="bilinear")
+        _check(o, ref, 1e-4, f"pyramid {sz} vs fp64")
+        _check(o, torch.nn.functional.interpolate(xg, size=tuple(sz), mode="bilinear").cpu(), 2e-6, f"pyramid {sz} vs ATen on the device")
