@@ -359,7 +359,10 @@ __global__ void __launch_bounds__(GEMV_THREADS) linear_gemv_kernel(const float* 
 // block that arrives last adds them IN SLICE ORDER (deterministic) and applies bias / activation.
 #define GEMVB_THREADS 256
 #define GEMVB_R 8
-template <int KV>
+// NH (round 5): up to NH groups of 8 right-hand sides against ONE pass over the weights — the block keeps its 8 x KL weight values in
+// registers and runs the x rows of every group past them (group h + 1's rows are requested while group h is reduced); the partial sums
+// of a group land in their own slab of the workspace, the last block of a row group adds and finishes all of them.
+template <int KV, int NH>
 __global__ void __launch_bounds__(GEMVB_THREADS, 2) linear_gemv_batch_kernel(const float* __restrict__ x, int B, int K, const float* __restrict__ W,
                                                                               const float* __restrict__ bias, int act, float* __restrict__ out,
                                                                               int O, float* __restrict__ ws) {
@@ -370,17 +373,27 @@ __global__ void __launch_bounds__(GEMVB_THREADS, 2) linear_gemv_batch_kernel(con
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kbase = ks * KL + tid * 4;
   f32x4 xr[8][KV];
+  auto load_x = [&](int h) {
 #pragma unroll
-  for (int b = 0; b < 8; ++b)
+    for (int b = 0; b < 8; ++b)
 #pragma unroll
-    for (int v = 0; v < KV; ++v)
-      xr[b][v] = b < B ? *reinterpret_cast<const f32x4*>(x + (size_t)b * K + kbase + v * (GEMVB_THREADS * 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int v = 0; v < KV; ++v)
+        xr[b][v] = 8 * h + b < B ? *reinterpret_cast<const f32x4*>(x + (size_t)(8 * h + b) * K + kbase + v * (GEMVB_THREADS * 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  load_x(0);
   f32x4 wv[R][KV];
 #pragma unroll
   for (int v = 0; v < KV; ++v)
 #pragma unroll
     for (int r = 0; r < R; ++r)
       wv[r][v] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(W + (size_t)(og * R + r) * K + kbase + v * (GEMVB_THREADS * 4)));
+  int idx = 0;
+#pragma unroll
+  for (int sft = 0; sft < 6; ++sft) idx |= ((lane >> (5 - sft)) & 1) << sft;
+  float part[NH];
+#pragma unroll
+  for (int h = 0; h < NH; ++h) {
+  if (8 * h >= B) { part[h] = 0.f; continue; }
   float acc[R * 8];                       // value index i = r * 8 + b
 #pragma unroll
   for (int r = 0; r < R; ++r)
@@ -392,6 +405,7 @@ __global__ void __launch_bounds__(GEMVB_THREADS, 2) linear_gemv_batch_kernel(con
         a += wv[r][v][0] * xr[b][v][0] + wv[r][v][1] * xr[b][v][1] + wv[r][v][2] * xr[b][v][2] + wv[r][v][3] * xr[b][v][3];
       acc[r * 8 + b] = a;
     }
+  if (h + 1 < NH && 8 * (h + 1) < B) load_x(h + 1);      // the next group's rows travel while this one is reduced
   // transposing butterfly: after the step with lane bit `bit` every lane holds half as many values, each summed over that bit; at the
   // end lane L holds the wave's sum of value index bitrev6(L)
   int bit = 32;
@@ -404,28 +418,37 @@ __global__ void __launch_bounds__(GEMVB_THREADS, 2) linear_gemv_batch_kernel(con
       acc[i] = keep + __shfl_xor(send, bit, 64);
     }
   }
-  int idx = 0;
-#pragma unroll
-  for (int sft = 0; sft < 6; ++sft) idx |= ((lane >> (5 - sft)) & 1) << sft;
+  if (h > 0) __syncthreads();                            // the previous group's sums have been read
   red[wave][idx] = acc[0];
   __syncthreads();
-  float part = 0.f;
+  float pt = 0.f;
   if (tid < R * 8) {
 #pragma unroll
-    for (int w = 0; w < GEMVB_THREADS / 64; ++w) part += red[w][tid];
+    for (int w = 0; w < GEMVB_THREADS / 64; ++w) pt += red[w][tid];
+  }
+  part[h] = pt;
   }
   if (KS > 1) {
-    float* slab = ws + G6D_WS_COUNTERS + (size_t)og * KS * (R * 8);
-    if (tid < R * 8) asm volatile("global_store_dword %0, %1, off sc1" ::"v"(slab + ks * (R * 8) + tid), "v"(part) : "memory");
+    float* slab = ws + G6D_WS_COUNTERS + (size_t)og * NH * KS * (R * 8);       // [group h][slice][R * 8]
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+      if (tid < R * 8 && 8 * h < B) asm volatile("global_store_dword %0, %1, off sc1" ::"v"(slab + (h * KS + ks) * (R * 8) + tid), "v"(part[h]) : "memory");
     if (!g6d_split_arrive(reinterpret_cast<int*>(ws) + og, KS, &flag)) return;
     if (tid < R * 8) {
-      part = 0.f;
-      for (int z = 0; z < KS; ++z) part += slab[z * (R * 8) + tid];
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        if (8 * h >= B) continue;
+        float pt = 0.f;
+        for (int z = 0; z < KS; ++z) pt += slab[(h * KS + z) * (R * 8) + tid];
+        part[h] = pt;
+      }
     }
   }
   if (tid < R * 8) {
     const int r = tid >> 3, b = tid & 7, o = og * R + r;
-    if (b < B) out[(size_t)b * O + o] = apply_act(part + (bias ? bias[o] : 0.f), act);
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+      if (8 * h + b < B) out[(size_t)(8 * h + b) * O + o] = apply_act(part[h] + (bias ? bias[o] : 0.f), act);
   }
 }
 
@@ -566,16 +589,28 @@ extern "C" int g6d_linear_gemv_batch(const float* x, int B, int K, const float* 
   constexpr int KL = GEMVB_THREADS * 4 * 2;                 // KV = 2: K slices of 2048 floats
   const bool rows_ok = O % GEMVB_R == 0 && K % KL == 0 && O / GEMVB_R <= G6D_WS_COUNTERS;
   const int KS = rows_ok ? K / KL : 0;
-  const size_t need = G6D_WS_COUNTER_BYTES + (size_t)(O / GEMVB_R) * (KS > 0 ? KS : 1) * GEMVB_R * 8 * sizeof(float);
-  // groups of <= 8 right-hand sides; a group of one, short rows or a missing workspace take the row-per-block kernel.  Later groups
-  // re-read W, which (67 MB) then comes out of the 256 MB Infinity Cache rather than HBM.
-  for (int b0 = 0; b0 < B; b0 += 8) {
-    const int nb = B - b0 < 8 ? B - b0 : 8;
+  // up to 32 right-hand sides per launch = ONE pass over the weights (round 5; round 4: one pass per 8): the block holds its weight
+  // values in registers and runs 1, 2 or 4 groups of 8 rows of x past them.  A single right-hand side, short rows or a missing workspace
+  // take the row-per-block kernel.
+  for (int b0 = 0; b0 < B; b0 += 32) {
+    const int nb = B - b0 < 32 ? B - b0 : 32;
+    const int nh = nb <= 8 ? 1 : (nb <= 16 ? 2 : 4);
+    const size_t need = G6D_WS_COUNTER_BYTES + (size_t)(O / GEMVB_R) * nh * (KS > 0 ? KS : 1) * GEMVB_R * 8 * sizeof(float);
     const float* xg = x + (size_t)b0 * K;
     float* og = out + (size_t)b0 * O;
     if (nb >= 2 && rows_ok && KS >= 2 && workspace && workspace_bytes >= need && g6d_aligned16(workspace)) {
-      hipLaunchKernelGGL(linear_gemv_batch_kernel<2>, dim3(O / GEMVB_R, KS), dim3(GEMVB_THREADS), 0, STREAM(stream), xg, nb, K, W, bias, act, og, O,
-                         workspace);
+      const dim3 grid(O / GEMVB_R, KS);
+      if (nh == 1) hipLaunchKernelGGL((linear_gemv_batch_kernel<2, 1>), grid, dim3(GEMVB_THREADS), 0, STREAM(stream), xg, nb, K, W, bias, act, og, O, workspace);
+      else if (nh == 2) hipLaunchKernelGGL((linear_gemv_batch_kernel<2, 2>), grid, dim3(GEMVB_THREADS), 0, STREAM(stream), xg, nb, K, W, bias, act, og, O, workspace);
+      else hipLaunchKernelGGL((linear_gemv_batch_kernel<2, 4>), grid, dim3(GEMVB_THREADS), 0, STREAM(stream), xg, nb, K, W, bias, act, og, O, workspace);
+    } else if (nb > 8) {                     // (fallback kernels take <= 8 rows per launch)
+      for (int c0 = 0; c0 < nb; c0 += 8) {
+        const int nc = nb - c0 < 8 ? nb - c0 : 8;
+        if (K >= GEMV_THREADS * 4 * 16)
+          hipLaunchKernelGGL(linear_gemv_kernel<16>, dim3(O), dim3(GEMV_THREADS), 0, STREAM(stream), xg + (size_t)c0 * K, nc, K, W, bias, act, og + (size_t)c0 * O, O);
+        else
+          hipLaunchKernelGGL(linear_gemv_kernel<4>, dim3(O), dim3(GEMV_THREADS), 0, STREAM(stream), xg + (size_t)c0 * K, nc, K, W, bias, act, og + (size_t)c0 * O, O);
+      }
     } else if (K >= GEMV_THREADS * 4 * 16) {
       hipLaunchKernelGGL(linear_gemv_kernel<16>, dim3(O), dim3(GEMV_THREADS), 0, STREAM(stream), xg, nb, K, W, bias, act, og, O);
     } else {

@@ -502,7 +502,10 @@ def test_selector_tail_ops(ops):
                                        # first FC layer with 2 / 8 queries, a ragged group (11 = 8 + 3), configs[4]'s 32, and shapes that
                                        # fall back to the row-per-block kernel (O % 8 != 0; one K slice)
                                        (2, 32768, 512, 2), (8, 32768, 512, 2), (11, 8192, 64, 1), (32, 32768, 512, 0), (5, 8192, 20, 0),
-                                       (4, 4096, 16, 2)])
+                                       (4, 4096, 16, 2),
+                                       # round 5: up to 32 right-hand sides per weight pass (2 / 4 groups of 8 in one block): the bench's 16,
+                                       # ragged 20 = 8 + 8 + 4, two launches for 40 = 32 + 8, 19 rows on the fall-back kernels
+                                       (16, 32768, 512, 2), (20, 8192, 64, 1), (40, 8192, 64, 0), (19, 8192, 20, 0)])
 def test_linear_gemv(ops, B, K, O, act):
     g = torch.Generator().manual_seed(12)
     x, W, b = _rand(g, B, K), _rand(g, O, K, scale=K ** -0.5), _rand(g, O, scale=0.1)
