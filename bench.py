@@ -211,8 +211,9 @@ def main():
     ap.add_argument("--batch", type=int, default=16,
                     help="queries per step: they go through every launch together (M dimension of the conv / correlation grids, one "
                          "pass over the selector's reference cache, one FC weight stream), 1..32 (the detector cuts at 16)")
-    ap.add_argument("--lanes", type=int, default=2,
-                    help="independent hipGraph copies (one batch each) kept in flight on separate streams")
+    ap.add_argument("--lanes", type=int, default=3,
+                    help="independent hipGraph copies (one batch each) kept in flight on separate streams (round 5, batches of 16: 2 lanes "
+                         "247.7, 3 lanes 251.5, 4 lanes 251.4 images/s; 32 x 2: 251.1 — profiles/r05_batch_lanes.md)")
     ap.add_argument("--serial", action="store_true",
                     help="profiling aid: no stream fork/join and no graph, so that per-kernel durations in a rocprofv3 "
                          "trace are not inflated by overlap (this is how the roofline pass itself runs)")
