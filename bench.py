@@ -139,7 +139,7 @@ def ref_sweep(dev, B, lanes, steps, warmup):
         for _ in range(2): pipe.selector.compute_view_point_feats(g_in)
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph, stream=stream), torch.no_grad():
+    with torch.cuda.graph(graph, stream=stream, capture_error_mode="thread_local"), torch.no_grad():
         g_out = pipe.selector.compute_view_point_feats(g_in)
     for _ in range(2): graph.replay()
     torch.cuda.synchronize()
@@ -221,6 +221,10 @@ def main():
                     help="graph mode: also fork the independent branches of ONE query (4 detector scales, 3 selector levels, "
                          "3 refiner feature branches) onto side streams inside each graph.  Off by default: measured, the "
                          "chip is filled better by whole queries in flight on separate streams (89 vs 69 images/s)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="create the process group at world size 1 as well (RCCL accepts every collective on one rank): the multi-rank "
+                         "plumbing of the query-replica mode — barrier, MAX-reduce of the time, all-gather of the rows, graph capture next to the "
+                         "process group's watchdog thread — then runs on a 1-GPU box exactly as it does on N (tests/test_rccl_world1_gpu.py)")
     ap.add_argument("--shard-refs", action="store_true",
                     help="strong-scaling variant: all ranks work on the SAME query stream, the selector's reference cache "
                          "is sharded over the ranks (RCCL statistics all-reduces + feature all-gather); default is query replicas")
@@ -237,7 +241,7 @@ def main():
     backend = os.environ.get("G6D_DIST_BACKEND") or ("nccl" if n_dev >= want_world else "gloo")   # nccl = RCCL over xGMI
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % n_dev)
     # `--shard-refs --gpus 1`: a one-rank RCCL process group — the sharded path issues its 9 + 1 collectives per batch on it
-    rank, world, local = parallel.init_from_env(backend=backend, force=args.shard_refs and want_world == 1)
+    rank, world, local = parallel.init_from_env(backend=backend, force=(args.shard_refs or args.force_dist) and want_world == 1)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     local = local % n_dev                            # (fewer GPUs than ranks: several ranks share a device, gloo)
@@ -333,7 +337,8 @@ def main():
     prof, ops.PROFILE = ops.PROFILE, None
     prof_hbm, ops.PROFILE_HBM = ops.PROFILE_HBM or {}, None
     stages = stage_times(pipe, fulls[0:1], crops[0:1]) if (rank == 0 and not shard_refs) else None   # (sharded stages hold collectives)
-    rows = parallel.gather_rows(torch.cat(rows, 0), world * args.steps * B) if (world > 1 and not shard_refs) else torch.cat(rows, 0)
+    rows = (parallel.gather_rows(torch.cat(rows, 0), world * args.steps * B) if ((world > 1 or args.force_dist) and not shard_refs)
+            else torch.cat(rows, 0))
     n_queries = args.steps * B if shard_refs else world * args.steps * B
     # latency of ONE query alone: a batch-1 graph on one lane, replays back to back (what a single camera stream would see); measured
     # without and with the query's independent branches (selector levels, refiner feature branches) forked onto side streams

@@ -167,7 +167,7 @@ class DeviceChain:
                         self.query_batch(g_img, g_K)
                 torch.cuda.synchronize(d)
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, stream=stream):
+                with torch.cuda.graph(graph, stream=stream, capture_error_mode="thread_local"):
                     out = self.query_batch(g_img, g_K)
                 self._lanes.append((graph, stream, g_img, g_K, out, None))
             torch.cuda.synchronize(d)

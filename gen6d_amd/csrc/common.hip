@@ -1,6 +1,7 @@
 // Error bookkeeping and ABI version for libgen6d_hip.
 #include "g6d_common.h"
 #include <string.h>
+#include <stdint.h>
 #include <stdio.h>
 #include <atomic>
 #include <mutex>
@@ -90,11 +91,19 @@ extern "C" int g6d_marker(int id, g6d_stream_t stream) {
   return g6d_check_launch("g6d_marker");
 }
 
-// Stream-ordered zero fill of device memory (the per-query InstanceNorm statistics arena): a memset node in a captured graph
-// instead of a fill kernel.
+// Stream-ordered zero fill of device memory (the per-query InstanceNorm statistics arena, up to its high-water mark).  An own kernel, not
+// hipMemsetAsync: captured into a hipGraph, the runtime's memset NODE did not clear a 2-4 MB extent (batches of 16: the replayed rows
+// were garbage while the eager launches and the smaller graphs of the tests were right — profiles/r05_notes.md), a kernel node does.
+__global__ void g6d_zero_kernel(uint4* p, size_t n16, unsigned char* tail, int ntail) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) p[i] = uint4{0u, 0u, 0u, 0u};
+  if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0;
+}
 extern "C" int g6d_zero_bytes(void* ptr, size_t bytes, g6d_stream_t stream) {
-  if (!ptr && bytes) { g6d_set_error("zero_bytes: null pointer"); return G6D_EINVAL; }
+  if ((!ptr && bytes) || (reinterpret_cast<uintptr_t>(ptr) & 15)) { g6d_set_error("zero_bytes: null or unaligned pointer (16 bytes)"); return G6D_EINVAL; }
   if (bytes == 0) return G6D_OK;
-  if (hipMemsetAsync(ptr, 0, bytes, reinterpret_cast<hipStream_t>(stream)) != hipSuccess) { g6d_set_error("zero_bytes: hipMemsetAsync failed"); return G6D_ELAUNCH; }
-  return G6D_OK;
+  const size_t n16 = bytes / 16;
+  const size_t blocks = (n16 + 255) / 256;
+  hipLaunchKernelGGL(g6d_zero_kernel, dim3((unsigned)(blocks < 4096 ? (blocks ? blocks : 1) : 4096)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     reinterpret_cast<uint4*>(ptr), n16, reinterpret_cast<unsigned char*>(ptr) + n16 * 16, (int)(bytes - n16 * 16));
+  return g6d_check_launch("g6d_zero_bytes");
 }

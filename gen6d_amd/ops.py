@@ -354,9 +354,9 @@ def stats_arena_begin(device):
         _ARENA[key] = [torch.zeros(ARENA_DOUBLES, dtype=torch.float64, device=device), 0, 0]
     a = _ARENA[key]
     # only what has ever been handed out of this arena needs clearing (a[2] = its all-time high-water mark: everything behind it is
-    # still zero from the allocation); hipMemsetAsync through the C ABI — a memset node in a captured graph, not a fill kernel over
-    # 16 MB.  (A captured memset keeps the size it had at capture time: the lanes' streams, and with them their arenas, are private to
-    # their graphs, whose replays hand out the same slices every time.)
+    # still zero from the allocation): g6d_zero_bytes over a few MB instead of a fill over the arena's 16 MB.  (A captured launch keeps
+    # the size it had at capture time: the lanes' streams, and with them their arenas, are private to their graphs, whose replays
+    # hand out the same slices every time; capture() warms the arena up first.)
     if a[2]:
         _lib.check(_lib.load().g6d_zero_bytes(_ptr(a[0]), a[2] * 8, _stream()), "g6d_zero_bytes")
     a[1] = 0

@@ -357,7 +357,8 @@ int g6d_detector_decode(const float* scores, int ld_s, const float* offset, int 
  * Source index as ATen: scale = in / out, src = scale * (dst + 0.5) - 0.5 clamped at 0. */
 int g6d_resize_bilinear_pyramid(const float* src, int planes, int H, int W, int nscale, const int* hs, const int* ws,
                                 float* const* dsts, g6d_stream_t stream);
-/* (ABI v10) Stream-ordered zero fill of `bytes` bytes of device memory (hipMemsetAsync: a memset node in a captured graph). */
+/* (ABI v10) Stream-ordered zero fill of `bytes` bytes of device memory at a 16-byte aligned address (an own kernel: the runtime's memset node
+ * lost writes inside captured graphs). */
 int g6d_zero_bytes(void* ptr, size_t bytes, g6d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------

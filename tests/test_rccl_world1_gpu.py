@@ -85,3 +85,22 @@ def test_sharded_path_on_rccl_world1_eager_and_captured(tmp_path):
         record("test_sharded_path_on_rccl_world1_eager_and_captured", "captured graph rows vs golden rows (rel)", float(tail.split()[-1]), 1e-4)
     except Exception:
         pass
+
+
+def test_replica_bench_plumbing_on_rccl_world1():
+    """bench.py's query-replica mode with the process group forced at world size 1: barrier, MAX-reduce of the time, all-gather of the
+    result rows and the hipGraph capture (three lanes) all run next to RCCL and the process group's watchdog thread, as they will on N
+    GPUs; the gathered rows keep the reference's golden rows."""
+    import json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "3", "--warmup", "1", "--batch", "4",
+                          "--no-cpu-baseline", "--no-cached", "--no-chained", "--no-sweep", "--lowp", ""], env=env, capture_output=True, text=True,
+                         timeout=420)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["backend"] == "nccl" and d["ranks_seen"] == 1 and d["n_gpus"] == 1
+    pv = d["parity_vs_reference"]
+    assert pv["ref_idx_equal"] and pv["max_rel_diff_row"] <= 1e-4 and pv["rows_checked"] == 12, pv

@@ -11,6 +11,7 @@ import sys, json
 for line in sys.stdin:
     if line.startswith('{'):
         r = json.loads(line)
-        print('knobs [$k]: %.1f images/s, %.2f ms/step, single %.2f ms, wino %.2f ms/step (frac %.3f), conv %.2f ms/step' % (r['value'], r['ms_per_step'], r.get('single_query_ms') or 0, r['roofline']['ms_per_step'], r['roofline']['frac'], r['roofline_conv']['ms_per_step']))
+        pv = r.get('parity_vs_reference') or {}
+        print('knobs [$k]: %.1f images/s, %.2f ms/step, single %.2f ms, wino %.2f ms/step (frac %.3f), conv %.2f ms/step, parity %.1e argmax %s' % (r['value'], r['ms_per_step'], r.get('single_query_ms') or 0, r['roofline']['ms_per_step'], r['roofline']['frac'], r['roofline_conv']['ms_per_step'], pv.get('max_rel_diff_row', -1), pv.get('ref_idx_equal')))
 " || tail -3 /tmp/knob_err.log
 done

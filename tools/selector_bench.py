@@ -35,7 +35,7 @@ def main():
                     sel.compute_view_point_feats(crop)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=stream):
+            with torch.cuda.graph(graph, stream=stream, capture_error_mode="thread_local"):
                 out = sel.compute_view_point_feats(crop)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
