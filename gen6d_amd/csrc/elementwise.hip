@@ -452,6 +452,88 @@ __global__ void __launch_bounds__(GEMVB_THREADS, 2) linear_gemv_batch_kernel(con
   }
 }
 
+
+// ---- the same layer on the matrix cores (round 5): with 2..32 right-hand sides the 8-rows-x-K-slice kernel above is bound by its
+// vector-ALU work (512 FMAs + a 63-step butterfly per thread and group of 8 rows: 39 us for 16 right-hand sides against a 13 us weight
+// stream).  As a GEMM it is M = O weight rows, N = right-hand sides (padded to 32), K = 32768: v_mfma_f32_32x32x2_f32 consumes 64 weight
+// values per instruction — 7.8 us of matrix-pipe time for the 67 MB layer, so the stream from HBM is what is left.
+//   block  = 4 waves x (32 weight rows, K range KW): wave w of block (rg, ns) owns k in [(4 ns + w) KW, +KW) of rows 32 rg .. 32 rg + 31
+//   lane   = (i = lane & 31, h = lane >> 5): one 16-byte load of W[32 rg + i][k + 4h .. +3] (non-temporal: streamed once) and one of
+//            x[i][k + 4h .. +3] (L2; zeros for i >= B) feed FOUR MFMAs (MFMA s consumes k + s and k + 4 + s on both sides: the same
+//            permutation of K for both operands, as conv_igemm.hip); U = 8 such pairs are requested before the first is used
+//   finish = the four waves add their accumulators through LDS, the NS blocks of a row group meet through the workspace (partials written
+//            through, last block adds them in slice order: bit-equal from run to run), bias / activation, out[b][o] for b < B.
+#define GEMVM_KW 256
+template <int U>
+__global__ void __launch_bounds__(256, 2) linear_gemv_mfma_kernel(const float* __restrict__ x, int B, int K, const float* __restrict__ W,
+                                                                  const float* __restrict__ bias, int act, float* __restrict__ out, int O,
+                                                                  float* __restrict__ ws) {
+  __shared__ __attribute__((aligned(16))) float red[3][16][64];
+  __shared__ int flag;
+  const int rg = blockIdx.x, ns = blockIdx.y, NS = gridDim.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const size_t k0 = (size_t)(4 * ns + wave) * GEMVM_KW + 4 * h;
+  const float* wp = W + (size_t)(32 * rg + i) * K + k0;
+  const bool xv = i < B;
+  const float* xp = x + (size_t)(xv ? i : 0) * K + k0;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll 1
+  for (int k = 0; k < GEMVM_KW; k += 8 * U) {
+    f32x4 a[U], b[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) a[u] = *reinterpret_cast<const f32x4*>(wp + k + 8 * u);      // (plain: the four loads that share a 128-byte line of a row meet in L1)
+#pragma unroll
+    for (int u = 0; u < U; ++u) b[u] = xv ? *reinterpret_cast<const f32x4*>(xp + k + 8 * u) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][s_], b[u][s_], acc, 0, 0, 0);
+  }
+  // waves 1..3 -> LDS, wave 0 adds them in wave order
+  if (wave > 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave - 1][r][lane] = acc[r];
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int w = 0; w < 3; ++w)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] += red[w][r][lane];
+  }
+  if (NS > 1) {
+    float* slab = ws + G6D_WS_COUNTERS + (size_t)rg * NS * 1024;            // [slice][16 registers as 4 x 16 bytes][64 lanes]
+    if (wave == 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        g6d_store_wt(slab + (size_t)ns * 1024 + (q * 64 + lane) * 4, f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]});
+    }
+    if (!g6d_split_arrive(reinterpret_cast<int*>(ws) + rg, NS, &flag)) return;
+    if (wave == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      for (int z = 0; z < NS; ++z) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(slab + (size_t)z * 1024 + (q * 64 + lane) * 4);
+          acc[4 * q] += v[0]; acc[4 * q + 1] += v[1]; acc[4 * q + 2] += v[2]; acc[4 * q + 3] += v[3];
+        }
+      }
+    }
+  }
+  if (wave == 0 && i < B) {
+    // accumulator register r of lane (i, h): weight row (r & 3) + 8 (r >> 2) + 4 h of the group, right-hand side i
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = 32 * rg + (r & 3) + 8 * (r >> 2) + 4 * h;
+      out[(size_t)i * O + o] = apply_act(acc[r] + (bias ? bias[o] : 0.f), act);
+    }
+  }
+}
+
 inline int grid_for(long long total, int block) {
   long long g = (total + block - 1) / block;
   return (int)(g > 65535 * 16 ? 65535 * 16 : (g < 1 ? 1 : g));
@@ -589,20 +671,27 @@ extern "C" int g6d_linear_gemv_batch(const float* x, int B, int K, const float* 
   constexpr int KL = GEMVB_THREADS * 4 * 2;                 // KV = 2: K slices of 2048 floats
   const bool rows_ok = O % GEMVB_R == 0 && K % KL == 0 && O / GEMVB_R <= G6D_WS_COUNTERS;
   const int KS = rows_ok ? K / KL : 0;
-  // up to 32 right-hand sides per launch = ONE pass over the weights (round 5; round 4: one pass per 8): the block holds its weight
-  // values in registers and runs 1, 2 or 4 groups of 8 rows of x past them.  A single right-hand side, short rows or a missing workspace
-  // take the row-per-block kernel.
-  for (int b0 = 0; b0 < B; b0 += 32) {
-    const int nb = B - b0 < 32 ? B - b0 : 32;
-    const int nh = nb <= 8 ? 1 : (nb <= 16 ? 2 : 4);
+  // Measured (profiles/r05_gemv.md, 67 MB layer): vector-ALU kernel 22 us for <= 8 right-hand sides, 37 us for 16 (two groups per block),
+  // 430 us for 32 (four groups: spills); matrix-core kernel 35-40 us for ANY count up to 32 (its 32-byte pieces of 32 weight rows per
+  // load reach 1.9 TB/s; FC as a 1x1 conv on conv_igemm: 40-45 us).  So: groups of <= 16 on the vector-ALU kernel, 17..32 on the matrix
+  // cores.  Knob gemv_mfma: 1 = that rule, 2 = matrix cores whenever eligible (tests), 0 = never (groups of <= 16).
+  const int mf = (int)g6d_knob(G6D_KNOB_GEMV_MFMA);
+  const int NSm = K / (4 * GEMVM_KW);
+  const bool mfma_ok = mf != 0 && O % 32 == 0 && K % (4 * GEMVM_KW) == 0 && O / 32 <= G6D_WS_COUNTERS && workspace && g6d_aligned16(workspace) &&
+                       workspace_bytes >= G6D_WS_COUNTER_BYTES + (size_t)(O / 32) * NSm * 1024 * sizeof(float);
+  const int gmax = (mfma_ok && (mf == 2 || B > 16)) ? 32 : 16;
+  for (int b0 = 0; b0 < B; b0 += gmax) {
+    const int nb = B - b0 < gmax ? B - b0 : gmax;
+    const int nh = nb <= 8 ? 1 : 2;
     const size_t need = G6D_WS_COUNTER_BYTES + (size_t)(O / GEMVB_R) * nh * (KS > 0 ? KS : 1) * GEMVB_R * 8 * sizeof(float);
     const float* xg = x + (size_t)b0 * K;
     float* og = out + (size_t)b0 * O;
-    if (nb >= 2 && rows_ok && KS >= 2 && workspace && workspace_bytes >= need && g6d_aligned16(workspace)) {
+    if (mfma_ok && nb >= 2 && (mf == 2 || nb > 16)) {
+      hipLaunchKernelGGL((linear_gemv_mfma_kernel<8>), dim3(O / 32, NSm), dim3(256), 0, STREAM(stream), xg, nb, K, W, bias, act, og, O, workspace);
+    } else if (nb >= 2 && rows_ok && KS >= 2 && workspace && workspace_bytes >= need && g6d_aligned16(workspace)) {
       const dim3 grid(O / GEMVB_R, KS);
       if (nh == 1) hipLaunchKernelGGL((linear_gemv_batch_kernel<2, 1>), grid, dim3(GEMVB_THREADS), 0, STREAM(stream), xg, nb, K, W, bias, act, og, O, workspace);
-      else if (nh == 2) hipLaunchKernelGGL((linear_gemv_batch_kernel<2, 2>), grid, dim3(GEMVB_THREADS), 0, STREAM(stream), xg, nb, K, W, bias, act, og, O, workspace);
-      else hipLaunchKernelGGL((linear_gemv_batch_kernel<2, 4>), grid, dim3(GEMVB_THREADS), 0, STREAM(stream), xg, nb, K, W, bias, act, og, O, workspace);
+      else hipLaunchKernelGGL((linear_gemv_batch_kernel<2, 2>), grid, dim3(GEMVB_THREADS), 0, STREAM(stream), xg, nb, K, W, bias, act, og, O, workspace);
     } else if (nb > 8) {                     // (fallback kernels take <= 8 rows per launch)
       for (int c0 = 0; c0 < nb; c0 += 8) {
         const int nc = nb - c0 < 8 ? nb - c0 : 8;

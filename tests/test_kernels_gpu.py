@@ -506,7 +506,9 @@ def test_selector_tail_ops(ops):
                                        # round 5: up to 32 right-hand sides per weight pass (2 / 4 groups of 8 in one block): the bench's 16,
                                        # ragged 20 = 8 + 8 + 4, two launches for 40 = 32 + 8, 19 rows on the fall-back kernels
                                        (16, 32768, 512, 2), (20, 8192, 64, 1), (40, 8192, 64, 0), (19, 8192, 20, 0)])
-def test_linear_gemv(ops, B, K, O, act):
+@pytest.mark.parametrize("mfma", [2, 1, 0], ids=["matrix-cores", "product-rule", "vector-alu"])   # knob gemv_mfma (round 5): 2..32 right-hand sides as a GEMM
+def test_linear_gemv(ops, B, K, O, act, mfma, knob):
+    knob("gemv_mfma", mfma)
     g = torch.Generator().manual_seed(12)
     x, W, b = _rand(g, B, K), _rand(g, O, K, scale=K ** -0.5), _rand(g, O, scale=0.1)
     out = ops.linear_gemv(x.cuda(), W.cuda(), b.cuda(), act)
