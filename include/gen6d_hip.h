@@ -440,10 +440,12 @@ int g6d_warp_batch(const unsigned char* stack, const unsigned char* single, cons
 int g6d_linear_gemv(const float* x, int B, int K, const float* W, const float* bias, int O, int act, float* out,
                     g6d_stream_t stream);
 
-/* (ABI v9) The same layer for ANY number of right-hand sides (network/refiner.py:249-269 takes [qn, ...] queries): groups of up to 8 rows of
- * x per weight pass; groups of >= 2 with O % 8 == 0 and K % 2048 == 0 run 8 output rows x one 2048-float K slice per block (x read once
- * per 8 rows, partial sums joined in slice order through `workspace`: G6D_WORKSPACE_COUNTER_BYTES of counters, zero at rest, then
- * O * K / 2048 * 8 floats), anything else the row-per-block kernel of g6d_linear_gemv. */
+/* (ABI v9) The same layer for ANY number of right-hand sides (network/refiner.py:249-269 takes [qn, ...] queries).  Since v10 ONE pass over
+ * the weights serves up to 32 rows of x: groups of 2..16 with O % 8 == 0 and K % 2048 == 0 run 8 output rows x one 2048-float K slice per
+ * block with one or two groups of 8 rows of x against the block's weight values; groups of 17..32 with O % 32 == 0 and K % 1024 == 0 run
+ * as a GEMM on the matrix cores (32 weight rows x 256 k per wave).  Partial sums are joined in slice order through `workspace`
+ * (G6D_WORKSPACE_COUNTER_BYTES of counters, zero at rest, then <= O * K / 256 floats); anything else takes the row-per-block kernel of
+ * g6d_linear_gemv. */
 int g6d_linear_gemv_batch(const float* x, int B, int K, const float* W, const float* bias, int O, int act, float* out, float* workspace,
                           size_t workspace_bytes, g6d_stream_t stream);
 

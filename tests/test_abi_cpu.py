@@ -116,3 +116,10 @@ def test_integration_doc_covers_every_entry_point():
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     missing = [n for n in _declared() if f"`{n}`" not in doc]
     assert not missing, f"INTEGRATION.md does not mention: {missing}"
+
+
+def test_graft_entry_build_runs_here():
+    """The driver's "does it build" check: __graft_entry__.build() compiles (make is up to date in a built tree), loads the library and
+    agrees with it on the ABI version (round 5 bumped the library to v10 while build() still asserted 9: caught by running it)."""
+    import __graft_entry__ as g
+    g.build()
