@@ -284,6 +284,62 @@ __global__ void __launch_bounds__(64) attention_kernel(const float* __restrict__
   }
 }
 
+
+// The same attention with one 256-thread block per (query of the batch, head) for n <= 64 tokens and dh <= 64 (the selector: 64
+// references, 8 heads of 64): Q, K, V of the head are gathered into LDS ONCE (the wave-per-token kernel above re-reads K and V for each
+// of the n tokens with 32-byte strides: 114 us per launch at 16 queries, 0.35 % of a step), scores / softmax / P V run out of LDS.
+//   thread (i = tid >> 2, c = tid & 3): token i, score columns / output channels c, c + 4, ... (16 each)
+#define ATT_N 64
+#define ATT_LD (ATT_N + 1)
+__global__ void __launch_bounds__(256) attention_block_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                              const float* __restrict__ v, int ld, int n, int dh, int heads,
+                                                              float* __restrict__ out, int ld_out) {
+  __shared__ float Q[ATT_N][ATT_LD], K[ATT_N][ATT_LD], V[ATT_N][ATT_LD], P[ATT_N][ATT_LD];
+  const int h = blockIdx.x, tid = threadIdx.x;
+  const size_t base = (size_t)blockIdx.y * n * ld;
+  for (int e = tid; e < ATT_N * ATT_N; e += 256) {
+    const int j = e / ATT_N, d = e - j * ATT_N;
+    const bool ok = j < n && d < dh;
+    const size_t o = base + (size_t)j * ld + d * heads + h;
+    Q[j][d] = ok ? q[o] : 0.f; K[j][d] = ok ? k[o] : 0.f; V[j][d] = ok ? v[o] : 0.f;
+  }
+  __syncthreads();
+  const int i = tid >> 2, c = tid & 3;
+  const float inv = 1.f / sqrtf((float)dh);
+  float sc[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) sc[t] = 0.f;
+  for (int d = 0; d < dh; ++d) {
+    const float qv = Q[i][d];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) sc[t] += qv * K[c + 4 * t][d];
+  }
+  float mx = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < 16; ++t) { sc[t] = c + 4 * t < n ? sc[t] * inv : -INFINITY; mx = fmaxf(mx, sc[t]); }
+  mx = fmaxf(mx, __shfl_xor(mx, 1, 64)); mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int t = 0; t < 16; ++t) { const float e = c + 4 * t < n ? expf(sc[t] - mx) : 0.f; P[i][c + 4 * t] = e; sum += e; }
+  sum += __shfl_xor(sum, 1, 64); sum += __shfl_xor(sum, 2, 64);
+  __syncthreads();
+  float ov[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) ov[t] = 0.f;
+  for (int j = 0; j < n; ++j) {
+    const float pv = P[i][j];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) ov[t] += pv * V[j][c + 4 * t];
+  }
+  if (i < n) {
+    const float rsum = 1.f / sum;
+    float* o = out + ((size_t)blockIdx.y * n + i) * ld_out + h;
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+      if (c + 4 * t < dh) o[(c + 4 * t) * heads] = ov[t] * rsum;
+  }
+}
+
 // Weight-streaming GEMV: one block of 512 threads per output row, B <= 8 right-hand sides.  HBM-bound (the refiner's
 // first FC layer reads 67 MB of weights for 33 MFLOP): every thread keeps four independent 16-byte weight loads in
 // flight so that two resident blocks per CU cover the HBM latency-bandwidth product (~64 KB per CU).
@@ -643,7 +699,10 @@ extern "C" int g6d_attention(const float* q, const float* k, const float* v, int
   if (!q || !k || !v || !out || n <= 0 || heads <= 0 || C % heads || batch < 1 || batch > 65535) { g6d_set_error("attention: bad args"); return G6D_EINVAL; }
   size_t lds = (size_t)(C / heads + n) * sizeof(float);
   if (lds > 60000) { g6d_set_error("attention: n too large"); return G6D_EINVAL; }
-  hipLaunchKernelGGL(attention_kernel, dim3(n * heads, batch), dim3(64), lds, STREAM(stream), q, k, v, ld, n, C, heads, out, ld_out);
+  if (n <= ATT_N && C / heads <= ATT_N)
+    hipLaunchKernelGGL(attention_block_kernel, dim3(heads, batch), dim3(256), 0, STREAM(stream), q, k, v, ld, n, C / heads, heads, out, ld_out);
+  else
+    hipLaunchKernelGGL(attention_kernel, dim3(n * heads, batch), dim3(64), lds, STREAM(stream), q, k, v, ld, n, C, heads, out, ld_out);
   return g6d_check_launch("attention");
 }
 

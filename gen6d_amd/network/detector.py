@@ -78,7 +78,15 @@ class Detector(ParamBank):
             l0 = [self.conv_w(f"{h}.0") for h in heads]
             pk["h0"] = (torch.cat([w for w, _ in l0], 0).contiguous(), torch.cat([b for _, b in l0], 0).contiguous())
             pk["h1"] = [self.conv_w(f"{h}.2") for h in heads]
-            pk["h2"] = [self.conv_w(f"{h}.4") for h in heads]
+            # the three heads' last convs (1 + 1 + 2 output channels on their own 64-channel inputs) as ONE conv 192 -> 4 with
+            # block-diagonal weights: the zero blocks add exact zeros, one launch instead of three latency-bound ones
+            l2 = [self.conv_w(f"{h}.4") for h in heads]
+            w4 = torch.zeros((sum(w.shape[0] for w, _ in l2), 9, 192), dtype=torch.float32, device=l2[0][0].device)
+            row = 0
+            for i, (w, _) in enumerate(l2):
+                w4[row:row + w.shape[0], :, 64 * i:64 * i + 64] = w
+                row += w.shape[0]
+            pk["h2"] = (w4.contiguous(), torch.cat([b for _, b in l2], 0).contiguous())
             self._packed = pk
         return self._packed
 
@@ -211,14 +219,10 @@ class Detector(ParamBank):
         ops.conv(feats.view(qn, 1, hs, ws, 64), pk["h0"][0], pk["h0"][1], a, ksize=k3, pad=p3, out_act=1)
         b = torch.empty_like(a)
         o4 = torch.empty((qn, 1, hs, ws, 4), dtype=torch.float32, device=dev)
-        col = 0
         for i in range(3):
             w1, b1 = pk["h1"][i]
             ops.conv(a[..., 64 * i:64 * i + 64], w1, b1, b[..., 64 * i:64 * i + 64], ksize=k3, pad=p3, out_act=1)
-            w2, b2 = pk["h2"][i]
-            co = w2.shape[0]
-            ops.conv(b[..., 64 * i:64 * i + 64], w2, b2, o4[..., col:col + co], ksize=k3, pad=p3)
-            col += co
+        ops.conv(b, pk["h2"][0], pk["h2"][1], o4, ksize=k3, pad=p3)            # score | scale | offset x, y
         o4 = o4.view(qn * P, 4)                                                # score, scale, offset x, offset y
         res = ops.detector_decode(o4[:, 0:1], o4[:, 2:4], o4[:, 1:2], hs, ws, self.pool_ratio, batch=qn)
         return o4.view(qn, hs, ws, 4), res.view(qn, 5), (hs, ws)

@@ -444,7 +444,7 @@ int g6d_linear_gemv(const float* x, int B, int K, const float* W, const float* b
  * the weights serves up to 32 rows of x: groups of 2..16 with O % 8 == 0 and K % 2048 == 0 run 8 output rows x one 2048-float K slice per
  * block with one or two groups of 8 rows of x against the block's weight values; groups of 17..32 with O % 32 == 0 and K % 1024 == 0 run
  * as a GEMM on the matrix cores (32 weight rows x 256 k per wave).  Partial sums are joined in slice order through `workspace`
- * (G6D_WORKSPACE_COUNTER_BYTES of counters, zero at rest, then <= O * K / 256 floats); anything else takes the row-per-block kernel of
+ * (G6D_WORKSPACE_COUNTER_BYTES of counters, zero at rest, then <= O * K / 32 floats); anything else takes the row-per-block kernel of
  * g6d_linear_gemv. */
 int g6d_linear_gemv_batch(const float* x, int B, int K, const float* W, const float* bias, int O, int act, float* out, float* workspace,
                           size_t workspace_bytes, g6d_stream_t stream);

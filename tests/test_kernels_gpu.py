@@ -838,3 +838,17 @@ def test_resize_bilinear_pyramid(ops, N, H, W):
         ref = torch.nn.functional.interpolate(x.double(), size=tuple(sz), mode="bilinear")
         _check(o, ref, 1e-4, f"pyramid {sz} vs fp64")
         _check(o, torch.nn.functional.interpolate(xg, size=tuple(sz), mode="bilinear").cpu(), 2e-6, f"pyramid {sz} vs ATen on the device")
+
+
+@pytest.mark.parametrize("n,heads,C,B", [(64, 8, 512, 5), (37, 8, 512, 2), (100, 8, 512, 2), (20, 4, 512, 1), (64, 8, 256, 3)])
+def test_attention_kernels(ops, n, heads, C, B):
+    """AttentionBlock's attention (reference network/attention.py:4-17, head split c -> (d = c // heads, head = c % heads)) on both
+    kernels: one block per (query, head) with Q / K / V of the head in LDS for n <= 64 tokens and head width <= 64 (round 5), one wave
+    per (head, token) otherwise (n = 100; 4 heads of 128)."""
+    g = torch.Generator().manual_seed(77 + n)
+    qkv = _rand(g, B * n, 3 * C, scale=1.5).cuda()
+    out = torch.empty((B * n, C), device="cuda"); ref = torch.empty((B * n, C), dtype=torch.float64)
+    ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], heads, out, batch=B)
+    d = _d(qkv)
+    ref_ops.attention(d[:, :C], d[:, C:2 * C], d[:, 2 * C:], heads, ref, batch=B)
+    _check(out, ref, 1e-5, "attention")
