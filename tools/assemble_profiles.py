@@ -37,7 +37,7 @@ def main():
     steps = ser["steps"]
     open(os.path.join(P, f"{RND}_bench_kernel_stats.md"), "w").write(
         f"# rocprofv3 --kernel-trace --stats of `python bench.py --steps {steps} --warmup 2 --no-cpu-baseline --no-cached --lowp ''` (1x MI355X)\n\n"
-        f"Default launch mode ({fin['config']['launch']}): a step = one batch of {fin.get('batch', 1)} queries.  Where the two batches in\n"
+        f"Default launch mode ({fin['config']['launch']}): a step = one batch of {fin.get('batch', 1)} queries.  Where the batches in\n"
         "flight overlap, per-kernel durations are inflated by sharing the chip (sum of durations > wall time of the region); the\n"
         "serialised run next to this file is the one to compare with the roofline.\n"
         "Produced by tools/profile_round.sh + tools/rocpd_stats.py from the rocpd database, cut to the timed region by the two\n"
@@ -74,18 +74,18 @@ def main():
     traffic = json.load(open(os.path.join(G, "pmc_conv_traffic.json")))
     open(os.path.join(P, f"{RND}_pmc_hbm.md"), "w").write(
         "# HBM traffic counters (rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes, no other trace domains)\n\n"
-        "`python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-cached --lowp '' --no-graph`, dispatches inside the timed region (2 steps = 2 batches of 8 queries). Unit: KB.\n"
+        "`python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-cached --lowp '' --no-graph`, dispatches inside the timed region (2 steps = 2 batches of the default size, 16 queries since round 4). Unit: KB.\n"
         "gfx950 note (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports half the bytes of a wide coalesced stream — double it before comparing.\n\n"
         "Checks against algorithmic bytes (per dispatch, tables below):\n"
-        "* `selector_levels_kernel` (score maps + product statistics of the three levels for the 8 queries of a batch, one launch): FETCH x2 vs\n"
+        "* `selector_levels_kernel` (score maps + product statistics of the three levels for 8 queries per launch: two launches per batch of 16): FETCH x2 vs\n"
         "  algorithmic 168 + 42 + 10.5 = 220.5 MB of reference cache, read ONCE per batch (+ 8 x 3.3 MB of fp64 R1/R2 sums, 8 x 0.7 MB of query rows).\n"
-        "* `refiner_volume_kernel`: WRITE vs algorithmic 8 x 50.3 MB per launch (mean|query 33.5 MB + std 16.8 MB per query).\n"
+        "* `refiner_volume_kernel`: WRITE vs algorithmic (queries per launch) x 50.3 MB (mean|query 33.5 MB + std 16.8 MB per query).\n"
         f"* conv family (tools/pmc_conv_traffic.py -> {RND}_pmc_conv_traffic.json): {traffic['hbm_bytes_per_launch'] / 1e6:.1f} MB HBM-side per launch; "
         f"Winograd family: {traffic.get('winograd_family', {}).get('hbm_bytes_per_launch', 0) / 1e6:.1f} MB per launch — both far from HBM-bound.\n\n"
         "## FETCH_SIZE\n" + rd("pmc_fetch.md") + "\n## WRITE_SIZE\n" + rd("pmc_write.md"))
     open(os.path.join(P, f"{RND}_pmc_mfma.md"), "w").write(
         "# MFMA-busy counter (rocprofv3 --kernel-trace --pmc MfmaUtil, own pass)\n\n"
-        "`python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-cached --lowp '' --no-graph --serial` (batches of 8 queries); `MfmaUtil` is rocprofv3's derived metric\n"
+        "`python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-cached --lowp '' --no-graph --serial` (default batches); `MfmaUtil` is rocprofv3's derived metric\n"
         "`sum(SQ_VALU_MFMA_BUSY_CYCLES) / (max(GRBM_GUI_ACTIVE) * SIMD_NUM) * 100` per dispatch, i.e. chip-wide: a launch whose grid\n"
         "fills half the CUs cannot exceed 50.  `per dispatch` is the plain mean over the kernel's dispatches inside the timed region\n"
         "(small and large layers of one instantiation mixed), the last column weights every dispatch with its duration.\n"
@@ -97,7 +97,8 @@ def main():
                      ("layer_table_fp16.md", "layer_table_fp16.md"),
                      ("batch_sweep_all.txt", "batch_sweep.txt"), ("prof_b1_serial_stats.md", "kernel_stats_single_query.md"),
                      ("bench_gpus2.json", "bench_gpus2.json"), ("bench_gpus2_shard.json", "bench_gpus2_shard_refs.json"),
-                     ("bench_chained.json", "bench_chained.json")):
+                     ("bench_chained.json", "bench_chained.json"), ("bench_shard_rccl_world1.json", "bench_shard_refs_rccl_world1.json"),
+                     ("bench_force_dist.json", "bench_force_dist_rccl_world1.json")):
         if os.path.exists(os.path.join(G, src)):
             shutil.copy(os.path.join(G, src), os.path.join(P, f"{RND}_{dst}"))
     if os.path.exists(os.path.join(G, "convbench_direct.log")):

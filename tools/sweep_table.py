@@ -8,9 +8,9 @@ import sys
 def main():
     d = json.loads([l for l in open(sys.argv[1]) if l.startswith('{"metric')][-1])
     sw = d["sweep"]
-    lines = ["# Reference-view sweep on round-4 code (1x MI355X, fp32, `python bench.py`: the `sweep` object of the default line)", "",
+    lines = ["# Reference-view sweep (1x MI355X, fp32, `python bench.py`: the `sweep` object of the default line)", "",
              f"Full pipeline = detector 480x640 vs 32 refs (4 scales) + selector 128x128 crop vs N refs x 5 rotations + 3 refiner steps; batches of "
-             f"{d['batch']} queries per launch, 2 batches in flight (hipGraph replay), synthetic weights.  `64 x 36` = BASELINE configs[1], the selector alone",
+             f"{d['batch']} queries per launch, {d['config']['launch'].split('), ')[-1]} (hipGraph replay), synthetic weights.  `64 x 36` = BASELINE configs[1], the selector alone",
              "(one captured graph, one batch at a time).  Winograd fraction = FLOPs executed in the Winograd domain / HIP-event time of the family's",
              "launches in a serialised eager pass / 157.3 TFLOP/s.  Parity = selector logits against the reference's own module (tests/golden).", "",
              "| selector refs x rotations | workload | throughput | ms per batch | Winograd family TFLOP/s executed (fraction of fp32 MFMA peak) | all MFMA-family launches | logits vs reference (bar 1e-4) |",
