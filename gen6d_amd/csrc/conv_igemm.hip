@@ -54,7 +54,7 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const G6dConv p, con
                                                          const int nChunks, const int itersPerSplit,
                                                          const int totalIters, const int splits, const unsigned in_bytes,
                                                          const unsigned w_bytes, const unsigned mul_bytes, const int pm_hw,
-                                                         const int pm_tiles) {
+                                                         const int pm_tiles, const int pm_ny_count) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int WM = BM / WGM, WN = BN / WGN;
   constexpr int MT = WM / 32, NT = WN / 32;
@@ -72,16 +72,21 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const G6dConv p, con
   // (pm_hw = Ho*Wo > 0: small 2-D maps, stride 1, many images — the selector's 4x4 / 8x8 stacks over 2560 hypothesis images): a tile is
   // ONE output position (oy, ox) of BM consecutive images, so the taps that fall into the zero padding are the same for every row
   // of the tile and the K loop simply skips them — a 3x3 "same" conv on a 4x4 map has 100 live (position, tap) pairs of 144 (1.44x
-  // fewer K steps), on an 8x8 map 484 of 576.  Block id -> (image tile, position): hardware hands consecutive ids to the 8 XCDs in
-  // turn, so within a group of 8 image tiles the id runs (tile-in-group fastest, then position): XCD k gets ALL positions of image
-  // tile 8g + k back to back, and the up-to-9 position tiles that read the same input rows meet in that XCD's L2.
-  int pm_pos = 0, pm_tile = blockIdx.x;
+  // fewer K steps), on an 8x8 map 484 of 576.  Block id (1-D grid) -> (image tile, channel tile, position): hardware hands consecutive
+  // ids to the 8 XCDs in turn, so within a group of 8 image tiles the id runs (tile-in-group fastest, then channel tile, then position):
+  // XCD k gets ALL channel tiles and positions of image tile 8g + k back to back — its 64 resident blocks are 16 positions x 4 channel
+  // tiles of ONE image tile, whose 2 MB of input rows (each read by up to 9 positions x 4 channel tiles) stay in that XCD's 4 MB L2.
+  // (First version: channel tiles in gridDim.y, i.e. four image tiles x 16 positions resident per XCD = 8 MB of input: the family's
+  // HBM-side traffic went from 171 to 262 MB per launch, profiles/r05_pmc_conv_traffic.json.)
+  int pm_pos = 0, pm_tile = blockIdx.x, pm_ny = blockIdx.y;
   if (pm_hw > 0) {
-    const int per = 8 * pm_hw, g = blockIdx.x / per, r = blockIdx.x - g * per;
+    const int per = 8 * pm_ny_count * pm_hw, g = blockIdx.x / per, r = blockIdx.x - g * per;
     const int m8 = min(8, pm_tiles - 8 * g);
-    pm_pos = r / m8; pm_tile = 8 * g + (r - pm_pos * m8);
+    const int r2 = r / m8;
+    pm_tile = 8 * g + (r - r2 * m8);
+    pm_pos = r2 / pm_ny_count; pm_ny = r2 - pm_pos * pm_ny_count;
   }
-  const int m0 = pm_tile * BM, n0 = blockIdx.y * BN;            // (position-major: first IMAGE of the tile)
+  const int m0 = pm_tile * BM, n0 = pm_ny * BN;                 // (position-major: first IMAGE of the tile)
   auto row_m = [&](int r) { return pm_hw > 0 ? (m0 + r) * pm_hw + pm_pos : m0 + r; };      // tile row -> output position index m
   int ky0 = 0, ky1 = p.kh - 1, kx0 = 0, kx1 = p.kw - 1;        // live taps of the tile (position-major: the padding taps are cut)
   if (pm_hw > 0) {
@@ -482,7 +487,8 @@ int launch_mm(const G6dConv& d, int M, int T, int nChunks, int splits, hipStream
   splits = (total + ips - 1) / ips;
   const bool pm = igemm_position_major(d, BM, splits);
   const int pm_hw = pm ? d.Ho * d.Wo : 0, pm_tiles = pm ? (d.N + BM - 1) / BM : 0;
-  dim3 grid(pm ? pm_hw * pm_tiles : (M + BM - 1) / BM, (d.Cout + BN - 1) / BN, splits);
+  const int ny = (d.Cout + BN - 1) / BN;
+  dim3 grid(pm ? pm_hw * pm_tiles * ny : (M + BM - 1) / BM, pm ? 1 : ny, splits);
   const size_t lds_bytes = 2 * (size_t)(BM + BN) * LDS_K * sizeof(float);
   g6d_allow_lds(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WGM, WGN, MODE, MM>), (int)lds_bytes);
   // extents of the buffer-load descriptors (the activation and multiplier descriptors start `pad` elements in front of the tensor)
@@ -493,7 +499,7 @@ int launch_mm(const G6dConv& d, int M, int T, int nChunks, int splits, hipStream
   const unsigned w_bytes = (unsigned)((long long)d.Cout * T * d.Cin * 4);
   const unsigned mul_bytes = (unsigned)((n_mul * d.Hi * d.Wi * d.Cin + pad_m) * 4);
   hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WGM, WGN, MODE, MM>), grid, dim3(256), lds_bytes, stream, d, M, T, nChunks,
-                     ips, total, splits, in_bytes, w_bytes, mul_bytes, pm_hw, pm_tiles);
+                     ips, total, splits, in_bytes, w_bytes, mul_bytes, pm_hw, pm_tiles, ny);
   return g6d_check_launch("conv_igemm");
 }
 
