@@ -130,26 +130,63 @@ __global__ void __launch_bounds__(256) decode_kernel(const float* __restrict__ s
 // clamped to the last row / column.  A scale of the source's own size is not a destination: the caller passes the image itself on.
 struct PyrArgs { const float* src; int planes, H, W, n; int h[4], w[4]; long long first[5]; float* dst[4]; };
 
+// VEC = 4: a thread produces four consecutive outputs of a row (all widths % 4 == 0, destinations 16-byte aligned) and stores them as one
+// 16-byte piece; first[] then counts pieces.  (The first version — one output per thread, 64-bit index arithmetic — took 176 us per batch
+// of 16 queries against 115 us for the three ATen launches it replaced.)
+#define PYR_PL 4                           // image planes per work item
+template <int VEC>
 __global__ void resize_pyramid_kernel(const PyrArgs a) {
-  const long long total = a.first[a.n];
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+  // a work item = VEC consecutive outputs of one row of one destination for PYR_PL consecutive image planes: source columns / weights are
+  // formed once (the index arithmetic — three runtime divisions — is amortised over 16 outputs) and all 16 x PYR_PL loads are requested
+  // before the first value is used.  (One output per thread: 176 us per batch of 16 queries; one item walking all 48 planes: 186 us — too
+  // few threads; this version 148 us; ATen's three launches: 115 us — 0.05 % of a step apart.)
+  const unsigned total = (unsigned)a.first[a.n];
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     int k = 0;
 #pragma unroll
-    for (int j = 1; j < 4; ++j) k = (j < a.n && i >= a.first[j]) ? j : k;
-    const long long l = i - a.first[k];
-    const int h = a.h[k], w = a.w[k];
-    const int x = (int)(l % w); const long long t = l / w;
-    const int y = (int)(t % h), pl = (int)(t / h);
+    for (int j = 1; j < 4; ++j) k = (j < a.n && i >= (unsigned)a.first[j]) ? j : k;
+    const unsigned l = i - (unsigned)a.first[k];
+    const int h = a.h[k], w = a.w[k], wv = w / VEC;
+    const int xq = (int)(l % (unsigned)wv); const unsigned t = l / (unsigned)wv;
+    const int y = (int)(t % (unsigned)h), pg = (int)(t / (unsigned)h);
     const float ry = (float)a.H / (float)h, rx = (float)a.W / (float)w;
     float sy = ry * (y + 0.5f) - 0.5f; if (sy < 0.f) sy = 0.f;
-    float sx = rx * (x + 0.5f) - 0.5f; if (sx < 0.f) sx = 0.f;
-    const int y0 = min((int)sy, a.H - 1), x0 = min((int)sx, a.W - 1);
-    const int y1 = y0 + (y0 < a.H - 1), x1 = x0 + (x0 < a.W - 1);
-    const float ly = sy - y0, lx = sx - x0, hy = 1.f - ly, hx = 1.f - lx;
-    const float* b = a.src + (size_t)pl * a.H * a.W;
-    const float v = hy * (hx * b[(size_t)y0 * a.W + x0] + lx * b[(size_t)y0 * a.W + x1]) +
-                    ly * (hx * b[(size_t)y1 * a.W + x0] + lx * b[(size_t)y1 * a.W + x1]);
-    a.dst[k][l] = v;
+    const int y0 = min((int)sy, a.H - 1);
+    const int y1 = y0 + (y0 < a.H - 1);
+    const float ly = sy - y0, hy = 1.f - ly;
+    int x0[VEC], x1[VEC]; float lx[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const int x = xq * VEC + e;
+      float sx = rx * (x + 0.5f) - 0.5f; if (sx < 0.f) sx = 0.f;
+      x0[e] = min((int)sx, a.W - 1);
+      x1[e] = x0[e] + (x0[e] < a.W - 1);
+      lx[e] = sx - x0[e];
+    }
+    const size_t sstride = (size_t)a.H * a.W, dstride = (size_t)h * w;
+    const int pl0 = pg * PYR_PL;
+    const float* r0 = a.src + (size_t)pl0 * sstride + (size_t)y0 * a.W;
+    const float* r1 = a.src + (size_t)pl0 * sstride + (size_t)y1 * a.W;
+    float t00[PYR_PL][VEC], t01[PYR_PL][VEC], t10[PYR_PL][VEC], t11[PYR_PL][VEC];
+#pragma unroll
+    for (int p_ = 0; p_ < PYR_PL; ++p_) {
+      const size_t o = (size_t)min(p_, a.planes - 1 - pl0) * sstride;          // (planes beyond the last repeat it; not stored)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) { t00[p_][e] = r0[o + x0[e]]; t01[p_][e] = r0[o + x1[e]]; t10[p_][e] = r1[o + x0[e]]; t11[p_][e] = r1[o + x1[e]]; }
+    }
+    float* d = a.dst[k] + (size_t)pl0 * dstride + (size_t)y * w + xq * VEC;
+#pragma unroll
+    for (int p_ = 0; p_ < PYR_PL; ++p_) {
+      if (pl0 + p_ >= a.planes) break;
+      float v[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const float hx = 1.f - lx[e];
+        v[e] = hy * (hx * t00[p_][e] + lx[e] * t01[p_][e]) + ly * (hx * t10[p_][e] + lx[e] * t11[p_][e]);
+      }
+      if constexpr (VEC == 4) *reinterpret_cast<f32x4*>(d + p_ * dstride) = f32x4{v[0], v[1], v[2], v[3]};
+      else d[p_ * dstride] = v[0];
+    }
   }
 }
 }  // namespace
@@ -197,14 +234,20 @@ extern "C" int g6d_resize_bilinear_pyramid(const float* src, int planes, int H, 
   }
   PyrArgs a = {};
   a.src = src; a.planes = planes; a.H = H; a.W = W; a.n = nscale;
-  long long tot = 0;
-  for (int k = 0; k < nscale; ++k) {
+  bool vec = true;
+  for (int k = 0; k < nscale; ++k)
     if (hs[k] <= 0 || ws[k] <= 0 || !dsts[k]) { g6d_set_error("resize_bilinear_pyramid: bad destination"); return G6D_EINVAL; }
+    else vec = vec && (ws[k] & 3) == 0 && g6d_aligned16(dsts[k]);
+  long long tot = 0;                      // work items: PYR_PL planes x (4 outputs of a row when every width allows it, else one)
+  for (int k = 0; k < nscale; ++k) {
     a.h[k] = hs[k]; a.w[k] = ws[k]; a.dst[k] = dsts[k]; a.first[k] = tot;
-    tot += (long long)planes * hs[k] * ws[k];
+    tot += (long long)((planes + PYR_PL - 1) / PYR_PL) * hs[k] * (vec ? ws[k] / 4 : ws[k]);
   }
   for (int k = nscale; k < 5; ++k) a.first[k] = tot;
+  if (tot >= (1ll << 32)) { g6d_set_error("resize_bilinear_pyramid: more than 2^32 work items"); return G6D_EINVAL; }
   const long long blocks = (tot + 255) / 256;
-  hipLaunchKernelGGL(resize_pyramid_kernel, dim3((unsigned)(blocks < 65536 * 8 ? blocks : 65536 * 8)), dim3(256), 0, STREAM(stream), a);
+  const dim3 grid((unsigned)(blocks < 65536 * 8 ? blocks : 65536 * 8));
+  if (vec) hipLaunchKernelGGL(resize_pyramid_kernel<4>, grid, dim3(256), 0, STREAM(stream), a);
+  else hipLaunchKernelGGL(resize_pyramid_kernel<1>, grid, dim3(256), 0, STREAM(stream), a);
   return g6d_check_launch("resize_bilinear_pyramid");
 }

@@ -825,6 +825,7 @@ def test_resize_bilinear_pyramid(ops, N, H, W):
     sizes = [Detector._scale_size(H, W, s) for s in (0.5, 0.0, -0.5, -1.0)]
     if (H, W) == (45, 77):
         sizes[1] = (H, W)                         # (odd sizes: the identity scale is not rounded up to a multiple of 32 here)
+        sizes[2] = (23, 39)                       # a width that is not a multiple of 4: the one-output-per-thread path
     xg = x.cuda()
     outs = ops.resize_bilinear_pyramid(xg, sizes)
     torch.cuda.synchronize()
