@@ -198,3 +198,67 @@ def test_reference_sharded_detector_32_refs(tmp_path, tag, world, port):
                          env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert out.stdout.count("sharded detector ok") == world
+
+
+FORCED_WORKER = textwrap.dedent("""
+    import sys, numpy as np, torch
+    sys.path.insert(0, %r); sys.path.insert(0, %r)
+    import ref_ops
+    from gen6d_amd import ops, parallel, synth
+    from gen6d_amd.network import name2network
+    for name in dir(ops):                       # CPU emulation of the HIP ops (host-logic test)
+        if not name.startswith("_") and callable(getattr(ops, name)) and hasattr(ref_ops, name):
+            setattr(ops, name, getattr(ref_ops, name))
+    rank, world, local = parallel.init_from_env(backend="gloo", force=True)      # no launcher: a one-rank group on a free port
+    assert (rank, world) == (0, 1) and parallel.backend_name() == "gloo"
+    g = dict(np.load(%r))
+    rfn, an = int(g["rfn"]), int(g["an"])
+    case = synth.selector_case(rfn, an)
+    other = synth.imgs_to_tensor(synth.synth_images(1, 128, 128, 977))
+    ques = torch.cat([case["que_imgs"], other], 0)
+    outs = {}
+    for forced in (False, True):
+        net = name2network["selector"]({"name": "t", "selector_angle_num": an}).eval()
+        net.load_state_dict(synth.synth_state_dict("selector", an=an))
+        net.set_shard(0, 1, force_collectives=forced)
+        assert net.sharded == forced
+        parallel.COLLECTIVE_LOG = []
+        with torch.no_grad():
+            net.extract_ref_feats(case["ref_imgs"], case["ref_poses"], case["object_center"], case["object_vert"])
+            n_build = len(parallel.COLLECTIVE_LOG)
+            outs[forced] = net.compute_view_point_feats(ques)
+        n_query = len(parallel.COLLECTIVE_LOG) - n_build
+        parallel.COLLECTIVE_LOG = None
+        assert (n_build, n_query) == ((1, 9) if forced else (0, 0)), (forced, n_build, n_query)
+    for a, b in zip(outs[True], outs[False]):
+        np.testing.assert_allclose(a.numpy(), b.numpy(), atol=1e-5)
+    np.testing.assert_allclose(outs[True][0][0:1].numpy(), g["logits"], atol=2e-3)
+    det = name2network["detector"]({"name": "t"}).eval()
+    det.load_state_dict(synth.synth_state_dict("detector"))
+    dc = synth.detector_case(8, 128, 128)
+    res = {}
+    for forced in (False, True):
+        det.set_shard(0, 1, force_collectives=forced)
+        parallel.COLLECTIVE_LOG = []
+        with torch.no_grad():
+            det.load_impl(dc["ref_imgs"])
+            res[forced] = det.detect_impl(dc["que_imgs"])
+        n = len(parallel.COLLECTIVE_LOG); parallel.COLLECTIVE_LOG = None
+        assert n == (1 if forced else 0), (forced, n)
+    assert torch.equal(res[True]["scores"], res[False]["scores"]) and torch.equal(res[True]["que_select_id"], res[False]["que_select_id"])
+    print("forced collectives at world size 1 ok")
+""")
+
+
+def test_forced_collectives_on_a_one_rank_group(tmp_path):
+    """`set_shard(0, 1, force_collectives=True)` (round 5: how the sharded path meets RCCL on a 1-GPU box, tests/test_rccl_world1_gpu.py)
+    on a one-rank gloo group: 1 collective at build time and 9 per batch of queries in the selector, 1 in the detector, none without the
+    flag, and the same logits / angles / scores either way."""
+    script = tmp_path / "forced_worker.py"
+    script.write_text(FORCED_WORKER % (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden", "sel_small.npz")))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="4")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "forced collectives at world size 1 ok" in out.stdout
