@@ -47,6 +47,9 @@ namespace {
 // direct-to-LDS copy is lane-linear).  Both layouts make every ds_read_b128 of the fragment loops bank-conflict free
 // (checked exhaustively over the four 16-lane service groups of the instruction; plain 12-float rows were 3-way, plain
 // [co][8] rows 2-way conflicted).
+#ifndef WINO_M3_RAW_AUX
+#define WINO_M3_RAW_AUX 0                   // cache policy of the raw pieces of the product layers (profiling builds: 2 = non-temporal)
+#endif
 #define WQ_PIX 101                         // position stride between quarters (10 x 10 used)
 #define WRAW_LD 8                          // floats per raw patch position
 #define WRAW_FLOATS (4 * WQ_PIX * WRAW_LD) // 3232
@@ -242,7 +245,7 @@ __global__ void __launch_bounds__(64 * NWM * NWN, 1) wino_conv3x3_kernel(const W
       // tensor and get zeros from the hardware — no select when the piece goes to LDS; for 2-D layers the lane offset is a
       // constant of the piece and the chunk's channel offset is the instruction's scalar offset: no vector-ALU work at all
       u32x4 raw;
-      if constexpr (KD == 1) raw = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, pboff[j], cc * 32, 0));
+      if constexpr (KD == 1) raw = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, pboff[j], cc * 32, (MODE == 3 ? WINO_M3_RAW_AUX : 0)));
       else raw = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, v ? (unsigned)off << 2 : 0x80000000u, 0, 0));
       rp[j] = __builtin_bit_cast(f32x4, raw);
     }
