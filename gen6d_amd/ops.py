@@ -353,12 +353,13 @@ def stats_arena_begin(device):
     if key not in _ARENA:
         _ARENA[key] = [torch.zeros(ARENA_DOUBLES, dtype=torch.float64, device=device), 0, 0]
     a = _ARENA[key]
-    # only what has ever been handed out of this arena needs clearing (a[2] = its all-time high-water mark: everything behind it is
-    # still zero from the allocation): g6d_zero_bytes over a few MB instead of a fill over the arena's 16 MB.  (A captured launch keeps
-    # the size it had at capture time: the lanes' streams, and with them their arenas, are private to their graphs, whose replays
-    # hand out the same slices every time; capture() warms the arena up first.)
-    if a[2]:
-        _lib.check(_lib.load().g6d_zero_bytes(_ptr(a[0]), a[2] * 8, _stream()), "g6d_zero_bytes")
+    # Eager launches clear only what has ever been handed out of this arena (a[2] = its all-time high-water mark: everything behind it
+    # is still zero from the allocation) — 2-4 MB instead of 16.  A CAPTURED clear keeps the size it had at capture time, and eager work
+    # of another shape on the same stream could later dirty the arena beyond it: under capture the whole arena is cleared (four 16 MB
+    # fills per batch of 16 queries = 20 us of a 63 ms step buy a replay that is right whatever ran on the stream in between).
+    n_clear = ARENA_DOUBLES if (a[0].is_cuda and torch.cuda.is_current_stream_capturing()) else a[2]
+    if n_clear:
+        _lib.check(_lib.load().g6d_zero_bytes(_ptr(a[0]), n_clear * 8, _stream()), "g6d_zero_bytes")
     a[1] = 0
     _CUR_ARENA = a
 

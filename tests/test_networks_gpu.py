@@ -271,3 +271,35 @@ def test_alternative_paths_keep_parity(switches):
                           "test_detector and det_small or test_selector_golden and sel_small or test_refiner"],
                          env=dict(os.environ, G6D_TEST_SWITCHES=switches), capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+
+
+def test_captured_graph_survives_larger_eager_work_on_its_stream():
+    """The InstanceNorm statistics arena is keyed by the launching stream and cleared up to its high-water mark by eager calls; a captured
+    clear keeps its size.  A graph captured with 2 queries must still be right after an EAGER batch of 8 queries has dirtied more of the same
+    stream's arena (round 5: captured clears cover the whole arena)."""
+    case = synth.selector_case(8, 5)
+    net = _net("selector")
+    q2 = synth.imgs_to_tensor(synth.synth_images(2, 128, 128, seed=61)).cuda()
+    q8 = synth.imgs_to_tensor(synth.synth_images(8, 128, 128, seed=62)).cuda()
+    stream = torch.cuda.Stream()
+    with torch.no_grad():
+        net.extract_ref_feats(case["ref_imgs"].cuda(), case["ref_poses"].cuda(), case["object_center"].cuda(), case["object_vert"].cuda())
+        want = net.compute_view_point_feats(q2)[0].clone()
+        stream.wait_stream(torch.cuda.current_stream())
+        g_in = q2.clone()
+        with torch.cuda.stream(stream):
+            for _ in range(2):
+                net.compute_view_point_feats(g_in)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream, capture_error_mode="thread_local"):
+            g_out = net.compute_view_point_feats(g_in)[0]
+        with torch.cuda.stream(stream):
+            graph.replay()
+            first = g_out.clone()
+            net.compute_view_point_feats(q8)                 # eager, same stream, four times the statistics
+            graph.replay()
+            second = g_out.clone()
+        torch.cuda.synchronize()
+    assert float((first - want).abs().max()) <= 1e-4
+    assert float((second - want).abs().max()) <= 1e-4, "the replay after larger eager work on the stream differs: stale statistics"
