@@ -53,8 +53,9 @@ const KnobDef kKnobs[G6D_KNOB_COUNT] = {
     {"conv_wino", 1},         // conv family: eligible layers on the F(2x2,3x3) kernel
     {"conv_wino16", 1},       // ... and on its 16-bit variant in the reduced-precision mode
     {"wino_min_work", -1},    // Winograd profitability rule: -1 = built-in thresholds, 0 = off, > 0 = minimum M*K*Cout
-    {"w43_map", 1},           // F(4x4,3x3): block id -> (pixel tile, channel slice): 1 a tile's slices on one XCD (measured +0.7 % on the
-                              // bench line, profiles/r05_w43_experiments.md), 0 grid order, 2 slices fastest
+    {"w43_map", 2},           // F(4x4,3x3): block id -> (pixel tile, channel slice): 2 slices fastest (a tile's slices on neighbouring XCDs: the
+                              // best THROUGHPUT with three batches in flight, +1.2 % over 1), 1 a tile's slices on one XCD (the best serialised
+                              // time), 0 grid order — profiles/r05_w43_experiments.md
     {"conv_pm", 1},           // conv_igemm: position-major tiles for small 2-D maps with many images (padding taps skipped): 1 layers with an
                               // InstanceNorm prologue (where it measured faster), 2 every eligible layer, 0 row order
     {"gemv_mfma", 1},         // linear layers on the matrix cores: 1 for 17..32 right-hand sides (measured rule), 2 from 2 on, 0 never
