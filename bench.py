@@ -184,15 +184,13 @@ def main():
     ap.add_argument("--sel-refs", type=int, default=64)
     ap.add_argument("--det-refs", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--lowp", default="fp16,bf16mix,fp16all",
-                    help="comma list of reduced-precision matrix-core modes measured AFTER the fp32 headline (same launch mode, "
-                         "same steps) and reported in the `lowp` object: operands bf16 / fp16, fp32 accumulate; '' = skip.  Default fp16 "
-                         "only: bf16's 8-bit mantissa moves the selector logits by more than the top-2 margin of some queries (the "
-                         "viewpoint arg-max flips on 1 of the 4 synthetic queries once the trunk runs in bf16) — available as `--lowp bf16,fp16`; "
-                         "fp16 = the product's reduced-precision scheme (all three networks on fp16 operands; the selector's query trunk and "
-                         "attention / predictor tail — a few small launches — stay on fp32 operands: ViewpointSelector.default_cfg['lowp_keep_fp32']); "
-                         "bf16mix = bf16 in the detector and the refiner, that selector; fp16all = nothing kept on fp32 (fails the margin bar: "
-                         "reported to show what the keep-list buys); fp16sel32 = the whole selector on fp32 operands")
+    ap.add_argument("--lowp", default="fp16,fp16ref32,bf16",
+                    help="comma list of reduced-precision schemes measured AFTER the fp32 headline (same launch mode, same steps) and "
+                         "reported in the `lowp` object, each with its ALL-ROWS parity bar (gen6d_amd/bars.py) on the 4 bench queries + 16 held-out "
+                         "ones; '' = skip.  fp16 = every stage on fp16 operands (selector query trunk / tail on fp32: cfg lowp_keep_fp32) — "
+                         "BASELINE configs[4]; fp16ref32 = the same with the refiner on fp32 operands (the scheme that holds the all-rows bar on "
+                         "the synthetic weights); bf16 = every stage on bf16 operands — BASELINE configs[2] as it reads; also: bf16mix (detector / "
+                         "refiner bf16, selector fp16), fp16all (nothing kept on fp32), fp16sel32 (selector fp32)")
     ap.add_argument("--lowp-lanes", type=int, default=3,
                     help="batches in flight during the reduced-precision passes (their kernels are ~2x shorter, so replay gaps weigh "
                          "more: 342 images/s with 2, 357 with 3; fp32 gains 1 %% from a third lane and keeps the 2 of --lanes)")
@@ -267,8 +265,9 @@ def main():
     no_fork = args.serial or (use_graph and not args.fork)
     if no_fork:
         ops.SERIAL = True
-    # (sharded: ONE graph in flight — two replays on different streams could run their collectives in different orders on different ranks)
-    lanes = (1 if shard_refs else max(1, args.lanes)) if use_graph else 1
+    # (sharded: every lane's graph enqueues its collectives on its OWN communicator — parallel.lane_groups — so several batches can be in
+    # flight; collectives only have to be issued in the same order on every rank WITHIN a communicator, and lane i's replays are)
+    lanes = max(1, args.lanes) if use_graph else 1
     if use_graph:
         pipe.capture(lanes=lanes, batch=B)
     main_stream = torch.cuda.current_stream(dev)
@@ -483,9 +482,11 @@ def main():
         idx4 = torch.arange(4, device=dev)
         with torch.no_grad():
             sh_rows = pipe.query(fulls[idx4], crops[idx4])
-            pipe.selector.sharded = pipe.detector.sharded = False
+            for net in (pipe.selector, pipe.detector):
+                net.set_shard(rank, world, force_collectives=False)
             un_rows = pipe.query(fulls[idx4], crops[idx4])
-            pipe.selector.sharded = pipe.detector.sharded = True
+            for net in (pipe.selector, pipe.detector):
+                net.set_shard(rank, world, force_collectives=True)
         dd = (sh_rows - un_rows).abs()
         result["sharded_vs_unsharded"] = {"max_abs_diff_row": float(dd.max()), "max_rel_diff_row": float((dd / un_rows.abs().clamp(min=1.0)).max()),
                                           "ref_idx_equal": bool((sh_rows[:, 3] == un_rows[:, 3]).all()),
@@ -507,6 +508,64 @@ def main():
     #      the headline.  Same pipeline, same launch mode, matrix-core operands rounded to bf16 / fp16 in the conv / correlation
     #      kernels (fp32 accumulation, fp32 InstanceNorm statistics, fp32 trunk).
     lowp, headline_lanes = {}, lanes
+    # name -> (matrix-core operand type of the enclosing context, selector override, selector keep-list (None = cfg default), refiner override)
+    LOWP_SCHEMES = {
+        "fp16": ("fp16", None, None, None),            # BASELINE configs[4]: every stage on fp16 operands (selector trunk / tail kept on fp32)
+        "fp16ref32": ("fp16", None, None, "fp32"),     # detector + selector fp16, refiner fp32: the scheme that holds the all-rows bar
+        "bf16": ("bf16", None, None, None),            # BASELINE configs[2] as it reads: every stage on bf16 operands
+        "bf16mix": ("bf16", "fp16", None, None),       # detector + refiner bf16, selector fp16
+        "fp16all": ("fp16", None, (), None),           # nothing kept on fp32 anywhere
+        "fp16sel32": ("fp16", "fp32", None, None),
+    }
+    SCHEME_TEXT = {
+        "fp16": "detector, selector, refiner on fp16 operands; selector parts on fp32 operands: {kept} (profiles/r05_lowp_selector_sensitivity.md)",
+        "fp16ref32": "detector and selector on fp16 operands (selector parts on fp32: {kept}), refiner on fp32 operands — every part of the synthetic "
+                     "refiner ALONE moves the pose heads by 0.6-1.6e-2 in fp16 (profiles/r06_lowp_refiner_sensitivity.md), so the all-rows bar needs it on fp32",
+        "bf16": "detector, selector, refiner on bf16 operands (selector parts on fp32: {kept}) — BASELINE configs[2] as it reads",
+        "bf16mix": "detector and refiner bf16, selector fp16 with {kept} on fp32 operands",
+        "fp16all": "every matrix-core launch on fp16 operands, nothing kept on fp32",
+        "fp16sel32": "detector fp16, selector fp32, refiner fp16"}
+
+    def set_scheme(name):
+        mode, sel_mode, keep, ref_mode = LOWP_SCHEMES.get(name, (name, None, None, None))
+        pipe.selector.cfg["math_mode"] = sel_mode
+        pipe.selector.cfg["lowp_keep_fp32"] = pipe.selector.default_cfg["lowp_keep_fp32"] if keep is None else keep
+        pipe.refiner.cfg["math_mode"] = ref_mode
+        return mode
+
+    def reset_scheme():
+        pipe.selector.cfg["math_mode"] = None
+        pipe.selector.cfg["lowp_keep_fp32"] = pipe.selector.default_cfg["lowp_keep_fp32"]
+        pipe.refiner.cfg["math_mode"] = None
+
+    # the gate queries of the reduced-precision modes (gen6d_amd/bars.py): the 4 bench queries + 16 HELD-OUT queries nothing was tuned on
+    # (tests/golden/pipeline_rows_heldout.npz: rows and logits of the reference's own modules), with the fp32 path's rows of the same queries
+    from gen6d_amd import bars
+    gate = {}
+    try:
+        if (args.sel_refs, args.det_refs) == (64, 32) and world == 1 and not shard_refs:
+            for tag, n, fs, cs, fn in (("bench4", 4, 100, 200, "pipeline_rows.npz"), ("heldout16", 16, 300, 400, "pipeline_rows_heldout.npz")):
+                gp = os.path.join(ROOT, "tests", "golden", fn)
+                if not os.path.exists(gp):
+                    continue
+                g_ = np.load(gp)
+                gf = fulls if n == 4 else synth.imgs_to_tensor(synth.synth_images(n, 480, 640, seed=fs)).to(dev)
+                gc = crops if n == 4 else synth.imgs_to_tensor(synth.synth_images(n, 128, 128, seed=cs)).to(dev)
+                with torch.no_grad():
+                    r32_, l32_ = pipe.query(gf, gc).cpu(), pipe.selector.compute_view_point_feats(gc)[0].cpu()
+                gate[tag] = (gf, gc, torch.from_numpy(g_["rows"]).float(), torch.from_numpy(g_["logits"]).float(), r32_, l32_)
+            if "heldout16" in gate:
+                _, _, gr_, gl_, r32_, l32_ = gate["heldout16"]
+                e_ = bars.row_errors(r32_, gr_)
+                result["parity_vs_reference_heldout"] = {
+                    "rows_checked": 16, "ref_idx_equal": e_["ref_idx_equal"], "max_rel_diff_row": e_["max_rel"],
+                    "logits_max_abs_diff": float((l32_ - gl_).abs().max()), "argmax_equal": bool((l32_.argmax(1) == gl_.argmax(1)).all()),
+                    "ok": bool(e_["ref_idx_equal"] and e_["max_rel"] <= bars.FP32_REL and float((l32_ - gl_).abs().max()) <= bars.FP32_REL),
+                    "source": "tests/golden/pipeline_rows_heldout.npz: 16 more synthetic queries (frames seed 300, crops seed 400) through the reference's "
+                              "own modules (tests/golden/make_golden_r06.py); fp32 path, eager batch of 16"}
+    except Exception as e:
+        result.setdefault("side_leg_errors", {})["gate_queries"] = f"{type(e).__name__}: {e}"[:600]
+
     try:
         modes = [m for m in args.lowp.split(",") if m] if (use_graph and world == 1 and not shard_refs) else []
         # the first re-captured pass after the serialised eager roofline pass measures ~15 % low whatever its type (bf16 first: 169 /
@@ -516,15 +575,7 @@ def main():
         LOWP_PEAK_TFLOPS = 2500.0                          # dense 16-bit MFMA peak (MI355X_MICROARCH.md; AMD's 5 PFLOP/s figure is 2:1 sparse)
         gold_npz = np.load(gpath) if ((args.sel_refs, args.det_refs) == (64, 32) and os.path.exists(gpath)) else None
         for pi, mode_name in enumerate(modes[:1] + modes):
-            # "bf16mix": bf16 operands in the detector and the refiner, fp16 in the selector — the stage whose 13 stacked InstanceNorms
-            # amplify bf16's 8-bit mantissa past the top-2 logit margin of some queries (network cfg key `math_mode` overrides the context)
-            # "fp16sel32": fp16 operands in the detector and the refiner, the selector on fp32 operands — the scheme that keeps the logit
-            # error below a quarter of the smallest top-2 margin (tools/lowp_selector_schemes.py: an fp32 query trunk / product conv alone
-            # only reach 0.30 / 0.29 of the margin; the 13 stacked InstanceNorms carry the rounding of every fp16 layer to the logits)
-            mode = {"bf16mix": "bf16", "fp16sel32": "fp16", "fp16all": "fp16"}.get(mode_name, mode_name)
-            pipe.selector.cfg["math_mode"] = {"bf16mix": "fp16", "fp16sel32": "fp32"}.get(mode_name)
-            keep_default = pipe.selector.default_cfg["lowp_keep_fp32"]
-            pipe.selector.cfg["lowp_keep_fp32"] = () if mode_name == "fp16all" else keep_default
+            mode = set_scheme(mode_name)
             with ops.math_mode(mode):
                 pipe.capture(lanes=lanes, batch=B)
             lane_busy[:] = [None] * lanes
@@ -540,66 +591,68 @@ def main():
             entry = {"dtype": mode_name, "value": nl * B / ldt, "unit": "images/s", "ms_per_step": ldt / nl * 1e3, "queries": nl * B, "batch": B,
                      "lanes": lanes}
             kept = ", ".join(pipe.selector.cfg["lowp_keep_fp32"]) or "nothing"
-            entry["scheme"] = {
-                "fp16": f"detector, selector, refiner on fp16 operands; selector parts on fp32 operands: {kept} (profiles/r05_lowp_selector_sensitivity.md)",
-                "bf16mix": f"detector and refiner bf16, selector fp16 with {kept} on fp32 operands (bf16 breaks the margin bar in every InstanceNorm-stack layer)",
-                "fp16all": "every matrix-core launch on fp16 operands, nothing kept on fp32: the selector's trunk and tail carry the logit error past the bar",
-                "fp16sel32": "detector fp16, selector fp32, refiner fp16"}.get(mode_name, mode_name)
+            entry["scheme"] = SCHEME_TEXT.get(mode_name, mode_name).format(kept=kept)
             entry["default_scheme"] = mode_name == "fp16"
             if pi > 0:
                 # roofline of the mode: serialised eager pass of the same steps with HIP events around every MFMA-family launch
                 ops.SERIAL = True
-                with ops.math_mode(mode):
+                with ops.math_mode(mode), torch.no_grad():
                     step(0, eager=True); torch.cuda.synchronize()
                     ops.PROFILE, ops.PROFILE_HBM = [], {}
                     for i in range(args.steps):
                         step(args.warmup + i, eager=True)
                     torch.cuda.synchronize()
                     lp, ops.PROFILE, ops.PROFILE_HBM = ops.PROFILE, None, None
-                    if gold_npz is not None:              # selector logits of the 4 synthetic queries in this mode vs the reference's
-                        lg = pipe.selector.compute_view_point_feats(crops)[0].cpu()
+                    # the ALL-ROWS bar (gen6d_amd/bars.py) on the 4 bench queries and the 16 held-out ones, eager, in this mode
+                    gate_out = {}
+                    for tag, (gf, gc, gr_, gl_, r32_, l32_) in gate.items():
+                        mrows, mlog = pipe.query(gf, gc).cpu(), pipe.selector.compute_view_point_feats(gc)[0].cpu()
+                        gate_out[tag] = bars.lowp_all_rows(mrows, gr_, r32_, mlog, gl_)
                 ops.SERIAL = no_fork
                 fl = sum(p[0] for p in lp); ms = sum(p[1].elapsed_time(p[2]) for p in lp)
                 wino = [p for p in lp if p[3].startswith("wino3x3")]
+                c16 = [p for p in lp if p[3].startswith("conv16")]
                 entry["roofline"] = {"bound": "mfma", "achieved": fl / (ms * 1e-3) / 1e12, "peak": LOWP_PEAK_TFLOPS, "unit": "TFLOP/s",
                                      "frac": fl / (ms * 1e-3) / 1e12 / LOWP_PEAK_TFLOPS, "traffic": None,
-                                     "kernel": "all MFMA-family launches of a step (16-bit Winograd trunk / conv family, corr16_patch, conv_igemm / conv_patch "
-                                               "with 16-bit operands)", "flops_counted": "EXECUTED (Winograd launches: direct-form / 2.25)",
+                                     "kernel": "all MFMA-family launches of a step (conv16 direct implicit-GEMM kernels on 16-bit activations, 16-bit "
+                                               "Winograd conv family, corr16_patch, conv_igemm / conv_patch with 16-bit operands)",
+                                     "flops_counted": "EXECUTED (Winograd launches: direct-form / 2.25)",
                                      "mfma_ms_per_step": ms / args.steps, "gflop_executed_per_step": fl / args.steps / 1e9,
                                      "winograd_share_of_ms": sum(p[1].elapsed_time(p[2]) for p in wino) / ms if ms > 0 else None,
-                                     "lds_bytes_per_chunk": {"wino16b_conv3x3_kernel": 316 * 1024, "note": "raw patch 98 + V 64 + filter fragments 64 read, "
-                                                             "V 32 + raw 26 + filters 32 written per 16-channel chunk (DESIGN.md 4.7); the LDS write rate is the bound"},
+                                     "conv16_direct": ({"ms_per_step": sum(p[1].elapsed_time(p[2]) for p in c16) / args.steps,
+                                                        "achieved": sum(p[0] for p in c16) / (sum(p[1].elapsed_time(p[2]) for p in c16) * 1e-3) / 1e12,
+                                                        "launches_per_step": len(c16) / args.steps} if c16 else None),
                                      "measured": "HIP events around every launch, serialised eager re-run of the same steps"}
-                if gold_npz is not None:
-                    gl = torch.from_numpy(gold_npz["logits"]).float()
-                    top2 = gl.topk(2, 1)[0]
-                    margin = float((top2[:, 0] - top2[:, 1]).min())
-                    err = float((lg - gl).abs().max())
-                    entry["selector_logits"] = {"max_abs_err": err, "min_top2_margin_of_the_4_queries": margin, "err_over_margin": err / margin,
-                                                "bar": 0.25, "ok": bool(err <= 0.25 * margin),
-                                                "argmax_equal": bool((lg.argmax(1) == gl.argmax(1)).all())}
+                if gate_out:
+                    entry["all_rows"] = gate_out
+                    entry["ok"] = bool(all(v["ok"] for v in gate_out.values()))
+                    worst = max(gate_out.values(), key=lambda v: v["logits"]["worst_err_over_own_margin"])["logits"]
+                    entry["selector_logits"] = {"max_abs_err": max(v["logits"]["max_abs_err"] for v in gate_out.values()),
+                                                "worst_err_over_own_margin": worst["worst_err_over_own_margin"], "bar": bars.LOWP_MARGIN_FRAC,
+                                                "ok": bool(all(v["ok_logits"] for v in gate_out.values())),
+                                                "argmax_equal": bool(all(v["logits"]["argmax_equal"] for v in gate_out.values())),
+                                                "queries": sum(v["queries"] for v in gate_out.values())}
             if gold_npz is not None:
                 gold = torch.from_numpy(gold_npz["rows"]).float()
                 ref = torch.stack([gold[j] for i in range(args.steps) for j in images_of(args.warmup + i)])
                 r32 = torch.stack([row32[j] for i in range(args.steps) for j in images_of(args.warmup + i)])
                 d = (lrows - ref).abs()
                 entry["parity_vs_reference"] = {
+                    "what": "the timed rows of this mode (graph replay) against the reference's golden rows of the 4 bench queries",
                     "ref_idx_equal": bool((lrows[:, 3].long() == ref[:, 3].long()).all()),
                     "detection_cell_px": float(d[:, 0:2].max()), "max_abs_diff_row": float(d.max()),
                     "max_rel_diff_row": float((d / ref.abs().clamp(min=1.0)).max()),
                     "vs_fp32_path_max_rel": float(((lrows - r32).abs() / r32.abs().clamp(min=1.0)).max())}
             if pi > 0:
                 lowp[mode_name] = entry
-        pipe.selector.cfg["math_mode"] = None
-        pipe.selector.cfg["lowp_keep_fp32"] = pipe.selector.default_cfg["lowp_keep_fp32"]
+        reset_scheme()
         if lowp:
             result["lowp"] = lowp
         lanes = headline_lanes
     except Exception as e:                 # a side measurement must not take the headline line with it
         result.setdefault("side_leg_errors", {})["lowp"] = f"{type(e).__name__}: {e}"[:600]
     finally:
-        pipe.selector.cfg["math_mode"] = None
-        pipe.selector.cfg["lowp_keep_fp32"] = pipe.selector.default_cfg["lowp_keep_fp32"]
+        reset_scheme()
         lanes = headline_lanes
         if lowp:
             result["lowp"] = lowp

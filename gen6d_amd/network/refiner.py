@@ -85,7 +85,11 @@ class RefFeatureCache:
 class VolumeRefiner(ParamBank):
     # ref_feat_cache_deg: 0 = the reference's exact alignment, nothing cached (default); > 0 = alignment angles snapped to this
     # grid (degrees) and reference-crop features cached per (view, bucket) — opt-in: the snapped angle changes the crops
-    default_cfg = {"refiner_sample_num": 32, "ref_feat_cache_deg": 0.0}
+    # lowp_keep_fp32 / lowp_only: as in ViewpointSelector — parts that stay on fp32 matrix-core operands in the reduced-precision mode:
+    # "trunk" (VGG on the crops), "featnet" (the four conv pairs of the 2-D feature net), "embed" (mean_embed / var_embed on the 32^3
+    # volume), "stack" (volume_net conv0..conv4), "tail" (conv5 pair on 8^3 / 4^3 maps); lowp_only: ONLY the named parts on 16 bits
+    # (tools/lowp_refiner_sensitivity.py)
+    default_cfg = {"refiner_sample_num": 32, "ref_feat_cache_deg": 0.0, "lowp_keep_fp32": (), "lowp_only": None}
 
     def __init__(self, cfg):
         self.cfg = {**self.default_cfg, **cfg}
@@ -97,6 +101,13 @@ class VolumeRefiner(ParamBank):
     def load_state_dict(self, *a, **k):
         self.feat_cache.clear()                      # cached features belong to the weights they were computed with
         return super().load_state_dict(*a, **k)
+
+    def _mm(self, *names):
+        """math-mode context of one part: fp32 if listed in cfg['lowp_keep_fp32'] (with cfg['lowp_only']: if NOT listed there)."""
+        only = self.cfg.get("lowp_only")
+        keep = self.cfg.get("lowp_keep_fp32") or ()
+        fp32 = (not any(n in only for n in names)) if only is not None else any(n in keep for n in names)
+        return ops.math_mode("fp32" if fp32 else None, inherit_if_none=True)
 
     def angle_step(self):
         """Snap grid of the reference alignment in radians (0 = exact, no caching)."""
@@ -153,7 +164,8 @@ class VolumeRefiner(ParamBank):
         n, _, h, w = imgs.shape
         dev = imgs.device
         big = (n >= F43_MIN_QUERIES * 7) if f43 is None else bool(f43)
-        f3, f5, f7 = trunk_features(pk["vgg"], imgs, ("c3", "c5", "c7_pre"), True, f43=TRUNK_F43 and big)      # channels-last, L2-normalised
+        with self._mm("trunk"):
+            f3, f5, f7 = trunk_features(pk["vgg"], imgs, ("c3", "c5", "c7_pre"), True, f43=TRUNK_F43 and big)      # channels-last, L2-normalised
 
         def pair(name, x):
             """conv, IN, ReLU, conv, (IN returned as affine) — per-image statistics."""
@@ -184,8 +196,9 @@ class VolumeRefiner(ParamBank):
             y, sc, sh = pair("conv2", f7)
             ops.upsample_bilinear(y, cat[..., 128:192], 4, sc, sh, per_n=True)
 
-        ops.fork_join([b0, b1, b2], dev)
-        y, sc, sh = pair("conv_out", cat)
+        with self._mm("featnet"):
+            ops.fork_join([b0, b1, b2], dev)
+            y, sc, sh = pair("conv_out", cat)
         out = torch.empty((n, 1, hq, wq, 128), dtype=torch.float32, device=dev)
         ops.affine_act_pool(y, out, sc, sh, per_n=True)
         return out.view(n, hq, wq, 128)
@@ -222,19 +235,22 @@ class VolumeRefiner(ParamBank):
             aff = c3(x, pk[name][0], y, stats_c=64, count=vox)
             c3(y, pk[name][1], cat[..., sl], aff=aff)
 
-        embed("v_mean_embed", mean_in.view(qn, sn, sn, sn, 256), slice(0, 64))
-        embed("v_var_embed", std.view(qn, sn, sn, sn, 128), slice(64, 128))
+        with self._mm("embed"):
+            embed("v_mean_embed", mean_in.view(qn, sn, sn, sn, 256), slice(0, 64))
+            embed("v_var_embed", std.view(qn, sn, sn, sn, 128), slice(64, 128))
         x, aff, s = cat, None, sn
-        for name, co, stride in (("v_conv0", 64, 1), ("v_conv1", 128, 2), ("v_conv2", 128, 1), ("v_conv3", 256, 2),
-                                 ("v_conv4", 256, 1)):
-            s = s // stride
-            y = buf(s, co)
-            x, aff = y, c3(x, pk[name], y, stride=stride, aff=aff, stats_c=co, count=s ** 3)
+        with self._mm("stack"):
+            for name, co, stride in (("v_conv0", 64, 1), ("v_conv1", 128, 2), ("v_conv2", 128, 1), ("v_conv3", 256, 2),
+                                     ("v_conv4", 256, 1)):
+                s = s // stride
+                y = buf(s, co)
+                x, aff = y, c3(x, pk[name], y, stride=stride, aff=aff, stats_c=co, count=s ** 3)
         s = s // 2
         y = buf(s, 512)
-        aff = c3(x, pk["v_conv5"][0], y, stride=2, aff=aff, stats_c=512, count=s ** 3)
-        code = buf(s, 512)
-        c3(y, pk["v_conv5"][1], code, aff=aff)
+        with self._mm("tail"):
+            aff = c3(x, pk["v_conv5"][0], y, stride=2, aff=aff, stats_c=512, count=s ** 3)
+            code = buf(s, 512)
+            c3(y, pk["v_conv5"][1], code, aff=aff)
         return code.view(qn, s ** 3, 512) if batched else code.view(s ** 3, 512)
 
     def run_regressor(self, code):

@@ -17,21 +17,38 @@ def init_from_env(backend=None, force=False):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if (world > 1 or force) and not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if "MASTER_PORT" not in os.environ:
-            if world == 1:                                  # no launcher: any free port will do
-                import socket
-                with socket.socket() as sock:
-                    sock.bind(("127.0.0.1", 0))
-                    os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
-            else:
-                os.environ["MASTER_PORT"] = "29533"
         if backend is None:
             backend = os.environ.get("G6D_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        if world == 1 and "MASTER_PORT" not in os.environ:
+            # no launcher: a one-rank group rendezvous through a private file (picking "a free port" and re-binding it later is a race
+            # between processes that do this at the same time, e.g. parallel pytest workers — ADVICE r05)
+            import tempfile
+            fd, path = tempfile.mkstemp(prefix="g6d_pg_")
+            os.close(fd)
+            os.unlink(path)                                 # FileStore wants to create the file itself
+            dist.init_process_group(backend=backend, rank=0, world_size=1, init_method="file://" + path)
+        else:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
+
+
+_LANE_GROUPS = []
+
+
+def lane_groups(n):
+    """One process group (under RCCL: one communicator) per hipGraph lane.  Collectives are ordered WITHIN a communicator only, so two
+    batches in flight on different streams may run their collectives in either order as long as every lane's graph enqueues on its own
+    communicator: lane i's replays are issued in the same order on every rank, which is all RCCL asks for.  Lane 0 uses the default
+    group (None); the others are created once, collectively (every rank must call this with the same n), and reused by later captures."""
+    if not dist.is_initialized():
+        return [None] * n
+    while len(_LANE_GROUPS) < n - 1:
+        _LANE_GROUPS.append(dist.new_group(backend=dist.get_backend()))
+    return [None] + _LANE_GROUPS[:n - 1]
 
 
 def shard_range(n_items, rank, world):

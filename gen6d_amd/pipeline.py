@@ -4,7 +4,7 @@ Used by bench.py, __graft_entry__.smoke() and the GPU tests; mirrors `Gen6DEstim
 (det 32 refs, sel 64 refs x 5 rotations, 6 refiner views, refine_iter 3)."""
 import torch
 
-from . import ops, synth
+from . import ops, parallel, synth
 from .network import name2network
 from .network import refiner as refiner_mod
 
@@ -100,7 +100,13 @@ class TensorPipeline:
         if batch is not None:
             full_shape, crop_shape = (batch,) + tuple(full_shape[1:]), (batch,) + tuple(crop_shape[1:])
         self._lanes = []
-        for _ in range(lanes):
+        # reference-sharded mode: every lane enqueues its collectives on its OWN communicator (parallel.lane_groups), so that several
+        # batches can be in flight — the order of collectives only has to agree between ranks within a communicator
+        sharded = self.selector.sharded or self.detector.sharded
+        groups = parallel.lane_groups(lanes) if sharded else [None] * lanes
+        for li in range(lanes):
+            if sharded:
+                self.selector.group = self.detector.group = groups[li]
             g_full = torch.zeros(full_shape, dtype=torch.float32, device=d)
             g_crop = torch.zeros(crop_shape, dtype=torch.float32, device=d)
             stream = torch.cuda.Stream(device=d)
@@ -115,6 +121,8 @@ class TensorPipeline:
             with torch.cuda.graph(graph, stream=stream, capture_error_mode="thread_local"):
                 g_out = self.query(g_full, g_crop, cached_refs)
             self._lanes.append((graph, stream, g_full, g_crop, g_out))
+        if sharded:
+            self.selector.group = self.detector.group = groups[0]      # eager calls between replays: the default communicator
         torch.cuda.synchronize(d)
         return self._lanes
 

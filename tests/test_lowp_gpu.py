@@ -127,17 +127,18 @@ def test_corr2d_patch16_multi(mode, sizes, Cin, Cout, k):
     record("test_corr2d_patch16_multi", f"{mode} {sizes} x{Cin} -> {Cout}, {k}x{k}", e_ref, TOL[mode], note="relative to range")
 
 
-@pytest.mark.parametrize("mode,keep,lo,hi", [("fp16", None, 0.0, 0.25), ("fp16", (), 0.25, 1.0), ("bf16", None, 0.25, 4.0), ("bf16", (), 0.25, 8.0)],
+@pytest.mark.parametrize("mode,keep,hi", [("fp16", None, 0.25), ("fp16", (), 1.0), ("bf16", None, 4.0), ("bf16", (), 8.0)],
                          ids=["fp16-default-scheme", "fp16-nothing-kept", "bf16-default-keep-list", "bf16-nothing-kept"])
-def test_selector_headline_lowp(golden, mode, keep, lo, hi):
+def test_selector_headline_lowp(golden, mode, keep, hi):
     """64 references x 5 rotations in the reduced-precision modes against the reference's own logits — the four synthetic queries of
     bench.py (tests/golden/pipeline_rows.npz), whose smallest top-2 margin is 0.038.  The bounds are TIED TO THE MARGIN as on the bench
     line (lo / hi in units of it).  The product's scheme — fp16 with the cfg default keep-list (query trunk and
     attention / predictor tail on fp32 operands, the InstanceNorm stacks on fp16); "bf16mix" on the bench line is this selector inside a
     bf16 pipeline — must keep every logit within a QUARTER of the margin: the arg-max is then equal by construction.  The other three
     document why: fp16 with nothing kept and bf16 (with or without the keep-list: every InstanceNorm-stack layer alone moves the logits by
-    0.2-0.8 of the margin in bf16) stay within their type's rounding class but EXCEED the quarter bar
-    (profiles/r05_lowp_selector_sensitivity.md); should one of them start to hold it, the default / DESIGN.md want updating."""
+    0.2-0.8 of the margin in bf16) are held to their type's rounding class only — UPPER bounds (a lower bound turns a better
+    result into a failure); that they exceed the quarter bar on this box is recorded in the parity log, not asserted
+    (profiles/r05_lowp_selector_sensitivity.md)."""
     g = golden("pipeline_rows")
     gl = g["logits"]
     top2 = np.sort(gl, 1)[:, -2:]
@@ -153,10 +154,63 @@ def test_selector_headline_lowp(golden, mode, keep, lo, hi):
         got = net.compute_view_point_feats(crops)[0].cpu().numpy()
     err = float(np.abs(got - gl).max())
     record("test_selector_headline_lowp", f"{mode} keep={'default' if keep is None else keep} 64x5 logits of 4 queries vs reference golden "
-           f"(smallest top-2 margin {margin:.4f})", err, hi * margin)
-    assert lo * margin <= err <= hi * margin, (err / margin, lo, hi)
+           f"(smallest top-2 margin {margin:.4f})", err, hi * margin,
+           note="" if hi <= 0.25 else f"informational: {err / margin:.2f} of the margin (the product scheme's bar is 0.25)")
+    assert err <= hi * margin, (err / margin, hi)
     if hi <= 0.25:
         assert np.array_equal(got.argmax(1), gl.argmax(1)), (err, margin)
+
+
+ALL_ROWS_SCHEMES = {   # name -> (context mode, selector cfg math_mode, refiner cfg math_mode, must hold the all-rows bar)
+    "fp16ref32": ("fp16", None, "fp32", True),     # detector + selector fp16, refiner fp32: the scheme that holds every bar
+    "fp16": ("fp16", None, None, False),           # BASELINE configs[4]: logits / position / scale hold, the synthetic refiner's pose heads do not
+    "bf16": ("bf16", None, None, False),           # BASELINE configs[2] as it reads
+}
+
+
+@pytest.mark.parametrize("scheme", list(ALL_ROWS_SCHEMES))
+def test_pipeline_all_rows_lowp(golden, scheme):
+    """The ALL-ROWS bar of the reduced-precision modes (gen6d_amd/bars.py): every column of the [26]-wide result rows
+    — detection position, scale, viewpoint index, angle and the 21 pose-head outputs of the three refinement steps — plus the selector
+    logits, on the four bench queries AND on sixteen held-out queries nothing was tuned on (tests/golden/pipeline_rows_heldout.npz, outputs of
+    the reference's own modules), against the reference's rows and against the fp32 path's.  `fp16ref32` must hold every bar.  `fp16` must
+    hold the logit, viewpoint, position and scale bars on all 20 queries; its pose heads are recorded and bounded at 5e-2 only: every part of
+    the synthetic refiner alone moves them by 0.6-1.6e-2 in fp16 (profiles/r06_lowp_refiner_sensitivity.md), the bar is 5e-3.  `bf16` is
+    recorded with its type's bounds (it does not hold the logit bar; arg-max equality is not asserted)."""
+    from gen6d_amd import bars, ops
+    from gen6d_amd.pipeline import TensorPipeline
+    mode, sel_mode, ref_mode, must_hold = ALL_ROWS_SCHEMES[scheme]
+    dev = torch.device("cuda", 0)
+    pipe = TensorPipeline(dev)
+    pipe.build()
+    sets = {}
+    for tag, n, fs, cs, fn in (("bench4", 4, 100, 200, "pipeline_rows"), ("heldout16", 16, 300, 400, "pipeline_rows_heldout")):
+        g = golden(fn)
+        sets[tag] = (synth.imgs_to_tensor(synth.synth_images(n, 480, 640, seed=fs)).to(dev),
+                     synth.imgs_to_tensor(synth.synth_images(n, 128, 128, seed=cs)).to(dev),
+                     torch.from_numpy(np.asarray(g["rows"])).float(), torch.from_numpy(np.asarray(g["logits"])).float())
+    with torch.no_grad():
+        r32 = {t: pipe.query(v[0], v[1]).cpu() for t, v in sets.items()}
+        l32 = {t: pipe.selector.compute_view_point_feats(v[1])[0].cpu() for t, v in sets.items()}
+        pipe.selector.cfg["math_mode"], pipe.refiner.cfg["math_mode"] = sel_mode, ref_mode
+        with ops.math_mode(mode):
+            got = {t: (pipe.query(v[0], v[1]).cpu(), pipe.selector.compute_view_point_feats(v[1])[0].cpu()) for t, v in sets.items()}
+    for t, v in sets.items():
+        e32 = bars.row_errors(r32[t], v[2])
+        assert e32["ref_idx_equal"] and e32["max_rel"] <= bars.FP32_REL and float((l32[t] - v[3]).abs().max()) <= bars.FP32_REL, (t, e32)
+        b = bars.lowp_all_rows(got[t][0], v[2], r32[t], got[t][1], v[3])
+        worst = max(b["vs_reference"]["pose_heads_rel"], b["vs_fp32_path"]["pose_heads_rel"])
+        record("test_pipeline_all_rows_lowp", f"{scheme} {t}: pose heads rel (worst of vs reference / vs fp32 path)", worst, bars.LOWP_REL,
+               note=f"ok_rows={b['ok_rows']} ok_logits={b['ok_logits']} position {b['vs_reference']['position_px']:.3f} px, scale(log2) "
+                    f"{b['vs_reference']['scale_log2_rel']:.2e}, logits {b['logits']['worst_err_over_own_margin']:.3f} of own margin")
+        if must_hold:
+            assert b["ok"], (scheme, t, b)
+        elif scheme == "fp16":
+            assert b["ok_logits"] and b["vs_reference"]["ref_idx_equal"], (t, b["logits"])
+            assert b["vs_reference"]["position_px"] <= bars.LOWP_POS_PX and b["vs_reference"]["scale_log2_rel"] <= bars.LOWP_REL, (t, b["vs_reference"])
+            assert worst <= 5e-2, (t, worst)
+        else:
+            assert b["vs_reference"]["position_px"] <= 2.0 and worst <= 0.5, (t, b["vs_reference"])
 
 
 @pytest.mark.parametrize("mode", ["bf16", "fp16"])

@@ -5,7 +5,8 @@ A one-rank `nccl` process group accepts every collective, so with `set_shard(0, 
 collectives per batch through ncclAllReduce / ncclAllGather on device tensors on the launch stream.  The worker
   * counts them (10 per batch of queries, 1 at build time),
   * compares the eager rows with the plain (collective-free) path on the same pipeline,
-  * captures the batch — kernels AND collectives — into ONE hipGraph, replays it on other images and compares again,
+  * captures the batch — kernels AND collectives — into ONE hipGraph per lane, three lanes on three communicators (round 6), replays
+    them concurrently on other images and compares again,
   * holds the rows to the reference's golden rows (tests/golden/pipeline_rows.npz).
 It runs in a subprocess under a timeout: a communicator that wedges must not take the test session (or the box) with it.
 """
@@ -44,18 +45,23 @@ WORKER = textwrap.dedent("""
     assert n_build == 1 and n_query == 10, (n_build, n_query, kinds)       # R1/R2 at build; 9 selector + 1 detector per batch
     assert kinds.count("all_reduce_max") == 1 and kinds.count("all_reduce_sum") == 6 and kinds.count("all_gather_rows") == 3, kinds
     # the same pipeline without collectives
-    pipe.selector.sharded = pipe.detector.sharded = False
+    for net in (pipe.selector, pipe.detector):
+        net.set_shard(0, 1, force_collectives=False)
     rows_un = torch.cat([pipe.query(fulls[i:i + B], crops[i:i + B]) for i in (0, 2)], 0)
-    pipe.selector.sharded = pipe.detector.sharded = True
+    for net in (pipe.selector, pipe.detector):
+        net.set_shard(0, 1, force_collectives=True)
     torch.cuda.synchronize()
     rel = lambda a, b: float(((a - b).abs() / b.abs().clamp(min=1.0)).max())
     e_eager = rel(rows_sh, rows_un[0:B])
     assert e_eager <= 1e-4 and bool((rows_sh[:, 3] == rows_un[0:B, 3]).all()), e_eager
-    # kernels + collectives of a batch in ONE hipGraph; replayed on the captured images and on two others
-    pipe.capture(lanes=1, batch=B)
+    # kernels + collectives of a batch in ONE hipGraph per lane, every lane on its OWN communicator (parallel.lane_groups; round 6:
+    # three batches in flight in the sharded mode too); the three replays are enqueued back to back and overlap
+    LANES = 3
+    pipe.capture(lanes=LANES, batch=B)
+    assert len(parallel._LANE_GROUPS) == LANES - 1 and pipe.selector.group is None
+    pend = [pipe.query_graph(fulls[i:i + B], crops[i:i + B], lane) for lane, i in enumerate((0, 2, 0))]
     got = []
-    for i in (0, 2, 0):
-        out, stream = pipe.query_graph(fulls[i:i + B], crops[i:i + B], 0)
+    for out, stream in pend:
         stream.synchronize()
         got.append(out.clone())
     e_graph = max(rel(got[0], rows_un[0:B]), rel(got[1], rows_un[2:4]), rel(got[2], rows_un[0:B]))
