@@ -1,0 +1,332 @@
+// conv16_direct.hip — direct (implicit-GEMM) 3x3 / 3x3x3 convolution on 16-bit ACTIVATIONS: the reduced-precision mode's own kernel
+// family (round 6; BASELINE configs[2] "bf16" / configs[4] "fp16 MFMA convs").
+//
+// Replaces, in the reduced-precision mode only, the VGG trunks' 3x3 layers (reference network/pretrain_models.py:9-31,66-72; detector
+// pyramid detector.py:188-197,236-241; refiner crops refiner.py:64-78) and the first convs of the refiner's 32^3 volume net
+// (refiner.py:88-143).  Until round 5 that mode kept fp32 activations in HBM and LDS and rounded operands when fragments left LDS:
+// its 16-bit Winograd kernels were bound by LDS WRITES of fp32 data.  Here activations are fp16 / bf16 NHWC in HBM:
+//   * both operand tiles of a K step go global -> LDS by DMA (buffer_load_dwordx4 ... lds: no VGPR round trip, no ds_write, no
+//     conversion), 16 bytes = 8 channels per lane; zero padding and ragged tile edges are the buffer's out-of-range zero fill;
+//   * K step = 64 input channels of ONE tap (128 B per pixel row and per filter row): the LDS image [row][8 slots of 16 B] is lane-linear
+//     as the DMA demands, and bank-conflict free for the ds_read_b128 fragment reads because the lane that FILLS slot s of row r fetches
+//     channel group s ^ ((r >> 1) & 7) — the swizzle sits on the source address (cdna_hip_programming.md rule 21);
+//   * v_mfma_f32_32x32x16_{f16,bf16}, fp32 accumulation; block = 128 output pixels x 128 output channels, 4 waves of 64 x 64 (2 x 2
+//     accumulator tiles), two LDS stages of 32 KB, two blocks per CU (the second block's MFMAs cover this block's barrier / DMA waits);
+//   * a tile is TH x TW pixels (TH TW = 128, TW a power of two chosen per map width) of the "tall image" [N D H rows][W columns], so 2x2
+//     max-pool windows never straddle tiles and small maps pack several images into one tile;
+//   * epilogue through LDS: bias, ReLU, then 16-byte stores of the full map (16-bit or fp32) and / or the 2x2 max-pooled map, and
+//     optionally per-(image group, channel) sum / sum of squares in fp64 for the InstanceNorm that follows (volume net).
+// K order: input-channel slice outermost, taps innermost — the nine shifted reads of a 16 KB slice hit L1 / L2.
+#include "g6d_common.h"
+
+namespace {
+
+constexpr int C16_BM = 128, C16_BN = 128, C16_BK = 64;
+constexpr int C16_STAGE = (C16_BM + C16_BN) * C16_BK * 2;      // 32 KB
+constexpr int C16_LDS = 2 * C16_STAGE;                         // 64 KB
+constexpr int C16_EP_LD = 68;                                  // floats per pixel row of the epilogue tile (64 channels + 4: conflict-free b128 reads)
+constexpr unsigned C16_OOB = 0x80000000u;
+
+struct C16Seg {
+  const char* in; char* full; char* pool;
+  int H, W, DH;            // map height / width, rows per image group (D * H)
+  int rows;                // N * D * H rows of the tall image
+  int ld_in, ld_full, ld_pool;
+  int tw_log2, tiles_x, tile0;
+  unsigned in_bytes;       // extent of the input buffer as the descriptor sees it (incl. the back-shift)
+  int back;                // bytes the descriptor base lies BEFORE the tensor (offset of tap (0,0,0) from the centre, negated)
+};
+struct C16Params {
+  C16Seg seg[4];
+  int nseg, Cin, Cout, kd, D, relu, full_type, pool_type;   // *_type: 0 none, 1 = 16-bit (the operand type), 2 = fp32
+  const char* w; unsigned w_bytes; const float* bias;
+  int ptiles, nN;
+  double* stats; int stat_rows_per_group;                    // optional: [groups][Cout][2]
+};
+
+template <int MM> struct C16T;
+template <> struct C16T<1> { typedef __bf16 T; typedef bf16x8 V; };
+template <> struct C16T<2> { typedef _Float16 T; typedef f16x8 V; };
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t c16_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+
+template <int MM>
+__global__ __launch_bounds__(256, 2) void conv16_kernel(const C16Params p) {
+  typedef typename C16T<MM>::T T;
+  typedef typename C16T<MM>::V V8;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  // block id -> (pixel tile, channel tile): the nN channel tiles of a pixel tile run back to back on ONE XCD (ids = xcd mod 8)
+  const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+  const int nt = jj % p.nN, ptile = (jj / p.nN) * 8 + xcd;
+  if (ptile >= p.ptiles) return;
+  int si = 0;
+#pragma unroll
+  for (int i = 1; i < 4; ++i) if (i < p.nseg && ptile >= p.seg[i].tile0) si = i;
+  const C16Seg& sg = p.seg[si];
+  const int t = ptile - sg.tile0;
+  const int tw_log2 = sg.tw_log2, TW = 1 << tw_log2;
+  const int tx = t % sg.tiles_x, ty = t / sg.tiles_x;
+  const int g0 = ty * (C16_BM >> tw_log2), x0 = tx * TW;
+  const int H = sg.H, W = sg.W, D = p.D;
+  const int ntaps = 9 * p.kd;
+
+  // ---- geometry of the four A rows this lane fills per K step: byte offset of the (shifted-back) centre pixel + tap validity mask
+  unsigned a_off[4], a_mask[4], b_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = 32 * wv + 8 * i + (lane >> 3);
+    const int slot = (lane & 7) ^ ((r >> 1) & 7);
+    const int g = g0 + (r >> tw_log2), x = x0 + (r & (TW - 1));
+    unsigned m = 0;
+    if (g < sg.rows && x < W) {
+      const int y = g % H, z = (g / H) % D;
+      unsigned my = (y > 0 ? 1u : 0u) | 2u | (y < H - 1 ? 4u : 0u);            // ky = 0,1,2 valid
+      unsigned mx = (x > 0 ? 1u : 0u) | 2u | (x < W - 1 ? 4u : 0u);
+      unsigned m9 = 0;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) if (my >> ky & 1) m9 |= mx << (3 * ky);
+      if (p.kd == 3) {
+        if (z > 0) m |= m9;
+        m |= m9 << 9;
+        if (z < D - 1) m |= m9 << 18;
+      } else m = m9;
+    }
+    a_mask[i] = m;
+    a_off[i] = (unsigned)(((long)g * W + x) * sg.ld_in * 2) + slot * 16;
+    b_off[i] = (unsigned)((long)(nt * C16_BN + r) * ntaps * p.Cin * 2) + slot * 16;
+  }
+  const __amdgpu_buffer_rsrc_t rs_in = c16_rsrc(sg.in - sg.back, sg.in_bytes);
+  const __amdgpu_buffer_rsrc_t rs_w = c16_rsrc(p.w, p.w_bytes);
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+
+  const int nchunk = p.Cin / C16_BK, nk = nchunk * ntaps;
+  // K-step state (scalar): tap = (kz, ky, kx), channel chunk
+  auto issue = [&](int k, int stage) {
+    const int c = k / ntaps, tap = k - c * ntaps;
+    const int kz = tap / 9, r9 = tap - 9 * kz, ky = r9 / 3, kx = r9 - 3 * ky;
+    const unsigned a_k = (unsigned)(((kz * H + ky) * W + kx) * sg.ld_in * 2 + c * (C16_BK * 2));
+    const unsigned b_k = (unsigned)((tap * p.Cin + c * C16_BK) * 2);
+    char* sa = lds + stage * C16_STAGE + (32 * wv) * 128;
+    char* sb = sa + C16_BM * 128;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned vo = (a_mask[i] >> tap & 1u) ? a_off[i] + a_k : C16_OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr)(sa + i * 1024), 16, vo, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr)(sb + i * 1024), 16, b_off[i] + b_k, 0, 0, 0);
+  };
+
+  const int wm = wv >> 1, wn = wv & 1;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  // fragment read offsets: row = tile row (lane & 31), logical slot 2 ks + (lane >> 5) -> physical slot ^ ((row >> 1) & 7)
+  const int frow = lane & 31, fhalf = lane >> 5, fsw = (frow >> 1) & 7;
+  const int a_rd = (64 * wm + frow) * 128, b_rd = C16_BM * 128 + (64 * wn + frow) * 128;
+
+  issue(0, 0);
+  for (int k = 0; k < nk; ++k) {
+    const int stage = k & 1;
+    if (k + 1 < nk) {
+      issue(k + 1, stage ^ 1);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    const char* st = lds + stage * C16_STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int sl = ((2 * ks + fhalf) ^ fsw) * 16;
+      V8 a0 = *reinterpret_cast<const V8*>(st + a_rd + sl);
+      V8 a1 = *reinterpret_cast<const V8*>(st + a_rd + 32 * 128 + sl);
+      V8 b0 = *reinterpret_cast<const V8*>(st + b_rd + sl);
+      V8 b1 = *reinterpret_cast<const V8*>(st + b_rd + 32 * 128 + sl);
+      if constexpr (MM == 1) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+      } else {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[1][1], 0, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                       // every wave has read this stage: the next iteration may refill it
+  }
+
+  // ---- epilogue: two passes of 64 channels through an fp32 LDS tile [128 px][68]
+  float* ep = reinterpret_cast<float*>(lds);
+  double* red = reinterpret_cast<double*>(lds + C16_BM * C16_EP_LD * 4);       // [4 quarters][64 ch][2] statistics partials
+  const int TH2 = (C16_BM >> tw_log2) >> 1, TW2 = TW >> 1;
+#pragma unroll 1
+  for (int h = 0; h < 2; ++h) {
+    const int cbase = nt * C16_BN + 64 * h;
+    if (wn == h) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt2 = 0; nt2 < 2; ++nt2) {
+          const float bv = p.bias ? p.bias[cbase + 32 * nt2 + (lane & 31)] : 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int px = 64 * wm + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            float v = acc[mt][nt2][r] + bv;
+            if (p.relu) v = fmaxf(v, 0.f);
+            ep[px * C16_EP_LD + 32 * nt2 + (lane & 31)] = v;
+          }
+        }
+    }
+    __syncthreads();
+    if (p.full_type == 1) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int px = (tid >> 3) + 32 * j, ch = (tid & 7) * 8;
+        const int g = g0 + (px >> tw_log2), x = x0 + (px & (TW - 1));
+        if (g < sg.rows && x < W) {
+          const f32x4 v0 = *reinterpret_cast<const f32x4*>(ep + px * C16_EP_LD + ch), v1 = *reinterpret_cast<const f32x4*>(ep + px * C16_EP_LD + ch + 4);
+          V8 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { o[e] = (T)v0[e]; o[4 + e] = (T)v1[e]; }
+          *reinterpret_cast<V8*>(sg.full + (((long)g * W + x) * sg.ld_full + cbase + ch) * 2) = o;
+        }
+      }
+    } else if (p.full_type == 2) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int px = (tid >> 4) + 16 * j, ch = (tid & 15) * 4;
+        const int g = g0 + (px >> tw_log2), x = x0 + (px & (TW - 1));
+        if (g < sg.rows && x < W)
+          *reinterpret_cast<f32x4*>(sg.full + (((long)g * W + x) * sg.ld_full + cbase + ch) * 4) = *reinterpret_cast<const f32x4*>(ep + px * C16_EP_LD + ch);
+      }
+    }
+    if (p.pool_type) {
+      const int per = p.pool_type == 1 ? 8 : 4, chunks = 64 / per;      // channels per item, items per pooled pixel
+      for (int it = tid; it < 32 * chunks; it += 256) {
+        const int pp = it / chunks, ch = (it - pp * chunks) * per;
+        const int pry = pp / TW2, prx = pp - pry * TW2;
+        const int r00 = ((2 * pry) << tw_log2) + 2 * prx;
+        const int g = g0 + 2 * pry, x = x0 + 2 * prx;
+        if (pry < TH2 && g < sg.rows && x < W) {
+          float m[8];
+#pragma unroll
+          for (int e = 0; e < 8; e += 4) {
+            if (e < per) {
+              const f32x4 q0 = *reinterpret_cast<const f32x4*>(ep + r00 * C16_EP_LD + ch + e), q1 = *reinterpret_cast<const f32x4*>(ep + (r00 + 1) * C16_EP_LD + ch + e);
+              const f32x4 q2 = *reinterpret_cast<const f32x4*>(ep + (r00 + TW) * C16_EP_LD + ch + e), q3 = *reinterpret_cast<const f32x4*>(ep + (r00 + TW + 1) * C16_EP_LD + ch + e);
+#pragma unroll
+              for (int u = 0; u < 4; ++u) m[e + u] = fmaxf(fmaxf(q0[u], q1[u]), fmaxf(q2[u], q3[u]));
+            }
+          }
+          const long o = ((long)(g >> 1) * (W >> 1) + (x >> 1)) * sg.ld_pool + cbase + ch;
+          if (p.pool_type == 1) {
+            V8 ov;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ov[e] = (T)m[e];
+            *reinterpret_cast<V8*>(sg.pool + o * 2) = ov;
+          } else {
+            f32x4 ov = {m[0], m[1], m[2], m[3]};
+            *reinterpret_cast<f32x4*>(sg.pool + o * 4) = ov;
+          }
+        }
+      }
+    }
+    if (p.stats) {
+      // per-(group, channel) sum / sum of squares of the fp32 results of the tile's VALID pixels (a tile never straddles groups)
+      const int c = tid & 63, q = tid >> 6;
+      float s1 = 0.f, s2 = 0.f;
+      for (int px = 32 * q; px < 32 * q + 32; ++px) {
+        const int g = g0 + (px >> tw_log2), x = x0 + (px & (TW - 1));
+        if (g < sg.rows && x < W) { const float v = ep[px * C16_EP_LD + c]; s1 += v; s2 += v * v; }
+      }
+      red[(q * 64 + c) * 2] = (double)s1; red[(q * 64 + c) * 2 + 1] = (double)s2;
+      __syncthreads();
+      if (tid < 128) {
+        const int cc = tid >> 1, w = tid & 1;
+        const double v = red[(0 * 64 + cc) * 2 + w] + red[(1 * 64 + cc) * 2 + w] + red[(2 * 64 + cc) * 2 + w] + red[(3 * 64 + cc) * 2 + w];
+        const int grp = p.stat_rows_per_group > 0 ? (int)(((long)g0 * W) / p.stat_rows_per_group) : 0;
+        atomicAdd(p.stats + ((long)grp * p.Cout + cbase + cc) * 2 + w, v);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+int c16_pick_tw(int W, int pool) {
+  // tile width (power of two, 4..64; even for pooling) with the least column overhang, ties -> the wider tile
+  int best = 8; double bw = 1e9;
+  for (int tw = 64; tw >= (pool ? 4 : 4); tw >>= 1) {
+    const double waste = (double)((W + tw - 1) / tw * tw) / W;
+    if (waste < bw - 1e-9) { bw = waste; best = tw; }
+  }
+  return best;
+}
+
+}  // namespace
+
+extern "C" int g6d_conv16_direct_multi(const G6dConv16Seg* segs, int nseg, int Cin, const void* W16, const float* bias, int Cout, int kd,
+                                       int relu, int full_type, int pool_type, int math_mode, double* stats, int stat_rows_per_group,
+                                       g6d_stream_t stream) {
+  if (!segs || nseg < 1 || nseg > 4 || !W16) { g6d_set_error("conv16_direct: 1..4 segments and filters expected"); return G6D_EINVAL; }
+  if (math_mode != 1 && math_mode != 2) { g6d_set_error("conv16_direct: math_mode 1 (bf16) or 2 (fp16)"); return G6D_EINVAL; }
+  if (Cin % C16_BK || Cout % C16_BN || (kd != 1 && kd != 3)) { g6d_set_error("conv16_direct: Cin % 64, Cout % 128, kd in {1,3} expected"); return G6D_EINVAL; }
+  if (full_type < 0 || full_type > 2 || pool_type < 0 || pool_type > 2 || (!full_type && !pool_type && !stats)) { g6d_set_error("conv16_direct: output types"); return G6D_EINVAL; }
+  if (pool_type && kd != 1) { g6d_set_error("conv16_direct: pooling is 2-D only"); return G6D_EINVAL; }
+  C16Params p = {};
+  p.nseg = nseg; p.Cin = Cin; p.Cout = Cout; p.kd = kd; p.relu = relu; p.full_type = full_type; p.pool_type = pool_type;
+  p.w = static_cast<const char*>(W16); p.bias = bias; p.stats = stats; p.stat_rows_per_group = stat_rows_per_group;
+  const long wb = (long)Cout * 9 * kd * Cin * 2;
+  if (wb >= (1L << 31)) { g6d_set_error("conv16_direct: filters beyond 2 GB"); return G6D_EINVAL; }
+  p.w_bytes = (unsigned)wb;
+  p.nN = Cout / C16_BN;
+  int tiles = 0, D0 = segs[0].D;
+  for (int i = 0; i < nseg; ++i) {
+    const G6dConv16Seg& s = segs[i];
+    C16Seg& o = p.seg[i];
+    if (!s.in || s.N < 1 || s.D < 1 || s.H < 1 || s.W < 1 || s.ld_in < Cin || s.D != D0 || (kd == 1 && s.D != 1)) { g6d_set_error("conv16_direct: bad segment"); return G6D_EINVAL; }
+    if ((full_type && (!s.out_full || s.ld_full < Cout)) || (pool_type && (!s.out_pool || s.ld_pool < Cout || (s.H & 1) || (s.W & 1)))) {
+      g6d_set_error("conv16_direct: outputs missing / odd map with pooling"); return G6D_EINVAL;
+    }
+    if (!g6d_aligned16(s.in) || (s.ld_in & 7) || (full_type && (!g6d_aligned16(s.out_full) || (s.ld_full & 7))) || (pool_type && (!g6d_aligned16(s.out_pool) || (s.ld_pool & 7)))) {
+      g6d_set_error("conv16_direct: 16-byte aligned rows expected"); return G6D_EINVAL;
+    }
+    o.in = static_cast<const char*>(s.in); o.full = static_cast<char*>(s.out_full); o.pool = static_cast<char*>(s.out_pool);
+    o.H = s.H; o.W = s.W; o.DH = s.D * s.H; o.rows = s.N * s.D * s.H;
+    o.ld_in = s.ld_in; o.ld_full = s.ld_full; o.ld_pool = s.ld_pool;
+    const int tw = c16_pick_tw(s.W, pool_type != 0);
+    int l2 = 0; while ((1 << l2) < tw) ++l2;
+    o.tw_log2 = l2; o.tiles_x = (s.W + tw - 1) / tw; o.tile0 = tiles;
+    const int th = C16_BM / tw;
+    if (stats && stat_rows_per_group > 0 && ((long)stat_rows_per_group % ((long)th * s.W) != 0)) { g6d_set_error("conv16_direct: statistics groups must be whole tile rows"); return G6D_EINVAL; }
+    tiles += o.tiles_x * ((o.rows + th - 1) / th);
+    // the descriptor starts (kd == 3 ? H W : 0) + W + 1 pixels before the tensor: tap offsets are then non-negative
+    const long back = ((long)(kd == 3 ? s.H * s.W : 0) + s.W + 1) * s.ld_in * 2;
+    const long ext = (long)o.rows * s.W * s.ld_in * 2 + back;
+    if (ext >= (1L << 31)) { g6d_set_error("conv16_direct: a segment's input beyond 2 GB"); return G6D_EINVAL; }
+    o.back = (int)back; o.in_bytes = (unsigned)ext;
+  }
+  p.D = D0;
+  p.ptiles = tiles;
+  const int blocks = (tiles + 7) / 8 * 8 * p.nN;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (math_mode == 1) {
+    g6d_allow_lds(reinterpret_cast<const void*>(&conv16_kernel<1>), C16_LDS);
+    hipLaunchKernelGGL(conv16_kernel<1>, dim3(blocks), dim3(256), C16_LDS, st, p);
+  } else {
+    g6d_allow_lds(reinterpret_cast<const void*>(&conv16_kernel<2>), C16_LDS);
+    hipLaunchKernelGGL(conv16_kernel<2>, dim3(blocks), dim3(256), C16_LDS, st, p);
+  }
+  return g6d_check_launch("conv16_direct");
+}

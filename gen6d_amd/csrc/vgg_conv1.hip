@@ -139,9 +139,12 @@ __global__ void __launch_bounds__(C1_THREADS) vgg_conv1_pool_kernel(const float*
 #define M1_IH (2 * M1_PTY + 2)
 #define M1_IWP 80                       // row pitch = 16 mod 32: the two conv rows of a pool window hit disjoint banks
 
+// OT: element type of the channels-last result — float, or (round 6, the reduced-precision mode's 16-bit activation path: the input of
+// g6d_conv16_direct_multi) _Float16 / __bf16, rounded once here.
+template <typename OT>
 __global__ void __launch_bounds__(256) vgg_conv1_pool_mfma_kernel(const float* __restrict__ in, const float* __restrict__ w_oihw,
                                                                   const float* __restrict__ bias, int H, int W, int Ho, int Wo,
-                                                                  float* __restrict__ out, const Conv1Norm nm) {
+                                                                  OT* __restrict__ out, const Conv1Norm nm) {
   __shared__ float tile[C1_CIN][M1_IH][M1_IWP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
@@ -193,8 +196,8 @@ __global__ void __launch_bounds__(256) vgg_conv1_pool_mfma_kernel(const float* _
         if (px < Wo) {
           const float m0 = fmaxf(fmaxf(acc0[4 * j], acc0[4 * j + 1]), fmaxf(acc0[4 * j + 2], acc0[4 * j + 3])) + b0;   // max(a)+b == max(a+b)
           const float m1 = fmaxf(fmaxf(acc1[4 * j], acc1[4 * j + 1]), fmaxf(acc1[4 * j + 2], acc1[4 * j + 3])) + b1;
-          float* o = out + ((size_t)(n * Ho + py) * Wo + px) * C1_COUT;
-          o[li] = fmaxf(m0, 0.f); o[li + 32] = fmaxf(m1, 0.f);         // relu(max) == max(relu)
+          OT* o = out + ((size_t)(n * Ho + py) * Wo + px) * C1_COUT;
+          o[li] = (OT)fmaxf(m0, 0.f); o[li + 32] = (OT)fmaxf(m1, 0.f);         // relu(max) == max(relu)
         }
       }
     }
@@ -216,7 +219,7 @@ int conv1_launch(const float* in, int N, int H, int W, const float* w_oihw, cons
   // channels-last results take the matrix-core kernel (knob conv1_mfma = 0: the vector-pipe kernel)
   const bool use_mfma = g6d_knob(G6D_KNOB_CONV1_MFMA) != 0;
   if (nhwc && use_mfma) {
-    hipLaunchKernelGGL(vgg_conv1_pool_mfma_kernel, dim3((Wo + M1_PTX - 1) / M1_PTX, (Ho + M1_PTY - 1) / M1_PTY, N), dim3(256), 0,
+    hipLaunchKernelGGL(vgg_conv1_pool_mfma_kernel<float>, dim3((Wo + M1_PTX - 1) / M1_PTX, (Ho + M1_PTY - 1) / M1_PTY, N), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), in, w_oihw, bias, H, W, Ho, Wo, out, nm);
     return g6d_check_launch("vgg_conv1_pool_mfma");
   }
@@ -245,6 +248,30 @@ extern "C" int g6d_vgg_conv1_pool_nhwc_norm(const float* in, int N, int H, int W
                                             int Cout, const float* mean_host, const float* std_host, float* out, g6d_stream_t stream) {
   if (!mean_host || !std_host) { g6d_set_error("vgg_conv1_pool_nhwc_norm: mean / std missing"); return G6D_EINVAL; }
   return conv1_launch(in, N, H, W, w_oihw, bias, Cin, Cout, out, 1, stream, mean_host, std_host);
+}
+
+// The same layer with a 16-BIT channels-last result (math_mode 1 = bf16, 2 = fp16; ABI v11): the first layer of the reduced-precision
+// mode's 16-bit activation path, rounded once in the epilogue.  mean_host / std_host may be NULL (already normalised input).
+extern "C" int g6d_vgg_conv1_pool_nhwc16(const float* in, int N, int H, int W, const float* w_oihw, const float* bias, int Cin, int Cout,
+                                         const float* mean_host, const float* std_host, void* out16, int math_mode, g6d_stream_t stream) {
+  if (!in || !w_oihw || !bias || !out16 || N <= 0 || N > 65535 || H < 2 || W < 2 || Cin != C1_CIN || Cout != C1_COUT ||
+      (math_mode != 1 && math_mode != 2) || (long long)N * Cout * (H / 2) * (W / 2) >= (1ll << 31)) {
+    g6d_set_error("vgg_conv1_pool_nhwc16: bad args (3 -> 64 channels, H, W >= 2, math_mode 1 / 2)"); return G6D_EINVAL;
+  }
+  const int Ho = H / 2, Wo = W / 2;
+  Conv1Norm nm = {};
+  if (mean_host && std_host) {
+    for (int c = 0; c < C1_CIN; ++c) { nm.mean[c] = mean_host[c]; nm.std[c] = std_host[c]; }
+    nm.on = 1;
+  }
+  const dim3 grid((Wo + M1_PTX - 1) / M1_PTX, (Ho + M1_PTY - 1) / M1_PTY, N);
+  if (math_mode == 1)
+    hipLaunchKernelGGL(vgg_conv1_pool_mfma_kernel<__bf16>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), in, w_oihw, bias, H, W, Ho, Wo,
+                       static_cast<__bf16*>(out16), nm);
+  else
+    hipLaunchKernelGGL(vgg_conv1_pool_mfma_kernel<_Float16>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), in, w_oihw, bias, H, W, Ho, Wo,
+                       static_cast<_Float16*>(out16), nm);
+  return g6d_check_launch("vgg_conv1_pool_mfma16");
 }
 
 #else   // ---- host emulation of the two phases, thread by thread (tests only) -------------------------------------

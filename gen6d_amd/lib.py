@@ -15,6 +15,13 @@ class G6dWinoSeg(C.Structure):
                 ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("ld_in", C.c_int32), ("ld_full", C.c_int32), ("ld_pool", C.c_int32)]
 
 
+class G6dConv16Seg(C.Structure):
+    """include/gen6d_hip.h: one map size of g6d_conv16_direct_multi (16-bit activations)."""
+    _fields_ = [("in_", C.c_void_p), ("out_full", C.c_void_p), ("out_pool", C.c_void_p),
+                ("N", C.c_int32), ("D", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("ld_in", C.c_int32), ("ld_full", C.c_int32),
+                ("ld_pool", C.c_int32)]
+
+
 class G6dCorrSeg(C.Structure):
     """include/gen6d_hip.h: one map of g6d_corr2d_patch_multi."""
     _fields_ = [("in_", C.c_void_p), ("out", C.c_void_p), ("H", C.c_int32), ("W", C.c_int32), ("ld_in", C.c_int32), ("ld_out", C.c_int32),
@@ -58,6 +65,8 @@ SIGNATURES = {
     "g6d_bias_relu_pool_nchw": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
     "g6d_vgg_conv1_pool": [_P, _I, _I, _I, _P, _P, _I, _I, _P, _P],
     "g6d_vgg_conv1_pool_nhwc": [_P, _I, _I, _I, _P, _P, _I, _I, _P, _P],
+    "g6d_vgg_conv1_pool_nhwc16": [_P, _I, _I, _I, _P, _P, _I, _I, _P, _P, _P, _I, _P],
+    "g6d_conv16_direct_multi": [_P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P],
     "g6d_vgg_conv1_pool_nhwc_norm": [_P, _I, _I, _I, _P, _P, _I, _I, _P, _P, _P, _P],
     "g6d_wino_conv3x3": [_P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _P, _I, _P, C.c_size_t, _P],
     "g6d_wino_conv3x3_multi": [_P, _I, _I, _P, _P, _I, _I, _P, C.c_size_t, _P],

@@ -176,9 +176,19 @@ class TrunkLayer(tuple):
             self._u16[dtype] = winograd_filters16(self._w, dtype)
         return self._u16[dtype]
 
+    def w16(self, dtype):
+        """The layer's (BatchNorm-folded) filters for the direct 16-bit kernel: [Cout, 9, Cin] rounded to `dtype` (g6d_conv16_direct_multi)."""
+        key = ("direct", dtype)
+        if key not in self._u16:
+            co, ci = self._w.shape[:2]
+            self._u16[key] = self._w.permute(0, 2, 3, 1).reshape(co, 9, ci).to(dtype).contiguous()
+        return self._u16[key]
+
 
 _LOWP_DTYPE = {1: torch.bfloat16, 2: torch.float16}
 LOWP_TRUNK = True        # reduced-precision mode: trunk on the 16-bit Winograd kernel (False, set by tools / tests: stays on the fp32 kernel)
+CONV16_TRUNK = True      # reduced-precision mode (round 6): trunk on 16-bit ACTIVATIONS and the direct 16-bit kernel (g6d_conv16_direct_multi:
+                         # 1.5-1.8x the 16-bit Winograd kernel per layer); False (tools / tests): the round-5 path above
 
 
 def _wino_layer(xs, layer, relu=True, full=True, pool=False, f43=False):
@@ -221,10 +231,45 @@ def vgg_taps_cl(packed, x, taps, norm=None, f43=False):
     return {k: v for k, v in out.items() if v is not None and (k in taps or k == "c7_pre")}
 
 
+def _conv16_eligible(xs, taps):
+    """The 16-bit activation path pools whole 2x2 windows only: every pooled layer's map must have even sides (the detector's pyramid
+    sizes are multiples of 32, the crops 128: always true there; other sizes keep the round-5 path, whose kernels pool with floor)."""
+    need = 32 if "p7" in taps else 16
+    return all(x.shape[2] % need == 0 and x.shape[3] % need == 0 for x in xs) and len(xs) <= 4
+
+
+def _vgg_taps_conv16(packed, xs, taps, norm):
+    """The trunk in the reduced-precision mode since round 6: activations are fp16 / bf16 channels-last from the first layer's epilogue
+    on, the seven 3x3 layers run on the direct 16-bit kernel (DMA-staged operand tiles, v_mfma_f32_32x32x16), and only the requested
+    taps are written in fp32 for their consumers."""
+    w0, b0 = packed[0]
+    t16 = _LOWP_DTYPE[ops.MATH_MODE]
+    f32 = torch.float32
+    cur = [ops.vgg_conv1_pool_nhwc16(x.contiguous(), w0, b0, norm=norm) for x in xs]       # conv0 + ReLU + pool, per size
+
+    def layer(i, cur, relu=True, full=None, pool=None):
+        return ops.conv16_direct_multi(cur, packed[i].w16(t16), packed[i][1], relu=relu, full=full, pool=pool)
+
+    _, cur = layer(1, cur, pool=t16)
+    cur, _ = layer(2, cur, full=t16)
+    c3, cur = layer(3, cur, full=f32 if "c3" in taps else None, pool=t16)
+    cur, _ = layer(4, cur, full=t16)
+    c5, cur = layer(5, cur, full=f32 if "c5" in taps else None, pool=t16)
+    cur, _ = layer(6, cur, full=t16)
+    c7, p7 = layer(7, cur, relu=False, full=f32, pool=f32 if "p7" in taps else None)
+    outs = []
+    for i in range(len(xs)):
+        d = {"c3": c3[i], "c5": c5[i], "c7_pre": c7[i], "p7": p7[i]}
+        outs.append({k: v for k, v in d.items() if v is not None and (k in taps or k == "c7_pre")})
+    return outs
+
+
 def vgg_taps_cl_multi(packed, xs, taps, norm=None, f43=False):
     """vgg_taps_cl for several image sizes at once (the scales of the detector's pyramid): every Winograd layer is ONE launch
     over all sizes (ops.wino_conv3x3_multi).  xs: list of [1,3,h_i,w_i] images (normalised, or in [0,1] with norm) -> list of
     tap dicts.  f43: the seven Winograd layers on the F(4x4,3x3) kernel (fp32 mode only)."""
+    if ops.MATH_MODE and LOWP_TRUNK and CONV16_TRUNK and hasattr(packed[1], "w16") and _conv16_eligible(xs, taps):
+        return _vgg_taps_conv16(packed, xs, taps, norm)
     w0, b0 = packed[0]
     dev = xs[0].device
     cur = ops.alloc_like_segments([(x.shape[0], x.shape[2] // 2, x.shape[3] // 2, w0.shape[0]) for x in xs], dev)

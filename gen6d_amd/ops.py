@@ -669,6 +669,71 @@ def wino16_conv3x3_multi(xs, U16, bias, relu=True, full=True, pool=False):
     return ys, yps
 
 
+_T16 = {1: torch.bfloat16, 2: torch.float16}
+
+
+def vgg_conv1_pool_nhwc16(x, w_oihw, bias, out=None, norm=None):
+    """vgg_conv1_pool_nhwc with a 16-bit channels-last result (the operand type of the current math mode): the first layer of the
+    reduced-precision mode's 16-bit activation path (g6d_vgg_conv1_pool_nhwc16)."""
+    _need_gpu(x, w_oihw, bias)
+    if not MATH_MODE:
+        raise RuntimeError("vgg_conv1_pool_nhwc16: reduced-precision mode only")
+    N, Cin, H, W = x.shape
+    Cout = w_oihw.shape[0]
+    if out is None:
+        out = torch.empty((N, H // 2, W // 2, Cout), dtype=_T16[MATH_MODE], device=x.device)
+    if out.dtype != _T16[MATH_MODE] or not out.is_contiguous() or tuple(out.shape) != (N, H // 2, W // 2, Cout):
+        raise ValueError("vgg_conv1_pool_nhwc16: out must be a dense 16-bit [N,H/2,W/2,64] tensor of the mode's type")
+    mean = std = None
+    if norm is not None:
+        mean, std = (C.c_float * 3)(*norm[0]), (C.c_float * 3)(*norm[1])
+    _lib.check(_lib.load().g6d_vgg_conv1_pool_nhwc16(_ptr(x.contiguous()), N, H, W, _ptr(w_oihw.contiguous()), _ptr(bias), Cin, Cout,
+                                                     mean, std, _ptr(out), int(MATH_MODE), _stream()), "g6d_vgg_conv1_pool_nhwc16")
+    return out
+
+
+def conv16_direct_multi(xs, w16, bias, relu=True, full=None, pool=None, kd=1, stats=None, rows_per_group=0):
+    """Direct 3x3 / 3x3x3 convolution on 16-bit activations (g6d_conv16_direct_multi; reduced-precision mode only).
+    xs: 1..4 dense channels-last 16-bit tensors [N,H,W,Cin] (kd = 1) or [N,D,H,W,Cin] (kd = 3); w16 [Cout, kd*9, Cin] of the same type.
+    full / pool: None = not produced, else torch.float32 or the 16-bit type -> lists of dense outputs [N,(D,)H,W,Cout] / [N,H/2,W/2,Cout]
+    (None where not produced).  stats [G,Cout,2] fp64 (zeroed): sum / sum of squares of the fp32 results are added."""
+    _need_gpu(w16, *xs)
+    if not MATH_MODE:
+        raise RuntimeError("conv16_direct_multi: reduced-precision mode only")
+    t16 = _T16[MATH_MODE]
+    Cout, taps, Cin = w16.shape
+    if w16.dtype != t16 or taps != 9 * kd or not w16.is_contiguous():
+        raise ValueError("conv16_direct_multi: filters must be contiguous [Cout, kd*9, Cin] of the mode's 16-bit type")
+    code = {None: 0, t16: 1, torch.float32: 2}
+    if full not in code or pool not in code:
+        raise ValueError("conv16_direct_multi: output types are None, float32 or the mode's 16-bit type")
+    segs = (_lib.G6dConv16Seg * len(xs))()
+    fulls, pools, flops, sizes, nbytes = [], [], 0.0, [], 2.0 * w16.numel()
+    for i, x in enumerate(xs):
+        if x.dtype != t16 or not x.is_contiguous() or x.dim() != (4 if kd == 1 else 5) or x.shape[-1] != Cin:
+            raise ValueError(f"conv16_direct_multi: input {i} must be a dense {t16} channels-last tensor with {Cin} channels")
+        N, D, H, W = (x.shape[0], 1, x.shape[1], x.shape[2]) if kd == 1 else tuple(x.shape[:4])
+        lead = (N, H, W) if kd == 1 else (N, D, H, W)
+        f = torch.empty(lead + (Cout,), dtype=full, device=x.device) if full is not None else None
+        q = torch.empty((N, H // 2, W // 2, Cout), dtype=pool, device=x.device) if pool is not None else None
+        fulls.append(f); pools.append(q)
+        segs[i] = _lib.G6dConv16Seg(in_=x.data_ptr(), out_full=f.data_ptr() if f is not None else None,
+                                    out_pool=q.data_ptr() if q is not None else None, N=N, D=D, H=H, W=W, ld_in=Cin, ld_full=Cout, ld_pool=Cout)
+        flops += 2.0 * N * D * H * W * Cout * taps * Cin
+        nbytes += 2.0 * x.numel() + sum(t.numel() * t.element_size() for t in (f, q) if t is not None)
+        sizes.append("x".join(str(v) for v in lead))
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.check(_lib.load().g6d_conv16_direct_multi(segs, len(xs), Cin, _ptr(w16), _ptr(bias), Cout, int(kd), int(bool(relu)), code[full], code[pool],
+                                                  int(MATH_MODE), _ptr(stats), int(rows_per_group), _stream()), "g6d_conv16_direct_multi")
+    if PROFILE is not None:
+        e1.record()
+        PROFILE.append((flops, e0, e1, f"conv16 direct in={'+'.join(sizes)}x{Cin} out={Cout} k={'3x' if kd == 3 else ''}3x3"
+                        f"{' full' if full is not None else ''}{' pool' if pool is not None else ''}{' stats' if stats is not None else ''}", nbytes, flops))
+    return fulls, pools
+
+
 def l2norm_rows(x):
     """In-place F.normalize over the last axis of a channels-last tensor whose rows are dense (ld = C), or of a 2-D row-strided
     view [rows, C] (ld = x.stride(0))."""

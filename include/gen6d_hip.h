@@ -226,6 +226,12 @@ int g6d_vgg_conv1_pool_nhwc(const float* in, int N, int H, int W, const float* w
  * while the input tile is staged — replaces the two elementwise passes of img_norm in front of every trunk call. */
 int g6d_vgg_conv1_pool_nhwc_norm(const float* in, int N, int H, int W, const float* w_oihw, const float* bias, int Cin, int Cout,
                                  const float* mean_host, const float* std_host, float* out, g6d_stream_t stream);
+/* g6d_vgg_conv1_pool_nhwc(_norm) with a 16-BIT channels-last result [N][H/2][W/2][64] (ABI v11; math_mode 1 = bf16, 2 = fp16): the first
+ * layer of the reduced-precision mode's 16-bit activation path (its output feeds g6d_conv16_direct_multi).  fp32 arithmetic, rounded
+ * once in the epilogue.  mean_host / std_host: NULL = the input is already normalised. */
+int g6d_vgg_conv1_pool_nhwc16(const float* in, int N, int H, int W, const float* w_oihw, const float* bias, int Cin, int Cout,
+                              const float* mean_host, const float* std_host, void* out16, int math_mode, g6d_stream_t stream);
+
 
 /* The 3x3 layers 64->128 ... 512->512 of the VGG-11-BN trunks (reference network/pretrain_models.py:9-31,61-72:
  * vgg11_bn features[4..28], BatchNorm folded) as Winograd F(2x2,3x3) on fp32 MFMA with the trunk's bias, ReLU and 2x2
@@ -260,6 +266,28 @@ int g6d_wino_conv3x3_multi(const G6dWinoSeg* segs, int nseg, int Cin, const floa
  * two 16-byte halves swapped, as in g6d_wino_conv3x3's U); Cin % 16 == 0, Cout % 64 == 0. */
 int g6d_wino16_conv3x3_multi(const G6dWinoSeg* segs, int nseg, int Cin, const void* U16, const float* bias, int Cout, int relu,
                              int math_mode, float* workspace, size_t workspace_bytes, g6d_stream_t stream);
+
+/* Direct (implicit-GEMM) 3x3 / 3x3x3 "same" convolution on 16-BIT ACTIVATIONS (ABI v11, round 6): the reduced-precision mode's own kernel
+ * family for the VGG trunks (reference network/pretrain_models.py:9-31,66-72; the detector's image pyramid network/detector.py:188-197,
+ * 236-241; the refiner's crops network/refiner.py:64-78) and the first convs of the refiner's 32^3 volume net (network/refiner.py:88-143).
+ * math_mode 1 = bf16, 2 = fp16: `in`, W16 and every 16-bit output hold that type; accumulation fp32 (v_mfma_f32_32x32x16_{bf16,f16}).
+ *   in     [N][D][H][W][ld_in] 16-bit, channels-last (D = 1 for the 2-D layers), Cin % 64 == 0, rows 16-byte aligned
+ *   W16    [Cout][kd*9][Cin] 16-bit, tap = (kz*3 + ky)*3 + kx, Cout % 128 == 0;  bias [Cout] fp32 or NULL
+ *   y = conv(in) + bias;  relu != 0: y = max(y, 0)
+ *   out_full [N][D][H][W][ld_full] = y        element type full_type: 0 = not written, 1 = the 16-bit type, 2 = fp32
+ *   out_pool [N][H/2][W/2][ld_pool] = maxpool2x2(y) (2-D only, H and W even)     element type pool_type, same coding
+ *   stats (optional) [groups][Cout][2] fp64, zeroed by the caller: sum and sum of squares of y (fp32 values, before rounding) per
+ *        (image group, channel) are ADDED; group of a pixel = (its index in [N][D][H][W]) / stat_rows_per_group (0 = one group)
+ * Up to 4 map sizes per launch (the scales of the detector's pyramid) like g6d_wino_conv3x3_multi; all segments share D and the
+ * kinds of output.  No workspace: the K loop is never split. */
+typedef struct G6dConv16Seg {
+  const void* in;
+  void* out_full;
+  void* out_pool;
+  int32_t N, D, H, W, ld_in, ld_full, ld_pool;
+} G6dConv16Seg;
+int g6d_conv16_direct_multi(const G6dConv16Seg* segs, int nseg, int Cin, const void* W16, const float* bias, int Cout, int kd, int relu,
+                            int full_type, int pool_type, int math_mode, double* stats, int stat_rows_per_group, g6d_stream_t stream);
 
 /* g6d_wino_conv3x3_multi on the Winograd F(4x4,3x3) kernel (ABI v8, fp32 on v_mfma_f32_16x16x4_f32): 36 multiplications per 16
  * outputs — 4x fewer than the direct form, 1.78x fewer than F(2x2,3x3) — with the interpolation points (0, +-3/4, +-3/2, inf), whose

@@ -1,0 +1,103 @@
+"""g6d_conv16_direct_multi / g6d_vgg_conv1_pool_nhwc16 (ABI v11, round 6): the reduced-precision mode's direct convolution on 16-bit
+activations, against the float64 convolution of the SAME rounded operands (the kernel's own arithmetic: exact products of 16-bit values,
+fp32 accumulation — bar 2e-5 of the output range, plus half an ulp of the output type where the output is 16-bit) on ragged multi-map
+launches, small maps that pack several images into a tile, pooled / full / fp32 / 16-bit outputs, 3x3x3 layers and statistics."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from parity_log import record
+
+pytestmark = pytest.mark.gpu
+
+T16 = {"bf16": torch.bfloat16, "fp16": torch.float16}
+ULP = {"bf16": 2.0 ** -8, "fp16": 2.0 ** -11}
+
+
+def _rand(g, *shape, scale=1.0):
+    return (torch.rand(shape, generator=g) * 2 - 1) * scale
+
+
+CASES = [
+    # segments (N, H, W) or (N, D, H, W); Cin; Cout; relu; full type; pool type; kd
+    dict(segs=[(2, 16, 24)], Cin=64, Cout=128, relu=True, full="t16", pool="t16"),
+    dict(segs=[(2, 22, 30), (1, 16, 20), (3, 6, 10)], Cin=128, Cout=256, relu=True, full="f32", pool="f32"),     # ragged widths, three maps
+    dict(segs=[(5, 8, 8)], Cin=512, Cout=512, relu=False, full="t16", pool=None),                                 # two images per tile
+    dict(segs=[(1, 44, 58), (2, 30, 40)], Cin=256, Cout=128, relu=True, full=None, pool="t16"),                   # pooled output only
+    dict(segs=[(3, 4, 4)], Cin=64, Cout=128, relu=True, full="f32", pool="t16"),                                  # 4x4 maps: 8 images per tile
+    dict(segs=[(2, 8, 8, 8)], Cin=64, Cout=128, relu=False, full="f32", pool=None, kd=3, stats=True),             # 3x3x3 with statistics
+    dict(segs=[(1, 16, 16, 16)], Cin=128, Cout=128, relu=False, full="t16", pool=None, kd=3, stats=True),
+]
+
+
+@pytest.mark.parametrize("mode", ["fp16", "bf16"])
+@pytest.mark.parametrize("case", CASES, ids=[f"case{i}" for i in range(len(CASES))])
+def test_conv16_direct_multi(mode, case):
+    from gen6d_amd import ops
+    c = case
+    kd = c.get("kd", 1)
+    t16 = T16[mode]
+    g = torch.Generator().manual_seed(31 + c["Cin"] + len(c["segs"]))
+    taps = 9 * kd
+    w = _rand(g, c["Cout"], taps, c["Cin"], scale=(1.0 / (taps * c["Cin"])) ** 0.5 * 3).to(t16)
+    b = _rand(g, c["Cout"], scale=0.2)
+    xs = [_rand(g, *s, c["Cin"]).to(t16) for s in c["segs"]]
+    ty = {"t16": t16, "f32": torch.float32, None: None}
+    groups = sum(s[0] for s in c["segs"])
+    stats = torch.zeros((c["segs"][0][0], c["Cout"], 2), dtype=torch.float64, device="cuda") if c.get("stats") else None
+    rpg = 0
+    if stats is not None:
+        s0 = c["segs"][0]
+        rpg = s0[1] * s0[2] * s0[3]
+    with ops.math_mode(mode):
+        fulls, pools = ops.conv16_direct_multi([x.cuda() for x in xs], w.cuda(), b.cuda(), relu=c["relu"], full=ty[c["full"]], pool=ty[c["pool"]],
+                                               kd=kd, stats=stats, rows_per_group=rpg)
+    torch.cuda.synchronize()
+    worst = 0.0
+    for i, x in enumerate(xs):
+        xd = x.double()
+        if kd == 1:
+            w4 = w.double().reshape(c["Cout"], 3, 3, c["Cin"]).permute(0, 3, 1, 2)
+            ref = F.conv2d(xd.permute(0, 3, 1, 2), w4, b.double(), padding=1).permute(0, 2, 3, 1)
+        else:
+            w5 = w.double().reshape(c["Cout"], 3, 3, 3, c["Cin"]).permute(0, 4, 1, 2, 3)
+            ref = F.conv3d(xd.permute(0, 4, 1, 2, 3), w5, b.double(), padding=1).permute(0, 2, 3, 4, 1)
+        if stats is not None and i == 0:
+            s1 = ref.reshape(ref.shape[0], -1, c["Cout"]).sum(1)
+            s2 = (ref * ref).reshape(ref.shape[0], -1, c["Cout"]).sum(1)
+            got = stats.cpu()
+            n = ref[0].numel() / c["Cout"]
+            assert (got[:, :, 0] - s1).abs().max() / n <= 2e-5 * ref.abs().max(), "statistics: sum"
+            assert (got[:, :, 1] - s2).abs().max() / n <= 4e-5 * ref.abs().max() ** 2, "statistics: sum of squares"
+        if c["relu"]:
+            ref = F.relu(ref)
+        rng = float(ref.abs().max())
+        if fulls[i] is not None:
+            tol = 2e-5 + (ULP[mode] if fulls[i].dtype != torch.float32 else 0.0)
+            e = float((fulls[i].cpu().double() - ref).abs().max()) / rng
+            worst = max(worst, e / tol)
+            assert e <= tol, (i, "full", e, tol)
+        if pools[i] is not None:
+            pr = F.max_pool2d(ref.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+            tol = 2e-5 + (ULP[mode] if pools[i].dtype != torch.float32 else 0.0)
+            e = float((pools[i].cpu().double() - pr).abs().max()) / rng
+            worst = max(worst, e / tol)
+            assert e <= tol, (i, "pool", e, tol)
+    record("test_conv16_direct_multi", f"{mode} {c['segs']} x{c['Cin']} -> {c['Cout']} kd={kd} (error / bar)", worst, 1.0, note="vs fp64 conv of the rounded operands")
+    assert groups > 0
+
+
+@pytest.mark.parametrize("mode", ["fp16", "bf16"])
+def test_vgg_conv1_pool_nhwc16(mode):
+    """The first trunk layer with a 16-bit result equals the fp32 kernel's result rounded once."""
+    from gen6d_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand((2, 3, 44, 60), generator=g).cuda()
+    w = _rand(g, 64, 3, 3, 3, scale=0.3).cuda()
+    b = _rand(g, 64, scale=0.1).cuda()
+    norm = ((0.485, 0.456, 0.406), (0.229, 0.224, 0.225))
+    ref = ops.vgg_conv1_pool_nhwc(x, w, b, norm=norm)
+    with ops.math_mode(mode):
+        got = ops.vgg_conv1_pool_nhwc16(x, w, b, norm=norm)
+    assert got.dtype == T16[mode]
+    assert torch.equal(got, ref.to(T16[mode]))
