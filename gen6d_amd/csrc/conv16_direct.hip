@@ -42,6 +42,8 @@ struct C16Params {
   const char* w; unsigned w_bytes; const float* bias;
   int ptiles, nN;
   double* stats; int stat_rows_per_group;                    // optional: [groups][Cout][2]
+  float acc_scale;                                           // y = acc * acc_scale + bias (the filters may carry a power-of-two scale)
+  int ablate;                                                // knob c16_ablate (timing experiments)
 };
 
 template <int MM> struct C16T;
@@ -52,9 +54,138 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t c16_rsrc(const void* p, unsign
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
 }
 
+// Epilogue shared by both kernels: two passes of 64 channels through an fp32 LDS tile [128 px][68]; bias, ReLU, then 16-byte stores.
+// Output element types (full_type / pool_type): 1 = the 16-bit type T, 2 = fp32, 3 = fp16 hi / lo PAIR [pixel][2][Cout] (hi = rn16(v),
+// lo = rn16(v - hi): the input format of the MM = 3 kernel; ld counts 16-bit elements and holds both planes).
+template <int MM>
+__device__ __forceinline__ void c16_epilogue(const C16Params& p, const C16Seg& sg, f32x16 (&acc)[2][2], char* lds, int tid, int lane, int wv, int nt,
+                                             int g0, int x0, int tw_log2) {
+  typedef typename C16T<MM>::T T;
+  typedef typename C16T<MM>::V V8;
+  const int wm = wv >> 1, wn = wv & 1;
+  const int TW = 1 << tw_log2, W = sg.W;
+  float* ep = reinterpret_cast<float*>(lds);
+  double* red = reinterpret_cast<double*>(lds + C16_BM * C16_EP_LD * 4);       // [4 quarters][64 ch][2] statistics partials
+  const int TH2 = (C16_BM >> tw_log2) >> 1, TW2 = TW >> 1;
+#pragma unroll 1
+  for (int h = 0; h < 2; ++h) {
+    const int cbase = nt * C16_BN + 64 * h;
+    if (wn == h) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt2 = 0; nt2 < 2; ++nt2) {
+          const float bv = p.bias ? p.bias[cbase + 32 * nt2 + (lane & 31)] : 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int px = 64 * wm + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            float v = fmaf(acc[mt][nt2][r], p.acc_scale, bv);
+            if (p.relu) v = fmaxf(v, 0.f);
+            ep[px * C16_EP_LD + 32 * nt2 + (lane & 31)] = v;
+          }
+        }
+    }
+    __syncthreads();
+    if (p.full_type == 1) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int px = (tid >> 3) + 32 * j, ch = (tid & 7) * 8;
+        const int g = g0 + (px >> tw_log2), x = x0 + (px & (TW - 1));
+        if (g < sg.rows && x < W) {
+          const f32x4 v0 = *reinterpret_cast<const f32x4*>(ep + px * C16_EP_LD + ch), v1 = *reinterpret_cast<const f32x4*>(ep + px * C16_EP_LD + ch + 4);
+          V8 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { o[e] = (T)v0[e]; o[4 + e] = (T)v1[e]; }
+          *reinterpret_cast<V8*>(sg.full + (((long)g * W + x) * sg.ld_full + cbase + ch) * 2) = o;
+        }
+      }
+    } else if (p.full_type == 3) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int px = (tid >> 3) + 32 * j, ch = (tid & 7) * 8;
+        const int g = g0 + (px >> tw_log2), x = x0 + (px & (TW - 1));
+        if (g < sg.rows && x < W) {
+          const f32x4 v0 = *reinterpret_cast<const f32x4*>(ep + px * C16_EP_LD + ch), v1 = *reinterpret_cast<const f32x4*>(ep + px * C16_EP_LD + ch + 4);
+          V8 hi, lo;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            hi[e] = (T)v0[e]; lo[e] = (T)(v0[e] - (float)hi[e]);
+            hi[4 + e] = (T)v1[e]; lo[4 + e] = (T)(v1[e] - (float)hi[4 + e]);
+          }
+          char* o = sg.full + (((long)g * W + x) * sg.ld_full + cbase + ch) * 2;
+          *reinterpret_cast<V8*>(o) = hi;
+          *reinterpret_cast<V8*>(o + p.Cout * 2) = lo;
+        }
+      }
+    } else if (p.full_type == 2) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int px = (tid >> 4) + 16 * j, ch = (tid & 15) * 4;
+        const int g = g0 + (px >> tw_log2), x = x0 + (px & (TW - 1));
+        if (g < sg.rows && x < W)
+          *reinterpret_cast<f32x4*>(sg.full + (((long)g * W + x) * sg.ld_full + cbase + ch) * 4) = *reinterpret_cast<const f32x4*>(ep + px * C16_EP_LD + ch);
+      }
+    }
+    if (p.pool_type) {
+      const int per = p.pool_type == 2 ? 4 : 8, chunks = 64 / per;      // channels per item, items per pooled pixel
+      for (int it = tid; it < 32 * chunks; it += 256) {
+        const int pp = it / chunks, ch = (it - pp * chunks) * per;
+        const int pry = pp / TW2, prx = pp - pry * TW2;
+        const int r00 = ((2 * pry) << tw_log2) + 2 * prx;
+        const int g = g0 + 2 * pry, x = x0 + 2 * prx;
+        if (pry < TH2 && g < sg.rows && x < W) {
+          float m[8];
+#pragma unroll
+          for (int e = 0; e < 8; e += 4) {
+            if (e < per) {
+              const f32x4 q0 = *reinterpret_cast<const f32x4*>(ep + r00 * C16_EP_LD + ch + e), q1 = *reinterpret_cast<const f32x4*>(ep + (r00 + 1) * C16_EP_LD + ch + e);
+              const f32x4 q2 = *reinterpret_cast<const f32x4*>(ep + (r00 + TW) * C16_EP_LD + ch + e), q3 = *reinterpret_cast<const f32x4*>(ep + (r00 + TW + 1) * C16_EP_LD + ch + e);
+#pragma unroll
+              for (int u = 0; u < 4; ++u) m[e + u] = fmaxf(fmaxf(q0[u], q1[u]), fmaxf(q2[u], q3[u]));
+            }
+          }
+          const long o = ((long)(g >> 1) * (W >> 1) + (x >> 1)) * sg.ld_pool + cbase + ch;
+          if (p.pool_type == 1) {
+            V8 ov;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ov[e] = (T)m[e];
+            *reinterpret_cast<V8*>(sg.pool + o * 2) = ov;
+          } else if (p.pool_type == 3) {
+            V8 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { hi[e] = (T)m[e]; lo[e] = (T)(m[e] - (float)hi[e]); }
+            *reinterpret_cast<V8*>(sg.pool + o * 2) = hi;
+            *reinterpret_cast<V8*>(sg.pool + (o + p.Cout) * 2) = lo;
+          } else {
+            f32x4 ov = {m[0], m[1], m[2], m[3]};
+            *reinterpret_cast<f32x4*>(sg.pool + o * 4) = ov;
+          }
+        }
+      }
+    }
+    if (p.stats) {
+      // per-(group, channel) sum / sum of squares of the fp32 results of the tile's VALID pixels (a tile never straddles groups)
+      const int c = tid & 63, q = tid >> 6;
+      float s1 = 0.f, s2 = 0.f;
+      for (int px = 32 * q; px < 32 * q + 32; ++px) {
+        const int g = g0 + (px >> tw_log2), x = x0 + (px & (TW - 1));
+        if (g < sg.rows && x < W) { const float v = ep[px * C16_EP_LD + c]; s1 += v; s2 += v * v; }
+      }
+      red[(q * 64 + c) * 2] = (double)s1; red[(q * 64 + c) * 2 + 1] = (double)s2;
+      __syncthreads();
+      if (tid < 128) {
+        const int cc = tid >> 1, w = tid & 1;
+        const double v = red[(0 * 64 + cc) * 2 + w] + red[(1 * 64 + cc) * 2 + w] + red[(2 * 64 + cc) * 2 + w] + red[(3 * 64 + cc) * 2 + w];
+        const int grp = p.stat_rows_per_group > 0 ? (int)(((long)g0 * W) / p.stat_rows_per_group) : 0;
+        atomicAdd(p.stats + ((long)grp * p.Cout + cbase + cc) * 2 + w, v);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 template <int MM>
 __global__ __launch_bounds__(256, 2) void conv16_kernel(const C16Params p) {
-  typedef typename C16T<MM>::T T;
   typedef typename C16T<MM>::V V8;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -111,14 +242,18 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const C16Params p) {
     const unsigned b_k = (unsigned)((tap * p.Cin + c * C16_BK) * 2);
     char* sa = lds + stage * C16_STAGE + (32 * wv) * 128;
     char* sb = sa + C16_BM * 128;
+    if (!((p.ablate & 1) && k > 1)) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const unsigned vo = (a_mask[i] >> tap & 1u) ? a_off[i] + a_k : C16_OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr)(sa + i * 1024), 16, vo, 0, 0, 0);
+      for (int i = 0; i < 4; ++i) {
+        const unsigned vo = (a_mask[i] >> tap & 1u) ? a_off[i] + a_k : C16_OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr)(sa + i * 1024), 16, vo, 0, 0, 0);
+      }
     }
+    if (!((p.ablate & 2) && k > 1)) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr)(sb + i * 1024), 16, b_off[i] + b_k, 0, 0, 0);
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr)(sb + i * 1024), 16, b_off[i] + b_k, 0, 0, 0);
+    }
   };
 
   const int wm = wv >> 1, wn = wv & 1;
@@ -138,7 +273,8 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const C16Params p) {
     const int stage = k & 1;
     if (k + 1 < nk) {
       issue(k + 1, stage ^ 1);
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      if (p.ablate) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -167,101 +303,181 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const C16Params p) {
     __builtin_amdgcn_s_barrier();                       // every wave has read this stage: the next iteration may refill it
   }
 
-  // ---- epilogue: two passes of 64 channels through an fp32 LDS tile [128 px][68]
-  float* ep = reinterpret_cast<float*>(lds);
-  double* red = reinterpret_cast<double*>(lds + C16_BM * C16_EP_LD * 4);       // [4 quarters][64 ch][2] statistics partials
-  const int TH2 = (C16_BM >> tw_log2) >> 1, TW2 = TW >> 1;
-#pragma unroll 1
-  for (int h = 0; h < 2; ++h) {
-    const int cbase = nt * C16_BN + 64 * h;
-    if (wn == h) {
+  c16_epilogue<MM>(p, sg, acc, lds, tid, lane, wv, nt, g0, x0, tw_log2);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// conv16r_kernel: the same tile with the FILTER operand kept out of LDS.  Measured on the kernel above: a wave spends as long issuing
+// its 8 LDS-DMA pieces per K step (~100 cycles each beside MFMAs) as in its 16 MFMAs.  The filters are therefore packed on the host in
+// FRAGMENT order — [channel tile][K step][ks][plane][32-channel group j][lane][8 values]: one coalesced 1 KB run per wave instruction,
+// L2-resident — and go straight into registers one K step ahead (plain global loads: ~6 cycles of issue); only the activation tile
+// takes the DMA path (4 pieces per wave and step), LDS holds 16 KB per stage, and the fragment loop reads LDS for A only.
+//   MM = 1 / 2  bf16 / fp16 operands, K step = 64 channels of one tap
+//   MM = 3      fp32-class arithmetic on the fp16 matrix cores: every operand is a PAIR of fp16 values (hi = rn16(x), lo = rn16(x - hi);
+//               gfx950's MFMA keeps fp16 subnormals, tools/ubench/mfma_f16_denorm.hip), activations [pixel][2][C] (hi plane, lo plane),
+//               acc += a_hi b_hi + a_hi b_lo + a_lo b_hi (the dropped lo x lo term is 2^-22 relative): 3 MFMAs of 32 cycles per 16 channels
+//               against 8 x 64 cycles on the fp32 matrix cores.  K step = 32 channels (two planes of 64-byte rows: the same 16 KB stage).
+template <int MM> struct C16R {
+  static constexpr int BK = MM == 3 ? 32 : 64, NP = MM == 3 ? 2 : 1, KS = BK / 16, ROWB = BK * 2, SL = ROWB / 16;
+  static constexpr int STAGE = NP * C16_BM * ROWB;            // 16 KB
+  static constexpr int RPI = 1024 / ROWB;                     // rows one DMA wave-instruction fills (8 / 16)
+};
+template <int MM> struct C16T3 { typedef typename C16T<MM == 3 ? 2 : MM>::T T; typedef typename C16T<MM == 3 ? 2 : MM>::V V; };
+
+template <int MM>
+__device__ __forceinline__ f32x16 c16_mfma(typename C16T3<MM>::V a, typename C16T3<MM>::V b, f32x16 c) {
+  if constexpr (MM == 1) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+template <int MM, int NSTAGE>
+__global__ __launch_bounds__(256, 2) void conv16r_kernel(const C16Params p) {
+  typedef typename C16T3<MM>::V V8;
+  typedef C16R<MM> R;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+  const int nt = jj % p.nN, ptile = (jj / p.nN) * 8 + xcd;
+  if (ptile >= p.ptiles) return;
+  int si = 0;
+#pragma unroll
+  for (int i = 1; i < 4; ++i) if (i < p.nseg && ptile >= p.seg[i].tile0) si = i;
+  const C16Seg& sg = p.seg[si];
+  const int t = ptile - sg.tile0;
+  const int tw_log2 = sg.tw_log2, TW = 1 << tw_log2;
+  const int tx = t % sg.tiles_x, ty = t / sg.tiles_x;
+  const int g0 = ty * (C16_BM >> tw_log2), x0 = tx * TW;
+  const int H = sg.H, W = sg.W, D = p.D;
+  const int ntaps = 9 * p.kd;
+
+  // ---- A rows this lane fills: instruction i of wave wv covers plane i / (4 / NP), rows 32 wv + RPI (i % (4 / NP)) + lane / SL
+  constexpr int NR = 4 / R::NP;                                // distinct rows per lane (4 / 2)
+  unsigned a_off[NR], a_mask[NR];
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    const int r = 32 * wv + R::RPI * i + lane / R::SL;
+    const int sw = R::SL == 8 ? (r >> 1) & 7 : (r >> 2) & 3;
+    const int slot = (lane & (R::SL - 1)) ^ sw;
+    const int g = g0 + (r >> tw_log2), x = x0 + (r & (TW - 1));
+    unsigned m = 0;
+    if (g < sg.rows && x < W) {
+      const int y = g % H, z = (g / H) % D;
+      unsigned my = (y > 0 ? 1u : 0u) | 2u | (y < H - 1 ? 4u : 0u);
+      unsigned mx = (x > 0 ? 1u : 0u) | 2u | (x < W - 1 ? 4u : 0u);
+      unsigned m9 = 0;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) if (my >> ky & 1) m9 |= mx << (3 * ky);
+      if (p.kd == 3) {
+        if (z > 0) m |= m9;
+        m |= m9 << 9;
+        if (z < D - 1) m |= m9 << 18;
+      } else m = m9;
+    }
+    a_mask[i] = m;
+    a_off[i] = (unsigned)(((long)g * W + x) * sg.ld_in * 2) + slot * 16;
+  }
+  const __amdgpu_buffer_rsrc_t rs_in = c16_rsrc(sg.in - sg.back, sg.in_bytes);
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  const int nchunk = p.Cin / R::BK, nk = nchunk * ntaps;
+  const int plane_bytes = p.Cin * 2;                            // MM = 3: the lo plane of a pixel follows its hi plane
+
+  auto issue_a = [&](int k, int stage) {
+    const int c = k / ntaps, tap = k - c * ntaps;
+    const int kz = tap / 9, r9 = tap - 9 * kz, ky = r9 / 3, kx = r9 - 3 * ky;
+    const unsigned a_k = (unsigned)(((kz * H + ky) * W + kx) * sg.ld_in * 2 + c * (R::BK * 2));
+    char* sa = lds + stage * R::STAGE;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ri = i % NR, pl = i / NR;
+      const unsigned vo = (a_mask[ri] >> tap & 1u) ? a_off[ri] + a_k + pl * plane_bytes : C16_OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr)(sa + pl * (C16_BM * R::ROWB) + (32 * wv + R::RPI * ri) * R::ROWB), 16, vo, 0, 0, 0);
+    }
+  };
+  // ---- B fragments of K step k: [ks][plane][t] 16 bytes per lane, one coalesced 1 KB run per wave instruction.  Hand-issued loads:
+  // beside LDS-DMA requests hipcc waits vmcnt(0) for any load it tracks (the whole pipeline drained every other step, ISA checked), so
+  // these are invisible to its wait-count pass and retired by the counted s_waitcnt at the end of the step that requested them.
+  const int wm = wv >> 1, wn = wv & 1;
+  constexpr int NB = R::KS * R::NP * 2;                        // 8
+  constexpr int STEP_B = R::KS * R::NP * 4 * 1024;             // bytes of one K step of one channel tile
+  const char* wtile = p.w + (long)nt * nk * STEP_B;             // (uniform)
+  const unsigned b_voff = (2 * wn) * 1024 + lane * 16;
+  auto load_b = [&](int k, V8 (&b)[NB]) {
+    const char* ws = wtile + (long)k * STEP_B;
+#pragma unroll
+    for (int q = 0; q < R::KS * R::NP; ++q) {
+      const char* wq = ws + q * 4096;
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(b[2 * q]) : "v"(b_voff), "s"(wq) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(b[2 * q + 1]) : "v"(b_voff), "s"(wq) : "memory");
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  const int frow = lane & 31, fhalf = lane >> 5;
+  const int fsw = R::SL == 8 ? (frow >> 1) & 7 : (frow >> 2) & 3;
+  const int a_rd = (64 * wm + frow) * R::ROWB;
+
+  auto compute = [&](int stage, const V8 (&b)[NB]) {
+    const char* st = lds + stage * R::STAGE;
+#pragma unroll
+    for (int ks = 0; ks < R::KS; ++ks) {
+      const int sl = ((2 * ks + fhalf) ^ fsw) * 16;
+      V8 a[R::NP][2];
+#pragma unroll
+      for (int pl = 0; pl < R::NP; ++pl) {
+        a[pl][0] = *reinterpret_cast<const V8*>(st + pl * (C16_BM * R::ROWB) + a_rd + sl);
+        a[pl][1] = *reinterpret_cast<const V8*>(st + pl * (C16_BM * R::ROWB) + a_rd + 32 * R::ROWB + sl);
+      }
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int nt2 = 0; nt2 < 2; ++nt2) {
-          const float bv = p.bias ? p.bias[cbase + 32 * nt2 + (lane & 31)] : 0.f;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int px = 64 * wm + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            float v = acc[mt][nt2][r] + bv;
-            if (p.relu) v = fmaxf(v, 0.f);
-            ep[px * C16_EP_LD + 32 * nt2 + (lane & 31)] = v;
+        for (int n2 = 0; n2 < 2; ++n2) {
+          acc[mt][n2] = c16_mfma<MM>(a[0][mt], b[(ks * R::NP) * 2 + n2], acc[mt][n2]);
+          if constexpr (MM == 3) {
+            acc[mt][n2] = c16_mfma<MM>(a[0][mt], b[(ks * R::NP + 1) * 2 + n2], acc[mt][n2]);      // hi x lo
+            acc[mt][n2] = c16_mfma<MM>(a[1][mt], b[(ks * R::NP) * 2 + n2], acc[mt][n2]);          // lo x hi
           }
         }
     }
-    __syncthreads();
-    if (p.full_type == 1) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int px = (tid >> 3) + 32 * j, ch = (tid & 7) * 8;
-        const int g = g0 + (px >> tw_log2), x = x0 + (px & (TW - 1));
-        if (g < sg.rows && x < W) {
-          const f32x4 v0 = *reinterpret_cast<const f32x4*>(ep + px * C16_EP_LD + ch), v1 = *reinterpret_cast<const f32x4*>(ep + px * C16_EP_LD + ch + 4);
-          V8 o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { o[e] = (T)v0[e]; o[4 + e] = (T)v1[e]; }
-          *reinterpret_cast<V8*>(sg.full + (((long)g * W + x) * sg.ld_full + cbase + ch) * 2) = o;
-        }
-      }
-    } else if (p.full_type == 2) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int px = (tid >> 4) + 16 * j, ch = (tid & 15) * 4;
-        const int g = g0 + (px >> tw_log2), x = x0 + (px & (TW - 1));
-        if (g < sg.rows && x < W)
-          *reinterpret_cast<f32x4*>(sg.full + (((long)g * W + x) * sg.ld_full + cbase + ch) * 4) = *reinterpret_cast<const f32x4*>(ep + px * C16_EP_LD + ch);
-      }
-    }
-    if (p.pool_type) {
-      const int per = p.pool_type == 1 ? 8 : 4, chunks = 64 / per;      // channels per item, items per pooled pixel
-      for (int it = tid; it < 32 * chunks; it += 256) {
-        const int pp = it / chunks, ch = (it - pp * chunks) * per;
-        const int pry = pp / TW2, prx = pp - pry * TW2;
-        const int r00 = ((2 * pry) << tw_log2) + 2 * prx;
-        const int g = g0 + 2 * pry, x = x0 + 2 * prx;
-        if (pry < TH2 && g < sg.rows && x < W) {
-          float m[8];
-#pragma unroll
-          for (int e = 0; e < 8; e += 4) {
-            if (e < per) {
-              const f32x4 q0 = *reinterpret_cast<const f32x4*>(ep + r00 * C16_EP_LD + ch + e), q1 = *reinterpret_cast<const f32x4*>(ep + (r00 + 1) * C16_EP_LD + ch + e);
-              const f32x4 q2 = *reinterpret_cast<const f32x4*>(ep + (r00 + TW) * C16_EP_LD + ch + e), q3 = *reinterpret_cast<const f32x4*>(ep + (r00 + TW + 1) * C16_EP_LD + ch + e);
-#pragma unroll
-              for (int u = 0; u < 4; ++u) m[e + u] = fmaxf(fmaxf(q0[u], q1[u]), fmaxf(q2[u], q3[u]));
-            }
-          }
-          const long o = ((long)(g >> 1) * (W >> 1) + (x >> 1)) * sg.ld_pool + cbase + ch;
-          if (p.pool_type == 1) {
-            V8 ov;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) ov[e] = (T)m[e];
-            *reinterpret_cast<V8*>(sg.pool + o * 2) = ov;
-          } else {
-            f32x4 ov = {m[0], m[1], m[2], m[3]};
-            *reinterpret_cast<f32x4*>(sg.pool + o * 4) = ov;
-          }
-        }
-      }
-    }
-    if (p.stats) {
-      // per-(group, channel) sum / sum of squares of the fp32 results of the tile's VALID pixels (a tile never straddles groups)
-      const int c = tid & 63, q = tid >> 6;
-      float s1 = 0.f, s2 = 0.f;
-      for (int px = 32 * q; px < 32 * q + 32; ++px) {
-        const int g = g0 + (px >> tw_log2), x = x0 + (px & (TW - 1));
-        if (g < sg.rows && x < W) { const float v = ep[px * C16_EP_LD + c]; s1 += v; s2 += v * v; }
-      }
-      red[(q * 64 + c) * 2] = (double)s1; red[(q * 64 + c) * 2 + 1] = (double)s2;
-      __syncthreads();
-      if (tid < 128) {
-        const int cc = tid >> 1, w = tid & 1;
-        const double v = red[(0 * 64 + cc) * 2 + w] + red[(1 * 64 + cc) * 2 + w] + red[(2 * 64 + cc) * 2 + w] + red[(3 * 64 + cc) * 2 + w];
-        const int grp = p.stat_rows_per_group > 0 ? (int)(((long)g0 * W) / p.stat_rows_per_group) : 0;
-        atomicAdd(p.stats + ((long)grp * p.Cout + cbase + cc) * 2 + w, v);
-      }
-    }
-    __syncthreads();
+  };
+
+  // ---- K loop, three LDS stages, ONE barrier per step.  Step k: request B(k+1) and the DMA of step k+2 (into the stage step k-1 read:
+  // every wave passed the barrier that ended it), compute step k, then retire B(k+1) and DMA(k+1) with a counted wait that leaves only
+  // this step's four DMA pieces in flight (requests return in order), and meet at the barrier — which both frees stage k % 3 and
+  // publishes everybody's DMA(k+1).
+  static_assert(NSTAGE == 3, "the stage arithmetic below assumes three stages");
+  V8 b0[NB], b1[NB];
+  load_b(0, b0);
+  issue_a(0, 0);
+  if (nk > 1) { issue_a(1, 1); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  int stage = 0;
+  auto step = [&](int k, const V8 (&bc)[NB], V8 (&bn)[NB]) {
+    if (k + 1 < nk && !((p.ablate & 2) && k > 1)) load_b(k + 1, bn);
+    const int s2 = stage >= 1 ? stage - 1 : 2;               // (stage + 2) % 3
+    if (k + 2 < nk && !((p.ablate & 1) && k > 1)) issue_a(k + 2, s2);
+    compute(stage, bc);
+    if (k + 2 < nk && !p.ablate) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    stage = stage == 2 ? 0 : stage + 1;
+  };
+#pragma unroll 1
+  for (int k = 0; k < nk; k += 2) {
+    step(k, b0, b1);
+    if (k + 1 < nk) step(k + 1, b1, b0);
   }
+  c16_epilogue<MM == 3 ? 2 : MM>(p, sg, acc, lds, tid, lane, wv, nt, g0, x0, tw_log2);
 }
 
 int c16_pick_tw(int W, int pool) {
@@ -276,18 +492,25 @@ int c16_pick_tw(int W, int pool) {
 
 }  // namespace
 
-extern "C" int g6d_conv16_direct_multi(const G6dConv16Seg* segs, int nseg, int Cin, const void* W16, const float* bias, int Cout, int kd,
-                                       int relu, int full_type, int pool_type, int math_mode, double* stats, int stat_rows_per_group,
-                                       g6d_stream_t stream) {
+extern "C" int g6d_conv16_direct_multi(const G6dConv16Seg* segs, int nseg, int Cin, const void* W16, int w_layout, float acc_scale,
+                                       const float* bias, int Cout, int kd, int relu, int full_type, int pool_type, int math_mode, double* stats,
+                                       int stat_rows_per_group, g6d_stream_t stream) {
   if (!segs || nseg < 1 || nseg > 4 || !W16) { g6d_set_error("conv16_direct: 1..4 segments and filters expected"); return G6D_EINVAL; }
-  if (math_mode != 1 && math_mode != 2) { g6d_set_error("conv16_direct: math_mode 1 (bf16) or 2 (fp16)"); return G6D_EINVAL; }
-  if (Cin % C16_BK || Cout % C16_BN || (kd != 1 && kd != 3)) { g6d_set_error("conv16_direct: Cin % 64, Cout % 128, kd in {1,3} expected"); return G6D_EINVAL; }
-  if (full_type < 0 || full_type > 2 || pool_type < 0 || pool_type > 2 || (!full_type && !pool_type && !stats)) { g6d_set_error("conv16_direct: output types"); return G6D_EINVAL; }
+  if (math_mode < 1 || math_mode > 3 || (w_layout != 0 && w_layout != 1) || (math_mode == 3 && w_layout != 1)) {
+    g6d_set_error("conv16_direct: math_mode 1 (bf16) / 2 (fp16) / 3 (fp16 hi-lo pairs, fragment-major filters only)"); return G6D_EINVAL;
+  }
+  const int bk = math_mode == 3 ? 32 : C16_BK, planes = math_mode == 3 ? 2 : 1;
+  if (Cin % bk || Cout % C16_BN || (kd != 1 && kd != 3)) { g6d_set_error("conv16_direct: Cin % 64 (32 for pairs), Cout % 128, kd in {1,3} expected"); return G6D_EINVAL; }
+  const int t16 = math_mode == 3 ? 3 : 1;                    // the 16-bit output coding of this mode
+  auto type_ok = [&](int t) { return t == 0 || t == 2 || t == t16; };
+  if (!type_ok(full_type) || !type_ok(pool_type) || (!full_type && !pool_type && !stats)) { g6d_set_error("conv16_direct: output types"); return G6D_EINVAL; }
   if (pool_type && kd != 1) { g6d_set_error("conv16_direct: pooling is 2-D only"); return G6D_EINVAL; }
   C16Params p = {};
   p.nseg = nseg; p.Cin = Cin; p.Cout = Cout; p.kd = kd; p.relu = relu; p.full_type = full_type; p.pool_type = pool_type;
   p.w = static_cast<const char*>(W16); p.bias = bias; p.stats = stats; p.stat_rows_per_group = stat_rows_per_group;
-  const long wb = (long)Cout * 9 * kd * Cin * 2;
+  p.acc_scale = acc_scale != 0.f ? acc_scale : 1.f;
+  p.ablate = (int)g6d_knob(G6D_KNOB_C16_ABLATE);
+  const long wb = (long)Cout * 9 * kd * Cin * 2 * planes;
   if (wb >= (1L << 31)) { g6d_set_error("conv16_direct: filters beyond 2 GB"); return G6D_EINVAL; }
   p.w_bytes = (unsigned)wb;
   p.nN = Cout / C16_BN;
@@ -295,8 +518,9 @@ extern "C" int g6d_conv16_direct_multi(const G6dConv16Seg* segs, int nseg, int C
   for (int i = 0; i < nseg; ++i) {
     const G6dConv16Seg& s = segs[i];
     C16Seg& o = p.seg[i];
-    if (!s.in || s.N < 1 || s.D < 1 || s.H < 1 || s.W < 1 || s.ld_in < Cin || s.D != D0 || (kd == 1 && s.D != 1)) { g6d_set_error("conv16_direct: bad segment"); return G6D_EINVAL; }
-    if ((full_type && (!s.out_full || s.ld_full < Cout)) || (pool_type && (!s.out_pool || s.ld_pool < Cout || (s.H & 1) || (s.W & 1)))) {
+    if (!s.in || s.N < 1 || s.D < 1 || s.H < 1 || s.W < 1 || s.ld_in < planes * Cin || s.D != D0 || (kd == 1 && s.D != 1)) { g6d_set_error("conv16_direct: bad segment"); return G6D_EINVAL; }
+    const int need_full = full_type == 3 ? 2 * Cout : Cout, need_pool = pool_type == 3 ? 2 * Cout : Cout;
+    if ((full_type && (!s.out_full || s.ld_full < need_full)) || (pool_type && (!s.out_pool || s.ld_pool < need_pool || (s.H & 1) || (s.W & 1)))) {
       g6d_set_error("conv16_direct: outputs missing / odd map with pooling"); return G6D_EINVAL;
     }
     if (!g6d_aligned16(s.in) || (s.ld_in & 7) || (full_type && (!g6d_aligned16(s.out_full) || (s.ld_full & 7))) || (pool_type && (!g6d_aligned16(s.out_pool) || (s.ld_pool & 7)))) {
@@ -321,12 +545,26 @@ extern "C" int g6d_conv16_direct_multi(const G6dConv16Seg* segs, int nseg, int C
   p.ptiles = tiles;
   const int blocks = (tiles + 7) / 8 * 8 * p.nN;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (math_mode == 1) {
-    g6d_allow_lds(reinterpret_cast<const void*>(&conv16_kernel<1>), C16_LDS);
-    hipLaunchKernelGGL(conv16_kernel<1>, dim3(blocks), dim3(256), C16_LDS, st, p);
-  } else {
-    g6d_allow_lds(reinterpret_cast<const void*>(&conv16_kernel<2>), C16_LDS);
-    hipLaunchKernelGGL(conv16_kernel<2>, dim3(blocks), dim3(256), C16_LDS, st, p);
+  if (w_layout == 0) {
+    if (math_mode == 1) {
+      g6d_allow_lds(reinterpret_cast<const void*>(&conv16_kernel<1>), C16_LDS);
+      hipLaunchKernelGGL(conv16_kernel<1>, dim3(blocks), dim3(256), C16_LDS, st, p);
+    } else {
+      g6d_allow_lds(reinterpret_cast<const void*>(&conv16_kernel<2>), C16_LDS);
+      hipLaunchKernelGGL(conv16_kernel<2>, dim3(blocks), dim3(256), C16_LDS, st, p);
+    }
+    return g6d_check_launch("conv16_direct");
   }
-  return g6d_check_launch("conv16_direct");
+  constexpr int NST = 3, LDSR = NST * 16384;                   // three 16 KB stages (>= the epilogue's 38.9 KB tile)
+  if (math_mode == 1) {
+    g6d_allow_lds(reinterpret_cast<const void*>(&conv16r_kernel<1, NST>), LDSR);
+    hipLaunchKernelGGL((conv16r_kernel<1, NST>), dim3(blocks), dim3(256), LDSR, st, p);
+  } else if (math_mode == 2) {
+    g6d_allow_lds(reinterpret_cast<const void*>(&conv16r_kernel<2, NST>), LDSR);
+    hipLaunchKernelGGL((conv16r_kernel<2, NST>), dim3(blocks), dim3(256), LDSR, st, p);
+  } else {
+    g6d_allow_lds(reinterpret_cast<const void*>(&conv16r_kernel<3, NST>), LDSR);
+    hipLaunchKernelGGL((conv16r_kernel<3, NST>), dim3(blocks), dim3(256), LDSR, st, p);
+  }
+  return g6d_check_launch("conv16r_direct");
 }

@@ -141,7 +141,9 @@ __global__ void __launch_bounds__(C1_THREADS) vgg_conv1_pool_kernel(const float*
 
 // OT: element type of the channels-last result — float, or (round 6, the reduced-precision mode's 16-bit activation path: the input of
 // g6d_conv16_direct_multi) _Float16 / __bf16, rounded once here.
-template <typename OT>
+// PAIR (round 6): fp16 hi / lo pairs [pixel][2][64] — hi = rn16(v), lo = rn16(v - hi) — the input format of the fp32 path's
+// split-precision trunk kernel (g6d_conv16_direct_multi, math_mode 3).
+template <typename OT, bool PAIR = false>
 __global__ void __launch_bounds__(256) vgg_conv1_pool_mfma_kernel(const float* __restrict__ in, const float* __restrict__ w_oihw,
                                                                   const float* __restrict__ bias, int H, int W, int Ho, int Wo,
                                                                   OT* __restrict__ out, const Conv1Norm nm) {
@@ -196,8 +198,10 @@ __global__ void __launch_bounds__(256) vgg_conv1_pool_mfma_kernel(const float* _
         if (px < Wo) {
           const float m0 = fmaxf(fmaxf(acc0[4 * j], acc0[4 * j + 1]), fmaxf(acc0[4 * j + 2], acc0[4 * j + 3])) + b0;   // max(a)+b == max(a+b)
           const float m1 = fmaxf(fmaxf(acc1[4 * j], acc1[4 * j + 1]), fmaxf(acc1[4 * j + 2], acc1[4 * j + 3])) + b1;
-          OT* o = out + ((size_t)(n * Ho + py) * Wo + px) * C1_COUT;
-          o[li] = (OT)fmaxf(m0, 0.f); o[li + 32] = (OT)fmaxf(m1, 0.f);         // relu(max) == max(relu)
+          OT* o = out + ((size_t)(n * Ho + py) * Wo + px) * (PAIR ? 2 * C1_COUT : C1_COUT);
+          const float r0 = fmaxf(m0, 0.f), r1 = fmaxf(m1, 0.f);               // relu(max) == max(relu)
+          o[li] = (OT)r0; o[li + 32] = (OT)r1;
+          if constexpr (PAIR) { o[C1_COUT + li] = (OT)(r0 - (float)(OT)r0); o[C1_COUT + li + 32] = (OT)(r1 - (float)(OT)r1); }
         }
       }
     }
@@ -251,12 +255,13 @@ extern "C" int g6d_vgg_conv1_pool_nhwc_norm(const float* in, int N, int H, int W
 }
 
 // The same layer with a 16-BIT channels-last result (math_mode 1 = bf16, 2 = fp16; ABI v11): the first layer of the reduced-precision
-// mode's 16-bit activation path, rounded once in the epilogue.  mean_host / std_host may be NULL (already normalised input).
+// mode's 16-bit activation path, rounded once in the epilogue; math_mode 3: fp16 hi / lo pairs [N][H/2][W/2][2][64], the first layer of
+// the fp32 path's split-precision trunk.  mean_host / std_host may be NULL (already normalised input).
 extern "C" int g6d_vgg_conv1_pool_nhwc16(const float* in, int N, int H, int W, const float* w_oihw, const float* bias, int Cin, int Cout,
                                          const float* mean_host, const float* std_host, void* out16, int math_mode, g6d_stream_t stream) {
   if (!in || !w_oihw || !bias || !out16 || N <= 0 || N > 65535 || H < 2 || W < 2 || Cin != C1_CIN || Cout != C1_COUT ||
-      (math_mode != 1 && math_mode != 2) || (long long)N * Cout * (H / 2) * (W / 2) >= (1ll << 31)) {
-    g6d_set_error("vgg_conv1_pool_nhwc16: bad args (3 -> 64 channels, H, W >= 2, math_mode 1 / 2)"); return G6D_EINVAL;
+      math_mode < 1 || math_mode > 3 || (long long)N * Cout * (H / 2) * (W / 2) >= (1ll << 30)) {
+    g6d_set_error("vgg_conv1_pool_nhwc16: bad args (3 -> 64 channels, H, W >= 2, math_mode 1 / 2 / 3)"); return G6D_EINVAL;
   }
   const int Ho = H / 2, Wo = W / 2;
   Conv1Norm nm = {};
@@ -268,9 +273,12 @@ extern "C" int g6d_vgg_conv1_pool_nhwc16(const float* in, int N, int H, int W, c
   if (math_mode == 1)
     hipLaunchKernelGGL(vgg_conv1_pool_mfma_kernel<__bf16>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), in, w_oihw, bias, H, W, Ho, Wo,
                        static_cast<__bf16*>(out16), nm);
-  else
+  else if (math_mode == 2)
     hipLaunchKernelGGL(vgg_conv1_pool_mfma_kernel<_Float16>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), in, w_oihw, bias, H, W, Ho, Wo,
                        static_cast<_Float16*>(out16), nm);
+  else
+    hipLaunchKernelGGL((vgg_conv1_pool_mfma_kernel<_Float16, true>), grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), in, w_oihw, bias, H, W,
+                       Ho, Wo, static_cast<_Float16*>(out16), nm);
   return g6d_check_launch("vgg_conv1_pool_mfma16");
 }
 

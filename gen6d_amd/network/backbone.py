@@ -176,12 +176,15 @@ class TrunkLayer(tuple):
             self._u16[dtype] = winograd_filters16(self._w, dtype)
         return self._u16[dtype]
 
-    def w16(self, dtype):
-        """The layer's (BatchNorm-folded) filters for the direct 16-bit kernel: [Cout, 9, Cin] rounded to `dtype` (g6d_conv16_direct_multi)."""
-        key = ("direct", dtype)
+    def w16(self, mode):
+        """The layer's (BatchNorm-folded) filters for the direct kernel on 16-bit activations (ops.conv16_pack, fragment-major): mode 1 / 2 =
+        rounded to bf16 / fp16 (the reduced-precision mode), 3 = fp16 hi / lo pairs (the fp32 path's split-precision trunk)."""
+        key = ("direct", mode)
         if key not in self._u16:
             co, ci = self._w.shape[:2]
-            self._u16[key] = self._w.permute(0, 2, 3, 1).reshape(co, 9, ci).to(dtype).contiguous()
+            # bf16 / fp16: both operand tiles through LDS (measured 9 % faster than filters in registers: the register variant pulls every
+            # filter fragment once per wave instead of once per block, profiles/r06_conv16_bench.md); pairs: fragment-major filters in registers
+            self._u16[key] = ops.conv16_pack(self._w.permute(0, 2, 3, 1).reshape(co, 9, ci).contiguous(), mode, layout=1 if mode == 3 else 0)
         return self._u16[key]
 
 
@@ -189,6 +192,10 @@ _LOWP_DTYPE = {1: torch.bfloat16, 2: torch.float16}
 LOWP_TRUNK = True        # reduced-precision mode: trunk on the 16-bit Winograd kernel (False, set by tools / tests: stays on the fp32 kernel)
 CONV16_TRUNK = True      # reduced-precision mode (round 6): trunk on 16-bit ACTIVATIONS and the direct 16-bit kernel (g6d_conv16_direct_multi:
                          # 1.5-1.8x the 16-bit Winograd kernel per layer); False (tools / tests): the round-5 path above
+SPLIT16_TRUNK = True     # fp32 path (round 6): the trunks that ran on the F(4x4,3x3) kernel (detector pyramid, refiner crops) on the SAME direct
+                         # kernel with every operand a pair of fp16 values (hi + lo, 22+ significand bits; 3 MFMAs per product on the 16-bit
+                         # matrix cores instead of the fp32 ones): fp32-class results — smaller error than F(4x4,3x3)'s — at 1.3-1.6x its speed.
+                         # False (tools / tests): the F(4x4,3x3) kernel of rounds 4-5
 
 
 def _wino_layer(xs, layer, relu=True, full=True, pool=False, f43=False):
@@ -238,17 +245,18 @@ def _conv16_eligible(xs, taps):
     return all(x.shape[2] % need == 0 and x.shape[3] % need == 0 for x in xs) and len(xs) <= 4
 
 
-def _vgg_taps_conv16(packed, xs, taps, norm):
-    """The trunk in the reduced-precision mode since round 6: activations are fp16 / bf16 channels-last from the first layer's epilogue
-    on, the seven 3x3 layers run on the direct 16-bit kernel (DMA-staged operand tiles, v_mfma_f32_32x32x16), and only the requested
-    taps are written in fp32 for their consumers."""
+def _vgg_taps_conv16(packed, xs, taps, norm, mode):
+    """The trunk on 16-bit activations (round 6): from the first layer's epilogue on the maps are fp16 / bf16 channels-last (mode 1 / 2:
+    the reduced-precision mode) or fp16 hi / lo PAIRS (mode 3: the fp32 path), the seven 3x3 layers run on the direct kernel
+    (DMA-staged activation tiles, filters in registers, v_mfma_f32_32x32x16), and only the requested taps are written in fp32 for their
+    consumers."""
     w0, b0 = packed[0]
-    t16 = _LOWP_DTYPE[ops.MATH_MODE]
+    t16 = "t16"
     f32 = torch.float32
-    cur = [ops.vgg_conv1_pool_nhwc16(x.contiguous(), w0, b0, norm=norm) for x in xs]       # conv0 + ReLU + pool, per size
+    cur = [ops.vgg_conv1_pool_nhwc16(x.contiguous(), w0, b0, norm=norm, mode=mode) for x in xs]       # conv0 + ReLU + pool, per size
 
     def layer(i, cur, relu=True, full=None, pool=None):
-        return ops.conv16_direct_multi(cur, packed[i].w16(t16), packed[i][1], relu=relu, full=full, pool=pool)
+        return ops.conv16_direct_multi(cur, packed[i].w16(mode), packed[i][1], relu=relu, full=full, pool=pool)
 
     _, cur = layer(1, cur, pool=t16)
     cur, _ = layer(2, cur, full=t16)
@@ -269,7 +277,9 @@ def vgg_taps_cl_multi(packed, xs, taps, norm=None, f43=False):
     over all sizes (ops.wino_conv3x3_multi).  xs: list of [1,3,h_i,w_i] images (normalised, or in [0,1] with norm) -> list of
     tap dicts.  f43: the seven Winograd layers on the F(4x4,3x3) kernel (fp32 mode only)."""
     if ops.MATH_MODE and LOWP_TRUNK and CONV16_TRUNK and hasattr(packed[1], "w16") and _conv16_eligible(xs, taps):
-        return _vgg_taps_conv16(packed, xs, taps, norm)
+        return _vgg_taps_conv16(packed, xs, taps, norm, ops.MATH_MODE)
+    if f43 and not ops.MATH_MODE and SPLIT16_TRUNK and hasattr(packed[1], "w16") and _conv16_eligible(xs, taps):
+        return _vgg_taps_conv16(packed, xs, taps, norm, 3)
     w0, b0 = packed[0]
     dev = xs[0].device
     cur = ops.alloc_like_segments([(x.shape[0], x.shape[2] // 2, x.shape[3] // 2, w0.shape[0]) for x in xs], dev)

@@ -669,67 +669,122 @@ def wino16_conv3x3_multi(xs, U16, bias, relu=True, full=True, pool=False):
     return ys, yps
 
 
-_T16 = {1: torch.bfloat16, 2: torch.float16}
+_T16 = {1: torch.bfloat16, 2: torch.float16, 3: torch.float16}
 
 
-def vgg_conv1_pool_nhwc16(x, w_oihw, bias, out=None, norm=None):
-    """vgg_conv1_pool_nhwc with a 16-bit channels-last result (the operand type of the current math mode): the first layer of the
-    reduced-precision mode's 16-bit activation path (g6d_vgg_conv1_pool_nhwc16)."""
+class Conv16Filters:
+    """Filters of g6d_conv16_direct_multi: `data` (16-bit, flat), `layout` (0 = [Cout][taps][Cin] rows, 1 = fragment-major), `mode`
+    (1 bf16, 2 fp16, 3 fp16 hi / lo pairs), `acc_scale` (1 / the power-of-two scale the filters carry), and the layer's shape."""
+
+    def __init__(self, data, layout, mode, acc_scale, Cout, taps, Cin):
+        self.data, self.layout, self.mode, self.acc_scale, self.Cout, self.taps, self.Cin = data, layout, mode, acc_scale, Cout, taps, Cin
+
+
+def conv16_pack(w_taps, mode, layout=1):
+    """[Cout, taps, Cin] fp32 filters (tap = (kz*3 + ky)*3 + kx) -> Conv16Filters for `mode` (1 bf16, 2 fp16, 3 fp16 hi / lo pairs).
+    layout 1 (fragment-major, include/gen6d_hip.h): [Cout/128][Cin/BK][taps][BK/16][planes][4][64 lanes][8], BK = 64 (pairs: 32), lane l
+    of group j holds filter co = 128 tile + 32 j + (l & 31), ci = BK slice + 16 ks + 8 (l >> 5) + e.  Mode 3: the filters are scaled by an
+    exact power of two S (their lo parts stay normal fp16 numbers; the kernel multiplies the accumulators by 1 / S) and split in fp64."""
+    co, taps, ci = w_taps.shape
+    bk = 32 if mode == 3 else 64
+    if co % 128 or ci % bk:
+        raise ValueError("conv16_pack: Cout % 128 == 0 and Cin % 64 (pairs: 32) == 0 expected")
+    acc_scale = 1.0
+    if mode == 3:
+        import math
+        amax = float(w_taps.abs().max())
+        S = 2.0 ** min(14, math.floor(math.log2(2048.0 / max(amax, 1e-30))))
+        w = w_taps.double() * S
+        hi = w.to(torch.float16)
+        lo = (w - hi.double()).to(torch.float16)
+        planes = torch.stack([hi, lo], 0)
+        acc_scale = 1.0 / S
+    else:
+        planes = w_taps.to(_T16[mode])[None]
+    if layout == 0:
+        if mode == 3:
+            raise ValueError("conv16_pack: pairs need the fragment-major layout")
+        return Conv16Filters(planes[0].contiguous(), 0, mode, 1.0, co, taps, ci)
+    P, ks = planes.shape[0], bk // 16
+    x = planes.reshape(P, co // 128, 4, 32, taps, ci // bk, ks, 2, 8)           # P, tile, j, l31, tap, slice, ks, half, e
+    x = x.permute(1, 5, 4, 6, 0, 2, 7, 3, 8).contiguous()                        # tile, slice, tap, ks, P, j, half, l31, e
+    return Conv16Filters(x.reshape(-1), 1, mode, acc_scale, co, taps, ci)
+
+
+def vgg_conv1_pool_nhwc16(x, w_oihw, bias, out=None, norm=None, mode=None):
+    """vgg_conv1_pool_nhwc with a 16-bit channels-last result (g6d_vgg_conv1_pool_nhwc16): mode 1 / 2 (default: the current math mode) =
+    bf16 / fp16 [N,H/2,W/2,64], the first layer of the reduced-precision mode's 16-bit activation path; mode 3 = fp16 hi / lo pairs
+    [N,H/2,W/2,2,64], the first layer of the fp32 path's split-precision trunk."""
     _need_gpu(x, w_oihw, bias)
-    if not MATH_MODE:
-        raise RuntimeError("vgg_conv1_pool_nhwc16: reduced-precision mode only")
+    mode = MATH_MODE if mode is None else mode
+    if mode not in _T16:
+        raise RuntimeError("vgg_conv1_pool_nhwc16: mode 1 (bf16), 2 (fp16) or 3 (fp16 pairs)")
     N, Cin, H, W = x.shape
     Cout = w_oihw.shape[0]
+    shape = (N, H // 2, W // 2, 2, Cout) if mode == 3 else (N, H // 2, W // 2, Cout)
     if out is None:
-        out = torch.empty((N, H // 2, W // 2, Cout), dtype=_T16[MATH_MODE], device=x.device)
-    if out.dtype != _T16[MATH_MODE] or not out.is_contiguous() or tuple(out.shape) != (N, H // 2, W // 2, Cout):
-        raise ValueError("vgg_conv1_pool_nhwc16: out must be a dense 16-bit [N,H/2,W/2,64] tensor of the mode's type")
+        out = torch.empty(shape, dtype=_T16[mode], device=x.device)
+    if out.dtype != _T16[mode] or not out.is_contiguous() or tuple(out.shape) != shape:
+        raise ValueError(f"vgg_conv1_pool_nhwc16: out must be a dense {_T16[mode]} tensor of shape {shape}")
     mean = std = None
     if norm is not None:
         mean, std = (C.c_float * 3)(*norm[0]), (C.c_float * 3)(*norm[1])
     _lib.check(_lib.load().g6d_vgg_conv1_pool_nhwc16(_ptr(x.contiguous()), N, H, W, _ptr(w_oihw.contiguous()), _ptr(bias), Cin, Cout,
-                                                     mean, std, _ptr(out), int(MATH_MODE), _stream()), "g6d_vgg_conv1_pool_nhwc16")
+                                                     mean, std, _ptr(out), int(mode), _stream()), "g6d_vgg_conv1_pool_nhwc16")
     return out
 
 
-def conv16_direct_multi(xs, w16, bias, relu=True, full=None, pool=None, kd=1, stats=None, rows_per_group=0):
-    """Direct 3x3 / 3x3x3 convolution on 16-bit activations (g6d_conv16_direct_multi; reduced-precision mode only).
-    xs: 1..4 dense channels-last 16-bit tensors [N,H,W,Cin] (kd = 1) or [N,D,H,W,Cin] (kd = 3); w16 [Cout, kd*9, Cin] of the same type.
-    full / pool: None = not produced, else torch.float32 or the 16-bit type -> lists of dense outputs [N,(D,)H,W,Cout] / [N,H/2,W/2,Cout]
+def conv16_direct_multi(xs, filt, bias, relu=True, full=None, pool=None, kd=1, stats=None, rows_per_group=0):
+    """Direct 3x3 / 3x3x3 convolution on 16-bit activations (g6d_conv16_direct_multi).  filt: Conv16Filters (conv16_pack); its mode
+    decides the arithmetic: 1 / 2 = bf16 / fp16 operands (the reduced-precision mode), 3 = fp16 hi / lo pairs (fp32-class results: the
+    fp32 path's trunk).  xs: 1..4 dense channels-last tensors of the mode's 16-bit type, [N,H,W,Cin] (kd = 1) or [N,D,H,W,Cin] (kd = 3);
+    pairs carry an extra plane axis in front of the channels: [N,H,W,2,Cin].
+    full / pool: None = not produced, torch.float32, or "t16" = the mode's 16-bit format (pairs for mode 3) -> lists of dense outputs
     (None where not produced).  stats [G,Cout,2] fp64 (zeroed): sum / sum of squares of the fp32 results are added."""
-    _need_gpu(w16, *xs)
-    if not MATH_MODE:
-        raise RuntimeError("conv16_direct_multi: reduced-precision mode only")
-    t16 = _T16[MATH_MODE]
-    Cout, taps, Cin = w16.shape
-    if w16.dtype != t16 or taps != 9 * kd or not w16.is_contiguous():
-        raise ValueError("conv16_direct_multi: filters must be contiguous [Cout, kd*9, Cin] of the mode's 16-bit type")
-    code = {None: 0, t16: 1, torch.float32: 2}
+    _need_gpu(filt.data, *xs)
+    mode = filt.mode
+    t16 = _T16[mode]
+    Cout, taps, Cin = filt.Cout, filt.taps, filt.Cin
+    if taps != 9 * kd:
+        raise ValueError("conv16_direct_multi: filters / kd mismatch")
+    pair = mode == 3
+    code = {None: 0, "t16": 3 if pair else 1, torch.float32: 2}
     if full not in code or pool not in code:
-        raise ValueError("conv16_direct_multi: output types are None, float32 or the mode's 16-bit type")
+        raise ValueError('conv16_direct_multi: output types are None, torch.float32 or "t16"')
     segs = (_lib.G6dConv16Seg * len(xs))()
-    fulls, pools, flops, sizes, nbytes = [], [], 0.0, [], 2.0 * w16.numel()
+    fulls, pools, flops, sizes, nbytes = [], [], 0.0, [], 2.0 * filt.data.numel()
+    nd = (4 if kd == 1 else 5) + (1 if pair else 0)
     for i, x in enumerate(xs):
-        if x.dtype != t16 or not x.is_contiguous() or x.dim() != (4 if kd == 1 else 5) or x.shape[-1] != Cin:
-            raise ValueError(f"conv16_direct_multi: input {i} must be a dense {t16} channels-last tensor with {Cin} channels")
+        if x.dtype != t16 or not x.is_contiguous() or x.dim() != nd or x.shape[-1] != Cin or (pair and x.shape[-2] != 2):
+            raise ValueError(f"conv16_direct_multi: input {i} must be a dense {t16} channels-last tensor with {Cin} channels{' in hi / lo planes' if pair else ''}")
         N, D, H, W = (x.shape[0], 1, x.shape[1], x.shape[2]) if kd == 1 else tuple(x.shape[:4])
         lead = (N, H, W) if kd == 1 else (N, D, H, W)
-        f = torch.empty(lead + (Cout,), dtype=full, device=x.device) if full is not None else None
-        q = torch.empty((N, H // 2, W // 2, Cout), dtype=pool, device=x.device) if pool is not None else None
+
+        def alloc(kind, lead_):
+            if kind is None:
+                return None
+            if kind == "t16":
+                return torch.empty(lead_ + ((2, Cout) if pair else (Cout,)), dtype=t16, device=x.device)
+            return torch.empty(lead_ + (Cout,), dtype=torch.float32, device=x.device)
+        f, q = alloc(full, lead), alloc(pool, (N, H // 2, W // 2))
         fulls.append(f); pools.append(q)
+        ld = lambda t_: (2 * Cout if t_.dtype != torch.float32 and pair else Cout)
         segs[i] = _lib.G6dConv16Seg(in_=x.data_ptr(), out_full=f.data_ptr() if f is not None else None,
-                                    out_pool=q.data_ptr() if q is not None else None, N=N, D=D, H=H, W=W, ld_in=Cin, ld_full=Cout, ld_pool=Cout)
+                                    out_pool=q.data_ptr() if q is not None else None, N=N, D=D, H=H, W=W, ld_in=(2 if pair else 1) * Cin,
+                                    ld_full=ld(f) if f is not None else 0, ld_pool=ld(q) if q is not None else 0)
         flops += 2.0 * N * D * H * W * Cout * taps * Cin
-        nbytes += 2.0 * x.numel() + sum(t.numel() * t.element_size() for t in (f, q) if t is not None)
+        nbytes += x.numel() * 2.0 + sum(t.numel() * t.element_size() for t in (f, q) if t is not None)
         sizes.append("x".join(str(v) for v in lead))
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.check(_lib.load().g6d_conv16_direct_multi(segs, len(xs), Cin, _ptr(w16), _ptr(bias), Cout, int(kd), int(bool(relu)), code[full], code[pool],
-                                                  int(MATH_MODE), _ptr(stats), int(rows_per_group), _stream()), "g6d_conv16_direct_multi")
+    _lib.check(_lib.load().g6d_conv16_direct_multi(segs, len(xs), Cin, _ptr(filt.data), int(filt.layout), float(filt.acc_scale), _ptr(bias), Cout, int(kd),
+                                                  int(bool(relu)), code[full], code[pool], int(mode), _ptr(stats), int(rows_per_group), _stream()),
+               "g6d_conv16_direct_multi")
     if PROFILE is not None:
         e1.record()
-        PROFILE.append((flops, e0, e1, f"conv16 direct in={'+'.join(sizes)}x{Cin} out={Cout} k={'3x' if kd == 3 else ''}3x3"
+        # mode 3 executes three 16-bit MFMAs per product: booked as "conv16x3" with the DIRECT-FORM flops (what the fp32 kernels it replaces are booked with / 4)
+        PROFILE.append((flops, e0, e1, f"{'conv16x3' if pair else 'conv16'} direct in={'+'.join(sizes)}x{Cin} out={Cout} k={'3x' if kd == 3 else ''}3x3"
                         f"{' full' if full is not None else ''}{' pool' if pool is not None else ''}{' stats' if stats is not None else ''}", nbytes, flops))
     return fulls, pools
 

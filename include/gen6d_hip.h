@@ -39,7 +39,7 @@ const char* g6d_last_error(void);
 /* Launch-policy knobs.  The library reads NO environment variable: every dispatch decision that tools/ and tests want to force (a kernel
  * variant for an A/B run, a constant of a split model for a sweep) is a named knob with the product default — conv_patch, tile_policy,
  * split_target, patch_pipe, corr_slots, sel_rowq, conv1_mfma, w43_split_max / _gain / w43_chunk_us, wino_debug, conv_wino43, wino_wide,
- * wino_split_max / _gain / _fix / _per, wino16_2w, conv_wino, conv_wino16, wino_min_work, w43_map, conv_pm, gemv_mfma (gen6d_amd/csrc/common.hip lists meanings
+ * wino_split_max / _gain / _fix / _per, wino16_2w, conv_wino, conv_wino16, wino_min_work, w43_map, conv_pm, gemv_mfma, c16_ablate (gen6d_amd/csrc/common.hip lists meanings
  * and defaults).  Process-wide; reads and writes are relaxed atomics (a launch racing with g6d_set_knob sees the old or the new value):
  * set them before the launches they are meant to steer.  g6d_set_knob returns G6D_EINVAL for an unknown name; g6d_get_knob returns
  * -1e300 for one. */
@@ -228,7 +228,8 @@ int g6d_vgg_conv1_pool_nhwc_norm(const float* in, int N, int H, int W, const flo
                                  const float* mean_host, const float* std_host, float* out, g6d_stream_t stream);
 /* g6d_vgg_conv1_pool_nhwc(_norm) with a 16-BIT channels-last result [N][H/2][W/2][64] (ABI v11; math_mode 1 = bf16, 2 = fp16): the first
  * layer of the reduced-precision mode's 16-bit activation path (its output feeds g6d_conv16_direct_multi).  fp32 arithmetic, rounded
- * once in the epilogue.  mean_host / std_host: NULL = the input is already normalised. */
+ * once in the epilogue.  math_mode 3: fp16 hi / lo pairs [N][H/2][W/2][2][64] (hi = rn16(v), lo = rn16(v - hi)), the input format of
+ * g6d_conv16_direct_multi's math_mode 3 (the fp32 path's trunk).  mean_host / std_host: NULL = the input is already normalised. */
 int g6d_vgg_conv1_pool_nhwc16(const float* in, int N, int H, int W, const float* w_oihw, const float* bias, int Cin, int Cout,
                               const float* mean_host, const float* std_host, void* out16, int math_mode, g6d_stream_t stream);
 
@@ -267,14 +268,26 @@ int g6d_wino_conv3x3_multi(const G6dWinoSeg* segs, int nseg, int Cin, const floa
 int g6d_wino16_conv3x3_multi(const G6dWinoSeg* segs, int nseg, int Cin, const void* U16, const float* bias, int Cout, int relu,
                              int math_mode, float* workspace, size_t workspace_bytes, g6d_stream_t stream);
 
-/* Direct (implicit-GEMM) 3x3 / 3x3x3 "same" convolution on 16-BIT ACTIVATIONS (ABI v11, round 6): the reduced-precision mode's own kernel
- * family for the VGG trunks (reference network/pretrain_models.py:9-31,66-72; the detector's image pyramid network/detector.py:188-197,
- * 236-241; the refiner's crops network/refiner.py:64-78) and the first convs of the refiner's 32^3 volume net (network/refiner.py:88-143).
- * math_mode 1 = bf16, 2 = fp16: `in`, W16 and every 16-bit output hold that type; accumulation fp32 (v_mfma_f32_32x32x16_{bf16,f16}).
- *   in     [N][D][H][W][ld_in] 16-bit, channels-last (D = 1 for the 2-D layers), Cin % 64 == 0, rows 16-byte aligned
- *   W16    [Cout][kd*9][Cin] 16-bit, tap = (kz*3 + ky)*3 + kx, Cout % 128 == 0;  bias [Cout] fp32 or NULL
- *   y = conv(in) + bias;  relu != 0: y = max(y, 0)
- *   out_full [N][D][H][W][ld_full] = y        element type full_type: 0 = not written, 1 = the 16-bit type, 2 = fp32
+/* Direct (implicit-GEMM) 3x3 / 3x3x3 "same" convolution on 16-BIT ACTIVATIONS (ABI v11, round 6): the kernel family of the VGG trunks
+ * (reference network/pretrain_models.py:9-31,66-72; the detector's image pyramid network/detector.py:188-197,236-241; the refiner's
+ * crops network/refiner.py:64-78).  v_mfma_f32_32x32x16_{bf16,f16}, fp32 accumulation; the activation tile of a K step goes
+ * global -> LDS by DMA (zero padding = the buffer's out-of-range zero fill).
+ *   math_mode 1 = bf16, 2 = fp16   the reduced-precision mode (BASELINE configs[2] / [4]): `in`, W16 and 16-bit outputs hold that type
+ *   math_mode 3                    fp32-CLASS arithmetic on the fp16 matrix cores, used by the fp32 path: every operand is a PAIR of fp16
+ *                                  values hi = rn16(x), lo = rn16(x - hi) (22+ significand bits; the MFMA keeps fp16 subnormals) and
+ *                                  acc += a_hi b_hi + a_hi b_lo + a_lo b_hi — 3 MFMAs of 32 cycles per 16 channels against 8 x 64 cycles
+ *                                  on the fp32 matrix cores.  Activations [pixel][2][C]: the hi plane, then the lo plane (ld >= 2 C).
+ *   in     [N][D][H][W][ld_in] 16-bit channels-last (D = 1 for the 2-D layers), rows 16-byte aligned; Cin % 64 == 0 (pairs: % 32)
+ *   W16    w_layout 0: [Cout][kd*9][Cin] rows, tap = (kz*3 + ky)*3 + kx (math_mode 1 / 2; both operand tiles staged through LDS)
+ *          w_layout 1: FRAGMENT-major, read straight into registers one K step ahead (K step = BK = 64 channels, pairs 32, of one tap;
+ *            steps ordered channel slice outermost, taps innermost):
+ *            [Cout/128][Cin/BK * kd*9 steps][BK/16 ks][planes][4 groups j][64 lanes][8 values], value e of lane l =
+ *            filter (co = 128 tile + 32 j + (l & 31), tap, ci = BK slice + 16 ks + 8 (l >> 5) + e); planes = 1, or 2 (hi, lo) for pairs
+ *          Cout % 128 == 0;  bias [Cout] fp32 or NULL
+ *   y = acc_scale * conv(in, W16) + bias  (acc_scale: the filters may carry an exact power-of-two scale that keeps their lo parts
+ *       normal; 0 = 1);  relu != 0: y = max(y, 0)
+ *   out_full [N][D][H][W][ld_full] = y        element type full_type: 0 = not written, 1 = the 16-bit type (modes 1 / 2), 2 = fp32,
+ *                                             3 = fp16 pairs [pixel][2][Cout] (mode 3; ld_full >= 2 Cout)
  *   out_pool [N][H/2][W/2][ld_pool] = maxpool2x2(y) (2-D only, H and W even)     element type pool_type, same coding
  *   stats (optional) [groups][Cout][2] fp64, zeroed by the caller: sum and sum of squares of y (fp32 values, before rounding) per
  *        (image group, channel) are ADDED; group of a pixel = (its index in [N][D][H][W]) / stat_rows_per_group (0 = one group)
@@ -286,8 +299,9 @@ typedef struct G6dConv16Seg {
   void* out_pool;
   int32_t N, D, H, W, ld_in, ld_full, ld_pool;
 } G6dConv16Seg;
-int g6d_conv16_direct_multi(const G6dConv16Seg* segs, int nseg, int Cin, const void* W16, const float* bias, int Cout, int kd, int relu,
-                            int full_type, int pool_type, int math_mode, double* stats, int stat_rows_per_group, g6d_stream_t stream);
+int g6d_conv16_direct_multi(const G6dConv16Seg* segs, int nseg, int Cin, const void* W16, int w_layout, float acc_scale, const float* bias,
+                            int Cout, int kd, int relu, int full_type, int pool_type, int math_mode, double* stats, int stat_rows_per_group,
+                            g6d_stream_t stream);
 
 /* g6d_wino_conv3x3_multi on the Winograd F(4x4,3x3) kernel (ABI v8, fp32 on v_mfma_f32_16x16x4_f32): 36 multiplications per 16
  * outputs — 4x fewer than the direct form, 1.78x fewer than F(2x2,3x3) — with the interpolation points (0, +-3/4, +-3/2, inf), whose

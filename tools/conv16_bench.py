@@ -9,7 +9,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from gen6d_amd import lib, ops                                  # noqa: E402
-from gen6d_amd.network.backbone import winograd_filters16       # noqa: E402
+from gen6d_amd.network.backbone import winograd43_filters, winograd_filters16       # noqa: E402
 
 
 def timed(fn, reps=5):
@@ -36,9 +36,10 @@ def main():
              ("crop/8", 16, 256, 512, True, False), ("crop/8", 16, 512, 512, True, True), ("crop/16", 8, 512, 512, True, False),
              ("crop/16", 8, 512, 512, True, False)]
     g = torch.Generator().manual_seed(1)
-    print(f"# batch {B}, {mode}: direct 16-bit convolution on 16-bit activations vs the 16-bit Winograd kernel on fp32 activations (us per launch, direct-form TFLOP/s)")
-    print("| layer | maps | Cin -> Cout | outputs | conv16 direct us | TFLOP/s | wino16 us | direct-form TFLOP/s | speed-up |\n|---|---|---|---|---|---|---|---|---|")
-    tot = [0.0, 0.0]
+    print(f"# batch {B}: the direct kernel on 16-bit activations (g6d_conv16_direct_multi) per trunk layer, us per launch (direct-form TFLOP/s)")
+    print(f"# reduced precision ({mode}): filters in registers | filters through LDS | the 16-bit Winograd kernel it replaces;  fp32 path: fp16 hi / lo pairs (3 MFMAs per product) | the F(4x4,3x3) kernel it replaces")
+    print(f"| layer | maps | Cin -> Cout | outputs | {mode} reg-B | {mode} LDS-B | wino16 | vs wino16 | pairs (fp32-class) | wino43 fp32 | vs wino43 |\n|---|---|---|---|---|---|---|---|---|---|---|")
+    tot = [0.0] * 5
     for group in ("pyramid", "crops"):
         for spec in (layers if group == "pyramid" else crops):
             if group == "pyramid":
@@ -49,18 +50,29 @@ def main():
                 shapes = [(7 * B, hw, hw)]
             w = ((torch.rand((co, ci, 3, 3), generator=g) * 2 - 1) * (1.0 / (9 * ci)) ** 0.5 * 3).to(dev)
             bias = torch.zeros(co, device=dev)
-            w16 = w.permute(0, 2, 3, 1).reshape(co, 9, ci).contiguous().to(t16)
-            xs16 = [torch.rand((n, h, ww, ci), generator=g).to(dev).to(t16) for n, h, ww in shapes]
-            xs32 = [x.float() for x in xs16]
-            u16 = winograd_filters16(w, t16)
+            wt = w.permute(0, 2, 3, 1).reshape(co, 9, ci).contiguous()
+            mm = {"fp16": 2, "bf16": 1}[mode]
+            f_reg, f_lds, f_pair = ops.conv16_pack(wt, mm, 1), ops.conv16_pack(wt, mm, 0), ops.conv16_pack(wt, 3, 1)
+            xs32 = ops.alloc_like_segments([(n, h, ww, ci) for n, h, ww in shapes], dev)
+            for x in xs32:
+                x.copy_(torch.rand(x.shape, generator=g))
+            xs16 = [x.to(t16) for x in xs32]
+            xsp = [torch.stack([x.half(), (x - x.half().float()).half()], -2).contiguous() for x in xs32]
+            u16, u43 = winograd_filters16(w, t16), winograd43_filters(w)
             flops = sum(2.0 * n * h * ww * co * 9 * ci for n, h, ww in shapes)
+            o16 = lambda on: "t16" if on else None
+            t_reg = timed(lambda: ops.conv16_direct_multi(xs16, f_reg, bias, relu=True, full=o16(full), pool=o16(pool)))
+            t_lds = timed(lambda: ops.conv16_direct_multi(xs16, f_lds, bias, relu=True, full=o16(full), pool=o16(pool)))
+            t_pair = timed(lambda: ops.conv16_direct_multi(xsp, f_pair, bias, relu=True, full=o16(full), pool=o16(pool)))
             with ops.math_mode(mode):
-                td = timed(lambda: ops.conv16_direct_multi(xs16, w16, bias, relu=True, full=t16 if full else None, pool=t16 if pool else None))
-                tw = timed(lambda: ops.wino16_conv3x3_multi(xs32, u16, bias, relu=True, full=full, pool=pool))
-            tot[0] += td; tot[1] += tw
+                t_w16 = timed(lambda: ops.wino16_conv3x3_multi(xs32, u16, bias, relu=True, full=full, pool=pool))
+            t_w43 = timed(lambda: ops.wino43_conv3x3_multi(xs32, u43, bias, relu=True, full=full, pool=pool))
+            for i, v in enumerate((t_reg, t_lds, t_w16, t_pair, t_w43)):
+                tot[i] += v
+            tf = lambda us: f"{us:.0f} ({flops / us / 1e6:.0f})"
             print(f"| {tag} | {'+'.join(f'{n}x{h}x{ww}' for n, h, ww in shapes)} | {ci} -> {co} | {'full ' if full else ''}{'pool' if pool else ''} | "
-                  f"{td:.1f} | {flops / td / 1e6:.0f} | {tw:.1f} | {flops / tw / 1e6:.0f} | {tw / td:.2f}x |")
-    print(f"| **total** | | | | {tot[0]:.0f} | | {tot[1]:.0f} | | {tot[1] / tot[0]:.2f}x |")
+                  f"{tf(t_reg)} | {tf(t_lds)} | {tf(t_w16)} | {t_w16 / t_reg:.2f}x | {tf(t_pair)} | {tf(t_w43)} | {t_w43 / t_pair:.2f}x |")
+    print(f"| **total us** | | | | {tot[0]:.0f} | {tot[1]:.0f} | {tot[2]:.0f} | {tot[2] / tot[0]:.2f}x | {tot[3]:.0f} | {tot[4]:.0f} | {tot[4] / tot[3]:.2f}x |")
 
 
 if __name__ == "__main__":
