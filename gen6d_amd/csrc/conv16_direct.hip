@@ -35,6 +35,10 @@ struct C16Seg {
   int tw_log2, tiles_x, tile0;
   unsigned in_bytes;       // extent of the input buffer as the descriptor sees it (incl. the back-shift)
   int back;                // bytes the descriptor base lies BEFORE the tensor (offset of tap (0,0,0) from the centre, negated)
+  // halo-patch kernel (conv16h_kernel): its own tiling of the same segment
+  int h_tw_log2, h_tiles_x, h_tile0, h_tpi;      // tile width, tiles per row, first tile, tiles per image (0: tiles of whole small images)
+  int h_segh, h_bands;                            // rows per band (min(H, TH)), bands per tile (TH / h_segh: > 1 when a tile holds several images)
+  int h_swa, h_swd;                               // LDS slot swizzle: ((pcol >> h_swa) + prow * h_swd) & (slots - 1)
 };
 struct C16Params {
   C16Seg seg[4];
@@ -57,41 +61,33 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t c16_rsrc(const void* p, unsign
 // Epilogue shared by both kernels: two passes of 64 channels through an fp32 LDS tile [128 px][68]; bias, ReLU, then 16-byte stores.
 // Output element types (full_type / pool_type): 1 = the 16-bit type T, 2 = fp32, 3 = fp16 hi / lo PAIR [pixel][2][Cout] (hi = rn16(v),
 // lo = rn16(v - hi): the input format of the MM = 3 kernel; ld counts 16-bit elements and holds both planes).
-template <int MM>
-__device__ __forceinline__ void c16_epilogue(const C16Params& p, const C16Seg& sg, f32x16 (&acc)[2][2], char* lds, int tid, int lane, int wv, int nt,
-                                             int g0, int x0, int tw_log2) {
+template <int MM, typename WriteTile>
+__device__ __forceinline__ void c16_epilogue(const C16Params& p, const C16Seg& sg, char* lds, int tid, int nt, int g0, int x0, int tw_log2, int ylim,
+                                             WriteTile write_tile) {
+  // write_tile(h, ep, cbase): the waves that own channels [cbase, cbase + 64) of the block store acc * acc_scale + bias (+ ReLU) of the
+  // tile's 128 pixels into ep[pixel * C16_EP_LD + channel - cbase];  ylim: tile rows below it lie inside the image
   typedef typename C16T<MM>::T T;
   typedef typename C16T<MM>::V V8;
-  const int wm = wv >> 1, wn = wv & 1;
   const int TW = 1 << tw_log2, W = sg.W;
   float* ep = reinterpret_cast<float*>(lds);
   double* red = reinterpret_cast<double*>(lds + C16_BM * C16_EP_LD * 4);       // [4 quarters][64 ch][2] statistics partials
   const int TH2 = (C16_BM >> tw_log2) >> 1, TW2 = TW >> 1;
+  auto inside = [&](int px, int& g, int& x) {
+    const int py = px >> tw_log2;
+    g = g0 + py; x = x0 + (px & (TW - 1));
+    return py < ylim && g < sg.rows && x < W;
+  };
 #pragma unroll 1
   for (int h = 0; h < 2; ++h) {
     const int cbase = nt * C16_BN + 64 * h;
-    if (wn == h) {
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int nt2 = 0; nt2 < 2; ++nt2) {
-          const float bv = p.bias ? p.bias[cbase + 32 * nt2 + (lane & 31)] : 0.f;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int px = 64 * wm + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            float v = fmaf(acc[mt][nt2][r], p.acc_scale, bv);
-            if (p.relu) v = fmaxf(v, 0.f);
-            ep[px * C16_EP_LD + 32 * nt2 + (lane & 31)] = v;
-          }
-        }
-    }
+    write_tile(h, ep, cbase);
     __syncthreads();
     if (p.full_type == 1) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int px = (tid >> 3) + 32 * j, ch = (tid & 7) * 8;
-        const int g = g0 + (px >> tw_log2), x = x0 + (px & (TW - 1));
-        if (g < sg.rows && x < W) {
+        int g, x;
+        if (inside(px, g, x)) {
           const f32x4 v0 = *reinterpret_cast<const f32x4*>(ep + px * C16_EP_LD + ch), v1 = *reinterpret_cast<const f32x4*>(ep + px * C16_EP_LD + ch + 4);
           V8 o;
 #pragma unroll
@@ -103,8 +99,8 @@ __device__ __forceinline__ void c16_epilogue(const C16Params& p, const C16Seg& s
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int px = (tid >> 3) + 32 * j, ch = (tid & 7) * 8;
-        const int g = g0 + (px >> tw_log2), x = x0 + (px & (TW - 1));
-        if (g < sg.rows && x < W) {
+        int g, x;
+        if (inside(px, g, x)) {
           const f32x4 v0 = *reinterpret_cast<const f32x4*>(ep + px * C16_EP_LD + ch), v1 = *reinterpret_cast<const f32x4*>(ep + px * C16_EP_LD + ch + 4);
           V8 hi, lo;
 #pragma unroll
@@ -121,8 +117,8 @@ __device__ __forceinline__ void c16_epilogue(const C16Params& p, const C16Seg& s
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int px = (tid >> 4) + 16 * j, ch = (tid & 15) * 4;
-        const int g = g0 + (px >> tw_log2), x = x0 + (px & (TW - 1));
-        if (g < sg.rows && x < W)
+        int g, x;
+        if (inside(px, g, x))
           *reinterpret_cast<f32x4*>(sg.full + (((long)g * W + x) * sg.ld_full + cbase + ch) * 4) = *reinterpret_cast<const f32x4*>(ep + px * C16_EP_LD + ch);
       }
     }
@@ -133,7 +129,7 @@ __device__ __forceinline__ void c16_epilogue(const C16Params& p, const C16Seg& s
         const int pry = pp / TW2, prx = pp - pry * TW2;
         const int r00 = ((2 * pry) << tw_log2) + 2 * prx;
         const int g = g0 + 2 * pry, x = x0 + 2 * prx;
-        if (pry < TH2 && g < sg.rows && x < W) {
+        if (pry < TH2 && 2 * pry < ylim && g < sg.rows && x < W) {
           float m[8];
 #pragma unroll
           for (int e = 0; e < 8; e += 4) {
@@ -168,8 +164,8 @@ __device__ __forceinline__ void c16_epilogue(const C16Params& p, const C16Seg& s
       const int c = tid & 63, q = tid >> 6;
       float s1 = 0.f, s2 = 0.f;
       for (int px = 32 * q; px < 32 * q + 32; ++px) {
-        const int g = g0 + (px >> tw_log2), x = x0 + (px & (TW - 1));
-        if (g < sg.rows && x < W) { const float v = ep[px * C16_EP_LD + c]; s1 += v; s2 += v * v; }
+        int g, x;
+        if (inside(px, g, x)) { const float v = ep[px * C16_EP_LD + c]; s1 += v; s2 += v * v; }
       }
       red[(q * 64 + c) * 2] = (double)s1; red[(q * 64 + c) * 2 + 1] = (double)s2;
       __syncthreads();
@@ -182,6 +178,25 @@ __device__ __forceinline__ void c16_epilogue(const C16Params& p, const C16Seg& s
     }
     __syncthreads();
   }
+}
+
+// The 2 x 2 wave layout of conv16_kernel / conv16r_kernel: wave (wm, wn) holds pixels 64 wm .. + 63 x channels 64 wn .. + 63.
+__device__ __forceinline__ void c16_write22(const C16Params& p, const f32x16 (&acc)[2][2], int lane, int wv, int h, float* ep, int cbase) {
+  const int wm = wv >> 1, wn = wv & 1;
+  if (wn != h) return;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt2 = 0; nt2 < 2; ++nt2) {
+      const float bv = p.bias ? p.bias[cbase + 32 * nt2 + (lane & 31)] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int px = 64 * wm + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        float v = fmaf(acc[mt][nt2][r], p.acc_scale, bv);
+        if (p.relu) v = fmaxf(v, 0.f);
+        ep[px * C16_EP_LD + 32 * nt2 + (lane & 31)] = v;
+      }
+    }
 }
 
 template <int MM>
@@ -303,7 +318,8 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const C16Params p) {
     __builtin_amdgcn_s_barrier();                       // every wave has read this stage: the next iteration may refill it
   }
 
-  c16_epilogue<MM>(p, sg, acc, lds, tid, lane, wv, nt, g0, x0, tw_log2);
+  c16_epilogue<MM>(p, sg, lds, tid, nt, g0, x0, tw_log2, C16_BM >> tw_log2,
+                   [&](int h, float* ep, int cbase) { c16_write22(p, acc, lane, wv, h, ep, cbase); });
 }
 
 
@@ -477,7 +493,243 @@ __global__ __launch_bounds__(256, 2) void conv16r_kernel(const C16Params p) {
     step(k, b0, b1);
     if (k + 1 < nk) step(k + 1, b1, b0);
   }
-  c16_epilogue<MM == 3 ? 2 : MM>(p, sg, acc, lds, tid, lane, wv, nt, g0, x0, tw_log2);
+  c16_epilogue<MM == 3 ? 2 : MM>(p, sg, lds, tid, nt, g0, x0, tw_log2, C16_BM >> tw_log2,
+                                 [&](int h, float* ep, int cbase) { c16_write22(p, acc, lane, wv, h, ep, cbase); });
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// conv16h_kernel: the HALO-PATCH variant (2-D layers).  Measured on the two kernels above (tools/conv16_ablate.py): without the
+// activation requests they run 15 % faster, without the filter requests 14 %, without both 38 % — a step's 32-48 KB of vector-memory
+// traffic is what holds them at a third of the MFMA rate.  Here
+//   * the activations of a 64-channel slice (pairs: 32) are staged ONCE per slice as the tile's halo patch — (TH + 2) x (TW + 2) pixels
+//     (tiles of several small images: one band of H + 2 rows per image, so that zero padding between images stays zero) — and all nine
+//     taps read shifted windows of it: 2.9 KB of activation traffic per tap instead of 16 KB, and ONE barrier per slice instead of two
+//     per tap (between them the waves run free: the patch is read-only and the filters are private);
+//   * the waves split the block's 128 output channels (wave w: all 128 pixels x channels 32 w .. 32 w + 31), so that every filter
+//     fragment is requested by exactly one wave — fragment-major filters straight into registers, one tap ahead: 16 KB per tap and block;
+//   * the patch rows are lane-linear for the DMA and swizzled by (patch row, patch column) so that the shifted ds_read_b128 fragment
+//     reads of every tap are bank-conflict free (exhaustive search, tools/ubench/conv16_swizzle.py).
+template <int MM>
+__global__ __launch_bounds__(256, 2) void conv16h_kernel(const C16Params p) {
+  typedef typename C16T3<MM>::V V8;
+  typedef C16R<MM> R;
+  constexpr int PROWS = 288, PATCHB = PROWS * R::ROWB, STAGE = R::NP * PATCHB;      // 36,864 B per stage in both modes
+  constexpr int NPI = 9;                                       // DMA wave-instructions per wave and slice at most (288 rows)
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+  const int nt = jj % p.nN, ptile = (jj / p.nN) * 8 + xcd;
+  if (ptile >= p.ptiles) return;
+  int si = 0;
+#pragma unroll
+  for (int i = 1; i < 4; ++i) if (i < p.nseg && ptile >= p.seg[i].h_tile0) si = i;
+  const C16Seg& sg = p.seg[si];
+  const int t = ptile - sg.h_tile0;
+  const int tw_log2 = sg.h_tw_log2, TW = 1 << tw_log2, TH = C16_BM >> tw_log2, PW = TW + 2;
+  const int H = sg.H, W = sg.W;
+  int g0, x0, y0, ylim;
+  if (sg.h_tpi > 0) {                                          // tiles inside one image
+    const int n = t / sg.h_tpi, r = t - n * sg.h_tpi;
+    const int ty = r / sg.h_tiles_x, tx = r - ty * sg.h_tiles_x;
+    y0 = ty * TH; x0 = tx * TW; g0 = n * H + y0; ylim = min(TH, H - y0);
+  } else {                                                     // tiles of TH / H whole images
+    const int ty = t / sg.h_tiles_x, tx = t - ty * sg.h_tiles_x;
+    y0 = 0; x0 = tx * TW; g0 = ty * TH; ylim = TH;
+  }
+  const int segh = sg.h_segh, bandr = segh + 2, P = sg.h_bands * bandr * PW;      // patch rows
+  const int swa = sg.h_swa, swd = sg.h_swd;
+  const int NI = (P + R::RPI - 1) / R::RPI;                    // DMA wave-instructions per plane
+
+  // ---- patch rows this lane fills: instruction idx = wv + 4 i -> plane idx / NI, rows RPI (idx % NI) + lane / SL
+  unsigned poff[NPI];
+#pragma unroll
+  for (int i = 0; i < NPI; ++i) {
+    const int idx = wv + 4 * i, pl = idx / NI, ii = idx - pl * NI;
+    const int q = ii * R::RPI + lane / R::SL;
+    const int prow = q / PW, pcol = q - prow * PW;
+    const int b = prow / bandr, lr = prow - b * bandr - 1;     // band, row inside the band's image rows (-1 .. segh)
+    const int g = g0 + b * segh + lr, x = x0 + pcol - 1;
+    const int yimg = y0 + lr;                                  // (whole-image tiles: y0 = 0, lr = the image row)
+    const bool ok = pl < R::NP && q < P && yimg >= 0 && yimg < H && g < sg.rows && x >= 0 && x < W;
+    const int slot = (lane & (R::SL - 1)) ^ (((pcol >> swa) + prow * swd) & (R::SL - 1));
+    poff[i] = ok ? (unsigned)((((long)g * W + x) * sg.ld_in + pl * p.Cin) * 2 + slot * 16) : C16_OOB;
+  }
+  const __amdgpu_buffer_rsrc_t rs_in = c16_rsrc(sg.in, sg.in_bytes - sg.back);
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  const int nchunk = p.Cin / R::BK, nk = nchunk * 9;
+  auto issue_patch = [&](int c, int stage) {
+    char* sa = lds + stage * STAGE;
+    const unsigned ck = (unsigned)(c * (R::BK * 2));
+    // ALWAYS NPI requests per wave (the counted wait of the step below depends on it): the surplus ones ask for an out-of-range offset
+    // and write zeros into the stage's last KB, which is unused whenever there is a surplus
+#pragma unroll
+    for (int i = 0; i < NPI; ++i) {
+      const int idx = wv + 4 * i;
+      const bool live = idx < R::NP * NI;
+      const int pl = live ? idx / NI : 0, ii = live ? idx - pl * NI : 0;
+      const unsigned vo = (!live || poff[i] == C16_OOB) ? C16_OOB : poff[i] + ck;
+      char* dst = live ? sa + pl * PATCHB + ii * 1024 : sa + STAGE - 1024;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr)dst, 16, vo, 0, 0, 0);
+    }
+  };
+  // ---- filter fragments of step s = 9 c + tap: [ks][plane] 16 bytes per lane of THIS wave's 32 channels, hand-issued (see conv16r_kernel)
+  constexpr int NB = R::KS * R::NP;                            // 4
+  constexpr int STEP_B = R::KS * R::NP * 4 * 1024;
+  const char* wtile = p.w + (long)nt * nk * STEP_B;
+  const unsigned b_voff = wv * 1024 + lane * 16;
+  auto load_b = [&](int s_, V8 (&b)[NB]) {
+    const char* ws = wtile + (long)s_ * STEP_B;
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+      const char* wq = ws + q * 4096;
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(b[q]) : "v"(b_voff), "s"(wq) : "memory");
+    }
+  };
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+  // ---- fragment geometry: m-tile mt = tile pixels 32 mt + (lane & 31) -> patch (row, column) of tap (0, 0)
+  const int fhalf = lane >> 5;
+  int fq[4], frow[4], fcol[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int r = 32 * mt + (lane & 31), py = r >> tw_log2, px = r & (TW - 1);
+    const int b = py / segh, ly = py - b * segh;
+    frow[mt] = b * bandr + ly; fcol[mt] = px; fq[mt] = frow[mt] * PW + px;
+  }
+  // Fragment reads run ONE MFMA GROUP AHEAD in a second register set (first version: the compiler kept two fragment registers and
+  // every MFMA waited out the LDS latency of a read issued one instruction earlier — the ISA showed ds_read / s_waitcnt / v_mfma triples):
+  // while the MFMAs of (tap, ks) issue, the fragments of (tap, ks + 1) — or of the next tap's ks = 0 inside the same slice — are in flight.
+  struct Frag { V8 a[R::NP][4]; };
+  auto frag_addr = [&](int ky, int kx, int (&abase)[4], int (&asw)[4]) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      abase[mt] = (fq[mt] + ky * PW + kx) * R::ROWB;
+      asw[mt] = ((fcol[mt] + kx) >> swa) + (frow[mt] + ky) * swd;
+    }
+  };
+  auto frag_read = [&](Frag& f, int stage, const int (&abase)[4], const int (&asw)[4], int ks) {
+    const char* st = lds + stage * STAGE;
+#pragma unroll
+    for (int pl = 0; pl < R::NP; ++pl)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+        f.a[pl][mt] = *reinterpret_cast<const V8*>(st + pl * PATCHB + abase[mt] + ((((2 * ks + fhalf) ^ asw[mt]) & (R::SL - 1)) << 4));
+  };
+  auto mfmas = [&](const Frag& f, const V8 (&b)[NB], int ks) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      acc[mt] = c16_mfma<MM>(f.a[0][mt], b[ks * R::NP], acc[mt]);
+      if constexpr (MM == 3) {
+        acc[mt] = c16_mfma<MM>(f.a[0][mt], b[ks * R::NP + 1], acc[mt]);      // hi x lo
+        acc[mt] = c16_mfma<MM>(f.a[1][mt], b[ks * R::NP], acc[mt]);          // lo x hi
+      }
+    }
+  };
+
+  // ---- K loop: slices outermost (one patch, one barrier each), the nine taps inside.  The filter fragments run TWO steps ahead in a
+  // ring of three register sets (requests return in order, so before step s the wait allows what was requested after B(s): two filter
+  // sets = 8 loads, plus the 9 patch pieces while they are younger than B(s)).
+  V8 b0[NB], b1[NB], b2[NB];
+  load_b(0, b0);
+  if (nk > 1) load_b(1, b1);
+  issue_patch(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  int stage = 0, tap = 0, ky = 0, kx = 0, c = 0;
+  int abase[4], asw[4];
+  Frag f0, f1;
+  frag_addr(0, 0, abase, asw);
+  frag_read(f0, 0, abase, asw, 0);
+  // one step; `fc` holds the fragments of (this tap, ks = 0) on entry and of (next tap, ks = 0) on exit (KS even: the sets swap back)
+  auto step = [&](int s_, const V8 (&bc)[NB], V8 (&bfar)[NB], Frag& fc, Frag& fn) {
+    const bool more = s_ + 2 < nk;
+    if (more) load_b(s_ + 2, bfar);
+    if (tap == 0 && c + 1 < nchunk) issue_patch(c + 1, stage ^ 1);      // first tap of a slice: request the next slice's patch
+    if (!more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (tap < 3 && c + 1 < nchunk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NB + NPI) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NB) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    const bool last_tap = tap == 8;
+    int nky = ky, nkx = kx + 1;
+    if (nkx == 3) { nkx = 0; ++nky; }
+    int nbase[4], nsw[4];
+    frag_addr(last_tap ? 0 : nky, last_tap ? 0 : nkx, nbase, nsw);
+#pragma unroll
+    for (int ks = 0; ks < R::KS; ++ks) {
+      Frag& cur = (ks & 1) ? fn : fc;
+      Frag& nxt = (ks & 1) ? fc : fn;
+      if (ks + 1 < R::KS) frag_read(nxt, stage, abase, asw, ks + 1);
+      else if (!last_tap) frag_read(nxt, stage, nbase, nsw, 0);          // the next tap reads the same patch
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(cur, bc, ks);
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) { abase[mt] = nbase[mt]; asw[mt] = nsw[mt]; }
+    ++tap; kx = nkx; ky = nky;
+    if (last_tap) {
+      tap = 0; ky = 0; kx = 0; ++c;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                            // every wave has read this patch and received its share of the next
+      __builtin_amdgcn_sched_barrier(0);
+      stage ^= 1;
+      if (c < nchunk) frag_read(fc, stage, abase, asw, 0);     // (KS even: after the ks loop the "current" set is fc again)
+    }
+  };
+  static_assert(R::KS % 2 == 0, "the fragment sets swap back after an even number of MFMA groups");
+#pragma unroll 1
+  for (int s_ = 0; s_ < nk; s_ += 3) {                        // (nk = 9 slices: a multiple of 3)
+    step(s_, b0, b2, f0, f1);
+    step(s_ + 1, b1, b0, f0, f1);
+    step(s_ + 2, b2, b1, f0, f1);
+  }
+  // ---- epilogue: wave w holds channels 32 w .. 32 w + 31 of all 128 pixels
+  c16_epilogue<MM == 3 ? 2 : MM>(p, sg, lds, tid, nt, g0, x0, tw_log2, ylim, [&](int h, float* ep, int cbase) {
+    if ((wv >> 1) != h) return;
+    const float bv = p.bias ? p.bias[cbase + 32 * (wv & 1) + (lane & 31)] : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int px = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        float v = fmaf(acc[mt][r], p.acc_scale, bv);
+        if (p.relu) v = fmaxf(v, 0.f);
+        ep[px * C16_EP_LD + 32 * (wv & 1) + (lane & 31)] = v;
+      }
+  });
+}
+
+// Tiling of one segment for the halo-patch kernel: the tile width (32 / 16 / 8 / 4) with the least overhang; false if none fits
+// (a map lower than the tile must divide it: tiles of whole images)
+bool c16_halo_tiling(const G6dConv16Seg& s, int rowb, C16Seg& o, int& tiles) {
+  double best = 1e30;
+  bool found = false;
+  for (int tw = 32; tw >= 4; tw >>= 1) {
+    const int th = C16_BM / tw, tx = (s.W + tw - 1) / tw;
+    long nt; int tpi, segh, bands;
+    if (s.H >= th) { tpi = tx * ((s.H + th - 1) / th); nt = (long)s.N * tpi; segh = th; bands = 1; }
+    else {
+      if (th % s.H) continue;
+      tpi = 0; nt = (long)tx * (((long)s.N * s.H + th - 1) / th); segh = s.H; bands = th / s.H;
+    }
+    if (bands * (segh + 2) * (tw + 2) > 288) continue;
+    const double waste = (double)nt * C16_BM / ((double)s.N * s.H * s.W);
+    if (waste < best - 1e-9) {
+      best = waste; found = true;
+      int l2 = 0; while ((1 << l2) < tw) ++l2;
+      o.h_tw_log2 = l2; o.h_tiles_x = tx; o.h_tpi = tpi; o.h_segh = segh; o.h_bands = bands;
+      tiles = (int)nt;
+      // conflict-free slot swizzles found by tools/ubench/conv16_swizzle.py: ((pcol >> a) + prow * d) & (slots - 1)
+      if (rowb == 128) { o.h_swa = tw == 16 ? 0 : 1; o.h_swd = tw == 4 ? 2 : (tw == 8 ? 4 : (tw == 16 ? 1 : 0)); }
+      else { o.h_swa = tw == 32 ? 2 : (tw == 16 ? 1 : 0); o.h_swd = tw <= 8 ? 1 : 0; }
+    }
+  }
+  return found;
 }
 
 int c16_pick_tw(int W, int pool) {
@@ -543,8 +795,40 @@ extern "C" int g6d_conv16_direct_multi(const G6dConv16Seg* segs, int nseg, int C
   }
   p.D = D0;
   p.ptiles = tiles;
-  const int blocks = (tiles + 7) / 8 * 8 * p.nN;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  // fragment-major filters, 2-D layer: the halo-patch kernel when every segment has a tiling for it (knob conv16_halo = 0: never)
+  if (w_layout == 1 && kd == 1 && g6d_knob(G6D_KNOB_CONV16_HALO) != 0) {
+    bool ok = true;
+    int htiles = 0;
+    for (int i = 0; i < nseg && ok; ++i) {
+      int nt_ = 0;
+      ok = c16_halo_tiling(segs[i], math_mode == 3 ? 64 : 128, p.seg[i], nt_);
+      p.seg[i].h_tile0 = htiles; htiles += nt_;
+      if (stats && stat_rows_per_group > 0 && ok) {
+        const C16Seg& o = p.seg[i];
+        const int th = C16_BM >> o.h_tw_log2;
+        // a tile must lie inside one statistics group: in-image tiles do when groups are whole images; tiles of whole images when the group is too
+        ok = (stat_rows_per_group % (segs[i].H * segs[i].W) == 0) && (o.h_tpi > 0 || ((long)stat_rows_per_group % ((long)th * segs[i].W) == 0));
+      }
+    }
+    if (ok) {
+      p.ptiles = htiles;
+      const int hblocks = (htiles + 7) / 8 * 8 * p.nN;
+      constexpr int LDSH = 2 * 36864;
+      if (math_mode == 1) {
+        g6d_allow_lds(reinterpret_cast<const void*>(&conv16h_kernel<1>), LDSH);
+        hipLaunchKernelGGL(conv16h_kernel<1>, dim3(hblocks), dim3(256), LDSH, st, p);
+      } else if (math_mode == 2) {
+        g6d_allow_lds(reinterpret_cast<const void*>(&conv16h_kernel<2>), LDSH);
+        hipLaunchKernelGGL(conv16h_kernel<2>, dim3(hblocks), dim3(256), LDSH, st, p);
+      } else {
+        g6d_allow_lds(reinterpret_cast<const void*>(&conv16h_kernel<3>), LDSH);
+        hipLaunchKernelGGL(conv16h_kernel<3>, dim3(hblocks), dim3(256), LDSH, st, p);
+      }
+      return g6d_check_launch("conv16h_direct");
+    }
+  }
+  const int blocks = (tiles + 7) / 8 * 8 * p.nN;
   if (w_layout == 0) {
     if (math_mode == 1) {
       g6d_allow_lds(reinterpret_cast<const void*>(&conv16_kernel<1>), C16_LDS);

@@ -37,19 +37,22 @@ CASES = [
     dict(segs=[(5, 8, 8)], Cin=512, Cout=512, relu=False, full="t16", pool=None),                                 # two images per tile
     dict(segs=[(1, 44, 58), (2, 30, 40)], Cin=256, Cout=128, relu=True, full=None, pool="t16"),                   # pooled output only
     dict(segs=[(3, 4, 4)], Cin=64, Cout=128, relu=True, full="f32", pool="t16"),                                  # 4x4 maps: 8 images per tile
+    dict(segs=[(2, 30, 34), (1, 6, 36)], Cin=64, Cout=128, relu=True, full="t16", pool="f32"),                    # heights that are no multiple of the tile
+    dict(segs=[(3, 16, 16)], Cin=128, Cout=128, relu=False, full="f32", pool=None, stats=True, rpg=256),           # 2-D statistics per image
     dict(segs=[(2, 8, 8, 8)], Cin=64, Cout=128, relu=False, full="f32", pool=None, kd=3, stats=True),             # 3x3x3 with statistics
     dict(segs=[(1, 16, 16, 16)], Cin=128, Cout=128, relu=False, full="t16", pool=None, kd=3, stats=True),
 ]
 
 
-@pytest.mark.parametrize("mode,layout", [("fp16", 1), ("bf16", 1), ("fp16", 0), ("pairs", 1)],
-                         ids=["fp16-regB", "bf16-regB", "fp16-ldsB", "pairs"])
+@pytest.mark.parametrize("mode,layout,halo", [("fp16", 1, 1), ("bf16", 1, 1), ("pairs", 1, 1), ("fp16", 1, 0), ("pairs", 1, 0), ("fp16", 0, 0)],
+                         ids=["fp16-halo", "bf16-halo", "pairs-halo", "fp16-regB", "pairs-regB", "fp16-ldsB"])
 @pytest.mark.parametrize("case", CASES, ids=[f"case{i}" for i in range(len(CASES))])
-def test_conv16_direct_multi(mode, layout, case):
+def test_conv16_direct_multi(mode, layout, halo, case, knob):
     """mode "pairs" = math_mode 3: every operand an fp16 hi / lo pair, fp32-CLASS results (the fp32 path's trunk kernel): the bar is 2e-6
     of the output range against the float64 convolution of the fp32 operands themselves (the fp32 Winograd kernels it replaces are held
     to 2e-5 / 4e-5)."""
     from gen6d_amd import ops
+    knob("conv16_halo", halo)         # fragment-major filters: the halo-patch kernel (2-D layers) or the per-tap kernel
     c = case
     kd = c.get("kd", 1)
     t16 = T16[mode]
@@ -67,7 +70,7 @@ def test_conv16_direct_multi(mode, layout, case):
     rpg = 0
     if stats is not None:
         s0 = c["segs"][0]
-        rpg = s0[1] * s0[2] * s0[3]
+        rpg = c.get("rpg") or s0[1] * s0[2] * s0[3]
     filt = ops.conv16_pack(w.cuda(), MODE[mode], layout)
     xin = [(_split(x) if pairs else x.to(t16)).cuda() for x in xs]
     fulls, pools = ops.conv16_direct_multi(xin, filt, b.cuda(), relu=c["relu"], full=ty[c["full"]], pool=ty[c["pool"]], kd=kd, stats=stats,

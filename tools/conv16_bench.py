@@ -37,9 +37,10 @@ def main():
              ("crop/16", 8, 512, 512, True, False)]
     g = torch.Generator().manual_seed(1)
     print(f"# batch {B}: the direct kernel on 16-bit activations (g6d_conv16_direct_multi) per trunk layer, us per launch (direct-form TFLOP/s)")
-    print(f"# reduced precision ({mode}): filters in registers | filters through LDS | the 16-bit Winograd kernel it replaces;  fp32 path: fp16 hi / lo pairs (3 MFMAs per product) | the F(4x4,3x3) kernel it replaces")
-    print(f"| layer | maps | Cin -> Cout | outputs | {mode} reg-B | {mode} LDS-B | wino16 | vs wino16 | pairs (fp32-class) | wino43 fp32 | vs wino43 |\n|---|---|---|---|---|---|---|---|---|---|---|")
-    tot = [0.0] * 5
+    print(f"# reduced precision ({mode}): halo-patch kernel | per-tap kernel, filters in registers | per-tap kernel, filters through LDS | the 16-bit Winograd kernel they replace")
+    print("# fp32 path: fp16 hi / lo pairs (3 MFMAs per product, fp32-class results) on the halo-patch kernel | on the per-tap kernel | the F(4x4,3x3) fp32 kernel they replace")
+    print(f"| layer | maps | Cin -> Cout | outputs | {mode} halo | {mode} reg-B | {mode} LDS-B | wino16 | halo vs wino16 | pairs halo | pairs reg-B | wino43 fp32 | halo vs wino43 |\n|---|---|---|---|---|---|---|---|---|---|---|---|---|")
+    tot = [0.0] * 7
     for group in ("pyramid", "crops"):
         for spec in (layers if group == "pyramid" else crops):
             if group == "pyramid":
@@ -61,18 +62,23 @@ def main():
             u16, u43 = winograd_filters16(w, t16), winograd43_filters(w)
             flops = sum(2.0 * n * h * ww * co * 9 * ci for n, h, ww in shapes)
             o16 = lambda on: "t16" if on else None
-            t_reg = timed(lambda: ops.conv16_direct_multi(xs16, f_reg, bias, relu=True, full=o16(full), pool=o16(pool)))
-            t_lds = timed(lambda: ops.conv16_direct_multi(xs16, f_lds, bias, relu=True, full=o16(full), pool=o16(pool)))
-            t_pair = timed(lambda: ops.conv16_direct_multi(xsp, f_pair, bias, relu=True, full=o16(full), pool=o16(pool)))
+            run16 = lambda f: timed(lambda: ops.conv16_direct_multi(xs16, f, bias, relu=True, full=o16(full), pool=o16(pool)))
+            runp = lambda: timed(lambda: ops.conv16_direct_multi(xsp, f_pair, bias, relu=True, full=o16(full), pool=o16(pool)))
+            lib.set_knob("conv16_halo", 1)
+            t_halo, t_phalo = run16(f_reg), runp()
+            lib.set_knob("conv16_halo", 0)
+            t_reg, t_pair = run16(f_reg), runp()
+            lib.reset_knobs()
+            t_lds = run16(f_lds)
             with ops.math_mode(mode):
                 t_w16 = timed(lambda: ops.wino16_conv3x3_multi(xs32, u16, bias, relu=True, full=full, pool=pool))
             t_w43 = timed(lambda: ops.wino43_conv3x3_multi(xs32, u43, bias, relu=True, full=full, pool=pool))
-            for i, v in enumerate((t_reg, t_lds, t_w16, t_pair, t_w43)):
+            for i, v in enumerate((t_halo, t_reg, t_lds, t_w16, t_phalo, t_pair, t_w43)):
                 tot[i] += v
             tf = lambda us: f"{us:.0f} ({flops / us / 1e6:.0f})"
             print(f"| {tag} | {'+'.join(f'{n}x{h}x{ww}' for n, h, ww in shapes)} | {ci} -> {co} | {'full ' if full else ''}{'pool' if pool else ''} | "
-                  f"{tf(t_reg)} | {tf(t_lds)} | {tf(t_w16)} | {t_w16 / t_reg:.2f}x | {tf(t_pair)} | {tf(t_w43)} | {t_w43 / t_pair:.2f}x |")
-    print(f"| **total us** | | | | {tot[0]:.0f} | {tot[1]:.0f} | {tot[2]:.0f} | {tot[2] / tot[0]:.2f}x | {tot[3]:.0f} | {tot[4]:.0f} | {tot[4] / tot[3]:.2f}x |")
+                  f"{tf(t_halo)} | {tf(t_reg)} | {tf(t_lds)} | {tf(t_w16)} | {t_w16 / t_halo:.2f}x | {tf(t_phalo)} | {tf(t_pair)} | {tf(t_w43)} | {t_w43 / t_phalo:.2f}x |")
+    print(f"| **total us** | | | | {tot[0]:.0f} | {tot[1]:.0f} | {tot[2]:.0f} | {tot[3]:.0f} | {tot[3] / tot[0]:.2f}x | {tot[4]:.0f} | {tot[5]:.0f} | {tot[6]:.0f} | {tot[6] / tot[4]:.2f}x |")
 
 
 if __name__ == "__main__":

@@ -1,8 +1,8 @@
 # bench.py under launch-policy knobs (tools/toolenv.py: KNOBS="name=value,..."): bash tools/knob_bench.sh "w43_split_gain=1.0" "w43_chunk_us=2.2" ...
-# (an empty string = product defaults).  One line per setting.
+# (an empty string = product defaults; "knobs;module.ATTR=0" adds Python-level switches, tools/toolenv.py PYSW).  One line per setting.
 cd ${GRAFT_REPO_ROOT:-.}
 for k in "$@"; do
-  KNOBS="$k" timeout 300 python -c "
+  KNOBS="${k%%;*}" PYSW="$( [[ "$k" == *";"* ]] && echo "${k#*;}" )" timeout 300 python -c "
 import sys, runpy
 sys.path.insert(0, 'tools'); import toolenv
 sys.argv = ['bench.py', '--steps', '${STEPS:-10}', '--warmup', '3', '--no-cpu-baseline', '--no-cached', '--no-chained', '--no-sweep', '--lowp', '']

@@ -12,3 +12,9 @@ if os.environ.get("G6D_LIB_PATH"):
 for item in filter(None, os.environ.get("KNOBS", "").split(",")):
     name, val = item.split("=")
     lib.set_knob(name.strip(), float(val))
+# PYSW="gen6d_amd.network.backbone.SPLIT16_TRUNK=0,...": module-level A/B switches of the package (tools only)
+for item in filter(None, os.environ.get("PYSW", "").split(",")):
+    path, val = item.split("=")
+    mod, attr = path.strip().rsplit(".", 1)
+    import importlib
+    setattr(importlib.import_module(mod), attr, type(getattr(importlib.import_module(mod), attr))(int(val)))
