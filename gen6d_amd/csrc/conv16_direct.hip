@@ -58,124 +58,152 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t c16_rsrc(const void* p, unsign
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
 }
 
-// Epilogue shared by both kernels: two passes of 64 channels through an fp32 LDS tile [128 px][68]; bias, ReLU, then 16-byte stores.
+// Epilogue, one PASS = one fp32 LDS tile ep[NPX px][68] of 64 output channels (already holding acc * acc_scale + bias (+ ReLU) of tile
+// pixels px0 .. px0 + NPX - 1, the NT threads synchronised): 16-byte stores of the full map and / or the 2x2 max-pooled map, optional
+// per-(group, channel) statistics.  NPX is a multiple of two tile rows (pool windows stay inside a pass).
 // Output element types (full_type / pool_type): 1 = the 16-bit type T, 2 = fp32, 3 = fp16 hi / lo PAIR [pixel][2][Cout] (hi = rn16(v),
-// lo = rn16(v - hi): the input format of the MM = 3 kernel; ld counts 16-bit elements and holds both planes).
-template <int MM, typename WriteTile>
-__device__ __forceinline__ void c16_epilogue(const C16Params& p, const C16Seg& sg, char* lds, int tid, int nt, int g0, int x0, int tw_log2, int ylim,
-                                             WriteTile write_tile) {
-  // write_tile(h, ep, cbase): the waves that own channels [cbase, cbase + 64) of the block store acc * acc_scale + bias (+ ReLU) of the
-  // tile's 128 pixels into ep[pixel * C16_EP_LD + channel - cbase];  ylim: tile rows below it lie inside the image
+// lo = rn16(v - hi): the input format of the MM = 3 kernels; ld counts 16-bit elements and holds both planes).
+// NT = threads that share the pass (256: the whole block, NPX = 128; 64: one wave, tid = lane, no block-wide synchronisation inside).
+template <int MM, int NT, int NPX, int CH = 64>
+__device__ __forceinline__ void c16_epilogue_pass(const C16Params& p, const C16Seg& sg, const float* ep, double* red, int tid, int cbase, int g0, int x0,
+                                                  int tw_log2, int ylim, int px0) {
   typedef typename C16T<MM>::T T;
   typedef typename C16T<MM>::V V8;
+  static_assert(NT == 64 || (NPX == 128 && CH == 64), "the block-wide form handles whole tiles of 64 channels");
+  constexpr int C8 = CH / 8, C4 = CH / 4;                                           // 16-byte items per pixel: 16-bit / fp32 output
   const int TW = 1 << tw_log2, W = sg.W;
-  float* ep = reinterpret_cast<float*>(lds);
-  double* red = reinterpret_cast<double*>(lds + C16_BM * C16_EP_LD * 4);       // [4 quarters][64 ch][2] statistics partials
-  const int TH2 = (C16_BM >> tw_log2) >> 1, TW2 = TW >> 1;
-  auto inside = [&](int px, int& g, int& x) {
-    const int py = px >> tw_log2;
+  const int TW2 = TW >> 1, py0 = px0 >> tw_log2, PR2 = (NPX >> tw_log2) >> 1;      // first tile row of the pass, pooled rows of the pass
+  auto inside = [&](int lp, int& g, int& x) {                                       // lp: pixel of the pass = row of ep
+    const int px = px0 + lp, py = px >> tw_log2;
     g = g0 + py; x = x0 + (px & (TW - 1));
     return py < ylim && g < sg.rows && x < W;
   };
-#pragma unroll 1
-  for (int h = 0; h < 2; ++h) {
-    const int cbase = nt * C16_BN + 64 * h;
-    write_tile(h, ep, cbase);
-    __syncthreads();
-    if (p.full_type == 1) {
+  if (p.full_type == 1) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int px = (tid >> 3) + 32 * j, ch = (tid & 7) * 8;
-        int g, x;
-        if (inside(px, g, x)) {
-          const f32x4 v0 = *reinterpret_cast<const f32x4*>(ep + px * C16_EP_LD + ch), v1 = *reinterpret_cast<const f32x4*>(ep + px * C16_EP_LD + ch + 4);
-          V8 o;
+    for (int j = 0; j < NPX * C8 / NT; ++j) {
+      const int lp = tid / C8 + (NT / C8) * j, ch = (tid % C8) * 8;
+      int g, x;
+      if (inside(lp, g, x)) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(ep + lp * C16_EP_LD + ch), v1 = *reinterpret_cast<const f32x4*>(ep + lp * C16_EP_LD + ch + 4);
+        V8 o;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { o[e] = (T)v0[e]; o[4 + e] = (T)v1[e]; }
-          *reinterpret_cast<V8*>(sg.full + (((long)g * W + x) * sg.ld_full + cbase + ch) * 2) = o;
-        }
+        for (int e = 0; e < 4; ++e) { o[e] = (T)v0[e]; o[4 + e] = (T)v1[e]; }
+        *reinterpret_cast<V8*>(sg.full + (((long)g * W + x) * sg.ld_full + cbase + ch) * 2) = o;
       }
-    } else if (p.full_type == 3) {
+    }
+  } else if (p.full_type == 3) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int px = (tid >> 3) + 32 * j, ch = (tid & 7) * 8;
-        int g, x;
-        if (inside(px, g, x)) {
-          const f32x4 v0 = *reinterpret_cast<const f32x4*>(ep + px * C16_EP_LD + ch), v1 = *reinterpret_cast<const f32x4*>(ep + px * C16_EP_LD + ch + 4);
+    for (int j = 0; j < NPX * C8 / NT; ++j) {
+      const int lp = tid / C8 + (NT / C8) * j, ch = (tid % C8) * 8;
+      int g, x;
+      if (inside(lp, g, x)) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(ep + lp * C16_EP_LD + ch), v1 = *reinterpret_cast<const f32x4*>(ep + lp * C16_EP_LD + ch + 4);
+        V8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          hi[e] = (T)v0[e]; lo[e] = (T)(v0[e] - (float)hi[e]);
+          hi[4 + e] = (T)v1[e]; lo[4 + e] = (T)(v1[e] - (float)hi[4 + e]);
+        }
+        char* o = sg.full + (((long)g * W + x) * sg.ld_full + cbase + ch) * 2;
+        *reinterpret_cast<V8*>(o) = hi;
+        *reinterpret_cast<V8*>(o + p.Cout * 2) = lo;
+      }
+    }
+  } else if (p.full_type == 2) {
+#pragma unroll
+    for (int j = 0; j < NPX * C4 / NT; ++j) {
+      const int lp = tid / C4 + (NT / C4) * j, ch = (tid % C4) * 4;
+      int g, x;
+      if (inside(lp, g, x))
+        *reinterpret_cast<f32x4*>(sg.full + (((long)g * W + x) * sg.ld_full + cbase + ch) * 4) = *reinterpret_cast<const f32x4*>(ep + lp * C16_EP_LD + ch);
+    }
+  }
+  if (p.pool_type) {
+    const int per = p.pool_type == 2 ? 4 : 8, chunks = CH / per;      // channels per item, items per pooled pixel
+    for (int it = tid; it < (NPX / 4) * chunks; it += NT) {
+      const int pp = it / chunks, ch = (it - pp * chunks) * per;
+      const int pry = pp / TW2, prx = pp - pry * TW2;
+      const int r00 = ((2 * pry) << tw_log2) + 2 * prx;
+      const int g = g0 + py0 + 2 * pry, x = x0 + 2 * prx;
+      if (pry < PR2 && py0 + 2 * pry < ylim && g < sg.rows && x < W) {
+        float m[8];
+#pragma unroll
+        for (int e = 0; e < 8; e += 4) {
+          if (e < per) {
+            const f32x4 q0 = *reinterpret_cast<const f32x4*>(ep + r00 * C16_EP_LD + ch + e), q1 = *reinterpret_cast<const f32x4*>(ep + (r00 + 1) * C16_EP_LD + ch + e);
+            const f32x4 q2 = *reinterpret_cast<const f32x4*>(ep + (r00 + TW) * C16_EP_LD + ch + e), q3 = *reinterpret_cast<const f32x4*>(ep + (r00 + TW + 1) * C16_EP_LD + ch + e);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) m[e + u] = fmaxf(fmaxf(q0[u], q1[u]), fmaxf(q2[u], q3[u]));
+          }
+        }
+        const long o = ((long)(g >> 1) * (W >> 1) + (x >> 1)) * sg.ld_pool + cbase + ch;
+        if (p.pool_type == 1) {
+          V8 ov;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ov[e] = (T)m[e];
+          *reinterpret_cast<V8*>(sg.pool + o * 2) = ov;
+        } else if (p.pool_type == 3) {
           V8 hi, lo;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            hi[e] = (T)v0[e]; lo[e] = (T)(v0[e] - (float)hi[e]);
-            hi[4 + e] = (T)v1[e]; lo[4 + e] = (T)(v1[e] - (float)hi[4 + e]);
-          }
-          char* o = sg.full + (((long)g * W + x) * sg.ld_full + cbase + ch) * 2;
-          *reinterpret_cast<V8*>(o) = hi;
-          *reinterpret_cast<V8*>(o + p.Cout * 2) = lo;
-        }
-      }
-    } else if (p.full_type == 2) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int px = (tid >> 4) + 16 * j, ch = (tid & 15) * 4;
-        int g, x;
-        if (inside(px, g, x))
-          *reinterpret_cast<f32x4*>(sg.full + (((long)g * W + x) * sg.ld_full + cbase + ch) * 4) = *reinterpret_cast<const f32x4*>(ep + px * C16_EP_LD + ch);
-      }
-    }
-    if (p.pool_type) {
-      const int per = p.pool_type == 2 ? 4 : 8, chunks = 64 / per;      // channels per item, items per pooled pixel
-      for (int it = tid; it < 32 * chunks; it += 256) {
-        const int pp = it / chunks, ch = (it - pp * chunks) * per;
-        const int pry = pp / TW2, prx = pp - pry * TW2;
-        const int r00 = ((2 * pry) << tw_log2) + 2 * prx;
-        const int g = g0 + 2 * pry, x = x0 + 2 * prx;
-        if (pry < TH2 && 2 * pry < ylim && g < sg.rows && x < W) {
-          float m[8];
-#pragma unroll
-          for (int e = 0; e < 8; e += 4) {
-            if (e < per) {
-              const f32x4 q0 = *reinterpret_cast<const f32x4*>(ep + r00 * C16_EP_LD + ch + e), q1 = *reinterpret_cast<const f32x4*>(ep + (r00 + 1) * C16_EP_LD + ch + e);
-              const f32x4 q2 = *reinterpret_cast<const f32x4*>(ep + (r00 + TW) * C16_EP_LD + ch + e), q3 = *reinterpret_cast<const f32x4*>(ep + (r00 + TW + 1) * C16_EP_LD + ch + e);
-#pragma unroll
-              for (int u = 0; u < 4; ++u) m[e + u] = fmaxf(fmaxf(q0[u], q1[u]), fmaxf(q2[u], q3[u]));
-            }
-          }
-          const long o = ((long)(g >> 1) * (W >> 1) + (x >> 1)) * sg.ld_pool + cbase + ch;
-          if (p.pool_type == 1) {
-            V8 ov;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) ov[e] = (T)m[e];
-            *reinterpret_cast<V8*>(sg.pool + o * 2) = ov;
-          } else if (p.pool_type == 3) {
-            V8 hi, lo;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { hi[e] = (T)m[e]; lo[e] = (T)(m[e] - (float)hi[e]); }
-            *reinterpret_cast<V8*>(sg.pool + o * 2) = hi;
-            *reinterpret_cast<V8*>(sg.pool + (o + p.Cout) * 2) = lo;
-          } else {
-            f32x4 ov = {m[0], m[1], m[2], m[3]};
-            *reinterpret_cast<f32x4*>(sg.pool + o * 4) = ov;
-          }
+          for (int e = 0; e < 8; ++e) { hi[e] = (T)m[e]; lo[e] = (T)(m[e] - (float)hi[e]); }
+          *reinterpret_cast<V8*>(sg.pool + o * 2) = hi;
+          *reinterpret_cast<V8*>(sg.pool + (o + p.Cout) * 2) = lo;
+        } else {
+          f32x4 ov = {m[0], m[1], m[2], m[3]};
+          *reinterpret_cast<f32x4*>(sg.pool + o * 4) = ov;
         }
       }
     }
-    if (p.stats) {
-      // per-(group, channel) sum / sum of squares of the fp32 results of the tile's VALID pixels (a tile never straddles groups)
+  }
+  if (p.stats) {
+    // per-(group, channel) sum / sum of squares of the fp32 results of the tile's VALID pixels (a tile never straddles groups)
+    const int grp = p.stat_rows_per_group > 0 ? (int)(((long)g0 * W) / p.stat_rows_per_group) : 0;
+    if constexpr (NT == 256) {
       const int c = tid & 63, q = tid >> 6;
       float s1 = 0.f, s2 = 0.f;
-      for (int px = 32 * q; px < 32 * q + 32; ++px) {
+      for (int lp = 32 * q; lp < 32 * q + 32; ++lp) {
         int g, x;
-        if (inside(px, g, x)) { const float v = ep[px * C16_EP_LD + c]; s1 += v; s2 += v * v; }
+        if (inside(lp, g, x)) { const float v = ep[lp * C16_EP_LD + c]; s1 += v; s2 += v * v; }
       }
       red[(q * 64 + c) * 2] = (double)s1; red[(q * 64 + c) * 2 + 1] = (double)s2;
       __syncthreads();
       if (tid < 128) {
         const int cc = tid >> 1, w = tid & 1;
         const double v = red[(0 * 64 + cc) * 2 + w] + red[(1 * 64 + cc) * 2 + w] + red[(2 * 64 + cc) * 2 + w] + red[(3 * 64 + cc) * 2 + w];
-        const int grp = p.stat_rows_per_group > 0 ? (int)(((long)g0 * W) / p.stat_rows_per_group) : 0;
         atomicAdd(p.stats + ((long)grp * p.Cout + cbase + cc) * 2 + w, v);
       }
+    } else {
+      // one wave: lane = channel; fp32 partial sums of 32 pixels each, combined in fp64
+      if (tid >= CH) return;
+      double d1 = 0.0, d2 = 0.0;
+      for (int q = 0; q < NPX / 32; ++q) {
+        float s1 = 0.f, s2 = 0.f;
+        for (int lp = 32 * q; lp < 32 * q + 32; ++lp) {
+          int g, x;
+          if (inside(lp, g, x)) { const float v = ep[lp * C16_EP_LD + tid]; s1 += v; s2 += v * v; }
+        }
+        d1 += (double)s1; d2 += (double)s2;
+      }
+      atomicAdd(p.stats + ((long)grp * p.Cout + cbase + tid) * 2, d1);
+      atomicAdd(p.stats + ((long)grp * p.Cout + cbase + tid) * 2 + 1, d2);
     }
+  }
+}
+
+// Epilogue of the per-tap kernels: two passes of 64 channels through ONE fp32 LDS tile.
+template <int MM, typename WriteTile>
+__device__ __forceinline__ void c16_epilogue(const C16Params& p, const C16Seg& sg, char* lds, int tid, int nt, int g0, int x0, int tw_log2, int ylim,
+                                             WriteTile write_tile) {
+  // write_tile(h, ep, cbase): the waves that own channels [cbase, cbase + 64) of the block store acc * acc_scale + bias (+ ReLU) of the
+  // tile's 128 pixels into ep[pixel * C16_EP_LD + channel - cbase];  ylim: tile rows below it lie inside the image
+  float* ep = reinterpret_cast<float*>(lds);
+  double* red = reinterpret_cast<double*>(lds + C16_BM * C16_EP_LD * 4);       // [4 quarters][64 ch][2] statistics partials
+#pragma unroll 1
+  for (int h = 0; h < 2; ++h) {
+    const int cbase = nt * C16_BN + 64 * h;
+    write_tile(h, ep, cbase);
+    __syncthreads();
+    c16_epilogue_pass<MM, 256, 128>(p, sg, ep, red, tid, cbase, g0, x0, tw_log2, ylim, 0);
     __syncthreads();
   }
 }
@@ -499,214 +527,299 @@ __global__ __launch_bounds__(256, 2) void conv16r_kernel(const C16Params p) {
 
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// conv16h_kernel: the HALO-PATCH variant (2-D layers).  Measured on the two kernels above (tools/conv16_ablate.py): without the
+// conv16w_kernel: the HALO-PATCH kernel (2-D layers).  Measured on the two kernels above (tools/conv16_ablate.py): without the
 // activation requests they run 15 % faster, without the filter requests 14 %, without both 38 % — a step's 32-48 KB of vector-memory
-// traffic is what holds them at a third of the MFMA rate.  Here
-//   * the activations of a 64-channel slice (pairs: 32) are staged ONCE per slice as the tile's halo patch — (TH + 2) x (TW + 2) pixels
-//     (tiles of several small images: one band of H + 2 rows per image, so that zero padding between images stays zero) — and all nine
-//     taps read shifted windows of it: 2.9 KB of activation traffic per tap instead of 16 KB, and ONE barrier per slice instead of two
-//     per tap (between them the waves run free: the patch is read-only and the filters are private);
-//   * the waves split the block's 128 output channels (wave w: all 128 pixels x channels 32 w .. 32 w + 31), so that every filter
-//     fragment is requested by exactly one wave — fragment-major filters straight into registers, one tap ahead: 16 KB per tap and block;
-//   * the patch rows are lane-linear for the DMA and swizzled by (patch row, patch column) so that the shifted ds_read_b128 fragment
-//     reads of every tap are bank-conflict free (exhaustive search, tools/ubench/conv16_swizzle.py).
-template <int MM>
-__global__ __launch_bounds__(256, 2) void conv16h_kernel(const C16Params p) {
-  typedef typename C16T3<MM>::V V8;
-  typedef C16R<MM> R;
-  constexpr int PROWS = 288, PATCHB = PROWS * R::ROWB, STAGE = R::NP * PATCHB;      // 36,864 B per stage in both modes
-  constexpr int NPI = 9;                                       // DMA wave-instructions per wave and slice at most (288 rows)
-  extern __shared__ __attribute__((aligned(16))) char lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
-  const int nt = jj % p.nN, ptile = (jj / p.nN) * 8 + xcd;
-  if (ptile >= p.ptiles) return;
+// traffic and two barriers per 16 MFMAs hold them at a third of the MFMA rate.  Here
+//   * the activations of a 32-channel slice are staged ONCE per slice as the tile's halo patch — (TH + 2) x (TW + 2) pixels (tiles of
+//     several small images: one band of H + 2 rows per image, so that zero padding between images stays zero) — and all nine taps read
+//     shifted windows of it: ~1.4 KB of activation traffic per tap instead of 8, ONE barrier per slice (between barriers the waves run
+//     free: the patch is read-only and the filters are private);
+//   * a wave owns 128 pixels x 64 output channels (4 x 2 accumulator tiles): an activation fragment read from LDS feeds two MFMAs and
+//     a filter fragment four — 64 B/clk/CU of ds_read_b128 and 32 B/clk/CU of filter loads at the full MFMA rate (LDS delivers 256,
+//     L2 ~56).  A block is four waves: WM pixel tiles x (4 / WM) channel groups — 128 px x 256 ch, or 2 tiles x 128 ch for Cout = 128;
+//   * filters: fragment-major, straight into registers TWO taps ahead (ring of three sets, hand-issued loads and counted waits);
+//   * a patch row holds 64 B (4 slots of 16 B), lane-linear for the DMA, the slot swizzled by (patch row, column) so that the shifted
+//     ds_read_b128 fragment reads of every tap are bank-conflict free (tools/ubench/conv16_swizzle.py); a fragment address is
+//     row base | swizzled slot, and the second 16-channel half of the slice is that address ^ 32: one VALU per read;
+//   * the nine taps are unrolled (tap offsets are immediates); the epilogue is PRIVATE to a wave (its own fp32 LDS tile, no block
+//     barrier): blocks and waves drift apart freely, one block's epilogue runs beside its neighbours' MFMAs.
+//   MM = 1 / 2: bf16 / fp16, a wave owns 128 px x 64 ch.  MM = 3: fp16 hi / lo pairs (see conv16r_kernel), two planes per patch, three
+//   MFMAs per product; a wave owns 128 px x 32 ch (64 accumulator registers: with the two-plane fragment and filter sets a 64-channel
+//   wave needs > 256 registers = one block per CU, every prologue and epilogue exposed).  Two blocks per CU in every mode.
+// timing experiments only (WRONG results), a compile-time switch (make FLAGS_conv16_direct=-DC16W_ABLATE=n): after the first slice, bit 0 = no
+// patch requests, bit 1 = no filter requests, bit 2 = no fragment reads
+#ifndef C16W_ABLATE
+#define C16W_ABLATE 0
+#endif
+template <int MM> struct C16W {
+  static constexpr int NP = MM == 3 ? 2 : 1, KS = 2, NI_MAX = 18;             // planes, 16-channel groups per slice, DMA pieces per plane at most
+  static constexpr int PLANE = NI_MAX * 1024;                                   // 288 patch rows of 64 B
+  static constexpr int NT2 = MM == 3 ? 1 : 2;                                   // 32-channel accumulator tiles per wave (a wave = 128 px x 32 NT2 ch)
+  static constexpr int NBL = KS * NP * NT2;                                     // filter loads per tap and wave
+  static constexpr int NPX = 64;                                                // pixels per epilogue pass
+  static constexpr int EPW = NPX * C16_EP_LD * 4;                               // a wave's epilogue tile
+};
+
+struct C16Geom {      // one 128-pixel tile of the halo tiling (block-uniform)
+  int si, g0, x0, y0, ylim, tw_log2, PW, segh, bandr, P, swa, swd, ni;
+};
+__device__ __forceinline__ C16Geom c16w_geom(const C16Params& p, int ptile) {
+  C16Geom o;
   int si = 0;
 #pragma unroll
   for (int i = 1; i < 4; ++i) if (i < p.nseg && ptile >= p.seg[i].h_tile0) si = i;
   const C16Seg& sg = p.seg[si];
   const int t = ptile - sg.h_tile0;
-  const int tw_log2 = sg.h_tw_log2, TW = 1 << tw_log2, TH = C16_BM >> tw_log2, PW = TW + 2;
-  const int H = sg.H, W = sg.W;
-  int g0, x0, y0, ylim;
+  o.si = si; o.tw_log2 = sg.h_tw_log2;
+  const int TW = 1 << o.tw_log2, TH = C16_BM >> o.tw_log2;
+  o.PW = TW + 2;
   if (sg.h_tpi > 0) {                                          // tiles inside one image
     const int n = t / sg.h_tpi, r = t - n * sg.h_tpi;
     const int ty = r / sg.h_tiles_x, tx = r - ty * sg.h_tiles_x;
-    y0 = ty * TH; x0 = tx * TW; g0 = n * H + y0; ylim = min(TH, H - y0);
+    o.y0 = ty * TH; o.x0 = tx * TW; o.g0 = n * sg.H + o.y0; o.ylim = min(TH, sg.H - o.y0);
   } else {                                                     // tiles of TH / H whole images
     const int ty = t / sg.h_tiles_x, tx = t - ty * sg.h_tiles_x;
-    y0 = 0; x0 = tx * TW; g0 = ty * TH; ylim = TH;
+    o.y0 = 0; o.x0 = tx * TW; o.g0 = ty * TH; o.ylim = TH;
   }
-  const int segh = sg.h_segh, bandr = segh + 2, P = sg.h_bands * bandr * PW;      // patch rows
-  const int swa = sg.h_swa, swd = sg.h_swd;
-  const int NI = (P + R::RPI - 1) / R::RPI;                    // DMA wave-instructions per plane
+  o.segh = sg.h_segh; o.bandr = sg.h_segh + 2; o.P = sg.h_bands * o.bandr * o.PW;
+  o.swa = sg.h_swa; o.swd = sg.h_swd; o.ni = (o.P + 15) >> 4;
+  return o;
+}
 
-  // ---- patch rows this lane fills: instruction idx = wv + 4 i -> plane idx / NI, rows RPI (idx % NI) + lane / SL
-  unsigned poff[NPI];
-#pragma unroll
-  for (int i = 0; i < NPI; ++i) {
-    const int idx = wv + 4 * i, pl = idx / NI, ii = idx - pl * NI;
-    const int q = ii * R::RPI + lane / R::SL;
-    const int prow = q / PW, pcol = q - prow * PW;
-    const int b = prow / bandr, lr = prow - b * bandr - 1;     // band, row inside the band's image rows (-1 .. segh)
-    const int g = g0 + b * segh + lr, x = x0 + pcol - 1;
-    const int yimg = y0 + lr;                                  // (whole-image tiles: y0 = 0, lr = the image row)
-    const bool ok = pl < R::NP && q < P && yimg >= 0 && yimg < H && g < sg.rows && x >= 0 && x < W;
-    const int slot = (lane & (R::SL - 1)) ^ (((pcol >> swa) + prow * swd) & (R::SL - 1));
-    poff[i] = ok ? (unsigned)((((long)g * W + x) * sg.ld_in + pl * p.Cin) * 2 + slot * 16) : C16_OOB;
+// s_waitcnt vmcnt(BASE + n) for a wave-uniform run-time n in [0, HI] (the instruction takes an immediate only): a compare chain
+template <int BASE, int HI>
+__device__ __forceinline__ void c16_wait_vm(int n) {
+  if constexpr (HI == 0) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE) : "memory");
+  } else {
+    if (n >= HI) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE + HI) : "memory");
+    else c16_wait_vm<BASE, HI - 1>(n);
   }
-  const __amdgpu_buffer_rsrc_t rs_in = c16_rsrc(sg.in, sg.in_bytes - sg.back);
+}
+
+template <int MM, int WM>
+__global__ __launch_bounds__(256, 2) void conv16w_kernel(const C16Params p) {
+  typedef typename C16T3<MM>::V V8;
+  typedef C16W<MM> R;
+  constexpr int WN = 4 / WM, NP = R::NP, KS = R::KS, NBL = R::NBL, NT2 = R::NT2, CW = 32 * NT2;
+  constexpr int TILE_B = NP * R::PLANE, STAGE = WM * TILE_B;
+  constexpr int NPIT = (NP * R::NI_MAX + 3) / 4;               // DMA wave-instructions per wave, tile and slice at most
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // block id -> (tile group, channel block): the channel blocks of a tile group run back to back on ONE XCD (ids = xcd mod 8)
+  const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+  const int cb = jj % p.nN, tg = (jj / p.nN) * 8 + xcd;
+  if (tg * WM >= p.ptiles) return;
+  const int wm = wv / WN, wn = wv % WN;
+  const int nchunk = p.Cin >> 5;
   typedef __attribute__((address_space(3))) void* lds_ptr;
-  const int nchunk = p.Cin / R::BK, nk = nchunk * 9;
-  auto issue_patch = [&](int c, int stage) {
-    char* sa = lds + stage * STAGE;
-    const unsigned ck = (unsigned)(c * (R::BK * 2));
-    // ALWAYS NPI requests per wave (the counted wait of the step below depends on it): the surplus ones ask for an out-of-range offset
-    // and write zeros into the stage's last KB, which is unused whenever there is a surplus
+
+  // ---- the patch pieces this lane requests per slice: tile tl, piece k = wv + 4 i of its NP * ni pieces (plane k / ni, rows 16 (k % ni) + lane / 4)
+  unsigned poff[WM][NPIT];
+  int nreq = 0, t_ni[WM], t_si[WM];
 #pragma unroll
-    for (int i = 0; i < NPI; ++i) {
-      const int idx = wv + 4 * i;
-      const bool live = idx < R::NP * NI;
-      const int pl = live ? idx / NI : 0, ii = live ? idx - pl * NI : 0;
-      const unsigned vo = (!live || poff[i] == C16_OOB) ? C16_OOB : poff[i] + ck;
-      char* dst = live ? sa + pl * PATCHB + ii * 1024 : sa + STAGE - 1024;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr)dst, 16, vo, 0, 0, 0);
+  for (int tl = 0; tl < WM; ++tl) {
+    const C16Geom gm = c16w_geom(p, min(tg * WM + tl, p.ptiles - 1));
+    const C16Seg& sg = p.seg[gm.si];
+    const int npt = NP * gm.ni;
+    t_ni[tl] = gm.ni; t_si[tl] = gm.si;
+#pragma unroll
+    for (int i = 0; i < NPIT; ++i) {
+      const int k = wv + 4 * i;
+      if (k < npt) ++nreq;
+      const int pl = k >= gm.ni ? 1 : 0, ii = k - pl * gm.ni;
+      const int q = ii * 16 + (lane >> 2);
+      const int prow = q / gm.PW, pcol = q - prow * gm.PW;
+      const int b = prow / gm.bandr, lr = prow - b * gm.bandr - 1;   // band, row inside the band's image rows (-1 .. segh)
+      const int g = gm.g0 + b * gm.segh + lr, x = gm.x0 + pcol - 1;
+      const int yimg = gm.y0 + lr;                                    // (whole-image tiles: y0 = 0, lr = the image row)
+      const bool ok = k < npt && q < gm.P && yimg >= 0 && yimg < sg.H && g < sg.rows && x >= 0 && x < sg.W;
+      const int slot = (lane & 3) ^ (((pcol >> gm.swa) + prow * gm.swd) & 3);
+      poff[tl][i] = ok ? (unsigned)((((long)g * sg.W + x) * sg.ld_in + pl * p.Cin) * 2 + slot * 16) : C16_OOB;
     }
-  };
-  // ---- filter fragments of step s = 9 c + tap: [ks][plane] 16 bytes per lane of THIS wave's 32 channels, hand-issued (see conv16r_kernel)
-  constexpr int NB = R::KS * R::NP;                            // 4
-  constexpr int STEP_B = R::KS * R::NP * 4 * 1024;
-  const char* wtile = p.w + (long)nt * nk * STEP_B;
-  const unsigned b_voff = wv * 1024 + lane * 16;
-  auto load_b = [&](int s_, V8 (&b)[NB]) {
-    const char* ws = wtile + (long)s_ * STEP_B;
+  }
+  nreq = __builtin_amdgcn_readfirstlane(nreq);
+  auto issue_patch = [&](int c, int stage) {
+    const unsigned ck = c < nchunk ? (unsigned)(c * 64) : C16_OOB;      // past the last slice: zero fill (keeps the request count uniform)
 #pragma unroll
-    for (int q = 0; q < NB; ++q) {
-      const char* wq = ws + q * 4096;
-      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(b[q]) : "v"(b_voff), "s"(wq) : "memory");
+    for (int tl = 0; tl < WM; ++tl) {
+      const C16Seg& sg = p.seg[t_si[tl]];
+      const __amdgpu_buffer_rsrc_t rs_in = c16_rsrc(sg.in, sg.in_bytes - sg.back);
+      const int ni = t_ni[tl], npt = NP * ni;
+#pragma unroll
+      for (int i = 0; i < NPIT; ++i) {
+        const int k = wv + 4 * i;
+        if (k < npt) {
+          const int pl = k >= ni ? 1 : 0, ii = k - pl * ni;
+          const unsigned vo = (poff[tl][i] | ck) >= C16_OOB ? C16_OOB : poff[tl][i] + ck;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr)(lds + stage * STAGE + tl * TILE_B + pl * R::PLANE + ii * 1024), 16, vo, 0, 0, 0);
+        }
+      }
     }
   };
 
-  f32x16 acc[4];
+  // ---- filter fragments of (slice c, tap t): KS x NP x 2 pieces of 16 bytes per lane of THIS wave's 64 channels, hand-issued (see
+  // conv16r_kernel).  Packed K steps hold 64 channels (pairs: 32): slice c is half (c & 1) of packed step (c >> 1) * 9 + t.
+  const int chan0 = (cb * WN + wn) * CW;
+  const int nkp = (MM == 3 ? nchunk : nchunk >> 1) * 9;
+  const char* wtile = p.w + (long)(chan0 >> 7) * nkp * 16384;
+  unsigned bvo[KS * NP];
+#pragma unroll
+  for (int q = 0; q < KS * NP; ++q) bvo[q] = q * 4096 + ((chan0 >> 5) & 3) * 1024 + lane * 16;
+  // The requests walk the packed filters in step order with a running pointer: + 16 KB per tap; at a slice boundary + 16 KB for pairs,
+  // and for the 16-bit modes (two 32-channel slices per packed step) + 8 KB - 8 x 16 KB into an odd slice, + 8 KB out of it.  Past the
+  // last step the pointer stays on the first one (a harmless reload: the request count per step stays uniform).
+  const char* wp = wtile;
+  int wleft = nchunk * 9;
+  auto load_b = [&](int c, int t, V8 (&b)[NBL]) {                // (c, t): the step being requested — requests are issued in step order
+    const unsigned long wa = (unsigned long)(wleft > 0 ? wp : wtile);
+    const char* ws = reinterpret_cast<const char*>((unsigned long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)wa) |
+                                                   ((unsigned long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(wa >> 32)) << 32));
+#pragma unroll
+    for (int q = 0; q < KS * NP; ++q) {
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(b[NT2 * q]) : "v"(bvo[q]), "s"(ws) : "memory");
+      if constexpr (NT2 == 2) asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(b[NT2 * q + 1]) : "v"(bvo[q]), "s"(ws) : "memory");
+    }
+    --wleft;
+    if (t < 8 || MM == 3) wp += 16384;
+    else wp += (c & 1) ? 8192 : 8192 - 8 * 16384;
+  };
+
+  // ---- fragment geometry of this wave's tile: m-tile mt = tile pixels 32 mt + (lane & 31) -> patch row of tap (0, 0)
+  const C16Geom gm = c16w_geom(p, min(tg * WM + wm, p.ptiles - 1));
+  const int fhalf = lane >> 5;
+  // slot swizzle of patch (row, column): ((column >> swa) + row * swd) & 3, and swd != 0 only with swa == 0 (c16_halo_tiling): with
+  // fe = column + row * swd (swa == 0) or column (swd == 0) the swizzle of tap (ky, kx) is ((fe + kx) >> swa) + ky * swd
+  int qb[4], fe[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int r = 32 * mt + (lane & 31), py = r >> gm.tw_log2, px = r & ((1 << gm.tw_log2) - 1);
+    const int b = py / gm.segh, ly = py - b * gm.segh;
+    const int frow = b * gm.bandr + ly;
+    qb[mt] = (frow * gm.PW + px) * 64 + wm * TILE_B; fe[mt] = px + frow * gm.swd;
+  }
+  const int PW64 = gm.PW * 64, swa = gm.swa, swd = gm.swd;
+  auto tap_addr = [&](int ky, int kx, int stage, int (&tb)[4]) {
+    const int so = stage * STAGE + (ky * PW64 + kx * 64);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int sw = ((fe[mt] + kx) >> swa) + ky * swd;
+      tb[mt] = qb[mt] + so + (((fhalf ^ sw) & 3) << 4);
+    }
+  };
+  auto frag_read = [&](int addr, V8 (&a)[NP]) {
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl) a[pl] = *reinterpret_cast<const V8*>(lds + pl * R::PLANE + addr);
+  };
+  f32x16 acc[4][NT2];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
-  // ---- fragment geometry: m-tile mt = tile pixels 32 mt + (lane & 31) -> patch (row, column) of tap (0, 0)
-  const int fhalf = lane >> 5;
-  int fq[4], frow[4], fcol[4];
+    for (int b = 0; b < NT2; ++b)
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
-    const int r = 32 * mt + (lane & 31), py = r >> tw_log2, px = r & (TW - 1);
-    const int b = py / segh, ly = py - b * segh;
-    frow[mt] = b * bandr + ly; fcol[mt] = px; fq[mt] = frow[mt] * PW + px;
-  }
-  // Fragment reads run ONE MFMA GROUP AHEAD in a second register set (first version: the compiler kept two fragment registers and
-  // every MFMA waited out the LDS latency of a read issued one instruction earlier — the ISA showed ds_read / s_waitcnt / v_mfma triples):
-  // while the MFMAs of (tap, ks) issue, the fragments of (tap, ks + 1) — or of the next tap's ks = 0 inside the same slice — are in flight.
-  struct Frag { V8 a[R::NP][4]; };
-  auto frag_addr = [&](int ky, int kx, int (&abase)[4], int (&asw)[4]) {
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  // the MFMAs of one m-tile and one 16-channel group: b[(ks * NP + plane) * NT2 + n2];  pairs: hi x hi, hi x lo, lo x hi
+  auto mfmas = [&](int mt, const V8 (&a)[NP], const V8 (&b)[NBL], int ks) {
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      abase[mt] = (fq[mt] + ky * PW + kx) * R::ROWB;
-      asw[mt] = ((fcol[mt] + kx) >> swa) + (frow[mt] + ky) * swd;
-    }
-  };
-  auto frag_read = [&](Frag& f, int stage, const int (&abase)[4], const int (&asw)[4], int ks) {
-    const char* st = lds + stage * STAGE;
+    for (int term = 0; term < (MM == 3 ? 3 : 1); ++term) {
+      const int pa = term == 2 ? 1 : 0, pb = term == 1 ? 1 : 0;
 #pragma unroll
-    for (int pl = 0; pl < R::NP; ++pl)
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
-        f.a[pl][mt] = *reinterpret_cast<const V8*>(st + pl * PATCHB + abase[mt] + ((((2 * ks + fhalf) ^ asw[mt]) & (R::SL - 1)) << 4));
-  };
-  auto mfmas = [&](const Frag& f, const V8 (&b)[NB], int ks) {
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      acc[mt] = c16_mfma<MM>(f.a[0][mt], b[ks * R::NP], acc[mt]);
-      if constexpr (MM == 3) {
-        acc[mt] = c16_mfma<MM>(f.a[0][mt], b[ks * R::NP + 1], acc[mt]);      // hi x lo
-        acc[mt] = c16_mfma<MM>(f.a[1][mt], b[ks * R::NP], acc[mt]);          // lo x hi
-      }
+      for (int n2 = 0; n2 < NT2; ++n2) acc[mt][n2] = c16_mfma<MM>(a[pa], b[(ks * NP + pb) * NT2 + n2], acc[mt][n2]);
     }
   };
 
-  // ---- K loop: slices outermost (one patch, one barrier each), the nine taps inside.  The filter fragments run TWO steps ahead in a
-  // ring of three register sets (requests return in order, so before step s the wait allows what was requested after B(s): two filter
-  // sets = 8 loads, plus the 9 patch pieces while they are younger than B(s)).
-  V8 b0[NB], b1[NB], b2[NB];
-  load_b(0, b0);
-  if (nk > 1) load_b(1, b1);
+  // ---- K loop: slices outermost (one patch, one barrier each), the nine taps unrolled inside.  Requests return in order: before the
+  // MFMAs of step (c, t) the wait allows what was requested after B(c, t) — two filter sets, plus the next patch while it is younger.
+  // ONE set of activation fragments, replaced m-tile by m-tile: right after the MFMAs of (m-tile, 16-channel group) have issued, the
+  // same registers receive the m-tile's fragment of the NEXT group (the other half of the slice, or the next tap) — consumed eight
+  // MFMAs later.
+  V8 bs[3][NBL];
+  V8 fa[4][NP];
+  int tb[4], ntb[4];
   issue_patch(0, 0);
+  load_b(0, 0, bs[0]);
+  load_b(0, 1, bs[1]);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
-  int stage = 0, tap = 0, ky = 0, kx = 0, c = 0;
-  int abase[4], asw[4];
-  Frag f0, f1;
-  frag_addr(0, 0, abase, asw);
-  frag_read(f0, 0, abase, asw, 0);
-  // one step; `fc` holds the fragments of (this tap, ks = 0) on entry and of (next tap, ks = 0) on exit (KS even: the sets swap back)
-  auto step = [&](int s_, const V8 (&bc)[NB], V8 (&bfar)[NB], Frag& fc, Frag& fn) {
-    const bool more = s_ + 2 < nk;
-    if (more) load_b(s_ + 2, bfar);
-    if (tap == 0 && c + 1 < nchunk) issue_patch(c + 1, stage ^ 1);      // first tap of a slice: request the next slice's patch
-    if (!more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (tap < 3 && c + 1 < nchunk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NB + NPI) : "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NB) : "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    const bool last_tap = tap == 8;
-    int nky = ky, nkx = kx + 1;
-    if (nkx == 3) { nkx = 0; ++nky; }
-    int nbase[4], nsw[4];
-    frag_addr(last_tap ? 0 : nky, last_tap ? 0 : nkx, nbase, nsw);
+  tap_addr(0, 0, 0, tb);
 #pragma unroll
-    for (int ks = 0; ks < R::KS; ++ks) {
-      Frag& cur = (ks & 1) ? fn : fc;
-      Frag& nxt = (ks & 1) ? fc : fn;
-      if (ks + 1 < R::KS) frag_read(nxt, stage, abase, asw, ks + 1);
-      else if (!last_tap) frag_read(nxt, stage, nbase, nsw, 0);          // the next tap reads the same patch
-      __builtin_amdgcn_sched_barrier(0);
-      mfmas(cur, bc, ks);
-    }
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) { abase[mt] = nbase[mt]; asw[mt] = nsw[mt]; }
-    ++tap; kx = nkx; ky = nky;
-    if (last_tap) {
-      tap = 0; ky = 0; kx = 0; ++c;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                            // every wave has read this patch and received its share of the next
-      __builtin_amdgcn_sched_barrier(0);
-      stage ^= 1;
-      if (c < nchunk) frag_read(fc, stage, abase, asw, 0);     // (KS even: after the ks loop the "current" set is fc again)
-    }
-  };
-  static_assert(R::KS % 2 == 0, "the fragment sets swap back after an even number of MFMA groups");
+  for (int mt = 0; mt < 4; ++mt) frag_read(tb[mt], fa[mt]);
+  int stage = 0;
 #pragma unroll 1
-  for (int s_ = 0; s_ < nk; s_ += 3) {                        // (nk = 9 slices: a multiple of 3)
-    step(s_, b0, b2, f0, f1);
-    step(s_ + 1, b1, b0, f0, f1);
-    step(s_ + 2, b2, b1, f0, f1);
-  }
-  // ---- epilogue: wave w holds channels 32 w .. 32 w + 31 of all 128 pixels
-  c16_epilogue<MM == 3 ? 2 : MM>(p, sg, lds, tid, nt, g0, x0, tw_log2, ylim, [&](int h, float* ep, int cbase) {
-    if ((wv >> 1) != h) return;
-    const float bv = p.bias ? p.bias[cbase + 32 * (wv & 1) + (lane & 31)] : 0.f;
+  for (int c = 0; c < nchunk; ++c) {
+    // (opaque to the optimiser: it would otherwise hoist the 36 per-(tap, m-tile) swizzle terms out of the slice loop and spill them)
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < 4; ++mt) asm volatile("" : "+v"(fe[mt]), "+v"(qb[mt]));
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int px = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        float v = fmaf(acc[mt][r], p.acc_scale, bv);
-        if (p.relu) v = fmaxf(v, 0.f);
-        ep[px * C16_EP_LD + 32 * (wv & 1) + (lane & 31)] = v;
+    for (int t = 0; t < 9; ++t) {
+      const int t2 = (t + 2) % 9, c2 = c + (t + 2) / 9;
+      if (!((C16W_ABLATE & 2) && c > 0)) load_b(c2, t2, bs[(t + 2) % 3]);
+      if (t == 0 && !((C16W_ABLATE & 1) && c > 0)) issue_patch(c + 1, stage ^ 1);
+      if (C16W_ABLATE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (t < 3) c16_wait_vm<2 * NBL, WM * NPIT>(nreq);
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NBL) : "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      if (t < 8) tap_addr((t + 1) / 3, (t + 1) % 3, stage, ntb);
+      else tap_addr(0, 0, stage ^ 1, ntb);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        mfmas(mt, fa[mt], bs[t % 3], 0);
+        if (!((C16W_ABLATE & 4) && c > 0)) frag_read(tb[mt] ^ 32, fa[mt]);
+        __builtin_amdgcn_sched_barrier(0);
       }
-  });
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        mfmas(mt, fa[mt], bs[t % 3], 1);
+        if (t < 8 && !((C16W_ABLATE & 4) && c > 0)) frag_read(ntb[mt], fa[mt]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) tb[mt] = ntb[mt];
+      if (t == 8) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                          // every wave has read this patch and received its share of the next
+        __builtin_amdgcn_sched_barrier(0);
+        stage ^= 1;
+        if (c + 1 < nchunk) {
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) frag_read(tb[mt], fa[mt]);
+        }
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the look-ahead requests past the end (filters, zero fill) have landed
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- epilogue, private to the wave: its 128 px x 64 ch go through its own fp32 LDS tile in passes of NPX pixels
+  if (tg * WM + wm >= p.ptiles) return;                         // (the odd tile of the last group)
+  const C16Seg& sg = p.seg[gm.si];
+  float* ep = reinterpret_cast<float*>(lds + wv * R::EPW);
+  float bv[NT2];
+#pragma unroll
+  for (int n2 = 0; n2 < NT2; ++n2) bv[n2] = p.bias ? p.bias[chan0 + 32 * n2 + (lane & 31)] : 0.f;
+  constexpr int MTP = R::NPX / 32;                              // m-tiles per pass
+#pragma unroll
+  for (int ps = 0; ps < 4 / MTP; ++ps) {
+#pragma unroll
+    for (int m = 0; m < MTP; ++m)
+#pragma unroll
+      for (int n2 = 0; n2 < NT2; ++n2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int px = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          float v = fmaf(acc[ps * MTP + m][n2][r], p.acc_scale, bv[n2]);
+          if (p.relu) v = fmaxf(v, 0.f);
+          ep[px * C16_EP_LD + 32 * n2 + (lane & 31)] = v;
+        }
+    c16_epilogue_pass<MM == 3 ? 2 : MM, 64, R::NPX, CW>(p, sg, ep, nullptr, lane, chan0, gm.g0, gm.x0, gm.tw_log2, gm.ylim, ps * R::NPX);
+  }
 }
 
 // Tiling of one segment for the halo-patch kernel: the tile width (32 / 16 / 8 / 4) with the least overhang; false if none fits
 // (a map lower than the tile must divide it: tiles of whole images)
-bool c16_halo_tiling(const G6dConv16Seg& s, int rowb, C16Seg& o, int& tiles) {
+bool c16_halo_tiling(const G6dConv16Seg& s, C16Seg& o, int& tiles) {
   double best = 1e30;
   bool found = false;
   for (int tw = 32; tw >= 4; tw >>= 1) {
@@ -725,8 +838,7 @@ bool c16_halo_tiling(const G6dConv16Seg& s, int rowb, C16Seg& o, int& tiles) {
       o.h_tw_log2 = l2; o.h_tiles_x = tx; o.h_tpi = tpi; o.h_segh = segh; o.h_bands = bands;
       tiles = (int)nt;
       // conflict-free slot swizzles found by tools/ubench/conv16_swizzle.py: ((pcol >> a) + prow * d) & (slots - 1)
-      if (rowb == 128) { o.h_swa = tw == 16 ? 0 : 1; o.h_swd = tw == 4 ? 2 : (tw == 8 ? 4 : (tw == 16 ? 1 : 0)); }
-      else { o.h_swa = tw == 32 ? 2 : (tw == 16 ? 1 : 0); o.h_swd = tw <= 8 ? 1 : 0; }
+      o.h_swa = tw == 32 ? 2 : (tw == 16 ? 1 : 0); o.h_swd = tw <= 8 ? 1 : 0;             // (64-byte patch rows: 4 slots)
     }
   }
   return found;
@@ -802,7 +914,7 @@ extern "C" int g6d_conv16_direct_multi(const G6dConv16Seg* segs, int nseg, int C
     int htiles = 0;
     for (int i = 0; i < nseg && ok; ++i) {
       int nt_ = 0;
-      ok = c16_halo_tiling(segs[i], math_mode == 3 ? 64 : 128, p.seg[i], nt_);
+      ok = c16_halo_tiling(segs[i], p.seg[i], nt_);
       p.seg[i].h_tile0 = htiles; htiles += nt_;
       if (stats && stat_rows_per_group > 0 && ok) {
         const C16Seg& o = p.seg[i];
@@ -812,20 +924,23 @@ extern "C" int g6d_conv16_direct_multi(const G6dConv16Seg* segs, int nseg, int C
       }
     }
     if (ok) {
+      // a block = 4 waves of 128 px x 64 ch (pairs: 32 ch): one pixel tile x 256 (128) channels, or two pixel tiles x 128 channels
+      const int cw = 32 * (math_mode == 3 ? C16W<3>::NT2 : C16W<2>::NT2);
+      const int wm = Cout % (4 * cw) == 0 ? 1 : 2;
       p.ptiles = htiles;
-      const int hblocks = (htiles + 7) / 8 * 8 * p.nN;
-      constexpr int LDSH = 2 * 36864;
-      if (math_mode == 1) {
-        g6d_allow_lds(reinterpret_cast<const void*>(&conv16h_kernel<1>), LDSH);
-        hipLaunchKernelGGL(conv16h_kernel<1>, dim3(hblocks), dim3(256), LDSH, st, p);
-      } else if (math_mode == 2) {
-        g6d_allow_lds(reinterpret_cast<const void*>(&conv16h_kernel<2>), LDSH);
-        hipLaunchKernelGGL(conv16h_kernel<2>, dim3(hblocks), dim3(256), LDSH, st, p);
-      } else {
-        g6d_allow_lds(reinterpret_cast<const void*>(&conv16h_kernel<3>), LDSH);
-        hipLaunchKernelGGL(conv16h_kernel<3>, dim3(hblocks), dim3(256), LDSH, st, p);
-      }
-      return g6d_check_launch("conv16h_direct");
+      p.nN = Cout / (cw * (4 / wm));
+      const int hblocks = ((htiles + wm - 1) / wm + 7) / 8 * 8 * p.nN;
+      auto launch = [&](auto kern, int main_lds, int ep_lds) {
+        const int bytes = main_lds > ep_lds ? main_lds : ep_lds;
+        g6d_allow_lds(reinterpret_cast<const void*>(kern), bytes);
+        hipLaunchKernelGGL(kern, dim3(hblocks), dim3(256), bytes, st, p);
+      };
+#define C16W_LAUNCH(MM_, WM_) launch(&conv16w_kernel<MM_, WM_>, 2 * WM_ * C16W<MM_>::NP * C16W<MM_>::PLANE, 4 * C16W<MM_>::EPW)
+      if (math_mode == 1) { if (wm == 1) C16W_LAUNCH(1, 1); else C16W_LAUNCH(1, 2); }
+      else if (math_mode == 2) { if (wm == 1) C16W_LAUNCH(2, 1); else C16W_LAUNCH(2, 2); }
+      else C16W_LAUNCH(3, 1);                               // (Cout % 128 == 0: always one tile per block)
+#undef C16W_LAUNCH
+      return g6d_check_launch("conv16w_direct");
     }
   }
   const int blocks = (tiles + 7) / 8 * 8 * p.nN;

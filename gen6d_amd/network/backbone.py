@@ -184,7 +184,7 @@ class TrunkLayer(tuple):
             co, ci = self._w.shape[:2]
             # bf16 / fp16: both operand tiles through LDS (measured 9 % faster than filters in registers: the register variant pulls every
             # filter fragment once per wave instead of once per block, profiles/r06_conv16_bench.md); pairs: fragment-major filters in registers
-            self._u16[key] = ops.conv16_pack(self._w.permute(0, 2, 3, 1).reshape(co, 9, ci).contiguous(), mode, layout=1 if mode == 3 else 0)
+            self._u16[key] = ops.conv16_pack(self._w.permute(0, 2, 3, 1).reshape(co, 9, ci).contiguous(), mode, layout=1)
         return self._u16[key]
 
 

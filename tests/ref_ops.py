@@ -538,6 +538,73 @@ def warp_batch(stack, single, idx, hinv, dh, dw, out=None):
     return r
 
 
+# ---- the direct kernel on 16-bit activations (ops.conv16_*): references on the operands' own values -------------------------------
+_T16 = {1: torch.bfloat16, 2: torch.float16, 3: torch.float16}
+
+
+def _to_pairs(v):
+    hi = v.to(torch.float16)
+    lo = (v - hi.to(v.dtype)).to(torch.float16)
+    return torch.stack([hi, lo], -2)
+
+
+def vgg_conv1_pool_nhwc16(x, w_oihw, bias, out=None, norm=None, mode=None):
+    from gen6d_amd import ops
+    mode = ops.MATH_MODE if mode is None else mode
+    y = vgg_conv1_pool_nhwc(x, w_oihw, bias, norm=norm)
+    y = _to_pairs(y) if mode == 3 else y.to(_T16[mode])
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+class _RefConv16Filters:
+    def __init__(self, w_taps, mode, layout):
+        self.w, self.mode, self.layout = w_taps, mode, layout
+        self.Cout, self.taps, self.Cin = w_taps.shape
+        self.acc_scale = 1.0
+        self.data = w_taps
+
+
+def conv16_pack(w_taps, mode, layout=1):
+    """Reference: keeps the fp32 taps (mode 1 / 2: rounded to the 16-bit type, as the kernel's operands are)."""
+    w = w_taps if mode == 3 else w_taps.to(_T16[mode]).to(w_taps.dtype)
+    return _RefConv16Filters(w, mode, layout)
+
+
+def conv16_direct_multi(xs, filt, bias, relu=True, full=None, pool=None, kd=1, stats=None, rows_per_group=0):
+    """Reference of g6d_conv16_direct_multi on the VALUES of the operands (pairs: hi + lo), F.conv2d / F.conv3d in the filters' dtype."""
+    pair = filt.mode == 3
+    dt = filt.w.dtype if filt.w.dtype in (torch.float32, torch.float64) else torch.float32
+    fulls, pools = [], []
+    for x in xs:
+        v = (x[..., 0, :].to(dt) + x[..., 1, :].to(dt)) if pair else x.to(dt)
+        if kd == 1:
+            w = filt.w.to(dt).reshape(filt.Cout, 3, 3, filt.Cin).permute(0, 3, 1, 2)
+            y = F.conv2d(v.permute(0, 3, 1, 2), w, None if bias is None else bias.to(dt), padding=1).permute(0, 2, 3, 1)
+        else:
+            w = filt.w.to(dt).reshape(filt.Cout, 3, 3, 3, filt.Cin).permute(0, 4, 1, 2, 3)
+            y = F.conv3d(v.permute(0, 4, 1, 2, 3), w, None if bias is None else bias.to(dt), padding=1).permute(0, 2, 3, 4, 1)
+        if stats is not None:
+            g = y.reshape(-1, y.shape[-1]) if rows_per_group <= 0 else y.reshape(-1, rows_per_group, y.shape[-1])
+            g = g[None] if rows_per_group <= 0 else g
+            stats[:g.shape[0], :, 0] += g.double().sum(1)
+            stats[:g.shape[0], :, 1] += (g.double() ** 2).sum(1)
+        if relu:
+            y = F.relu(y)
+
+        def coded(t, kind):
+            if kind is None:
+                return None
+            if kind == "t16":
+                return _to_pairs(t) if pair else t.to(_T16[filt.mode])
+            return t.to(torch.float32).contiguous()
+        fulls.append(coded(y, full))
+        pools.append(coded(F.max_pool2d(y.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1), pool) if pool is not None else None)
+    return fulls, pools
+
+
 def patch_ops(monkeypatch):
     """Route gen6d_amd.ops.* to the references above (CPU host-logic tests only)."""
     import sys

@@ -8,6 +8,8 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tools'))
+import toolenv                                                  # noqa: E402,F401  (G6D_LIB_PATH / KNOBS)
 from gen6d_amd import lib, ops                                  # noqa: E402
 from gen6d_amd.network.backbone import winograd43_filters, winograd_filters16       # noqa: E402
 
