@@ -196,6 +196,11 @@ SPLIT16_TRUNK = True     # fp32 path (round 6): the trunks that ran on the F(4x4
                          # kernel with every operand a pair of fp16 values (hi + lo, 22+ significand bits; 3 MFMAs per product on the 16-bit
                          # matrix cores instead of the fp32 ones): fp32-class results — smaller error than F(4x4,3x3)'s — at 1.3-1.6x its speed.
                          # False (tools / tests): the F(4x4,3x3) kernel of rounds 4-5
+SPLIT16_ALWAYS = False   # ... and EVERY fp32 trunk call whose map sizes the kernel takes (the selector's query crops, the refiner's crops at
+                         # any batch size, the reference-side trunks at build time): the trunk's kernel is then a function of the layer, not
+                         # of how many queries share the launch, and its error (2e-6 of range) is below both Winograd kernels'.
+                         # False (default): only where F(4x4,3x3) ran — measured neutral on the batched step (270.9 vs 270.2 images/s) and
+                         # 0.2 ms slower on a single query (7.84 vs 7.62 ms: a crop's 224 tiles do not fill the chip)
 
 
 def _wino_layer(xs, layer, relu=True, full=True, pool=False, f43=False):
@@ -222,8 +227,8 @@ def vgg_taps_cl(packed, x, taps, norm=None, f43=False):
     """Own trunk, channels-last: x [n,3,h,w] normalised image (or an image in [0,1] with norm = (mean, std): the first layer
     normalises while it stages its input) -> {'c3': [n,h/4,w/4,256] post-ReLU, 'c5': [n,h/8,w/8,512] post-ReLU,
     'c7_pre': [n,h/16,w/16,512] pre-ReLU, 'p7': max-pool of c7_pre} (only the requested taps + c7_pre)."""
-    if (ops.MATH_MODE and LOWP_TRUNK) or f43:
-        # reduced precision: the multi-segment 16-bit kernel; f43: the F(4x4,3x3) kernel (one segment)
+    if (ops.MATH_MODE and LOWP_TRUNK) or f43 or (SPLIT16_TRUNK and SPLIT16_ALWAYS and hasattr(packed[1], "w16") and _conv16_eligible([x], taps)):
+        # reduced precision: the multi-segment 16-bit kernel; f43: the F(4x4,3x3) kernel (one segment); fp32 path: the split-precision kernel
         return vgg_taps_cl_multi(packed, [x], taps, norm=norm, f43=f43)[0]
     w0, b0 = packed[0]
     x = ops.vgg_conv1_pool_nhwc(x.contiguous(), w0, b0, norm=norm)              # (normalise +) conv0 + ReLU + pool
@@ -278,7 +283,7 @@ def vgg_taps_cl_multi(packed, xs, taps, norm=None, f43=False):
     tap dicts.  f43: the seven Winograd layers on the F(4x4,3x3) kernel (fp32 mode only)."""
     if ops.MATH_MODE and LOWP_TRUNK and CONV16_TRUNK and hasattr(packed[1], "w16") and _conv16_eligible(xs, taps):
         return _vgg_taps_conv16(packed, xs, taps, norm, ops.MATH_MODE)
-    if f43 and not ops.MATH_MODE and SPLIT16_TRUNK and hasattr(packed[1], "w16") and _conv16_eligible(xs, taps):
+    if (f43 or SPLIT16_ALWAYS) and not ops.MATH_MODE and SPLIT16_TRUNK and hasattr(packed[1], "w16") and _conv16_eligible(xs, taps):
         return _vgg_taps_conv16(packed, xs, taps, norm, 3)
     w0, b0 = packed[0]
     dev = xs[0].device
