@@ -367,7 +367,7 @@ def main():
     # summary of the same command (profiles/rNN_pmc_conv_traffic.json, newest round first; tools/pmc_conv_traffic.py), else null
     traffic_json, traffic_src = {}, None
     # (the CURRENT round's file or null: an older round's ratio printed beside this round's kernels would be stale — VERDICT r04 weak #4)
-    for name in ("r05_pmc_conv_traffic.json",):
+    for name in ("r06_pmc_conv_traffic.json",):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 traffic_json = json.load(f)
@@ -377,7 +377,7 @@ def main():
             pass
     tr_note = (f"STATIC, not measured in this run: {traffic_src} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                "`bench.py --no-graph`, tools/profile_round.sh); HBM-side bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024"
-               if traffic_src else "null: no PMC summary of this round's kernels is committed (profiles/r05_pmc_conv_traffic.json)")
+               if traffic_src else "null: no PMC summary of this round's kernels is committed (profiles/r06_pmc_conv_traffic.json)")
     # two MFMA-bound kernel families, both measured with HIP events around every launch (serialised eager re-run of the same
     # steps after the graph-replay timed region when graphs are used):
     #   conv      conv_igemm / conv_patch / corr_patch (split launches finish inside the kernel); executed = direct-form FLOPs
@@ -405,7 +405,7 @@ def main():
         fl = sum(p[0] for p in pp) * (3.0 if key == "split16" else 1.0)
         ms = sum(p[1].elapsed_time(p[2]) for p in pp)
         ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        tj = traffic_json if key == "conv" else traffic_json.get("winograd_family", {}) if key == "winograd" else {}
+        tj = traffic_json if key == "conv" else traffic_json.get("winograd_family" if key == "winograd" else "split16_family", {})
         peak = LOWP_MFMA_PEAK_TFLOPS if key == "split16" else FP32_MFMA_PEAK_TFLOPS
         fams[key] = {"bound": "mfma", "kernel": kname, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                      "frac": ach / peak, "traffic": tj.get("hbm_bytes_per_launch"), "traffic_source": tr_note if tj else None,

@@ -64,9 +64,9 @@ def _apply_session_switches():
 
 
 def pytest_sessionstart(session):
-    """Achieved parity errors of the GPU tests are appended to gpurun_out/parity_r05.jsonl (tools/parity_table.py turns
+    """Achieved parity errors of the GPU tests are appended to gpurun_out/parity_r06.jsonl (tools/parity_table.py turns
     them into profiles/r05_parity.md)."""
-    os.environ.setdefault("G6D_PARITY_LOG", os.path.join(ROOT, "gpurun_out", "parity_r05.jsonl"))
+    os.environ.setdefault("G6D_PARITY_LOG", os.path.join(ROOT, "gpurun_out", "parity_r06.jsonl"))
     _apply_session_switches()
 
 

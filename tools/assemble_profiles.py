@@ -48,10 +48,12 @@ def main():
     ms, main = family_ms(sstats)
     wms, wmain = family_ms(sstats, WFAMILY)
     fams = {ser["roofline"].get("family", "conv"): ser["roofline"]}
-    for k in ("conv", "winograd"):
+    for k in ("conv", "winograd", "split16"):
         if "roofline_" + k in ser:
             fams[k] = ser["roofline_" + k]
     r, w = fams["conv"], fams.get("winograd", {})
+    s16 = fams.get("split16", {})
+    s16ms, s16main = family_ms(sstats, ("conv16",))
     gflop_step = r["gflop_per_launch"] * r["launches_per_step"]
     wg = w.get("gflop_direct_form_per_step", 0.0)
     wexec = w.get("gflop_per_launch", 0.0) * w.get("launches_per_step", 0.0)
@@ -70,7 +72,12 @@ def main():
         f"{wexec:.1f} GFLOP executed in the Winograd domain (direct / 2.25 on F(2x2,3x3) launches, direct / 4 on F(4x4,3x3) launches) -> "
         f"{wexec / max(wms / steps, 1e-9):.1f} TFLOP/s executed, "
         f"{wg / max(wms / steps, 1e-9):.1f} TFLOP/s direct-form equivalent; bench.py: {w.get('ms_per_step', 0):.2f} ms per step, "
-        f"{w.get('achieved', 0):.1f} TFLOP/s executed; by transform: {json.dumps({k: {kk: round(vv, 2) for kk, vv in v.items()} for k, v in w.get('by_transform', {}).items()})}).\n\n" + sstats)
+        f"{w.get('achieved', 0):.1f} TFLOP/s executed; by transform: {json.dumps({k: {kk: round(vv, 2) for kk, vv in v.items()} for k, v in w.get('by_transform', {}).items()})}).\n"
+        "* split-precision family (conv16w_kernel<3, 1>: the detector pyramid's and the refiner crops' VGG trunks as a direct convolution on fp16 hi / lo\n"
+        "  pairs, three v_mfma_f32_32x32x16_f16 per product):\n"
+        f"  {s16ms:.2f} ms = {s16ms / steps:.2f} ms per step ({s16main / steps:.0f} launches per step, {s16.get('gflop_direct_form_per_step', 0):.1f} GFLOP per step in DIRECT form, x3 executed -> "
+        f"{3 * s16.get('gflop_direct_form_per_step', 0) / max(s16ms / steps, 1e-9):.1f} TFLOP/s executed on the 16-bit matrix cores by kernel durations; bench.py: "
+        f"{s16.get('ms_per_step', 0):.2f} ms per step, {s16.get('achieved', 0):.1f} TFLOP/s executed = {s16.get('frac', 0):.3f} of 2500).\n\n" + sstats)
     traffic = json.load(open(os.path.join(G, "pmc_conv_traffic.json")))
     open(os.path.join(P, f"{RND}_pmc_hbm.md"), "w").write(
         "# HBM traffic counters (rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes, no other trace domains)\n\n"
@@ -94,7 +101,9 @@ def main():
     shutil.copy(os.path.join(G, "pmc_conv_traffic.json"), os.path.join(P, f"{RND}_pmc_conv_traffic.json"))
     for src, dst in (("bench_final.json", "bench.json"), ("layer_table.md", "layer_table.md"), ("trunk_bench.md", "trunk_bench.md"),
                      ("layer_table_b8.md", "layer_table_batch8.md"), ("layer_table_b1.md", "layer_table_batch1.md"),
-                     ("layer_table_fp16.md", "layer_table_fp16.md"),
+                     ("layer_table_fp16.md", "layer_table_fp16.md"), ("layer_table_b16.md", "layer_table_batch16.md"),
+                     ("conv16_bench.md", "conv16_bench.md"), ("mfma16_peak.md", "mfma16_peak.md"), ("pmc_conv16_lds.md", "pmc_conv16_lds.md"),
+                     ("conv16w_scaling.md", "conv16w_scaling.md"),
                      ("batch_sweep_all.txt", "batch_sweep.txt"), ("prof_b1_serial_stats.md", "kernel_stats_single_query.md"),
                      ("bench_gpus2.json", "bench_gpus2.json"), ("bench_gpus2_shard.json", "bench_gpus2_shard_refs.json"),
                      ("bench_chained.json", "bench_chained.json"), ("bench_shard_rccl_world1.json", "bench_shard_refs_rccl_world1.json"),

@@ -1,8 +1,9 @@
 # Round-end measurements on the GPU box (gpurun): full GPU test suite, smoke, the bench line as the driver runs it, 2-rank gloo runs
+rm -rf gen6d_amd/csrc/_abl   # ablation builds of the round (28 MB of profiling binaries once rode on every driver push: VERDICT r05 weak #11)
 # (replicas / sharded references), then the rocprofv3 round profile (tools/profile_round.sh).  Raw outputs -> gpurun_out/;
 # tools/assemble_profiles.py rNN + tools/parity_table.py + tools/sweep_table.py commit them under profiles/.
 cd $GRAFT_REPO_ROOT
-export G6D_PARITY_LOG=$PWD/gpurun_out/parity_r05.jsonl; rm -f $G6D_PARITY_LOG
+export G6D_PARITY_LOG=$PWD/gpurun_out/parity_r06.jsonl; rm -f $G6D_PARITY_LOG
 (timeout 1500 python -m pytest tests -m gpu -q --maxfail=12 --durations=25 2>&1 | tail -70) > gpurun_out/final_tests.log; tail -3 gpurun_out/final_tests.log
 unset G6D_PARITY_LOG
 timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1

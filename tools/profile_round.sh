@@ -14,4 +14,18 @@ python $R/tools/rocpd_pmc.py /tmp/pu/pmc_results.db MfmaUtil > $R/gpurun_out/pmc
 cd $R
 BATCH=8 python tools/layer_table.py > gpurun_out/layer_table_b8.md 2>&1
 BATCH=1 python tools/layer_table.py > gpurun_out/layer_table_b1.md 2>&1
-BATCH=8 LOWP=fp16 python tools/layer_table.py > gpurun_out/layer_table_fp16.md 2>&1
+BATCH=16 LOWP=fp16 python tools/layer_table.py > gpurun_out/layer_table_fp16.md 2>&1
+BATCH=16 python tools/layer_table.py > gpurun_out/layer_table_b16.md 2>&1
+# round 6: the direct 16-bit convolution family per trunk layer, the sustained MFMA rate, and the LDS-side counters of the three generations
+# of the reduced-precision trunk kernel (16-bit Winograd on fp32 activations, per-tap direct kernel, halo-patch direct kernel)
+python tools/conv16_bench.py 16 fp16 > gpurun_out/conv16_bench.md 2>/dev/null
+tools/ubench/mfma16_peak.bin > gpurun_out/mfma16_peak.md 2>&1
+python tools/ubench/conv16w_scaling.py > gpurun_out/conv16w_scaling.md 2>/dev/null
+cd /tmp
+for c in SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT MfmaUtil; do
+  timeout 300 rocprofv3 --kernel-trace --pmc $c -d /tmp/pl_$c -o pmc -- python $R/tools/conv16_bench.py 16 fp16 > /dev/null 2>&1
+done
+( echo "# LDS-side counters of the reduced-precision trunk kernels (rocprofv3 --kernel-trace --pmc <one counter per pass> -- python tools/conv16_bench.py 16 fp16;"
+  echo "# every kernel runs the same 14 trunk layers 6 times: per-dispatch means are comparable between kernels)"
+  for c in SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT MfmaUtil; do echo; echo "## $c"; python $R/tools/rocpd_pmc.py /tmp/pl_$c/pmc_results.db $c | grep -i "kernel\|---\|conv16\|wino16\|wino43"; done ) > $R/gpurun_out/pmc_conv16_lds.md
+cd $R
