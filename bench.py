@@ -661,6 +661,9 @@ def main():
                 lowp[mode_name] = entry
         reset_scheme()
         if lowp:
+            # the scheme to use: the fastest one whose all-rows bar holds on the 4 bench + 16 held-out queries (None: none of the measured ones)
+            okd = [k for k, v in lowp.items() if isinstance(v, dict) and v.get("ok")]
+            lowp["recommended"] = max(okd, key=lambda k: lowp[k]["value"]) if okd else None
             result["lowp"] = lowp
         lanes = headline_lanes
     except Exception as e:                 # a side measurement must not take the headline line with it

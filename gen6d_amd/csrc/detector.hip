@@ -141,7 +141,9 @@ __global__ void resize_pyramid_kernel(const PyrArgs a) {
   // before the first value is used.  (One output per thread: 176 us per batch of 16 queries; one item walking all 48 planes: 186 us — too
   // few threads; this version 148 us; ATen's three launches: 115 us — 0.05 % of a step apart.)
   const unsigned total = (unsigned)a.first[a.n];
-  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+  // (64-bit walk: with totals near 2^32 a 32-bit index would wrap past the end instead of leaving the loop)
+  for (unsigned long i64 = blockIdx.x * blockDim.x + threadIdx.x; i64 < total; i64 += (unsigned long)gridDim.x * blockDim.x) {
+    const unsigned i = (unsigned)i64;
     int k = 0;
 #pragma unroll
     for (int j = 1; j < 4; ++j) k = (j < a.n && i >= (unsigned)a.first[j]) ? j : k;

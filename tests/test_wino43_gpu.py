@@ -164,11 +164,15 @@ W43_CONV_CASES = [
 ]
 
 
+@pytest.mark.parametrize("w43_map", [2, 1, 0], ids=lambda m: f"map{m}")
 @pytest.mark.parametrize("c", W43_CONV_CASES, ids=lambda c: f"{c['N']}x{c['D']}x{c['H']}_{c['Cin']}x{c['Cout']}")
-def test_conv_on_wino43_kernel(ops, c):
+def test_conv_on_wino43_kernel(ops, c, w43_map, knob):
     """ops.conv with G6dConv.weight_wino43: prologue (InstanceNorm affine, per-image tables), depth fold, statistics and their fused
-    finalisation on the F(4x4,3x3) kernel against the fp64 reference."""
+    finalisation on the F(4x4,3x3) kernel against the fp64 reference — under every block-id decode of the kernel (knob w43_map: 2 = slices
+    fastest (product default), 1 = XCD groups with a short last group, 0 = plain grid; the split-K tile counters and the finalize count
+    depend on that decode: ADVICE r05)."""
     from gen6d_amd.network.backbone import winograd43_filters_taps
+    knob("w43_map", w43_map)
     g = torch.Generator().manual_seed(43)
     N, D, H, W, Cin, Cout = c["N"], c["D"], c["H"], c["W"], c["Cin"], c["Cout"]
     kd = c.get("kd", 3)

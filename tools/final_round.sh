@@ -21,7 +21,7 @@ for f in ("bench_final", "bench_gpus2", "bench_gpus2_shard", "bench_shard_rccl_w
     try:
         d = json.loads(open(f"gpurun_out/{f}.json").read().strip().splitlines()[-1])
         print(f, round(d["value"], 2), "batch", d.get("batch"), d.get("ranks_seen"), d.get("backend"), "coll/query", (d.get("collectives_per_query") or {}).get("total"),
-              "single", d.get("single_query_ms"), {k: round(v["value"], 1) for k, v in (d.get("lowp") or {}).items()}, (d.get("chained") or {}).get("value"), d.get("parity_vs_reference"))
+              "single", d.get("single_query_ms"), {k: round(v["value"], 1) for k, v in (d.get("lowp") or {}).items() if isinstance(v, dict)}, (d.get("chained") or {}).get("value"), d.get("parity_vs_reference"))
     except Exception as e:
         print(f, "failed", e)
 PY
