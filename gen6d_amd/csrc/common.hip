@@ -61,6 +61,7 @@ const KnobDef kKnobs[G6D_KNOB_COUNT] = {
     {"gemv_mfma", 1},         // linear layers on the matrix cores: 1 for 17..32 right-hand sides (measured rule), 2 from 2 on, 0 never
     {"c16_ablate", 0},        // conv16_direct, timing experiments only (WRONG results): bit 0 = no activation DMA after the first steps, bit 1 = no filter requests after them
     {"conv16_halo", 1},       // conv16_direct with fragment-major filters, 2-D layers: the halo-patch kernel (0: the per-tap kernel conv16r)
+    {"conv_narrow", 1},       // conv_igemm: 3x3 layers with <= 4 output channels on the vector-ALU dot-product kernel (0: a matrix-core tile)
 };
 // Process-global table, filled when the library is loaded (static initialisation, before any entry point can run); reads and writes
 // are relaxed atomics, so a g6d_set_knob racing with launches on other threads is a benign race on one value (a launch sees the

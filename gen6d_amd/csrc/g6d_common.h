@@ -60,7 +60,7 @@ enum G6dKnob {
   G6D_KNOB_CONV_PATCH, G6D_KNOB_TILE_POLICY, G6D_KNOB_SPLIT_TARGET, G6D_KNOB_PATCH_PIPE, G6D_KNOB_CORR_SLOTS, G6D_KNOB_SEL_ROWQ,
   G6D_KNOB_CONV1_MFMA, G6D_KNOB_W43_SPLIT_MAX, G6D_KNOB_W43_SPLIT_GAIN, G6D_KNOB_W43_CHUNK_US, G6D_KNOB_WINO_DEBUG, G6D_KNOB_CONV_WINO43,
   G6D_KNOB_WINO_WIDE, G6D_KNOB_WINO_SPLIT_MAX, G6D_KNOB_WINO_SPLIT_GAIN, G6D_KNOB_WINO_SPLIT_FIX, G6D_KNOB_WINO_SPLIT_PER, G6D_KNOB_WINO16_2W,
-  G6D_KNOB_CONV_WINO, G6D_KNOB_CONV_WINO16, G6D_KNOB_WINO_MIN_WORK, G6D_KNOB_W43_MAP, G6D_KNOB_CONV_PM, G6D_KNOB_GEMV_MFMA, G6D_KNOB_C16_ABLATE, G6D_KNOB_CONV16_HALO, G6D_KNOB_COUNT
+  G6D_KNOB_CONV_WINO, G6D_KNOB_CONV_WINO16, G6D_KNOB_WINO_MIN_WORK, G6D_KNOB_W43_MAP, G6D_KNOB_CONV_PM, G6D_KNOB_GEMV_MFMA, G6D_KNOB_C16_ABLATE, G6D_KNOB_CONV16_HALO, G6D_KNOB_CONV_NARROW, G6D_KNOB_COUNT
 };
 double g6d_knob(int id);
 

@@ -210,7 +210,11 @@ def conv(x, w, bias, out, ksize=(1, 1, 1), stride=(1, 1, 1), pad=(0, 0, 0), mul=
         e1.record()
         fam = _lib.load().g6d_conv_plan(C.byref(d))
         fl = 2.0 * N * Do * Ho * Wo * Cout * kd * kh * kw * Cin
-        PROFILE.append((fl / 4 if fam == 3 else (fl / 2.25 if fam == 2 else fl), e0, e1,      # Winograd kernels: FLOPs executed in the transform domain
+        if fam == 4:          # narrow-output layer on the vector ALUs: bound by reading its input, booked with the HBM-bound kernels
+            if PROFILE_HBM is not None:
+                PROFILE_HBM.setdefault("conv_narrow", []).append((4.0 * (N * Di * Hi * Wi * Cin + w.numel() + N * Do * Ho * Wo * Cout), e0, e1))
+        else:
+            PROFILE.append((fl / 4 if fam == 3 else (fl / 2.25 if fam == 2 else fl), e0, e1,      # Winograd kernels: FLOPs executed in the transform domain
                         ("wino3x3 F43 " if fam == 3 else "wino3x3 " if fam == 2 else "") + f"conv N={N} in={Di}x{Hi}x{Wi}x{Cin} out={Do}x{Ho}x{Wo}x{Cout} k={kd}x{kh}x{kw} s={stride[0]}{stride[1]}{stride[2]}"
                         f"{' mul' if mul is not None else ''}{' aff' if in_scale is not None else ''}{' stats' if stats is not None else ''}",
                         # algorithmic bytes: every operand once (input images, multiplier maps, filters, output)

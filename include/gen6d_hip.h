@@ -39,7 +39,7 @@ const char* g6d_last_error(void);
 /* Launch-policy knobs.  The library reads NO environment variable: every dispatch decision that tools/ and tests want to force (a kernel
  * variant for an A/B run, a constant of a split model for a sweep) is a named knob with the product default — conv_patch, tile_policy,
  * split_target, patch_pipe, corr_slots, sel_rowq, conv1_mfma, w43_split_max / _gain / w43_chunk_us, wino_debug, conv_wino43, wino_wide,
- * wino_split_max / _gain / _fix / _per, wino16_2w, conv_wino, conv_wino16, wino_min_work, w43_map, conv_pm, gemv_mfma, c16_ablate, conv16_halo (gen6d_amd/csrc/common.hip lists meanings
+ * wino_split_max / _gain / _fix / _per, wino16_2w, conv_wino, conv_wino16, wino_min_work, w43_map, conv_pm, gemv_mfma, c16_ablate, conv16_halo, conv_narrow (gen6d_amd/csrc/common.hip lists meanings
  * and defaults).  Process-wide; reads and writes are relaxed atomics (a launch racing with g6d_set_knob sees the old or the new value):
  * set them before the launches they are meant to steer.  g6d_set_knob returns G6D_EINVAL for an unknown name; g6d_get_knob returns
  * -1e300 for one. */

@@ -36,6 +36,7 @@ def test_knobs_have_product_defaults_and_no_environment_reads():
     assert lib.get_knob("conv_wino") == 1 and lib.get_knob("wino_min_work") == -1 and lib.get_knob("split_target") == 512
     # (round 5's knobs: the name table and the enum of g6d_common.h must stay in the same order)
     assert lib.get_knob("w43_map") == 2 and lib.get_knob("conv_pm") == 1 and lib.get_knob("gemv_mfma") == 1
+    assert lib.get_knob("c16_ablate") == 0 and lib.get_knob("conv16_halo") == 1 and lib.get_knob("conv_narrow") == 1      # (round 6)
     lib.set_knob("conv_wino", 0)
     assert lib.get_knob("conv_wino") == 0
     lib.reset_knobs()

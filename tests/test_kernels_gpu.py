@@ -94,6 +94,24 @@ def test_conv_igemm(ops, case):
     _run_conv_case(ops, case, False)
 
 
+# Layers with at most four output channels (the detector heads' merged last conv, reference network/detector.py:164-184) run on the
+# vector-ALU dot-product kernel (conv_narrow_kernel, round 6): odd widths (partial pixel runs), Cin with idle lanes, a channel slice of
+# a wider input, every activation, and the matrix-core fall-back under the knob.
+NARROW_CASES = [
+    dict(N=3, D=1, H=9, W=13, Cin=192, Cout=4, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1)),
+    dict(N=2, D=1, H=5, W=8, Cin=64, Cout=1, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), act=1),
+    dict(N=1, D=1, H=16, W=21, Cin=256, Cout=3, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), act=2, ld_in=320, ld_out=8),
+    dict(N=16, D=1, H=60, W=80, Cin=192, Cout=4, k=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1)),                 # the headline's head layer
+]
+
+
+@pytest.mark.parametrize("narrow", [1, 0], ids=["vector-ALU", "matrix-core"])
+@pytest.mark.parametrize("case", NARROW_CASES, ids=lambda c: f"{c['N']}x{c['H']}x{c['W']}_{c['Cin']}x{c['Cout']}")
+def test_conv_narrow(ops, case, narrow, knob):
+    knob("conv_narrow", narrow)
+    _run_conv_case(ops, case, False)
+
+
 # Position-major tiles of conv_igemm (round 5): small 2-D maps with >= 4 tiles of images — a tile is one output position of 128 (64)
 # consecutive images and the K loop skips the taps that fall into the zero padding.  Ragged image counts (partial last tile, partial
 # last group of 8 tiles), every operand prologue, statistics groups that straddle tiles, and the forced fall-backs.
