@@ -27,5 +27,5 @@ for c in SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT MfmaUtil; do
 done
 ( echo "# LDS-side counters of the reduced-precision trunk kernels (rocprofv3 --kernel-trace --pmc <one counter per pass> -- python tools/conv16_bench.py 16 fp16;"
   echo "# every kernel runs the same 14 trunk layers 6 times: per-dispatch means are comparable between kernels)"
-  for c in SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT MfmaUtil; do echo; echo "## $c"; python $R/tools/rocpd_pmc.py /tmp/pl_$c/pmc_results.db $c | grep -i "kernel\|---\|conv16\|wino16\|wino43"; done ) > $R/gpurun_out/pmc_conv16_lds.md
+  for c in SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT MfmaUtil; do echo; echo "## $c"; python $R/tools/rocpd_pmc.py /tmp/pl_$c/pmc_results.db $c | grep "^| kernel\|^|---\|conv16\|wino16\|wino43"; done ) > $R/gpurun_out/pmc_conv16_lds.md
 cd $R
