@@ -93,6 +93,63 @@ def test_reference_sharded_selector_matches_golden(tmp_path, world, port):
     assert out.stdout.count("sharded selector ok") == world
 
 
+LANES_WORKER = textwrap.dedent("""
+    import sys, threading, time, numpy as np, torch
+    sys.path.insert(0, %r); sys.path.insert(0, %r)
+    import ref_ops
+    from gen6d_amd import ops, parallel, synth
+    from gen6d_amd.network import name2network
+    for name in dir(ops):
+        if not name.startswith("_") and callable(getattr(ops, name)) and hasattr(ref_ops, name):
+            setattr(ops, name, getattr(ref_ops, name))
+    rank, world, local = parallel.init_from_env(backend="gloo")
+    g = dict(np.load(%r))
+    rfn, an = int(g["rfn"]), int(g["an"])
+    groups = parallel.lane_groups(2)                     # lane 0: the default group, lane 1: its own communicator (created collectively)
+    assert groups[0] is None and groups[1] is not None
+    case = synth.selector_case(rfn, an)
+    nets, outs = [], [None, None]
+    for lane in range(2):
+        net = name2network["selector"]({"name": "t", "selector_angle_num": an}).eval()
+        net.load_state_dict(synth.synth_state_dict("selector", an=an))
+        net.set_shard(rank, world, group=groups[lane])
+        nets.append(net)
+
+    def run(lane):
+        with torch.no_grad():
+            outs[lane] = nets[lane]({"ref_imgs": case["ref_imgs"], "ref_imgs_info": {"poses": case["ref_poses"]},
+                                     "object_center": case["object_center"], "object_vert": case["object_vert"],
+                                     "que_imgs_info": {"imgs": case["que_imgs"]}, "eval": True})
+    # the two lanes run CONCURRENTLY, started in opposite orders on the two ranks: their collectives interleave differently on every
+    # rank — legal only because each lane's collectives live in their own communicator (inside one they would pair up wrongly or hang)
+    order = (0, 1) if rank %% 2 == 0 else (1, 0)
+    threads = [threading.Thread(target=run, args=(lane,)) for lane in order]
+    threads[0].start(); time.sleep(0.3); threads[1].start()
+    for t in threads:
+        t.join(timeout=500)
+        assert not t.is_alive(), "a lane hung"
+    for lane in range(2):
+        np.testing.assert_allclose(outs[lane]["ref_vp_logits"].numpy(), g["logits"], atol=2e-3)
+        assert np.array_equal(outs[lane]["ref_vp_logits"].argmax(1).numpy(), g["logits"].argmax(1))
+    assert torch.equal(outs[0]["ref_vp_logits"], outs[1]["ref_vp_logits"])
+    print("rank", rank, "two lanes ok")
+""")
+
+
+def test_two_lanes_on_two_communicators(tmp_path):
+    """Round 6: the reference-sharded mode keeps several batches in flight because every hipGraph lane enqueues its
+    collectives on its OWN process group (parallel.lane_groups).  Two gloo ranks, two lanes in threads started in opposite orders on the two
+    ranks: both lanes reproduce the reference's logits, bit-identically to each other."""
+    script = tmp_path / "lanes_worker.py"
+    script.write_text(LANES_WORKER % (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden", "sel_small.npz")))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29641", str(script)],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert out.stdout.count("two lanes ok") == 2
+
+
 DET_WORKER = textwrap.dedent("""
     import sys, numpy as np, torch
     sys.path.insert(0, %r); sys.path.insert(0, %r)
