@@ -83,7 +83,7 @@ extern "C" double g6d_get_knob(const char* name) {
 }
 extern "C" void g6d_reset_knobs(void) { knob_defaults(); }
 
-extern "C" int g6d_abi_version(void) { return 11; }
+extern "C" int g6d_abi_version(void) { return 12; }
 extern "C" const char* g6d_last_error(void) { return g_err; }
 extern "C" int g6d_sizeof_conv_desc(void) { return (int)sizeof(G6dConv); }
 

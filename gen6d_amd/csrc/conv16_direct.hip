@@ -615,18 +615,20 @@ __global__ __launch_bounds__(256, 2) void conv16w_kernel(const C16Params p) {
   typedef __attribute__((address_space(3))) void* lds_ptr;
 
   // ---- the patch pieces this lane requests per slice: tile tl, piece k = wv + 4 i of its NP * ni pieces (plane k / ni, rows 16 (k % ni) + lane / 4)
-  unsigned poff[WM][NPIT];
-  int nreq = 0, t_ni[WM], t_si[WM];
+  // A piece none of whose lanes lies inside the map (halo pixels outside the image, the tail of the last piece) is not requested: its LDS
+  // rows are zeroed here, once, in both stages (the geometry is the same for every slice).
+  unsigned poff[WM][NPIT], pmask[WM];
+  int t_ni[WM], t_si[WM];
 #pragma unroll
   for (int tl = 0; tl < WM; ++tl) {
     const C16Geom gm = c16w_geom(p, min(tg * WM + tl, p.ptiles - 1));
     const C16Seg& sg = p.seg[gm.si];
     const int npt = NP * gm.ni;
     t_ni[tl] = gm.ni; t_si[tl] = gm.si;
+    pmask[tl] = 0;
 #pragma unroll
     for (int i = 0; i < NPIT; ++i) {
       const int k = wv + 4 * i;
-      if (k < npt) ++nreq;
       const int pl = k >= gm.ni ? 1 : 0, ii = k - pl * gm.ni;
       const int q = ii * 16 + (lane >> 2);
       const int prow = q / gm.PW, pcol = q - prow * gm.PW;
@@ -636,22 +638,32 @@ __global__ __launch_bounds__(256, 2) void conv16w_kernel(const C16Params p) {
       const bool ok = k < npt && q < gm.P && yimg >= 0 && yimg < sg.H && g < sg.rows && x >= 0 && x < sg.W;
       const int slot = (lane & 3) ^ (((pcol >> gm.swa) + prow * gm.swd) & 3);
       poff[tl][i] = ok ? (unsigned)((((long)g * sg.W + x) * sg.ld_in + pl * p.Cin) * 2 + slot * 16) : C16_OOB;
+      if (k < npt) {
+        if (__builtin_amdgcn_ballot_w64(ok) != 0) pmask[tl] |= 1u << i;
+        else {
+          const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+          char* dst = lds + tl * TILE_B + pl * R::PLANE + ii * 1024 + lane * 16;
+          *reinterpret_cast<f32x4*>(dst) = z;
+          *reinterpret_cast<f32x4*>(dst + STAGE) = z;
+        }
+      }
     }
+    pmask[tl] = __builtin_amdgcn_readfirstlane(pmask[tl]);
   }
-  nreq = __builtin_amdgcn_readfirstlane(nreq);
   auto issue_patch = [&](int c, int stage) {
-    const unsigned ck = c < nchunk ? (unsigned)(c * 64) : C16_OOB;      // past the last slice: zero fill (keeps the request count uniform)
+    if (c >= nchunk) return;                                           // (no request past the last slice: the waits count 0 pieces there)
+    const unsigned ck = (unsigned)(c * 64);
 #pragma unroll
     for (int tl = 0; tl < WM; ++tl) {
       const C16Seg& sg = p.seg[t_si[tl]];
       const __amdgpu_buffer_rsrc_t rs_in = c16_rsrc(sg.in, sg.in_bytes - sg.back);
-      const int ni = t_ni[tl], npt = NP * ni;
+      const int ni = t_ni[tl];
 #pragma unroll
       for (int i = 0; i < NPIT; ++i) {
         const int k = wv + 4 * i;
-        if (k < npt) {
+        if (pmask[tl] >> i & 1) {
           const int pl = k >= ni ? 1 : 0, ii = k - pl * ni;
-          const unsigned vo = (poff[tl][i] | ck) >= C16_OOB ? C16_OOB : poff[tl][i] + ck;
+          const unsigned vo = poff[tl][i] == C16_OOB ? C16_OOB : poff[tl][i] + ck;
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr)(lds + stage * STAGE + tl * TILE_B + pl * R::PLANE + ii * 1024), 16, vo, 0, 0, 0);
         }
       }
@@ -728,8 +740,12 @@ __global__ __launch_bounds__(256, 2) void conv16w_kernel(const C16Params p) {
     }
   };
 
-  // ---- K loop: slices outermost (one patch, one barrier each), the nine taps unrolled inside.  Requests return in order: before the
-  // MFMAs of step (c, t) the wait allows what was requested after B(c, t) — two filter sets, plus the next patch while it is younger.
+  // ---- K loop: slices outermost (one patch, one barrier each), the nine taps unrolled inside.  FILTER loads return in order among
+  // themselves, so before the MFMAs of step (c, t) vmcnt(2 NBL) — the two younger filter sets — proves B(c, t) has arrived.  LDS-DMA
+  // requests are NOT ordered against them (measured on corr16_kernel: a counted wait that budgeted the younger patch pieces let MFMAs
+  // start on filters still in flight once the filters missed L2 — the DMA of L2-resident activations overtakes them): the wait therefore
+  // never budgets for DMA pieces (while some are in flight it is merely stricter than needed), and the wave's own pieces of the next
+  // patch are drained with vmcnt(0) before the slice's barrier.
   // ONE set of activation fragments, replaced m-tile by m-tile: right after the MFMAs of (m-tile, 16-channel group) have issued, the
   // same registers receive the m-tile's fragment of the NEXT group (the other half of the slice, or the next tap) — consumed eight
   // MFMAs later.
@@ -739,7 +755,7 @@ __global__ __launch_bounds__(256, 2) void conv16w_kernel(const C16Params p) {
   issue_patch(0, 0);
   load_b(0, 0, bs[0]);
   load_b(0, 1, bs[1]);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // (lgkmcnt: the zeroed halo pieces)
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
   tap_addr(0, 0, 0, tb);
@@ -757,7 +773,6 @@ __global__ __launch_bounds__(256, 2) void conv16w_kernel(const C16Params p) {
       if (!((C16W_ABLATE & 2) && c > 0)) load_b(c2, t2, bs[(t + 2) % 3]);
       if (t == 0 && !((C16W_ABLATE & 1) && c > 0)) issue_patch(c + 1, stage ^ 1);
       if (C16W_ABLATE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else if (t < 3) c16_wait_vm<2 * NBL, WM * NPIT>(nreq);
       else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NBL) : "memory");
       __builtin_amdgcn_sched_barrier(0);
       if (t < 8) tap_addr((t + 1) / 3, (t + 1) % 3, stage, ntb);
@@ -777,7 +792,7 @@ __global__ __launch_bounds__(256, 2) void conv16w_kernel(const C16Params p) {
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) tb[mt] = ntb[mt];
       if (t == 8) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (vmcnt: this wave's pieces of the next patch, see above)
         __builtin_amdgcn_s_barrier();                          // every wave has read this patch and received its share of the next
         __builtin_amdgcn_sched_barrier(0);
         stage ^= 1;
@@ -788,7 +803,7 @@ __global__ __launch_bounds__(256, 2) void conv16w_kernel(const C16Params p) {
       }
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the look-ahead requests past the end (filters, zero fill) have landed
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the look-ahead filter requests past the end have landed
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
 
@@ -816,6 +831,242 @@ __global__ __launch_bounds__(256, 2) void conv16w_kernel(const C16Params p) {
     c16_epilogue_pass<MM == 3 ? 2 : MM, 64, R::NPX, CW>(p, sg, ep, nullptr, lane, chan0, gm.g0, gm.x0, gm.tw_log2, gm.ylim, ps * R::NPX);
   }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// corr16_kernel: the detector's K x K correlation (K = 15, 7; reference network/detector.py:188-197,222-224: the query's feature map
+// correlated with the 32 reference-centre features) on 16-bit activations — the halo-patch scheme of conv16w_kernel with K^2 taps
+// per patch.  Cout = 32 (the reference views), so a 128-pixel tile has ONE wave's worth of output channels: the block's EIGHT waves
+// (two per SIMD) split the TAPS of every slice (wave w: taps w, w + 8, ...), each accumulates its partial 128 px x 32 ch sums over
+// all slices, and the partials are added through LDS at the end.  A NINTH wave requests the patches (see inside).
+//   * patch: (TH + K - 1) x (TW + K - 1) rows of 64 B, double-buffered (2 x 43 KB at K = 15); a row holds TWO fragments at addr and
+//     addr ^ 32: the two 16-channel groups of a 32-channel slice (MM = 1 / 2), or the hi and lo plane of a 16-channel slice (MM = 3:
+//     fp16 pairs, fp32-class results) — the same LDS geometry, addressing and filter traffic in both arithmetics;
+//   * filters: [slice][tap][2 fragments][64 lanes][8 values] (host: ops.corr16_pack), 2 KB per (slice, tap), straight into registers two
+//     of the wave's taps ahead; a slice's K^2 x 2 KB are read by one wave each;
+//   * per tap a wave issues 8 (MM = 3: 12) MFMAs, 8 ds_read_b128 (one fragment set, replaced m-tile by m-tile) and ~24 address VALUs.
+struct Corr16Seg {
+  const char* in; float* out;
+  int H, W, rows, ld_in, ld_out;
+  int tw_log2, tiles_x, tpi, tile0, swa, swd;
+  unsigned in_bytes;
+};
+struct Corr16Params {
+  Corr16Seg seg[4];
+  int nseg, Cin, K, ptiles, nslice;
+  const char* w;
+  float acc_scale;
+};
+constexpr int CORR16_STAGE = 42 * 1024;                      // 672 patch rows of 64 B (K = 15, 8 x 16 tile: 660)
+
+template <int MM>
+__global__ __launch_bounds__(576, 1) void corr16_kernel(const Corr16Params p) {
+  typedef typename C16T3<MM>::V V8;
+  constexpr int NPL = CORR16_STAGE / 1024;                    // patch pieces per slice at most (42)
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ptile = blockIdx.x;
+  int si = 0;
+#pragma unroll
+  for (int i = 1; i < 4; ++i) if (i < p.nseg && ptile >= p.seg[i].tile0) si = i;
+  const Corr16Seg& sg = p.seg[si];
+  const int t = ptile - sg.tile0;
+  const int tw_log2 = sg.tw_log2, TW = 1 << tw_log2, TH = C16_BM >> tw_log2, K = p.K, R = K >> 1;
+  const int PW = TW + K - 1, P = (TH + K - 1) * PW, NI = (P + 15) >> 4;
+  const int n = t / sg.tpi, r_ = t - n * sg.tpi;
+  const int ty = r_ / sg.tiles_x, tx = r_ - ty * sg.tiles_x;
+  const int y0 = ty * TH, x0 = tx * TW;
+  const int swa = sg.swa, swd = sg.swd;
+  const int nslice = p.nslice;
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  f32x16 acc[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+
+  if (wv == 8) {
+    // ---- THE LOADER WAVE.  LDS-DMA requests are not ordered against ordinary loads (a counted wait that budgeted a patch's pieces beside
+    // the filter loads let MFMAs start on filters still in flight, once the filters missed L2: wrong tiles at random), and they share
+    // the one vmcnt counter of their wave: the patches are therefore requested by a wave of their own, which does nothing else — its
+    // vmcnt(0) before every barrier is exact — and the eight computing waves count filter loads only.
+    // piece k: rows 16 k + lane / 4; physical slot lane & 3 holds logical slot (lane & 3) ^ swizzle — 16-bit modes: channel group L of the
+    // 32-channel slice; pairs: plane L >> 1, channel half L & 1 of the 16-channel slice
+    unsigned poff[NPL];
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+      const int q = k * 16 + (lane >> 2);
+      const int prow = q / PW, pcol = q - prow * PW;
+      const int y = y0 - R + prow, x = x0 - R + pcol;
+      const bool ok = k < NI && q < P && y >= 0 && y < sg.H && x >= 0 && x < sg.W;
+      const int L = (lane & 3) ^ (((pcol >> swa) + prow * swd) & 3);
+      const long px = ((long)n * sg.H + y) * sg.W + x;
+      const unsigned within = MM == 3 ? (unsigned)((L >> 1) * p.Cin * 2 + (L & 1) * 16) : (unsigned)(L * 16);
+      poff[k] = ok ? (unsigned)(px * sg.ld_in * 2) + within : C16_OOB;
+    }
+    const __amdgpu_buffer_rsrc_t rs_in = c16_rsrc(sg.in, sg.in_bytes);
+    auto issue_patch = [&](int c, int stage) {
+      const unsigned ck = (unsigned)(c * (MM == 3 ? 32 : 64));
+#pragma unroll
+      for (int k = 0; k < NPL; ++k)
+        if (k < NI) {
+          const unsigned vo = poff[k] == C16_OOB ? C16_OOB : poff[k] + ck;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr)(lds + stage * CORR16_STAGE + k * 1024), 16, vo, 0, 0, 0);
+        }
+    };
+    issue_patch(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                              // patch 0 is in place
+#pragma unroll 1
+    for (int c = 0; c < nslice; ++c) {
+      if (c + 1 < nslice) issue_patch(c + 1, (c + 1) & 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                            // slice c has been read by every wave, patch c + 1 is in place
+    }
+  } else {
+  // ---- filters: the wave's taps of every slice in order; running pointer, + 8 taps per step, past the end a harmless reload
+  const int T = K * K;
+  const int ntw = (T - wv + 7) >> 3;                          // taps of this wave per slice
+  const char* wp = p.w + (long)wv * 2048;
+  int wtap = wv, wleft = nslice * ntw;
+  const unsigned bvo = lane * 16;
+  auto load_b = [&](V8 (&b)[2]) {
+    const unsigned long wa = (unsigned long)(wleft > 0 ? wp : p.w);
+    const char* ws = reinterpret_cast<const char*>((unsigned long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)wa) |
+                                                   ((unsigned long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(wa >> 32)) << 32));
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(b[0]) : "v"(bvo), "s"(ws) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(b[1]) : "v"(bvo), "s"(ws) : "memory");
+    --wleft;
+    wtap += 8;
+    if (wtap < T) wp += 8 * 2048;
+    else { wp += (long)(T - wtap + 8 + wv) * 2048; wtap = wv; }      // first tap of this wave in the next slice
+  };
+
+  // ---- fragment geometry: m-tile mt = tile pixels 32 mt + (lane & 31); patch row of tap (0, 0) = the pixel's own (row, column)
+  const int fhalf = lane >> 5;
+  int qb[4], fe[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int r = 32 * mt + (lane & 31), py = r >> tw_log2, px = r & (TW - 1);
+    qb[mt] = (py * PW + px) * 64; fe[mt] = px + py * swd;
+  }
+  const int PW64 = PW * 64;
+  auto tap_addr = [&](int ky, int kx, int stage, int (&tb)[4]) {
+    const int so = stage * CORR16_STAGE + ky * PW64 + kx * 64;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int sw = ((fe[mt] + kx) >> swa) + ky * swd;
+      tb[mt] = qb[mt] + so + (((fhalf ^ sw) & 3) << 4);
+    }
+  };
+  V8 bs[3][2];
+  V8 fa[4][2];
+  int tb[4], ntb[4];
+  load_b(bs[0]);
+  load_b(bs[1]);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  const int ky0 = wv / K, kx0 = wv - ky0 * K;                 // the wave's first tap of a slice
+  int ky = ky0, kx = kx0;
+  tap_addr(ky, kx, 0, tb);
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    fa[mt][0] = *reinterpret_cast<const V8*>(lds + tb[mt]);
+    fa[mt][1] = *reinterpret_cast<const V8*>(lds + (tb[mt] ^ 32));
+  }
+  int stage = 0, it = 0, c = 0;                               // tap index of the wave inside the slice, slice
+  // One tap.  The filter ring runs through all slices without a break (period 3: the loop below is unrolled by three steps, slice
+  // boundaries are run-time state); the filters of the wave's tap after next are requested first.  Filter loads return in order and are
+  // the only requests of this wave: vmcnt(4) — the two younger sets — proves this step's filters have arrived.
+  auto step = [&](const V8 (&bc)[2], V8 (&bfar)[2]) {
+    const bool live = c < nslice, last = it == ntw - 1;
+    load_b(bfar);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (!live) return;                                        // (padding steps after the last slice: the step count is a multiple of three)
+    int nky = ky, nkx = kx + 8;
+    while (nkx >= K) { nkx -= K; ++nky; }
+    if (last) { nky = ky0; nkx = kx0; }
+    tap_addr(nky, nkx, last ? stage ^ 1 : stage, ntb);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      if constexpr (MM == 3) {
+        acc[mt] = c16_mfma<MM>(fa[mt][0], bc[0], acc[mt]);      // hi x hi
+        acc[mt] = c16_mfma<MM>(fa[mt][0], bc[1], acc[mt]);      // hi x lo
+        acc[mt] = c16_mfma<MM>(fa[mt][1], bc[0], acc[mt]);      // lo x hi
+      } else {
+        acc[mt] = c16_mfma<MM>(fa[mt][0], bc[0], acc[mt]);      // channels 0..15 of the slice
+        acc[mt] = c16_mfma<MM>(fa[mt][1], bc[1], acc[mt]);      // channels 16..31
+      }
+      if (!last) {
+        fa[mt][0] = *reinterpret_cast<const V8*>(lds + ntb[mt]);
+        fa[mt][1] = *reinterpret_cast<const V8*>(lds + (ntb[mt] ^ 32));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    ky = nky; kx = nkx;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) tb[mt] = ntb[mt];
+    ++it;
+    if (last) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                          // every wave has read this patch; the loader has the next one in place
+      __builtin_amdgcn_sched_barrier(0);
+      stage ^= 1; it = 0; ++c;
+      if (c < nslice) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          fa[mt][0] = *reinterpret_cast<const V8*>(lds + tb[mt]);
+          fa[mt][1] = *reinterpret_cast<const V8*>(lds + (tb[mt] ^ 32));
+        }
+      }
+    }
+  };
+  const int nsteps = nslice * ntw;
+#pragma unroll 1
+  for (int s_ = 0; s_ < nsteps; s_ += 3) {
+    asm volatile("" : "+v"(fe[0]), "+v"(fe[1]), "+v"(fe[2]), "+v"(fe[3]));
+    step(bs[0], bs[2]);
+    step(bs[1], bs[0]);
+    step(bs[2], bs[1]);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- the eight partial tiles are added through LDS, four at a time: [slot][128 px][33]
+  float* red = reinterpret_cast<float*>(lds);
+  float sum[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) sum[e] = 0.f;
+#pragma unroll 1
+  for (int rd = 0; rd < 2; ++rd) {
+    if (wv < 8 && (wv >> 2) == rd) {
+      float* mine = red + (wv & 3) * (128 * 33);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mine[(32 * mt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 33 + (lane & 31)] = acc[mt][r];
+    }
+    __syncthreads();
+    if (wv < 8)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int o = tid + 512 * e, px = o >> 5, ch = o & 31;
+      sum[e] += (red[px * 33 + ch] + red[128 * 33 + px * 33 + ch]) + (red[2 * 128 * 33 + px * 33 + ch] + red[3 * 128 * 33 + px * 33 + ch]);
+    }
+    __syncthreads();
+  }
+  if (wv < 8)
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int o = tid + 512 * e, px = o >> 5, ch = o & 31;
+    const int y = y0 + (px >> tw_log2), x = x0 + (px & (TW - 1));
+    if (y < sg.H && x < sg.W) sg.out[(((long)n * sg.H + y) * sg.W + x) * sg.ld_out + ch] = sum[e] * p.acc_scale;
+  }
+}
+
 
 // Tiling of one segment for the halo-patch kernel: the tile width (32 / 16 / 8 / 4) with the least overhang; false if none fits
 // (a map lower than the tile must divide it: tiles of whole images)
@@ -966,4 +1217,56 @@ extern "C" int g6d_conv16_direct_multi(const G6dConv16Seg* segs, int nseg, int C
     hipLaunchKernelGGL((conv16r_kernel<3, NST>), dim3(blocks), dim3(256), LDSR, st, p);
   }
   return g6d_check_launch("conv16r_direct");
+}
+
+extern "C" int g6d_corr16_multi(const G6dConv16Seg* segs, int nseg, int Cin, const void* W16, float acc_scale, int Cout, int k, int math_mode,
+                                g6d_stream_t stream) {
+  if (!segs || nseg < 1 || nseg > 4 || !W16) { g6d_set_error("corr16: 1..4 segments and filters expected"); return G6D_EINVAL; }
+  if (math_mode < 1 || math_mode > 3 || Cout != 32 || (k != 15 && k != 7) || Cin % 32) {
+    g6d_set_error("corr16: math_mode 1 (bf16) / 2 (fp16) / 3 (fp16 pairs), Cout = 32, k in {7, 15}, Cin % 32 == 0 expected"); return G6D_EINVAL;
+  }
+  const int planes = math_mode == 3 ? 2 : 1;
+  Corr16Params p = {};
+  p.nseg = nseg; p.Cin = Cin; p.K = k; p.w = static_cast<const char*>(W16); p.acc_scale = acc_scale != 0.f ? acc_scale : 1.f;
+  p.nslice = Cin / (math_mode == 3 ? 16 : 32);
+  int tiles = 0;
+  for (int i = 0; i < nseg; ++i) {
+    const G6dConv16Seg& s = segs[i];
+    Corr16Seg& o = p.seg[i];
+    if (!s.in || !s.out_full || s.N < 1 || s.D != 1 || s.H < 1 || s.W < 1 || s.ld_in < planes * Cin || s.ld_full < Cout || (s.ld_in & 7) ||
+        !g6d_aligned16(s.in) || !g6d_aligned16(s.out_full)) { g6d_set_error("corr16: bad segment"); return G6D_EINVAL; }
+    // tile width with the least overhang whose halo patch fits a stage (672 rows)
+    double best = 1e30; int btw = 0;
+    for (int tw = 32; tw >= 4; tw >>= 1) {
+      const int th = C16_BM / tw;
+      if ((th + k - 1) * (tw + k - 1) > CORR16_STAGE / 64) continue;
+      const double waste = (double)((s.W + tw - 1) / tw * tw) * ((s.H + th - 1) / th * th) / ((double)s.W * s.H);
+      if (waste < best - 1e-9) { best = waste; btw = tw; }
+    }
+    if (!btw) { g6d_set_error("corr16: no tile shape fits"); return G6D_EINVAL; }
+    int l2 = 0; while ((1 << l2) < btw) ++l2;
+    const int th = C16_BM / btw;
+    o.in = static_cast<const char*>(s.in); o.out = static_cast<float*>(s.out_full);
+    o.H = s.H; o.W = s.W; o.rows = s.N * s.H; o.ld_in = s.ld_in; o.ld_out = s.ld_full;
+    o.tw_log2 = l2; o.tiles_x = (s.W + btw - 1) / btw; o.tpi = o.tiles_x * ((s.H + th - 1) / th); o.tile0 = tiles;
+    o.swa = btw == 32 ? 2 : (btw == 16 ? 1 : 0); o.swd = btw <= 8 ? 1 : 0;
+    const long ext = (long)s.N * s.H * s.W * s.ld_in * 2;
+    if (ext >= (1L << 31)) { g6d_set_error("corr16: a segment's input beyond 2 GB"); return G6D_EINVAL; }
+    o.in_bytes = (unsigned)ext;
+    tiles += s.N * o.tpi;
+  }
+  p.ptiles = tiles;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  constexpr int LDSB = 2 * CORR16_STAGE;                       // (>= the 4 x 128 x 33 floats of the final reduction)
+  if (math_mode == 1) {
+    g6d_allow_lds(reinterpret_cast<const void*>(&corr16_kernel<1>), LDSB);
+    hipLaunchKernelGGL(corr16_kernel<1>, dim3(tiles), dim3(576), LDSB, st, p);
+  } else if (math_mode == 2) {
+    g6d_allow_lds(reinterpret_cast<const void*>(&corr16_kernel<2>), LDSB);
+    hipLaunchKernelGGL(corr16_kernel<2>, dim3(tiles), dim3(576), LDSB, st, p);
+  } else {
+    g6d_allow_lds(reinterpret_cast<const void*>(&corr16_kernel<3>), LDSB);
+    hipLaunchKernelGGL(corr16_kernel<3>, dim3(tiles), dim3(576), LDSB, st, p);
+  }
+  return g6d_check_launch("corr16");
 }

@@ -793,6 +793,64 @@ def conv16_direct_multi(xs, filt, bias, relu=True, full=None, pool=None, kd=1, s
     return fulls, pools
 
 
+def corr16_pack(w_taps, mode):
+    """[32, k*k, Cin] fp32 reference-centre features (tap = ky*k + kx) -> the filters of g6d_corr16_multi for `mode` (1 bf16, 2 fp16, 3 fp16
+    hi / lo pairs): [Cin/S][k*k][2][64 lanes][8] with S = 32 and fragment f = the slice's 16-channel group (modes 1 / 2), S = 16 and f = hi / lo
+    plane (mode 3); lane l holds reference l & 31, channels S c + 16 f (modes 1 / 2) + 8 (l >> 5) + e.  Mode 3 scales by an exact power of two."""
+    co, taps, ci = w_taps.shape
+    if co != 32 or ci % 32:
+        raise ValueError("corr16_pack: 32 references and Cin % 32 == 0 expected")
+    acc_scale = 1.0
+    if mode == 3:
+        import math
+        amax = float(w_taps.abs().max())
+        S = 2.0 ** min(14, math.floor(math.log2(2048.0 / max(amax, 1e-30))))
+        w = w_taps.double() * S
+        hi = w.to(torch.float16)
+        lo = (w - hi.double()).to(torch.float16)
+        acc_scale = 1.0 / S
+        x = torch.stack([hi, lo], 0).reshape(2, 32, taps, ci // 16, 2, 8)           # plane, r, tap, slice, half, e
+        x = x.permute(3, 2, 0, 4, 1, 5).contiguous()                                 # slice, tap, plane, half, r, e
+    else:
+        x = w_taps.to(_T16[mode]).reshape(32, taps, ci // 32, 2, 2, 8)               # r, tap, slice, group, half, e
+        x = x.permute(2, 1, 3, 4, 0, 5).contiguous()                                 # slice, tap, group, half, r, e
+    k = int(round(taps ** 0.5))
+    f = Conv16Filters(x.reshape(-1), 1, mode, acc_scale, co, taps, ci)
+    f.k = k
+    return f
+
+
+def corr16_multi(xs, filt, outs):
+    """The detector's k x k correlation on 16-bit activations (g6d_corr16_multi).  xs: 1..4 dense channels-last maps [N,H,W,Cin] of the
+    mode's 16-bit type (pairs: [N,H,W,2,Cin]); outs: fp32 [N,1,H,W,32] (or [N,H,W,32]) dense; filt: corr16_pack(...)."""
+    _need_gpu(filt.data, *xs, *outs)
+    mode, Cin = filt.mode, filt.Cin
+    pair = mode == 3
+    segs = (_lib.G6dConv16Seg * len(xs))()
+    flops, sizes, nbytes = 0.0, [], 2.0 * filt.data.numel()
+    for i, (x, o) in enumerate(zip(xs, outs)):
+        if x.dtype != _T16[mode] or not x.is_contiguous() or x.dim() != (5 if pair else 4) or x.shape[-1] != Cin or not o.is_contiguous() \
+                or o.dtype != torch.float32 or o.shape[-1] != 32:
+            raise ValueError("corr16_multi: dense 16-bit channels-last inputs and dense fp32 outputs with 32 channels expected")
+        N, H, W = x.shape[0], x.shape[1], x.shape[2]
+        if o.numel() != N * H * W * 32:
+            raise ValueError("corr16_multi: output shape mismatch")
+        segs[i] = _lib.G6dConv16Seg(in_=x.data_ptr(), out_full=o.data_ptr(), out_pool=None, N=N, D=1, H=H, W=W, ld_in=(2 if pair else 1) * Cin,
+                                    ld_full=32, ld_pool=0)
+        flops += 2.0 * N * H * W * 32 * filt.taps * Cin
+        nbytes += x.numel() * 2.0 + o.numel() * 4.0
+        sizes.append(f"{N}x{H}x{W}")
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.check(_lib.load().g6d_corr16_multi(segs, len(xs), Cin, _ptr(filt.data), float(filt.acc_scale), 32, int(filt.k), int(mode), _stream()),
+               "g6d_corr16_multi")
+    if PROFILE is not None:
+        e1.record()
+        PROFILE.append((flops, e0, e1, f"{'conv16x3' if pair else 'conv16'} corr in={'+'.join(sizes)}x{Cin} out=32 k={filt.k}x{filt.k}", nbytes, flops))
+    return outs
+
+
 def l2norm_rows(x):
     """In-place F.normalize over the last axis of a channels-last tensor whose rows are dense (ld = C), or of a 2-D row-strided
     view [rows, C] (ld = x.stride(0))."""

@@ -303,6 +303,16 @@ int g6d_conv16_direct_multi(const G6dConv16Seg* segs, int nseg, int Cin, const v
                             int Cout, int kd, int relu, int full_type, int pool_type, int math_mode, double* stats, int stat_rows_per_group,
                             g6d_stream_t stream);
 
+/* The detector's K x K correlation (network/detector.py:188-197,222-224: query feature map x the 32 reference-centre features) on 16-bit
+ * activations, halo-patch kernel with the K^2 taps of a slice split over the eight waves of a block (ABI v12; csrc/conv16_direct.hip,
+ * corr16_kernel).  segs[i]: in = [N][H][W][ld_in] of the mode's 16-bit type (mode 3: [pixel][2][Cin] fp16 hi / lo pairs), out_full = fp32
+ * [N][H][W][ld_full] (ld_full >= 32), D = 1; out = acc_scale * sum_{ky,kx,c} in[y + ky - K/2][x + kx - K/2][c] * w[r][ky K + kx][c] with zero
+ * padding.  W16 (host: ops.corr16_pack): [Cin / S][K K][2][64 lanes][8 values] 16-bit — S = 32 channels per slice and fragment f = the
+ * slice's 16-channel group (modes 1 / 2), or S = 16 and f = hi / lo plane (mode 3); lane l of a fragment holds reference r = l & 31,
+ * channels S c + (16 f for modes 1 / 2) + 8 (l >> 5) + e.  Cout = 32, k in {7, 15}, Cin % 32 == 0, up to 4 map sizes per launch. */
+int g6d_corr16_multi(const G6dConv16Seg* segs, int nseg, int Cin, const void* W16, float acc_scale, int Cout, int k, int math_mode,
+                     g6d_stream_t stream);
+
 /* g6d_wino_conv3x3_multi on the Winograd F(4x4,3x3) kernel (ABI v8, fp32 on v_mfma_f32_16x16x4_f32): 36 multiplications per 16
  * outputs — 4x fewer than the direct form, 1.78x fewer than F(2x2,3x3) — with the interpolation points (0, +-3/4, +-3/2, inf), whose
  * fp32 error is ~1.3e-6 of the output range at Cin = 512 (F(2x2,3x3): 2.5e-7; the textbook points 0, +-1, +-2: 4.6e-6).  Meant for the

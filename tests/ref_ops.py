@@ -605,6 +605,24 @@ def conv16_direct_multi(xs, filt, bias, relu=True, full=None, pool=None, kd=1, s
     return fulls, pools
 
 
+def corr16_pack(w_taps, mode):
+    f = conv16_pack(w_taps, mode, 1)
+    f.k = int(round(w_taps.shape[1] ** 0.5))
+    return f
+
+
+def corr16_multi(xs, filt, outs):
+    pair = filt.mode == 3
+    dt = filt.w.dtype if filt.w.dtype in (torch.float32, torch.float64) else torch.float32
+    k = filt.k
+    for x, o in zip(xs, outs):
+        v = (x[..., 0, :].to(dt) + x[..., 1, :].to(dt)) if pair else x.to(dt)
+        w = filt.w.to(dt).reshape(filt.Cout, k, k, filt.Cin).permute(0, 3, 1, 2)
+        y = F.conv2d(v.permute(0, 3, 1, 2), w, None, padding=k // 2).permute(0, 2, 3, 1)
+        o.copy_(y.reshape(o.shape).to(o.dtype))
+    return outs
+
+
 def patch_ops(monkeypatch):
     """Route gen6d_amd.ops.* to the references above (CPU host-logic tests only)."""
     import sys

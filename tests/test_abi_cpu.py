@@ -23,7 +23,7 @@ def test_header_symbols_exported():
     assert len(names) >= 20
     for n in names:
         assert hasattr(l, n), f"{n} declared in gen6d_hip.h but not exported by libgen6d_hip.so"
-    assert l.g6d_abi_version() == 11
+    assert l.g6d_abi_version() == 12
     # every typed binding corresponds to a declared symbol and vice versa
     assert set(lib.SIGNATURES) | {"g6d_abi_version", "g6d_last_error", "g6d_sizeof_conv_desc", "g6d_set_knob", "g6d_get_knob",
                                   "g6d_reset_knobs"} == set(names)

@@ -115,6 +115,45 @@ def test_conv16_direct_multi(mode, layout, halo, case, knob):
     assert groups > 0
 
 
+CORR_CASES = [
+    dict(N=1, sizes=[(16, 16)], Cin=64, k=15),
+    dict(N=3, sizes=[(22, 30), (9, 13)], Cin=64, k=15),                                   # ragged maps, two sizes
+    dict(N=2, sizes=[(11, 15), (32, 40)], Cin=128, k=7),
+    dict(N=1, sizes=[(88, 116), (60, 80), (44, 60), (32, 40)], Cin=512, k=15),           # the headline's pyramid, one query
+]
+
+
+@pytest.mark.parametrize("mode", ["fp16", "bf16", "pairs"])
+@pytest.mark.parametrize("case", CORR_CASES, ids=lambda c: f"{c['N']}x{len(c['sizes'])}maps_{c['Cin']}_k{c['k']}")
+def test_corr16_multi(mode, case):
+    """The detector's k x k correlation on 16-bit activations against the fp64 direct correlation of the operands' own values
+    (pairs: of the fp32 operands — fp32-class results, bar 2e-6 of range)."""
+    from gen6d_amd import ops
+    c = case
+    pairs = mode == "pairs"
+    t16 = T16[mode]
+    g = torch.Generator().manual_seed(77 + c["Cin"] + c["k"])
+    T = c["k"] * c["k"]
+    w = _rand(g, 32, T, c["Cin"], scale=(3.0 / (T * c["Cin"])) ** 0.5)
+    w = w if pairs else w.to(t16).float()
+    xs = [_rand(g, c["N"], h, ww, c["Cin"]) for h, ww in c["sizes"]]
+    xs = xs if pairs else [x.to(t16).float() for x in xs]
+    filt = ops.corr16_pack(w.cuda(), MODE[mode])
+    xin = [(_split(x) if pairs else x.to(t16)).cuda() for x in xs]
+    outs = [torch.full((c["N"], 1, h, ww, 32), -5.0, device="cuda") for h, ww in c["sizes"]]
+    ops.corr16_multi(xin, filt, outs)
+    torch.cuda.synchronize()
+    base = 2e-6 if pairs else 2e-5
+    worst = 0.0
+    for x, o in zip(xs, outs):
+        w4 = w.double().reshape(32, c["k"], c["k"], c["Cin"]).permute(0, 3, 1, 2)
+        ref = F.conv2d(x.double().permute(0, 3, 1, 2), w4, None, padding=c["k"] // 2).permute(0, 2, 3, 1)
+        e = float((o[:, 0].cpu().double() - ref).abs().max()) / float(ref.abs().max())
+        worst = max(worst, e / base)
+        assert e <= base, (tuple(x.shape), e, base)
+    record("test_corr16_multi", f"{mode} {c['sizes']} x{c['Cin']} k={c['k']} (error / bar)", worst, 1.0)
+
+
 @pytest.mark.parametrize("mode", ["fp16", "bf16", "pairs"])
 def test_vgg_conv1_pool_nhwc16(mode):
     """The first trunk layer with a 16-bit result equals the fp32 kernel's result rounded once (pairs: split once)."""
