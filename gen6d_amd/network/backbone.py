@@ -250,7 +250,7 @@ def _conv16_eligible(xs, taps):
     return all(x.shape[2] % need == 0 and x.shape[3] % need == 0 for x in xs) and len(xs) <= 4
 
 
-def _vgg_taps_conv16(packed, xs, taps, norm, mode):
+def _vgg_taps_conv16(packed, xs, taps, norm, mode, taps16=()):
     """The trunk on 16-bit activations (round 6): from the first layer's epilogue on the maps are fp16 / bf16 channels-last (mode 1 / 2:
     the reduced-precision mode) or fp16 hi / lo PAIRS (mode 3: the fp32 path), the seven 3x3 layers run on the direct kernel
     (DMA-staged activation tiles, filters in registers, v_mfma_f32_32x32x16), and only the requested taps are written in fp32 for their
@@ -267,7 +267,8 @@ def _vgg_taps_conv16(packed, xs, taps, norm, mode):
     cur, _ = layer(2, cur, full=t16)
     c3, cur = layer(3, cur, full=f32 if "c3" in taps else None, pool=t16)
     cur, _ = layer(4, cur, full=t16)
-    c5, cur = layer(5, cur, full=f32 if "c5" in taps else None, pool=t16)
+    # (taps16: taps handed over in the kernel's own 16-bit / pair format — the detector's 15x15 correlation reads c5 that way)
+    c5, cur = layer(5, cur, full=(t16 if "c5" in taps16 else f32) if "c5" in taps else None, pool=t16)
     cur, _ = layer(6, cur, full=t16)
     c7, p7 = layer(7, cur, relu=False, full=f32, pool=f32 if "p7" in taps else None)
     outs = []
@@ -277,14 +278,14 @@ def _vgg_taps_conv16(packed, xs, taps, norm, mode):
     return outs
 
 
-def vgg_taps_cl_multi(packed, xs, taps, norm=None, f43=False):
+def vgg_taps_cl_multi(packed, xs, taps, norm=None, f43=False, taps16=()):
     """vgg_taps_cl for several image sizes at once (the scales of the detector's pyramid): every Winograd layer is ONE launch
     over all sizes (ops.wino_conv3x3_multi).  xs: list of [1,3,h_i,w_i] images (normalised, or in [0,1] with norm) -> list of
     tap dicts.  f43: the seven Winograd layers on the F(4x4,3x3) kernel (fp32 mode only)."""
     if ops.MATH_MODE and LOWP_TRUNK and CONV16_TRUNK and hasattr(packed[1], "w16") and _conv16_eligible(xs, taps):
-        return _vgg_taps_conv16(packed, xs, taps, norm, ops.MATH_MODE)
+        return _vgg_taps_conv16(packed, xs, taps, norm, ops.MATH_MODE, taps16)
     if (f43 or SPLIT16_ALWAYS) and not ops.MATH_MODE and SPLIT16_TRUNK and hasattr(packed[1], "w16") and _conv16_eligible(xs, taps):
-        return _vgg_taps_conv16(packed, xs, taps, norm, 3)
+        return _vgg_taps_conv16(packed, xs, taps, norm, 3, taps16)
     w0, b0 = packed[0]
     dev = xs[0].device
     cur = ops.alloc_like_segments([(x.shape[0], x.shape[2] // 2, x.shape[3] // 2, w0.shape[0]) for x in xs], dev)
@@ -304,13 +305,15 @@ def vgg_taps_cl_multi(packed, xs, taps, norm=None, f43=False):
     return outs
 
 
-def trunk_features_multi(packed, imgs_list, keys, f43=False):
+def trunk_features_multi(packed, imgs_list, keys, f43=False, taps16=()):
     """trunk_features (no L2 normalisation) for a list of [1,3,h_i,w_i] images of different sizes -> list of lists of
-    [1,1,h_l,w_l,C] maps.  One launch per layer for all sizes (up to 4 per launch)."""
+    [1,1,h_l,w_l,C] maps.  One launch per layer for all sizes (up to 4 per launch).  taps16: keys that may come back in the 16-bit
+    activation format of the direct kernel ([n,h,w,C] fp16 / bf16, or [n,h,w,2,C] fp16 pairs on the fp32 path) when the trunk runs on it —
+    the caller checks the dtype."""
     if len(imgs_list) > 4:
         return [trunk_features(packed, im, keys, False) for im in imgs_list]
-    taps = vgg_taps_cl_multi(packed, imgs_list, set(keys), norm=_IMG_NORM, f43=f43)
-    return [[t[k].unsqueeze(1) for k in keys] for t in taps]
+    taps = vgg_taps_cl_multi(packed, imgs_list, set(keys), norm=_IMG_NORM, f43=f43, taps16=taps16)
+    return [[(t[k] if t[k].dtype != torch.float32 else t[k].unsqueeze(1)) for k in keys] for t in taps]
 
 
 def trunk_features(packed, imgs, keys, l2norm, f43=False):

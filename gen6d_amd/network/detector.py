@@ -29,6 +29,9 @@ CORR_WINO = True         # the 15x15 correlation level in the Winograd domain, 5
 # multiplications than F(2x2,3x3) at ~5x its rounding error — the detector holds ~4e-6 of the score range against the 1e-4 bar
 # (tests/test_parity_timed_gpu.py).  False: the F(2x2,3x3) kernels of round 3 (tools/ A/B runs and tests flip this attribute).
 F43 = True
+CORR16 = True            # round 6: the 15x15 correlation level on the halo-patch kernel of the 16-bit matrix cores (g6d_corr16_multi) whenever the
+                         # trunk hands its input over as 16-bit activations (reduced precision) or fp16 hi / lo pairs (fp32 path: fp32-class
+                         # results); False (tools / tests): the F(4x4,3x3) / corr16_patch kernels of rounds 4-5
 CORR7_F43 = True         # the 7x7 level as 3x3 blocks of 3x3 on zero-extended 9x9 filters in the F(4x4,3x3) domain (20.25 instead of 49
                          # multiplications per output) when rfn % 32 == 0 and fp32; False: corr_patch
 MAX_BATCH = 16       # most queries that share one set of launches; _detect_impl_fp cuts the chunk further for larger images (the pyramid's
@@ -105,6 +108,7 @@ class Detector(ParamBank):
         feats = self.extract_feats(ref_imgs)                       # [rfn_local,1,k,k,512]
         self.ref_center_feats = [f.reshape(f.shape[0], f.shape[2] * f.shape[3], 512).contiguous() for f in feats]
         self.ref_ksize = [f.shape[2] for f in feats]               # 15, 7, 3
+        self._corr16 = {}                                          # (packed filters of g6d_corr16_multi, built on first use)
         self.ref_shape = [120, 120]
         # Winograd-domain filters of the 15x15 level (the reference views used as filters: transformed once per object)
         rfn = self.ref_center_feats[0].shape[0]
@@ -113,6 +117,14 @@ class Detector(ParamBank):
         self.ref_wino15_43 = winograd43_corr_filters(self.ref_center_feats[0], 15) if (ok15 and F43) else None
         ok7 = CORR_WINO and F43 and CORR7_F43 and self.ref_ksize[1] == 7 and rfn % 32 == 0
         self.ref_wino7_43 = winograd43_corr_filters_padded(self.ref_center_feats[1], 7)[0] if ok7 else None
+
+    def _corr16_filters(self, level, mode):
+        """The reference-centre features of a level packed for g6d_corr16_multi (ops.corr16_pack), built on first use per (level, mode)."""
+        cache = self.__dict__.setdefault("_corr16", {})
+        key = (level, mode, self.ref_center_feats[level].data_ptr())
+        if key not in cache:
+            cache[key] = ops.corr16_pack(self.ref_center_feats[level], mode)
+        return cache[key]
 
     # ------------------------------------------------------------------ detection
     def _scores_one_scale(self, que_img, scale_idx, stacked, hs, ws):
@@ -128,6 +140,16 @@ class Detector(ParamBank):
         maps = [[None] * 3 for _ in feats]
         for l, (wref, k) in enumerate(zip(self.ref_center_feats, self.ref_ksize)):
             xs = [f[l] for f in feats]
+            if xs[0].dtype != torch.float32:
+                # the trunk handed this level over as 16-bit activations (reduced precision) or fp16 hi / lo pairs (fp32 path): the halo-patch
+                # correlation kernel on the 16-bit matrix cores (csrc/conv16_direct.hip, corr16_kernel)
+                mode = 3 if xs[0].dim() == 5 else (1 if xs[0].dtype == torch.bfloat16 else 2)
+                filt = self._corr16_filters(l, mode)
+                outs = [torch.empty((qn, 1, x.shape[1], x.shape[2], rfn), dtype=torch.float32, device=dev) for x in xs]
+                ops.corr16_multi(xs, filt, outs)
+                for i, o in enumerate(outs):
+                    maps[i][l] = o.reshape(qn * o.shape[2] * o.shape[3], rfn)
+                continue
             # one launch over all scales addresses the maps with 32-bit offsets from a common base (offset + extent < 2^29 floats on the
             # Winograd routes): maps that do not come out of one buffer (a trunk that allocates every scale on its own) are gathered first
             lo = min(x.data_ptr() for x in xs)
@@ -159,7 +181,8 @@ class Detector(ParamBank):
             for i, o in enumerate(outs):
                 maps[i][l] = o.reshape(qn * o.shape[2] * o.shape[3], rfn)
         for f, si, m in zip(feats, scale_ids, maps):
-            ops.detector_assemble(m[0], m[1], m[2], f[0].shape[2], f[0].shape[3], self.cfg["vgg_score_stats"],
+            hc, wc = (f[0].shape[2], f[0].shape[3]) if f[0].dtype == torch.float32 else (f[0].shape[1], f[0].shape[2])
+            ops.detector_assemble(m[0], m[1], m[2], hc, wc, self.cfg["vgg_score_stats"],
                                   float(self.cfg["vgg_score_max"]), hs, ws, si, stacked, batch=qn)
 
     def _scores_from_feats(self, feats, scale_idx, stacked, hs, ws):
@@ -207,7 +230,9 @@ class Detector(ParamBank):
             # over); the correlations of the scales then run side by side
             # the image pyramid in ONE launch (g6d_resize_bilinear_pyramid; the scale of the query's own size is the query itself)
             pyr = ops.resize_bilinear_pyramid(que_imgs, [self._scale_size(hq, wq, sc) for _, sc in order])
-            feats = trunk_features_multi(pk["vgg"], pyr, ("c5", "c7_pre", "p7"), f43=F43)
+            # (CORR16: the 15x15 level's input in the trunk kernel's 16-bit / pair format -> g6d_corr16_multi)
+            t16 = ("c5",) if (CORR16 and self.ref_ksize[0] == 15 and self.ref_center_feats[0].shape[0] == 32) else ()
+            feats = trunk_features_multi(pk["vgg"], pyr, ("c5", "c7_pre", "p7"), f43=F43, taps16=t16)
             self._scores_from_pyramid(feats, [si for si, _ in order], stacked, hs, ws)
         else:
             ops.fork_join([(lambda si=si, sc=sc: self._scores_one_scale(resized(sc), si, stacked, hs, ws)) for si, sc in order], dev)
