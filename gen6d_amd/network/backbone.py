@@ -270,7 +270,7 @@ def _vgg_taps_conv16(packed, xs, taps, norm, mode, taps16=()):
     # (taps16: taps handed over in the kernel's own 16-bit / pair format — the detector's 15x15 correlation reads c5 that way)
     c5, cur = layer(5, cur, full=(t16 if "c5" in taps16 else f32) if "c5" in taps else None, pool=t16)
     cur, _ = layer(6, cur, full=t16)
-    c7, p7 = layer(7, cur, relu=False, full=f32, pool=f32 if "p7" in taps else None)
+    c7, p7 = layer(7, cur, relu=False, full=t16 if "c7_pre" in taps16 else f32, pool=f32 if "p7" in taps else None)
     outs = []
     for i in range(len(xs)):
         d = {"c3": c3[i], "c5": c5[i], "c7_pre": c7[i], "p7": p7[i]}

@@ -32,6 +32,7 @@ F43 = True
 CORR16 = True            # round 6: the 15x15 correlation level on the halo-patch kernel of the 16-bit matrix cores (g6d_corr16_multi) whenever the
                          # trunk hands its input over as 16-bit activations (reduced precision) or fp16 hi / lo pairs (fp32 path: fp32-class
                          # results); False (tools / tests): the F(4x4,3x3) / corr16_patch kernels of rounds 4-5
+CORR16_7 = True          # ... and the 7x7 level (its input c7_pre in the same format)
 CORR7_F43 = True         # the 7x7 level as 3x3 blocks of 3x3 on zero-extended 9x9 filters in the F(4x4,3x3) domain (20.25 instead of 49
                          # multiplications per output) when rfn % 32 == 0 and fp32; False: corr_patch
 MAX_BATCH = 16       # most queries that share one set of launches; _detect_impl_fp cuts the chunk further for larger images (the pyramid's
@@ -231,7 +232,9 @@ class Detector(ParamBank):
             # the image pyramid in ONE launch (g6d_resize_bilinear_pyramid; the scale of the query's own size is the query itself)
             pyr = ops.resize_bilinear_pyramid(que_imgs, [self._scale_size(hq, wq, sc) for _, sc in order])
             # (CORR16: the 15x15 level's input in the trunk kernel's 16-bit / pair format -> g6d_corr16_multi)
-            t16 = ("c5",) if (CORR16 and self.ref_ksize[0] == 15 and self.ref_center_feats[0].shape[0] == 32) else ()
+            t16 = ()
+            if CORR16 and self.ref_center_feats[0].shape[0] == 32:
+                t16 = (("c5",) if self.ref_ksize[0] == 15 else ()) + (("c7_pre",) if (CORR16_7 and self.ref_ksize[1] == 7) else ())
             feats = trunk_features_multi(pk["vgg"], pyr, ("c5", "c7_pre", "p7"), f43=F43, taps16=t16)
             self._scores_from_pyramid(feats, [si for si, _ in order], stacked, hs, ws)
         else:
