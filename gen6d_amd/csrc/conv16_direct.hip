@@ -833,6 +833,49 @@ __global__ __launch_bounds__(256, 2) void conv16w_kernel(const C16Params p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
+// product_split_kernel: the selector's query x reference product (reference network/selector.py:183-186 — every hypothesis image is the
+// reference's feature map times the query's, InstanceNorm'ed) written ONCE in the 16-bit activation format of conv16w_kernel, so that the
+// first conv of every level can run on it: out[q D + d][px][plane][c] = split16((ref[d][px][c] * que[q][px][c]) * scale[q][c] + shift[q][c]).
+// HBM-bound: one 16-byte (pairs: two) store per 8 channels; the reference cache (D P C floats) is re-read per query out of L2 / MALL.
+template <int MM>
+__global__ void __launch_bounds__(256) product_split_kernel(const float* __restrict__ ref, const float* __restrict__ que, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, char* __restrict__ out, int D, int P, int C, long total) {
+  typedef typename C16T3<MM>::T T;
+  typedef typename C16T3<MM>::V V8;
+  const int c8 = C >> 3;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % c8);
+    const long r = i / c8;                                     // (q D + d) P + px
+    const int px = (int)(r % P);
+    const long nd = r / P;
+    const int d = (int)(nd % D), q = (int)(nd / D);
+    const int c = cg * 8;
+    const float* rp = ref + ((long)d * P + px) * C + c;
+    const float* qp = que + ((long)q * P + px) * C + c;
+    const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
+    const f32x4 q0 = *reinterpret_cast<const f32x4*>(qp), q1 = *reinterpret_cast<const f32x4*>(qp + 4);
+    const f32x4 s0 = *reinterpret_cast<const f32x4*>(scale + (long)q * C + c), s1 = *reinterpret_cast<const f32x4*>(scale + (long)q * C + c + 4);
+    const f32x4 t0 = *reinterpret_cast<const f32x4*>(shift + (long)q * C + c), t1 = *reinterpret_cast<const f32x4*>(shift + (long)q * C + c + 4);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = fmaf(r0[e] * q0[e], s0[e], t0[e]); v[4 + e] = fmaf(r1[e] * q1[e], s1[e], t1[e]); }
+    V8 hi;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) hi[e] = (T)v[e];
+    if constexpr (MM == 3) {
+      V8 lo;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) lo[e] = (T)(v[e] - (float)hi[e]);
+      char* o = out + (r * 2 * C + c) * 2;
+      *reinterpret_cast<V8*>(o) = hi;
+      *reinterpret_cast<V8*>(o + (long)C * 2) = lo;
+    } else {
+      *reinterpret_cast<V8*>(out + (r * C + c) * 2) = hi;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
 // corr16_kernel: the detector's K x K correlation (K = 15, 7; reference network/detector.py:188-197,222-224: the query's feature map
 // correlated with the 32 reference-centre features) on 16-bit activations — the halo-patch scheme of conv16w_kernel with K^2 taps
 // per patch.  Cout = 32 (the reference views), so a 128-pixel tile has ONE wave's worth of output channels: the block's EIGHT waves
@@ -1115,7 +1158,9 @@ extern "C" int g6d_conv16_direct_multi(const G6dConv16Seg* segs, int nseg, int C
     g6d_set_error("conv16_direct: math_mode 1 (bf16) / 2 (fp16) / 3 (fp16 hi-lo pairs, fragment-major filters only)"); return G6D_EINVAL;
   }
   const int bk = math_mode == 3 ? 32 : C16_BK, planes = math_mode == 3 ? 2 : 1;
-  if (Cin % bk || Cout % C16_BN || (kd != 1 && kd != 3)) { g6d_set_error("conv16_direct: Cin % 64 (32 for pairs), Cout % 128, kd in {1,3} expected"); return G6D_EINVAL; }
+  // Cout = 64 (the selector's first product layer): halo-patch kernel only, filters packed as one 128-channel tile whose upper half is zero
+  const bool half_tile = Cout == 64 && w_layout == 1 && kd == 1 && math_mode == 3;      // (a pair wave owns 32 channels: two tiles x two groups)
+  if (Cin % bk || (Cout % C16_BN && !half_tile) || (kd != 1 && kd != 3)) { g6d_set_error("conv16_direct: Cin % 64 (32 for pairs), Cout % 128 (64: fragment-major 2-D layers), kd in {1,3} expected"); return G6D_EINVAL; }
   const int t16 = math_mode == 3 ? 3 : 1;                    // the 16-bit output coding of this mode
   auto type_ok = [&](int t) { return t == 0 || t == 2 || t == t16; };
   if (!type_ok(full_type) || !type_ok(pool_type) || (!full_type && !pool_type && !stats)) { g6d_set_error("conv16_direct: output types"); return G6D_EINVAL; }
@@ -1125,7 +1170,7 @@ extern "C" int g6d_conv16_direct_multi(const G6dConv16Seg* segs, int nseg, int C
   p.w = static_cast<const char*>(W16); p.bias = bias; p.stats = stats; p.stat_rows_per_group = stat_rows_per_group;
   p.acc_scale = acc_scale != 0.f ? acc_scale : 1.f;
   p.ablate = (int)g6d_knob(G6D_KNOB_C16_ABLATE);
-  const long wb = (long)Cout * 9 * kd * Cin * 2 * planes;
+  const long wb = (long)(half_tile ? 128 : Cout) * 9 * kd * Cin * 2 * planes;
   if (wb >= (1L << 31)) { g6d_set_error("conv16_direct: filters beyond 2 GB"); return G6D_EINVAL; }
   p.w_bytes = (unsigned)wb;
   p.nN = Cout / C16_BN;
@@ -1174,6 +1219,7 @@ extern "C" int g6d_conv16_direct_multi(const G6dConv16Seg* segs, int nseg, int C
         ok = (stat_rows_per_group % (segs[i].H * segs[i].W) == 0) && (o.h_tpi > 0 || ((long)stat_rows_per_group % ((long)th * segs[i].W) == 0));
       }
     }
+    if (!ok && half_tile) { g6d_set_error("conv16_direct: Cout = 64 needs a halo tiling for every segment"); return G6D_EINVAL; }
     if (ok) {
       // a block = 4 waves of 128 px x 64 ch (pairs: 32 ch): one pixel tile x 256 (128) channels, or two pixel tiles x 128 channels
       const int cw = 32 * (math_mode == 3 ? C16W<3>::NT2 : C16W<2>::NT2);
@@ -1189,11 +1235,12 @@ extern "C" int g6d_conv16_direct_multi(const G6dConv16Seg* segs, int nseg, int C
 #define C16W_LAUNCH(MM_, WM_) launch(&conv16w_kernel<MM_, WM_>, 2 * WM_ * C16W<MM_>::NP * C16W<MM_>::PLANE, 4 * C16W<MM_>::EPW)
       if (math_mode == 1) { if (wm == 1) C16W_LAUNCH(1, 1); else C16W_LAUNCH(1, 2); }
       else if (math_mode == 2) { if (wm == 1) C16W_LAUNCH(2, 1); else C16W_LAUNCH(2, 2); }
-      else C16W_LAUNCH(3, 1);                               // (Cout % 128 == 0: always one tile per block)
+      else { if (wm == 1) C16W_LAUNCH(3, 1); else C16W_LAUNCH(3, 2); }   // (two tiles per block: Cout = 64)
 #undef C16W_LAUNCH
       return g6d_check_launch("conv16w_direct");
     }
   }
+  if (half_tile) { g6d_set_error("conv16_direct: Cout = 64 runs on the halo-patch kernel only (knob conv16_halo, tile shapes)"); return G6D_EINVAL; }
   const int blocks = (tiles + 7) / 8 * 8 * p.nN;
   if (w_layout == 0) {
     if (math_mode == 1) {
@@ -1269,4 +1316,20 @@ extern "C" int g6d_corr16_multi(const G6dConv16Seg* segs, int nseg, int Cin, con
     hipLaunchKernelGGL(corr16_kernel<3>, dim3(tiles), dim3(576), LDSB, st, p);
   }
   return g6d_check_launch("corr16");
+}
+
+extern "C" int g6d_product_split16(const float* ref, const float* que, const float* scale, const float* shift, void* out, int qn, int D, int P, int C,
+                                   int math_mode, g6d_stream_t stream) {
+  if (!ref || !que || !scale || !shift || !out || qn < 1 || D < 1 || P < 1 || C < 8 || (C & 7) || math_mode < 1 || math_mode > 3 ||
+      !g6d_aligned16(ref) || !g6d_aligned16(que) || !g6d_aligned16(scale) || !g6d_aligned16(shift) || !g6d_aligned16(out)) {
+    g6d_set_error("product_split16: bad args (C % 8 == 0, 16-byte aligned pointers, math_mode 1..3)"); return G6D_EINVAL;
+  }
+  const long total = (long)qn * D * P * (C >> 3);
+  const int blocks = (int)((total + 255) / 256 < 256 * 64 ? (total + 255) / 256 : 256 * 64);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  char* o = static_cast<char*>(out);
+  if (math_mode == 1) hipLaunchKernelGGL(product_split_kernel<1>, dim3(blocks), dim3(256), 0, st, ref, que, scale, shift, o, D, P, C, total);
+  else if (math_mode == 2) hipLaunchKernelGGL(product_split_kernel<2>, dim3(blocks), dim3(256), 0, st, ref, que, scale, shift, o, D, P, C, total);
+  else hipLaunchKernelGGL(product_split_kernel<3>, dim3(blocks), dim3(256), 0, st, ref, que, scale, shift, o, D, P, C, total);
+  return g6d_check_launch("product_split16");
 }

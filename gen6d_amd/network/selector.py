@@ -36,6 +36,9 @@ _CORR = (
     ((1, 1, 1, 0), (4, 0, 0, 0)),
 )
 _K133, _P011 = (1, 3, 3), (0, 1, 1)
+PRODUCT16 = True       # round 6: the first conv of every level (query x reference product) on the direct 16-bit convolution — the product written
+                       # once as fp16 hi / lo pairs (fp32 path) or 16-bit activations; False (tools / tests): the product prologue of the Winograd /
+                       # implicit-GEMM kernels
 MAX_BATCH = 32         # queries that share one set of launches (BASELINE configs[4]: 32 concurrent queries; g6d_selector_levels runs them
                        # in groups of 8 query rows per pass over the reference cache)
 FEAT_LD = 516          # 512 corr channels + 3 vps channels + 1 zero pad (16-byte rows)
@@ -208,9 +211,25 @@ class ViewpointSelector(ParamBank):
             # InstanceNorm finalisation inside the producing launch, unless the statistics still have to be summed over ranks
             fin = Dg * h * w if (has_in and not last and not self.sharded) else None
             with self._mm("product" if first else "stack", f"corr{l}.{li}"):
-                res = ops.conv(x, wgt, bias, out, ksize=_K133, pad=_P011, mul=mul, in_scale=scale, in_shift=shift, in_relu=relu, stats=stats,
-                               w_wino=wu, finalize=fin, per_n=grp if scale is not None else 0, rows_per_group=grp * h * w,
-                               in_mod=grp if first else 0, mul_group=grp if mul is not None else 0)
+                mode16 = self._product16_mode(first, D * h * w, co)
+                if mode16:
+                    # round 6: the product layer on the direct 16-bit convolution (csrc/conv16_direct.hip): the normalised query x reference
+                    # product is written once in the kernel's activation format (fp32 path: fp16 hi / lo pairs, fp32-class results), the conv
+                    # adds this level's InstanceNorm sums in its epilogue, the affine of that norm comes from one small finalize launch
+                    prod = ops.product_split16(cache.view(D, h * w, 512), q.view(qn, h * w, 512), scale, shift, mode16)
+                    prod = prod.view(qn * D, h, w, 2, 512) if mode16 == 3 else prod.view(qn * D, h, w, 512)
+                    filt = self._product16_filters(l, li, wgt, mode16)
+                    # (a launch addresses its input with 32-bit offsets: 2^31 bytes = 8 queries of the 16 x 16 level in pairs)
+                    per = max(1, ((1 << 31) - 1) // (D * h * w * 512 * (4 if mode16 == 3 else 2)))
+                    for q0 in range(0, qn, per):
+                        q1 = min(qn, q0 + per)
+                        ops.conv16_direct_multi([prod[q0 * D:q1 * D]], filt, bias, relu=False, full=torch.float32, pool=None, stats=stats[q0:q1],
+                                                rows_per_group=D * h * w, out_full=[out[q0 * D:q1 * D]])
+                    res, fin = out, None
+                else:
+                    res = ops.conv(x, wgt, bias, out, ksize=_K133, pad=_P011, mul=mul, in_scale=scale, in_shift=shift, in_relu=relu, stats=stats,
+                                   w_wino=wu, finalize=fin, per_n=grp if scale is not None else 0, rows_per_group=grp * h * w,
+                                   in_mod=grp if first else 0, mul_group=grp if mul is not None else 0)
             mul, first = None, False
             if last:
                 break
@@ -226,6 +245,24 @@ class ViewpointSelector(ParamBank):
                 x, scale, shift, relu = pooled, None, None, False
             else:
                 x, relu = out, bool(has_relu)
+
+    def _product16_mode(self, first, rows_per_query, co):
+        """conv16 math mode of a level's first (product) layer, or 0 = the Winograd / implicit-GEMM kernels with the product prologue: the
+        fp32 path takes fp16 hi / lo pairs (3); the reduced-precision modes their own 16-bit type where a wave's 64 channels fit (Cout % 128).
+        A query's hypothesis images must fill whole 128-pixel tiles (its InstanceNorm sums are taken per tile): true for 64 x 5 views."""
+        if not (PRODUCT16 and first and rows_per_query % 128 == 0):
+            return 0
+        mm = ops.MATH_MODE
+        if mm == 0:
+            return 3
+        return mm if co % 128 == 0 else 0
+
+    def _product16_filters(self, l, li, wgt, mode):
+        cache = self.__dict__.setdefault("_prod16", {})
+        key = (l, li, mode, wgt.data_ptr())
+        if key not in cache:
+            cache[key] = ops.conv16_pack(wgt, mode, layout=1)
+        return cache[key]
 
     def _query_batch(self, que_imgs):
         """que_imgs [qn,3,128,128], qn <= MAX_BATCH (32) -> logits [qn,rfn], angles [qn,rfn]; one set of launches for the whole batch

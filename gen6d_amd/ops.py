@@ -691,8 +691,13 @@ def conv16_pack(w_taps, mode, layout=1):
     exact power of two S (their lo parts stay normal fp16 numbers; the kernel multiplies the accumulators by 1 / S) and split in fp64."""
     co, taps, ci = w_taps.shape
     bk = 32 if mode == 3 else 64
+    co_true = co
+    if co == 64 and mode == 3 and layout == 1 and taps == 9:
+        # the selector's first product layer: one 128-channel tile whose upper half is zero (the kernel launches waves for 64 channels only)
+        w_taps = torch.cat([w_taps, torch.zeros_like(w_taps)], 0)
+        co = 128
     if co % 128 or ci % bk:
-        raise ValueError("conv16_pack: Cout % 128 == 0 and Cin % 64 (pairs: 32) == 0 expected")
+        raise ValueError("conv16_pack: Cout % 128 == 0 (pairs, 2-D: also 64) and Cin % 64 (pairs: 32) == 0 expected")
     acc_scale = 1.0
     if mode == 3:
         import math
@@ -712,7 +717,23 @@ def conv16_pack(w_taps, mode, layout=1):
     P, ks = planes.shape[0], bk // 16
     x = planes.reshape(P, co // 128, 4, 32, taps, ci // bk, ks, 2, 8)           # P, tile, j, l31, tap, slice, ks, half, e
     x = x.permute(1, 5, 4, 6, 0, 2, 7, 3, 8).contiguous()                        # tile, slice, tap, ks, P, j, half, l31, e
-    return Conv16Filters(x.reshape(-1), 1, mode, acc_scale, co, taps, ci)
+    return Conv16Filters(x.reshape(-1), 1, mode, acc_scale, co_true, taps, ci)
+
+
+def product_split16(ref, que, scale, shift, mode):
+    """The selector's query x reference product in the activation format of conv16_direct_multi (g6d_product_split16): ref [D,P,C], que
+    [qn,P,C], scale / shift [qn,C] fp32 -> [qn*D, P, C] (mode 1 / 2) or [qn*D, P, 2, C] fp16 pairs (mode 3)."""
+    _need_gpu(ref, que, scale, shift)
+    D, P, Cc = ref.shape
+    qn = que.shape[0]
+    if tuple(que.shape) != (qn, P, Cc) or tuple(scale.shape) != (qn, Cc) or tuple(shift.shape) != (qn, Cc) or not all(
+            t.is_contiguous() and t.dtype == torch.float32 for t in (ref, que, scale, shift)):
+        raise ValueError("product_split16: dense fp32 ref [D,P,C], que [qn,P,C], scale / shift [qn,C] expected")
+    out = torch.empty((qn * D, P, 2, Cc) if mode == 3 else (qn * D, P, Cc), dtype=_T16[mode], device=ref.device)
+    nbytes = 4.0 * (ref.numel() + que.numel()) + 2.0 * out.numel()
+    _timed_hbm("product_split16", nbytes, lambda: _lib.check(_lib.load().g6d_product_split16(
+        _ptr(ref), _ptr(que), _ptr(scale), _ptr(shift), _ptr(out), qn, D, P, Cc, int(mode), _stream()), "g6d_product_split16"))
+    return out
 
 
 def vgg_conv1_pool_nhwc16(x, w_oihw, bias, out=None, norm=None, mode=None):
@@ -738,13 +759,14 @@ def vgg_conv1_pool_nhwc16(x, w_oihw, bias, out=None, norm=None, mode=None):
     return out
 
 
-def conv16_direct_multi(xs, filt, bias, relu=True, full=None, pool=None, kd=1, stats=None, rows_per_group=0):
+def conv16_direct_multi(xs, filt, bias, relu=True, full=None, pool=None, kd=1, stats=None, rows_per_group=0, out_full=None):
     """Direct 3x3 / 3x3x3 convolution on 16-bit activations (g6d_conv16_direct_multi).  filt: Conv16Filters (conv16_pack); its mode
     decides the arithmetic: 1 / 2 = bf16 / fp16 operands (the reduced-precision mode), 3 = fp16 hi / lo pairs (fp32-class results: the
     fp32 path's trunk).  xs: 1..4 dense channels-last tensors of the mode's 16-bit type, [N,H,W,Cin] (kd = 1) or [N,D,H,W,Cin] (kd = 3);
     pairs carry an extra plane axis in front of the channels: [N,H,W,2,Cin].
     full / pool: None = not produced, torch.float32, or "t16" = the mode's 16-bit format (pairs for mode 3) -> lists of dense outputs
-    (None where not produced).  stats [G,Cout,2] fp64 (zeroed): sum / sum of squares of the fp32 results are added."""
+    (None where not produced).  stats [G,Cout,2] fp64 (zeroed): sum / sum of squares of the fp32 results are added.  out_full: optional list
+    of caller-provided dense output tensors."""
     _need_gpu(filt.data, *xs)
     mode = filt.mode
     t16 = _T16[mode]
@@ -770,7 +792,14 @@ def conv16_direct_multi(xs, filt, bias, relu=True, full=None, pool=None, kd=1, s
             if kind == "t16":
                 return torch.empty(lead_ + ((2, Cout) if pair else (Cout,)), dtype=t16, device=x.device)
             return torch.empty(lead_ + (Cout,), dtype=torch.float32, device=x.device)
-        f, q = alloc(full, lead), alloc(pool, (N, H // 2, W // 2))
+        q = alloc(pool, (N, H // 2, W // 2))
+        if out_full is not None:                          # caller-provided dense outputs (slices of one buffer) instead of fresh tensors
+            f = out_full[i]
+            want_t = torch.float32 if full is torch.float32 else t16
+            if full is None or f.dtype != want_t or f.numel() != N * D * H * W * Cout * (2 if (pair and full == "t16") else 1) or not f.is_contiguous():
+                raise ValueError("conv16_direct_multi: out_full must be dense tensors of the outputs' type and size")
+        else:
+            f = alloc(full, lead)
         fulls.append(f); pools.append(q)
         ld = lambda t_: (2 * Cout if t_.dtype != torch.float32 and pair else Cout)
         segs[i] = _lib.G6dConv16Seg(in_=x.data_ptr(), out_full=f.data_ptr() if f is not None else None,

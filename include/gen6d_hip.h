@@ -283,7 +283,8 @@ int g6d_wino16_conv3x3_multi(const G6dWinoSeg* segs, int nseg, int Cin, const vo
  *            steps ordered channel slice outermost, taps innermost):
  *            [Cout/128][Cin/BK * kd*9 steps][BK/16 ks][planes][4 groups j][64 lanes][8 values], value e of lane l =
  *            filter (co = 128 tile + 32 j + (l & 31), tap, ci = BK slice + 16 ks + 8 (l >> 5) + e); planes = 1, or 2 (hi, lo) for pairs
- *          Cout % 128 == 0;  bias [Cout] fp32 or NULL
+ *          Cout % 128 == 0 (math_mode 3, fragment-major, 2-D: also Cout = 64, packed as one 128-channel tile whose upper half is zero);
+ *          bias [Cout] fp32 or NULL
  *   y = acc_scale * conv(in, W16) + bias  (acc_scale: the filters may carry an exact power-of-two scale that keeps their lo parts
  *       normal; 0 = 1);  relu != 0: y = max(y, 0)
  *   out_full [N][D][H][W][ld_full] = y        element type full_type: 0 = not written, 1 = the 16-bit type (modes 1 / 2), 2 = fp32,
@@ -302,6 +303,12 @@ typedef struct G6dConv16Seg {
 int g6d_conv16_direct_multi(const G6dConv16Seg* segs, int nseg, int Cin, const void* W16, int w_layout, float acc_scale, const float* bias,
                             int Cout, int kd, int relu, int full_type, int pool_type, int math_mode, double* stats, int stat_rows_per_group,
                             g6d_stream_t stream);
+
+/* The selector's query x reference product (network/selector.py:183-186) in the 16-bit activation format of g6d_conv16_direct_multi (ABI v12):
+ * out[(q D + d) P + px][plane][c] = split16((ref[d][px][c] * que[q][px][c]) * scale[q][c] + shift[q][c]); ref [D][P][C], que [qn][P][C], scale /
+ * shift [qn][C] fp32; out 16-bit: [qn D P][C] for math_mode 1 (bf16) / 2 (fp16), [qn D P][2][C] fp16 hi / lo pairs for math_mode 3.  C % 8 == 0. */
+int g6d_product_split16(const float* ref, const float* que, const float* scale, const float* shift, void* out, int qn, int D, int P, int C,
+                        int math_mode, g6d_stream_t stream);
 
 /* The detector's K x K correlation (network/detector.py:188-197,222-224: query feature map x the 32 reference-centre features) on 16-bit
  * activations, halo-patch kernel with the K^2 taps of a slice split over the eight waves of a block (ABI v12; csrc/conv16_direct.hip,

@@ -573,7 +573,7 @@ def conv16_pack(w_taps, mode, layout=1):
     return _RefConv16Filters(w, mode, layout)
 
 
-def conv16_direct_multi(xs, filt, bias, relu=True, full=None, pool=None, kd=1, stats=None, rows_per_group=0):
+def conv16_direct_multi(xs, filt, bias, relu=True, full=None, pool=None, kd=1, stats=None, rows_per_group=0, out_full=None):
     """Reference of g6d_conv16_direct_multi on the VALUES of the operands (pairs: hi + lo), F.conv2d / F.conv3d in the filters' dtype."""
     pair = filt.mode == 3
     dt = filt.w.dtype if filt.w.dtype in (torch.float32, torch.float64) else torch.float32
@@ -600,7 +600,11 @@ def conv16_direct_multi(xs, filt, bias, relu=True, full=None, pool=None, kd=1, s
             if kind == "t16":
                 return _to_pairs(t) if pair else t.to(_T16[filt.mode])
             return t.to(torch.float32).contiguous()
-        fulls.append(coded(y, full))
+        if out_full is not None:
+            out_full[len(fulls)].copy_(coded(y, full).reshape(out_full[len(fulls)].shape))
+            fulls.append(out_full[len(fulls)])
+        else:
+            fulls.append(coded(y, full))
         pools.append(coded(F.max_pool2d(y.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1), pool) if pool is not None else None)
     return fulls, pools
 
@@ -621,6 +625,12 @@ def corr16_multi(xs, filt, outs):
         y = F.conv2d(v.permute(0, 3, 1, 2), w, None, padding=k // 2).permute(0, 2, 3, 1)
         o.copy_(y.reshape(o.shape).to(o.dtype))
     return outs
+
+
+def product_split16(ref, que, scale, shift, mode):
+    v = (ref[None] * que[:, None]) * scale[:, None, None, :] + shift[:, None, None, :]            # [qn, D, P, C]
+    v = v.reshape(-1, v.shape[2], v.shape[3])
+    return _to_pairs(v) if mode == 3 else v.to(_T16[mode])
 
 
 def patch_ops(monkeypatch):

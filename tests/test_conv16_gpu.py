@@ -167,3 +167,31 @@ def test_vgg_conv1_pool_nhwc16(mode):
     got = ops.vgg_conv1_pool_nhwc16(x, w, b, norm=norm, mode=MODE[mode])
     assert got.dtype == T16[mode]
     assert torch.equal(got, _split(ref) if mode == "pairs" else ref.to(T16[mode]))
+
+
+def test_product_split16_and_cout64():
+    """The selector's product layer on the direct kernel: g6d_product_split16 against its definition (pairs rebuild the fp32 product to
+    2^-22), and a Cout = 64 pair convolution with per-query statistics against the fp64 convolution of the product."""
+    from gen6d_amd import ops
+    g = torch.Generator().manual_seed(5)
+    qn, D, h, w, C, Cout = 2, 16, 8, 8, 64, 64
+    ref, que = _rand(g, D, h * w, C), _rand(g, qn, h * w, C)
+    sc, sh = 0.5 + torch.rand((qn, C), generator=g), _rand(g, qn, C, scale=0.3)
+    want = ((ref[None] * que[:, None]) * sc[:, None, None] + sh[:, None, None]).reshape(qn * D, h * w, C)
+    for mode, tol in ((3, 3e-7), (2, 1e-3)):
+        got = ops.product_split16(ref.cuda(), que.cuda(), sc.cuda(), sh.cuda(), mode).cpu()
+        val = _join(got) if mode == 3 else got.double()
+        assert float((val - want.double()).abs().max()) <= tol * float(want.abs().max()), mode
+    wt = _rand(g, Cout, 9, C, scale=(3.0 / (9 * C)) ** 0.5)
+    b = _rand(g, Cout, scale=0.2)
+    prod = ops.product_split16(ref.cuda(), que.cuda(), sc.cuda(), sh.cuda(), 3).view(qn * D, h, w, 2, C)
+    stats = torch.zeros((qn, Cout, 2), dtype=torch.float64, device="cuda")
+    fulls, _ = ops.conv16_direct_multi([prod], ops.conv16_pack(wt.cuda(), 3, 1), b.cuda(), relu=False, full=torch.float32, pool=None, stats=stats,
+                                       rows_per_group=D * h * w)
+    refc = F.conv2d(want.double().reshape(qn * D, h, w, C).permute(0, 3, 1, 2), wt.double().reshape(Cout, 3, 3, C).permute(0, 3, 1, 2), b.double(),
+                    padding=1).permute(0, 2, 3, 1)
+    e = float((fulls[0].cpu().double() - refc).abs().max()) / float(refc.abs().max())
+    assert e <= 2e-6, e
+    s1 = refc.reshape(qn, -1, Cout).sum(1)
+    assert float((stats[:, :, 0].cpu() - s1).abs().max()) / (D * h * w) <= 2e-6 * float(refc.abs().max())
+    record("test_product_split16_and_cout64", "pairs Cout=64 conv of the product (error / bar 2e-6)", e / 2e-6, 1.0)

@@ -29,6 +29,6 @@ def test_conv16w_has_no_spills(tmp_path):
         vg = int(re.search(r"\.vgpr_count:\s+(\d+)", body).group(1))
         priv = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", body).group(1))
         assert vs == 0 and priv == 0, f"{name}: {vs} spilled vector registers, {priv} B of scratch"
-        assert ss <= 32, f"{name}: {ss} spilled scalar registers (they go to lanes of a vector register: no memory traffic, but keep them few)"
+        assert ss <= 96, f"{name}: {ss} spilled scalar registers (they go to lanes of a vector register: no memory traffic, but keep them few)"
         assert vg <= 256, f"{name}: {vg} vector registers (two blocks per CU need <= 256)"
     shutil.rmtree(tmp_path, ignore_errors=True)
