@@ -875,6 +875,61 @@ __global__ void __launch_bounds__(256) product_split_kernel(const float* __restr
   }
 }
 
+// affine_split16_kernel: y = pool2x2?(relu?(x * scale[g][c] + shift[g][c])) of an fp32 channels-last map written in the 16-bit activation
+// format of conv16w_kernel (pairs on the fp32 path) — the InstanceNorm affine + ReLU (+ MaxPool) between two convs of the selector's stacks
+// (reference network/selector.py:27-77), which the Winograd / implicit-GEMM kernels apply in their operand prologue and a DMA-staged
+// kernel cannot.  HBM-bound elementwise pass; image n uses table n / per_n (0: one table).
+template <int MM>
+__global__ void __launch_bounds__(256) affine_split16_kernel(const float* __restrict__ in, int ld_in, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            int per_n, int relu, int pool, int H, int W, int C, char* __restrict__ out, long total) {
+  typedef typename C16T3<MM>::T T;
+  typedef typename C16T3<MM>::V V8;
+  const int c8 = C >> 3, Ho = pool ? H >> 1 : H, Wo = pool ? W >> 1 : W;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % c8);
+    const long r = i / c8;                                     // output pixel (n Ho + y) Wo + x
+    const int x = (int)(r % Wo);
+    const long ny = r / Wo;
+    const int y = (int)(ny % Ho);
+    const long n = ny / Ho;
+    const int c = cg * 8;
+    const long tb = (per_n > 0 ? n / per_n : 0) * C + c;
+    f32x4 s0 = {1.f, 1.f, 1.f, 1.f}, s1 = s0, t0 = {0.f, 0.f, 0.f, 0.f}, t1 = t0;
+    if (scale) {
+      s0 = *reinterpret_cast<const f32x4*>(scale + tb); s1 = *reinterpret_cast<const f32x4*>(scale + tb + 4);
+      t0 = *reinterpret_cast<const f32x4*>(shift + tb); t1 = *reinterpret_cast<const f32x4*>(shift + tb + 4);
+    }
+    float v[8];
+    const int np = pool ? 2 : 1;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = -3.0e38f;
+    for (int dy = 0; dy < np; ++dy)
+      for (int dx = 0; dx < np; ++dx) {
+        const float* p_ = in + (((long)n * H + (pool ? 2 * y + dy : y)) * W + (pool ? 2 * x + dx : x)) * ld_in + c;
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(p_), a1 = *reinterpret_cast<const f32x4*>(p_ + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float u0 = fmaf(a0[e], s0[e], t0[e]), u1 = fmaf(a1[e], s1[e], t1[e]);
+          if (relu) { u0 = fmaxf(u0, 0.f); u1 = fmaxf(u1, 0.f); }
+          v[e] = fmaxf(v[e], u0); v[4 + e] = fmaxf(v[4 + e], u1);
+        }
+      }
+    V8 hi;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) hi[e] = (T)v[e];
+    if constexpr (MM == 3) {
+      V8 lo;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) lo[e] = (T)(v[e] - (float)hi[e]);
+      char* o = out + (r * 2 * C + c) * 2;
+      *reinterpret_cast<V8*>(o) = hi;
+      *reinterpret_cast<V8*>(o + (long)C * 2) = lo;
+    } else {
+      *reinterpret_cast<V8*>(out + (r * C + c) * 2) = hi;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------------
 // corr16_kernel: the detector's K x K correlation (K = 15, 7; reference network/detector.py:188-197,222-224: the query's feature map
 // correlated with the 32 reference-centre features) on 16-bit activations — the halo-patch scheme of conv16w_kernel with K^2 taps
@@ -1332,4 +1387,20 @@ extern "C" int g6d_product_split16(const float* ref, const float* que, const flo
   else if (math_mode == 2) hipLaunchKernelGGL(product_split_kernel<2>, dim3(blocks), dim3(256), 0, st, ref, que, scale, shift, o, D, P, C, total);
   else hipLaunchKernelGGL(product_split_kernel<3>, dim3(blocks), dim3(256), 0, st, ref, que, scale, shift, o, D, P, C, total);
   return g6d_check_launch("product_split16");
+}
+
+extern "C" int g6d_affine_split16(const float* in, int ld_in, const float* scale, const float* shift, int affine_per_n, int relu, int pool, int N, int H, int W,
+                                  int C, void* out, int math_mode, g6d_stream_t stream) {
+  if (!in || !out || N < 1 || H < 1 || W < 1 || C < 8 || (C & 7) || ld_in < C || (ld_in & 3) || (scale && !shift) || affine_per_n < 0 || math_mode < 1 ||
+      math_mode > 3 || (pool && ((H | W) & 1)) || !g6d_aligned16(in) || !g6d_aligned16(out) || (scale && (!g6d_aligned16(scale) || !g6d_aligned16(shift)))) {
+    g6d_set_error("affine_split16: bad args (C % 8 == 0, 16-byte aligned rows, even map with pooling, math_mode 1..3)"); return G6D_EINVAL;
+  }
+  const long total = (long)N * (pool ? H / 2 : H) * (pool ? W / 2 : W) * (C >> 3);
+  const int blocks = (int)((total + 255) / 256 < 256 * 64 ? (total + 255) / 256 : 256 * 64);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  char* o = static_cast<char*>(out);
+  if (math_mode == 1) hipLaunchKernelGGL(affine_split16_kernel<1>, dim3(blocks), dim3(256), 0, st, in, ld_in, scale, shift, affine_per_n, relu, pool, H, W, C, o, total);
+  else if (math_mode == 2) hipLaunchKernelGGL(affine_split16_kernel<2>, dim3(blocks), dim3(256), 0, st, in, ld_in, scale, shift, affine_per_n, relu, pool, H, W, C, o, total);
+  else hipLaunchKernelGGL(affine_split16_kernel<3>, dim3(blocks), dim3(256), 0, st, in, ld_in, scale, shift, affine_per_n, relu, pool, H, W, C, o, total);
+  return g6d_check_launch("affine_split16");
 }

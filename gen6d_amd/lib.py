@@ -69,6 +69,7 @@ SIGNATURES = {
     "g6d_conv16_direct_multi": [_P, _I, _I, _P, _I, _F, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P],
     "g6d_corr16_multi": [_P, _I, _I, _P, _F, _I, _I, _I, _P],
     "g6d_product_split16": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "g6d_affine_split16": [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P],
     "g6d_vgg_conv1_pool_nhwc_norm": [_P, _I, _I, _I, _P, _P, _I, _I, _P, _P, _P, _P],
     "g6d_wino_conv3x3": [_P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _P, _I, _P, C.c_size_t, _P],
     "g6d_wino_conv3x3_multi": [_P, _I, _I, _P, _P, _I, _I, _P, C.c_size_t, _P],

@@ -39,6 +39,8 @@ _K133, _P011 = (1, 3, 3), (0, 1, 1)
 PRODUCT16 = True       # round 6: the first conv of every level (query x reference product) on the direct 16-bit convolution — the product written
                        # once as fp16 hi / lo pairs (fp32 path) or 16-bit activations; False (tools / tests): the product prologue of the Winograd /
                        # implicit-GEMM kernels
+STACK16 = True         # ... and the levels' other 3x3 convs (InstanceNorm stacks): the previous norm's affine + ReLU as an elementwise pass into the
+                       # kernel's format (g6d_affine_split16); False: the operand prologues of the Winograd / implicit-GEMM kernels
 MAX_BATCH = 32         # queries that share one set of launches (BASELINE configs[4]: 32 concurrent queries; g6d_selector_levels runs them
                        # in groups of 8 query rows per pass over the reference cache)
 FEAT_LD = 516          # 512 corr channels + 3 vps channels + 1 zero pad (16-byte rows)
@@ -211,8 +213,21 @@ class ViewpointSelector(ParamBank):
             # InstanceNorm finalisation inside the producing launch, unless the statistics still have to be summed over ranks
             fin = Dg * h * w if (has_in and not last and not self.sharded) else None
             with self._mm("product" if first else "stack", f"corr{l}.{li}"):
-                mode16 = self._product16_mode(first, D * h * w, co)
-                if mode16:
+                mode16 = self._product16_mode(first, D * h * w, co) if first else self._stack16_mode(D * h * w, co, wgt.shape[2])
+                if mode16 and not first:
+                    # round 6: the stack layers too — the InstanceNorm affine + ReLU of the previous layer is applied by one elementwise pass that
+                    # writes the map in the direct kernel's format (g6d_affine_split16), the conv adds this layer's sums in its epilogue
+                    x16 = ops.affine_split16(x, scale, shift, grp if scale is not None else 0, relu, False, mode16)
+                    filt = self._product16_filters(l, li, wgt, mode16)
+                    ci = wgt.shape[2]
+                    per = max(1, ((1 << 31) - 1) // (D * h * w * ci * (4 if mode16 == 3 else 2)))
+                    for q0 in range(0, qn, per):
+                        q1 = min(qn, q0 + per)
+                        ops.conv16_direct_multi([x16[q0 * D:q1 * D]], filt, bias, relu=False, full=torch.float32, pool=None,
+                                                stats=stats[q0:q1] if stats is not None else None, rows_per_group=D * h * w,
+                                                out_full=[out[q0 * D:q1 * D, 0]])
+                    res, fin = out, None
+                elif mode16:
                     # round 6: the product layer on the direct 16-bit convolution (csrc/conv16_direct.hip): the normalised query x reference
                     # product is written once in the kernel's activation format (fp32 path: fp16 hi / lo pairs, fp32-class results), the conv
                     # adds this level's InstanceNorm sums in its epilogue, the affine of that norm comes from one small finalize launch
@@ -256,6 +271,15 @@ class ViewpointSelector(ParamBank):
         if mm == 0:
             return 3
         return mm if co % 128 == 0 else 0
+
+    def _stack16_mode(self, rows_per_query, co, ci):
+        """conv16 math mode of a stack layer (see _product16_mode), or 0."""
+        if not (STACK16 and rows_per_query % 128 == 0):
+            return 0
+        mm = ops.MATH_MODE
+        if mm == 0:
+            return 3 if (co % 64 == 0 and ci % 32 == 0) else 0
+        return mm if (co % 128 == 0 and ci % 64 == 0) else 0
 
     def _product16_filters(self, l, li, wgt, mode):
         cache = self.__dict__.setdefault("_prod16", {})

@@ -736,6 +736,21 @@ def product_split16(ref, que, scale, shift, mode):
     return out
 
 
+def affine_split16(x, scale, shift, per_n, relu, pool, mode):
+    """affine_act_pool (pool False / True = 2x2 max) with the result in the activation format of conv16_direct_multi (g6d_affine_split16):
+    x [N,1,H,W,C] fp32 view -> [N,Ho,Wo,C] (mode 1 / 2) or [N,Ho,Wo,2,C] fp16 pairs (mode 3)."""
+    _need_gpu(x)
+    N, D, H, W, Cc, ld_in = _cl5(x, "affine_split16.x")
+    if D != 1:
+        raise ValueError("affine_split16: 2-D maps expected")
+    Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+    out = torch.empty((N, Ho, Wo, 2, Cc) if mode == 3 else (N, Ho, Wo, Cc), dtype=_T16[mode], device=x.device)
+    _timed_hbm("affine_split16", 4.0 * N * H * W * Cc + 2.0 * out.numel(), lambda: _lib.check(_lib.load().g6d_affine_split16(
+        _ptr(x), ld_in, _ptr(scale), _ptr(shift), int(per_n), int(bool(relu)), int(bool(pool)), N, H, W, Cc, _ptr(out), int(mode), _stream()),
+        "g6d_affine_split16"))
+    return out
+
+
 def vgg_conv1_pool_nhwc16(x, w_oihw, bias, out=None, norm=None, mode=None):
     """vgg_conv1_pool_nhwc with a 16-bit channels-last result (g6d_vgg_conv1_pool_nhwc16): mode 1 / 2 (default: the current math mode) =
     bf16 / fp16 [N,H/2,W/2,64], the first layer of the reduced-precision mode's 16-bit activation path; mode 3 = fp16 hi / lo pairs
@@ -793,18 +808,24 @@ def conv16_direct_multi(xs, filt, bias, relu=True, full=None, pool=None, kd=1, s
                 return torch.empty(lead_ + ((2, Cout) if pair else (Cout,)), dtype=t16, device=x.device)
             return torch.empty(lead_ + (Cout,), dtype=torch.float32, device=x.device)
         q = alloc(pool, (N, H // 2, W // 2))
-        if out_full is not None:                          # caller-provided dense outputs (slices of one buffer) instead of fresh tensors
+        ld_f = None
+        if out_full is not None:                          # caller-provided outputs (slices of one buffer; fp32: also a channel slice of wider rows)
             f = out_full[i]
             want_t = torch.float32 if full is torch.float32 else t16
-            if full is None or f.dtype != want_t or f.numel() != N * D * H * W * Cout * (2 if (pair and full == "t16") else 1) or not f.is_contiguous():
-                raise ValueError("conv16_direct_multi: out_full must be dense tensors of the outputs' type and size")
+            nel = N * D * H * W * Cout * (2 if (pair and full == "t16") else 1)
+            if full is None or f.dtype != want_t or f.numel() != nel or f.stride(-1) != 1:
+                raise ValueError("conv16_direct_multi: out_full must hold the outputs' type and size")
+            if not f.is_contiguous():
+                ld_f = f.stride(-2)                       # [.., W, Cout] view of rows of ld_f elements
+                if full is not torch.float32 or f.shape[-1] != Cout or any(f.stride(d) != f.stride(d + 1) * f.shape[d + 1] for d in range(f.dim() - 2)):
+                    raise ValueError("conv16_direct_multi: a strided out_full must be an fp32 channel slice of dense rows")
         else:
             f = alloc(full, lead)
         fulls.append(f); pools.append(q)
         ld = lambda t_: (2 * Cout if t_.dtype != torch.float32 and pair else Cout)
         segs[i] = _lib.G6dConv16Seg(in_=x.data_ptr(), out_full=f.data_ptr() if f is not None else None,
                                     out_pool=q.data_ptr() if q is not None else None, N=N, D=D, H=H, W=W, ld_in=(2 if pair else 1) * Cin,
-                                    ld_full=ld(f) if f is not None else 0, ld_pool=ld(q) if q is not None else 0)
+                                    ld_full=(ld_f or ld(f)) if f is not None else 0, ld_pool=ld(q) if q is not None else 0)
         flops += 2.0 * N * D * H * W * Cout * taps * Cin
         nbytes += x.numel() * 2.0 + sum(t.numel() * t.element_size() for t in (f, q) if t is not None)
         sizes.append("x".join(str(v) for v in lead))

@@ -51,6 +51,17 @@ def lane_groups(n):
     return [None] + _LANE_GROUPS[:n - 1]
 
 
+def quiesce_watchdogs():
+    """Call after torch.cuda.synchronize() and before a hipGraph capture.  Every RCCL process group has a watchdog thread that polls the
+    end events of its eager collectives (every 100 ms) until it has seen them complete.  Once a capture has pulled the group's internal stream
+    into capture mode, HIP refuses the query of an event last recorded on that stream — also of one recorded BEFORE the capture — and the
+    watchdog takes the process down (hipErrorCapturedEvent; about half of the runs of tests/test_rccl_world1_gpu.py with three lanes on three
+    communicators).  After a device synchronise all eager collectives have completed, so two poll intervals later no watchdog holds an event."""
+    if dist.is_initialized() and dist.get_backend() == "nccl":
+        import time
+        time.sleep(0.3)
+
+
 def shard_range(n_items, rank, world):
     """Contiguous, balanced [begin, end) slice of n_items for this rank (first n_items % world ranks get one more)."""
     base, extra = divmod(n_items, world)

@@ -115,6 +115,7 @@ class TensorPipeline:
                 for _ in range(warmup):                  # workspaces, statistics arenas and allocator warm-up off-graph
                     self.query(g_full, g_crop, cached_refs)
             torch.cuda.synchronize(d)
+            parallel.quiesce_watchdogs()
             graph = torch.cuda.CUDAGraph()
             # thread_local: a process group's watchdog thread polls its work events while this thread captures; under the default
             # (global) capture mode such a query from another thread fails and takes the process down

@@ -310,6 +310,12 @@ int g6d_conv16_direct_multi(const G6dConv16Seg* segs, int nseg, int Cin, const v
 int g6d_product_split16(const float* ref, const float* que, const float* scale, const float* shift, void* out, int qn, int D, int P, int C,
                         int math_mode, g6d_stream_t stream);
 
+/* g6d_affine_act_pool (pool 0 / 1) with the result in the 16-bit activation format of g6d_conv16_direct_multi (ABI v12): [N][Ho][Wo][C] for
+ * math_mode 1 (bf16) / 2 (fp16), [N][Ho][Wo][2][C] fp16 hi / lo pairs for math_mode 3 — the InstanceNorm affine + ReLU (+ 2x2 max-pool) between two
+ * convs of the selector's stacks (network/selector.py:27-77) as a pass of its own, so that the next conv runs on the direct 16-bit kernel. */
+int g6d_affine_split16(const float* in, int ld_in, const float* scale, const float* shift, int affine_per_n, int relu, int pool, int N, int H, int W,
+                       int C, void* out, int math_mode, g6d_stream_t stream);
+
 /* The detector's K x K correlation (network/detector.py:188-197,222-224: query feature map x the 32 reference-centre features) on 16-bit
  * activations, halo-patch kernel with the K^2 taps of a slice split over the eight waves of a block (ABI v12; csrc/conv16_direct.hip,
  * corr16_kernel).  segs[i]: in = [N][H][W][ld_in] of the mode's 16-bit type (mode 3: [pixel][2][Cin] fp16 hi / lo pairs), out_full = fp32

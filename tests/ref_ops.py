@@ -633,6 +633,14 @@ def product_split16(ref, que, scale, shift, mode):
     return _to_pairs(v) if mode == 3 else v.to(_T16[mode])
 
 
+def affine_split16(x, scale, shift, per_n, relu, pool, mode):
+    N, D, H, W, C = x.shape
+    out = torch.empty((N, 1, H // 2, W // 2, C) if pool else (N, 1, H, W, C), dtype=x.dtype)
+    affine_act_pool(x, out, scale, shift, per_n=per_n, relu=relu, pool=1 if pool else 0)
+    v = out[:, 0]
+    return _to_pairs(v) if mode == 3 else v.to(_T16[mode])
+
+
 def patch_ops(monkeypatch):
     """Route gen6d_amd.ops.* to the references above (CPU host-logic tests only)."""
     import sys

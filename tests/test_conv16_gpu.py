@@ -195,3 +195,22 @@ def test_product_split16_and_cout64():
     s1 = refc.reshape(qn, -1, Cout).sum(1)
     assert float((stats[:, :, 0].cpu() - s1).abs().max()) / (D * h * w) <= 2e-6 * float(refc.abs().max())
     record("test_product_split16_and_cout64", "pairs Cout=64 conv of the product (error / bar 2e-6)", e / 2e-6, 1.0)
+
+
+@pytest.mark.parametrize("mode", ["pairs", "fp16"])
+@pytest.mark.parametrize("pool", [False, True])
+def test_affine_split16(mode, pool):
+    """g6d_affine_split16 = affine_act_pool (per-group tables, ReLU, optional 2x2 max-pool) written in the conv16 activation format."""
+    from gen6d_amd import ops
+    import ref_ops
+    g = torch.Generator().manual_seed(9)
+    N, H, W, C, ld = 6, 8, 12, 64, 96
+    buf = _rand(g, N, 1, H, W, ld)
+    x = buf[..., 16:16 + C]
+    sc, sh = 0.5 + torch.rand((3, C), generator=g), _rand(g, 3, C, scale=0.4)
+    want = torch.empty((N, 1, H // 2, W // 2, C) if pool else (N, 1, H, W, C))
+    ref_ops.affine_act_pool(x, want, sc, sh, per_n=2, relu=True, pool=1 if pool else 0)
+    got = ops.affine_split16(buf.cuda()[..., 16:16 + C], sc.cuda(), sh.cuda(), 2, True, pool, MODE[mode]).cpu()
+    val = _join(got) if mode == "pairs" else got.double()
+    tol = 3e-7 if mode == "pairs" else 1e-3
+    assert float((val - want[:, 0].double()).abs().max()) <= tol * float(want.abs().max())

@@ -58,7 +58,7 @@ def trunk_features(folded, imgs, keys, l2norm, f43=False):
     return outs
 
 
-def trunk_features_multi(folded, imgs_list, keys, f43=False):
+def trunk_features_multi(folded, imgs_list, keys, f43=False, taps16=()):
     return [trunk_features(folded, im, keys, False) for im in imgs_list]
 
 
