@@ -23,6 +23,9 @@ from .params import ParamBank, fold_vgg
 # Both pay from ~4 queries per launch on: one query's 7 crops / single volume leave most CUs without a block and the kernel's longer
 # per-block prologue / epilogue shows (measured per step at batch 1: crops' trunk 475 vs 320 us, volume layers 541 vs 418 us on
 # F(2x2,3x3); at batch 8: 1.06 vs 1.43 ms and 1.96 vs 3.06 ms the other way round)
+FEAT16 = False          # round 6 experiment: the 2-D feature net's convs on the direct split-precision kernel where a map fills whole 128-pixel
+                        # tiles (32 x 32 and 16 x 16 maps).  Correct (refiner goldens hold) but no faster at 112 crops: 300.8 against 304.1
+                        # images/s — the two extra elementwise passes per pair and the small grids eat what the matrix cores save; off
 F43_MIN_QUERIES = 4
 TRUNK_F43 = True        # the crops' VGG trunk on the F(4x4,3x3) kernel (1.31-1.35x over F(2x2,3x3) at 56 crops, profiles/r04_w43_bench_v5.md)
 # feature-net layers (name, index in the Sequential) that carry F(4x4,3x3) filters — measured per layer at 56 crops against F(2x2,3x3)
@@ -155,6 +158,13 @@ class VolumeRefiner(ParamBank):
             self._packed = pk
         return self._packed
 
+    def _feat16_filters(self, name, idx, w):
+        cache = self.__dict__.setdefault("_feat16", {})
+        key = (name, idx, w.data_ptr())
+        if key not in cache:
+            cache[key] = ops.conv16_pack(w, 3, layout=1)
+        return cache[key]
+
     # ------------------------------------------------------------------ 2-D feature net
     def run_feature_net(self, imgs, f43=None):
         """imgs [n,3,h,w] in [0,1] -> channels-last features [n,h/4,w/4,128] (reference refiner.py:64-78).
@@ -175,9 +185,21 @@ class VolumeRefiner(ParamBank):
             _, _, hh, ww, _ = x.shape
             y0 = torch.empty((n, 1, hh, ww, w0.shape[0]), dtype=torch.float32, device=dev)
             s0 = ops.new_stats(n, w0.shape[0], dev)
-            sc0, sh0 = ops.conv(x, w0, b0, y0, ksize=_K2, pad=_P2, stats=s0, rows_per_group=hh * ww, w_wino=u0, w_wino43=v0, finalize=hh * ww)
             y1 = torch.empty((n, 1, hh, ww, w1.shape[0]), dtype=torch.float32, device=dev)
             s1 = ops.new_stats(n, w1.shape[0], dev)
+            if FEAT16 and ops.MATH_MODE == 0 and (hh * ww) % 128 == 0 and all(w_.shape[2] % 32 == 0 and w_.shape[0] % 64 == 0 for w_ in (w0, w1)):
+                # round 6: both convs on the direct split-precision kernel (fp16 hi / lo pairs, fp32-class results, csrc/conv16_direct.hip): the
+                # input / the first norm's affine + ReLU are written in the kernel's format by one elementwise pass each, the per-image
+                # InstanceNorm sums come out of the convs' epilogues
+                f0, f1 = self._feat16_filters(name, 0, w0), self._feat16_filters(name, 1, w1)
+                ops.conv16_direct_multi([ops.affine_split16(x, None, None, 0, False, False, 3)], f0, b0, relu=False, full=torch.float32, pool=None,
+                                        stats=s0, rows_per_group=hh * ww, out_full=[y0[:, 0]])
+                sc0, sh0 = ops.stats_finalize(s0, hh * ww)
+                ops.conv16_direct_multi([ops.affine_split16(y0, sc0, sh0, 1, True, False, 3)], f1, b1, relu=False, full=torch.float32, pool=None,
+                                        stats=s1, rows_per_group=hh * ww, out_full=[y1[:, 0]])
+                sc1, sh1 = ops.stats_finalize(s1, hh * ww)
+                return y1, sc1, sh1
+            sc0, sh0 = ops.conv(x, w0, b0, y0, ksize=_K2, pad=_P2, stats=s0, rows_per_group=hh * ww, w_wino=u0, w_wino43=v0, finalize=hh * ww)
             sc1, sh1 = ops.conv(y0, w1, b1, y1, ksize=_K2, pad=_P2, in_scale=sc0, in_shift=sh0, in_relu=True, per_n=True,
                                 stats=s1, rows_per_group=hh * ww, w_wino=u1, w_wino43=v1, finalize=hh * ww)
             return y1, sc1, sh1
