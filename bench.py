@@ -391,9 +391,10 @@ def main():
                              "g6d_conv_igemm family: conv_igemm / conv_patch / corr_patch kernels (fp32 v_mfma_f32_32x32x2_f32); split "
                              "launches add their partial tiles inside the kernel"),
                             ("split16", lambda p: p[3].startswith("conv16"),
-                             "conv16w_kernel<3> (g6d_conv16_direct_multi, math mode 3): the VGG trunks of detector pyramid and refiner crops as a "
-                             "direct convolution on the 16-bit matrix cores with every operand an fp16 hi / lo pair — fp32-class results, THREE "
-                             "v_mfma_f32_32x32x16_f16 per product"),
+                             "conv16w_kernel<3, *> / corr16_kernel<3> (g6d_conv16_direct_multi, g6d_corr16_multi, math mode 3): direct convolution / "
+                             "correlation on the 16-bit matrix cores with every operand an fp16 hi / lo pair — fp32-class results, THREE "
+                             "v_mfma_f32_32x32x16_f16 per product: the VGG trunks of detector pyramid and refiner crops, the detector's 15x15 and 7x7 "
+                             "correlations, the selector's product layers and InstanceNorm stacks"),
                             ("winograd", lambda p: p[3].startswith("wino3x3"),
                              "Winograd kernels on the fp32 matrix cores: wino_conv3x3_kernel (F(2x2,3x3), v_mfma_f32_32x32x2_f32) and wino43_kernel "
                              "(F(4x4,3x3), v_mfma_f32_16x16x4_f32): own VGG trunks + the stride-1 3x3 / 3x3x3 layers g6d_conv_igemm routes to "

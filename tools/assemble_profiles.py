@@ -53,7 +53,7 @@ def main():
             fams[k] = ser["roofline_" + k]
     r, w = fams["conv"], fams.get("winograd", {})
     s16 = fams.get("split16", {})
-    s16ms, s16main = family_ms(sstats, ("conv16",))
+    s16ms, s16main = family_ms(sstats, ("conv16", "corr16"))
     gflop_step = r["gflop_per_launch"] * r["launches_per_step"]
     wg = w.get("gflop_direct_form_per_step", 0.0)
     wexec = w.get("gflop_per_launch", 0.0) * w.get("launches_per_step", 0.0)
@@ -73,8 +73,8 @@ def main():
         f"{wexec / max(wms / steps, 1e-9):.1f} TFLOP/s executed, "
         f"{wg / max(wms / steps, 1e-9):.1f} TFLOP/s direct-form equivalent; bench.py: {w.get('ms_per_step', 0):.2f} ms per step, "
         f"{w.get('achieved', 0):.1f} TFLOP/s executed; by transform: {json.dumps({k: {kk: round(vv, 2) for kk, vv in v.items()} for k, v in w.get('by_transform', {}).items()})}).\n"
-        "* split-precision family (conv16w_kernel<3, 1>: the detector pyramid's and the refiner crops' VGG trunks as a direct convolution on fp16 hi / lo\n"
-        "  pairs, three v_mfma_f32_32x32x16_f16 per product):\n"
+        "* split-precision family (conv16w_kernel<3, *> and corr16_kernel<3>: VGG trunks of detector pyramid and refiner crops, the detector's 15x15 / 7x7\n"
+        "  correlations, the selector's product layers and InstanceNorm stacks as direct convolutions on fp16 hi / lo pairs, three v_mfma_f32_32x32x16_f16 per product):\n"
         f"  {s16ms:.2f} ms = {s16ms / steps:.2f} ms per step ({s16main / steps:.0f} launches per step, {s16.get('gflop_direct_form_per_step', 0):.1f} GFLOP per step in DIRECT form, x3 executed -> "
         f"{3 * s16.get('gflop_direct_form_per_step', 0) / max(s16ms / steps, 1e-9):.1f} TFLOP/s executed on the 16-bit matrix cores by kernel durations; bench.py: "
         f"{s16.get('ms_per_step', 0):.2f} ms per step, {s16.get('achieved', 0):.1f} TFLOP/s executed = {s16.get('frac', 0):.3f} of 2500).\n\n" + sstats)

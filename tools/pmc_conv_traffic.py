@@ -47,9 +47,9 @@ def main():
     res["winograd_family"] = {"kernels": "wino_conv3x3_kernel + wino43_kernel (own trunks, the conv layers routed to them, the 15x15 correlation)",
                               "fetch_kb_total": wf, "write_kb_total": ww, "launches": wl,
                               "hbm_bytes_per_launch": (2 * wf + ww) * 1024 / max(wl, 1)}
-    sf, sl = family_sum(fetch_db, "FETCH_SIZE", ("conv16",), ("conv16",))
-    sw, _ = family_sum(write_db, "WRITE_SIZE", ("conv16",), ("conv16",))
-    res["split16_family"] = {"kernels": "conv16w_kernel<3> (the fp32 path's trunks on fp16 hi / lo pairs)", "fetch_kb_total": sf, "write_kb_total": sw,
+    sf, sl = family_sum(fetch_db, "FETCH_SIZE", ("conv16", "corr16"), ("conv16", "corr16"))
+    sw, _ = family_sum(write_db, "WRITE_SIZE", ("conv16", "corr16"), ("conv16", "corr16"))
+    res["split16_family"] = {"kernels": "conv16w_kernel<3, *> + corr16_kernel<3> (trunks, correlations, selector stacks on fp16 hi / lo pairs)", "fetch_kb_total": sf, "write_kb_total": sw,
                              "launches": sl, "hbm_bytes_per_launch": (2 * sf + sw) * 1024 / max(sl, 1)}
     with open(out, "w") as f:
         json.dump(res, f, indent=1)
