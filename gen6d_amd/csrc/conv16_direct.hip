@@ -933,9 +933,10 @@ __global__ void __launch_bounds__(256) affine_split16_kernel(const float* __rest
 // ---------------------------------------------------------------------------------------------------------------------------------
 // corr16_kernel: the detector's K x K correlation (K = 15, 7; reference network/detector.py:188-197,222-224: the query's feature map
 // correlated with the 32 reference-centre features) on 16-bit activations — the halo-patch scheme of conv16w_kernel with K^2 taps
-// per patch.  Cout = 32 (the reference views), so a 128-pixel tile has ONE wave's worth of output channels: the block's EIGHT waves
-// (two per SIMD) split the TAPS of every slice (wave w: taps w, w + 8, ...), each accumulates its partial 128 px x 32 ch sums over
-// all slices, and the partials are added through LDS at the end.  A NINTH wave requests the patches (see inside).
+// per patch.  Cout = 32 (the reference views), so a 128-pixel tile has ONE wave's worth of output channels: the block's CORR16_NW = 11
+// computing waves (three per SIMD with the loader, 150 registers each) split the TAPS of every slice (wave w: taps w, w + NW, ...), each
+// accumulates its partial 128 px x 32 ch sums over all slices, and the partials are added through LDS at the end.  One more wave
+// requests the patches (see inside).
 //   * patch: (TH + K - 1) x (TW + K - 1) rows of 64 B, double-buffered (2 x 43 KB at K = 15); a row holds TWO fragments at addr and
 //     addr ^ 32: the two 16-channel groups of a 32-channel slice (MM = 1 / 2), or the hi and lo plane of a 16-channel slice (MM = 3:
 //     fp16 pairs, fp32-class results) — the same LDS geometry, addressing and filter traffic in both arithmetics;
@@ -954,10 +955,12 @@ struct Corr16Params {
   const char* w;
   float acc_scale;
 };
+constexpr int CORR16_NW = 11;                                // computing waves per block (+ one loader wave)
 constexpr int CORR16_STAGE = 42 * 1024;                      // 672 patch rows of 64 B (K = 15, 8 x 16 tile: 660)
 
 template <int MM>
-__global__ __launch_bounds__(576, 1) void corr16_kernel(const Corr16Params p) {
+__global__ __launch_bounds__(64 * (CORR16_NW + 1), 1) void corr16_kernel(const Corr16Params p) {
+  constexpr int NW = CORR16_NW;                              // computing waves (the taps of a slice are dealt out to them in turn)
   typedef typename C16T3<MM>::V V8;
   constexpr int NPL = CORR16_STAGE / 1024;                    // patch pieces per slice at most (42)
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -982,7 +985,7 @@ __global__ __launch_bounds__(576, 1) void corr16_kernel(const Corr16Params p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
 
-  if (wv == 8) {
+  if (wv == NW) {
     // ---- THE LOADER WAVE.  LDS-DMA requests are not ordered against ordinary loads (a counted wait that budgeted a patch's pieces beside
     // the filter loads let MFMAs start on filters still in flight, once the filters missed L2: wrong tiles at random), and they share
     // the one vmcnt counter of their wave: the patches are therefore requested by a wave of their own, which does nothing else — its
@@ -1023,7 +1026,7 @@ __global__ __launch_bounds__(576, 1) void corr16_kernel(const Corr16Params p) {
   } else {
   // ---- filters: the wave's taps of every slice in order; running pointer, + 8 taps per step, past the end a harmless reload
   const int T = K * K;
-  const int ntw = (T - wv + 7) >> 3;                          // taps of this wave per slice
+  const int ntw = (T - wv + NW - 1) / NW;                     // taps of this wave per slice
   const char* wp = p.w + (long)wv * 2048;
   int wtap = wv, wleft = nslice * ntw;
   const unsigned bvo = lane * 16;
@@ -1034,9 +1037,9 @@ __global__ __launch_bounds__(576, 1) void corr16_kernel(const Corr16Params p) {
     asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(b[0]) : "v"(bvo), "s"(ws) : "memory");
     asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(b[1]) : "v"(bvo), "s"(ws) : "memory");
     --wleft;
-    wtap += 8;
-    if (wtap < T) wp += 8 * 2048;
-    else { wp += (long)(T - wtap + 8 + wv) * 2048; wtap = wv; }      // first tap of this wave in the next slice
+    wtap += NW;
+    if (wtap < T) wp += NW * 2048;
+    else { wp += (long)(T - wtap + NW + wv) * 2048; wtap = wv; }      // first tap of this wave in the next slice
   };
 
   // ---- fragment geometry: m-tile mt = tile pixels 32 mt + (lane & 31); patch row of tap (0, 0) = the pixel's own (row, column)
@@ -1082,7 +1085,7 @@ __global__ __launch_bounds__(576, 1) void corr16_kernel(const Corr16Params p) {
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     if (!live) return;                                        // (padding steps after the last slice: the step count is a multiple of three)
-    int nky = ky, nkx = kx + 8;
+    int nky = ky, nkx = kx + NW;
     while (nkx >= K) { nkx -= K; ++nky; }
     if (last) { nky = ky0; nkx = kx0; }
     tap_addr(nky, nkx, last ? stage ^ 1 : stage, ntb);
@@ -1139,8 +1142,8 @@ __global__ __launch_bounds__(576, 1) void corr16_kernel(const Corr16Params p) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) sum[e] = 0.f;
 #pragma unroll 1
-  for (int rd = 0; rd < 2; ++rd) {
-    if (wv < 8 && (wv >> 2) == rd) {
+  for (int rd = 0; rd < (NW + 3) / 4; ++rd) {
+    if (wv < NW && (wv >> 2) == rd) {
       float* mine = red + (wv & 3) * (128 * 33);
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt)
@@ -1152,7 +1155,8 @@ __global__ __launch_bounds__(576, 1) void corr16_kernel(const Corr16Params p) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int o = tid + 512 * e, px = o >> 5, ch = o & 31;
-      sum[e] += (red[px * 33 + ch] + red[128 * 33 + px * 33 + ch]) + (red[2 * 128 * 33 + px * 33 + ch] + red[3 * 128 * 33 + px * 33 + ch]);
+      const int ns = NW - 4 * rd < 4 ? NW - 4 * rd : 4;        // partial tiles written in this round
+      for (int sl = 0; sl < ns; ++sl) sum[e] += red[sl * 128 * 33 + px * 33 + ch];
     }
     __syncthreads();
   }
@@ -1362,13 +1366,13 @@ extern "C" int g6d_corr16_multi(const G6dConv16Seg* segs, int nseg, int Cin, con
   constexpr int LDSB = 2 * CORR16_STAGE;                       // (>= the 4 x 128 x 33 floats of the final reduction)
   if (math_mode == 1) {
     g6d_allow_lds(reinterpret_cast<const void*>(&corr16_kernel<1>), LDSB);
-    hipLaunchKernelGGL(corr16_kernel<1>, dim3(tiles), dim3(576), LDSB, st, p);
+    hipLaunchKernelGGL(corr16_kernel<1>, dim3(tiles), dim3(64 * (CORR16_NW + 1)), LDSB, st, p);
   } else if (math_mode == 2) {
     g6d_allow_lds(reinterpret_cast<const void*>(&corr16_kernel<2>), LDSB);
-    hipLaunchKernelGGL(corr16_kernel<2>, dim3(tiles), dim3(576), LDSB, st, p);
+    hipLaunchKernelGGL(corr16_kernel<2>, dim3(tiles), dim3(64 * (CORR16_NW + 1)), LDSB, st, p);
   } else {
     g6d_allow_lds(reinterpret_cast<const void*>(&corr16_kernel<3>), LDSB);
-    hipLaunchKernelGGL(corr16_kernel<3>, dim3(tiles), dim3(576), LDSB, st, p);
+    hipLaunchKernelGGL(corr16_kernel<3>, dim3(tiles), dim3(64 * (CORR16_NW + 1)), LDSB, st, p);
   }
   return g6d_check_launch("corr16");
 }
