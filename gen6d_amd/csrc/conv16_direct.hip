@@ -602,6 +602,7 @@ __global__ __launch_bounds__(256, 2) void conv16w_kernel(const C16Params p) {
   typedef typename C16T3<MM>::V V8;
   typedef C16W<MM> R;
   constexpr int WN = 4 / WM, NP = R::NP, KS = R::KS, NBL = R::NBL, NT2 = R::NT2, CW = 32 * NT2;
+  constexpr bool SINGLE = MM == 3 && WM == 2;                  // one patch stage instead of two (see the slice hand-over below)
   constexpr int TILE_B = NP * R::PLANE, STAGE = WM * TILE_B;
   constexpr int NPIT = (NP * R::NI_MAX + 3) / 4;               // DMA wave-instructions per wave, tile and slice at most
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -644,7 +645,7 @@ __global__ __launch_bounds__(256, 2) void conv16w_kernel(const C16Params p) {
           const f32x4 z = {0.f, 0.f, 0.f, 0.f};
           char* dst = lds + tl * TILE_B + pl * R::PLANE + ii * 1024 + lane * 16;
           *reinterpret_cast<f32x4*>(dst) = z;
-          *reinterpret_cast<f32x4*>(dst + STAGE) = z;
+          if constexpr (!SINGLE) *reinterpret_cast<f32x4*>(dst + STAGE) = z;
         }
       }
     }
@@ -771,12 +772,12 @@ __global__ __launch_bounds__(256, 2) void conv16w_kernel(const C16Params p) {
     for (int t = 0; t < 9; ++t) {
       const int t2 = (t + 2) % 9, c2 = c + (t + 2) / 9;
       if (!((C16W_ABLATE & 2) && c > 0)) load_b(c2, t2, bs[(t + 2) % 3]);
-      if (t == 0 && !((C16W_ABLATE & 1) && c > 0)) issue_patch(c + 1, stage ^ 1);
+      if (t == 0 && !SINGLE && !((C16W_ABLATE & 1) && c > 0)) issue_patch(c + 1, stage ^ 1);
       if (C16W_ABLATE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NBL) : "memory");
       __builtin_amdgcn_sched_barrier(0);
       if (t < 8) tap_addr((t + 1) / 3, (t + 1) % 3, stage, ntb);
-      else tap_addr(0, 0, stage ^ 1, ntb);
+      else tap_addr(0, 0, SINGLE ? 0 : stage ^ 1, ntb);
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
         mfmas(mt, fa[mt], bs[t % 3], 0);
@@ -795,7 +796,14 @@ __global__ __launch_bounds__(256, 2) void conv16w_kernel(const C16Params p) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (vmcnt: this wave's pieces of the next patch, see above)
         __builtin_amdgcn_s_barrier();                          // every wave has read this patch and received its share of the next
         __builtin_amdgcn_sched_barrier(0);
-        stage ^= 1;
+        if constexpr (SINGLE) {
+          // one LDS stage (the pair kernel's two-tile form: two stages would be 147 KB = one block per CU): the next patch is requested
+          // only now, into the stage everybody has just left; the other block of the CU computes while it arrives
+          issue_patch(c + 1, 0);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          __builtin_amdgcn_sched_barrier(0);
+        } else stage ^= 1;
         if (c + 1 < nchunk) {
 #pragma unroll
           for (int mt = 0; mt < 4; ++mt) frag_read(tb[mt], fa[mt]);
@@ -1291,7 +1299,7 @@ extern "C" int g6d_conv16_direct_multi(const G6dConv16Seg* segs, int nseg, int C
         g6d_allow_lds(reinterpret_cast<const void*>(kern), bytes);
         hipLaunchKernelGGL(kern, dim3(hblocks), dim3(256), bytes, st, p);
       };
-#define C16W_LAUNCH(MM_, WM_) launch(&conv16w_kernel<MM_, WM_>, 2 * WM_ * C16W<MM_>::NP * C16W<MM_>::PLANE, 4 * C16W<MM_>::EPW)
+#define C16W_LAUNCH(MM_, WM_) launch(&conv16w_kernel<MM_, WM_>, ((MM_ == 3 && WM_ == 2) ? 1 : 2) * WM_ * C16W<MM_>::NP * C16W<MM_>::PLANE, 4 * C16W<MM_>::EPW)
       if (math_mode == 1) { if (wm == 1) C16W_LAUNCH(1, 1); else C16W_LAUNCH(1, 2); }
       else if (math_mode == 2) { if (wm == 1) C16W_LAUNCH(2, 1); else C16W_LAUNCH(2, 2); }
       else { if (wm == 1) C16W_LAUNCH(3, 1); else C16W_LAUNCH(3, 2); }   // (two tiles per block: Cout = 64)
