@@ -764,7 +764,7 @@ __global__ __launch_bounds__(256, 2) void conv16w_kernel(const C16Params p) {
   for (int mt = 0; mt < 4; ++mt) frag_read(tb[mt], fa[mt]);
   int stage = 0;
 #pragma unroll 1
-  for (int c = 0; c < nchunk; ++c) {
+  for (int c = 0; c < ((C16W_ABLATE & 8) ? 0 : nchunk); ++c) {      // (ablation bit 3: no K loop at all — what a block costs outside it)
     // (opaque to the optimiser: it would otherwise hoist the 36 per-(tap, m-tile) swizzle terms out of the slice loop and spill them)
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) asm volatile("" : "+v"(fe[mt]), "+v"(qb[mt]));
