@@ -597,11 +597,11 @@ __device__ __forceinline__ void c16_wait_vm(int n) {
   }
 }
 
-template <int MM, int WM>
+template <int MM, int WM, int NT2 = C16W<MM>::NT2>
 __global__ __launch_bounds__(256, 2) void conv16w_kernel(const C16Params p) {
   typedef typename C16T3<MM>::V V8;
   typedef C16W<MM> R;
-  constexpr int WN = 4 / WM, NP = R::NP, KS = R::KS, NBL = R::NBL, NT2 = R::NT2, CW = 32 * NT2;
+  constexpr int WN = 4 / WM, NP = R::NP, KS = R::KS, NBL = KS * NP * NT2, CW = 32 * NT2;   // (NT2 = 1 in a 16-bit mode: 32-channel waves for Cout = 64)
   constexpr bool SINGLE = MM == 3 && WM == 2;                  // one patch stage instead of two (see the slice hand-over below)
   constexpr int TILE_B = NP * R::PLANE, STAGE = WM * TILE_B;
   constexpr int NPIT = (NP * R::NI_MAX + 3) / 4;               // DMA wave-instructions per wave, tile and slice at most
@@ -1226,7 +1226,7 @@ extern "C" int g6d_conv16_direct_multi(const G6dConv16Seg* segs, int nseg, int C
   }
   const int bk = math_mode == 3 ? 32 : C16_BK, planes = math_mode == 3 ? 2 : 1;
   // Cout = 64 (the selector's first product layer): halo-patch kernel only, filters packed as one 128-channel tile whose upper half is zero
-  const bool half_tile = Cout == 64 && w_layout == 1 && kd == 1 && math_mode == 3;      // (a pair wave owns 32 channels: two tiles x two groups)
+  const bool half_tile = Cout == 64 && w_layout == 1 && kd == 1;      // (32-channel waves: two pixel tiles x two channel groups per block)
   if (Cin % bk || (Cout % C16_BN && !half_tile) || (kd != 1 && kd != 3)) { g6d_set_error("conv16_direct: Cin % 64 (32 for pairs), Cout % 128 (64: fragment-major 2-D layers), kd in {1,3} expected"); return G6D_EINVAL; }
   const int t16 = math_mode == 3 ? 3 : 1;                    // the 16-bit output coding of this mode
   auto type_ok = [&](int t) { return t == 0 || t == 2 || t == t16; };
@@ -1289,7 +1289,7 @@ extern "C" int g6d_conv16_direct_multi(const G6dConv16Seg* segs, int nseg, int C
     if (!ok && half_tile) { g6d_set_error("conv16_direct: Cout = 64 needs a halo tiling for every segment"); return G6D_EINVAL; }
     if (ok) {
       // a block = 4 waves of 128 px x 64 ch (pairs: 32 ch): one pixel tile x 256 (128) channels, or two pixel tiles x 128 channels
-      const int cw = 32 * (math_mode == 3 ? C16W<3>::NT2 : C16W<2>::NT2);
+      const int cw = half_tile ? 32 : 32 * (math_mode == 3 ? C16W<3>::NT2 : C16W<2>::NT2);
       const int wm = Cout % (4 * cw) == 0 ? 1 : 2;
       p.ptiles = htiles;
       p.nN = Cout / (cw * (4 / wm));
@@ -1300,7 +1300,11 @@ extern "C" int g6d_conv16_direct_multi(const G6dConv16Seg* segs, int nseg, int C
         hipLaunchKernelGGL(kern, dim3(hblocks), dim3(256), bytes, st, p);
       };
 #define C16W_LAUNCH(MM_, WM_) launch(&conv16w_kernel<MM_, WM_>, ((MM_ == 3 && WM_ == 2) ? 1 : 2) * WM_ * C16W<MM_>::NP * C16W<MM_>::PLANE, 4 * C16W<MM_>::EPW)
-      if (math_mode == 1) { if (wm == 1) C16W_LAUNCH(1, 1); else C16W_LAUNCH(1, 2); }
+      if (half_tile && math_mode != 3) {
+        if (math_mode == 1) launch(&conv16w_kernel<1, 2, 1>, 2 * 2 * C16W<1>::PLANE, 4 * C16W<1>::EPW);
+        else launch(&conv16w_kernel<2, 2, 1>, 2 * 2 * C16W<2>::PLANE, 4 * C16W<2>::EPW);
+      }
+      else if (math_mode == 1) { if (wm == 1) C16W_LAUNCH(1, 1); else C16W_LAUNCH(1, 2); }
       else if (math_mode == 2) { if (wm == 1) C16W_LAUNCH(2, 1); else C16W_LAUNCH(2, 2); }
       else { if (wm == 1) C16W_LAUNCH(3, 1); else C16W_LAUNCH(3, 2); }   // (two tiles per block: Cout = 64)
 #undef C16W_LAUNCH

@@ -263,13 +263,15 @@ class ViewpointSelector(ParamBank):
 
     def _product16_mode(self, first, rows_per_query, co):
         """conv16 math mode of a level's first (product) layer, or 0 = the Winograd / implicit-GEMM kernels with the product prologue: the
-        fp32 path takes fp16 hi / lo pairs (3); the reduced-precision modes their own 16-bit type where a wave's 64 channels fit (Cout % 128).
+        fp32 path takes fp16 hi / lo pairs (3); the reduced-precision modes their own 16-bit type.
         A query's hypothesis images must fill whole 128-pixel tiles (its InstanceNorm sums are taken per tile): true for 64 x 5 views."""
         if not (PRODUCT16 and first and rows_per_query % 128 == 0):
             return 0
         mm = ops.MATH_MODE
         if mm == 0:
             return 3
+        # (Cout = 64 — level 0 — stays on the 16-bit Winograd kernel there: on the direct kernel's 32-channel waves it is 1 % faster end to end, but
+        # the product rounded once to 16 bits takes the fp16 schemes' logits past their quarter-margin bar: measured, fp16ref32 `ok` true -> false)
         return mm if co % 128 == 0 else 0
 
     def _stack16_mode(self, rows_per_query, co, ci):

@@ -692,7 +692,7 @@ def conv16_pack(w_taps, mode, layout=1):
     co, taps, ci = w_taps.shape
     bk = 32 if mode == 3 else 64
     co_true = co
-    if co == 64 and mode == 3 and layout == 1 and taps == 9:
+    if co == 64 and layout == 1 and taps == 9:
         # the selector's first product layer: one 128-channel tile whose upper half is zero (the kernel launches waves for 64 channels only)
         w_taps = torch.cat([w_taps, torch.zeros_like(w_taps)], 0)
         co = 128

@@ -283,7 +283,7 @@ int g6d_wino16_conv3x3_multi(const G6dWinoSeg* segs, int nseg, int Cin, const vo
  *            steps ordered channel slice outermost, taps innermost):
  *            [Cout/128][Cin/BK * kd*9 steps][BK/16 ks][planes][4 groups j][64 lanes][8 values], value e of lane l =
  *            filter (co = 128 tile + 32 j + (l & 31), tap, ci = BK slice + 16 ks + 8 (l >> 5) + e); planes = 1, or 2 (hi, lo) for pairs
- *          Cout % 128 == 0 (math_mode 3, fragment-major, 2-D: also Cout = 64, packed as one 128-channel tile whose upper half is zero);
+ *          Cout % 128 == 0 (fragment-major, 2-D: also Cout = 64, packed as one 128-channel tile whose upper half is zero);
  *          bias [Cout] fp32 or NULL
  *   y = acc_scale * conv(in, W16) + bias  (acc_scale: the filters may carry an exact power-of-two scale that keeps their lo parts
  *       normal; 0 = 1);  relu != 0: y = max(y, 0)
