@@ -848,37 +848,44 @@ __global__ __launch_bounds__(256, 2) void conv16w_kernel(const C16Params p) {
 template <int MM>
 __global__ void __launch_bounds__(256) product_split_kernel(const float* __restrict__ ref, const float* __restrict__ que, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, char* __restrict__ out, int D, int P, int C, long total) {
+  // a work item = 8 channels of one (query, pixel) for a run of PS_RUN hypotheses: the query's values and tables are loaded once per run
+  // (one reference load and one / two 16-byte stores per output instead of four loads)
   typedef typename C16T3<MM>::T T;
   typedef typename C16T3<MM>::V V8;
-  const int c8 = C >> 3;
+  constexpr int PS_RUN = 8;
+  const int c8 = C >> 3, nrun = (D + PS_RUN - 1) / PS_RUN;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int cg = (int)(i % c8);
-    const long r = i / c8;                                     // (q D + d) P + px
-    const int px = (int)(r % P);
-    const long nd = r / P;
-    const int d = (int)(nd % D), q = (int)(nd / D);
+    long r = i / c8;
+    const int px = (int)(r % P); r /= P;
+    const int run = (int)(r % nrun), q = (int)(r / nrun);
     const int c = cg * 8;
-    const float* rp = ref + ((long)d * P + px) * C + c;
     const float* qp = que + ((long)q * P + px) * C + c;
-    const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
     const f32x4 q0 = *reinterpret_cast<const f32x4*>(qp), q1 = *reinterpret_cast<const f32x4*>(qp + 4);
     const f32x4 s0 = *reinterpret_cast<const f32x4*>(scale + (long)q * C + c), s1 = *reinterpret_cast<const f32x4*>(scale + (long)q * C + c + 4);
     const f32x4 t0 = *reinterpret_cast<const f32x4*>(shift + (long)q * C + c), t1 = *reinterpret_cast<const f32x4*>(shift + (long)q * C + c + 4);
-    float v[8];
+    const int d1 = min(D, (run + 1) * PS_RUN);
+#pragma unroll 2
+    for (int d = run * PS_RUN; d < d1; ++d) {
+      const float* rp = ref + ((long)d * P + px) * C + c;
+      const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
+      float v[8];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { v[e] = fmaf(r0[e] * q0[e], s0[e], t0[e]); v[4 + e] = fmaf(r1[e] * q1[e], s1[e], t1[e]); }
-    V8 hi;
+      for (int e = 0; e < 4; ++e) { v[e] = fmaf(r0[e] * q0[e], s0[e], t0[e]); v[4 + e] = fmaf(r1[e] * q1[e], s1[e], t1[e]); }
+      V8 hi;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) hi[e] = (T)v[e];
-    if constexpr (MM == 3) {
-      V8 lo;
+      for (int e = 0; e < 8; ++e) hi[e] = (T)v[e];
+      const long row = ((long)q * D + d) * P + px;
+      if constexpr (MM == 3) {
+        V8 lo;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) lo[e] = (T)(v[e] - (float)hi[e]);
-      char* o = out + (r * 2 * C + c) * 2;
-      *reinterpret_cast<V8*>(o) = hi;
-      *reinterpret_cast<V8*>(o + (long)C * 2) = lo;
-    } else {
-      *reinterpret_cast<V8*>(out + (r * C + c) * 2) = hi;
+        for (int e = 0; e < 8; ++e) lo[e] = (T)(v[e] - (float)hi[e]);
+        char* o = out + (row * 2 * C + c) * 2;
+        *reinterpret_cast<V8*>(o) = hi;
+        *reinterpret_cast<V8*>(o + (long)C * 2) = lo;
+      } else {
+        *reinterpret_cast<V8*>(out + (row * C + c) * 2) = hi;
+      }
     }
   }
 }
@@ -1395,7 +1402,7 @@ extern "C" int g6d_product_split16(const float* ref, const float* que, const flo
       !g6d_aligned16(ref) || !g6d_aligned16(que) || !g6d_aligned16(scale) || !g6d_aligned16(shift) || !g6d_aligned16(out)) {
     g6d_set_error("product_split16: bad args (C % 8 == 0, 16-byte aligned pointers, math_mode 1..3)"); return G6D_EINVAL;
   }
-  const long total = (long)qn * D * P * (C >> 3);
+  const long total = (long)qn * ((D + 7) / 8) * P * (C >> 3);                  // work items: runs of 8 hypotheses
   const int blocks = (int)((total + 255) / 256 < 256 * 64 ? (total + 255) / 256 : 256 * 64);
   hipStream_t st = static_cast<hipStream_t>(stream);
   char* o = static_cast<char*>(out);
