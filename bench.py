@@ -448,6 +448,11 @@ def main():
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
         "scaling": "strong" if shard_refs else "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "arithmetic": "fp32 inputs, accumulation, statistics and results.  Since round 6 the VGG trunks of detector / refiner, the detector's 15x15 and 7x7 "
+                      "correlations and the selector's 3x3 stacks form every product from fp16 hi / lo PAIRS of both fp32 operands on the 16-bit matrix "
+                      "cores (three v_mfma_f32_32x32x16_f16 per product, fp32 accumulators; <= 2e-6 of a layer's output range against the float64 "
+                      "convolution of the fp32 operands: below the fp32 Winograd kernels they replaced); everything else on the fp32 matrix cores / "
+                      "vector ALUs.  Module switches restore round 5's all-fp32-core path (INTEGRATION.md section 4)",
         "batch": B, "images_per_step": B, "single_query_ms": single_ms, "single_query_ms_detail": single_detail,
         "config": {"workload": f"full tensor pipeline: detector 480x640 query vs {args.det_refs} refs (4 scales) + selector "
                                f"128x128 crop vs {args.sel_refs} refs x 5 rotations + 3 refiner steps (6 refs, 32^3 volume); "
